@@ -1,0 +1,210 @@
+"""Python binding of the C ABI (include/vcfdist_pr.h) -- ctypes over
+vcfdist_amd/lib/libvcfdist_pr.so.  Plumbing only: every result comes from the
+HIP kernels behind the ABI; there is no Python or CPU fallback, and a missing
+library or GPU raises."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _abi as A
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libvcfdist_pr.so")
+CSRC = os.path.join(HERE, "csrc")
+_LIB = None
+
+
+class VprError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "vcfdist_pr.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise VprError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no fallback path)")
+    L = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    L.vpr_version.restype = C.c_char_p
+    L.vpr_last_error.restype = C.c_char_p
+    L.vpr_last_error.argtypes = [H]
+    L.vpr_create.argtypes = [C.POINTER(A.VprConfig), C.POINTER(H)]
+    L.vpr_destroy.argtypes = [H]
+    L.vpr_run.argtypes = [H, C.POINTER(A.VprBatch), C.POINTER(A.VprResults)]
+    L.vpr_upload.argtypes = [H, C.POINTER(A.VprBatch)]
+    L.vpr_upload_variants.argtypes = [H, C.POINTER(A.VprVariants)]
+    L.vpr_execute.argtypes = [H]
+    L.vpr_download.argtypes = [H, C.POINTER(A.VprResults)]
+    L.vpr_get_timing.argtypes = [H, C.POINTER(A.VprTiming)]
+    L.vpr_download_path.restype = C.c_int64
+    L.vpr_download_path.argtypes = [H, C.c_int32, C.c_int32, C.c_int64, A.P_u8, A.P_i32, A.P_i32, A.P_u8, A.P_u8]
+    L.vpr_store_phase.restype = C.c_int32
+    L.vpr_store_phase.argtypes = [C.POINTER(C.c_int32), C.c_double, A.P_i32, A.P_i32]
+    L.vpr_batch_from_variants.argtypes = [C.POINTER(A.VprVariants), C.POINTER(H)]
+    L.vpr_owned_batch_view.restype = C.POINTER(A.VprBatch)
+    L.vpr_owned_batch_view.argtypes = [H]
+    L.vpr_owned_batch_free.argtypes = [H]
+    L.vpr_synth_default_params.argtypes = [C.POINTER(A.VprSynthParams)]
+    L.vpr_synth_create.argtypes = [C.POINTER(A.VprSynthParams), C.POINTER(H)]
+    L.vpr_synth_variants.restype = C.POINTER(A.VprVariants)
+    L.vpr_synth_variants.argtypes = [H]
+    L.vpr_synth_destroy.argtypes = [H]
+    _LIB = L
+    return L
+
+
+EXPORTED = [
+    "vpr_create", "vpr_destroy", "vpr_last_error", "vpr_version", "vpr_run", "vpr_upload",
+    "vpr_upload_variants", "vpr_execute", "vpr_download", "vpr_get_timing", "vpr_download_path",
+    "vpr_store_phase", "vpr_batch_from_variants", "vpr_owned_batch_view", "vpr_owned_batch_free",
+    "vpr_synth_default_params", "vpr_synth_create", "vpr_synth_variants", "vpr_synth_destroy",
+]
+
+
+def store_phase(s, thr=0.6):
+    arr = (C.c_int32 * 4)(*[int(x) for x in s])
+    o, w = C.c_int32(), C.c_int32()
+    ph = lib().vpr_store_phase(arr, thr, C.byref(o), C.byref(w))
+    return ph, o.value, w.value
+
+
+def batch_from_variants(variants: A.Variants) -> A.Batch:
+    """Host marshalling (generate_ptrs_strs x4 per supercluster) -> Level A Batch."""
+    L = lib()
+    vs = variants.as_struct()
+    ob = C.c_void_p()
+    rc = L.vpr_batch_from_variants(C.byref(vs), C.byref(ob))
+    if rc:
+        raise VprError(f"vpr_batch_from_variants failed: {rc}")
+    try:
+        return A.Batch.from_struct(L.vpr_owned_batch_view(ob).contents)
+    finally:
+        L.vpr_owned_batch_free(ob)
+
+
+def synth_params(**kw) -> A.VprSynthParams:
+    p = A.VprSynthParams()
+    lib().vpr_synth_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+class Synth:
+    """Owns a generated synthetic workload (variants + reference) inside the library."""
+
+    def __init__(self, **kw):
+        self.params = synth_params(**kw)
+        self._h = C.c_void_p()
+        rc = lib().vpr_synth_create(C.byref(self.params), C.byref(self._h))
+        if rc:
+            raise VprError(f"vpr_synth_create failed: {rc}")
+
+    @property
+    def struct(self):
+        return lib().vpr_synth_variants(self._h).contents
+
+    def variants(self) -> A.Variants:
+        return A.Variants.from_struct(self.struct)
+
+    def batch(self) -> A.Batch:
+        L = lib()
+        ob = C.c_void_p()
+        rc = L.vpr_batch_from_variants(L.vpr_synth_variants(self._h), C.byref(ob))
+        if rc:
+            raise VprError(f"vpr_batch_from_variants failed: {rc}")
+        try:
+            return A.Batch.from_struct(L.vpr_owned_batch_view(ob).contents)
+        finally:
+            L.vpr_owned_batch_free(ob)
+
+    def close(self):
+        if self._h:
+            lib().vpr_synth_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PrecisionRecall:
+    """Mirror of the reference's precision_recall_wrapper for a batch of superclusters."""
+
+    def __init__(self, cfg: A.VprConfig = None, device=0, **kw):
+        self.cfg = cfg or A.default_config(device=device, **kw)
+        self._h = C.c_void_p()
+        L = lib()
+        rc = L.vpr_create(C.byref(self.cfg), C.byref(self._h))
+        if rc:
+            raise VprError(f"vpr_create failed ({rc}): {L.vpr_last_error(None).decode()}")
+        self._batch = None
+
+    def _chk(self, rc, what):
+        if rc:
+            raise VprError(f"{what} failed ({rc}): {lib().vpr_last_error(self._h).decode()}")
+
+    def upload(self, batch: A.Batch):
+        self._batch = batch
+        s = batch.as_struct()
+        self._chk(lib().vpr_upload(self._h, C.byref(s)), "vpr_upload")
+
+    def execute(self):
+        self._chk(lib().vpr_execute(self._h), "vpr_execute")
+
+    def download(self) -> A.Results:
+        res = A.Results.for_batch(self._batch)
+        s = res.as_struct()
+        self._chk(lib().vpr_download(self._h, C.byref(s)), "vpr_download")
+        return res
+
+    def run(self, batch: A.Batch) -> A.Results:
+        self.upload(batch)
+        self.execute()
+        return self.download()
+
+    def timing(self) -> A.VprTiming:
+        t = A.VprTiming()
+        self._chk(lib().vpr_get_timing(self._h, C.byref(t)), "vpr_get_timing")
+        return t
+
+    def path(self, sc, aln):
+        """(plane, qri, ti, sync, edit) arrays of one alignment's walk (last workspace chunk only)."""
+        lq1, lq2, lt1, lt2, lr = self._batch.lens(sc)
+        cap = lq1 + lq2 + lr + lt1 + lt2 + 8
+        pl = np.zeros(cap, np.uint8); q = np.zeros(cap, np.int32); t = np.zeros(cap, np.int32)
+        sy = np.zeros(cap, np.uint8); ed = np.zeros(cap, np.uint8)
+        n = lib().vpr_download_path(self._h, sc, aln, cap, pl.ctypes.data_as(A.P_u8), q.ctypes.data_as(A.P_i32),
+                                    t.ctypes.data_as(A.P_i32), sy.ctypes.data_as(A.P_u8), ed.ctypes.data_as(A.P_u8))
+        if n < 0:
+            raise VprError(f"vpr_download_path failed: {n}")
+        return pl[:n], q[:n], t[:n], sy[:n], ed[:n]
+
+    def close(self):
+        if self._h:
+            lib().vpr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

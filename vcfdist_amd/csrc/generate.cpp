@@ -1,0 +1,242 @@
+// generate.cpp -- host marshalling: variants + reference -> flat Level A batch.
+//
+// Produces, for every supercluster and hap slot, what the reference's
+// generate_ptrs_strs (src/dist.cpp:145-242) produces into std::string /
+// vector<vector<int>> locals -- hap string, reference string, hap->ref and
+// ref->hap index + flag arrays -- but as one pass that sizes every output and a
+// second, thread-parallel pass that fills the flat CSR arrays in place.
+//
+// Semantics kept from the reference:
+//   * region [beg,end] inclusive; INS sits before `pos` (rlen 0); alleles carry no anchor base
+//   * matching run: ptr = index of the same base in the other string, flag 0
+//   * SUB: both sides flag VARIANT|VAR_BEG|VAR_END
+//   * INS of k: k hap entries pointing at the ref base *before* the insertion
+//     (ref_len-1), all VARIANT, first |= VAR_BEG|INS_LOC, last |= VAR_END
+//   * DEL of k: k ref entries pointing at the hap base before the deletion, all
+//     VARIANT, first |= VAR_BEG, last |= VAR_END
+// The reference string is taken from query hap 1's pass (the driver hands ref_q1
+// to every alignment, dist.cpp:1856,1868); all four passes cover the same
+// reference span.
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/vcfdist_pr.h"
+
+struct vpr_owned_batch {
+    std::vector<int64_t> hap_off[VPR_HAPS], ref_off, var_off[VPR_HAPS];
+    std::vector<uint8_t> hap_seq[VPR_HAPS], hap_flag[VPR_HAPS], ref_seq, ref_flag[2];
+    std::vector<int32_t> hap_ptr[VPR_HAPS], ref_ptr[2], var_pos[VPR_HAPS];
+    std::vector<float> var_qual[VPR_HAPS];
+    vpr_batch view;
+};
+
+namespace {
+
+struct Lens { int64_t hap, ref; int err; };
+
+// Walk one (supercluster, hap slot).  With FILL=false only lengths are computed.
+template <bool FILL>
+Lens walk(const vpr_variants *v, int slot, int sc,
+          uint8_t *hseq, int32_t *hptr, uint8_t *hflag,
+          uint8_t *rseq, int32_t *rptr, uint8_t *rflag) {
+    const int ctg = v->sc_ctg[sc];
+    const uint8_t *fa = v->ctg_seq + v->ctg_off[ctg];
+    const int64_t ctg_len = v->ctg_off[ctg + 1] - v->ctg_off[ctg];
+    const int32_t beg = v->sc_beg[sc], end = v->sc_end[sc];
+    int64_t var = v->var_off[slot][sc];
+    const int64_t var_end = v->var_off[slot][sc + 1];
+    int64_t nh = 0, nr = 0;
+    int32_t pos = beg;
+    if (beg < 0 || end >= ctg_len) return {0, 0, VPR_ERR_ARG};
+    while (pos <= end) {
+        if (var < var_end && v->var_pos[slot][var] == pos) {
+            const uint8_t *pool = v->allele_pool[slot];
+            const int64_t r0 = v->var_ref_off[slot][var], rl = v->var_ref_len[slot][var];
+            const int64_t a0 = v->var_alt_off[slot][var], al = v->var_alt_len[slot][var];
+            const uint8_t type = v->var_type[slot][var];
+            if (type == VPR_TYPE_INS) {
+                if (FILL) {
+                    for (int64_t k = 0; k < al; k++) {
+                        hseq[nh + k] = pool[a0 + k];
+                        hptr[nh + k] = int32_t(nr) - 1;
+                        hflag[nh + k] = VPR_PTR_VARIANT;
+                    }
+                    if (al > 0) {
+                        hflag[nh + al - 1] |= VPR_PTR_VAR_END;
+                        hflag[nh] |= VPR_PTR_VAR_BEG | VPR_PTR_INS_LOC;
+                    }
+                }
+                nh += al;
+            } else if (type == VPR_TYPE_DEL) {
+                if (FILL && rseq) {
+                    for (int64_t k = 0; k < rl; k++) {
+                        rseq[nr + k] = pool[r0 + k];
+                    }
+                }
+                if (FILL && rptr) {
+                    for (int64_t k = 0; k < rl; k++) {
+                        rptr[nr + k] = int32_t(nh) - 1;
+                        rflag[nr + k] = VPR_PTR_VARIANT;
+                    }
+                    if (rl > 0) {
+                        rflag[nr + rl - 1] |= VPR_PTR_VAR_END;
+                        rflag[nr] |= VPR_PTR_VAR_BEG;
+                    }
+                }
+                nr += rl;
+                pos += int32_t(rl);
+            } else if (type == VPR_TYPE_SUB) {
+                if (FILL) {
+                    for (int64_t k = 0; k < al; k++) hseq[nh + k] = pool[a0 + k];
+                    hptr[nh] = int32_t(nr);
+                    hflag[nh] = VPR_PTR_VARIANT | VPR_PTR_VAR_BEG | VPR_PTR_VAR_END;
+                    if (rseq) for (int64_t k = 0; k < rl; k++) rseq[nr + k] = pool[r0 + k];
+                    if (rptr) {
+                        rptr[nr] = int32_t(nh);
+                        rflag[nr] = VPR_PTR_VARIANT | VPR_PTR_VAR_BEG | VPR_PTR_VAR_END;
+                    }
+                }
+                if (al != 1 || rl != 1) return {0, 0, VPR_ERR_ARG};
+                nh += 1;
+                nr += 1;
+                pos += 1;
+            } else {
+                return {0, 0, VPR_ERR_ARG};  // only SUB/INS/DEL reach this path (dist.cpp:199-201)
+            }
+            var++;
+        } else {
+            const int32_t stop = (var < var_end) ? v->var_pos[slot][var] : end + 1;
+            if (stop <= pos) return {0, 0, VPR_ERR_ARG};  // overlapping / unsorted variants
+            const int64_t n = stop - pos;
+            if (FILL) {
+                for (int64_t k = 0; k < n; k++) {
+                    const uint8_t b = fa[pos + k];
+                    hseq[nh + k] = b;
+                    hptr[nh + k] = int32_t(nr + k);
+                    hflag[nh + k] = 0;
+                    if (rseq) rseq[nr + k] = b;
+                    if (rptr) {
+                        rptr[nr + k] = int32_t(nh + k);
+                        rflag[nr + k] = 0;
+                    }
+                }
+            }
+            nh += n;
+            nr += n;
+            pos = stop;
+        }
+    }
+    return {nh, nr, 0};
+}
+
+}  // namespace
+
+extern "C" {
+
+int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
+    if (!v || !out || v->n_sc < 0) return VPR_ERR_ARG;
+    vpr_owned_batch *B = new (std::nothrow) vpr_owned_batch();
+    if (!B) return VPR_ERR_NOMEM;
+    const int n = v->n_sc;
+    for (int h = 0; h < VPR_HAPS; h++) B->hap_off[h].assign(n + 1, 0);
+    B->ref_off.assign(n + 1, 0);
+
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nthreads = int(std::min<unsigned>(hw, 32));
+    std::atomic<int> err{0};
+
+    // pass 1: sizes
+    auto size_job = [&](int t) {
+        for (int sc = t; sc < n; sc += nthreads) {
+            for (int h = 0; h < VPR_HAPS; h++) {
+                Lens L = walk<false>(v, h, sc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                if (L.err) { err = L.err; return; }
+                B->hap_off[h][sc + 1] = L.hap;
+                if (h == 0) B->ref_off[sc + 1] = L.ref;
+                else if (L.ref != B->ref_off[sc + 1]) { err = VPR_ERR_ARG; return; }
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back(size_job, t);
+        for (auto &x : th) x.join();
+    }
+    if (err) { delete B; return err; }
+    for (int h = 0; h < VPR_HAPS; h++)
+        for (int sc = 0; sc < n; sc++) B->hap_off[h][sc + 1] += B->hap_off[h][sc];
+    for (int sc = 0; sc < n; sc++) B->ref_off[sc + 1] += B->ref_off[sc];
+
+    for (int h = 0; h < VPR_HAPS; h++) {
+        const int64_t m = B->hap_off[h][n];
+        B->hap_seq[h].resize(m);
+        B->hap_ptr[h].resize(m);
+        B->hap_flag[h].resize(m);
+    }
+    B->ref_seq.resize(B->ref_off[n]);
+    for (int h = 0; h < 2; h++) {
+        B->ref_ptr[h].resize(B->ref_off[n]);
+        B->ref_flag[h].resize(B->ref_off[n]);
+    }
+
+    // pass 2: fill
+    auto fill_job = [&](int t) {
+        for (int sc = t; sc < n; sc += nthreads) {
+            for (int h = 0; h < VPR_HAPS; h++) {
+                const int64_t ho = B->hap_off[h][sc], ro = B->ref_off[sc];
+                walk<true>(v, h, sc, B->hap_seq[h].data() + ho, B->hap_ptr[h].data() + ho,
+                           B->hap_flag[h].data() + ho,
+                           h == 0 ? B->ref_seq.data() + ro : nullptr,
+                           h < 2 ? B->ref_ptr[h].data() + ro : nullptr,
+                           h < 2 ? B->ref_flag[h].data() + ro : nullptr);
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back(fill_job, t);
+        for (auto &x : th) x.join();
+    }
+
+    // variants: positions relative to the supercluster start (dist.cpp:1075-1080)
+    for (int h = 0; h < VPR_HAPS; h++) {
+        B->var_off[h].assign(v->var_off[h], v->var_off[h] + n + 1);
+        const int64_t nv = v->var_off[h][n];
+        B->var_pos[h].resize(nv);
+        B->var_qual[h].assign(v->var_qual[h], v->var_qual[h] + nv);
+        for (int sc = 0; sc < n; sc++)
+            for (int64_t k = v->var_off[h][sc]; k < v->var_off[h][sc + 1]; k++)
+                B->var_pos[h][k] = v->var_pos[h][k] - v->sc_beg[sc];
+    }
+
+    vpr_batch &b = B->view;
+    memset(&b, 0, sizeof(b));
+    b.n_sc = n;
+    for (int h = 0; h < VPR_HAPS; h++) {
+        b.hap_off[h] = B->hap_off[h].data();
+        b.hap_seq[h] = B->hap_seq[h].data();
+        b.hap_ptr[h] = B->hap_ptr[h].data();
+        b.hap_flag[h] = B->hap_flag[h].data();
+        b.var_off[h] = B->var_off[h].data();
+        b.var_pos[h] = B->var_pos[h].data();
+        b.var_qual[h] = B->var_qual[h].data();
+    }
+    b.ref_off = B->ref_off.data();
+    b.ref_seq = B->ref_seq.data();
+    for (int h = 0; h < 2; h++) {
+        b.ref_ptr[h] = B->ref_ptr[h].data();
+        b.ref_flag[h] = B->ref_flag[h].data();
+    }
+    *out = B;
+    return VPR_OK;
+}
+
+const vpr_batch *vpr_owned_batch_view(const vpr_owned_batch *b) { return b ? &b->view : nullptr; }
+void vpr_owned_batch_free(vpr_owned_batch *b) { delete b; }
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// pr_device.h -- device-side data layout shared by the kernels and the host API.
+#ifndef PR_DEVICE_H_
+#define PR_DEVICE_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// forward-pass flag byte (reference defs.h:110-120 for the low 5 bits)
+#define F_INS 1
+#define F_DEL 2
+#define F_MAT 4
+#define F_SUB 8
+#define F_SWP 16
+#define F_CHOICE_SHIFT 5      // bits 5-6: rank of the chosen swap source within the cell's candidate list
+#define F_TIE 128             // bit 7: more than one optimal swap source (order-defined in the reference)
+
+#define PV 1   // PTR_VARIANT
+#define PB 2   // PTR_VAR_BEG
+#define PE 4   // PTR_VAR_END
+#define PI 8   // PTR_INS_LOC
+
+#define D_INF 0x3f000000
+#define S_NEG (-(1 << 28))
+
+// Level A batch resident in HBM (same CSR layout as vpr_batch) + derived position attributes
+struct DevBatch {
+    int32_t n_sc;
+    const int64_t *hap_off[4];
+    const uint8_t *hap_seq[4];
+    const int32_t *hap_ptr[4];
+    const uint8_t *hap_flag[4];
+    const int64_t *ref_off;
+    const uint8_t *ref_seq;
+    const int32_t *ref_ptr[2];
+    const uint8_t *ref_flag[2];
+    const int64_t *var_off[4];
+    const int32_t *var_pos[4];
+    // derived by k_prep_*:
+    int4 *cand_q[2];      // [hap positions of query hap h] allowed swap sources in the REF plane (ascending, -1 pad)
+    int4 *cand_r[2];      // [ref positions]               allowed swap sources in QUERY hap h
+    uint8_t *has_ins[4];  // [ref positions] an insertion of hap slot s sits at this ref index (dist.cpp:886-894)
+};
+
+// one (supercluster, alignment) work unit
+struct AlnDesc {
+    int64_t q_off, t_off, r_off;   // element offsets of the query hap / truth hap / ref strings
+    int32_t Lq, Lt, Lr;
+    int32_t qs, ts;                // hap slots (qs = i>>1, ts = 2 + (i&1))
+    int32_t sc, aln;
+    int32_t pitch[2];              // row pitch (bytes) of the [Lt][pitch] flag matrices, QUERY / REF plane
+    int64_t mat_off[2];            // byte offsets into the flag workspace
+    int64_t path_off;              // entry offset into the path scratch
+    int64_t sec_off;               // entry offset into the section table
+    int32_t sec_cap;
+    int32_t path_cap;
+    int64_t qv_beg, qv_end, tv_beg, tv_end;   // variant index ranges (batch-global, per hap slot)
+};
+
+// per-alignment scalars produced by the kernels
+struct AlnOut {
+    int32_t dist_q, dist_r;   // D at the two end cells after the forward sweep
+    int32_t s;                // min of the two
+    int32_t end_plane;        // 0 QUERY / 1 REF      (dist.cpp:436-439)
+    int32_t beg_plane;        // (dist.cpp:811-814)
+    uint32_t status;          // VPR_ST_*
+    int32_t path_len;
+    int32_t n_sec;
+};
+
+// one sync section that contains variants, dist.cpp:1190-1373 (32 bytes)
+struct Section {
+    int32_t q_lo, q_hi;       // query variant index range (q_lo, q_hi], i.e. query_var_ptr+1 .. prev_query_var_ptr
+    int32_t t_lo, t_hi;       // truth variant index range likewise
+    int32_t sync_group;
+    int32_t query_ed;
+    int32_t ref_ed;           // valid unless deferred
+    int32_t flags;            // bit0: deferred to k_ed; bit1: no variants (kept only for the WARN checks)
+};
+#define SEC_DEFERRED 1
+#define SEC_NOVAR 2
+
+// a deferred wf_ed call: both segments longer than the inline limit
+struct EdJob {
+    int32_t aln, sec;         // alignment id, section index within the alignment
+    int32_t ref_beg, ref_len; // ref segment (index into this alignment's ref string)
+    int32_t tru_beg, tru_len; // truth segment
+};
+
+// packed walk entry: qri | plane<<31,  ti | sync<<31 | edit<<30
+struct PathEnt { uint32_t a, b; };
+
+#endif

@@ -1,0 +1,768 @@
+// pr_kernels.hip -- hand-written gfx950 kernels of the precision/recall path.
+//
+//   k_prep_cand / k_prep_ins   position attributes derived from the pointer arrays
+//   k_fwd<NT,C>   K1: forward two-plane edit-distance sweep      (calc_prec_recall_aln,  dist.cpp:251-443)
+//   k_bwd<NT,C>   K2: backward max-TP sweep over the optimal DAG (calc_prec_recall_path, dist.cpp:486-823)
+//   k_walk        K3: path walk, sync points, credit sections    (get_prec_recall_path_sync :842-999,
+//                                                                 calc_prec_recall :1005-1401)
+//   k_ed          K4: edit distance of deferred sync sections    (wf_ed, dist.cpp:1406-1506)
+//
+// Formulation (DESIGN.md "Kernels"): every edge of the two-plane graph except INS
+// consumes one truth base, so both planes are swept row by row over the truth
+// index t.  One workgroup owns one (supercluster, alignment); thread `tid` owns C
+// consecutive cells of each plane, keeps their distances in registers, mirrors the
+// row in LDS for neighbour / swap-edge reads, and the in-row INS chain
+//   D[q] = min_k (base[q-k] + k)
+// is a prefix-min scan of (base[q]-q) done with wave shuffles plus one LDS hop
+// across waves.  Integer work only: no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vcfdist_pr.h"
+#include "pr_device.h"
+
+__device__ __forceinline__ bool fwd_allow(int f) { return !(f & PV) || (f & PE); }  // dist.cpp:336-339
+__device__ __forceinline__ bool bwd_allow(int f) { return !(f & PV) || (f & PB); }  // dist.cpp:600-601
+
+// ---------------------------------------------------------------------------
+// K0: position attributes
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int find_sc(const int64_t *off, int n, int64_t g) {
+    int lo = 0, hi = n;  // largest sc with off[sc] <= g
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// dir 0: sources = positions of query hap h, destinations in the REF plane   -> cand_r[h]
+// dir 1: sources = ref positions (ref->query hap h ptrs), destinations in hap h -> cand_q[h]
+__global__ void k_prep_cand(DevBatch B, int h, int dir, int64_t n_src, uint32_t *err) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= n_src) return;
+    const int64_t *src_off = dir == 0 ? B.hap_off[h] : B.ref_off;
+    const int64_t *dst_off = dir == 0 ? B.ref_off : B.hap_off[h];
+    const int32_t *ptr = dir == 0 ? B.hap_ptr[h] : B.ref_ptr[h];
+    const uint8_t *flg = dir == 0 ? B.hap_flag[h] : B.ref_flag[h];
+    int4 *cand = dir == 0 ? B.cand_r[h] : B.cand_q[h];
+    if (!fwd_allow(flg[g])) return;
+    const int sc = find_sc(src_off, B.n_sc, g);
+    const int64_t s0 = src_off[sc];
+    const int32_t x = int32_t(g - s0);
+    const int32_t p = ptr[g];
+    const int64_t dlen = dst_off[sc + 1] - dst_off[sc];
+    const int64_t d = int64_t(p) + 1;
+    if (d < 1 || d >= dlen) return;
+    int rank = 0;
+    for (int64_t y = g - 1; y >= s0 && ptr[y] == p; y--)
+        if (fwd_allow(flg[y])) rank++;
+    if (rank >= 4) { atomicOr(err, VPR_ST_ERR_LIMIT); return; }
+    int32_t *slot = reinterpret_cast<int32_t *>(cand + dst_off[sc] + d);
+    slot[rank] = x;
+}
+
+__global__ void k_prep_ins(DevBatch B, int slot, int64_t n_src) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= n_src) return;
+    if (!(B.hap_flag[slot][g] & PI)) return;
+    const int sc = find_sc(B.hap_off[slot], B.n_sc, g);
+    const int32_t p = B.hap_ptr[slot][g];
+    if (p >= 0) B.has_ins[slot][B.ref_off[sc] + p] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// block-wide exclusive prefix-min of two ints (one per plane), tid order.
+// wsc: 2*(NT/64) ints of LDS.  Contains one __syncthreads().
+// ---------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void block_excl_prefix_min2(int &a, int &b, int32_t *wsc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int ia = a, ib = b;  // inclusive within the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
+        if (lane >= o) { ia = min(ia, ta); ib = min(ib, tb); }
+    }
+    int ea = __shfl_up(ia, 1), eb = __shfl_up(ib, 1);
+    if (lane == 0) { ea = D_INF; eb = D_INF; }
+    if (NT > 64) {
+        if (lane == 63) { wsc[wave * 2] = ia; wsc[wave * 2 + 1] = ib; }
+        __syncthreads();
+        for (int w = 0; w < wave; w++) { ea = min(ea, wsc[w * 2]); eb = min(eb, wsc[w * 2 + 1]); }
+    } else {
+        __syncthreads();
+    }
+    a = ea; b = eb;
+}
+
+// ---------------------------------------------------------------------------
+// K1: forward sweep.  Flag matrices are [plane][t][pitch] bytes in HBM.
+// ---------------------------------------------------------------------------
+template <int C> struct FlagVec;
+template <> struct FlagVec<1> { typedef uint8_t T; };
+template <> struct FlagVec<4> { typedef uint32_t T; };
+template <> struct FlagVec<8> { typedef uint2 T; };
+template <> struct FlagVec<16> { typedef uint4 T; };
+template <> struct FlagVec<32> { struct __align__(16) T { uint4 a, b; }; };
+
+template <int NT, int C>
+__global__ void __launch_bounds__(NT) k_fwd(DevBatch B, const AlnDesc *__restrict__ descs,
+                                            const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
+                                            AlnOut *__restrict__ outs) {
+    const int a = work[blockIdx.x];
+    const AlnDesc d = descs[a];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
+    const int PQ = (Lq + C - 1) / C * C, PR = (Lr + C - 1) / C * C;
+    extern __shared__ __align__(16) int32_t lds[];
+    int32_t *rowD[2] = {lds, lds + PQ + 4};         // +4: keep 16-B alignment, 1 pad
+    int32_t *wsc = lds + PQ + PR + 8;
+
+    const uint8_t *seq[2] = {B.hap_seq[d.qs] + d.q_off, B.ref_seq + d.r_off};
+    const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off;
+    const uint8_t *Tf = B.hap_flag[d.ts] + d.t_off;
+    const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
+    const int Lp[2] = {Lq, Lr};
+    const int Pp[2] = {PQ, PR};
+    uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
+    const int q0 = tid * C;
+
+    // per-cell constants
+    uint8_t sb[2][C];
+    int32_t c0[2][C];
+    uint32_t multi[2] = {0, 0};
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int q = q0 + c;
+            sb[p][c] = 0xff;
+            c0[p][c] = -1;
+            if (q < Lp[p]) {
+                sb[p][c] = seq[p][q];
+                const int4 cc = cand[p][q];
+                c0[p][c] = cc.x;
+                if (cc.y >= 0) multi[p] |= 1u << c;
+            }
+        }
+    }
+
+    // row 0: D = q (INS chain from the origin), dist.cpp:300-305,397-405
+    int32_t dp[2][C];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        uint8_t fl[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int q = q0 + c;
+            dp[p][c] = q;   // phantom cells (q >= L) continue the chain harmlessly
+            fl[c] = (q == 0) ? F_MAT : F_INS;
+            if (q0 < Pp[p]) rowD[p][q] = q;
+        }
+        if (q0 < Lp[p]) {
+            typename FlagVec<C>::T v;
+            __builtin_memcpy(&v, fl, C);
+            *reinterpret_cast<typename FlagVec<C>::T *>(mat[p] + q0) = v;
+        }
+    }
+    __syncthreads();
+
+    uint32_t tchunk = 0;  // lane l holds truth base and flag of row (t & ~63) + l
+    for (int t = 1; t < Lt; t++) {
+        if ((t & 63) == 0 || t == 1) {
+            const int tt = (t & ~63) + lane;
+            tchunk = 0;
+            if (tt < Lt) tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
+        }
+        // T[t], and the truth flag of row t-1 (may live in the previous 64-chunk)
+        const uint32_t cur = __shfl(tchunk, t & 63);
+        const uint8_t Tt = cur & 0xff;
+        const int tf_prev = ((t & 63) == 0) ? int(Tf[t - 1]) : int((__shfl(tchunk, (t - 1) & 63) >> 8) & 0xff);
+        const bool at = fwd_allow(tf_prev);
+
+        int32_t bv[2][C];     // base - q
+        uint8_t mk[2][C];     // flags achieving base
+        int cmin[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int32_t *other = rowD[1 - p];
+            int diag = (q0 > 0 && q0 < Pp[p]) ? rowD[p][q0 - 1] : D_INF;
+            int run = D_INF;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int q = q0 + c;
+                const int up = dp[p][c];
+                const bool match = sb[p][c] == Tt;
+                const int cm = match ? diag : diag + 1;
+                int b = min(cm, up + 1);
+                int sw = D_INF;
+                int choice = 0;
+                bool tie = false;
+                if (match && at && c0[p][c] >= 0) {
+                    sw = other[c0[p][c]];
+                    if (multi[p] & (1u << c)) {
+                        const int4 cc = cand[p][q];
+                        const int v1 = other[cc.y];
+                        if (v1 <= sw) { tie = (v1 == sw); sw = v1; choice = 1; }
+                        if (cc.z >= 0) {
+                            const int v2 = other[cc.z];
+                            if (v2 <= sw) { tie = (v2 == sw); sw = v2; choice = 2; }
+                            if (cc.w >= 0) {
+                                const int v3 = other[cc.w];
+                                if (v3 <= sw) { tie = (v3 == sw); sw = v3; choice = 3; }
+                            }
+                        }
+                    }
+                    b = min(b, sw);
+                }
+                uint8_t m = 0;
+                if (match && diag == b) m |= F_MAT;
+                if (diag + 1 == b) m |= F_SUB;
+                if (up + 1 == b) m |= F_DEL;
+                if (sw == b) m |= F_SWP | (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
+                mk[p][c] = m;
+                bv[p][c] = b - q;
+                run = min(run, b - q);
+                diag = up;
+            }
+            cmin[p] = run;
+        }
+        int carryQ = cmin[0], carryR = cmin[1];
+        block_excl_prefix_min2<NT>(carryQ, carryR, wsc);   // barrier inside: all reads of rowD are done
+        const int carry[2] = {carryQ, carryR};
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            uint8_t fl[C];
+            int run = carry[p];
+            int left = carry[p] + q0 - 1;   // D of cell q0-1 in this row
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int q = q0 + c;
+                const int nb = bv[p][c];
+                uint8_t f = 0;
+                if (nb <= run) { run = nb; f = mk[p][c]; }
+                const int Dn = run + q;
+                if (left + 1 == Dn && q > 0) f |= F_INS;
+                fl[c] = f;
+                dp[p][c] = Dn;
+                left = Dn;
+            }
+            if (q0 < Lp[p]) {
+#pragma unroll
+                for (int c = 0; c < C; c++) rowD[p][q0 + c] = dp[p][c];
+                typename FlagVec<C>::T v;
+                __builtin_memcpy(&v, fl, C);
+                *reinterpret_cast<typename FlagVec<C>::T *>(mat[p] + size_t(t) * d.pitch[p] + q0) = v;
+            }
+        }
+        __syncthreads();
+    }
+    // end cells
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        if (q0 + c == Lq - 1) outs[a].dist_q = dp[0][c];
+        if (q0 + c == Lr - 1) outs[a].dist_r = dp[1][c];
+    }
+}
+
+// one thread per alignment: s, end plane (prefer QUERY, dist.cpp:436-439)
+__global__ void k_fwd_finish(const int32_t *__restrict__ work, int n, AlnOut *__restrict__ outs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    AlnOut &o = outs[work[i]];
+    o.s = min(o.dist_q, o.dist_r);
+    o.end_plane = (o.dist_q <= o.dist_r) ? VPR_PLANE_QUERY : VPR_PLANE_REF;
+}
+
+// ---------------------------------------------------------------------------
+// K2: backward max-TP sweep.  Reads the forward flags row by row (t descending),
+// overwrites them in place with path_ptrs (low 5 bits; 0 = cell not on an optimal path).
+// A suffix scan of max-plus maps  x -> max(A, x + B)  carries the in-row INS chain.
+// ---------------------------------------------------------------------------
+struct MP { int A, B; };   // B < 0  <=> link broken
+__device__ __forceinline__ MP mp_compose(MP l, MP r) {   // l applied after r
+    MP o;
+    if (l.B < 0) return l;
+    o.A = max(l.A, r.A + l.B);
+    o.B = (r.B < 0) ? -1 : r.B + l.B;
+    return o;
+}
+
+// Inclusive suffix composition across the block; returns for each thread the value flowing in from
+// its right neighbour, i.e. H_{tid+1}(NEG).A.  wsc: 4*(NT/64) ints.  One __syncthreads().
+template <int NT>
+__device__ __forceinline__ void block_suffix_mp2(MP gq, MP gr, int &inq, int &inr, int32_t *wsc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    MP hq = gq, hr = gr;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        MP tq, tr;
+        tq.A = __shfl_down(hq.A, o); tq.B = __shfl_down(hq.B, o);
+        tr.A = __shfl_down(hr.A, o); tr.B = __shfl_down(hr.B, o);
+        if (lane + o < 64) { hq = mp_compose(hq, tq); hr = mp_compose(hr, tr); }
+    }
+    // exclusive: function of everything to the right within the wave
+    MP eq, er;
+    eq.A = __shfl_down(hq.A, 1); eq.B = __shfl_down(hq.B, 1);
+    er.A = __shfl_down(hr.A, 1); er.B = __shfl_down(hr.B, 1);
+    if (lane == 63) { eq.A = S_NEG; eq.B = 0; er.A = S_NEG; er.B = 0; }   // identity
+    if (NT > 64) {
+        if (lane == 0) { wsc[wave * 4] = hq.A; wsc[wave * 4 + 1] = hq.B; wsc[wave * 4 + 2] = hr.A; wsc[wave * 4 + 3] = hr.B; }
+        __syncthreads();
+        // value entering this wave from the right = fold of waves NT/64-1 .. wave+1 applied to NEG
+        int xq = S_NEG, xr = S_NEG;
+        for (int w = NT / 64 - 1; w > wave; w--) {
+            const int Aq = wsc[w * 4], Bq = wsc[w * 4 + 1], Ar = wsc[w * 4 + 2], Br = wsc[w * 4 + 3];
+            xq = (Bq < 0) ? Aq : max(Aq, xq + Bq);
+            xr = (Br < 0) ? Ar : max(Ar, xr + Br);
+        }
+        inq = (eq.B < 0) ? eq.A : max(eq.A, xq + eq.B);
+        inr = (er.B < 0) ? er.A : max(er.A, xr + er.B);
+    } else {
+        __syncthreads();
+        inq = eq.A; inr = er.A;
+    }
+}
+
+template <int NT, int C>
+__global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restrict__ descs,
+                                            const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
+                                            AlnOut *__restrict__ outs) {
+    const int a = work[blockIdx.x];
+    const AlnDesc d = descs[a];
+    const int tid = threadIdx.x;
+    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
+    const int PQ = (Lq + C - 1) / C * C, PR = (Lr + C - 1) / C * C;
+    const int Lp[2] = {Lq, Lr};
+    const int Pp[2] = {PQ, PR};
+    extern __shared__ __align__(16) int32_t lds[];
+    // score rows (int32) of row t+1, flag rows (bytes) of rows t+1 / t (double buffered)
+    int32_t *srow[2] = {lds, lds + PQ + 4};
+    uint8_t *fbase = reinterpret_cast<uint8_t *>(lds + PQ + PR + 8);
+    const int FQ = (PQ + 16 + 15) & ~15, FR = (PR + 16 + 15) & ~15;   // bytes per flag row incl. guard
+    uint8_t *frow[2][2] = {{fbase, fbase + FQ}, {fbase + FQ + FR, fbase + 2 * FQ + FR}};
+    int32_t *wsc = reinterpret_cast<int32_t *>(fbase + 2 * (FQ + FR));
+
+    const int32_t *ptr[2] = {B.hap_ptr[d.qs] + d.q_off, B.ref_ptr[d.qs] + d.r_off};
+    const uint8_t *pfl[2] = {B.hap_flag[d.qs] + d.q_off, B.ref_flag[d.qs] + d.r_off};
+    const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
+    uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
+    const int q0 = tid * C;
+    const int end_plane = outs[a].end_plane;
+
+    // per-cell constants
+    int32_t zq[2][C];       // swap target in the other plane (or -1 if this cell can never be a swap source)
+    uint8_t kc[2][C];       // bit0: tp of this cell (QUERY plane only); bits1-2: my rank in z's candidate list;
+                            // bit3: tp of z (only when z is on the QUERY plane)
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int q = q0 + c;
+            zq[p][c] = -1;
+            kc[p][c] = 0;
+            if (q < Lp[p]) {
+                const int pq = ptr[p][q];
+                const int fq = pfl[p][q];
+                if (p == 0 && q > 0 && ((pq != ptr[0][q - 1] + 1) || (fq & PB))) kc[p][c] |= 1;  // dist.cpp:572-574
+                const int z = pq + 1;
+                if (fwd_allow(fq) && z > 0 && z < Lp[1 - p] && bwd_allow(pfl[1 - p][z])) {
+                    const int4 cc = cand[1 - p][z];
+                    int rank = -1;
+                    if (cc.x == q) rank = 0; else if (cc.y == q) rank = 1; else if (cc.z == q) rank = 2; else if (cc.w == q) rank = 3;
+                    if (rank >= 0) {
+                        zq[p][c] = z;
+                        kc[p][c] |= rank << 1;
+                        if (p == 1) {  // z on the QUERY plane: leaving it scores tp(z), dist.cpp:656-658
+                            const int pz = ptr[0][z];
+                            if ((pz != ptr[0][z - 1] + 1) || (pfl[0][z] & PB)) kc[p][c] |= 8;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    int32_t sc[2][C];   // scores of row t+1 (S_NEG = unreachable)
+    uint8_t f1[2][C];   // forward flags of row t+1
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int c = 0; c < C; c++) { sc[p][c] = S_NEG; f1[p][c] = 0; }
+    // LDS rows for "row Lt": nothing reachable
+    for (int p = 0; p < 2; p++)
+        if (q0 < Pp[p])
+#pragma unroll
+            for (int c = 0; c < C; c++) { srow[p][q0 + c] = S_NEG; frow[0][p][q0 + c] = 0; }
+    // stage flags of row Lt-1 into frow[1]
+    uint8_t f0[2][C];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) f0[p][c] = 0;
+        if (q0 < Lp[p]) {
+            typename FlagVec<C>::T v = *reinterpret_cast<const typename FlagVec<C>::T *>(mat[p] + size_t(Lt - 1) * d.pitch[p] + q0);
+            __builtin_memcpy(f0[p], &v, C);
+#pragma unroll
+            for (int c = 0; c < C; c++) frow[1][p][q0 + c] = f0[p][c];
+        } else if (q0 < Pp[p]) {
+#pragma unroll
+            for (int c = 0; c < C; c++) frow[1][p][q0 + c] = 0;
+        }
+    }
+    if (tid == 0) {   // guard cells right of each row (read by the last thread as "q+1")
+        for (int p = 0; p < 2; p++) { srow[p][Pp[p]] = S_NEG; frow[0][p][Pp[p]] = 0; frow[1][p][Pp[p]] = 0; }
+    }
+    __syncthreads();
+    uint32_t tie_used = 0;
+
+    for (int t = Lt - 1; t >= 0; t--) {
+        const int cur = (Lt - 1 - t + 1) & 1;      // buffer holding row t's forward flags
+        const int nxt = cur ^ 1;                   // buffer holding row t+1's forward flags
+        // prefetch row t-1 flags from HBM
+        typename FlagVec<C>::T pf[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            if (t > 0 && q0 < Lp[p])
+                pf[p] = *reinterpret_cast<const typename FlagVec<C>::T *>(mat[p] + size_t(t - 1) * d.pitch[p] + q0);
+
+        int32_t base[2][C];
+        uint8_t bm[2][C];
+        int8_t lk[2][C];      // INS link from cell c+1 into c: tp value (0/1) or -1 broken
+        MP g[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int o = 1 - p;
+            // values of the cell to the right of this chunk
+            int xs_r = S_NEG; int xf_r = 0, xf0_r = 0, xtp_r = 0;
+            if (q0 + C <= Pp[p]) {
+                xs_r = srow[p][q0 + C];
+                xf_r = frow[nxt][p][q0 + C];
+                xf0_r = frow[cur][p][q0 + C];
+            }
+            if (p == 0 && q0 + C < Lq) {
+                const int qn = q0 + C;
+                xtp_r = ((ptr[0][qn] != ptr[0][qn - 1] + 1) || (pfl[0][qn] & PB)) ? 1 : 0;
+            }
+            MP G; G.A = S_NEG; G.B = 0;   // identity; composed from the right end of the chunk leftwards
+            bool first = true;
+#pragma unroll
+            for (int c = C - 1; c >= 0; c--) {
+                const int q = q0 + c;
+                // successor (q+1, t+1): MAT / SUB
+                const int xs = (c == C - 1) ? xs_r : sc[p][c + 1];
+                const int xf = (c == C - 1) ? xf_r : f1[p][c + 1];
+                const int xtp = (c == C - 1) ? xtp_r : (kc[p][c + 1] & 1);
+                int best = S_NEG; uint8_t m = 0;
+                if (xf & (F_MAT | F_SUB)) {
+                    const int v = xs + xtp;
+                    best = v; m = xf & (F_MAT | F_SUB);
+                }
+                // successor (q, t+1): DEL
+                if (f1[p][c] & F_DEL) {
+                    const int v = sc[p][c];
+                    if (v > best) { best = v; m = F_DEL; } else if (v == best) m |= F_DEL;
+                }
+                // swap successor z = (other plane, zq, t+1)
+                if (zq[p][c] >= 0) {
+                    const int zf = frow[nxt][o][zq[p][c]];
+                    if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((kc[p][c] >> 1) & 3)) {
+                        const int v = srow[o][zq[p][c]] + ((kc[p][c] >> 3) & 1);
+                        if (v >= 0 && (zf & F_TIE)) tie_used = 1;
+                        if (v > best) { best = v; m = F_SWP; } else if (v == best) m |= F_SWP;
+                    }
+                }
+                if (t == Lt - 1 && p == end_plane && q == Lp[p] - 1) { best = 0; m = F_MAT; }  // dist.cpp:538-546
+                if (q >= Lp[p]) { best = S_NEG; m = 0; }
+                base[p][c] = best;
+                bm[p][c] = m;
+                // INS link from (q+1, t) into (q, t): needs F_INS on row t's forward flags of q+1
+                const int xf0 = (c == C - 1) ? xf0_r : f0[p][c + 1];
+                const int l = (xf0 & F_INS) ? xtp : -1;
+                lk[p][c] = l;
+                MP F; F.A = best; F.B = l;
+                if (first) { G = F; first = false; } else G = mp_compose(F, G);
+            }
+            g[p] = G;
+        }
+        int inq, inr;
+        block_suffix_mp2<NT>(g[0], g[1], inq, inr, wsc);   // barrier: all reads of srow / frow[nxt] done
+        const int inc[2] = {inq, inr};
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            uint8_t out[C];
+            int prev = inc[p];
+#pragma unroll
+            for (int c = C - 1; c >= 0; c--) {
+                int v = base[p][c];
+                uint8_t m = bm[p][c];
+                if (lk[p][c] >= 0) {
+                    const int w = prev + lk[p][c];
+                    if (w > v) { v = w; m = F_INS; } else if (w == v) m |= F_INS;
+                }
+                if (v < 0) { v = S_NEG; m = 0; }
+                sc[p][c] = v;
+                out[c] = m;
+                prev = v;
+                f1[p][c] = f0[p][c];
+            }
+            if (q0 < Lp[p]) {
+                typename FlagVec<C>::T v;
+                __builtin_memcpy(&v, out, C);
+                *reinterpret_cast<typename FlagVec<C>::T *>(mat[p] + size_t(t) * d.pitch[p] + q0) = v;
+#pragma unroll
+                for (int c = 0; c < C; c++) srow[p][q0 + c] = sc[p][c];
+                if (t > 0) {
+                    __builtin_memcpy(f0[p], &pf[p], C);
+#pragma unroll
+                    for (int c = 0; c < C; c++) frow[nxt][p][q0 + c] = f0[p][c];   // nxt becomes "cur" of row t-1
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) outs[a].beg_plane = (sc[0][0] >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
+    if (tie_used) atomicOr(&outs[a].status, VPR_ST_SWAP_TIE);
+}
+
+// ---------------------------------------------------------------------------
+// K3: walk + sync points + credit sections; one lane per alignment.
+// ---------------------------------------------------------------------------
+__device__ int small_ed(const uint8_t *a, int m, const uint8_t *b, int n) {
+    // plain two-row Levenshtein for short segments (n <= 32); equals wf_ed (dist.cpp:1406-1506)
+    int row[33];
+    for (int j = 0; j <= n; j++) row[j] = j;
+    for (int i = 1; i <= m; i++) {
+        int diag = row[0];
+        row[0] = i;
+        const uint8_t ai = a[i - 1];
+        for (int j = 1; j <= n; j++) {
+            const int up = row[j];
+            const int v = min(min(up + 1, row[j - 1] + 1), diag + (ai != b[j - 1]));
+            diag = up;
+            row[j] = v;
+        }
+    }
+    return row[n];
+}
+
+__global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ work, int n_work,
+                       const uint8_t *__restrict__ ws, AlnOut *__restrict__ outs,
+                       PathEnt *__restrict__ paths, Section *__restrict__ secs,
+                       int32_t *const *__restrict__ fp_group /* [2 query haps * 2 swaps] */,
+                       EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap) {
+    const int wi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_work) return;
+    const int a = work[wi];
+    const AlnDesc d = descs[a];
+    AlnOut &O = outs[a];
+    const int qi = 0, ri = 1;   // planes
+    const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
+    const uint8_t *qfl = B.hap_flag[d.qs] + d.q_off;
+    const int32_t *t2r = B.hap_ptr[d.ts] + d.t_off;
+    const uint8_t *tfl = B.hap_flag[d.ts] + d.t_off;
+    const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
+    const uint8_t *insQ = B.has_ins[d.qs] + d.r_off;
+    const uint8_t *insT = B.has_ins[d.ts] + d.r_off;
+    const uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
+    const int q_size = d.Lq, r_size = d.Lr, t_size = d.Lt;
+    PathEnt *path = paths + d.path_off;
+    uint32_t status = 0;
+
+    // ---- forward walk, dist.cpp:865-998
+    int hi = O.beg_plane, qri = 0, ti = 0;
+    int64_t n = 0;
+    path[n++] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31), uint32_t(ti) | (1u << 31)};   // sync, no edit
+    bool ok = true;
+    while ((hi == ri && qri < r_size - 1) || (hi == qi && qri < q_size - 1) || ti < t_size - 1) {
+        const int p = mat[hi][size_t(ti) * d.pitch[hi] + qri] & 31;
+        int mv; uint32_t edit = 0;
+        if (hi == ri && (p & F_SWP)) { mv = F_SWP; hi = qi; qri = r2q[qri]; qri++; ti++; }
+        else if (p & F_MAT) { mv = F_MAT; qri++; ti++; }
+        else if (p & F_SUB) { mv = F_SUB; qri++; ti++; edit = 1; }
+        else if (p & F_INS) { mv = F_INS; qri++; edit = 1; }
+        else if (p & F_DEL) { mv = F_DEL; ti++; edit = 1; }
+        else if (hi == qi && (p & F_SWP)) { mv = F_SWP; hi = ri; qri = q2r[qri]; qri++; ti++; }
+        else { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+        // dist.cpp:941 breaks out here with edits one entry longer than sync; a valid optimal path never
+        // leaves the matrix, so report it like the reference's other walk failure
+        if ((hi == qi && qri >= q_size) || (hi == ri && qri >= r_size) || ti >= t_size) {
+            status |= VPR_ST_ERR_NO_PTR; ok = false; break;
+        }
+        const int consumes = mv & (F_MAT | F_SWP | F_SUB | F_DEL);
+        bool in_t = tfl[ti] & PV;
+        if (consumes) in_t = in_t && !(tfl[ti] & PB);
+        bool in_q = (hi == ri) ? false : bool(qfl[qri] & PV);
+        if (hi == qi && consumes) in_q = in_q && !(qfl[qri] & PB);
+        const int tr = t2r[ti];
+        const int qr = (hi == ri) ? qri : q2r[qri];
+        const bool ins_loc = (insQ[tr] | insT[tr] | insQ[qr] | insT[qr]) != 0;
+        const bool sync = !in_t && !in_q && !ins_loc && tr == qr && (mv & (F_MAT | F_SWP | F_SUB));
+        if (n >= d.path_cap) { status |= VPR_ST_ERR_LIMIT; ok = false; break; }
+        path[n++] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31), uint32_t(ti) | (uint32_t(sync) << 31) | (edit << 30)};
+    }
+    O.path_len = int32_t(n);
+    if (!ok) { atomicOr(&O.status, status); O.n_sec = 0; return; }
+
+    // The reference keeps three parallel vectors: path (P entries), sync and edits (P+1 entries, the last
+    // being the forced final sync with edit=false).  Here entry k carries sync[k], edits[k] for k < n = P;
+    // the virtual entry n is (sync=1, edit=0).
+    // ---- backward credit walk, dist.cpp:1035-1400
+    const uint8_t *Rs = B.ref_seq + d.r_off;
+    const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off;
+    const int swap = (d.aln == 1 || d.aln == 2);
+    const int32_t *qv_pos = B.var_pos[d.qs];
+    const int32_t *tv_pos = B.var_pos[d.ts];
+    int32_t *fpg = fp_group[d.qs * 2 + swap];   // qs is 0 or 1
+    Section *sec = secs + d.sec_off;
+    int n_sec = 0;
+
+    int sync_group = 0;
+    const int end_hi = O.end_plane;
+    int cur_hi = end_hi;
+    const int qri_size = (end_hi == qi) ? q_size : r_size;
+    int prev_hi = cur_hi, prev_qri = qri_size - 1, prev_ti = t_size - 1;
+    int prev_sync_ref_idx = r_size, prev_sync_truth_idx = t_size;
+    int query_ed = 0;
+    int64_t query_var_ptr = d.qv_end - 1, truth_var_ptr = d.tv_end - 1;
+    int query_var_pos = (query_var_ptr >= d.qv_beg) ? qv_pos[query_var_ptr] : 0;
+    int truth_var_pos = (truth_var_ptr >= d.tv_beg) ? tv_pos[truth_var_ptr] : 0;
+    int64_t prev_query_var_ptr = query_var_ptr, prev_truth_var_ptr = truth_var_ptr;
+    int64_t sync_idx = n;   // index into the (P+1)-long sync/edit arrays; entry n is the virtual final one
+
+    while (sync_idx >= 0) {
+        const int query_ref_pos = (prev_hi == ri) ? prev_qri : q2r[prev_qri];
+        while (query_ref_pos < query_var_pos && query_var_ptr >= d.qv_beg) {
+            if (cur_hi == ri) fpg[query_var_ptr] = sync_group++;   // FP: passed on the REF plane, dist.cpp:1157-1168
+            query_var_ptr--;
+            query_var_pos = (query_var_ptr < d.qv_beg) ? -1 : qv_pos[query_var_ptr];
+        }
+        const int truth_ref_pos = t2r[prev_ti];
+        while (truth_ref_pos < truth_var_pos && truth_var_ptr >= d.tv_beg) {
+            truth_var_ptr--;
+            truth_var_pos = (truth_var_ptr < d.tv_beg) ? -1 : tv_pos[truth_var_ptr];
+        }
+        const bool is_sync = (sync_idx == n) ? true : bool(path[sync_idx].b >> 31);
+        const int is_edit = (sync_idx == n) ? 0 : int((path[sync_idx].b >> 30) & 1);
+        if (is_sync) {
+            const int sync_ref_idx = (prev_hi == ri) ? prev_qri + 1 : q2r[prev_qri] + 1;
+            const int sync_truth_idx = prev_ti + 1;
+            int rl = prev_sync_ref_idx - sync_ref_idx, tl = prev_sync_truth_idx - sync_truth_idx;
+            if (rl < 0 || rl > r_size - sync_ref_idx) rl = r_size - sync_ref_idx;   // std::string::substr clamp
+            if (tl < 0 || tl > t_size - sync_truth_idx) tl = t_size - sync_truth_idx;
+            const bool has_q = query_var_ptr != prev_query_var_ptr;
+            const bool has_t = truth_var_ptr != prev_truth_var_ptr;
+            int ref_ed = -1;
+            bool deferred = false;
+            if (rl == 0) ref_ed = tl;
+            else if (tl == 0) ref_ed = rl;
+            else if (rl == 1 && tl == 1) ref_ed = (Rs[sync_ref_idx] != Ts[sync_truth_idx]);
+            else if (!has_q && !has_t && rl == tl) {
+                bool same = true;
+                for (int k = 0; k < rl && same; k++) same = (Rs[sync_ref_idx + k] == Ts[sync_truth_idx + k]);
+                if (same) ref_ed = 0;
+            }
+            if (ref_ed < 0) {
+                if (tl <= 32) ref_ed = small_ed(Rs + sync_ref_idx, rl, Ts + sync_truth_idx, tl);
+                else if (rl <= 32) ref_ed = small_ed(Ts + sync_truth_idx, tl, Rs + sync_ref_idx, rl);
+                else deferred = true;
+            }
+            if (has_q || has_t || deferred) {
+                if (n_sec < d.sec_cap) {
+                    Section S;
+                    S.q_lo = int32_t(query_var_ptr); S.q_hi = int32_t(prev_query_var_ptr);
+                    S.t_lo = int32_t(truth_var_ptr); S.t_hi = int32_t(prev_truth_var_ptr);
+                    S.sync_group = sync_group; S.query_ed = query_ed; S.ref_ed = ref_ed;
+                    S.flags = (deferred ? SEC_DEFERRED : 0) | ((has_q || has_t) ? 0 : SEC_NOVAR);
+                    if (deferred) {
+                        const int32_t j = atomicAdd(n_jobs, 1);
+                        if (j < jobs_cap) jobs[j] = EdJob{a, n_sec, sync_ref_idx, rl, sync_truth_idx, tl};
+                        else status |= VPR_ST_ERR_LIMIT;
+                    }
+                    sec[n_sec++] = S;
+                } else status |= VPR_ST_ERR_LIMIT;
+            } else {
+                // no variants, distance known: only the "should never happen" checks, dist.cpp:1203-1214
+                if (ref_ed != 0) status |= VPR_ST_WARN_REF_ED;
+                if (query_ed != ref_ed) status |= VPR_ST_WARN_QUERY_ED;
+                if (query_ed > ref_ed) status |= VPR_ST_WARN_EXCEEDS;
+            }
+            if (has_q || has_t) sync_group++;
+            prev_query_var_ptr = query_var_ptr;
+            prev_truth_var_ptr = truth_var_ptr;
+            prev_sync_ref_idx = sync_ref_idx;
+            prev_sync_truth_idx = sync_truth_idx;
+            query_ed = 0;
+        }
+        query_ed += is_edit;
+        sync_idx--;
+        if (sync_idx < 0) break;
+        cur_hi = prev_hi;
+        const PathEnt e = path[sync_idx];
+        prev_qri = int(e.a & 0x7fffffffu);
+        prev_hi = int(e.a >> 31);
+        prev_ti = int(e.b & 0x3fffffffu);
+        query_var_pos = (query_var_ptr < d.qv_beg) ? -1 : qv_pos[query_var_ptr];
+        truth_var_pos = (truth_var_ptr < d.tv_beg) ? -1 : tv_pos[truth_var_ptr];
+    }
+    O.n_sec = n_sec;
+    if (status) atomicOr(&O.status, status);
+}
+
+// ---------------------------------------------------------------------------
+// K4: edit distance of deferred sections; one wave per section, row sweep over
+// the shorter string with lanes over the longer one (same scan as K1, one plane).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_ed(DevBatch B, const AlnDesc *__restrict__ descs,
+                                           const EdJob *__restrict__ jobs, int n_jobs,
+                                           Section *__restrict__ secs, int32_t *__restrict__ scratch,
+                                           int64_t scratch_stride) {
+    const int j = blockIdx.x;
+    if (j >= n_jobs) return;
+    const EdJob J = jobs[j];
+    const AlnDesc d = descs[J.aln];
+    Section &S = secs[d.sec_off + J.sec];
+    const uint8_t *Rs = B.ref_seq + d.r_off + J.ref_beg;
+    const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off + J.tru_beg;
+    // X = longer string (lanes), Y = shorter (rows)
+    const uint8_t *X = Rs, *Y = Ts;
+    int nx = J.ref_len, ny = J.tru_len;
+    if (nx < ny) { X = Ts; Y = Rs; const int tmp = nx; nx = ny; ny = tmp; }
+    int32_t *row = scratch + int64_t(j) * scratch_stride;   // nx+1 ints: D[y][x], x = 0..nx
+    const int lane = threadIdx.x;
+    for (int x = lane; x <= nx; x += 64) row[x] = x;
+    __syncthreads();
+    for (int y = 1; y <= ny; y++) {
+        const uint8_t yc = Y[y - 1];
+        int carry = D_INF;      // prefix-min of (base - x) over everything left of the current tile
+        int diag_in = y - 1;    // D[y-1][x0-1] for the first tile = D[y-1][0]... handled below
+        for (int x0 = 0; x0 <= nx; x0 += 64) {
+            const int x = x0 + lane;
+            int up = D_INF, dg = D_INF;
+            if (x <= nx) up = row[x];
+            dg = __shfl_up(up, 1);
+            if (lane == 0) dg = (x0 == 0) ? D_INF : diag_in;
+            const int last_up = __shfl(up, 63);
+            int b = D_INF;
+            if (x <= nx) {
+                if (x == 0) b = y;
+                else b = min(up + 1, dg + (X[x - 1] != yc));
+            }
+            int v = b - x;
+            int iv = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int tv = __shfl_up(iv, o);
+                if (lane >= o) iv = min(iv, tv);
+            }
+            iv = min(iv, carry);
+            if (x <= nx) row[x] = iv + x;
+            carry = __shfl(iv, 63);
+            diag_in = last_up;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) { S.ref_ed = row[nx]; S.flags &= ~SEC_DEFERRED; }
+}
+
