@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py -- supercluster-alignments/s of the MI355X precision/recall path.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`, one process per GPU
+(torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE), rank 0 prints ONE JSON line.
+
+A "step" is one pass of the hot path (K1 forward sweep, K2 backward sweep, K3 walk +
+credit sections, K4 section edit distances, result download + float finalisation)
+over one batch of synthetic superclusters that is already resident in HBM.
+
+Workload (config.workload = "wgs_synth"): BASELINE.json configs[1] (HG002 WGS small
+variants on one MI355X) emulated with the generator of SURVEY.md 8(d): spans
+log-normal (median 20, sigma 1.2, clipped to [4, 10000]), Poisson(max(1, L/200))
+sites, 80 % SNP, 70 % homozygous, truth = query kept/dropped/perturbed 0.9/0.05/0.05,
+20 % tandem-repeat spans; real HG002 data is not available offline.  Each rank owns
+the same number of superclusters with a rank-specific seed (weak scaling: superclusters
+are independent, no data-path collective); the per-type TP/FP/FN tallies are summed
+with one all-reduce (RCCL) at the end of every step.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def make_workload(api, n_sc, seed, workload):
+    if workload == "wgs_synth":
+        return api.Synth(n_sc=n_sc, seed=seed, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=10000)
+    if workload == "stress_synth":   # configs[4]: log-uniform 32..16384
+        return api.Synth(n_sc=n_sc, seed=seed, len_mode=0, len_a=32.0, len_b=16384.0, len_min=32, len_max=16384)
+    raise SystemExit(f"unknown workload {workload}")
+
+
+def tally(res, batch_types=None):
+    """TP/FP/FN counts of the phasing each supercluster's alignment distances select
+    (sc_phase SWAP -> swap slot 1, otherwise slot 0); int64[2 callsets][3 errtypes]."""
+    out = np.zeros((2, 3), np.int64)
+    # per-variant choice needs the supercluster of each variant: use var_off of the batch
+    for h in range(4):
+        sc_of_var = res._sc_of_var[h]
+        use_swap = (res.sc_phase[sc_of_var] == 1)
+        et = np.where(use_swap, res.errtype[h][1], res.errtype[h][0])
+        cs = h >> 1
+        for e in range(3):
+            out[cs, e] += int((et == e).sum())
+    return out
+
+
+def cpu_baseline(batch, target_s=15.0):
+    """Time the CPU oracle (a port of the reference's algorithm, single thread) on a bounded
+    sample of the same workload.  Checker code used as a *reported baseline* only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    rng = np.random.RandomState(1234)
+    n = batch.n_sc
+    # probe on 2000 random superclusters, then size the sample for ~target_s
+    probe = np.sort(rng.choice(n, size=min(n, 2000), replace=False))
+    sub = batch.subset(probe)
+    t0 = time.perf_counter()
+    oracle_lib.run(sub)
+    dt = time.perf_counter() - t0
+    per = dt / len(probe)
+    m = int(min(n, max(len(probe), target_s / max(per, 1e-9))))
+    if m > len(probe) * 1.5:
+        samp = np.sort(rng.choice(n, size=m, replace=False))
+        sub = batch.subset(samp)
+        t0 = time.perf_counter()
+        oracle_lib.run(sub)
+        dt = time.perf_counter() - t0
+    else:
+        samp = probe
+    return {
+        "value": round(4 * len(samp) / dt, 1), "unit": "supercluster-alignments/s", "cores": 1, "kind": "port",
+        "sample": f"{len(samp)} superclusters drawn uniformly from the bench batch ({sub.dense_cells():.3e} dense cells), "
+                  f"{dt:.1f} s single-thread oracle (oracle/pr_oracle.cpp)",
+        "cells_per_s": round(sub.dense_cells() / dt, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-sc", type=int, default=1000000, help="superclusters per GPU")
+    ap.add_argument("--workload", default="wgs_synth")
+    ap.add_argument("--seed", type=int, default=0x5eed)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from vcfdist_amd import api, _abi as A
+    api.build()
+    syn = make_workload(api, args.n_sc, args.seed + 7919 * rank, args.workload)
+    batch = syn.batch(copy=False)
+    pr = api.PrecisionRecall(device=local_rank)
+    pr.upload(batch)                    # inputs resident in HBM before the timed region
+    sc_of_var = [np.repeat(np.arange(batch.n_sc), np.diff(batch.var_off[h])) for h in range(4)]
+    dev = torch.device("cuda", local_rank)
+
+    def step():
+        pr.execute()
+        res = pr.download()
+        res._sc_of_var = sc_of_var
+        t = torch.from_numpy(tally(res)).to(dev)
+        if dist is not None:
+            dist.all_reduce(t)          # the one collective of the path: TP/FP/FN tallies (int64 sum)
+        return res, t
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    kern_ms = []
+    stats_acc = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, t = step()
+        tm = pr.timing()
+        kern_ms.append(tm.ms_total)
+        for s in pr.launch_stats():
+            key = (s.kind, s.threads, s.cells_per_thread)
+            a = stats_acc.setdefault(key, [0, 0.0, 0, 0])
+            a[0] += 1; a[1] += s.ms; a[2] += s.bytes_algorithmic; a[3] += s.cells
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    total_aln = 4 * args.n_sc * world * args.steps
+    value = total_aln / elapsed
+    if rank == 0:
+        tm = pr.timing()
+        names = {1: "k_fwd", 2: "k_bwd", 3: "k_walk", 4: "k_ed"}
+        dom = max(stats_acc.items(), key=lambda kv: kv[1][1])
+        (kind, nt, c), (nl, ms, byt, cells) = dom
+        # dominant kernel: algorithmic bytes per launch / average launch duration (HIP events on the library stream)
+        achieved = (byt / nl) / (ms / nl * 1e-3) / 1e9 if ms > 0 else 0.0
+        roof = {
+            "bound": "hbm", "kernel": f"{names[kind]}<{nt},{c}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "launches": nl, "avg_launch_ms": round(ms / nl, 4), "algorithmic_bytes_per_launch": int(byt / nl),
+            "dense_cells_per_launch": int(cells / nl),
+        }
+        per_kernel = {f"{names[k[0]]}<{k[1]},{k[2]}>": {"launches": v[0], "ms": round(v[1], 3)}
+                      for k, v in sorted(stats_acc.items())}
+        out = {
+            "metric": "supercluster-alignments/sec", "value": round(value, 1), "unit": "supercluster-alignments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": args.workload, "superclusters_per_gpu": args.n_sc,
+                       "span_dist": "lognormal(median 20, sigma 1.2) clip [4,10000]" if args.workload == "wgs_synth"
+                       else "loguniform [32,16384]", "sharding": f"{world} ranks x independent superclusters"},
+            "dense_cells_per_s": round(tm.cells_dense * world * args.steps / elapsed, 1),
+            "kernel_ms_per_step": round(float(np.mean(kern_ms)), 3),
+            "kernel_only_value": round(4 * args.n_sc / (float(np.mean(kern_ms)) * 1e-3), 1),
+            "kernels": per_kernel,
+            "tally_TP_FP_FN": t.cpu().numpy().tolist(),
+            "order_defined_swap_ties": int((res.aln_status & 1).sum()),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch)
+            out["cpu_baseline"]["host"] = f"{os.cpu_count()} logical cores visible"
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,20 +148,21 @@ void forward_pass(const AlnIn &in, AlnState &A, bool track_writers) {
 
     CellSet curr_wave, prev_wave;
     A.s = 0;
-    std::unordered_map<Cell, Cell> first_writer;
+    // (*swap_pred_maps[i])[z] = x, dist.cpp:347,376 -- last writer wins.  Cells that get more than one
+    // distinct writer are remembered: the kept value then depends on the container iteration order, and
+    // VPR_ST_SWAP_TIE is part of the result contract.
     auto record_swap = [&](const Cell &z, const Cell &x) {
         A.st.writes++;
-        if (track_writers) {
-            auto it = A.swap_pred.find(z);
-            if (it != A.swap_pred.end() && !(it->second == x)) {
-                A.st.conflict_writes++;
-                auto &w = A.swap_writers[z];
-                if (w.empty()) w.push_back(it->second);
-                if (std::find(w.begin(), w.end(), x) == w.end()) w.push_back(x);
-            }
+        auto ins = A.swap_pred.emplace(z, x);
+        if (!ins.second && !(ins.first->second == x)) {
+            A.st.conflict_writes++;
+            auto &w = A.swap_writers[z];
+            if (w.empty()) w.push_back(ins.first->second);
+            if (std::find(w.begin(), w.end(), x) == w.end()) w.push_back(x);
+            ins.first->second = x;
         }
-        A.swap_pred[z] = x;
     };
+    (void)track_writers;
 
     while (true) {
         if (fifo.empty()) { A.status |= VPR_ST_ERR_UNFINISHED; return; }  // dist.cpp:314

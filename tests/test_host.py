@@ -1,0 +1,89 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol
+include/vcfdist_pr.h declares, host marshalling equals the oracle's generate_ptrs_strs,
+store_phase matches, the generator is deterministic, and without a GPU the library fails
+loudly (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from vcfdist_amd import _abi as A
+from vcfdist_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    api.build()
+    hdr = open(os.path.join(ROOT, "include", "vcfdist_pr.h")).read()
+    declared = set(re.findall(r"\b(vpr_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = api.lib()
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(api.EXPORTED) <= declared
+
+
+def test_struct_sizes_match_header():
+    # spot-check the ctypes mirror against the C layout through a round trip of the synth params
+    p = api.synth_params(n_sc=3, seed=9)
+    assert p.n_sc == 3 and p.seed == 9 and abs(p.var_per_base - 1 / 200) < 1e-12 and p.max_qual == 60
+
+
+def test_no_gpu_is_a_hard_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(api.VprError, match="no HIP device|no CPU fallback"):
+        api.PrecisionRecall()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_sc=300, len_a=6, len_b=80, len_min=5, len_max=80, var_per_base=0.1, p_snp=0.5, p_repeat=0.5, seed=3),
+    dict(n_sc=50, len_a=100, len_b=3000, len_max=3000, seed=4),
+])
+def test_host_marshalling_equals_oracle_generate(kw):
+    syn = api.Synth(**kw)
+    mine = syn.batch()
+    ref = O.generate(syn.variants())
+    for h in range(4):
+        for f in ("hap_off", "hap_seq", "hap_ptr", "hap_flag", "var_off", "var_pos", "var_qual"):
+            assert np.array_equal(getattr(mine, f)[h], getattr(ref, f)[h]), (f, h)
+    assert np.array_equal(mine.ref_off, ref.ref_off) and np.array_equal(mine.ref_seq, ref.ref_seq)
+    for h in range(2):
+        assert np.array_equal(mine.ref_ptr[h], ref.ref_ptr[h]) and np.array_equal(mine.ref_flag[h], ref.ref_flag[h])
+
+
+def test_marshalling_rejects_overlapping_variants():
+    ref = "ACGTACGTACGTACGT"
+    bad = [(5, A.TYPE_DEL, "CGT", "", 10.0), (6, A.TYPE_SUB, "G", "A", 10.0)]
+    v = A.Variants.from_sites([ref], [dict(ctg=0, beg=3, end=12, vars=[bad, [], [], []])])
+    with pytest.raises(api.VprError):
+        api.batch_from_variants(v)
+
+
+def test_store_phase_matches_oracle():
+    rng = np.random.RandomState(0)
+    for _ in range(2000):
+        s = rng.randint(0, 12, 4).tolist()
+        assert api.store_phase(s) == O.store_phase(s), s
+
+
+def test_synth_is_deterministic_and_seed_sensitive():
+    a = api.Synth(n_sc=100, seed=42).variants()
+    b = api.Synth(n_sc=100, seed=42).variants()
+    c = api.Synth(n_sc=100, seed=43).variants()
+    assert np.array_equal(a.ctg_seq, b.ctg_seq) and np.array_equal(a.var_pos[0], b.var_pos[0])
+    assert not np.array_equal(a.ctg_seq, c.ctg_seq)
+
+
+def test_batch_subset_roundtrip():
+    b = api.Synth(n_sc=30, len_a=10, len_b=100, len_max=100, seed=1).batch()
+    sub = b.subset([3, 7, 7, 29])
+    assert sub.n_sc == 4 and sub.lens(1) == b.lens(7) and sub.lens(2) == b.lens(7) and sub.lens(3) == b.lens(29)
+    r_all = O.run(b)
+    r_sub = O.run(sub)
+    assert r_sub.aln_dist.tolist() == np.concatenate([r_all.aln_dist[4 * i:4 * i + 4] for i in (3, 7, 7, 29)]).tolist()

@@ -1,0 +1,148 @@
+"""CPU tests of the oracle (oracle/pr_oracle.cpp): pinned against the reference-produced
+toy vector recorded in SURVEY.md Appendix A.1, textbook Levenshtein, an independent dense
+dynamic programme, and hand-checked credit assignments."""
+import numpy as np
+import pytest
+
+import dense_model as M
+import oracle_lib as O
+from vcfdist_amd import _abi as A
+
+S, I, D = A.TYPE_SUB, A.TYPE_INS, A.TYPE_DEL
+
+
+def toy_variants():
+    ref = "ACGTACGTTTTTGGCA"
+    qv = [(4, S, "A", "G", 30.0), (8, I, "", "TT", 30.0), (12, D, "GG", "", 30.0)]
+    tv = [(4, S, "A", "G", 30.0)]
+    return A.Variants.from_sites([ref], [dict(ctg=0, beg=3, end=15, vars=[qv, qv, tv, tv])])
+
+
+def test_generate_matches_reference_toy_vector():
+    """output of the unmodified reference's generate_ptrs_strs on
+    ref ACGTACGTTTTTGGCA, region [3,15], SUB@4 A->G, INS@8 TT, DEL@12 GG."""
+    b = O.generate(toy_variants())
+    assert bytes(b.hap_seq[0]).decode() == "TGCGTTTTTTTCA"
+    assert b.hap_ptr[0].tolist() == [0, 1, 2, 3, 4, 4, 4, 5, 6, 7, 8, 11, 12]
+    assert b.hap_flag[0].tolist() == [0, 7, 0, 0, 0, 11, 5, 0, 0, 0, 0, 0, 0]
+    assert b.ref_ptr[0].tolist() == [0, 1, 2, 3, 4, 7, 8, 9, 10, 10, 10, 11, 12]
+    assert b.ref_flag[0].tolist() == [0, 7, 0, 0, 0, 0, 0, 0, 0, 3, 5, 0, 0]
+    assert bytes(b.ref_seq).decode() == "TACGTTTTTGGCA"
+
+
+def test_forward_matches_reference_toy_vector():
+    """Same appendix: against a truth carrying only the SUB, s = 0 on all four alignments and
+    the end cell is on the QUERY plane (the false INS and DEL are bypassed through REF)."""
+    b = O.generate(toy_variants())
+    ex = O.Extra(b, want=(0, 0))
+    r = O.run(b, extra=ex)
+    assert r.aln_dist.tolist() == [0, 0, 0, 0]
+    assert r.aln_end_plane.tolist() == [0, 0, 0, 0]
+    # the walk leaves the QUERY plane around both false variants
+    plane, qri, ti, sync, edit = ex.path_arrays()
+    assert plane.tolist() == [0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0]
+    assert edit.sum() == 0
+    # credit: SUB is TP with credit 1 (ref_ed 1 -> query_ed 0); INS and DEL are FP in groups of their own
+    for h in (0, 1):
+        assert r.errtype[h][0].tolist() == [A.ERRTYPE_TP, A.ERRTYPE_FP, A.ERRTYPE_FP]
+        assert r.credit[h][0].tolist() == [1.0, 0.0, 0.0]
+        assert r.ref_ed[h][0].tolist() == [1, 0, 0]
+    for h in (2, 3):
+        assert r.errtype[h][0].tolist() == [A.ERRTYPE_TP]
+        assert r.callq[h][0].tolist() == [30.0]
+    assert r.sc_phase.tolist() == [A.PHASE_NONE]
+
+
+def lev(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def test_edit_distance_is_levenshtein():
+    rng = np.random.RandomState(5)
+    for _ in range(1500):
+        k = rng.randint(2, 5)
+        a = bytes(rng.randint(65, 65 + k, rng.randint(0, 14)).astype(np.uint8))
+        b = bytes(rng.randint(65, 65 + k, rng.randint(0, 14)).astype(np.uint8))
+        assert O.edit_distance(a, b) == lev(a, b), (a, b)
+    assert O.edit_distance(b"", b"ACG") == 3 and O.edit_distance(b"AC", b"") == 2
+
+
+def test_store_phase():
+    # dist.cpp:456-469: equal -> NONE; zero protects division; float ratio vs 0.6
+    assert O.store_phase([0, 0, 0, 0]) == (A.PHASE_NONE, 0, 0)
+    assert O.store_phase([0, 3, 4, 0]) == (A.PHASE_ORIG, 0, 7)
+    assert O.store_phase([2, 0, 0, 1]) == (A.PHASE_SWAP, 3, 0)
+    assert O.store_phase([5, 1, 1, 5])[0] == A.PHASE_SWAP      # 1 - 2/10 = 0.8 > 0.6
+    assert O.store_phase([2, 1, 1, 2])[0] == A.PHASE_NONE      # 1 - 2/4 = 0.5
+    assert O.store_phase([1, 3, 3, 1])[0] == A.PHASE_ORIG      # 1 - 2/6 = 0.667
+
+
+@pytest.mark.parametrize("seed,lmax,rate", [(1, 40, 0.08), (2, 30, 0.2), (4, 14, 0.3)])
+def test_dense_model_equals_sparse_oracle(seed, lmax, rate):
+    """The dense row-sweep formulation the kernels use gives the oracle's distance, end plane,
+    flag bytes on every cell with D <= s, and (outside order-defined swap ties) its backward
+    scores / path pointers / begin plane."""
+    from vcfdist_amd import api
+    syn = api.Synth(n_sc=60, len_a=6, len_b=lmax, len_min=5, len_max=lmax, var_per_base=rate, p_repeat=0.5,
+                    p_snp=0.5, seed=seed)
+    B = syn.batch()
+    for sc in range(B.n_sc):
+        one = B.subset([sc])
+        for aln in range(4):
+            ex = O.Extra(one, want=(0, aln), dump_matrices=True)
+            r = O.run(one, extra=ex)
+            qs, ts = aln >> 1, 2 + (aln & 1)
+            Q, T, R = bytes(one.hap_seq[qs]), bytes(one.hap_seq[ts]), bytes(one.ref_seq)
+            Dm, FL, TIE, CH = M.forward(Q, R, T, one.hap_ptr[qs], one.hap_flag[qs], one.ref_ptr[qs],
+                                        one.ref_flag[qs], one.hap_flag[ts])
+            dq, dr = Dm[0][len(Q) - 1, len(T) - 1], Dm[1][len(R) - 1, len(T) - 1]
+            s = min(dq, dr)
+            endp = 0 if dq == s else 1
+            assert s == r.aln_dist[aln] and endp == r.aln_end_plane[aln]
+            for pl in range(2):
+                mask = Dm[pl] <= s
+                assert (FL[pl][mask] == ex.flags[pl][mask]).all()
+                assert not ex.flags[pl][~mask].any()
+            if ex.swap_used_conflict_nonmax[aln] == 0:
+                SC, PP = M.backward(Q, R, T, one.hap_ptr[qs], one.hap_flag[qs], one.ref_ptr[qs],
+                                    one.ref_flag[qs], FL, CH, endp)
+                for pl in range(2):
+                    assert (SC[pl] == ex.pscore[pl]).all() and (PP[pl] == ex.pptr[pl]).all()
+                assert (0 if SC[0][0, 0] >= 0 else 1) == r.aln_beg_plane[aln]
+
+
+def test_identical_haps_are_all_tp():
+    """truth == query: every alignment has distance 0 (ORIG and SWAP both 0 for homozygous sets),
+    every variant TP with credit 1."""
+    from vcfdist_amd import api
+    syn = api.Synth(n_sc=40, len_a=20, len_b=200, len_max=200, p_keep=1.0, p_drop=0.0, p_hom=1.0, seed=11)
+    b = syn.batch()
+    r = O.run(b)
+    assert (r.aln_dist == 0).all()
+    for h in range(4):
+        for w in range(2):
+            assert (r.errtype[h][w] == A.ERRTYPE_TP).all()
+            assert (r.credit[h][w] == 1.0).all()
+
+
+def test_dropped_truth_variant_is_fp_and_missing_query_is_fn():
+    ref = "ACGTACGTACGTACGTACGT"
+    q = [(5, S, "C", "T", 20.0), (12, S, "A", "G", 33.0)]
+    t = [(5, S, "C", "T", 50.0)]
+    v = A.Variants.from_sites([ref], [dict(ctg=0, beg=4, end=14, vars=[q, q, t, t])])
+    r = O.run(O.generate(v))
+    assert r.errtype[0][0].tolist() == [A.ERRTYPE_TP, A.ERRTYPE_FP]
+    assert r.callq[0][0].tolist() == [20.0, 33.0]
+    assert r.errtype[2][0].tolist() == [A.ERRTYPE_TP] and r.callq[2][0].tolist() == [20.0]
+    # swap roles: the extra variant is now in the truth -> FN with callq = max_qual
+    v2 = A.Variants.from_sites([ref], [dict(ctg=0, beg=4, end=14, vars=[t, t, q, q])])
+    r2 = O.run(O.generate(v2))
+    assert r2.errtype[2][0].tolist() == [A.ERRTYPE_TP, A.ERRTYPE_FN]
+    assert r2.callq[2][0].tolist() == [50.0, 60.0]
+    assert r2.aln_dist.tolist() == [1, 1, 1, 1]

@@ -81,6 +81,13 @@ class VprTiming(C.Structure):
     ]
 
 
+class VprLaunchStat(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("threads", C.c_int32), ("cells_per_thread", C.c_int32), ("n_units", C.c_int32),
+        ("cells", C.c_int64), ("bytes_algorithmic", C.c_int64), ("ms", C.c_double),
+    ]
+
+
 class VprSynthParams(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("n_sc", C.c_int32), ("len_mode", C.c_int32),
@@ -106,11 +113,17 @@ def _arr(x, dtype):
     return np.ascontiguousarray(np.asarray(x, dtype=dtype))
 
 
+_COPY = True   # module switch used by from_struct(copy=False): view C memory instead of copying
+
+
 def _from_ptr(p, n, dtype):
-    """Copy n elements from a ctypes pointer into a fresh numpy array."""
+    """n elements behind a ctypes pointer as a numpy array (a copy unless _COPY is off)."""
     if n == 0:
         return np.zeros(0, dtype=dtype)
-    return np.ctypeslib.as_array(p, shape=(n,)).astype(dtype, copy=True)
+    addr = C.cast(p, C.c_void_p).value
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(addr)
+    a = np.frombuffer(buf, dtype=dtype, count=n)
+    return a.copy() if _COPY else a
 
 
 class Batch:
@@ -132,8 +145,20 @@ class Batch:
         self.var_qual = [_arr(a, np.float32) for a in var_qual]
 
     @classmethod
-    def from_struct(cls, s):
-        """Deep-copy a vpr_batch view (e.g. of a vpr_owned_batch) into numpy arrays."""
+    def from_struct(cls, s, copy=True, owner=None):
+        """Numpy view of a vpr_batch (e.g. of a vpr_owned_batch).  copy=False keeps views into the
+        C memory; `owner` is then stored on the Batch to keep that memory alive."""
+        global _COPY
+        _COPY = copy
+        try:
+            b = cls._from_struct(s)
+        finally:
+            _COPY = True
+        b._owner = owner
+        return b
+
+    @classmethod
+    def _from_struct(cls, s):
         n = s.n_sc
         hap_off = [_from_ptr(s.hap_off[h], n + 1, np.int64) for h in range(HAPS)]
         ref_off = _from_ptr(s.ref_off, n + 1, np.int64)

@@ -50,6 +50,7 @@ def lib():
     L.vpr_execute.argtypes = [H]
     L.vpr_download.argtypes = [H, C.POINTER(A.VprResults)]
     L.vpr_get_timing.argtypes = [H, C.POINTER(A.VprTiming)]
+    L.vpr_get_launch_stats.argtypes = [H, C.POINTER(A.VprLaunchStat), C.c_int32]
     L.vpr_download_path.restype = C.c_int64
     L.vpr_download_path.argtypes = [H, C.c_int32, C.c_int32, C.c_int64, A.P_u8, A.P_i32, A.P_i32, A.P_u8, A.P_u8]
     L.vpr_store_phase.restype = C.c_int32
@@ -69,7 +70,8 @@ def lib():
 
 EXPORTED = [
     "vpr_create", "vpr_destroy", "vpr_last_error", "vpr_version", "vpr_run", "vpr_upload",
-    "vpr_upload_variants", "vpr_execute", "vpr_download", "vpr_get_timing", "vpr_download_path",
+    "vpr_upload_variants", "vpr_execute", "vpr_download", "vpr_get_timing", "vpr_get_launch_stats",
+    "vpr_download_path",
     "vpr_store_phase", "vpr_batch_from_variants", "vpr_owned_batch_view", "vpr_owned_batch_free",
     "vpr_synth_default_params", "vpr_synth_create", "vpr_synth_variants", "vpr_synth_destroy",
 ]
@@ -106,6 +108,21 @@ def synth_params(**kw) -> A.VprSynthParams:
     return p
 
 
+class _Owned:
+    """Keeps a vpr_owned_batch alive for numpy views into it."""
+
+    def __init__(self, h):
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vpr_owned_batch_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 class Synth:
     """Owns a generated synthetic workload (variants + reference) inside the library."""
 
@@ -123,12 +140,16 @@ class Synth:
     def variants(self) -> A.Variants:
         return A.Variants.from_struct(self.struct)
 
-    def batch(self) -> A.Batch:
+    def batch(self, copy=True) -> A.Batch:
+        """Level A batch of the workload.  copy=False returns numpy views into the library-owned
+        buffers (no second copy of a multi-GB batch); the Batch keeps them alive."""
         L = lib()
         ob = C.c_void_p()
         rc = L.vpr_batch_from_variants(L.vpr_synth_variants(self._h), C.byref(ob))
         if rc:
             raise VprError(f"vpr_batch_from_variants failed: {rc}")
+        if not copy:
+            return A.Batch.from_struct(L.vpr_owned_batch_view(ob).contents, copy=False, owner=_Owned(ob))
         try:
             return A.Batch.from_struct(L.vpr_owned_batch_view(ob).contents)
         finally:
@@ -185,6 +206,18 @@ class PrecisionRecall:
         t = A.VprTiming()
         self._chk(lib().vpr_get_timing(self._h, C.byref(t)), "vpr_get_timing")
         return t
+
+    def launch_stats(self):
+        L = lib()
+        n = L.vpr_get_launch_stats(self._h, None, 0)
+        arr = (A.VprLaunchStat * max(n, 1))()
+        L.vpr_get_launch_stats(self._h, arr, n)
+        return [arr[i] for i in range(n)]
+
+    def upload_variants(self, variants_struct, batch_for_results):
+        """Upload a vpr_variants struct (e.g. Synth.struct); `batch_for_results` only sizes the result buffers."""
+        self._batch = batch_for_results
+        self._chk(lib().vpr_upload_variants(self._h, C.byref(variants_struct)), "vpr_upload_variants")
 
     def path(self, sc, aln):
         """(plane, qri, ti, sync, edit) arrays of one alignment's walk (last workspace chunk only)."""

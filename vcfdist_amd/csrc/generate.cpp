@@ -152,7 +152,7 @@ int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
 
     // pass 1: sizes
     auto size_job = [&](int t) {
-        for (int sc = t; sc < n; sc += nthreads) {
+        for (int sc = int(int64_t(n) * t / nthreads), e = int(int64_t(n) * (t + 1) / nthreads); sc < e; sc++) {
             for (int h = 0; h < VPR_HAPS; h++) {
                 Lens L = walk<false>(v, h, sc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
                 if (L.err) { err = L.err; return; }
@@ -186,7 +186,7 @@ int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
 
     // pass 2: fill
     auto fill_job = [&](int t) {
-        for (int sc = t; sc < n; sc += nthreads) {
+        for (int sc = int(int64_t(n) * t / nthreads), e = int(int64_t(n) * (t + 1) / nthreads); sc < e; sc++) {
             for (int h = 0; h < VPR_HAPS; h++) {
                 const int64_t ho = B->hap_off[h][sc], ro = B->ref_off[sc];
                 walk<true>(v, h, sc, B->hap_seq[h].data() + ho, B->hap_ptr[h].data() + ho,

@@ -31,7 +31,7 @@ const size_t LDS_MAX = 160 * 1024;
 struct Launch { int cls; int64_t work_off; int32_t count; };   // one k_fwd/k_bwd launch
 struct Chunk { std::vector<Launch> launches; int64_t work_off; int32_t count; };
 
-struct EvPair { hipEvent_t a, b; int kind; };
+struct EvPair { hipEvent_t a, b; int kind; vpr_launch_stat st; };
 
 }  // namespace
 
@@ -39,6 +39,8 @@ struct vpr_handle {
     vpr_config cfg;
     std::string err;
     hipStream_t stream = nullptr;
+    hipStream_t cls_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void *> allocs;          // batch-lifetime device allocations
     DevBatch dB;
     // host mirrors needed for planning / finalisation
@@ -188,6 +190,14 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
         delete h;
         return fail(nullptr, VPR_ERR_DEVICE, "hipSetDevice/hipStreamCreate failed");
     }
+    for (int k = 0; k < N_CLASSES; k++) {
+        if (hipStreamCreateWithFlags(&h->cls_stream[k], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming) != hipSuccess) {
+            return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
+        }
+    }
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess)
+        return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     // allow the big classes to use the whole 160 KiB LDS of a CU
     for (int k = 0; k < N_CLASSES; k++) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_kernel(k)),
@@ -204,6 +214,11 @@ void vpr_destroy(vpr_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     free_batch(h);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (int k = 0; k < 8; k++) {
+        if (h->cls_stream[k]) (void)hipStreamDestroy(h->cls_stream[k]);
+        if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     delete h;
 }
 
@@ -414,13 +429,14 @@ int vpr_execute(vpr_handle *h) {
         HIPCHK(h, hipMemsetAsync(h->d_fp[q], 0xff, std::max<int64_t>(h->n_var[q >> 1], 1) * 4, st));
     HIPCHK(h, hipMemsetAsync(h->d_njobs, 0, 4, st));
 
-    auto timed = [&](int kind, auto &&launch) -> int {
-        EvPair ev; ev.kind = kind;
+    // HIP events bracket each launch on the stream the kernel is launched on
+    auto timed = [&](int kind, const vpr_launch_stat &ls, hipStream_t ks, auto &&launch) -> int {
+        EvPair ev; ev.kind = kind; ev.st = ls; ev.st.kind = kind;
         HIPCHK(h, hipEventCreate(&ev.a));
         HIPCHK(h, hipEventCreate(&ev.b));
-        HIPCHK(h, hipEventRecord(ev.a, st));
+        HIPCHK(h, hipEventRecord(ev.a, ks));
         launch();
-        HIPCHK(h, hipEventRecord(ev.b, st));
+        HIPCHK(h, hipEventRecord(ev.b, ks));
         h->events.push_back(ev);
         return VPR_OK;
     };
@@ -430,34 +446,54 @@ int vpr_execute(vpr_handle *h) {
     HIPCHK(h, hipEventRecord(t0, st));
     int64_t n_fwd = 0;
     for (const Chunk &ch : h->chunks) {
+        // fork: the kernel classes of one chunk touch disjoint alignments and workspace regions, so each
+        // class runs its K1 -> K2 -> K3 pipeline on its own stream and the chunk joins before the
+        // workspace is reused
+        HIPCHK(h, hipEventRecord(h->ev_fork, st));
         for (const Launch &L : ch.launches) {
             const KernelClass &K = CLASSES[L.cls];
+            hipStream_t ks = h->cls_stream[L.cls];
+            HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
             size_t lds_f = 0, lds_b = 0;
+            vpr_launch_stat ls;
+            memset(&ls, 0, sizeof(ls));
+            ls.threads = K.nt; ls.cells_per_thread = K.c; ls.n_units = L.count;
+            int64_t in_bytes = 0;
             for (int32_t w = 0; w < L.count; w++) {   // the launch's dynamic LDS = its largest member
                 const AlnDesc &d = h->descs[h->work[L.work_off + w]];
                 lds_f = std::max(lds_f, fwd_lds_bytes(L.cls, d.Lq, d.Lr));
                 lds_b = std::max(lds_b, bwd_lds_bytes(L.cls, d.Lq, d.Lr));
+                ls.cells += int64_t(d.Lq + d.Lr) * d.Lt;
+                // strings 1 B/base; pointer+flag arrays 5 B/element (q->r, r->q, t->r)
+                in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
             }
-            int rc = timed(1, [&] {
-                hipLaunchKernelGGL(fwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_f, st, h->dB, h->d_descs,
+            ls.bytes_algorithmic = ls.cells + in_bytes;
+            int rc = timed(1, ls, ks, [&] {
+                hipLaunchKernelGGL(fwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_f, ks, h->dB, h->d_descs,
                                    h->d_work + L.work_off, h->d_ws, h->d_outs);
-                hipLaunchKernelGGL(k_fwd_finish, dim3((L.count + 255) / 256), dim3(256), 0, st,
+                hipLaunchKernelGGL(k_fwd_finish, dim3((L.count + 255) / 256), dim3(256), 0, ks,
                                    h->d_work + L.work_off, L.count, h->d_outs);
             });
             if (rc) return rc;
             n_fwd++;
-            rc = timed(2, [&] {
-                hipLaunchKernelGGL(bwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_b, st, h->dB, h->d_descs,
+            ls.bytes_algorithmic = ls.cells;
+            rc = timed(2, ls, ks, [&] {
+                hipLaunchKernelGGL(bwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
                                    h->d_work + L.work_off, h->d_ws, h->d_outs);
             });
             if (rc) return rc;
+            vpr_launch_stat ws_;
+            memset(&ws_, 0, sizeof(ws_));
+            ws_.threads = 64; ws_.n_units = L.count;
+            rc = timed(3, ws_, ks, [&] {
+                hipLaunchKernelGGL(k_walk, dim3((L.count + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
+                                   h->d_work + L.work_off, L.count, h->d_ws, h->d_outs, h->d_paths, h->d_secs,
+                                   h->d_fp_table, h->d_jobs, h->d_njobs, h->jobs_cap);
+            });
+            if (rc) return rc;
+            HIPCHK(h, hipEventRecord(h->ev_join[L.cls], ks));
+            HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[L.cls], 0));
         }
-        int rc = timed(3, [&] {
-            hipLaunchKernelGGL(k_walk, dim3((ch.count + 63) / 64), dim3(64), 0, st, h->dB, h->d_descs,
-                               h->d_work + ch.work_off, ch.count, h->d_ws, h->d_outs, h->d_paths, h->d_secs,
-                               h->d_fp_table, h->d_jobs, h->d_njobs, h->jobs_cap);
-        });
-        if (rc) return rc;
     }
     // K4: deferred section edit distances
     int32_t n_jobs = 0;
@@ -482,7 +518,10 @@ int vpr_execute(vpr_handle *h) {
         }
         for (int32_t j0 = 0; j0 < n_jobs; j0 += per) {
             const int32_t cnt = std::min(per, n_jobs - j0);
-            int rc = timed(4, [&] {
+            vpr_launch_stat es_;
+            memset(&es_, 0, sizeof(es_));
+            es_.threads = 64; es_.n_units = cnt;
+            int rc = timed(4, es_, st, [&] {
                 hipLaunchKernelGGL(k_ed, dim3(cnt), dim3(64), 0, st, h->dB, h->d_descs, h->d_jobs + j0, cnt,
                                    h->d_secs, h->d_ed_scratch, stride);
             });
@@ -499,6 +538,7 @@ int vpr_execute(vpr_handle *h) {
     for (auto &e : h->events) {
         float m = 0;
         (void)hipEventElapsedTime(&m, e.a, e.b);
+        e.st.ms = m;
         if (e.kind == 1) h->timing.ms_fwd += m;
         else if (e.kind == 2) h->timing.ms_bwd += m;
         else if (e.kind == 3) h->timing.ms_walk += m;
@@ -509,6 +549,13 @@ int vpr_execute(vpr_handle *h) {
     (void)hipEventDestroy(t1);
     h->executed = true;
     return VPR_OK;
+}
+
+int vpr_get_launch_stats(const vpr_handle *h, vpr_launch_stat *out, int32_t cap) {
+    if (!h) return VPR_ERR_ARG;
+    const int32_t n = int32_t(h->events.size());
+    for (int32_t k = 0; k < n && k < cap && out; k++) out[k] = h->events[k].st;
+    return n;
 }
 
 int vpr_get_timing(const vpr_handle *h, vpr_timing *t) {

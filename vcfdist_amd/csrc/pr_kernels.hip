@@ -72,6 +72,18 @@ __global__ void k_prep_ins(DevBatch B, int slot, int64_t n_src) {
 }
 
 // ---------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for
+// every outstanding HBM flag-row store at each row of the sweep; the rows of one alignment never read
+// each other's global stores inside a kernel, so only lgkmcnt has to be drained.  A single-wave
+// workgroup needs no s_barrier at all: LDS operations of one wave execute in program order.
+// ---------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void lds_barrier() {
+    if (NT > 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------
 // block-wide exclusive prefix-min of two ints (one per plane), tid order.
 // wsc: 2*(NT/64) ints of LDS.  Contains one __syncthreads().
 // ---------------------------------------------------------------------------
@@ -88,10 +100,10 @@ __device__ __forceinline__ void block_excl_prefix_min2(int &a, int &b, int32_t *
     if (lane == 0) { ea = D_INF; eb = D_INF; }
     if (NT > 64) {
         if (lane == 63) { wsc[wave * 2] = ia; wsc[wave * 2 + 1] = ib; }
-        __syncthreads();
+        lds_barrier<NT>();
         for (int w = 0; w < wave; w++) { ea = min(ea, wsc[w * 2]); eb = min(eb, wsc[w * 2 + 1]); }
     } else {
-        __syncthreads();
+        lds_barrier<NT>();
     }
     a = ea; b = eb;
 }
@@ -105,6 +117,24 @@ template <> struct FlagVec<4> { typedef uint32_t T; };
 template <> struct FlagVec<8> { typedef uint2 T; };
 template <> struct FlagVec<16> { typedef uint4 T; };
 template <> struct FlagVec<32> { struct __align__(16) T { uint4 a, b; }; };
+
+// C flag bytes of one thread's chunk held in whole VGPRs (a lone uint8_t would be packed with its
+// neighbour into one register, which forces a wait right behind the load)
+template <int C> struct FlagReg { typename FlagVec<C>::T v; };
+template <> struct FlagReg<1> { uint32_t v; };
+template <int C> __device__ __forceinline__ FlagReg<C> load_flags(const uint8_t *p) {
+    FlagReg<C> r;
+    r.v = *reinterpret_cast<const typename FlagVec<C>::T *>(p);
+    return r;
+}
+template <> __device__ __forceinline__ FlagReg<1> load_flags<1>(const uint8_t *p) {
+    FlagReg<1> r;
+    r.v = *p;
+    return r;
+}
+template <int C> __device__ __forceinline__ void unpack_flags(const FlagReg<C> &r, uint8_t *out) {
+    __builtin_memcpy(out, &r.v, C);
+}
 
 template <int NT, int C>
 __global__ void __launch_bounds__(NT) k_fwd(DevBatch B, const AlnDesc *__restrict__ descs,
@@ -148,6 +178,15 @@ __global__ void __launch_bounds__(NT) k_fwd(DevBatch B, const AlnDesc *__restric
         }
     }
 
+    // Force the waits for the loads above to happen here: the compiler otherwise parks its
+    // s_waitcnt vmcnt(0) at the first use inside the row loop, where it would also drain the previous
+    // row's flag stores every iteration.
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int c = 0; c < C; c++) asm volatile("" ::"v"(uint32_t(sb[p][c])), "v"(c0[p][c]));
+    asm volatile("" ::"v"(multi[0]), "v"(multi[1]));
+
     // row 0: D = q (INS chain from the origin), dist.cpp:300-305,397-405
     int32_t dp[2][C];
 #pragma unroll
@@ -166,20 +205,24 @@ __global__ void __launch_bounds__(NT) k_fwd(DevBatch B, const AlnDesc *__restric
             *reinterpret_cast<typename FlagVec<C>::T *>(mat[p] + q0) = v;
         }
     }
-    __syncthreads();
+    lds_barrier<NT>();
 
-    uint32_t tchunk = 0;  // lane l holds truth base and flag of row (t & ~63) + l
+    // lane l holds truth base and truth flag of row (t & ~63) + l; refilled every 64 rows so the hot loop
+    // has no global load (a vmcnt wait there would also wait for the previous rows' flag stores)
+    uint32_t tchunk = 0;
+    if (lane < Lt) tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
+    uint32_t tlast = 0;   // entry of row (t & ~63) - 1
     for (int t = 1; t < Lt; t++) {
-        if ((t & 63) == 0 || t == 1) {
-            const int tt = (t & ~63) + lane;
+        if ((t & 63) == 0) {
+            tlast = __builtin_amdgcn_readlane(tchunk, 63);
+            const int tt = t + lane;
             tchunk = 0;
             if (tt < Lt) tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
         }
-        // T[t], and the truth flag of row t-1 (may live in the previous 64-chunk)
-        const uint32_t cur = __shfl(tchunk, t & 63);
+        const uint32_t cur = __builtin_amdgcn_readlane(tchunk, t & 63);
+        const uint32_t prv = ((t & 63) == 0) ? tlast : uint32_t(__builtin_amdgcn_readlane(tchunk, (t - 1) & 63));
         const uint8_t Tt = cur & 0xff;
-        const int tf_prev = ((t & 63) == 0) ? int(Tf[t - 1]) : int((__shfl(tchunk, (t - 1) & 63) >> 8) & 0xff);
-        const bool at = fwd_allow(tf_prev);
+        const bool at = fwd_allow(int((prv >> 8) & 0xff));   // truth flag of row t-1, dist.cpp:338-339
 
         int32_t bv[2][C];     // base - q
         uint8_t mk[2][C];     // flags achieving base
@@ -256,7 +299,7 @@ __global__ void __launch_bounds__(NT) k_fwd(DevBatch B, const AlnDesc *__restric
                 *reinterpret_cast<typename FlagVec<C>::T *>(mat[p] + size_t(t) * d.pitch[p] + q0) = v;
             }
         }
-        __syncthreads();
+        lds_barrier<NT>();
     }
     // end cells
 #pragma unroll
@@ -309,7 +352,7 @@ __device__ __forceinline__ void block_suffix_mp2(MP gq, MP gr, int &inq, int &in
     if (lane == 63) { eq.A = S_NEG; eq.B = 0; er.A = S_NEG; er.B = 0; }   // identity
     if (NT > 64) {
         if (lane == 0) { wsc[wave * 4] = hq.A; wsc[wave * 4 + 1] = hq.B; wsc[wave * 4 + 2] = hr.A; wsc[wave * 4 + 3] = hr.B; }
-        __syncthreads();
+        lds_barrier<NT>();
         // value entering this wave from the right = fold of waves NT/64-1 .. wave+1 applied to NEG
         int xq = S_NEG, xr = S_NEG;
         for (int w = NT / 64 - 1; w > wave; w--) {
@@ -320,7 +363,7 @@ __device__ __forceinline__ void block_suffix_mp2(MP gq, MP gr, int &inq, int &in
         inq = (eq.B < 0) ? eq.A : max(eq.A, xq + eq.B);
         inr = (er.B < 0) ? er.A : max(er.A, xr + er.B);
     } else {
-        __syncthreads();
+        lds_barrier<NT>();
         inq = eq.A; inr = er.A;
     }
 }
@@ -338,12 +381,16 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
     const int Pp[2] = {PQ, PR};
     extern __shared__ __align__(16) int32_t lds[];
     // score rows (int32) of row t+1, flag rows (bytes) of rows t+1 / t (double buffered)
-    int32_t *srow[2] = {lds, lds + PQ + 4};
+    // All LDS accesses go through integer offsets from the one extern array so they stay ds_* instructions
+    // (runtime-selected pointers degrade to flat_* loads, which wait on vmcnt as well).
+    const int SO[2] = {0, PQ + 4};                                    // score rows (int32 index into lds)
     uint8_t *fbase = reinterpret_cast<uint8_t *>(lds + PQ + PR + 8);
     const int FQ = (PQ + 16 + 15) & ~15, FR = (PR + 16 + 15) & ~15;   // bytes per flag row incl. guard
-    uint8_t *frow[2][2] = {{fbase, fbase + FQ}, {fbase + FQ + FR, fbase + 2 * FQ + FR}};
-    int32_t *wsc = reinterpret_cast<int32_t *>(fbase + 2 * (FQ + FR));
-
+    const int FP[2] = {0, FQ};                                        // plane offset inside one flag buffer
+    const int FB = FQ + FR;                                           // bytes per flag buffer (two planes)
+    int32_t *wsc = reinterpret_cast<int32_t *>(fbase + 2 * FB);
+#define SROW(p, i) lds[SO[p] + (i)]
+#define FROW(b, p, i) fbase[(b) * FB + FP[p] + (i)]
     const int32_t *ptr[2] = {B.hap_ptr[d.qs] + d.q_off, B.ref_ptr[d.qs] + d.r_off};
     const uint8_t *pfl[2] = {B.hap_flag[d.qs] + d.q_off, B.ref_flag[d.qs] + d.r_off};
     const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
@@ -384,6 +431,13 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
         }
     }
 
+    // tp of the QUERY-plane cell right of this chunk (constant over rows)
+    int xtp_right = 0;
+    if (q0 + C < Lq) {
+        const int qn = q0 + C;
+        xtp_right = ((ptr[0][qn] != ptr[0][qn - 1] + 1) || (pfl[0][qn] & PB)) ? 1 : 0;
+    }
+
     int32_t sc[2][C];   // scores of row t+1 (S_NEG = unreachable)
     uint8_t f1[2][C];   // forward flags of row t+1
 #pragma unroll
@@ -394,8 +448,8 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
     for (int p = 0; p < 2; p++)
         if (q0 < Pp[p])
 #pragma unroll
-            for (int c = 0; c < C; c++) { srow[p][q0 + c] = S_NEG; frow[0][p][q0 + c] = 0; }
-    // stage flags of row Lt-1 into frow[1]
+            for (int c = 0; c < C; c++) { SROW(p, q0 + c) = S_NEG; FROW(0, p, q0 + c) = 0; }
+    // stage flags of row Lt-1 into flag buffer 1
     uint8_t f0[2][C];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
@@ -405,27 +459,28 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
             typename FlagVec<C>::T v = *reinterpret_cast<const typename FlagVec<C>::T *>(mat[p] + size_t(Lt - 1) * d.pitch[p] + q0);
             __builtin_memcpy(f0[p], &v, C);
 #pragma unroll
-            for (int c = 0; c < C; c++) frow[1][p][q0 + c] = f0[p][c];
+            for (int c = 0; c < C; c++) FROW(1, p, q0 + c) = f0[p][c];
         } else if (q0 < Pp[p]) {
 #pragma unroll
-            for (int c = 0; c < C; c++) frow[1][p][q0 + c] = 0;
+            for (int c = 0; c < C; c++) FROW(1, p, q0 + c) = 0;
         }
     }
     if (tid == 0) {   // guard cells right of each row (read by the last thread as "q+1")
-        for (int p = 0; p < 2; p++) { srow[p][Pp[p]] = S_NEG; frow[0][p][Pp[p]] = 0; frow[1][p][Pp[p]] = 0; }
+        for (int p = 0; p < 2; p++) { SROW(p, Pp[p]) = S_NEG; FROW(0, p, Pp[p]) = 0; FROW(1, p, Pp[p]) = 0; }
     }
-    __syncthreads();
+    lds_barrier<NT>();
     uint32_t tie_used = 0;
+    // Software pipeline of the flag-row loads: pf holds row t-1, requested at the end of iteration t+1,
+    // *before* that iteration's path_ptr stores were issued.  vmcnt retires in order, so waiting for pf
+    // (with the younger stores still allowed in flight) never waits for a store younger than one row.
+    FlagReg<C> pf[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+        if (Lt >= 2 && q0 < Lp[p]) pf[p] = load_flags<C>(mat[p] + size_t(Lt - 2) * d.pitch[p] + q0);
 
     for (int t = Lt - 1; t >= 0; t--) {
         const int cur = (Lt - 1 - t + 1) & 1;      // buffer holding row t's forward flags
         const int nxt = cur ^ 1;                   // buffer holding row t+1's forward flags
-        // prefetch row t-1 flags from HBM
-        typename FlagVec<C>::T pf[2];
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-            if (t > 0 && q0 < Lp[p])
-                pf[p] = *reinterpret_cast<const typename FlagVec<C>::T *>(mat[p] + size_t(t - 1) * d.pitch[p] + q0);
 
         int32_t base[2][C];
         uint8_t bm[2][C];
@@ -437,14 +492,11 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
             // values of the cell to the right of this chunk
             int xs_r = S_NEG; int xf_r = 0, xf0_r = 0, xtp_r = 0;
             if (q0 + C <= Pp[p]) {
-                xs_r = srow[p][q0 + C];
-                xf_r = frow[nxt][p][q0 + C];
-                xf0_r = frow[cur][p][q0 + C];
+                xs_r = SROW(p, q0 + C);
+                xf_r = FROW(nxt, p, q0 + C);
+                xf0_r = FROW(cur, p, q0 + C);
             }
-            if (p == 0 && q0 + C < Lq) {
-                const int qn = q0 + C;
-                xtp_r = ((ptr[0][qn] != ptr[0][qn - 1] + 1) || (pfl[0][qn] & PB)) ? 1 : 0;
-            }
+            if (p == 0) xtp_r = xtp_right;
             MP G; G.A = S_NEG; G.B = 0;   // identity; composed from the right end of the chunk leftwards
             bool first = true;
 #pragma unroll
@@ -466,9 +518,9 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
                 }
                 // swap successor z = (other plane, zq, t+1)
                 if (zq[p][c] >= 0) {
-                    const int zf = frow[nxt][o][zq[p][c]];
+                    const int zf = FROW(nxt, o, zq[p][c]);
                     if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((kc[p][c] >> 1) & 3)) {
-                        const int v = srow[o][zq[p][c]] + ((kc[p][c] >> 3) & 1);
+                        const int v = SROW(o, zq[p][c]) + ((kc[p][c] >> 3) & 1);
                         if (v >= 0 && (zf & F_TIE)) tie_used = 1;
                         if (v > best) { best = v; m = F_SWP; } else if (v == best) m |= F_SWP;
                     }
@@ -487,11 +539,11 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
             g[p] = G;
         }
         int inq, inr;
-        block_suffix_mp2<NT>(g[0], g[1], inq, inr, wsc);   // barrier: all reads of srow / frow[nxt] done
+        block_suffix_mp2<NT>(g[0], g[1], inq, inr, wsc);   // barrier: all reads of the score rows / flag buffer nxt done
         const int inc[2] = {inq, inr};
+        uint8_t out[2][C];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            uint8_t out[C];
             int prev = inc[p];
 #pragma unroll
             for (int c = C - 1; c >= 0; c--) {
@@ -503,28 +555,40 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
                 }
                 if (v < 0) { v = S_NEG; m = 0; }
                 sc[p][c] = v;
-                out[c] = m;
+                out[p][c] = m;
                 prev = v;
                 f1[p][c] = f0[p][c];
             }
             if (q0 < Lp[p]) {
-                typename FlagVec<C>::T v;
-                __builtin_memcpy(&v, out, C);
-                *reinterpret_cast<typename FlagVec<C>::T *>(mat[p] + size_t(t) * d.pitch[p] + q0) = v;
 #pragma unroll
-                for (int c = 0; c < C; c++) srow[p][q0 + c] = sc[p][c];
+                for (int c = 0; c < C; c++) SROW(p, q0 + c) = sc[p][c];
                 if (t > 0) {
-                    __builtin_memcpy(f0[p], &pf[p], C);
+                    unpack_flags<C>(pf[p], f0[p]);   // row t-1 flags (requested one row ago)
 #pragma unroll
-                    for (int c = 0; c < C; c++) frow[nxt][p][q0 + c] = f0[p][c];   // nxt becomes "cur" of row t-1
+                    for (int c = 0; c < C; c++) FROW(nxt, p, q0 + c) = f0[p][c];   // nxt becomes "cur" of row t-1
                 }
             }
         }
-        __syncthreads();
+        // request row t-2 for both planes, then store this row's path_ptrs (loads first, see above)
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            if (t > 1 && q0 < Lp[p]) pf[p] = load_flags<C>(mat[p] + size_t(t - 2) * d.pitch[p] + q0);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            if (q0 < Lp[p]) {
+                typename FlagVec<C>::T v;
+                __builtin_memcpy(&v, out[p], C);
+                *reinterpret_cast<typename FlagVec<C>::T *>(mat[p] + size_t(t) * d.pitch[p] + q0) = v;
+            }
+        lds_barrier<NT>();
     }
     if (tid == 0) outs[a].beg_plane = (sc[0][0] >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
     if (tie_used) atomicOr(&outs[a].status, VPR_ST_SWAP_TIE);
 }
+
+// ---------------------------------------------------------------------------
+#undef SROW
+#undef FROW
 
 // ---------------------------------------------------------------------------
 // K3: walk + sync points + credit sections; one lane per alignment.
