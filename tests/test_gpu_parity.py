@@ -43,6 +43,7 @@ def compare(batch, cfg=None, expect_exact=False):
     return got, want, int(tied_sc.sum()), pr
 
 
+@pytest.mark.parametrize("band_mode", [1, 0])
 @pytest.mark.parametrize("name,kw", [
     ("tiny_repeats", dict(n_sc=400, len_a=6, len_b=60, len_min=5, len_max=60, seed=1, var_per_base=0.08, p_snp=0.5, p_repeat=0.5)),
     ("c64x4", dict(n_sc=200, len_a=65, len_b=250, len_min=65, len_max=250, seed=2, var_per_base=0.03)),
@@ -52,16 +53,28 @@ def compare(batch, cfg=None, expect_exact=False):
     ("mixed", dict(n_sc=300, len_a=8, len_b=2500, len_min=5, len_max=2500, seed=6)),
     ("wgs_like", dict(n_sc=3000, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=3000, seed=8)),
 ])
-def test_parity_by_kernel_class(name, kw):
+def test_parity_by_kernel_class(name, kw, band_mode):
     batch = api.Synth(**kw).batch()
-    got, want, ntie, pr = compare(batch)
+    got, want, ntie, pr = compare(batch, A.default_config(band_mode=band_mode))
     t = pr.timing()
-    print(f"{name}: {batch.n_sc} sc, {batch.dense_cells():.3e} cells, kernels {t.ms_total:.2f} ms, {ntie} order-defined ties skipped")
+    print(f"{name} band_mode={band_mode}: {batch.n_sc} sc, {batch.dense_cells():.3e} dense cells, "
+          f"{t.cells_touched:.3e} touched, {t.n_band_retries} retries, kernels {t.ms_total:.2f} ms, "
+          f"{ntie} order-defined ties skipped")
 
 
-def test_big_class_1024x16_single():
+@pytest.mark.parametrize("band_mode", [1, 0])
+def test_big_class_1024x16_single(band_mode):
     batch = api.Synth(n_sc=1, len_mode=2, len_a=9000.0, len_min=9000, len_max=9000, seed=9).batch()
-    compare(batch)
+    compare(batch, A.default_config(band_mode=band_mode))
+
+
+def test_band_retries_reach_wider_windows_and_dense():
+    """Dropping most truth variants of indel-rich haps makes s large, so 64-cell windows fail the exit
+    test and the alignment is re-run with wider windows / the dense kernels; results stay exact."""
+    batch = api.Synth(n_sc=40, len_a=400, len_b=3000, len_min=400, len_max=3000, seed=17, var_per_base=0.05,
+                      p_snp=0.2, indel_mean=12.0, p_keep=0.3, p_drop=0.6).batch()
+    got, want, ntie, pr = compare(batch)
+    assert pr.timing().n_band_retries > 0
 
 
 def test_minimum_sizes_and_empty_haps():
@@ -101,8 +114,10 @@ def test_sv_sized_sections_use_deferred_edit_distance():
 def test_workspace_chunking_gives_identical_results():
     batch = api.Synth(n_sc=120, len_a=50, len_b=800, len_max=800, seed=12).batch()
     full = api.PrecisionRecall().run(batch)
-    small = api.PrecisionRecall(A.default_config(workspace_bytes=4 << 20)).run(batch)
+    small = api.PrecisionRecall(A.default_config(workspace_bytes=8 << 20)).run(batch)
     assert not full.diff(small)
+    dense = api.PrecisionRecall(A.default_config(band_mode=0, workspace_bytes=8 << 20)).run(batch)
+    assert not full.diff(dense)
 
 
 def test_results_independent_of_batch_order():

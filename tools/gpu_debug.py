@@ -13,7 +13,7 @@ def check(name, **kw):
     ex = O.Extra(b)
     want = O.run(b, extra=ex)
     t1 = time.time()
-    pr = api.PrecisionRecall(device=0)
+    pr = api.PrecisionRecall(A.default_config(band_mode=int(os.environ.get("BAND", "1"))))
     got = pr.run(b)
     t2 = time.time()
     tm = pr.timing()
@@ -21,7 +21,7 @@ def check(name, **kw):
     bad = got.diff(want)
     print(f"== {name}: n_sc={b.n_sc} cells={b.dense_cells():.3e} oracle {t1-t0:.2f}s gpu-total {t2-t1:.2f}s "
           f"kernels {tm.ms_total:.2f}ms (fwd {tm.ms_fwd:.2f} bwd {tm.ms_bwd:.2f} walk {tm.ms_walk:.2f} ed {tm.ms_ed:.2f}) "
-          f"ties(nonmax sc)={int(nonmax.sum())}")
+          f"ties(nonmax sc)={int(nonmax.sum())} touched={tm.cells_touched:.3e} retries={tm.n_band_retries}")
     if bad:
         for line in bad[:12]:
             print("   ", line)

@@ -99,7 +99,7 @@ class VprSynthParams(C.Structure):
     ]
 
 
-def default_config(device=0, band_mode=0, workspace_bytes=0):
+def default_config(device=0, band_mode=1, workspace_bytes=0):
     """The reference's defaults: globals.h:27 (max_qual), :49 (credit), :46 (phase)."""
     return VprConfig(device=device, max_qual=60.0, credit_threshold=0.7, phase_threshold=0.6,
                      workspace_bytes=workspace_bytes, band_mode=band_mode, reserved=0)

@@ -1,6 +1,11 @@
 // pr_api.hip -- host side of the C ABI (include/vcfdist_pr.h): device memory,
-// work planning, kernel launches on the library's own stream, result download
+// work planning, kernel launches on the library's own streams, result download
 // and the float finalisation of calc_prec_recall (dist.cpp:1284-1353).
+//
+// Execution plan (band_mode 1, the default): every alignment first runs the exact banded
+// single-wave kernels (pr_band.hip) with a 64-cell window; alignments whose window fails the
+// exit test (exit_min <= s) are re-run with 256, then 1024 cells, then with the dense
+// workgroup-per-alignment kernels (pr_kernels.hip).  band_mode 0 runs the dense kernels only.
 //
 // There is no CPU fallback: without a HIP device every entry point that needs one
 // returns VPR_ERR_DEVICE.
@@ -17,19 +22,35 @@
 #include "../../include/vcfdist_pr.h"
 #include "pr_device.h"
 #include "pr_kernels.hip"
+#include "pr_band.hip"
 
 namespace {
 
 struct KernelClass { int nt, c, max_len; };
-// thread-chunk configurations: a plane of up to nt*c cells per row
+// dense thread-chunk configurations: a plane of up to nt*c cells per row
 const KernelClass CLASSES[] = {
     {64, 1, 64}, {64, 4, 256}, {256, 4, 1024}, {256, 8, 2048}, {1024, 8, 8192}, {1024, 16, 16384}, {1024, 32, 32768},
 };
 const int N_CLASSES = sizeof(CLASSES) / sizeof(CLASSES[0]);
 const size_t LDS_MAX = 160 * 1024;
+const int BAND_C[] = {1, 4, 16};          // banded rounds: windows of 64, 256, 1024 cells
+const int N_BAND = 3;
 
-struct Launch { int cls; int64_t work_off; int32_t count; };   // one k_fwd/k_bwd launch
-struct Chunk { std::vector<Launch> launches; int64_t work_off; int32_t count; };
+struct Launch { int cls; int64_t work_off; int32_t count; };   // dense: one k_fwd/k_bwd launch of a class
+struct Chunk {
+    int64_t work_off = 0; int32_t count = 0;   // slice of the plan's work list
+    std::vector<Launch> launches;              // dense plans only
+    int64_t cells = 0, in_bytes = 0;           // touched cells / input bytes of the chunk
+};
+// a set of alignments with workspace offsets assigned; band_c == 0 means dense kernels
+struct Plan {
+    int band_c = 0;
+    std::vector<AlnDesc> descs;     // compact, in work-list order
+    std::vector<int32_t> work;      // alignment ids
+    std::vector<Chunk> chunks;
+    AlnDesc *d_descs = nullptr;     // device copy of `descs` (plan 0 only, cached)
+    int32_t *d_work = nullptr;
+};
 
 struct EvPair { hipEvent_t a, b; int kind; vpr_launch_stat st; };
 
@@ -48,21 +69,24 @@ struct vpr_handle {
     std::vector<int64_t> var_off[4];
     std::vector<float> var_qual[4];
     int64_t n_var[4] = {0, 0, 0, 0};
-    std::vector<AlnDesc> descs;
-    std::vector<int32_t> work;           // alignment ids, grouped by chunk and class
-    std::vector<Chunk> chunks;
+    std::vector<AlnDesc> descs;          // base descriptors (no workspace offsets)
+    Plan plan0;                          // first round over all alignments, cached at upload
+    std::vector<int32_t> dirty;          // alignments whose device descriptor was overwritten by a retry round
     // device side
     AlnDesc *d_descs = nullptr;
     AlnOut *d_outs = nullptr;
-    int32_t *d_work = nullptr;
-    uint8_t *d_ws = nullptr; size_t ws_bytes = 0;
-    PathEnt *d_paths = nullptr; size_t path_entries = 0;
+    uint8_t *d_arena = nullptr; int64_t arena_bytes = 0;
     Section *d_secs = nullptr; int64_t n_secs_cap = 0;
     int32_t *d_fp[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t **d_fp_table = nullptr;
     EdJob *d_jobs = nullptr; int32_t jobs_cap = 0; int32_t *d_njobs = nullptr;
     uint32_t *d_err = nullptr;
+    int32_t *d_ok = nullptr, *d_fail = nullptr, *d_cnt = nullptr;   // partition lists + 2 counters
+    AlnDesc *d_tmp_descs = nullptr; size_t tmp_descs_cap = 0;
+    int32_t *d_tmp_work = nullptr; size_t tmp_work_cap = 0;
     int32_t *d_ed_scratch = nullptr; size_t ed_scratch_ints = 0;
+    int32_t last_path_a0 = -1;           // alignments of the last chunk (their walks are still in the arena)
+    std::vector<int32_t> last_chunk;
     std::vector<EvPair> events;
     vpr_timing timing;
     bool uploaded = false, executed = false;
@@ -90,13 +114,13 @@ int fail(vpr_handle *h, int code, const char *fmt, ...) {
     } while (0)
 
 template <typename T>
-int dev_alloc(vpr_handle *h, T **p, size_t n, bool batch_lifetime = true) {
+int dev_alloc(vpr_handle *h, T **p, size_t n) {
     *p = nullptr;
     if (n == 0) n = 1;
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, n * sizeof(T));
     if (e != hipSuccess) return fail(h, VPR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
-    if (batch_lifetime) h->allocs.push_back(q);
+    h->allocs.push_back(q);
     *p = static_cast<T *>(q);
     return VPR_OK;
 }
@@ -116,9 +140,13 @@ void free_batch(vpr_handle *h) {
     h->allocs.clear();
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     h->events.clear();
-    h->descs.clear(); h->work.clear(); h->chunks.clear();
-    h->d_ws = nullptr; h->d_paths = nullptr; h->d_secs = nullptr;
+    h->descs.clear();
+    h->plan0 = Plan();
+    h->dirty.clear();
+    h->d_arena = nullptr; h->d_secs = nullptr;
     h->d_ed_scratch = nullptr; h->ed_scratch_ints = 0;
+    h->d_tmp_descs = nullptr; h->tmp_descs_cap = 0;
+    h->d_tmp_work = nullptr; h->tmp_work_cap = 0;
     h->uploaded = h->executed = false;
 }
 
@@ -163,8 +191,108 @@ AlnKernel bwd_kernel(int cls) {
         default: return k_bwd<1024, 32>;
     }
 }
+typedef void (*BandFwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, int32_t *, AlnOut *);
+typedef void (*BandBwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, const int32_t *, AlnOut *);
+BandFwd band_fwd_kernel(int c) {
+    switch (c) {
+        case 1: return k_fwd_band<1, true>;
+        case 4: return k_fwd_band<4, true>;
+        default: return k_fwd_band<16, true>;
+    }
+}
+BandBwd band_bwd_kernel(int c) {
+    switch (c) {
+        case 1: return k_bwd_band<1>;
+        case 4: return k_bwd_band<4>;
+        default: return k_bwd_band<16>;
+    }
+}
 
 int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+__global__ void k_partition(const int32_t *__restrict__ work, int n, const AlnOut *__restrict__ outs,
+                            int32_t *__restrict__ ok_list, int32_t *__restrict__ fail_list, int32_t *__restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int a = work[i];
+    if (outs[a].band_ok) ok_list[atomicAdd(&cnt[0], 1)] = a;
+    else fail_list[atomicAdd(&cnt[1], 1)] = a;
+}
+
+__global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AlnDesc d = src[i];
+    dst[d.sc * 4 + d.aln] = d;
+}
+
+// Assign arena offsets (flag matrices, band origins, walk scratch) to `alns` and cut them into chunks
+// that fit the arena.  band_c > 0: banded layout with a 64*band_c window; 0: dense layout + kernel classes.
+int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int band_c, Plan &P) {
+    P = Plan();
+    P.band_c = band_c;
+    const int W = 64 * band_c;
+    std::vector<int32_t> order(alns);
+    auto mat_bytes = [&](int32_t a) -> int64_t {
+        const AlnDesc &d = h->descs[a];
+        if (band_c) return int64_t(round_up(std::min(W, d.Lq), 16) + round_up(std::min(W, d.Lr), 16)) * d.Lt;
+        return int64_t(round_up(d.Lq, 32) + round_up(d.Lr, 32)) * d.Lt;
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return mat_bytes(x) > mat_bytes(y); });
+    size_t k = 0;
+    while (k < order.size()) {
+        Chunk ch;
+        ch.work_off = int64_t(P.work.size());
+        int64_t used = 0;
+        std::vector<std::vector<int32_t>> by_cls(N_CLASSES);
+        std::vector<std::vector<AlnDesc>> desc_cls(N_CLASSES);
+        const size_t k0 = k;
+        while (k < order.size()) {
+            AlnDesc d = h->descs[order[k]];
+            int cls = 0;
+            if (band_c) {
+                d.band_w = W;
+                d.pitch[0] = int32_t(round_up(std::min(W, d.Lq), 16));
+                d.pitch[1] = int32_t(round_up(std::min(W, d.Lr), 16));
+            } else {
+                d.band_w = 0;
+                d.pitch[0] = int32_t(round_up(d.Lq, 32));
+                d.pitch[1] = int32_t(round_up(d.Lr, 32));
+                cls = class_of(std::max(d.Lq, d.Lr));
+                if (cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX || bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX)
+                    return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d too long for the dense kernels (Lq=%d Lr=%d)",
+                                d.sc, d.aln, d.Lq, d.Lr);
+            }
+            const int64_t m0 = round_up(int64_t(d.pitch[0]) * d.Lt, 64), m1 = round_up(int64_t(d.pitch[1]) * d.Lt, 64);
+            const int64_t bl = band_c ? round_up(int64_t(2) * d.Lt * 4, 64) : 0;
+            const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64);
+            const int64_t need = m0 + m1 + bl + pb + 64;
+            if (k > k0 && used + need > h->arena_bytes) break;
+            if (need > h->arena_bytes)
+                return fail(h, VPR_ERR_NOMEM, "workspace (%lld bytes) too small for supercluster %d alignment %d (%lld bytes)",
+                            (long long)h->arena_bytes, d.sc, d.aln, (long long)need);
+            d.mat_off[0] = used;
+            d.mat_off[1] = used + m0;
+            d.blo_off = (used + m0 + m1) / 4;            // int index into the arena
+            d.path_off = (used + m0 + m1 + bl) / int64_t(sizeof(PathEnt));
+            used += need;
+            ch.cells += band_c ? int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt : int64_t(d.Lq + d.Lr) * d.Lt;
+            ch.in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
+            by_cls[cls].push_back(order[k]);
+            desc_cls[cls].push_back(d);
+            k++;
+        }
+        for (int c = 0; c < N_CLASSES; c++) {
+            if (by_cls[c].empty()) continue;
+            if (!band_c) ch.launches.push_back(Launch{c, int64_t(P.work.size()), int32_t(by_cls[c].size())});
+            P.work.insert(P.work.end(), by_cls[c].begin(), by_cls[c].end());
+            P.descs.insert(P.descs.end(), desc_cls[c].begin(), desc_cls[c].end());
+        }
+        ch.count = int32_t(P.work.size() - ch.work_off);
+        P.chunks.push_back(std::move(ch));
+    }
+    return VPR_OK;
+}
 
 }  // namespace
 
@@ -198,7 +326,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess)
         return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
-    // allow the big classes to use the whole 160 KiB LDS of a CU
+    // allow the big dense classes to use the whole 160 KiB LDS of a CU
     for (int k = 0; k < N_CLASSES; k++) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_kernel(k)),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_MAX));
@@ -255,6 +383,10 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if ((rc = dev_upload(h, &D.ref_flag[q], b->ref_flag[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.cand_q[q], hap_len[q]))) return rc;
         if ((rc = dev_alloc(h, &D.cand_r[q], ref_len))) return rc;
+        if ((rc = dev_alloc(h, &D.fk_q[q], hap_len[q]))) return rc;
+        if ((rc = dev_alloc(h, &D.fk_r[q], ref_len))) return rc;
+        if ((rc = dev_alloc(h, &D.bk_q[q], hap_len[q]))) return rc;
+        if ((rc = dev_alloc(h, &D.bk_r[q], ref_len))) return rc;
         HIPCHK(h, hipMemsetAsync(D.cand_q[q], 0xff, std::max<int64_t>(hap_len[q], 1) * sizeof(int4), h->stream));
         HIPCHK(h, hipMemsetAsync(D.cand_r[q], 0xff, std::max<int64_t>(ref_len, 1) * sizeof(int4), h->stream));
     }
@@ -266,21 +398,23 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, h->stream));
+    auto blocks = [](int64_t n_) { return dim3(unsigned((n_ + 255) / 256)); };
     for (int q = 0; q < 2; q++) {
         if (hap_len[q] > 0)
-            hipLaunchKernelGGL(k_prep_cand, dim3(unsigned((hap_len[q] + 255) / 256)), dim3(256), 0, h->stream,
-                               D, q, 0, hap_len[q], h->d_err);
+            hipLaunchKernelGGL(k_prep_cand, blocks(hap_len[q]), dim3(256), 0, h->stream, D, q, 0, hap_len[q], h->d_err);
         if (ref_len > 0)
-            hipLaunchKernelGGL(k_prep_cand, dim3(unsigned((ref_len + 255) / 256)), dim3(256), 0, h->stream,
-                               D, q, 1, ref_len, h->d_err);
+            hipLaunchKernelGGL(k_prep_cand, blocks(ref_len), dim3(256), 0, h->stream, D, q, 1, ref_len, h->d_err);
+    }
+    for (int q = 0; q < 2; q++) {
+        if (hap_len[q] > 0) hipLaunchKernelGGL(k_prep_pack, blocks(hap_len[q]), dim3(256), 0, h->stream, D, q, 0, hap_len[q]);
+        if (ref_len > 0) hipLaunchKernelGGL(k_prep_pack, blocks(ref_len), dim3(256), 0, h->stream, D, q, 1, ref_len);
     }
     for (int s = 0; s < 4; s++)
         if (hap_len[s] > 0)
-            hipLaunchKernelGGL(k_prep_ins, dim3(unsigned((hap_len[s] + 255) / 256)), dim3(256), 0, h->stream,
-                               D, s, hap_len[s]);
+            hipLaunchKernelGGL(k_prep_ins, blocks(hap_len[s]), dim3(256), 0, h->stream, D, s, hap_len[s]);
     HIPCHK(h, hipEventRecord(e1, h->stream));
 
-    // ---- plan: descriptors, classes, workspace chunks
+    // ---- base descriptors
     h->descs.resize(size_t(n) * 4);
     int64_t sec_total = 0, jobs_total = 0;
     int64_t cells = 0, bytes_alg = 0;
@@ -300,7 +434,6 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
             d.Lq = int32_t(Lh[d.qs]); d.Lt = int32_t(Lh[d.ts]); d.Lr = int32_t(Lr);
             if (d.Lq < 1 || d.Lt < 1 || d.Lr < 1)
                 return fail(h, VPR_ERR_ARG, "supercluster %d has an empty string", sc);
-            d.pitch[0] = int32_t(round_up(d.Lq, 32)); d.pitch[1] = int32_t(round_up(d.Lr, 32));
             d.qv_beg = b->var_off[d.qs][sc]; d.qv_end = b->var_off[d.qs][sc + 1];
             d.tv_beg = b->var_off[d.ts][sc]; d.tv_end = b->var_off[d.ts][sc + 1];
             d.sec_cap = int32_t((d.qv_end - d.qv_beg) + (d.tv_end - d.tv_beg) + 4);
@@ -313,77 +446,11 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     }
     bytes_alg += 2 * cells;
     h->timing.cells_dense = cells;
-    h->timing.cells_touched = cells;
     h->timing.bytes_algorithmic = bytes_alg;
 
-    // order alignments by matrix size (descending) and cut into workspace chunks
-    std::vector<int32_t> order(size_t(n) * 4);
-    for (size_t k = 0; k < order.size(); k++) order[k] = int32_t(k);
-    auto mat_bytes = [&](int32_t a) {
-        const AlnDesc &d = h->descs[a];
-        return int64_t(d.pitch[0] + d.pitch[1]) * d.Lt;
-    };
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return mat_bytes(x) > mat_bytes(y); });
-
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
-    int64_t fixed = sec_total * int64_t(sizeof(Section)) + int64_t(n) * 4 * (sizeof(AlnDesc) + sizeof(AlnOut) + 4) +
-                    (h->n_var[0] + h->n_var[1]) * 8 + jobs_total * int64_t(sizeof(EdJob)) + (64 << 20);
-    int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes : int64_t(free_b * 0.8) - fixed;
-    if (budget < (16 << 20)) budget = 16 << 20;
-
-    h->work.clear();
-    size_t k = 0;
-    int64_t max_ws = 0, max_path = 0;
-    while (k < order.size()) {
-        Chunk ch;
-        ch.work_off = int64_t(h->work.size());
-        int64_t ws = 0, pe = 0;
-        std::vector<std::vector<int32_t>> by_cls(N_CLASSES);
-        size_t k0 = k;
-        while (k < order.size()) {
-            AlnDesc &d = h->descs[order[k]];
-            const int64_t mb = round_up(mat_bytes(order[k]), 64) + 64;
-            const int64_t pb = d.path_cap;
-            if (k > k0 && ws + mb + (pe + pb) * int64_t(sizeof(PathEnt)) > budget) break;
-            const int cls = class_of(std::max(d.Lq, d.Lr));
-            if (cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX || bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX)
-                return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d too long for this build (Lq=%d Lr=%d)",
-                            d.sc, d.aln, d.Lq, d.Lr);
-            d.mat_off[0] = ws;
-            d.mat_off[1] = ws + round_up(int64_t(d.pitch[0]) * d.Lt, 32);
-            d.path_off = pe;
-            ws += mb;
-            pe += pb;
-            by_cls[cls].push_back(order[k]);
-            k++;
-        }
-        if (ws + pe * int64_t(sizeof(PathEnt)) > budget && k - k0 == 1 && h->cfg.workspace_bytes > 0)
-            return fail(h, VPR_ERR_NOMEM, "workspace budget %lld too small for one alignment (%lld bytes)",
-                        (long long)budget, (long long)ws);
-        for (int c = 0; c < N_CLASSES; c++) {
-            if (by_cls[c].empty()) continue;
-            Launch L{c, int64_t(h->work.size()), int32_t(by_cls[c].size())};
-            h->work.insert(h->work.end(), by_cls[c].begin(), by_cls[c].end());
-            ch.launches.push_back(L);
-        }
-        ch.count = int32_t(h->work.size() - ch.work_off);
-        max_ws = std::max(max_ws, ws);
-        max_path = std::max(max_path, pe);
-        h->chunks.push_back(std::move(ch));
-    }
-
-    if ((rc = dev_alloc(h, &h->d_descs, h->descs.size()))) return rc;
-    if (!h->descs.empty())
-        HIPCHK(h, hipMemcpyAsync(h->d_descs, h->descs.data(), h->descs.size() * sizeof(AlnDesc), hipMemcpyHostToDevice, h->stream));
-    if ((rc = dev_alloc(h, &h->d_outs, h->descs.size()))) return rc;
-    if ((rc = dev_alloc(h, &h->d_work, h->work.size()))) return rc;
-    if (!h->work.empty())
-        HIPCHK(h, hipMemcpyAsync(h->d_work, h->work.data(), h->work.size() * 4, hipMemcpyHostToDevice, h->stream));
-    h->ws_bytes = size_t(max_ws);
-    if ((rc = dev_alloc(h, &h->d_ws, h->ws_bytes + 64))) return rc;
-    h->path_entries = size_t(max_path);
-    if ((rc = dev_alloc(h, &h->d_paths, h->path_entries + 1))) return rc;
+    const size_t na = h->descs.size();
+    if ((rc = dev_alloc(h, &h->d_descs, na))) return rc;
+    if ((rc = dev_alloc(h, &h->d_outs, na))) return rc;
     h->n_secs_cap = sec_total;
     if ((rc = dev_alloc(h, &h->d_secs, size_t(sec_total)))) return rc;
     for (int q = 0; q < 4; q++)
@@ -393,8 +460,44 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     h->jobs_cap = int32_t(std::min<int64_t>(jobs_total + 1, 0x7fffffff));
     if ((rc = dev_alloc(h, &h->d_jobs, size_t(h->jobs_cap)))) return rc;
     if ((rc = dev_alloc(h, &h->d_njobs, 1))) return rc;
+    if ((rc = dev_alloc(h, &h->d_ok, na))) return rc;
+    if ((rc = dev_alloc(h, &h->d_fail, na))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cnt, 2))) return rc;
+
+    // ---- arena for flag matrices, band origins and walks
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+    int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes : int64_t(double(free_b) * 0.6);
+    if (budget < (8 << 20)) budget = 8 << 20;
+    // do not allocate more than round 0 can use
+    {
+        int64_t want = 0;
+        const bool band = h->cfg.band_mode != 0;
+        for (const AlnDesc &d : h->descs) {
+            const int64_t pq = band ? round_up(std::min(64, d.Lq), 16) : round_up(d.Lq, 32);
+            const int64_t prr = band ? round_up(std::min(64, d.Lr), 16) : round_up(d.Lr, 32);
+            want += round_up(pq * d.Lt, 64) + round_up(prr * d.Lt, 64) + (band ? round_up(8 * int64_t(d.Lt), 64) : 0) +
+                    round_up(int64_t(d.path_cap) * 8, 64) + 64;
+        }
+        if (h->cfg.workspace_bytes <= 0) budget = std::min(budget, std::max<int64_t>(want, 256 << 20));
+    }
+    h->arena_bytes = budget;
+    if ((rc = dev_alloc(h, &h->d_arena, size_t(budget) + 256))) return rc;
+
+    // ---- round-0 plan over all alignments, cached (descriptors + work list live on the device)
+    std::vector<int32_t> all(na);
+    for (size_t k = 0; k < na; k++) all[k] = int32_t(k);
+    if ((rc = make_plan(h, all, h->cfg.band_mode ? BAND_C[0] : 0, h->plan0))) return rc;
+    if ((rc = dev_alloc(h, &h->plan0.d_descs, na))) return rc;
+    if ((rc = dev_alloc(h, &h->plan0.d_work, na))) return rc;
+    if (na) {
+        HIPCHK(h, hipMemcpyAsync(h->plan0.d_descs, h->plan0.descs.data(), na * sizeof(AlnDesc), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->plan0.d_work, h->plan0.work.data(), na * 4, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(na)), dim3(256), 0, h->stream, h->plan0.d_descs, int(na), h->d_descs);
+    }
 
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
     uint32_t err = 0;
     HIPCHK(h, hipMemcpy(&err, h->d_err, 4, hipMemcpyDeviceToHost));
     if (err) return fail(h, VPR_ERR_ARG, "more than 4 swap sources map to one position (unsupported variant layout)");
@@ -424,10 +527,16 @@ int vpr_execute(vpr_handle *h) {
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     h->events.clear();
     hipStream_t st = h->stream;
+    auto blocks = [](int64_t n_) { return dim3(unsigned((n_ + 255) / 256)); };
     HIPCHK(h, hipMemsetAsync(h->d_outs, 0, std::max<size_t>(h->descs.size(), 1) * sizeof(AlnOut), st));
     for (int q = 0; q < 4; q++)
         HIPCHK(h, hipMemsetAsync(h->d_fp[q], 0xff, std::max<int64_t>(h->n_var[q >> 1], 1) * 4, st));
     HIPCHK(h, hipMemsetAsync(h->d_njobs, 0, 4, st));
+    if (!h->dirty.empty()) {   // restore the round-0 descriptors a previous execute's retry rounds replaced
+        hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(h->descs.size())), dim3(256), 0, st, h->plan0.d_descs,
+                           int(h->descs.size()), h->d_descs);
+        h->dirty.clear();
+    }
 
     // HIP events bracket each launch on the stream the kernel is launched on
     auto timed = [&](int kind, const vpr_launch_stat &ls, hipStream_t ks, auto &&launch) -> int {
@@ -444,57 +553,165 @@ int vpr_execute(vpr_handle *h) {
     HIPCHK(h, hipEventCreate(&t0));
     HIPCHK(h, hipEventCreate(&t1));
     HIPCHK(h, hipEventRecord(t0, st));
-    int64_t n_fwd = 0;
-    for (const Chunk &ch : h->chunks) {
-        // fork: the kernel classes of one chunk touch disjoint alignments and workspace regions, so each
-        // class runs its K1 -> K2 -> K3 pipeline on its own stream and the chunk joins before the
-        // workspace is reused
-        HIPCHK(h, hipEventRecord(h->ev_fork, st));
-        for (const Launch &L : ch.launches) {
-            const KernelClass &K = CLASSES[L.cls];
-            hipStream_t ks = h->cls_stream[L.cls];
-            HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
-            size_t lds_f = 0, lds_b = 0;
+    int64_t n_fwd = 0, cells_touched = 0, n_retry = 0;
+    int32_t *arena_i32 = reinterpret_cast<int32_t *>(h->d_arena);
+    PathEnt *arena_path = reinterpret_cast<PathEnt *>(h->d_arena);
+
+    auto walk_launch = [&](const int32_t *d_list, int32_t count, hipStream_t ks) -> int {
+        vpr_launch_stat ws_;
+        memset(&ws_, 0, sizeof(ws_));
+        ws_.threads = 64; ws_.n_units = count;
+        return timed(3, ws_, ks, [&] {
+            hipLaunchKernelGGL(k_walk, dim3((count + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, d_list, count,
+                               h->d_arena, arena_i32, h->d_outs, arena_path, h->d_secs, h->d_fp_table, h->d_jobs,
+                               h->d_njobs, h->jobs_cap);
+        });
+    };
+
+    // ---- dense plan: per chunk, each kernel class runs K1 -> K2 -> K3 on its own stream
+    auto run_dense = [&](const Plan &P, const int32_t *d_work) -> int {
+        for (const Chunk &ch : P.chunks) {
+            HIPCHK(h, hipEventRecord(h->ev_fork, st));
+            for (const Launch &L : ch.launches) {
+                const KernelClass &K = CLASSES[L.cls];
+                hipStream_t ks = h->cls_stream[L.cls];
+                HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
+                size_t lds_f = 0, lds_b = 0;
+                vpr_launch_stat ls;
+                memset(&ls, 0, sizeof(ls));
+                ls.threads = K.nt; ls.cells_per_thread = K.c; ls.n_units = L.count;
+                int64_t in_bytes = 0;
+                for (int32_t w = 0; w < L.count; w++) {   // the launch's dynamic LDS = its largest member
+                    const AlnDesc &d = P.descs[L.work_off + w];
+                    lds_f = std::max(lds_f, fwd_lds_bytes(L.cls, d.Lq, d.Lr));
+                    lds_b = std::max(lds_b, bwd_lds_bytes(L.cls, d.Lq, d.Lr));
+                    ls.cells += int64_t(d.Lq + d.Lr) * d.Lt;
+                    in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
+                }
+                cells_touched += ls.cells;
+                ls.bytes_algorithmic = ls.cells + in_bytes;
+                int rc = timed(1, ls, ks, [&] {
+                    hipLaunchKernelGGL(fwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_f, ks, h->dB, h->d_descs,
+                                       d_work + L.work_off, h->d_arena, h->d_outs);
+                    hipLaunchKernelGGL(k_fwd_finish, dim3((L.count + 255) / 256), dim3(256), 0, ks,
+                                       d_work + L.work_off, L.count, h->d_outs);
+                });
+                if (rc) return rc;
+                n_fwd++;
+                ls.bytes_algorithmic = ls.cells;
+                rc = timed(2, ls, ks, [&] {
+                    hipLaunchKernelGGL(bwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
+                                       d_work + L.work_off, h->d_arena, h->d_outs);
+                });
+                if (rc) return rc;
+                if ((rc = walk_launch(d_work + L.work_off, L.count, ks))) return rc;
+                HIPCHK(h, hipEventRecord(h->ev_join[L.cls], ks));
+                HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[L.cls], 0));
+            }
+        }
+        return VPR_OK;
+    };
+
+    // ---- banded plan: K1b, accept/reject on the device, K2b + K3 for the accepted, collect the rest
+    auto run_band = [&](const Plan &P, const int32_t *d_work, std::vector<int32_t> &fails) -> int {
+        const int C = P.band_c;
+        for (const Chunk &ch : P.chunks) {
             vpr_launch_stat ls;
             memset(&ls, 0, sizeof(ls));
-            ls.threads = K.nt; ls.cells_per_thread = K.c; ls.n_units = L.count;
-            int64_t in_bytes = 0;
-            for (int32_t w = 0; w < L.count; w++) {   // the launch's dynamic LDS = its largest member
-                const AlnDesc &d = h->descs[h->work[L.work_off + w]];
-                lds_f = std::max(lds_f, fwd_lds_bytes(L.cls, d.Lq, d.Lr));
-                lds_b = std::max(lds_b, bwd_lds_bytes(L.cls, d.Lq, d.Lr));
-                ls.cells += int64_t(d.Lq + d.Lr) * d.Lt;
-                // strings 1 B/base; pointer+flag arrays 5 B/element (q->r, r->q, t->r)
-                in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
-            }
-            ls.bytes_algorithmic = ls.cells + in_bytes;
-            int rc = timed(1, ls, ks, [&] {
-                hipLaunchKernelGGL(fwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_f, ks, h->dB, h->d_descs,
-                                   h->d_work + L.work_off, h->d_ws, h->d_outs);
-                hipLaunchKernelGGL(k_fwd_finish, dim3((L.count + 255) / 256), dim3(256), 0, ks,
-                                   h->d_work + L.work_off, L.count, h->d_outs);
+            ls.threads = 64; ls.cells_per_thread = C; ls.n_units = ch.count;
+            ls.cells = ch.cells;
+            ls.bytes_algorithmic = ch.cells + ch.in_bytes;
+            cells_touched += ch.cells;
+            HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
+            int rc = timed(1, ls, st, [&] {
+                hipLaunchKernelGGL(band_fwd_kernel(C), dim3(ch.count), dim3(64), 0, st, h->dB, h->d_descs,
+                                   d_work + ch.work_off, h->d_arena, arena_i32, h->d_outs);
+                hipLaunchKernelGGL(k_fwd_band_finish, dim3((ch.count + 255) / 256), dim3(256), 0, st,
+                                   d_work + ch.work_off, ch.count, h->d_outs);
+                hipLaunchKernelGGL(k_partition, dim3((ch.count + 255) / 256), dim3(256), 0, st, d_work + ch.work_off,
+                                   ch.count, h->d_outs, h->d_ok, h->d_fail, h->d_cnt);
             });
             if (rc) return rc;
             n_fwd++;
-            ls.bytes_algorithmic = ls.cells;
-            rc = timed(2, ls, ks, [&] {
-                hipLaunchKernelGGL(bwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
-                                   h->d_work + L.work_off, h->d_ws, h->d_outs);
-            });
+            int32_t cnt[2] = {0, 0};
+            HIPCHK(h, hipMemcpyAsync(cnt, h->d_cnt, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            if (cnt[1] > 0) {
+                const size_t o = fails.size();
+                fails.resize(o + cnt[1]);
+                HIPCHK(h, hipMemcpy(fails.data() + o, h->d_fail, size_t(cnt[1]) * 4, hipMemcpyDeviceToHost));
+            }
+            if (cnt[0] > 0) {
+                ls.n_units = cnt[0];
+                ls.bytes_algorithmic = ch.cells;
+                rc = timed(2, ls, st, [&] {
+                    hipLaunchKernelGGL(band_bwd_kernel(C), dim3(cnt[0]), dim3(64), 0, st, h->dB, h->d_descs, h->d_ok,
+                                       h->d_arena, arena_i32, h->d_outs);
+                });
+                if (rc) return rc;
+                if ((rc = walk_launch(h->d_ok, cnt[0], st))) return rc;
+            }
+        }
+        return VPR_OK;
+    };
+
+    // upload a retry plan's descriptors / work list
+    auto stage_plan = [&](const Plan &P, const int32_t **d_work) -> int {
+        const size_t n = P.work.size();
+        if (h->tmp_descs_cap < n) {
+            int rc = dev_alloc(h, &h->d_tmp_descs, n * 2);
             if (rc) return rc;
-            vpr_launch_stat ws_;
-            memset(&ws_, 0, sizeof(ws_));
-            ws_.threads = 64; ws_.n_units = L.count;
-            rc = timed(3, ws_, ks, [&] {
-                hipLaunchKernelGGL(k_walk, dim3((L.count + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
-                                   h->d_work + L.work_off, L.count, h->d_ws, h->d_outs, h->d_paths, h->d_secs,
-                                   h->d_fp_table, h->d_jobs, h->d_njobs, h->jobs_cap);
-            });
+            h->tmp_descs_cap = n * 2;
+        }
+        if (h->tmp_work_cap < n) {
+            int rc = dev_alloc(h, &h->d_tmp_work, n * 2);
             if (rc) return rc;
-            HIPCHK(h, hipEventRecord(h->ev_join[L.cls], ks));
-            HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[L.cls], 0));
+            h->tmp_work_cap = n * 2;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->d_tmp_descs, P.descs.data(), n * sizeof(AlnDesc), hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(h->d_tmp_work, P.work.data(), n * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(n)), dim3(256), 0, st, h->d_tmp_descs, int(n), h->d_descs);
+        HIPCHK(h, hipStreamSynchronize(st));   // the staging buffers are reused by the next round
+        h->dirty.insert(h->dirty.end(), P.work.begin(), P.work.end());
+        *d_work = h->d_tmp_work;
+        return VPR_OK;
+    };
+
+    int rc = VPR_OK;
+    h->last_chunk.clear();
+    if (h->cfg.band_mode == 0) {
+        if ((rc = run_dense(h->plan0, h->plan0.d_work))) return rc;
+        if (!h->plan0.chunks.empty()) {
+            const Chunk &c = h->plan0.chunks.back();
+            h->last_chunk.assign(h->plan0.work.begin() + c.work_off, h->plan0.work.begin() + c.work_off + c.count);
+        }
+    } else {
+        std::vector<int32_t> fails;
+        if ((rc = run_band(h->plan0, h->plan0.d_work, fails))) return rc;
+        if (!h->plan0.chunks.empty()) {
+            const Chunk &c = h->plan0.chunks.back();
+            h->last_chunk.assign(h->plan0.work.begin() + c.work_off, h->plan0.work.begin() + c.work_off + c.count);
+        }
+        for (int r = 1; r <= N_BAND && !fails.empty(); r++) {
+            n_retry += int64_t(fails.size());
+            Plan P;
+            // windows wider than the alignment are pointless: go straight to the dense kernels
+            std::vector<int32_t> next;
+            const bool dense = (r == N_BAND);
+            if ((rc = make_plan(h, fails, dense ? 0 : BAND_C[r], P))) return rc;
+            const int32_t *d_work = nullptr;
+            if ((rc = stage_plan(P, &d_work))) return rc;
+            if (dense) { if ((rc = run_dense(P, d_work))) return rc; }
+            else { if ((rc = run_band(P, d_work, next))) return rc; }
+            if (!P.chunks.empty()) {
+                const Chunk &c = P.chunks.back();
+                h->last_chunk.assign(P.work.begin() + c.work_off, P.work.begin() + c.work_off + c.count);
+            }
+            HIPCHK(h, hipStreamSynchronize(st));
+            fails.swap(next);
         }
     }
+
     // K4: deferred section edit distances
     int32_t n_jobs = 0;
     HIPCHK(h, hipMemcpyAsync(&n_jobs, h->d_njobs, 4, hipMemcpyDeviceToHost, st));
@@ -506,13 +723,11 @@ int vpr_execute(vpr_handle *h) {
         int64_t stride = 0;
         for (const EdJob &j : jobs) stride = std::max<int64_t>(stride, std::max(j.ref_len, j.tru_len) + 1);
         stride = round_up(stride, 16);
-        // run in slices so the scratch stays bounded
-        const int64_t max_ints = int64_t(1) << 28;   // 1 GiB
+        const int64_t max_ints = int64_t(1) << 28;   // 1 GiB of scratch per slice
         const int32_t per = int32_t(std::max<int64_t>(1, std::min<int64_t>(n_jobs, max_ints / stride)));
         if (h->ed_scratch_ints < size_t(per * stride)) {
             int32_t *p;
-            int rc = dev_alloc(h, &p, size_t(per * stride));
-            if (rc) return rc;
+            if ((rc = dev_alloc(h, &p, size_t(per * stride)))) return rc;
             h->d_ed_scratch = p;
             h->ed_scratch_ints = size_t(per * stride);
         }
@@ -521,7 +736,7 @@ int vpr_execute(vpr_handle *h) {
             vpr_launch_stat es_;
             memset(&es_, 0, sizeof(es_));
             es_.threads = 64; es_.n_units = cnt;
-            int rc = timed(4, es_, st, [&] {
+            rc = timed(4, es_, st, [&] {
                 hipLaunchKernelGGL(k_ed, dim3(cnt), dim3(64), 0, st, h->dB, h->d_descs, h->d_jobs + j0, cnt,
                                    h->d_secs, h->d_ed_scratch, stride);
             });
@@ -545,6 +760,8 @@ int vpr_execute(vpr_handle *h) {
         else h->timing.ms_ed += m;
     }
     h->timing.n_fwd_launches = n_fwd;
+    h->timing.cells_touched = cells_touched;
+    h->timing.n_band_retries = n_retry;
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
     h->executed = true;
@@ -672,17 +889,17 @@ int vpr_run(vpr_handle *h, const vpr_batch *batch, vpr_results *res) {
 int64_t vpr_download_path(const vpr_handle *h, int32_t sc, int32_t aln, int64_t cap,
                           uint8_t *plane, int32_t *qri, int32_t *ti, uint8_t *sync, uint8_t *edit) {
     if (!h || !h->executed || sc < 0 || sc >= h->n_sc || aln < 0 || aln > 3) return VPR_ERR_ARG;
-    // the path scratch is reused per workspace chunk: only alignments of the last chunk are still resident
-    const size_t a = size_t(sc) * 4 + aln;
-    const Chunk &last = h->chunks.back();
-    bool in_last = false;
-    for (int32_t w = 0; w < last.count; w++) in_last |= (h->work[last.work_off + w] == int32_t(a));
-    if (!in_last) return VPR_ERR_STATE;
+    // the walk scratch lives in the arena and is reused per chunk: only the last chunk is still resident
+    const int32_t a = sc * 4 + aln;
+    if (std::find(h->last_chunk.begin(), h->last_chunk.end(), a) == h->last_chunk.end()) return VPR_ERR_STATE;
     AlnOut O;
+    AlnDesc d;
     if (hipMemcpy(&O, h->d_outs + a, sizeof(O), hipMemcpyDeviceToHost) != hipSuccess) return VPR_ERR_DEVICE;
+    if (hipMemcpy(&d, h->d_descs + a, sizeof(d), hipMemcpyDeviceToHost) != hipSuccess) return VPR_ERR_DEVICE;
     const int64_t n = std::min<int64_t>(O.path_len, cap);
     std::vector<PathEnt> p(n);
-    if (n && hipMemcpy(p.data(), h->d_paths + h->descs[a].path_off, n * sizeof(PathEnt), hipMemcpyDeviceToHost) != hipSuccess)
+    if (n && hipMemcpy(p.data(), reinterpret_cast<const PathEnt *>(h->d_arena) + d.path_off, n * sizeof(PathEnt),
+                       hipMemcpyDeviceToHost) != hipSuccess)
         return VPR_ERR_DEVICE;
     for (int64_t k = 0; k < n; k++) {
         plane[k] = uint8_t(p[k].a >> 31);

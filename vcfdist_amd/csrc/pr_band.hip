@@ -1,0 +1,551 @@
+// pr_band.hip -- exact *banded* single-wave kernels of the precision/recall path.
+//
+// The reference's wave expansion touches only cells with distance <= s (0.24 % of the dense
+// matrix on its own demo).  These kernels sweep, per row of the truth string, only a
+// window of W = 64*C cells per plane centred on the reference coordinate of that truth base
+// (REF plane: t2r[t]; QUERY plane: r2q[t2r[t]]), one wavefront per alignment, no workgroup barrier,
+// distances and per-position constants in small LDS rings.
+//
+// Exactness does not rest on the window heuristic: while sweeping, every cell that has a graph edge
+// (MAT/SUB, INS, DEL or plane swap) leaving the window contributes its distance to `exit_min`.
+// Any cell outside the window whose true distance is <= s would have an optimal path whose last
+// in-window cell is such an exit cell with distance <= s, so
+//        exit_min > s   =>   the window contains every cell with true distance <= s,
+// hence s, the end plane and the flag byte of every cell with D <= s equal the dense result.  When
+// the test fails the host re-runs the alignment with a 4x wider window and finally with the dense
+// kernels (pr_kernels.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vcfdist_pr.h"
+#include "pr_device.h"
+
+// ---------------------------------------------------------------------------
+// K0b: packed per-position constants (needs the candidate lists of k_prep_cand)
+// ---------------------------------------------------------------------------
+__global__ void k_prep_pack(DevBatch B, int h, int dir, int64_t n_pos) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= n_pos) return;
+    // this plane (the positions being packed) and the other plane (swap targets)
+    const int64_t *off = dir == 0 ? B.hap_off[h] : B.ref_off;
+    const int64_t *ooff = dir == 0 ? B.ref_off : B.hap_off[h];
+    const int32_t *ptr = dir == 0 ? B.hap_ptr[h] : B.ref_ptr[h];
+    const uint8_t *flg = dir == 0 ? B.hap_flag[h] : B.ref_flag[h];
+    const uint8_t *oflg = dir == 0 ? B.ref_flag[h] : B.hap_flag[h];
+    const uint8_t *seq = dir == 0 ? B.hap_seq[h] : B.ref_seq;
+    const int4 *cand = dir == 0 ? B.cand_q[h] : B.cand_r[h];      // sources of swaps *into* this position
+    const int4 *ocand = dir == 0 ? B.cand_r[h] : B.cand_q[h];     // candidate lists of the other plane
+    int2 *fk = dir == 0 ? B.fk_q[h] : B.fk_r[h];
+    int32_t *bk = dir == 0 ? B.bk_q[h] : B.bk_r[h];
+
+    int lo = 0, hi = B.n_sc;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
+    const int sc = lo;
+    const int32_t x = int32_t(g - off[sc]);
+    const int64_t olen = ooff[sc + 1] - ooff[sc];
+    const int f = flg[g];
+    const int32_t p = ptr[g];
+    const bool fa = !(f & PV) || (f & PE);
+    const int4 cc = cand[g];
+    int2 k;
+    k.x = cc.x < 0 ? -1 : (cc.x | (cc.y >= 0 ? FK_MULTI : 0));
+    k.y = int32_t((fa ? uint32_t(p + 1) & 0xffffffu : 0xffffffu) | (uint32_t(seq[g]) << 24));
+    fk[g] = k;
+
+    // backward constants
+    uint32_t z = FK_NONE24, bits = 0;
+    auto tp_of = [&](const int32_t *qptr, const uint8_t *qflg, int64_t base, int32_t q) -> uint32_t {
+        return (q > 0 && ((qptr[base + q] != qptr[base + q - 1] + 1) || (qflg[base + q] & PB))) ? 1u : 0u;
+    };
+    if (dir == 0) bits |= tp_of(ptr, flg, off[sc], x);            // tp of this QUERY-plane cell
+    const int64_t zz = int64_t(p) + 1;
+    if (fa && zz >= 1 && zz < olen) {
+        const int zf = oflg[ooff[sc] + zz];
+        if (!(zf & PV) || (zf & PB)) {                            // bwd_allow(z), dist.cpp:600-601,638-639
+            const int4 oc = ocand[ooff[sc] + zz];
+            int rank = -1;
+            if (oc.x == x) rank = 0; else if (oc.y == x) rank = 1; else if (oc.z == x) rank = 2; else if (oc.w == x) rank = 3;
+            if (rank >= 0) {
+                z = uint32_t(zz);
+                bits |= uint32_t(rank) << 1;
+                if (dir == 1) bits |= tp_of(B.hap_ptr[h], B.hap_flag[h], ooff[sc], int32_t(zz)) << 3;  // tp(z), z on QUERY
+            }
+        }
+    }
+    bk[g] = int32_t(z | (bits << 24));
+}
+
+// ---------------------------------------------------------------------------
+// DPP wave scans (gfx9 row_shr / row_bcast / wave_shr): ~12 VALU ops instead of six ds_bpermute hops
+// ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+// two independent inclusive prefix-min scans, interleaved
+__device__ __forceinline__ void wave_prefix_min2(int &a, int &b) {
+    a = min(a, dpp_mov<0x111, 0xf>(D_INF, a)); b = min(b, dpp_mov<0x111, 0xf>(D_INF, b));   // row_shr:1
+    a = min(a, dpp_mov<0x112, 0xf>(D_INF, a)); b = min(b, dpp_mov<0x112, 0xf>(D_INF, b));   // row_shr:2
+    a = min(a, dpp_mov<0x114, 0xf>(D_INF, a)); b = min(b, dpp_mov<0x114, 0xf>(D_INF, b));   // row_shr:4
+    a = min(a, dpp_mov<0x118, 0xf>(D_INF, a)); b = min(b, dpp_mov<0x118, 0xf>(D_INF, b));   // row_shr:8
+    a = min(a, dpp_mov<0x142, 0xa>(D_INF, a)); b = min(b, dpp_mov<0x142, 0xa>(D_INF, b));   // row_bcast:15
+    a = min(a, dpp_mov<0x143, 0xc>(D_INF, a)); b = min(b, dpp_mov<0x143, 0xc>(D_INF, b));   // row_bcast:31
+}
+__device__ __forceinline__ int wave_shr1(int x, int fill) { return dpp_mov<0x138, 0xf>(fill, x); }   // lane i <- lane i-1
+
+// band origin of row t: REF plane centred on t2r[t], QUERY plane on r2q[t2r[t]]
+template <int W>
+__device__ __forceinline__ void band_origin(const int32_t *t2r, const int32_t *r2q, int t, int Lt, int Lq, int Lr,
+                                            int &loQ, int &loR) {
+    loQ = 0; loR = 0;
+    if (t < Lt) {
+        const int tr = t2r[t];
+        loR = max(0, min(tr - W / 2, Lr - min(W, Lr)));
+        const int cq = r2q[min(max(tr, 0), Lr - 1)];
+        loQ = max(0, min(cq - W / 2, Lq - min(W, Lq)));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1b: banded forward sweep, one wavefront per alignment.
+// BANDMAT: flag rows stored band-relative ([t][x - lo(t)], pitch = band width); otherwise dense [t][x].
+// ---------------------------------------------------------------------------
+template <int C, bool BANDMAT>
+__global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__restrict__ descs,
+                                                 const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
+                                                 int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
+    constexpr int W = 64 * C, RS = 2 * W, M = RS - 1;
+    __shared__ int32_t Dr[2][2][RS];   // [row parity][plane][x & M]
+    __shared__ int2 Kr[2][RS];         // [plane][x & M] packed constants
+    const int a = work[blockIdx.x];
+    const AlnDesc d = descs[a];
+    const int lane = threadIdx.x;
+    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
+    const int Lp[2] = {Lq, Lr};
+    const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off;
+    const uint8_t *Tf = B.hap_flag[d.ts] + d.t_off;
+    const int32_t *t2r = B.hap_ptr[d.ts] + d.t_off;
+    const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
+    const int2 *fk[2] = {B.fk_q[d.qs] + d.q_off, B.fk_r[d.qs] + d.r_off};
+    const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
+    uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
+    int32_t *blo = blo_all + d.blo_off;
+
+    // band origins of rows [t0, t0+64) in lane (t - t0); next chunk kept one chunk ahead
+    int cbQ, cbR, nbQ, nbR;
+    band_origin<W>(t2r, r2q, lane, Lt, Lq, Lr, cbQ, cbR);
+    band_origin<W>(t2r, r2q, 64 + lane, Lt, Lq, Lr, nbQ, nbR);
+    if (lane < Lt) { blo[lane] = cbQ; blo[Lt + lane] = cbR; }
+    if (64 + lane < Lt) { blo[64 + lane] = nbQ; blo[Lt + 64 + lane] = nbR; }
+    uint32_t tchunk = 0, tlast = 0;
+    if (lane < Lt) tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
+
+    // constants ring: positions [0, khi] of each plane are resident
+    int khi[2] = {-1, -1};
+    auto fill = [&](int p, int upto) {
+        while (khi[p] < upto) {
+            const int x = khi[p] + 1 + lane;
+            if (x < Lp[p]) Kr[p][x & M] = fk[p][x];
+            khi[p] += 64;
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < 2; p++) fill(p, min(Lp[p], W) - 1);
+
+    int lo[2] = {0, 0}, hi[2] = {min(Lq, W) - 1, min(Lr, W) - 1};
+    int exit_min = D_INF;
+    int endD[2] = {D_INF, D_INF};
+    const int off0 = lane * C;
+
+    // ---- row 0: D = x along the INS chain from the origin (dist.cpp:300-305, 397-405)
+    {
+        int nlo[2] = {0, 0}, nhi[2] = {0, 0};
+        if (Lt > 1) {
+            nlo[0] = __builtin_amdgcn_readlane(cbQ, 1); nlo[1] = __builtin_amdgcn_readlane(cbR, 1);
+            nhi[0] = min(Lq - 1, nlo[0] + W - 1); nhi[1] = min(Lr - 1, nlo[1] + W - 1);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            uint8_t fl[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int x = off0 + c;
+                fl[c] = (x == 0) ? F_MAT : F_INS;
+                if (x <= hi[p]) {
+                    Dr[0][p][x & M] = x;
+                    bool ex = (x == hi[p] && hi[p] < Lp[p] - 1);
+                    if (Lt > 1) {
+                        ex = ex || x < nlo[p] || (x + 1 <= Lp[p] - 1 && x + 1 > nhi[p]);
+                        const uint32_t swt = uint32_t(Kr[p][x & M].y) & 0xffffffu;
+                        if (swt != FK_NONE24 && int(swt) < Lp[1 - p] && (int(swt) < nlo[1 - p] || int(swt) > nhi[1 - p])) ex = true;
+                    }
+                    if (ex) exit_min = min(exit_min, x);
+                    if (Lt == 1 && x == Lp[p] - 1) endD[p] = x;
+                }
+            }
+            if (off0 <= hi[p]) {
+                typename FlagVec<C>::T v;
+                __builtin_memcpy(&v, fl, C);
+                *reinterpret_cast<typename FlagVec<C>::T *>(mat[p] + off0) = v;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+
+    for (int t = 1; t < Lt; t++) {
+        int plo[2] = {lo[0], lo[1]}, phi[2] = {hi[0], hi[1]};
+        if ((t & 63) == 0) {   // advance the truth / band chunks
+            tlast = __builtin_amdgcn_readlane(tchunk, 63);
+            const int tt = t + lane;
+            tchunk = 0;
+            if (tt < Lt) tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
+            cbQ = nbQ; cbR = nbR;
+            band_origin<W>(t2r, r2q, t + 64 + lane, Lt, Lq, Lr, nbQ, nbR);
+            if (t + 64 + lane < Lt) { blo[t + 64 + lane] = nbQ; blo[Lt + t + 64 + lane] = nbR; }
+        }
+        const uint32_t cur = __builtin_amdgcn_readlane(tchunk, t & 63);
+        const uint32_t prv = ((t & 63) == 0) ? tlast : uint32_t(__builtin_amdgcn_readlane(tchunk, (t - 1) & 63));
+        const uint32_t Tt = cur & 0xff;
+        const bool at = fwd_allow(int((prv >> 8) & 0xff));
+        lo[0] = __builtin_amdgcn_readlane(cbQ, t & 63);
+        lo[1] = __builtin_amdgcn_readlane(cbR, t & 63);
+        hi[0] = min(Lq - 1, lo[0] + W - 1);
+        hi[1] = min(Lr - 1, lo[1] + W - 1);
+        int nlo[2] = {0, 0}, nhi[2] = {0, 0};
+        const bool has_next = t + 1 < Lt;
+        if (has_next) {
+            if (((t + 1) & 63) == 0) { nlo[0] = __builtin_amdgcn_readlane(nbQ, 0); nlo[1] = __builtin_amdgcn_readlane(nbR, 0); }
+            else { nlo[0] = __builtin_amdgcn_readlane(cbQ, (t + 1) & 63); nlo[1] = __builtin_amdgcn_readlane(cbR, (t + 1) & 63); }
+            nhi[0] = min(Lq - 1, nlo[0] + W - 1);
+            nhi[1] = min(Lr - 1, nlo[1] + W - 1);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            if (khi[p] < hi[p]) fill(p, hi[p]);
+        asm volatile("" ::: "memory");
+
+        const int pb = (t - 1) & 1, cb = t & 1;
+        int bv[2][C];
+        uint8_t mk[2][C];
+        int cmin[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int o = 1 - p;
+            const int x0 = lo[p] + off0;
+            int diag = (x0 - 1 >= plo[p] && x0 - 1 <= phi[p]) ? Dr[pb][p][(x0 - 1) & M] : D_INF;
+            int run = D_INF;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int x = x0 + c;
+                const bool valid = x <= hi[p];
+                const int2 k = Kr[p][x & M];
+                const int up = (x >= plo[p] && x <= phi[p]) ? Dr[pb][p][x & M] : D_INF;
+                const bool match = valid && (uint32_t(k.y) >> 24) == Tt;
+                const int cm = match ? diag : diag + 1;
+                int b = min(cm, up + 1);
+                int sw = D_INF, choice = 0;
+                bool tie = false;
+                if (match && at && k.x >= 0) {
+                    const int s0 = k.x & ~FK_MULTI;
+                    sw = (s0 >= plo[o] && s0 <= phi[o]) ? Dr[pb][o][s0 & M] : D_INF;
+                    if (k.x & FK_MULTI) {
+                        const int4 cc = cand[p][x];
+                        const int v1 = (cc.y >= plo[o] && cc.y <= phi[o]) ? Dr[pb][o][cc.y & M] : D_INF;
+                        if (v1 <= sw) { tie = (v1 == sw); sw = v1; choice = 1; }
+                        if (cc.z >= 0) {
+                            const int v2 = (cc.z >= plo[o] && cc.z <= phi[o]) ? Dr[pb][o][cc.z & M] : D_INF;
+                            if (v2 <= sw) { tie = (v2 == sw); sw = v2; choice = 2; }
+                            if (cc.w >= 0) {
+                                const int v3 = (cc.w >= plo[o] && cc.w <= phi[o]) ? Dr[pb][o][cc.w & M] : D_INF;
+                                if (v3 <= sw) { tie = (v3 == sw); sw = v3; choice = 3; }
+                            }
+                        }
+                    }
+                    b = min(b, sw);
+                }
+                uint8_t m = 0;
+                if (match && diag == b) m |= F_MAT;
+                if (diag + 1 == b) m |= F_SUB;
+                if (up + 1 == b) m |= F_DEL;
+                if (sw == b && sw < D_INF) m |= F_SWP | (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
+                mk[p][c] = m;
+                const int v = valid ? b - x : D_INF;
+                bv[p][c] = v;
+                run = min(run, v);
+                diag = up;
+            }
+            cmin[p] = run;
+        }
+        int iq = cmin[0], ir = cmin[1];
+        wave_prefix_min2(iq, ir);
+        const int carry[2] = {wave_shr1(iq, D_INF), wave_shr1(ir, D_INF)};
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int o = 1 - p;
+            const int x0 = lo[p] + off0;
+            uint8_t fl[C];
+            int run = carry[p];
+            int left = carry[p] + x0 - 1;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int x = x0 + c;
+                const int nb = bv[p][c];
+                uint8_t f = 0;
+                if (nb <= run) { run = nb; f = mk[p][c]; }
+                const int Dn = run + x;
+                if (left + 1 == Dn && x > 0) f |= F_INS;
+                fl[c] = f;
+                left = Dn;
+                if (x <= hi[p]) {
+                    Dr[cb][p][x & M] = Dn;
+                    bool ex = (x == hi[p] && hi[p] < Lp[p] - 1);
+                    if (has_next) {
+                        ex = ex || x < nlo[p] || (x + 1 <= Lp[p] - 1 && x + 1 > nhi[p]);
+                        const uint32_t swt = uint32_t(Kr[p][x & M].y) & 0xffffffu;
+                        if (swt != FK_NONE24 && int(swt) < Lp[o] && (int(swt) < nlo[o] || int(swt) > nhi[o])) ex = true;
+                    }
+                    if (ex) exit_min = min(exit_min, Dn);
+                    if (t == Lt - 1 && x == Lp[p] - 1) endD[p] = Dn;
+                }
+            }
+            if (x0 <= hi[p]) {
+                typename FlagVec<C>::T v;
+                __builtin_memcpy(&v, fl, C);
+                uint8_t *dst = BANDMAT ? mat[p] + size_t(t) * d.pitch[p] + off0 : mat[p] + size_t(t) * d.pitch[p] + x0;
+                if (BANDMAT || C == 1) {
+                    *reinterpret_cast<typename FlagVec<C>::T *>(dst) = v;
+                } else {   // dense layout: x0 is not C-aligned in general
+#pragma unroll
+                    for (int c = 0; c < C; c++) if (x0 + c <= hi[p]) dst[c] = fl[c];
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    // reductions: exit_min (min over lanes), end distances (one lane holds each)
+    int e0 = endD[0], e1 = endD[1];
+    wave_prefix_min2(e0, e1);
+    int em = exit_min, dummy = D_INF;
+    wave_prefix_min2(em, dummy);
+    if (lane == 63) {
+        outs[a].dist_q = e0;
+        outs[a].dist_r = e1;
+        outs[a].exit_min = em;
+    }
+}
+
+// s, end plane (prefer QUERY, dist.cpp:436-439) and the band acceptance test
+__global__ void k_fwd_band_finish(const int32_t *__restrict__ work, int n, AlnOut *__restrict__ outs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    AlnOut &o = outs[work[i]];
+    o.s = min(o.dist_q, o.dist_r);
+    o.end_plane = (o.dist_q <= o.dist_r) ? VPR_PLANE_QUERY : VPR_PLANE_REF;
+    o.band_ok = (o.s < D_INF / 2 && o.exit_min > o.s) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// K2b: banded backward max-TP sweep, one wavefront per alignment, band-relative flag rows.
+// Lanes are mirrored (lane 0 owns the highest cells of the window) so that the suffix composition of
+// the max-plus maps carrying the in-row INS chain is a *prefix* scan in lane order and can use the same
+// DPP pattern as the forward kernel.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_prefix_mp2(MP &a, MP &b) {
+#define MP_STEP(CTRL, RM)                                                                          \
+    {                                                                                              \
+        MP ta, tb;                                                                                 \
+        ta.A = dpp_mov<CTRL, RM>(S_NEG, a.A); ta.B = dpp_mov<CTRL, RM>(0, a.B);                    \
+        tb.A = dpp_mov<CTRL, RM>(S_NEG, b.A); tb.B = dpp_mov<CTRL, RM>(0, b.B);                    \
+        a = mp_compose(a, ta); b = mp_compose(b, tb);                                              \
+    }
+    MP_STEP(0x111, 0xf) MP_STEP(0x112, 0xf) MP_STEP(0x114, 0xf) MP_STEP(0x118, 0xf)
+    MP_STEP(0x142, 0xa) MP_STEP(0x143, 0xc)
+#undef MP_STEP
+}
+
+template <int C>
+__global__ void __launch_bounds__(64) k_bwd_band(DevBatch B, const AlnDesc *__restrict__ descs,
+                                                 const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
+                                                 const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
+    constexpr int W = 64 * C, RS = 2 * W, M = RS - 1;
+    __shared__ int32_t Sr[2][2][RS];   // scores      [row parity][plane][x & M]
+    __shared__ uint8_t Fr[2][2][RS];   // fwd flags   [row parity][plane][x & M]
+    __shared__ int32_t Br[2][RS];      // bk constants [plane][x & M]
+    const int a = work[blockIdx.x];
+    const AlnDesc d = descs[a];
+    const int lane = threadIdx.x;
+    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
+    const int Lp[2] = {Lq, Lr};
+    const int32_t *bk[2] = {B.bk_q[d.qs] + d.q_off, B.bk_r[d.qs] + d.r_off};
+    uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
+    const int32_t *blo = blo_all + d.blo_off;
+    const int end_plane = outs[a].end_plane;
+    const int off0 = (63 - lane) * C;
+
+    // band origins by 64-row chunk: cb = chunk of row t, hb = the chunk above it, lb = prefetched chunk below
+    auto load_chunk = [&](int t0, int &bq, int &br) {
+        bq = 0; br = 0;
+        const int tt = t0 + lane;
+        if (t0 >= 0 && tt < Lt) { bq = blo[tt]; br = blo[Lt + tt]; }
+    };
+    int cbQ, cbR, hbQ = 0, hbR = 0, lbQ, lbR;
+    const int tc0 = (Lt - 1) & ~63;
+    load_chunk(tc0, cbQ, cbR);
+    load_chunk(tc0 - 64, lbQ, lbR);
+
+    // constants ring: positions [klo, klo + RS) resident (filled downwards)
+    int klo[2] = {(Lq + 63) & ~63, (Lr + 63) & ~63};
+    auto fill = [&](int p, int downto) {
+        while (klo[p] > downto) {
+            const int x = klo[p] - 64 + lane;
+            if (x >= 0 && x < Lp[p]) Br[p][x & M] = bk[p][x];
+            klo[p] -= 64;
+        }
+    };
+
+    int lo[2], hi[2], nlo[2] = {0, 0}, nhi[2] = {-1, -1};
+    lo[0] = __builtin_amdgcn_readlane(cbQ, (Lt - 1) & 63);
+    lo[1] = __builtin_amdgcn_readlane(cbR, (Lt - 1) & 63);
+    FlagReg<C> pf[2];   // forward flags of the row below the current one, in flight
+    uint8_t f0[2][C];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        hi[p] = min(Lp[p] - 1, lo[p] + W - 1);
+        fill(p, lo[p]);
+#pragma unroll
+        for (int c = 0; c < C; c++) f0[p][c] = 0;
+        if (lo[p] + off0 <= hi[p]) {
+            FlagReg<C> r = load_flags<C>(mat[p] + size_t(Lt - 1) * d.pitch[p] + off0);
+            unpack_flags<C>(r, f0[p]);
+        }
+        if (Lt >= 2 && off0 < d.pitch[p]) pf[p] = load_flags<C>(mat[p] + size_t(Lt - 2) * d.pitch[p] + off0);
+    }
+    uint32_t tie_used = 0;
+    int beg_score = S_NEG;
+
+    for (int t = Lt - 1; t >= 0; t--) {
+        const int cb = t & 1, nb = cb ^ 1;
+        // stage row t's forward flags
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int x = lo[p] + off0 + c;
+                if (x <= hi[p]) Fr[cb][p][x & M] = f0[p][c];
+            }
+        asm volatile("" ::: "memory");
+
+        int32_t base[2][C];
+        uint8_t bm[2][C];
+        int8_t lk[2][C];
+        MP g[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int o = 1 - p;
+            const int xtop = lo[p] + off0 + C;   // cell right of this chunk
+            // (x+1, t+1) values for the top cell; afterwards they are handed down the chunk
+            int up_s = S_NEG, up_f = 0;
+            if (xtop >= nlo[p] && xtop <= nhi[p]) { up_s = Sr[nb][p][xtop & M]; up_f = Fr[nb][p][xtop & M]; }
+            int up_tp = (p == 0 && xtop < Lq) ? ((Br[0][xtop & M] >> 24) & 1) : 0;
+            int up_f0 = (xtop <= hi[p]) ? Fr[cb][p][xtop & M] : 0;
+            MP G; G.A = S_NEG; G.B = 0;
+            bool first = true;
+#pragma unroll
+            for (int c = C - 1; c >= 0; c--) {
+                const int x = lo[p] + off0 + c;
+                const bool valid = x <= hi[p];
+                const int bkx = Br[p][x & M];
+                int dn_s = S_NEG, dn_f = 0;
+                if (x >= nlo[p] && x <= nhi[p]) { dn_s = Sr[nb][p][x & M]; dn_f = Fr[nb][p][x & M]; }
+                int best = S_NEG; uint8_t m = 0;
+                if (up_f & (F_MAT | F_SUB)) { best = up_s + up_tp; m = up_f & (F_MAT | F_SUB); }
+                if (dn_f & F_DEL) {
+                    if (dn_s > best) { best = dn_s; m = F_DEL; } else if (dn_s == best) m |= F_DEL;
+                }
+                const int z = bkx & 0xffffff;
+                if (z != FK_NONE24 && z >= nlo[o] && z <= nhi[o]) {
+                    const int zf = Fr[nb][o][z & M];
+                    if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((bkx >> 25) & 3)) {
+                        const int v = Sr[nb][o][z & M] + ((bkx >> 27) & 1);
+                        if (v >= 0 && (zf & F_TIE)) tie_used = 1;
+                        if (v > best) { best = v; m = F_SWP; } else if (v == best) m |= F_SWP;
+                    }
+                }
+                if (t == Lt - 1 && p == end_plane && x == Lp[p] - 1) { best = 0; m = F_MAT; }   // dist.cpp:538-546
+                if (!valid) { best = S_NEG; m = 0; }
+                base[p][c] = best;
+                bm[p][c] = m;
+                const int l = (up_f0 & F_INS) ? up_tp : -1;
+                lk[p][c] = l;
+                MP F; F.A = best; F.B = l;
+                if (first) { G = F; first = false; } else G = mp_compose(F, G);
+                // hand this cell's values down as the (x+1) values of the next cell
+                up_s = dn_s; up_f = dn_f;
+                up_tp = (bkx >> 24) & 1;
+                up_f0 = f0[p][c];
+            }
+            g[p] = G;
+        }
+        MP hq = g[0], hr = g[1];
+        wave_prefix_mp2(hq, hr);
+        const int inc[2] = {wave_shr1(hq.A, S_NEG), wave_shr1(hr.A, S_NEG)};
+        uint8_t out[2][C];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            int prev = inc[p];
+#pragma unroll
+            for (int c = C - 1; c >= 0; c--) {
+                const int x = lo[p] + off0 + c;
+                int v = base[p][c];
+                uint8_t m = bm[p][c];
+                if (lk[p][c] >= 0) {
+                    const int w = prev + lk[p][c];
+                    if (w > v) { v = w; m = F_INS; } else if (w == v) m |= F_INS;
+                }
+                if (v < 0) { v = S_NEG; m = 0; }
+                out[p][c] = m;
+                prev = v;
+                if (x <= hi[p]) Sr[cb][p][x & M] = v;
+                if (t == 0 && p == 0 && x == 0) beg_score = v;
+            }
+        }
+        // next row's band, constants, and the flag-row pipeline (loads before stores, see k_bwd)
+        nlo[0] = lo[0]; nlo[1] = lo[1]; nhi[0] = hi[0]; nhi[1] = hi[1];
+        if (t > 0) {
+            if ((t & 63) == 0) {   // row t-1 lives in the chunk below
+                hbQ = cbQ; hbR = cbR; cbQ = lbQ; cbR = lbR;
+                load_chunk(((t - 1) & ~63) - 64, lbQ, lbR);
+            }
+            lo[0] = __builtin_amdgcn_readlane(cbQ, (t - 1) & 63);
+            lo[1] = __builtin_amdgcn_readlane(cbR, (t - 1) & 63);
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                hi[p] = min(Lp[p] - 1, lo[p] + W - 1);
+                if (klo[p] > lo[p]) fill(p, lo[p]);
+                unpack_flags<C>(pf[p], f0[p]);
+                if (!(lo[p] + off0 <= hi[p])) {
+#pragma unroll
+                    for (int c = 0; c < C; c++) f0[p][c] = 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            if (t > 1 && off0 < d.pitch[p]) pf[p] = load_flags<C>(mat[p] + size_t(t - 2) * d.pitch[p] + off0);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            if (off0 < d.pitch[p]) {
+                typename FlagVec<C>::T v;
+                __builtin_memcpy(&v, out[p], C);
+                *reinterpret_cast<typename FlagVec<C>::T *>(mat[p] + size_t(t) * d.pitch[p] + off0) = v;
+            }
+        asm volatile("" ::: "memory");
+    }
+    (void)hbQ; (void)hbR;
+    // (QUERY, 0, 0) is owned by the lane holding window offset 0 of row 0
+    int bs = beg_score, dummy = S_NEG;
+    bs = -bs; dummy = D_INF;   // reuse the min scan: max(score) = -min(-score)
+    wave_prefix_min2(bs, dummy);
+    if (lane == 63) outs[a].beg_plane = (-bs >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
+    if (tie_used) atomicOr(&outs[a].status, VPR_ST_SWAP_TIE);
+}

@@ -38,7 +38,18 @@ struct DevBatch {
     int4 *cand_q[2];      // [hap positions of query hap h] allowed swap sources in the REF plane (ascending, -1 pad)
     int4 *cand_r[2];      // [ref positions]               allowed swap sources in QUERY hap h
     uint8_t *has_ins[4];  // [ref positions] an insertion of hap slot s sits at this ref index (dist.cpp:886-894)
+    // packed per-position constants for the banded kernels (k_prep_pack):
+    //   fk_*: .x = first swap source (cand.x) | FK_MULTI if there are more, -1 if none
+    //         .y = swap target of this position as a *source* (ptr+1 if fwd_allow, else 0xffffff) | base << 24
+    //   bk_*: swap target z (24 bits, 0xffffff none; includes fwd_allow(src), bwd_allow(z), membership in z's
+    //         candidate list) | tp(this cell, QUERY plane only) << 24 | rank in z's list << 25 | tp(z) << 27
+    int2 *fk_q[2];        // [hap positions of query hap h]
+    int2 *fk_r[2];        // [ref positions]
+    int32_t *bk_q[2];
+    int32_t *bk_r[2];
 };
+#define FK_MULTI (1 << 30)
+#define FK_NONE24 0xffffff
 
 // one (supercluster, alignment) work unit
 struct AlnDesc {
@@ -52,6 +63,9 @@ struct AlnDesc {
     int64_t sec_off;               // entry offset into the section table
     int32_t sec_cap;
     int32_t path_cap;
+    int32_t band_w;                // 0: dense [Lt][pitch] matrices; >0: banded, row t holds cells [blo[t], blo[t]+band_w)
+    int32_t band_pad;
+    int64_t blo_off;               // int offset of this alignment's band origins: blo[plane*Lt + t]
     int64_t qv_beg, qv_end, tv_beg, tv_end;   // variant index ranges (batch-global, per hap slot)
 };
 
@@ -64,6 +78,8 @@ struct AlnOut {
     uint32_t status;          // VPR_ST_*
     int32_t path_len;
     int32_t n_sec;
+    int32_t exit_min;         // banded forward sweep: min D over cells with an edge leaving the band
+    int32_t band_ok;          // exit_min > s  =>  the band provably contains every cell with D <= s
 };
 
 // one sync section that contains variants, dist.cpp:1190-1373 (32 bytes)

@@ -612,7 +612,8 @@ __device__ int small_ed(const uint8_t *a, int m, const uint8_t *b, int n) {
 }
 
 __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ work, int n_work,
-                       const uint8_t *__restrict__ ws, AlnOut *__restrict__ outs,
+                       const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
+                       AlnOut *__restrict__ outs,
                        PathEnt *__restrict__ paths, Section *__restrict__ secs,
                        int32_t *const *__restrict__ fp_group /* [2 query haps * 2 swaps] */,
                        EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap) {
@@ -631,6 +632,8 @@ __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int3
     const uint8_t *insT = B.has_ins[d.ts] + d.r_off;
     const uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     const int q_size = d.Lq, r_size = d.Lr, t_size = d.Lt;
+    const bool banded = d.band_w > 0;   // rows hold cells [blo[t], blo[t]+band_w) of each plane
+    const int32_t *blo = blo_all + d.blo_off;
     PathEnt *path = paths + d.path_off;
     uint32_t status = 0;
 
@@ -640,7 +643,9 @@ __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int3
     path[n++] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31), uint32_t(ti) | (1u << 31)};   // sync, no edit
     bool ok = true;
     while ((hi == ri && qri < r_size - 1) || (hi == qi && qri < q_size - 1) || ti < t_size - 1) {
-        const int p = mat[hi][size_t(ti) * d.pitch[hi] + qri] & 31;
+        const int col = banded ? qri - blo[hi * t_size + ti] : qri;
+        if (banded && (col < 0 || col >= d.band_w)) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+        const int p = mat[hi][size_t(ti) * d.pitch[hi] + col] & 31;
         int mv; uint32_t edit = 0;
         if (hi == ri && (p & F_SWP)) { mv = F_SWP; hi = qi; qri = r2q[qri]; qri++; ti++; }
         else if (p & F_MAT) { mv = F_MAT; qri++; ti++; }
