@@ -40,7 +40,7 @@ def make_workload(api, n_sc, seed, workload):
     raise SystemExit(f"unknown workload {workload}")
 
 
-def tally(res, batch_types=None):
+def tally_numpy(res):
     """TP/FP/FN counts of the phasing each supercluster's alignment distances select
     (sc_phase SWAP -> swap slot 1, otherwise slot 0); int64[2 callsets][3 errtypes]."""
     out = np.zeros((2, 3), np.int64)
@@ -121,10 +121,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     def step():
-        pr.execute()
-        res = pr.download()
-        res._sc_of_var = sc_of_var
-        t = torch.from_numpy(tally(res)).to(dev)
+        pr.execute()                    # K1..K5 on the device
+        res = pr.download()             # final per-variant / per-supercluster results to host memory
+        t = torch.from_numpy(pr.tally()).to(dev)
         if dist is not None:
             dist.all_reduce(t)          # the one collective of the path: TP/FP/FN tallies (int64 sum)
         return res, t
@@ -150,6 +149,9 @@ def main():
             a[0] += 1; a[1] += s.ms; a[2] += s.bytes_algorithmic; a[3] += s.cells
     sync()
     elapsed = time.perf_counter() - t0
+    if rank == 0:       # the device tally must equal the one recomputed from the downloaded results
+        res._sc_of_var = sc_of_var
+        assert np.array_equal(tally_numpy(res), pr.tally()), "device tally != host tally"
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -159,7 +161,7 @@ def main():
     value = total_aln / elapsed
     if rank == 0:
         tm = pr.timing()
-        names = {1: "k_fwd", 2: "k_bwd", 3: "k_walk", 4: "k_ed"}
+        names = {1: "k_fwd", 2: "k_bwd", 3: "k_walk", 4: "k_ed", 5: "k_finalize"}
         dom = max(stats_acc.items(), key=lambda kv: kv[1][1])
         (kind, nt, c), (nl, ms, byt, cells) = dom
         # dominant kernel: algorithmic bytes per launch / average launch duration (HIP events on the library stream)

@@ -51,6 +51,7 @@ def lib():
     L.vpr_download.argtypes = [H, C.POINTER(A.VprResults)]
     L.vpr_get_timing.argtypes = [H, C.POINTER(A.VprTiming)]
     L.vpr_get_launch_stats.argtypes = [H, C.POINTER(A.VprLaunchStat), C.c_int32]
+    L.vpr_get_tally.argtypes = [H, C.POINTER(C.c_int64)]
     L.vpr_download_path.restype = C.c_int64
     L.vpr_download_path.argtypes = [H, C.c_int32, C.c_int32, C.c_int64, A.P_u8, A.P_i32, A.P_i32, A.P_u8, A.P_u8]
     L.vpr_store_phase.restype = C.c_int32
@@ -70,7 +71,7 @@ def lib():
 
 EXPORTED = [
     "vpr_create", "vpr_destroy", "vpr_last_error", "vpr_version", "vpr_run", "vpr_upload",
-    "vpr_upload_variants", "vpr_execute", "vpr_download", "vpr_get_timing", "vpr_get_launch_stats",
+    "vpr_upload_variants", "vpr_execute", "vpr_download", "vpr_get_timing", "vpr_get_launch_stats", "vpr_get_tally",
     "vpr_download_path",
     "vpr_store_phase", "vpr_batch_from_variants", "vpr_owned_batch_view", "vpr_owned_batch_free",
     "vpr_synth_default_params", "vpr_synth_create", "vpr_synth_variants", "vpr_synth_destroy",
@@ -206,6 +207,12 @@ class PrecisionRecall:
         t = A.VprTiming()
         self._chk(lib().vpr_get_timing(self._h, C.byref(t)), "vpr_get_timing")
         return t
+
+    def tally(self):
+        """int64[2 callsets][TP,FP,FN] accumulated on the device by the last execute."""
+        out = (C.c_int64 * 6)()
+        self._chk(lib().vpr_get_tally(self._h, out), "vpr_get_tally")
+        return np.array(list(out), dtype=np.int64).reshape(2, 3)
 
     def launch_stats(self):
         L = lib()

@@ -88,6 +88,7 @@ struct vpr_handle {
     int32_t last_path_a0 = -1;           // alignments of the last chunk (their walks are still in the arena)
     std::vector<int32_t> last_chunk;
     std::vector<EvPair> events;
+    DevResults dR;                       // final results, produced on the device
     vpr_timing timing;
     bool uploaded = false, executed = false;
 };
@@ -460,6 +461,34 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     h->jobs_cap = int32_t(std::min<int64_t>(jobs_total + 1, 0x7fffffff));
     if ((rc = dev_alloc(h, &h->d_jobs, size_t(h->jobs_cap)))) return rc;
     if ((rc = dev_alloc(h, &h->d_njobs, 1))) return rc;
+    // device-side result columns
+    DevResults &R = h->dR;
+    memset(&R, 0, sizeof(R));
+    for (int s = 0; s < 4; s++) {
+        const float *vq = nullptr;
+        if ((rc = dev_upload(h, &vq, b->var_qual[s], size_t(h->n_var[s])))) return rc;
+        R.var_qual[s] = vq;
+        for (int w = 0; w < 2; w++) {
+            const size_t nv = size_t(h->n_var[s]);
+            if ((rc = dev_alloc(h, &R.v[s][w].errtype, nv))) return rc;
+            if ((rc = dev_alloc(h, &R.v[s][w].sync_group, nv))) return rc;
+            if ((rc = dev_alloc(h, &R.v[s][w].credit, nv))) return rc;
+            if ((rc = dev_alloc(h, &R.v[s][w].ref_ed, nv))) return rc;
+            if ((rc = dev_alloc(h, &R.v[s][w].query_ed, nv))) return rc;
+            if ((rc = dev_alloc(h, &R.v[s][w].callq, nv))) return rc;
+        }
+    }
+    if ((rc = dev_alloc(h, &R.aln_dist, na))) return rc;
+    if ((rc = dev_alloc(h, &R.aln_end_plane, na))) return rc;
+    if ((rc = dev_alloc(h, &R.aln_beg_plane, na))) return rc;
+    if ((rc = dev_alloc(h, &R.aln_status, na))) return rc;
+    if ((rc = dev_alloc(h, &R.sc_phase, size_t(n)))) return rc;
+    if ((rc = dev_alloc(h, &R.orig_phase_dist, size_t(n)))) return rc;
+    if ((rc = dev_alloc(h, &R.swap_phase_dist, size_t(n)))) return rc;
+    if ((rc = dev_alloc(h, &R.tally, 6))) return rc;
+    R.max_qual = h->cfg.max_qual;
+    R.credit_threshold = h->cfg.credit_threshold;
+    R.phase_threshold = h->cfg.phase_threshold;
     if ((rc = dev_alloc(h, &h->d_ok, na))) return rc;
     if ((rc = dev_alloc(h, &h->d_fail, na))) return rc;
     if ((rc = dev_alloc(h, &h->d_cnt, 2))) return rc;
@@ -532,6 +561,18 @@ int vpr_execute(vpr_handle *h) {
     for (int q = 0; q < 4; q++)
         HIPCHK(h, hipMemsetAsync(h->d_fp[q], 0xff, std::max<int64_t>(h->n_var[q >> 1], 1) * 4, st));
     HIPCHK(h, hipMemsetAsync(h->d_njobs, 0, 4, st));
+    for (int s = 0; s < 4; s++)      // the reference's initial values: ERRTYPE_UN, 0 (variant.cpp:45-52)
+        for (int w = 0; w < 2; w++) {
+            const size_t nv = std::max<size_t>(size_t(h->n_var[s]), 1);
+            const VarCols &V = h->dR.v[s][w];
+            HIPCHK(h, hipMemsetAsync(V.errtype, VPR_ERRTYPE_UN, nv, st));
+            HIPCHK(h, hipMemsetAsync(V.sync_group, 0, nv * 4, st));
+            HIPCHK(h, hipMemsetAsync(V.credit, 0, nv * 4, st));
+            HIPCHK(h, hipMemsetAsync(V.ref_ed, 0, nv * 4, st));
+            HIPCHK(h, hipMemsetAsync(V.query_ed, 0, nv * 4, st));
+            HIPCHK(h, hipMemsetAsync(V.callq, 0, nv * 4, st));
+        }
+    HIPCHK(h, hipMemsetAsync(h->dR.tally, 0, 6 * sizeof(unsigned long long), st));
     if (!h->dirty.empty()) {   // restore the round-0 descriptors a previous execute's retry rounds replaced
         hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(h->descs.size())), dim3(256), 0, st, h->plan0.d_descs,
                            int(h->descs.size()), h->d_descs);
@@ -743,6 +784,20 @@ int vpr_execute(vpr_handle *h) {
             if (rc) return rc;
         }
     }
+    // K5: per-variant results, phase, tally
+    {
+        const int na = int(h->descs.size());
+        vpr_launch_stat fs_;
+        memset(&fs_, 0, sizeof(fs_));
+        fs_.threads = 128; fs_.n_units = na;
+        rc = timed(5, fs_, st, [&] {
+            if (na) hipLaunchKernelGGL(k_finalize, dim3((na + 127) / 128), dim3(128), 0, st, h->d_descs, na, h->d_outs,
+                                       h->d_secs, h->d_fp_table, h->dR);
+            if (h->n_sc) hipLaunchKernelGGL(k_phase_tally, dim3((h->n_sc + 127) / 128), dim3(128), 0, st, h->d_descs,
+                                            h->n_sc, h->dR);
+        });
+        if (rc) return rc;
+    }
     HIPCHK(h, hipEventRecord(t1, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
@@ -757,7 +812,7 @@ int vpr_execute(vpr_handle *h) {
         if (e.kind == 1) h->timing.ms_fwd += m;
         else if (e.kind == 2) h->timing.ms_bwd += m;
         else if (e.kind == 3) h->timing.ms_walk += m;
-        else h->timing.ms_ed += m;
+        else if (e.kind == 4) h->timing.ms_ed += m;
     }
     h->timing.n_fwd_launches = n_fwd;
     h->timing.cells_touched = cells_touched;
@@ -785,97 +840,38 @@ int vpr_download(vpr_handle *h, vpr_results *res) {
     if (!h || !res) return VPR_ERR_ARG;
     if (!h->executed) return fail(h, VPR_ERR_STATE, "vpr_download before vpr_execute");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    const size_t na = h->descs.size();
-    std::vector<AlnOut> outs(na);
-    std::vector<Section> secs(size_t(h->n_secs_cap));
-    std::vector<int32_t> fp[4];
-    if (na) HIPCHK(h, hipMemcpy(outs.data(), h->d_outs, na * sizeof(AlnOut), hipMemcpyDeviceToHost));
-    if (!secs.empty()) HIPCHK(h, hipMemcpy(secs.data(), h->d_secs, secs.size() * sizeof(Section), hipMemcpyDeviceToHost));
-    for (int q = 0; q < 4; q++) {
-        fp[q].resize(size_t(h->n_var[q >> 1]));
-        if (!fp[q].empty()) HIPCHK(h, hipMemcpy(fp[q].data(), h->d_fp[q], fp[q].size() * 4, hipMemcpyDeviceToHost));
+    const DevResults &R = h->dR;
+    const size_t na = h->descs.size(), n = size_t(h->n_sc);
+    // results were finalised on the device (k_finalize / k_phase_tally): plain copies into the caller's buffers
+    if (na) {
+        HIPCHK(h, hipMemcpy(res->aln_dist, R.aln_dist, na * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(res->aln_end_plane, R.aln_end_plane, na, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(res->aln_beg_plane, R.aln_beg_plane, na, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(res->aln_status, R.aln_status, na * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(res->sc_phase, R.sc_phase, n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(res->orig_phase_dist, R.orig_phase_dist, n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(res->swap_phase_dist, R.swap_phase_dist, n * 4, hipMemcpyDeviceToHost));
     }
-    const float max_qual = h->cfg.max_qual;
-    const double thr = h->cfg.credit_threshold;
-
-    auto job = [&](int sc0, int sc1) {
-        for (int sc = sc0; sc < sc1; sc++) {
-            int32_t s[4];
-            for (int i = 0; i < 4; i++) {
-                const size_t a = size_t(sc) * 4 + i;
-                const AlnOut &O = outs[a];
-                const AlnDesc &d = h->descs[a];
-                s[i] = O.s;
-                res->aln_dist[a] = O.s;
-                res->aln_end_plane[a] = uint8_t(O.end_plane);
-                res->aln_beg_plane[a] = uint8_t(O.beg_plane);
-                uint32_t status = O.status;
-                const int swap = (i == 1 || i == 2);
-                const int qs = d.qs, ts = d.ts;
-                const float *qq = h->var_qual[qs].data();
-                const int32_t *fpg = fp[qs * 2 + swap].data();
-                // query variants passed on the REF plane: FP in a group of their own, dist.cpp:1157-1168
-                for (int64_t v = d.qv_beg; v < d.qv_end; v++) {
-                    if (fpg[v] >= 0) {
-                        res->errtype[qs][swap][v] = VPR_ERRTYPE_FP;
-                        res->sync_group[qs][swap][v] = fpg[v];
-                        res->credit[qs][swap][v] = 0;
-                        res->ref_ed[qs][swap][v] = 0;
-                        res->query_ed[qs][swap][v] = 0;
-                        res->callq[qs][swap][v] = qq[v];
-                    }
-                }
-                if (!(status & (VPR_ST_ERR_NO_PTR | VPR_ST_ERR_UNFINISHED))) {
-                    for (int k = 0; k < O.n_sec; k++) {
-                        const Section &S = secs[size_t(d.sec_off) + k];
-                        int ref_ed = S.ref_ed;
-                        const int query_ed = S.query_ed;
-                        const bool has_q = S.q_hi != S.q_lo, has_t = S.t_hi != S.t_lo;
-                        if (!has_t && ref_ed != 0) status |= VPR_ST_WARN_REF_ED;            // dist.cpp:1203
-                        if (!has_q && query_ed != ref_ed) status |= VPR_ST_WARN_QUERY_ED;   // dist.cpp:1207
-                        if (query_ed > ref_ed) status |= VPR_ST_WARN_EXCEEDS;               // dist.cpp:1211
-                        if (ref_ed == 0 && has_t) { status |= VPR_ST_WARN_ZERO_ED; ref_ed = 1; }  // dist.cpp:1219-1223
-                        float callq = max_qual;                                             // dist.cpp:1284-1288
-                        for (int64_t v = S.q_hi; v > S.q_lo; v--) callq = std::min(callq, qq[v]);
-                        for (int64_t v = S.q_hi; v > S.q_lo; v--) {
-                            float credit = 1 - float(query_ed) / ref_ed;
-                            if (fpg[v] < 0) {   // "don't overwrite FPs", dist.cpp:1295
-                                res->errtype[qs][swap][v] = (credit >= thr) ? VPR_ERRTYPE_TP : VPR_ERRTYPE_FP;
-                                res->sync_group[qs][swap][v] = S.sync_group;
-                                res->credit[qs][swap][v] = credit;
-                                res->ref_ed[qs][swap][v] = ref_ed;
-                                res->query_ed[qs][swap][v] = query_ed;
-                                res->callq[qs][swap][v] = callq;
-                            }
-                        }
-                        for (int64_t v = S.t_hi; v > S.t_lo; v--) {
-                            float credit = 1 - float(query_ed) / ref_ed;
-                            const bool tp = credit >= thr;
-                            res->errtype[ts][swap][v] = tp ? VPR_ERRTYPE_TP : VPR_ERRTYPE_FN;
-                            res->sync_group[ts][swap][v] = S.sync_group;
-                            res->credit[ts][swap][v] = credit;
-                            res->ref_ed[ts][swap][v] = ref_ed;
-                            res->query_ed[ts][swap][v] = query_ed;
-                            res->callq[ts][swap][v] = tp ? callq : max_qual;
-                        }
-                    }
-                }
-                res->aln_status[a] = status;
-            }
-            res->sc_phase[sc] = vpr_store_phase(s, h->cfg.phase_threshold, &res->orig_phase_dist[sc],
-                                                &res->swap_phase_dist[sc]);
+    for (int s = 0; s < 4; s++) {
+        const size_t nv = size_t(h->n_var[s]);
+        if (!nv) continue;
+        for (int w = 0; w < 2; w++) {
+            HIPCHK(h, hipMemcpy(res->errtype[s][w], R.v[s][w].errtype, nv, hipMemcpyDeviceToHost));
+            HIPCHK(h, hipMemcpy(res->sync_group[s][w], R.v[s][w].sync_group, nv * 4, hipMemcpyDeviceToHost));
+            HIPCHK(h, hipMemcpy(res->credit[s][w], R.v[s][w].credit, nv * 4, hipMemcpyDeviceToHost));
+            HIPCHK(h, hipMemcpy(res->ref_ed[s][w], R.v[s][w].ref_ed, nv * 4, hipMemcpyDeviceToHost));
+            HIPCHK(h, hipMemcpy(res->query_ed[s][w], R.v[s][w].query_ed, nv * 4, hipMemcpyDeviceToHost));
+            HIPCHK(h, hipMemcpy(res->callq[s][w], R.v[s][w].callq, nv * 4, hipMemcpyDeviceToHost));
         }
-    };
-    const int n = h->n_sc;
-    const int nth = int(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32));
-    if (n < 4096 || nth == 1) {
-        job(0, n);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nth; t++)
-            th.emplace_back(job, int(int64_t(n) * t / nth), int(int64_t(n) * (t + 1) / nth));
-        for (auto &x : th) x.join();
     }
+    return VPR_OK;
+}
+
+int vpr_get_tally(const vpr_handle *h, int64_t out[6]) {
+    if (!h || !out || !h->executed) return VPR_ERR_ARG;
+    unsigned long long t[6];
+    if (hipMemcpy(t, h->dR.tally, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) return VPR_ERR_DEVICE;
+    for (int k = 0; k < 6; k++) out[k] = int64_t(t[k]);
     return VPR_OK;
 }
 

@@ -101,6 +101,28 @@ struct EdJob {
     int32_t tru_beg, tru_len; // truth segment
 };
 
+// per-variant result columns of one (hap slot, swap) -- ctgVariants::{errtypes,sync_group,credit,ref_ed,
+// query_ed,callq}[swap], variant.h:49-60
+struct VarCols {
+    uint8_t *errtype;
+    int32_t *sync_group;
+    float *credit;
+    int32_t *ref_ed;
+    int32_t *query_ed;
+    float *callq;
+};
+struct DevResults {
+    VarCols v[4][2];          // [hap slot][swap]
+    const float *var_qual[4];
+    int32_t *aln_dist;        // [n_sc*4]
+    uint8_t *aln_end_plane, *aln_beg_plane;
+    uint32_t *aln_status;
+    int32_t *sc_phase, *orig_phase_dist, *swap_phase_dist;   // [n_sc]
+    unsigned long long *tally;   // [2 callsets][3 errtypes]
+    float max_qual;
+    double credit_threshold, phase_threshold;
+};
+
 // packed walk entry: qri | plane<<31,  ti | sync<<31 | edit<<30
 struct PathEnt { uint32_t a, b; };
 

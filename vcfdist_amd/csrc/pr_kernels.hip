@@ -780,6 +780,101 @@ __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int3
 }
 
 // ---------------------------------------------------------------------------
+// K5: per-variant results from the sections (the float part of calc_prec_recall, dist.cpp:1157-1168 and
+// 1284-1353), store_phase (dist.cpp:449-475) and the TP/FP/FN tally.  hipcc's float division is
+// correctly rounded (no -ffast-math), so credit = 1 - float(query_ed)/ref_ed has the reference's bits;
+// the parity tests compare the bit patterns.
+// ---------------------------------------------------------------------------
+__global__ void k_finalize(const AlnDesc *__restrict__ descs, int n_aln, const AlnOut *__restrict__ outs,
+                           const Section *__restrict__ secs, int32_t *const *__restrict__ fp_group, DevResults R) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_aln) return;
+    const AlnDesc d = descs[a];
+    const AlnOut O = outs[a];
+    uint32_t status = O.status;
+    const int swap = (d.aln == 1 || d.aln == 2);
+    const VarCols Q = R.v[d.qs][swap], T = R.v[d.ts][swap];
+    const float *qq = R.var_qual[d.qs];
+    const int32_t *fpg = fp_group[d.qs * 2 + swap];
+    for (int64_t v = d.qv_beg; v < d.qv_end; v++) {   // passed on the REF plane: FP in a group of its own
+        const int g = fpg[v];
+        if (g >= 0) {
+            Q.errtype[v] = VPR_ERRTYPE_FP; Q.sync_group[v] = g; Q.credit[v] = 0; Q.ref_ed[v] = 0; Q.query_ed[v] = 0;
+            Q.callq[v] = qq[v];
+        }
+    }
+    if (!(status & (VPR_ST_ERR_NO_PTR | VPR_ST_ERR_UNFINISHED))) {
+        for (int k = 0; k < O.n_sec; k++) {
+            const Section S = secs[d.sec_off + k];
+            int ref_ed = S.ref_ed;
+            const int query_ed = S.query_ed;
+            const bool has_q = S.q_hi != S.q_lo, has_t = S.t_hi != S.t_lo;
+            if (!has_t && ref_ed != 0) status |= VPR_ST_WARN_REF_ED;            // dist.cpp:1203
+            if (!has_q && query_ed != ref_ed) status |= VPR_ST_WARN_QUERY_ED;   // dist.cpp:1207
+            if (query_ed > ref_ed) status |= VPR_ST_WARN_EXCEEDS;               // dist.cpp:1211
+            if (ref_ed == 0 && has_t) { status |= VPR_ST_WARN_ZERO_ED; ref_ed = 1; }   // dist.cpp:1219-1223
+            float callq = R.max_qual;                                            // dist.cpp:1284-1288
+            for (int64_t v = S.q_hi; v > S.q_lo; v--) callq = (qq[v] < callq) ? qq[v] : callq;   // std::min
+            // 0/0 (query variants that cancel out, no truth variant): the reference's x86-64 SSE division
+            // yields the default "real indefinite" NaN 0xFFC00000 and 1 - NaN keeps it; gfx950 would
+            // produce +NaN, so the reference's bit pattern is written explicitly
+            const float credit = (ref_ed == 0 && query_ed == 0) ? __uint_as_float(0xFFC00000u)
+                                                                : 1 - float(query_ed) / float(ref_ed);
+            const bool tp = double(credit) >= R.credit_threshold;
+            for (int64_t v = S.q_hi; v > S.q_lo; v--) {
+                if (fpg[v] < 0) {   // "don't overwrite FPs", dist.cpp:1295
+                    Q.errtype[v] = tp ? VPR_ERRTYPE_TP : VPR_ERRTYPE_FP;
+                    Q.sync_group[v] = S.sync_group; Q.credit[v] = credit; Q.ref_ed[v] = ref_ed;
+                    Q.query_ed[v] = query_ed; Q.callq[v] = callq;
+                }
+            }
+            for (int64_t v = S.t_hi; v > S.t_lo; v--) {
+                T.errtype[v] = tp ? VPR_ERRTYPE_TP : VPR_ERRTYPE_FN;
+                T.sync_group[v] = S.sync_group; T.credit[v] = credit; T.ref_ed[v] = ref_ed;
+                T.query_ed[v] = query_ed; T.callq[v] = tp ? callq : R.max_qual;
+            }
+        }
+    }
+    R.aln_dist[a] = O.s;
+    R.aln_end_plane[a] = uint8_t(O.end_plane);
+    R.aln_beg_plane[a] = uint8_t(O.beg_plane);
+    R.aln_status[a] = status;
+}
+
+// store_phase (dist.cpp:456-469) per supercluster, then the tally of the phasing it selects
+__global__ void k_phase_tally(const AlnDesc *__restrict__ descs, int n_sc, DevResults R) {
+    __shared__ unsigned long long blk[6];
+    if (threadIdx.x < 6) blk[threadIdx.x] = 0;
+    __syncthreads();
+    const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sc < n_sc) {
+        const int s0 = R.aln_dist[sc * 4], s1 = R.aln_dist[sc * 4 + 1], s2 = R.aln_dist[sc * 4 + 2], s3 = R.aln_dist[sc * 4 + 3];
+        const int orig = s0 + s3, swp = s2 + s1;
+        int phase = VPR_PHASE_NONE;
+        if (orig != swp) {
+            if (orig == 0) phase = VPR_PHASE_ORIG;
+            else if (swp == 0) phase = VPR_PHASE_SWAP;
+            else if (double(1 - float(swp) / float(orig)) > R.phase_threshold) phase = VPR_PHASE_SWAP;
+            else if (double(1 - float(orig) / float(swp)) > R.phase_threshold) phase = VPR_PHASE_ORIG;
+        }
+        R.sc_phase[sc] = phase;
+        R.orig_phase_dist[sc] = orig;
+        R.swap_phase_dist[sc] = swp;
+        const int w = (phase == VPR_PHASE_SWAP) ? 1 : 0;
+        // alignment 0 = (query hap 0, truth hap 0), alignment 3 = (query hap 1, truth hap 1): their variant ranges
+        const AlnDesc d0 = descs[sc * 4], d3 = descs[sc * 4 + 3];
+        unsigned cnt[6] = {0, 0, 0, 0, 0, 0};
+        for (int64_t v = d0.qv_beg; v < d0.qv_end; v++) { const int e = R.v[0][w].errtype[v]; if (e < 3) cnt[e]++; }
+        for (int64_t v = d3.qv_beg; v < d3.qv_end; v++) { const int e = R.v[1][w].errtype[v]; if (e < 3) cnt[e]++; }
+        for (int64_t v = d0.tv_beg; v < d0.tv_end; v++) { const int e = R.v[2][w].errtype[v]; if (e < 3) cnt[3 + e]++; }
+        for (int64_t v = d3.tv_beg; v < d3.tv_end; v++) { const int e = R.v[3][w].errtype[v]; if (e < 3) cnt[3 + e]++; }
+        for (int k = 0; k < 6; k++) if (cnt[k]) atomicAdd(&blk[k], (unsigned long long)cnt[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && blk[threadIdx.x]) atomicAdd(&R.tally[threadIdx.x], blk[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
 // K4: edit distance of deferred sections; one wave per section, row sweep over
 // the shorter string with lanes over the longer one (same scan as K1, one plane).
 // ---------------------------------------------------------------------------
