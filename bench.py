@@ -40,21 +40,6 @@ def make_workload(api, n_sc, seed, workload):
     raise SystemExit(f"unknown workload {workload}")
 
 
-def tally_numpy(res):
-    """TP/FP/FN counts of the phasing each supercluster's alignment distances select
-    (sc_phase SWAP -> swap slot 1, otherwise slot 0); int64[2 callsets][3 errtypes]."""
-    out = np.zeros((2, 3), np.int64)
-    # per-variant choice needs the supercluster of each variant: use var_off of the batch
-    for h in range(4):
-        sc_of_var = res._sc_of_var[h]
-        use_swap = (res.sc_phase[sc_of_var] == 1)
-        et = np.where(use_swap, res.errtype[h][1], res.errtype[h][0])
-        cs = h >> 1
-        for e in range(3):
-            out[cs, e] += int((et == e).sum())
-    return out
-
-
 def cpu_baseline(batch, target_s=15.0):
     """Time the CPU oracle (a port of the reference's algorithm, single thread) on a bounded
     sample of the same workload.  Checker code used as a *reported baseline* only."""
@@ -111,13 +96,12 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from vcfdist_amd import api, _abi as A
+    from vcfdist_amd import api, shard, _abi as A
     api.build()
-    syn = make_workload(api, args.n_sc, args.seed + 7919 * rank, args.workload)
+    syn = make_workload(api, args.n_sc, shard.rank_seed(args.seed, rank), args.workload)
     batch = syn.batch(copy=False)
     pr = api.PrecisionRecall(device=local_rank)
     pr.upload(batch)                    # inputs resident in HBM before the timed region
-    sc_of_var = [np.repeat(np.arange(batch.n_sc), np.diff(batch.var_off[h])) for h in range(4)]
     dev = torch.device("cuda", local_rank)
 
     def step():
@@ -150,8 +134,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if rank == 0:       # the device tally must equal the one recomputed from the downloaded results
-        res._sc_of_var = sc_of_var
-        assert np.array_equal(tally_numpy(res), pr.tally()), "device tally != host tally"
+        assert np.array_equal(shard.tally_from_results(res, batch.var_off), pr.tally()), "device tally != host tally"
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)

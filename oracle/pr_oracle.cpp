@@ -19,14 +19,15 @@
 // optimal swap predecessors is "last writer wins" and therefore depends on that
 // iteration order (dist.cpp:347,376).
 //
-// PARITY PIN: the reference cannot be built in this image (every translation
-// unit on the path includes htslib/vcf.h through variant.h:9 and htslib is not
-// installed; writing a stand-in header is not allowed).  The restatement is
-// pinned against (1) the reference-produced toy vector recorded in SURVEY.md
-// Appendix A.1, (2) textbook Levenshtein for edit_distance, (3) an independent
-// dense dynamic programme for the forward distances, and (4) the demo
-// known-answer of the reference (demo/output.txt, SNP row) through the
-// end-to-end host pipeline.  See DESIGN.md "Oracle and parity pin".
+// PARITY PIN -- "parity unpinned" against a live reference: the reference cannot be built in this
+// image (every translation unit on the path includes htslib/vcf.h through variant.h:9, htslib is not
+// installed, and writing a stand-in header is not allowed), and it ships no tests or golden vectors for
+// this path.  Partial pins that do exist (tests/test_oracle.py): (1) the reference-produced toy vector
+// recorded in SURVEY.md Appendix A.1 (strings, pointer/flag arrays, s = 0 x4, QUERY end plane),
+// (2) textbook Levenshtein for edit_distance, (3) an independent dense dynamic programme
+// (tests/dense_model.py) for distances, flags, backward scores and path pointers, (4) hand-derived
+// credit cases.  The demo known-answer (demo/output.txt) needs the rows of SURVEY 8(f).
+// See DESIGN.md section 5.
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
