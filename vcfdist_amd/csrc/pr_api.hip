@@ -211,13 +211,21 @@ BandBwd band_bwd_kernel(int c) {
 
 int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-__global__ void k_partition(const int32_t *__restrict__ work, int n, const AlnOut *__restrict__ outs,
-                            int32_t *__restrict__ ok_list, int32_t *__restrict__ fail_list, int32_t *__restrict__ cnt) {
+// Append the alignments whose window was rejected to the round's fail list (wave-aggregated: one atomic
+// per wave; 800 k contended single-word atomics would cost more than the forward sweep itself).
+__global__ void k_collect_fails(const int32_t *__restrict__ work, int n, const AlnOut *__restrict__ outs,
+                                int32_t *__restrict__ fail_list, int32_t *__restrict__ cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int a = work[i];
-    if (outs[a].band_ok) ok_list[atomicAdd(&cnt[0], 1)] = a;
-    else fail_list[atomicAdd(&cnt[1], 1)] = a;
+    const bool live = i < n;
+    const int a = live ? work[i] : 0;
+    const bool bad = live && !outs[a].band_ok;
+    const unsigned long long mbad = __ballot(bad);
+    if (!mbad) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(cnt, __popcll(mbad));
+    base = __shfl(base, 0);
+    if (bad) fail_list[base + __popcll(mbad & ((1ull << lane) - 1ull))] = a;
 }
 
 __global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc *__restrict__ dst) {
@@ -653,45 +661,64 @@ int vpr_execute(vpr_handle *h) {
         return VPR_OK;
     };
 
-    // ---- banded plan: K1b, accept/reject on the device, K2b + K3 for the accepted, collect the rest
+    // ---- banded plan.  Per chunk the work list (sorted longest first) is split into a long and a short
+    // part that run K1b -> K2b -> K3 on two streams: the long alignments are a latency chain (rows are
+    // sequential), the short ones a throughput problem, and they overlap.  K2b/K3 skip alignments whose
+    // window failed the exit test, so there is no host round trip inside a round; the rejected ids are
+    // collected on the device and read back once per round.
     auto run_band = [&](const Plan &P, const int32_t *d_work, std::vector<int32_t> &fails) -> int {
         const int C = P.band_c;
+        HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
         for (const Chunk &ch : P.chunks) {
-            vpr_launch_stat ls;
-            memset(&ls, 0, sizeof(ls));
-            ls.threads = 64; ls.cells_per_thread = C; ls.n_units = ch.count;
-            ls.cells = ch.cells;
-            ls.bytes_algorithmic = ch.cells + ch.in_bytes;
-            cells_touched += ch.cells;
-            HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
-            int rc = timed(1, ls, st, [&] {
-                hipLaunchKernelGGL(band_fwd_kernel(C), dim3(ch.count), dim3(64), 0, st, h->dB, h->d_descs,
-                                   d_work + ch.work_off, h->d_arena, arena_i32, h->d_outs);
-                hipLaunchKernelGGL(k_fwd_band_finish, dim3((ch.count + 255) / 256), dim3(256), 0, st,
-                                   d_work + ch.work_off, ch.count, h->d_outs);
-                hipLaunchKernelGGL(k_partition, dim3((ch.count + 255) / 256), dim3(256), 0, st, d_work + ch.work_off,
-                                   ch.count, h->d_outs, h->d_ok, h->d_fail, h->d_cnt);
-            });
-            if (rc) return rc;
-            n_fwd++;
-            int32_t cnt[2] = {0, 0};
-            HIPCHK(h, hipMemcpyAsync(cnt, h->d_cnt, 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(h, hipStreamSynchronize(st));
-            if (cnt[1] > 0) {
-                const size_t o = fails.size();
-                fails.resize(o + cnt[1]);
-                HIPCHK(h, hipMemcpy(fails.data() + o, h->d_fail, size_t(cnt[1]) * 4, hipMemcpyDeviceToHost));
-            }
-            if (cnt[0] > 0) {
-                ls.n_units = cnt[0];
-                ls.bytes_algorithmic = ch.cells;
-                rc = timed(2, ls, st, [&] {
-                    hipLaunchKernelGGL(band_bwd_kernel(C), dim3(cnt[0]), dim3(64), 0, st, h->dB, h->d_descs, h->d_ok,
+            int32_t n_long = 0;
+            while (n_long < ch.count && P.descs[ch.work_off + n_long].Lt >= 512) n_long++;
+            if (n_long == ch.count || ch.count < 4096) n_long = 0;     // nothing to overlap with
+            HIPCHK(h, hipEventRecord(h->ev_fork, st));
+            for (int part = 0; part < 2; part++) {
+                const int32_t off = part == 0 ? 0 : n_long, cnt = part == 0 ? n_long : ch.count - n_long;
+                if (cnt <= 0) continue;
+                hipStream_t ks = h->cls_stream[part];
+                HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
+                const int32_t *list = d_work + ch.work_off + off;
+                vpr_launch_stat ls;
+                memset(&ls, 0, sizeof(ls));
+                ls.threads = 64; ls.cells_per_thread = C; ls.n_units = cnt;
+                int64_t in_bytes = 0;
+                const int W = 64 * C;
+                for (int32_t w = 0; w < cnt; w++) {
+                    const AlnDesc &d = P.descs[ch.work_off + off + w];
+                    ls.cells += int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt;
+                    in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
+                }
+                ls.bytes_algorithmic = ls.cells + in_bytes;
+                cells_touched += ls.cells;
+                int rc = timed(1, ls, ks, [&] {
+                    hipLaunchKernelGGL(band_fwd_kernel(C), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
+                                       h->d_arena, arena_i32, h->d_outs);
+                    hipLaunchKernelGGL(k_fwd_band_finish, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs);
+                });
+                if (rc) return rc;
+                n_fwd++;
+                ls.bytes_algorithmic = ls.cells;
+                rc = timed(2, ls, ks, [&] {
+                    hipLaunchKernelGGL(band_bwd_kernel(C), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
                                        h->d_arena, arena_i32, h->d_outs);
                 });
                 if (rc) return rc;
-                if ((rc = walk_launch(h->d_ok, cnt[0], st))) return rc;
+                if ((rc = walk_launch(list, cnt, ks))) return rc;
+                hipLaunchKernelGGL(k_collect_fails, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs,
+                                   h->d_fail, h->d_cnt);
+                HIPCHK(h, hipEventRecord(h->ev_join[part], ks));
+                HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[part], 0));
             }
+        }
+        int32_t nf = 0;
+        HIPCHK(h, hipMemcpyAsync(&nf, h->d_cnt, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        if (nf > 0) {
+            fails.resize(size_t(nf));
+            HIPCHK(h, hipMemcpy(fails.data(), h->d_fail, size_t(nf) * 4, hipMemcpyDeviceToHost));
+            std::sort(fails.begin(), fails.end());   // deterministic planning of the next round
         }
         return VPR_OK;
     };

@@ -192,8 +192,18 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
     }
     asm volatile("" ::: "memory");
 
+    // band of the next row, carried from iteration to iteration
+    int nlo[2] = {0, 0}, nhi[2] = {0, 0};
+    if (Lt > 1) {
+        nlo[0] = __builtin_amdgcn_readlane(cbQ, 1); nlo[1] = __builtin_amdgcn_readlane(cbR, 1);
+        nhi[0] = min(Lq - 1, nlo[0] + W - 1); nhi[1] = min(Lr - 1, nlo[1] + W - 1);
+    }
+    // The row loop is written branch-free: every LDS ring read is unconditional (any index & M is inside
+    // the ring) and out-of-window values are replaced by D_INF with selects, so a row is one straight
+    // line of VALU/LDS work apart from the rare multi-candidate swap and the 64-row chunk refills.
     for (int t = 1; t < Lt; t++) {
-        int plo[2] = {lo[0], lo[1]}, phi[2] = {hi[0], hi[1]};
+        const int plo[2] = {lo[0], lo[1]}, phi[2] = {hi[0], hi[1]};
+        lo[0] = nlo[0]; lo[1] = nlo[1]; hi[0] = nhi[0]; hi[1] = nhi[1];
         if ((t & 63) == 0) {   // advance the truth / band chunks
             tlast = __builtin_amdgcn_readlane(tchunk, 63);
             const int tt = t + lane;
@@ -207,17 +217,14 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
         const uint32_t prv = ((t & 63) == 0) ? tlast : uint32_t(__builtin_amdgcn_readlane(tchunk, (t - 1) & 63));
         const uint32_t Tt = cur & 0xff;
         const bool at = fwd_allow(int((prv >> 8) & 0xff));
-        lo[0] = __builtin_amdgcn_readlane(cbQ, t & 63);
-        lo[1] = __builtin_amdgcn_readlane(cbR, t & 63);
-        hi[0] = min(Lq - 1, lo[0] + W - 1);
-        hi[1] = min(Lr - 1, lo[1] + W - 1);
-        int nlo[2] = {0, 0}, nhi[2] = {0, 0};
         const bool has_next = t + 1 < Lt;
         if (has_next) {
             if (((t + 1) & 63) == 0) { nlo[0] = __builtin_amdgcn_readlane(nbQ, 0); nlo[1] = __builtin_amdgcn_readlane(nbR, 0); }
             else { nlo[0] = __builtin_amdgcn_readlane(cbQ, (t + 1) & 63); nlo[1] = __builtin_amdgcn_readlane(cbR, (t + 1) & 63); }
             nhi[0] = min(Lq - 1, nlo[0] + W - 1);
             nhi[1] = min(Lr - 1, nlo[1] + W - 1);
+        } else {   // last row: nothing below, only the INS edge can leave the window
+            nlo[0] = 0; nlo[1] = 0; nhi[0] = Lq; nhi[1] = Lr;
         }
 #pragma unroll
         for (int p = 0; p < 2; p++)
@@ -226,54 +233,88 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
 
         const int pb = (t - 1) & 1, cb = t & 1;
         int bv[2][C];
-        uint8_t mk[2][C];
+        uint32_t mk[2][C];
+        int swt[2][C];
         int cmin[2];
+        bool any_multi = false;
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int o = 1 - p;
             const int x0 = lo[p] + off0;
-            int diag = (x0 - 1 >= plo[p] && x0 - 1 <= phi[p]) ? Dr[pb][p][(x0 - 1) & M] : D_INF;
+            int diag = Dr[pb][p][(x0 - 1) & M];
+            diag = (x0 - 1 >= plo[p] && x0 - 1 <= phi[p]) ? diag : D_INF;
             int run = D_INF;
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 const int x = x0 + c;
                 const bool valid = x <= hi[p];
                 const int2 k = Kr[p][x & M];
-                const int up = (x >= plo[p] && x <= phi[p]) ? Dr[pb][p][x & M] : D_INF;
+                int up = Dr[pb][p][x & M];
+                up = (x >= plo[p] && x <= phi[p]) ? up : D_INF;
                 const bool match = valid && (uint32_t(k.y) >> 24) == Tt;
+                const int s0 = k.x & (FK_MULTI - 1);
+                int sw = Dr[pb][o][s0 & M];
+                const bool sw_on = match && at && k.x >= 0;
+                sw = (sw_on && s0 >= plo[o] && s0 <= phi[o]) ? sw : D_INF;
+                any_multi = any_multi || (sw_on && (k.x & FK_MULTI));
                 const int cm = match ? diag : diag + 1;
-                int b = min(cm, up + 1);
-                int sw = D_INF, choice = 0;
-                bool tie = false;
-                if (match && at && k.x >= 0) {
-                    const int s0 = k.x & ~FK_MULTI;
-                    sw = (s0 >= plo[o] && s0 <= phi[o]) ? Dr[pb][o][s0 & M] : D_INF;
-                    if (k.x & FK_MULTI) {
+                const int b = min(min(cm, up + 1), sw);
+                uint32_t m = 0;
+                m |= (match && diag == b) ? F_MAT : 0;
+                m |= (diag + 1 == b) ? F_SUB : 0;
+                m |= (up + 1 == b) ? F_DEL : 0;
+                m |= (sw == b && sw < D_INF) ? F_SWP : 0;
+                mk[p][c] = m;
+                swt[p][c] = k.y & 0xffffff;
+                bv[p][c] = valid ? b - x : D_INF;
+                diag = up;
+            }
+        }
+        if (__builtin_expect(__any(any_multi), 0)) {
+            // rare: a cell with several allowed swap sources (an insertion/deletion boundary) -- redo those cells
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int o = 1 - p;
+                const int x0 = lo[p] + off0;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const int x = x0 + c;
+                    const int2 k = Kr[p][x & M];
+                    const bool match = x <= hi[p] && (uint32_t(k.y) >> 24) == Tt;
+                    if (match && at && k.x >= 0 && (k.x & FK_MULTI)) {
                         const int4 cc = cand[p][x];
-                        const int v1 = (cc.y >= plo[o] && cc.y <= phi[o]) ? Dr[pb][o][cc.y & M] : D_INF;
+                        auto dval = [&](int src) { return (src >= plo[o] && src <= phi[o]) ? Dr[pb][o][src & M] : D_INF; };
+                        int sw = dval(cc.x), choice = 0;
+                        bool tie = false;
+                        const int v1 = dval(cc.y);
                         if (v1 <= sw) { tie = (v1 == sw); sw = v1; choice = 1; }
                         if (cc.z >= 0) {
-                            const int v2 = (cc.z >= plo[o] && cc.z <= phi[o]) ? Dr[pb][o][cc.z & M] : D_INF;
+                            const int v2 = dval(cc.z);
                             if (v2 <= sw) { tie = (v2 == sw); sw = v2; choice = 2; }
                             if (cc.w >= 0) {
-                                const int v3 = (cc.w >= plo[o] && cc.w <= phi[o]) ? Dr[pb][o][cc.w & M] : D_INF;
+                                const int v3 = dval(cc.w);
                                 if (v3 <= sw) { tie = (v3 == sw); sw = v3; choice = 3; }
                             }
                         }
+                        const int up = (x >= plo[p] && x <= phi[p]) ? Dr[pb][p][x & M] : D_INF;
+                        const int dg = (x - 1 >= plo[p] && x - 1 <= phi[p]) ? Dr[pb][p][(x - 1) & M] : D_INF;
+                        const int b = min(min(dg, up + 1), sw);   // match is true here
+                        uint32_t m = 0;
+                        if (dg == b) m |= F_MAT;
+                        if (dg + 1 == b) m |= F_SUB;
+                        if (up + 1 == b) m |= F_DEL;
+                        if (sw == b && sw < D_INF) m |= F_SWP | (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
+                        mk[p][c] = m;
+                        bv[p][c] = b - x;
                     }
-                    b = min(b, sw);
                 }
-                uint8_t m = 0;
-                if (match && diag == b) m |= F_MAT;
-                if (diag + 1 == b) m |= F_SUB;
-                if (up + 1 == b) m |= F_DEL;
-                if (sw == b && sw < D_INF) m |= F_SWP | (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
-                mk[p][c] = m;
-                const int v = valid ? b - x : D_INF;
-                bv[p][c] = v;
-                run = min(run, v);
-                diag = up;
             }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            int run = D_INF;
+#pragma unroll
+            for (int c = 0; c < C; c++) run = min(run, bv[p][c]);
             cmin[p] = run;
         }
         int iq = cmin[0], ir = cmin[1];
@@ -290,23 +331,22 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
             for (int c = 0; c < C; c++) {
                 const int x = x0 + c;
                 const int nb = bv[p][c];
-                uint8_t f = 0;
-                if (nb <= run) { run = nb; f = mk[p][c]; }
+                const bool take = nb <= run;
+                run = min(run, nb);
+                uint32_t f = take ? mk[p][c] : 0;
                 const int Dn = run + x;
-                if (left + 1 == Dn && x > 0) f |= F_INS;
-                fl[c] = f;
+                f |= (left + 1 == Dn && x > 0) ? F_INS : 0;
+                fl[c] = uint8_t(f);
                 left = Dn;
-                if (x <= hi[p]) {
-                    Dr[cb][p][x & M] = Dn;
-                    bool ex = (x == hi[p] && hi[p] < Lp[p] - 1);
-                    if (has_next) {
-                        ex = ex || x < nlo[p] || (x + 1 <= Lp[p] - 1 && x + 1 > nhi[p]);
-                        const uint32_t swt = uint32_t(Kr[p][x & M].y) & 0xffffffu;
-                        if (swt != FK_NONE24 && int(swt) < Lp[o] && (int(swt) < nlo[o] || int(swt) > nhi[o])) ex = true;
-                    }
-                    if (ex) exit_min = min(exit_min, Dn);
-                    if (t == Lt - 1 && x == Lp[p] - 1) endD[p] = Dn;
-                }
+                const bool valid = x <= hi[p];
+                if (valid) Dr[cb][p][x & M] = Dn;
+                // edges leaving the window: INS to the right, DEL / diagonal into row t+1, plane swap
+                const int z = swt[p][c];
+                bool ex = (x == hi[p] && hi[p] < Lp[p] - 1);
+                ex = ex || (has_next && (x < nlo[p] || (x + 1 <= Lp[p] - 1 && x + 1 > nhi[p])));
+                ex = ex || (has_next && z != FK_NONE24 && z < Lp[o] && (z < nlo[o] || z > nhi[o]));
+                exit_min = (valid && ex) ? min(exit_min, Dn) : exit_min;
+                endD[p] = (valid && t == Lt - 1 && x == Lp[p] - 1) ? Dn : endD[p];
             }
             if (x0 <= hi[p]) {
                 typename FlagVec<C>::T v;
@@ -379,6 +419,7 @@ __global__ void __launch_bounds__(64) k_bwd_band(DevBatch B, const AlnDesc *__re
     const int32_t *bk[2] = {B.bk_q[d.qs] + d.q_off, B.bk_r[d.qs] + d.r_off};
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     const int32_t *blo = blo_all + d.blo_off;
+    if (!outs[a].band_ok) return;   // window rejected by the exit test: this alignment is re-run wider
     const int end_plane = outs[a].end_plane;
     const int off0 = (63 - lane) * C;
 

@@ -622,6 +622,7 @@ __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int3
     const int a = work[wi];
     const AlnDesc d = descs[a];
     AlnOut &O = outs[a];
+    if (d.band_w > 0 && !O.band_ok) return;   // rejected banded attempt: re-run with a wider window
     const int qi = 0, ri = 1;   // planes
     const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
     const uint8_t *qfl = B.hap_flag[d.qs] + d.q_off;
