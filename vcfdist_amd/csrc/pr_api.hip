@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -196,7 +197,8 @@ typedef void (*BandFwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, i
 typedef void (*BandBwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, const int32_t *, AlnOut *);
 BandFwd band_fwd_kernel(int c) {
     switch (c) {
-        case 1: return k_fwd_band<1, true>;
+        case 1:   // 64-cell window: striped, register-resident variant (VPR_NO_STRIPE=1 selects the ring variant)
+            return getenv("VPR_NO_STRIPE") ? BandFwd(k_fwd_band<1, true>) : BandFwd(k_fwd_stripe);
         case 4: return k_fwd_band<4, true>;
         default: return k_fwd_band<16, true>;
     }
@@ -274,7 +276,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int band_c, Plan 
             }
             const int64_t m0 = round_up(int64_t(d.pitch[0]) * d.Lt, 64), m1 = round_up(int64_t(d.pitch[1]) * d.Lt, 64);
             const int64_t bl = band_c ? round_up(int64_t(2) * d.Lt * 4, 64) : 0;
-            const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64);
+            const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64);   // 16 B per step
             const int64_t need = m0 + m1 + bl + pb + 64;
             if (k > k0 && used + need > h->arena_bytes) break;
             if (need > h->arena_bytes)
@@ -383,6 +385,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         h->var_off[s].assign(b->var_off[s], b->var_off[s] + n + 1);
         h->var_qual[s].assign(b->var_qual[s], b->var_qual[s] + h->n_var[s]);
         if ((rc = dev_alloc(h, &D.has_ins[s], ref_len))) return rc;
+        if ((rc = dev_alloc(h, &D.vs_hap[s], hap_len[s]))) return rc;
         HIPCHK(h, hipMemsetAsync(D.has_ins[s], 0, std::max<int64_t>(ref_len, 1), h->stream));
     }
     if ((rc = dev_upload(h, &D.ref_off, b->ref_off, n + 1))) return rc;
@@ -396,6 +399,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if ((rc = dev_alloc(h, &D.fk_r[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.bk_q[q], hap_len[q]))) return rc;
         if ((rc = dev_alloc(h, &D.bk_r[q], ref_len))) return rc;
+        if ((rc = dev_alloc(h, &D.vs_ref[q], ref_len))) return rc;
         HIPCHK(h, hipMemsetAsync(D.cand_q[q], 0xff, std::max<int64_t>(hap_len[q], 1) * sizeof(int4), h->stream));
         HIPCHK(h, hipMemsetAsync(D.cand_r[q], 0xff, std::max<int64_t>(ref_len, 1) * sizeof(int4), h->stream));
     }
@@ -421,6 +425,9 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     for (int s = 0; s < 4; s++)
         if (hap_len[s] > 0)
             hipLaunchKernelGGL(k_prep_ins, blocks(hap_len[s]), dim3(256), 0, h->stream, D, s, hap_len[s]);
+    if (n > 0)
+        for (int w = 0; w < 6; w++)
+            hipLaunchKernelGGL(k_prep_suffix, dim3((n + 63) / 64), dim3(64), 0, h->stream, D, w);
     HIPCHK(h, hipEventRecord(e1, h->stream));
 
     // ---- base descriptors
@@ -514,7 +521,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
             const int64_t pq = band ? round_up(std::min(64, d.Lq), 16) : round_up(d.Lq, 32);
             const int64_t prr = band ? round_up(std::min(64, d.Lr), 16) : round_up(d.Lr, 32);
             want += round_up(pq * d.Lt, 64) + round_up(prr * d.Lt, 64) + (band ? round_up(8 * int64_t(d.Lt), 64) : 0) +
-                    round_up(int64_t(d.path_cap) * 8, 64) + 64;
+                    round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64) + 64;
         }
         if (h->cfg.workspace_bytes <= 0) budget = std::min(budget, std::max<int64_t>(want, 256 << 20));
     }
@@ -606,14 +613,20 @@ int vpr_execute(vpr_handle *h) {
     int32_t *arena_i32 = reinterpret_cast<int32_t *>(h->d_arena);
     PathEnt *arena_path = reinterpret_cast<PathEnt *>(h->d_arena);
 
-    auto walk_launch = [&](const int32_t *d_list, int32_t count, hipStream_t ks) -> int {
+    // wave = true: one wavefront per alignment with LDS-staged window rows (long banded alignments)
+    auto walk_launch = [&](const int32_t *d_list, int32_t count, hipStream_t ks, bool wave) -> int {
         vpr_launch_stat ws_;
         memset(&ws_, 0, sizeof(ws_));
-        ws_.threads = 64; ws_.n_units = count;
+        ws_.threads = 64; ws_.n_units = count; ws_.cells_per_thread = wave ? 1 : 0;
         return timed(3, ws_, ks, [&] {
-            hipLaunchKernelGGL(k_walk, dim3((count + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, d_list, count,
-                               h->d_arena, arena_i32, h->d_outs, arena_path, h->d_secs, h->d_fp_table, h->d_jobs,
-                               h->d_njobs, h->jobs_cap);
+            if (wave)
+                hipLaunchKernelGGL(k_walk<true>, dim3(count), dim3(64), 0, ks, h->dB, h->d_descs, d_list, count,
+                                   h->d_arena, arena_i32, h->d_outs, arena_path, h->d_secs, h->d_fp_table,
+                                   h->d_jobs, h->d_njobs, h->jobs_cap);
+            else
+                hipLaunchKernelGGL(k_walk<false>, dim3((count + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, d_list,
+                                   count, h->d_arena, arena_i32, h->d_outs, arena_path, h->d_secs, h->d_fp_table,
+                                   h->d_jobs, h->d_njobs, h->jobs_cap);
         });
     };
 
@@ -653,7 +666,7 @@ int vpr_execute(vpr_handle *h) {
                                        d_work + L.work_off, h->d_arena, h->d_outs);
                 });
                 if (rc) return rc;
-                if ((rc = walk_launch(d_work + L.work_off, L.count, ks))) return rc;
+                if ((rc = walk_launch(d_work + L.work_off, L.count, ks, false))) return rc;
                 HIPCHK(h, hipEventRecord(h->ev_join[L.cls], ks));
                 HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[L.cls], 0));
             }
@@ -705,7 +718,9 @@ int vpr_execute(vpr_handle *h) {
                                        h->d_arena, arena_i32, h->d_outs);
                 });
                 if (rc) return rc;
-                if ((rc = walk_launch(list, cnt, ks))) return rc;
+                // long part (or a small launch of long retries): wave-per-alignment walk; windows up to 256
+                const bool wave_walk = C <= 4 && (part == 0 || cnt < 2048);
+                if ((rc = walk_launch(list, cnt, ks, wave_walk))) return rc;
                 hipLaunchKernelGGL(k_collect_fails, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs,
                                    h->d_fail, h->d_cnt);
                 HIPCHK(h, hipEventRecord(h->ev_join[part], ks));
@@ -719,6 +734,15 @@ int vpr_execute(vpr_handle *h) {
             fails.resize(size_t(nf));
             HIPCHK(h, hipMemcpy(fails.data(), h->d_fail, size_t(nf) * 4, hipMemcpyDeviceToHost));
             std::sort(fails.begin(), fails.end());   // deterministic planning of the next round
+            if (getenv("VPR_DEBUG")) {
+                for (int32_t a : fails) {
+                    AlnOut o;
+                    (void)hipMemcpy(&o, h->d_outs + a, sizeof(o), hipMemcpyDeviceToHost);
+                    const AlnDesc &d = h->descs[a];
+                    fprintf(stderr, "[vpr] band C=%d rejected sc %d aln %d: Lq %d Lr %d Lt %d  s %d exit_min %d dq %d dr %d\n",
+                            C, d.sc, d.aln, d.Lq, d.Lr, d.Lt, o.s, o.exit_min, o.dist_q, o.dist_r);
+                }
+            }
         }
         return VPR_OK;
     };

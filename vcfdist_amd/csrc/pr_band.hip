@@ -75,6 +75,22 @@ __global__ void k_prep_pack(DevBatch B, int h, int dir, int64_t n_pos) {
     bk[g] = int32_t(z | (bits << 24));
 }
 
+// suffix sums of |pointer step - 1| (an inserted base contributes 1, a crossed deletion its length):
+// which = 0..3: hap slot (hap -> ref pointers), 4..5: ref -> query hap (which - 4)
+__global__ void k_prep_suffix(DevBatch B, int which) {
+    const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sc >= B.n_sc) return;
+    const int64_t *off = which < 4 ? B.hap_off[which] : B.ref_off;
+    const int32_t *ptr = which < 4 ? B.hap_ptr[which] : B.ref_ptr[which - 4];
+    int32_t *out = which < 4 ? B.vs_hap[which] : B.vs_ref[which - 4];
+    const int64_t b = off[sc], e = off[sc + 1];
+    int32_t acc = 0;
+    for (int64_t i = e - 1; i >= b; i--) {
+        if (i > b) { const int w = ptr[i] - ptr[i - 1] - 1; acc += w < 0 ? -w : w; }
+        out[i] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // DPP wave scans (gfx9 row_shr / row_bcast / wave_shr): ~12 VALU ops instead of six ds_bpermute hops
 // ---------------------------------------------------------------------------
@@ -243,7 +259,6 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
             const int x0 = lo[p] + off0;
             int diag = Dr[pb][p][(x0 - 1) & M];
             diag = (x0 - 1 >= plo[p] && x0 - 1 <= phi[p]) ? diag : D_INF;
-            int run = D_INF;
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 const int x = x0 + c;
@@ -589,4 +604,267 @@ __global__ void __launch_bounds__(64) k_bwd_band(DevBatch B, const AlnDesc *__re
     wave_prefix_min2(bs, dummy);
     if (lane == 63) outs[a].beg_plane = (-bs >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
     if (tie_used) atomicOr(&outs[a].status, VPR_ST_SWAP_TIE);
+}
+
+// ===========================================================================
+// K1s: *striped* banded forward sweep (W = 64 cells, one wavefront per alignment).
+//
+// The window origin of each plane is constant over stripes of FS_K truth rows, so inside a stripe lane l
+// owns the same cell x = lo_p + l of every row: its distance, base, swap source and exit mask are
+// registers; the diagonal neighbour is a DPP wave_shr:1, the swap source a ds_bpermute, the INS chain the
+// DPP prefix-min.  Only the first row of a stripe re-aligns (bpermute by the origin shift).  Same
+// exactness argument as k_fwd_band: exit_min collects the distance of every cell with an edge leaving
+// the window (the last row of a stripe is tested against the next stripe's window).
+// ===========================================================================
+#define FS_K 8
+#define FS_W 64
+
+// value of lane `src` (any lane index; out-of-range sources give `fill`)
+__device__ __forceinline__ int lane_get(int src, int v, int fill) {
+    const int r = __builtin_amdgcn_ds_bpermute((src & 63) << 2, v);
+    return (src >= 0 && src < 64) ? r : fill;
+}
+
+// stripe origin: the window is centred between the reference coordinates of the stripe's first and last
+// truth row, so a jump of the diagonal inside the stripe (a truth indel) costs at most half its size of margin
+__device__ __forceinline__ void stripe_origin(const int32_t *t2r, const int32_t *r2q, int s, int n_stripes, int Lt,
+                                              int Lq, int Lr, int &loQ, int &loR) {
+    loQ = 0; loR = 0;
+    if (s > 0 && s < n_stripes) {   // stripe 0 starts at the origin
+        const int ta = s * FS_K, tb = min(ta + FS_K - 1, Lt - 1);
+        const int ra = t2r[ta], rb = t2r[tb];
+        const int qa = r2q[min(max(ra, 0), Lr - 1)], qb = r2q[min(max(rb, 0), Lr - 1)];
+        loR = max(0, min((ra + rb) / 2 - FS_W / 2, Lr - min(FS_W, Lr)));
+        loQ = max(0, min((qa + qb) / 2 - FS_W / 2, Lq - min(FS_W, Lq)));
+    }
+}
+
+__global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__restrict__ descs,
+                                                   const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
+                                                   int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
+    const int a = work[blockIdx.x];
+    const AlnDesc d = descs[a];
+    const int lane = threadIdx.x;
+    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
+    const int Lp[2] = {Lq, Lr};
+    const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off;
+    const uint8_t *Tf = B.hap_flag[d.ts] + d.t_off;
+    const int32_t *t2r = B.hap_ptr[d.ts] + d.t_off;
+    const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
+    const int2 *fk[2] = {B.fk_q[d.qs] + d.q_off, B.fk_r[d.qs] + d.r_off};
+    const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
+    const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
+    const int32_t *vsp[2] = {B.vs_hap[d.qs] + d.q_off, B.vs_ref[d.qs] + d.r_off};   // free-shift budget ahead
+    const int32_t *vst = B.vs_hap[d.ts] + d.t_off;
+    uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
+    int32_t *blo = blo_all + d.blo_off;
+    const int n_stripes = (Lt + FS_K - 1) / FS_K;
+
+    // stripe origins, 64 stripes per register chunk (lane l <-> stripe c0 + l); next chunk prefetched
+    int cbQ, cbR, nbQ, nbR;
+    stripe_origin(t2r, r2q, lane, n_stripes, Lt, Lq, Lr, cbQ, cbR);
+    stripe_origin(t2r, r2q, 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
+    uint32_t tchunk = 0, tlast = 0;
+    int tauchunk = 0, vtchunk = 0;       // t2r[t] and the truth hap's free-shift budget of rows (t & ~63) + lane
+    if (lane < Lt) {
+        tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
+        tauchunk = t2r[lane];
+        vtchunk = vst[max(lane - 1, 0)];
+    }
+
+    int exit_min = D_INF;
+    int Dp[2] = {lane, lane};            // row 0: D = x along the INS chain (origin 0)
+    int lo[2] = {0, 0}, hi[2] = {min(Lq, FS_W) - 1, min(Lr, FS_W) - 1};
+    int plo[2] = {0, 0};                 // origins of the previous stripe
+    int nlo[2] = {0, 0}, nhi[2] = {0, 0};
+    int2 kc[2], kn[2];                   // packed constants of this / the next stripe
+    int rhoc[2], rhon[2], vac[2], van[2];   // reference coordinate and free-shift budget of the lane's cell
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        kc[p] = make_int2(-1, int(0xffffffffu));
+        rhoc[p] = lane; vac[p] = 0;
+        if (lane <= hi[p]) {
+            kc[p] = fk[p][lane];
+            rhoc[p] = (p == 0) ? q2r[lane] : lane;
+            vac[p] = vsp[p][max(lane - 1, 0)];
+        }
+    }
+
+    for (int s = 0; s < n_stripes; s++) {
+        const int t0 = s * FS_K;
+        const int rows = min(FS_K, Lt - t0);
+        // ---- next stripe's window, prefetch of its constants
+        const bool has_next = s + 1 < n_stripes;
+        if (has_next) {
+            if (((s + 1) & 63) == 0) { nlo[0] = __builtin_amdgcn_readlane(nbQ, 0); nlo[1] = __builtin_amdgcn_readlane(nbR, 0); }
+            else { nlo[0] = __builtin_amdgcn_readlane(cbQ, (s + 1) & 63); nlo[1] = __builtin_amdgcn_readlane(cbR, (s + 1) & 63); }
+        } else { nlo[0] = lo[0]; nlo[1] = lo[1]; }
+        nhi[0] = min(Lq - 1, nlo[0] + FS_W - 1);
+        nhi[1] = min(Lr - 1, nlo[1] + FS_W - 1);
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            kn[p] = make_int2(-1, int(0xffffffffu));
+            rhon[p] = 0; van[p] = 0;
+            if (has_next && nlo[p] + lane <= nhi[p]) {
+                const int xn = nlo[p] + lane;
+                kn[p] = fk[p][xn];
+                rhon[p] = (p == 0) ? q2r[xn] : xn;
+                van[p] = vsp[p][max(xn - 1, 0)];
+            }
+        }
+        if (lane < rows) { blo[t0 + lane] = lo[0]; blo[Lt + t0 + lane] = lo[1]; }   // read by K2 / K3
+
+        // ---- per-lane constants of this stripe
+        int s0[2];
+        uint32_t base[2];
+        bool multi[2], ex_in[2], ex_last[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int o = 1 - p;
+            const int x = lo[p] + lane;
+            const bool valid = x <= hi[p];
+            s0[p] = (kc[p].x < 0) ? -1 : (kc[p].x & (FK_MULTI - 1));
+            multi[p] = kc[p].x >= 0 && (kc[p].x & FK_MULTI);
+            base[p] = valid ? (uint32_t(kc[p].y) >> 24) : 0xffu;
+            const int z = kc[p].y & 0xffffff;
+            const bool zok = valid && z != FK_NONE24 && z < Lp[o];
+            const bool ins_out = valid && x == hi[p] && hi[p] < Lp[p] - 1;
+            ex_in[p] = ins_out || (zok && (z < lo[o] || z > hi[o]));
+            ex_last[p] = ins_out || (has_next && valid && (x < nlo[p] || (x + 1 <= Lp[p] - 1 && x + 1 > nhi[p]))) ||
+                         (has_next && zok && (z < nlo[o] || z > nhi[o]));
+        }
+        uint8_t *rowp[2] = {mat[0] + size_t(t0) * d.pitch[0] + lane, mat[1] + size_t(t0) * d.pitch[1] + lane};
+        const bool st_ok[2] = {lane < d.pitch[0], lane < d.pitch[1]};
+
+        for (int r = 0; r < rows; r++) {
+            const int t = t0 + r;
+            const bool last = (r == rows - 1);
+            if (t == 0) {   // row 0, dist.cpp:300-305,397-405
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    if (st_ok[p]) *rowp[p] = (lane == 0) ? F_MAT : F_INS;
+                    rowp[p] += d.pitch[p];
+                    const bool ex = last ? ex_last[p] : ex_in[p];
+                    // lower bound of any path through this exit cell: D + what the diagonal offset still costs
+                    const int off0_ = rhoc[p] - __builtin_amdgcn_readlane(tauchunk, 0);
+                    const int lb0 = max((off0_ < 0 ? -off0_ : off0_) - vac[p] - __builtin_amdgcn_readlane(vtchunk, 0), 0);
+                    exit_min = ex ? min(exit_min, lane + lb0) : exit_min;
+                }
+                continue;
+            }
+            if ((t & 63) == 0) {
+                tlast = __builtin_amdgcn_readlane(tchunk, 63);
+                const int tt = t + lane;
+                tchunk = 0; tauchunk = 0; vtchunk = 0;
+                if (tt < Lt) {
+                    tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
+                    tauchunk = t2r[tt];
+                    vtchunk = vst[tt - 1];
+                }
+            }
+            const int tau = __builtin_amdgcn_readlane(tauchunk, t & 63);
+            const int vt = __builtin_amdgcn_readlane(vtchunk, t & 63);
+            const uint32_t cur = __builtin_amdgcn_readlane(tchunk, t & 63);
+            const uint32_t prv = ((t & 63) == 0) ? tlast : uint32_t(__builtin_amdgcn_readlane(tchunk, (t - 1) & 63));
+            const uint32_t Tt = cur & 0xff;
+            const bool at = fwd_allow(int((prv >> 8) & 0xff));
+            const bool first = (r == 0);   // the previous row belongs to the previous stripe (origins plo)
+
+            int v[2], up[2], dg[2], sw[2];
+            uint32_t mk[2];
+            bool match[2], need_multi = false;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int o = 1 - p;
+                if (first) {
+                    const int sh = lo[p] - plo[p];
+                    up[p] = lane_get(lane + sh, Dp[p], D_INF);
+                    dg[p] = lane_get(lane + sh - 1, Dp[p], D_INF);
+                } else {
+                    up[p] = Dp[p];
+                    dg[p] = wave_shr1(Dp[p], D_INF);
+                }
+                match[p] = base[p] == Tt;
+                const bool on = match[p] && at && s0[p] >= 0;
+                const int sv = lane_get(s0[p] - (first ? plo[o] : lo[o]), Dp[o], D_INF);
+                sw[p] = on ? sv : D_INF;
+                need_multi = need_multi || (on && multi[p]);
+            }
+            uint32_t swbits[2] = {0, 0};
+            if (__builtin_expect(__any(need_multi), 0)) {
+                // rare: several allowed swap sources (insertion / deletion boundary); keep the highest index
+                // among the optimal ones and remember ties (VPR_ST_SWAP_TIE)
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const int o = 1 - p;
+                    const bool need = match[p] && at && s0[p] >= 0 && multi[p];
+                    int4 cc = make_int4(-1, -1, -1, -1);
+                    if (need) cc = cand[p][lo[p] + lane];
+                    const int olo = first ? plo[o] : lo[o];
+                    const int srcs[3] = {cc.y, cc.z, cc.w};
+                    int choice = 0;
+                    bool tie = false;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const int val0 = lane_get(srcs[k] - olo, Dp[o], D_INF);
+                        const int val = (need && srcs[k] >= 0) ? val0 : D_INF;
+                        if (need && srcs[k] >= 0 && val <= sw[p]) { tie = (val == sw[p]); sw[p] = val; choice = k + 1; }
+                    }
+                    swbits[p] = (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int cm = dg[p] + (match[p] ? 0 : 1);
+                const int up1 = up[p] + 1;
+                const int b = min(min(cm, up1), sw[p]);
+                uint32_t m = (cm == b) ? (match[p] ? F_MAT : F_SUB) : 0;
+                m |= (up1 == b) ? F_DEL : 0;
+                m |= (sw[p] == b && sw[p] < D_INF) ? (F_SWP | swbits[p]) : 0;
+                mk[p] = m;
+                v[p] = b - lane;
+            }
+            int iq = v[0], ir = v[1];
+            wave_prefix_min2(iq, ir);
+            const int inc[2] = {iq, ir};
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int carry = wave_shr1(inc[p], D_INF);
+                const int Dn = inc[p] + lane;                       // inclusive prefix-min + x
+                uint32_t f = (v[p] <= carry) ? mk[p] : 0;
+                const int left = wave_shr1(Dn, D_INF);
+                f |= (left + 1 == Dn) ? F_INS : 0;
+                if (st_ok[p]) *rowp[p] = uint8_t(f);
+                rowp[p] += d.pitch[p];
+                // Exit test (see the header): a path through an exit cell costs at least D plus what it takes
+                // to bring the diagonal offset rho - tau back to zero, minus the indel sizes still ahead (each
+                // unit-cost edge moves the offset by at most 1 + the variants it crosses).
+                const bool ex = last ? ex_last[p] : ex_in[p];
+                const int doff = rhoc[p] - tau;
+                const int lb = max((doff < 0 ? -doff : doff) - vac[p] - vt, 0);
+                exit_min = ex ? min(exit_min, Dn + lb) : exit_min;
+                Dp[p] = Dn;
+            }
+        }
+        // ---- advance to the next stripe
+        plo[0] = lo[0]; plo[1] = lo[1];
+        lo[0] = nlo[0]; lo[1] = nlo[1]; hi[0] = nhi[0]; hi[1] = nhi[1];
+        kc[0] = kn[0]; kc[1] = kn[1];
+        rhoc[0] = rhon[0]; rhoc[1] = rhon[1]; vac[0] = van[0]; vac[1] = van[1];
+        if (((s + 1) & 63) == 0) {
+            cbQ = nbQ; cbR = nbR;
+            stripe_origin(t2r, r2q, s + 1 + 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
+        }
+    }
+    // end cells: row Lt-1 was computed with origins plo (the last stripe's)
+    const int eq = Lq - 1 - plo[0], er = Lr - 1 - plo[1];
+    const int dq = (eq >= 0 && eq < 64) ? __builtin_amdgcn_readlane(Dp[0], eq & 63) : D_INF;
+    const int dr = (er >= 0 && er < 64) ? __builtin_amdgcn_readlane(Dp[1], er & 63) : D_INF;
+    int em = exit_min, dummy = D_INF;
+    wave_prefix_min2(em, dummy);
+    if (lane == 63) {
+        outs[a].dist_q = dq;
+        outs[a].dist_r = dr;
+        outs[a].exit_min = em;
+    }
 }

@@ -47,6 +47,12 @@ struct DevBatch {
     int2 *fk_r[2];        // [ref positions]
     int32_t *bk_q[2];
     int32_t *bk_r[2];
+    // suffix sums of indel sizes (k_prep_suffix): vs_hap[s][i] = total size of the indels of hap slot s at hap
+    // positions >= i; vs_ref[h][r] = total size of query hap h's indels at ref positions >= r.  They bound how
+    // far the diagonal can still shift for free, which turns an exit cell's distance into a lower bound of any
+    // path through it (pr_band.hip, k_fwd_stripe).
+    int32_t *vs_hap[4];
+    int32_t *vs_ref[2];
 };
 #define FK_MULTI (1 << 30)
 #define FK_NONE24 0xffffff
@@ -123,7 +129,9 @@ struct DevResults {
     double credit_threshold, phase_threshold;
 };
 
-// packed walk entry: qri | plane<<31,  ti | sync<<31 | edit<<30
-struct PathEnt { uint32_t a, b; };
+// packed walk entry: a = qri | plane<<31,  b = ti | sync<<31 | edit<<30, plus the reference coordinates of
+// the cell (qref = qri on the REF plane, q2r[qri] on the QUERY plane; tref = t2r[ti]) so the backward credit
+// walk needs no pointer-array loads
+struct PathEnt { uint32_t a, b; int32_t qref, tref; };
 
 #endif

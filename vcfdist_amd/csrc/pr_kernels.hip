@@ -611,14 +611,27 @@ __device__ int small_ed(const uint8_t *a, int m, const uint8_t *b, int n) {
     return row[n];
 }
 
-__global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ work, int n_work,
+// WAVE = false: one lane per alignment (64 alignments per wave), flags read straight from HBM.
+// WAVE = true : one wavefront per alignment for the long ones; every lane runs the same (uniform) walk, the
+//               window rows of the path_ptr matrices are staged through an LDS tile with coalesced 16-byte
+//               loads, and lane 0 does the stores.  The walk is a chain of dependent steps, so the long
+//               alignments are latency-bound: an LDS hit per step instead of an HBM round trip.
+#define WALK_TR 32          // rows per LDS tile
+#define WALK_TW 256         // widest window staged (band C = 1 or 4)
+template <bool WAVE>
+__global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restrict__ descs,
+                       const int32_t *__restrict__ work, int n_work,
                        const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
                        AlnOut *__restrict__ outs,
                        PathEnt *__restrict__ paths, Section *__restrict__ secs,
                        int32_t *const *__restrict__ fp_group /* [2 query haps * 2 swaps] */,
                        EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap) {
-    const int wi = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __align__(16) uint8_t tile[WAVE ? 2 * WALK_TR * WALK_TW : 16];
+    __shared__ int32_t tblo[WAVE ? 2 * WALK_TR : 2];
+    const int wi = WAVE ? int(blockIdx.x) : int(blockIdx.x * blockDim.x + threadIdx.x);
     if (wi >= n_work) return;
+    const int lane = threadIdx.x & 63;
+    const bool lead = !WAVE || lane == 0;
     const int a = work[wi];
     const AlnDesc d = descs[a];
     AlnOut &O = outs[a];
@@ -637,16 +650,40 @@ __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int3
     const int32_t *blo = blo_all + d.blo_off;
     PathEnt *path = paths + d.path_off;
     uint32_t status = 0;
+    int tile_t0 = -(1 << 30);   // first truth row held by the LDS tile (WAVE only)
 
     // ---- forward walk, dist.cpp:865-998
     int hi = O.beg_plane, qri = 0, ti = 0;
     int64_t n = 0;
-    path[n++] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31), uint32_t(ti) | (1u << 31)};   // sync, no edit
+    if (lead) path[0] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31), uint32_t(ti) | (1u << 31),
+                                (hi == ri) ? 0 : q2r[0], t2r[0]};   // sync, no edit
+    n = 1;
     bool ok = true;
     while ((hi == ri && qri < r_size - 1) || (hi == qi && qri < q_size - 1) || ti < t_size - 1) {
-        const int col = banded ? qri - blo[hi * t_size + ti] : qri;
-        if (banded && (col < 0 || col >= d.band_w)) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
-        const int p = mat[hi][size_t(ti) * d.pitch[hi] + col] & 31;
+        int p;
+        if (WAVE) {
+            if (ti >= tile_t0 + WALK_TR) {   // stage the next WALK_TR rows of both planes (uniform branch)
+                tile_t0 = ti;
+                const int rows = min(WALK_TR, t_size - ti);
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                    const int nbytes = rows * d.pitch[pl];
+                    const uint8_t *src = mat[pl] + size_t(ti) * d.pitch[pl];
+                    for (int k = lane * 16; k < nbytes; k += 64 * 16)
+                        *reinterpret_cast<uint4 *>(tile + pl * WALK_TR * WALK_TW + k) = *reinterpret_cast<const uint4 *>(src + k);
+                    if (lane < rows) tblo[pl * WALK_TR + lane] = blo[pl * t_size + ti + lane];
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            const int r = ti - tile_t0;
+            const int col = qri - tblo[hi * WALK_TR + r];
+            if (col < 0 || col >= d.band_w) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+            p = tile[hi * WALK_TR * WALK_TW + r * d.pitch[hi] + col] & 31;
+        } else {
+            const int col = banded ? qri - blo[hi * t_size + ti] : qri;
+            if (banded && (col < 0 || col >= d.band_w)) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+            p = mat[hi][size_t(ti) * d.pitch[hi] + col] & 31;
+        }
         int mv; uint32_t edit = 0;
         if (hi == ri && (p & F_SWP)) { mv = F_SWP; hi = qi; qri = r2q[qri]; qri++; ti++; }
         else if (p & F_MAT) { mv = F_MAT; qri++; ti++; }
@@ -670,10 +707,13 @@ __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int3
         const bool ins_loc = (insQ[tr] | insT[tr] | insQ[qr] | insT[qr]) != 0;
         const bool sync = !in_t && !in_q && !ins_loc && tr == qr && (mv & (F_MAT | F_SWP | F_SUB));
         if (n >= d.path_cap) { status |= VPR_ST_ERR_LIMIT; ok = false; break; }
-        path[n++] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31), uint32_t(ti) | (uint32_t(sync) << 31) | (edit << 30)};
+        if (lead) path[n] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31),
+                                    uint32_t(ti) | (uint32_t(sync) << 31) | (edit << 30), qr, tr};
+        n++;
     }
-    O.path_len = int32_t(n);
-    if (!ok) { atomicOr(&O.status, status); O.n_sec = 0; return; }
+    if (lead) O.path_len = int32_t(n);
+    if (!ok) { if (lead) { atomicOr(&O.status, status); O.n_sec = 0; } return; }
+    if (WAVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // lane 0's path stores are read back below
 
     // The reference keeps three parallel vectors: path (P entries), sync and edits (P+1 entries, the last
     // being the forced final sync with edit=false).  Here entry k carries sync[k], edits[k] for k < n = P;
@@ -693,6 +733,8 @@ __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int3
     int cur_hi = end_hi;
     const int qri_size = (end_hi == qi) ? q_size : r_size;
     int prev_hi = cur_hi, prev_qri = qri_size - 1, prev_ti = t_size - 1;
+    int prev_qref = (end_hi == ri) ? r_size - 1 : q2r[q_size - 1];   // reference coordinates of the end cell
+    int prev_tref = t2r[t_size - 1];
     int prev_sync_ref_idx = r_size, prev_sync_truth_idx = t_size;
     int query_ed = 0;
     int64_t query_var_ptr = d.qv_end - 1, truth_var_ptr = d.tv_end - 1;
@@ -702,13 +744,16 @@ __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int3
     int64_t sync_idx = n;   // index into the (P+1)-long sync/edit arrays; entry n is the virtual final one
 
     while (sync_idx >= 0) {
-        const int query_ref_pos = (prev_hi == ri) ? prev_qri : q2r[prev_qri];
+        const int query_ref_pos = prev_qref;
         while (query_ref_pos < query_var_pos && query_var_ptr >= d.qv_beg) {
-            if (cur_hi == ri) fpg[query_var_ptr] = sync_group++;   // FP: passed on the REF plane, dist.cpp:1157-1168
+            if (cur_hi == ri) {   // FP: passed on the REF plane, dist.cpp:1157-1168
+                if (lead) fpg[query_var_ptr] = sync_group;
+                sync_group++;
+            }
             query_var_ptr--;
             query_var_pos = (query_var_ptr < d.qv_beg) ? -1 : qv_pos[query_var_ptr];
         }
-        const int truth_ref_pos = t2r[prev_ti];
+        const int truth_ref_pos = prev_tref;
         while (truth_ref_pos < truth_var_pos && truth_var_ptr >= d.tv_beg) {
             truth_var_ptr--;
             truth_var_pos = (truth_var_ptr < d.tv_beg) ? -1 : tv_pos[truth_var_ptr];
@@ -716,7 +761,7 @@ __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int3
         const bool is_sync = (sync_idx == n) ? true : bool(path[sync_idx].b >> 31);
         const int is_edit = (sync_idx == n) ? 0 : int((path[sync_idx].b >> 30) & 1);
         if (is_sync) {
-            const int sync_ref_idx = (prev_hi == ri) ? prev_qri + 1 : q2r[prev_qri] + 1;
+            const int sync_ref_idx = prev_qref + 1;
             const int sync_truth_idx = prev_ti + 1;
             int rl = prev_sync_ref_idx - sync_ref_idx, tl = prev_sync_truth_idx - sync_truth_idx;
             if (rl < 0 || rl > r_size - sync_ref_idx) rl = r_size - sync_ref_idx;   // std::string::substr clamp
@@ -745,12 +790,13 @@ __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int3
                     S.t_lo = int32_t(truth_var_ptr); S.t_hi = int32_t(prev_truth_var_ptr);
                     S.sync_group = sync_group; S.query_ed = query_ed; S.ref_ed = ref_ed;
                     S.flags = (deferred ? SEC_DEFERRED : 0) | ((has_q || has_t) ? 0 : SEC_NOVAR);
-                    if (deferred) {
+                    if (deferred && lead) {
                         const int32_t j = atomicAdd(n_jobs, 1);
                         if (j < jobs_cap) jobs[j] = EdJob{a, n_sec, sync_ref_idx, rl, sync_truth_idx, tl};
                         else status |= VPR_ST_ERR_LIMIT;
                     }
-                    sec[n_sec++] = S;
+                    if (lead) sec[n_sec] = S;
+                    n_sec++;
                 } else status |= VPR_ST_ERR_LIMIT;
             } else {
                 // no variants, distance known: only the "should never happen" checks, dist.cpp:1203-1214
@@ -773,11 +819,16 @@ __global__ void k_walk(DevBatch B, const AlnDesc *__restrict__ descs, const int3
         prev_qri = int(e.a & 0x7fffffffu);
         prev_hi = int(e.a >> 31);
         prev_ti = int(e.b & 0x3fffffffu);
+        prev_qref = e.qref;
+        prev_tref = e.tref;
         query_var_pos = (query_var_ptr < d.qv_beg) ? -1 : qv_pos[query_var_ptr];
         truth_var_pos = (truth_var_ptr < d.tv_beg) ? -1 : tv_pos[truth_var_ptr];
     }
-    O.n_sec = n_sec;
-    if (status) atomicOr(&O.status, status);
+    (void)prev_qri; (void)prev_ti;
+    if (lead) {
+        O.n_sec = n_sec;
+        if (status) atomicOr(&O.status, status);
+    }
 }
 
 // ---------------------------------------------------------------------------
