@@ -11,7 +11,7 @@ res = pr.download()
 print("stripe" if not os.environ.get("VPR_NO_STRIPE") else "ring", "retries", t.n_band_retries, "touched %.3e" % t.cells_touched,
       "fwd %.2f bwd %.2f walk %.2f total %.2f" % (t.ms_fwd, t.ms_bwd, t.ms_walk, t.ms_total))
 for s in pr.launch_stats():
-    if s.kind == 1: print("  fwd launch C=%d n=%d ms=%.3f" % (s.cells_per_thread, s.n_units, s.ms))
+    print("  kind %d C=%d n=%d ms=%.3f" % (s.kind, s.cells_per_thread, s.n_units, s.ms))
 d = res.aln_dist.reshape(-1, 4).max(axis=1)
 big = np.argsort(L)[-8:]
 print("largest L:", L[big].tolist(), "max s:", d[big].tolist())

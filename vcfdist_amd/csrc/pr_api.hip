@@ -205,7 +205,8 @@ BandFwd band_fwd_kernel(int c) {
 }
 BandBwd band_bwd_kernel(int c) {
     switch (c) {
-        case 1: return k_bwd_band<1>;
+        case 1:   // needs the stripe origins written by k_fwd_stripe
+            return getenv("VPR_NO_STRIPE") ? BandBwd(k_bwd_band<1>) : BandBwd(k_bwd_stripe);
         case 4: return k_bwd_band<4>;
         default: return k_bwd_band<16>;
     }

@@ -868,3 +868,174 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
         outs[a].exit_min = em;
     }
 }
+
+// ===========================================================================
+// K2s: striped banded backward max-TP sweep (W = 64), the mirror image of k_fwd_stripe: lanes are
+// reversed (lane l owns x = lo + 63 - l) so "x+1" is lane l-1 (DPP wave_shr:1) and the suffix composition of
+// the max-plus maps is a DPP prefix scan; scores and forward flags of row t+1 live in registers, the swap
+// successor comes through ds_bpermute, only the first row of a stripe re-aligns by the origin shift.
+// Uses the stripe origins k_fwd_stripe stored in blo (constant over FS_K rows).
+// ===========================================================================
+__global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__restrict__ descs,
+                                                   const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
+                                                   const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
+    const int a = work[blockIdx.x];
+    const AlnDesc d = descs[a];
+    if (!outs[a].band_ok) return;   // window rejected by the exit test: this alignment is re-run wider
+    const int lane = threadIdx.x;
+    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
+    const int Lp[2] = {Lq, Lr};
+    const int32_t *bk[2] = {B.bk_q[d.qs] + d.q_off, B.bk_r[d.qs] + d.r_off};
+    uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
+    const int32_t *blo = blo_all + d.blo_off;
+    const int end_plane = outs[a].end_plane;
+    const int n_stripes = (Lt + FS_K - 1) / FS_K;
+    const int col = 63 - lane;                     // window column of this lane
+    const bool st_ok[2] = {col < d.pitch[0], col < d.pitch[1]};
+
+    // stripe origins, 64 stripes per register chunk (lane l <-> stripe c0 + l); the chunk below is prefetched
+    auto load_chunk = [&](int c0, int &bq, int &br) {
+        bq = 0; br = 0;
+        const int s = c0 + lane;
+        if (c0 >= 0 && s < n_stripes) { bq = blo[s * FS_K]; br = blo[Lt + s * FS_K]; }
+    };
+    int cbQ, cbR, lbQ, lbR;
+    const int c_top = (n_stripes - 1) & ~63;
+    load_chunk(c_top, cbQ, cbR);
+    load_chunk(c_top - 64, lbQ, lbR);
+
+    int lo[2], hi[2], plo[2] = {0, 0};
+    lo[0] = __builtin_amdgcn_readlane(cbQ, (n_stripes - 1) & 63);
+    lo[1] = __builtin_amdgcn_readlane(cbR, (n_stripes - 1) & 63);
+    int bkc[2], bkn[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        hi[p] = min(Lp[p] - 1, lo[p] + FS_W - 1);
+        bkc[p] = int(FK_NONE24);
+        if (lo[p] + col <= hi[p]) bkc[p] = bk[p][lo[p] + col];
+    }
+    int sc1[2] = {S_NEG, S_NEG};     // scores of row t+1 (own column)
+    int f1[2] = {0, 0};              // forward flags of row t+1
+    int f0[2] = {0, 0}, pf[2] = {0, 0};
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        if (st_ok[p]) f0[p] = mat[p][size_t(Lt - 1) * d.pitch[p] + col];
+        if (Lt >= 2 && st_ok[p]) pf[p] = mat[p][size_t(Lt - 2) * d.pitch[p] + col];
+    }
+    uint32_t tie_used = 0;
+
+    for (int s = n_stripes - 1; s >= 0; s--) {
+        const int t0 = s * FS_K, t1 = min(t0 + FS_K, Lt) - 1;
+        // ---- the stripe below: origins and constants (prefetched)
+        int nlo[2] = {0, 0};
+        if (s > 0) {
+            if ((s & 63) == 0) { nlo[0] = __builtin_amdgcn_readlane(lbQ, 63); nlo[1] = __builtin_amdgcn_readlane(lbR, 63); }
+            else { nlo[0] = __builtin_amdgcn_readlane(cbQ, (s - 1) & 63); nlo[1] = __builtin_amdgcn_readlane(cbR, (s - 1) & 63); }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            bkn[p] = int(FK_NONE24);
+            const int xn = nlo[p] + col;
+            if (s > 0 && xn <= min(Lp[p] - 1, nlo[p] + FS_W - 1)) bkn[p] = bk[p][xn];
+        }
+        // ---- per-lane constants of this stripe
+        bool valid[2];
+        int tp_own[2], tp_right[2], zl[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            valid[p] = lo[p] + col <= hi[p];
+            tp_own[p] = (bkc[p] >> 24) & 1;
+            tp_right[p] = wave_shr1(tp_own[p], 0);
+            zl[p] = bkc[p] & 0xffffff;   // swap target (absolute index in the other plane) or FK_NONE24
+        }
+        const int sh[2] = {plo[0] - lo[0], plo[1] - lo[1]};   // origin shift against the stripe above (first row)
+        uint8_t *rowp[2] = {mat[0] + size_t(t1) * d.pitch[0] + col, mat[1] + size_t(t1) * d.pitch[1] + col};
+
+        for (int t = t1; t >= t0; t--) {
+            const bool first = (t == t1) && (s != n_stripes - 1);   // row t+1 is aligned to the stripe above
+            int best[2], lk[2];
+            uint32_t bm[2];
+            MP g[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int o = 1 - p;
+                int up_s, up_f, dn_s, dn_f;
+                if (first) {
+                    up_s = lane_get(lane + sh[p] - 1, sc1[p], S_NEG);
+                    up_f = lane_get(lane + sh[p] - 1, f1[p], 0);
+                    dn_s = lane_get(lane + sh[p], sc1[p], S_NEG);
+                    dn_f = lane_get(lane + sh[p], f1[p], 0);
+                } else {
+                    up_s = wave_shr1(sc1[p], S_NEG);
+                    up_f = wave_shr1(f1[p], 0);
+                    dn_s = sc1[p];
+                    dn_f = f1[p];
+                }
+                int b = S_NEG;
+                uint32_t m = 0;
+                if (up_f & (F_MAT | F_SUB)) { b = up_s + tp_right[p]; m = up_f & (F_MAT | F_SUB); }
+                if (dn_f & F_DEL) {
+                    if (dn_s > b) { b = dn_s; m = F_DEL; } else if (dn_s == b) m |= F_DEL;
+                }
+                // swap successor z = (other plane, zl, t+1): its lane in the alignment of row t+1
+                const int olo = first ? plo[o] : lo[o];
+                const int zlane = 63 - (zl[p] - olo);
+                const int zf = lane_get(zl[p] == int(FK_NONE24) ? -1 : zlane, f1[o], 0);
+                const int zs = lane_get(zl[p] == int(FK_NONE24) ? -1 : zlane, sc1[o], S_NEG);
+                if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((bkc[p] >> 25) & 3)) {
+                    const int v = zs + ((bkc[p] >> 27) & 1);
+                    if (v >= 0 && (zf & F_TIE)) tie_used = 1;
+                    if (v > b) { b = v; m = F_SWP; } else if (v == b) m |= F_SWP;
+                }
+                if (t == Lt - 1 && p == end_plane && lo[p] + col == Lp[p] - 1) { b = 0; m = F_MAT; }   // dist.cpp:538-546
+                if (!valid[p]) { b = S_NEG; m = 0; }
+                best[p] = b;
+                bm[p] = m;
+                const int f0r = wave_shr1(f0[p], 0);   // forward flags of (x+1, t)
+                lk[p] = (f0r & F_INS) ? tp_right[p] : -1;
+                g[p].A = b; g[p].B = lk[p];
+            }
+            MP hq = g[0], hr = g[1];
+            wave_prefix_mp2(hq, hr);
+            const int inc[2] = {wave_shr1(hq.A, S_NEG), wave_shr1(hr.A, S_NEG)};
+            uint32_t outm[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                int v = best[p];
+                uint32_t m = bm[p];
+                if (lk[p] >= 0) {
+                    const int w = inc[p] + lk[p];
+                    if (w > v) { v = w; m = F_INS; } else if (w == v) m |= F_INS;
+                }
+                if (v < 0) { v = S_NEG; m = 0; }
+                outm[p] = m;
+                sc1[p] = v;          // becomes the "row t+1" score of the next iteration
+                f1[p] = f0[p];       // ... and its forward flags
+                f0[p] = pf[p];       // forward flags of row t-1 (requested one row ago)
+            }
+            // request row t-2 for both planes, then store this row's path_ptrs (loads before stores: the wait
+            // for pf never has to wait for a store younger than one row)
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+                if (t > 1 && st_ok[p]) pf[p] = *(rowp[p] - 2 * ptrdiff_t(d.pitch[p]));
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                if (st_ok[p]) *rowp[p] = uint8_t(outm[p]);
+                rowp[p] -= d.pitch[p];
+            }
+        }
+        // ---- advance to the stripe below
+        plo[0] = lo[0]; plo[1] = lo[1];
+        lo[0] = nlo[0]; lo[1] = nlo[1];
+        hi[0] = min(Lq - 1, lo[0] + FS_W - 1); hi[1] = min(Lr - 1, lo[1] + FS_W - 1);
+        bkc[0] = bkn[0]; bkc[1] = bkn[1];
+        if ((s & 63) == 0 && s > 0) {
+            cbQ = lbQ; cbR = lbR;
+            load_chunk(((s - 1) & ~63) - 64, lbQ, lbR);
+        }
+    }
+    // (QUERY, 0, 0) is column 0 of row 0 = lane 63 (stripe 0 starts at the origin)
+    const int bs = __builtin_amdgcn_readlane(sc1[0], 63);
+    if (lane == 0) outs[a].beg_plane = (bs >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
+    if (tie_used) atomicOr(&outs[a].status, VPR_ST_SWAP_TIE);
+}
