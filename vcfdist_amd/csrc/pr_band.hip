@@ -659,6 +659,8 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     int32_t *blo = blo_all + d.blo_off;
     const int n_stripes = (Lt + FS_K - 1) / FS_K;
+    // flag bytes of one stripe (FS_K rows x pitch <= 64 B per plane), flushed with one 16-byte store per lane
+    __shared__ __align__(16) uint8_t fbuf[2][FS_K * FS_W];
 
     // stripe origins, 64 stripes per register chunk (lane l <-> stripe c0 + l); next chunk prefetched
     int cbQ, cbR, nbQ, nbR;
@@ -733,7 +735,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
             ex_last[p] = ins_out || (has_next && valid && (x < nlo[p] || (x + 1 <= Lp[p] - 1 && x + 1 > nhi[p]))) ||
                          (has_next && zok && (z < nlo[o] || z > nhi[o]));
         }
-        uint8_t *rowp[2] = {mat[0] + size_t(t0) * d.pitch[0] + lane, mat[1] + size_t(t0) * d.pitch[1] + lane};
+        int rowo[2] = {lane, lane};   // byte offset of this lane's cell inside the stripe's LDS block
         const bool st_ok[2] = {lane < d.pitch[0], lane < d.pitch[1]};
 
         for (int r = 0; r < rows; r++) {
@@ -742,8 +744,8 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
             if (t == 0) {   // row 0, dist.cpp:300-305,397-405
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
-                    if (st_ok[p]) *rowp[p] = (lane == 0) ? F_MAT : F_INS;
-                    rowp[p] += d.pitch[p];
+                    if (st_ok[p]) fbuf[p][rowo[p]] = (lane == 0) ? F_MAT : F_INS;
+                    rowo[p] += d.pitch[p];
                     const bool ex = last ? ex_last[p] : ex_in[p];
                     // lower bound of any path through this exit cell: D + what the diagonal offset still costs
                     const int off0_ = rhoc[p] - __builtin_amdgcn_readlane(tauchunk, 0);
@@ -834,8 +836,8 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
                 uint32_t f = (v[p] <= carry) ? mk[p] : 0;
                 const int left = wave_shr1(Dn, D_INF);
                 f |= (left + 1 == Dn) ? F_INS : 0;
-                if (st_ok[p]) *rowp[p] = uint8_t(f);
-                rowp[p] += d.pitch[p];
+                if (st_ok[p]) fbuf[p][rowo[p]] = uint8_t(f);
+                rowo[p] += d.pitch[p];
                 // Exit test (see the header): a path through an exit cell costs at least D plus what it takes
                 // to bring the diagonal offset rho - tau back to zero, minus the indel sizes still ahead (each
                 // unit-cost edge moves the offset by at most 1 + the variants it crosses).
@@ -846,6 +848,16 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
                 Dp[p] = Dn;
             }
         }
+        // ---- flush the stripe's flag rows: rows * pitch contiguous bytes per plane, 16 per lane
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int nbytes = rows * d.pitch[p];
+            if (lane * 16 < nbytes)
+                *reinterpret_cast<uint4 *>(mat[p] + size_t(t0) * d.pitch[p] + lane * 16) =
+                    *reinterpret_cast<const uint4 *>(&fbuf[p][lane * 16]);
+        }
+        asm volatile("" ::: "memory");
         // ---- advance to the next stripe
         plo[0] = lo[0]; plo[1] = lo[1];
         lo[0] = nlo[0]; lo[1] = nlo[1]; hi[0] = nhi[0]; hi[1] = nhi[1];
@@ -892,6 +904,23 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
     const int n_stripes = (Lt + FS_K - 1) / FS_K;
     const int col = 63 - lane;                     // window column of this lane
     const bool st_ok[2] = {col < d.pitch[0], col < d.pitch[1]};
+    // forward flags of the current / next-lower stripe (double buffered, 16-byte loads one stripe ahead) and
+    // the path_ptr rows produced for the current stripe (flushed with 16-byte stores)
+    __shared__ __align__(16) uint8_t fin[2][2][FS_K * FS_W];
+    __shared__ __align__(16) uint8_t fout[2][FS_K * FS_W];
+    uint4 pfv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    auto stage_load = [&](int s_) {    // request stripe s_'s forward-flag rows (16 B per lane and plane)
+        if (s_ < 0) return;
+        const int ta = s_ * FS_K, nr = min(ta + FS_K, Lt) - ta;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            if (lane * 16 < nr * d.pitch[p])
+                pfv[p] = *reinterpret_cast<const uint4 *>(mat[p] + size_t(ta) * d.pitch[p] + lane * 16);
+    };
+    auto stage_commit = [&](int buf) {  // ... and park them in LDS once they are needed (a stripe later)
+#pragma unroll
+        for (int p = 0; p < 2; p++) *reinterpret_cast<uint4 *>(&fin[buf][p][lane * 16]) = pfv[p];
+    };
 
     // stripe origins, 64 stripes per register chunk (lane l <-> stripe c0 + l); the chunk below is prefetched
     auto load_chunk = [&](int c0, int &bq, int &br) {
@@ -916,12 +945,8 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
     }
     int sc1[2] = {S_NEG, S_NEG};     // scores of row t+1 (own column)
     int f1[2] = {0, 0};              // forward flags of row t+1
-    int f0[2] = {0, 0}, pf[2] = {0, 0};
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-        if (st_ok[p]) f0[p] = mat[p][size_t(Lt - 1) * d.pitch[p] + col];
-        if (Lt >= 2 && st_ok[p]) pf[p] = mat[p][size_t(Lt - 2) * d.pitch[p] + col];
-    }
+    stage_load(n_stripes - 1);
+    stage_commit((n_stripes - 1) & 1);
     uint32_t tie_used = 0;
 
     for (int s = n_stripes - 1; s >= 0; s--) {
@@ -949,11 +974,14 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
             zl[p] = bkc[p] & 0xffffff;   // swap target (absolute index in the other plane) or FK_NONE24
         }
         const int sh[2] = {plo[0] - lo[0], plo[1] - lo[1]};   // origin shift against the stripe above (first row)
-        uint8_t *rowp[2] = {mat[0] + size_t(t1) * d.pitch[0] + col, mat[1] + size_t(t1) * d.pitch[1] + col};
+        stage_load(s - 1);                                     // prefetch the stripe below into registers
+        asm volatile("" ::: "memory");
+        const uint8_t *fcur[2] = {fin[s & 1][0], fin[s & 1][1]};
+        int rowo[2] = {(t1 - t0) * d.pitch[0] + col, (t1 - t0) * d.pitch[1] + col};
 
         for (int t = t1; t >= t0; t--) {
             const bool first = (t == t1) && (s != n_stripes - 1);   // row t+1 is aligned to the stripe above
-            int best[2], lk[2];
+            int best[2], lk[2], f0[2];
             uint32_t bm[2];
             MP g[2];
 #pragma unroll
@@ -991,6 +1019,7 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
                 if (!valid[p]) { b = S_NEG; m = 0; }
                 best[p] = b;
                 bm[p] = m;
+                f0[p] = st_ok[p] ? int(fcur[p][rowo[p]]) : 0;   // forward flags of (x, t), staged a stripe ago
                 const int f0r = wave_shr1(f0[p], 0);   // forward flags of (x+1, t)
                 lk[p] = (f0r & F_INS) ? tp_right[p] : -1;
                 g[p].A = b; g[p].B = lk[p];
@@ -1011,19 +1040,22 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
                 outm[p] = m;
                 sc1[p] = v;          // becomes the "row t+1" score of the next iteration
                 f1[p] = f0[p];       // ... and its forward flags
-                f0[p] = pf[p];       // forward flags of row t-1 (requested one row ago)
+                if (st_ok[p]) fout[p][rowo[p]] = uint8_t(m);
+                rowo[p] -= d.pitch[p];
             }
-            // request row t-2 for both planes, then store this row's path_ptrs (loads before stores: the wait
-            // for pf never has to wait for a store younger than one row)
-#pragma unroll
-            for (int p = 0; p < 2; p++)
-                if (t > 1 && st_ok[p]) pf[p] = *(rowp[p] - 2 * ptrdiff_t(d.pitch[p]));
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                if (st_ok[p]) *rowp[p] = uint8_t(outm[p]);
-                rowp[p] -= d.pitch[p];
-            }
+            (void)outm;
         }
+        stage_commit((s - 1) & 1);   // the prefetched rows of the stripe below (requested a stripe ago)
+        // ---- flush this stripe's path_ptr rows (in place of the forward flags), 16 bytes per lane
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int nbytes = (t1 - t0 + 1) * d.pitch[p];
+            if (lane * 16 < nbytes)
+                *reinterpret_cast<uint4 *>(mat[p] + size_t(t0) * d.pitch[p] + lane * 16) =
+                    *reinterpret_cast<const uint4 *>(&fout[p][lane * 16]);
+        }
+        asm volatile("" ::: "memory");
         // ---- advance to the stripe below
         plo[0] = lo[0]; plo[1] = lo[1];
         lo[0] = nlo[0]; lo[1] = nlo[1];
