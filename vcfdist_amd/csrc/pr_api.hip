@@ -206,7 +206,7 @@ BandFwd band_fwd_kernel(int c) {
 BandBwd band_bwd_kernel(int c) {
     switch (c) {
         case 1:   // needs the stripe origins written by k_fwd_stripe
-            return getenv("VPR_NO_STRIPE") ? BandBwd(k_bwd_band<1>) : BandBwd(k_bwd_stripe);
+            return (getenv("VPR_NO_STRIPE") || getenv("VPR_NO_STRIPE_BWD")) ? BandBwd(k_bwd_band<1>) : BandBwd(k_bwd_stripe);
         case 4: return k_bwd_band<4>;
         default: return k_bwd_band<16>;
     }

@@ -98,14 +98,33 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_mov(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
 }
-// two independent inclusive prefix-min scans, interleaved
+// Two independent inclusive prefix-min scans over the wave, interleaved, as 12 v_min_i32_dpp: with
+// bound_ctrl off a lane whose DPP source does not exist is simply disabled and keeps its value.  hipcc emits
+// v_mov_dpp + s_nop + v_min for the builtin form (3x the instructions), and it cannot see the DPP read
+// inside an asm statement, so the two wait states a DPP read needs after a VALU write of the same register
+// are spelled out here (the other scan's step + one s_nop).
 __device__ __forceinline__ void wave_prefix_min2(int &a, int &b) {
-    a = min(a, dpp_mov<0x111, 0xf>(D_INF, a)); b = min(b, dpp_mov<0x111, 0xf>(D_INF, b));   // row_shr:1
-    a = min(a, dpp_mov<0x112, 0xf>(D_INF, a)); b = min(b, dpp_mov<0x112, 0xf>(D_INF, b));   // row_shr:2
-    a = min(a, dpp_mov<0x114, 0xf>(D_INF, a)); b = min(b, dpp_mov<0x114, 0xf>(D_INF, b));   // row_shr:4
-    a = min(a, dpp_mov<0x118, 0xf>(D_INF, a)); b = min(b, dpp_mov<0x118, 0xf>(D_INF, b));   // row_shr:8
-    a = min(a, dpp_mov<0x142, 0xa>(D_INF, a)); b = min(b, dpp_mov<0x142, 0xa>(D_INF, b));   // row_bcast:15
-    a = min(a, dpp_mov<0x143, 0xc>(D_INF, a)); b = min(b, dpp_mov<0x143, 0xc>(D_INF, b));   // row_bcast:31
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_min_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_min_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ int wave_shr1(int x, int fill) { return dpp_mov<0x138, 0xf>(fill, x); }   // lane i <- lane i-1
 
@@ -919,7 +938,8 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
     };
     auto stage_commit = [&](int buf) {  // ... and park them in LDS once they are needed (a stripe later)
 #pragma unroll
-        for (int p = 0; p < 2; p++) *reinterpret_cast<uint4 *>(&fin[buf][p][lane * 16]) = pfv[p];
+        for (int p = 0; p < 2; p++)
+            if (lane * 16 < FS_K * FS_W) *reinterpret_cast<uint4 *>(&fin[buf][p][lane * 16]) = pfv[p];
     };
 
     // stripe origins, 64 stripes per register chunk (lane l <-> stripe c0 + l); the chunk below is prefetched
