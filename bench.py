@@ -97,7 +97,10 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from vcfdist_amd import api, shard, _abi as A
-    api.build()
+    if rank == 0:
+        api.build()                 # no-op when the in-tree library is current (the driver builds it beforehand)
+    if dist is not None:
+        dist.barrier()
     syn = make_workload(api, args.n_sc, shard.rank_seed(args.seed, rank), args.workload)
     batch = syn.batch(copy=False)
     pr = api.PrecisionRecall(device=local_rank)

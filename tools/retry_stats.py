@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from vcfdist_amd import api, _abi as A
-syn = api.Synth(n_sc=200000, seed=0x5eed, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=10000)
+syn = api.Synth(n_sc=int(os.environ.get("NSC", "200000")), seed=0x5eed, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=10000)
 b = syn.batch(copy=False)
 L = np.diff(b.ref_off)
 pr = api.PrecisionRecall(); pr.upload(b); pr.execute(); t = pr.timing()

@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
     constexpr int W = 64 * C, RS = 2 * W, M = RS - 1;
     __shared__ int32_t Dr[2][2][RS];   // [row parity][plane][x & M]
     __shared__ int2 Kr[2][RS];         // [plane][x & M] packed constants
+    __shared__ int2 Er[2][RS];         // [plane][x & M] {reference coordinate, free-shift budget ahead}
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     const int lane = threadIdx.x;
@@ -163,6 +164,9 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
     const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
     const int2 *fk[2] = {B.fk_q[d.qs] + d.q_off, B.fk_r[d.qs] + d.r_off};
     const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
+    const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
+    const int32_t *vsp[2] = {B.vs_hap[d.qs] + d.q_off, B.vs_ref[d.qs] + d.r_off};   // free-shift budget ahead
+    const int32_t *vst = B.vs_hap[d.ts] + d.t_off;
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     int32_t *blo = blo_all + d.blo_off;
 
@@ -173,14 +177,22 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
     if (lane < Lt) { blo[lane] = cbQ; blo[Lt + lane] = cbR; }
     if (64 + lane < Lt) { blo[64 + lane] = nbQ; blo[Lt + 64 + lane] = nbR; }
     uint32_t tchunk = 0, tlast = 0;
-    if (lane < Lt) tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
+    int tauchunk = 0, vtchunk = 0;
+    if (lane < Lt) {
+        tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
+        tauchunk = t2r[lane];
+        vtchunk = vst[max(lane - 1, 0)];
+    }
 
     // constants ring: positions [0, khi] of each plane are resident
     int khi[2] = {-1, -1};
     auto fill = [&](int p, int upto) {
         while (khi[p] < upto) {
             const int x = khi[p] + 1 + lane;
-            if (x < Lp[p]) Kr[p][x & M] = fk[p][x];
+            if (x < Lp[p]) {
+                Kr[p][x & M] = fk[p][x];
+                Er[p][x & M] = make_int2(p == 0 ? q2r[x] : x, vsp[p][max(x - 1, 0)]);
+            }
             khi[p] += 64;
         }
     };
@@ -214,7 +226,11 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
                         const uint32_t swt = uint32_t(Kr[p][x & M].y) & 0xffffffu;
                         if (swt != FK_NONE24 && int(swt) < Lp[1 - p] && (int(swt) < nlo[1 - p] || int(swt) > nhi[1 - p])) ex = true;
                     }
-                    if (ex) exit_min = min(exit_min, x);
+                    if (ex) {
+                        const int2 e = Er[p][x & M];
+                        const int off = e.x - t2r[0];
+                        exit_min = min(exit_min, x + max((off < 0 ? -off : off) - e.y - vst[0], 0));
+                    }
                     if (Lt == 1 && x == Lp[p] - 1) endD[p] = x;
                 }
             }
@@ -242,8 +258,12 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
         if ((t & 63) == 0) {   // advance the truth / band chunks
             tlast = __builtin_amdgcn_readlane(tchunk, 63);
             const int tt = t + lane;
-            tchunk = 0;
-            if (tt < Lt) tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
+            tchunk = 0; tauchunk = 0; vtchunk = 0;
+            if (tt < Lt) {
+                tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
+                tauchunk = t2r[tt];
+                vtchunk = vst[tt - 1];
+            }
             cbQ = nbQ; cbR = nbR;
             band_origin<W>(t2r, r2q, t + 64 + lane, Lt, Lq, Lr, nbQ, nbR);
             if (t + 64 + lane < Lt) { blo[t + 64 + lane] = nbQ; blo[Lt + t + 64 + lane] = nbR; }
@@ -252,6 +272,8 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
         const uint32_t prv = ((t & 63) == 0) ? tlast : uint32_t(__builtin_amdgcn_readlane(tchunk, (t - 1) & 63));
         const uint32_t Tt = cur & 0xff;
         const bool at = fwd_allow(int((prv >> 8) & 0xff));
+        const int tau = __builtin_amdgcn_readlane(tauchunk, t & 63);
+        const int vt = __builtin_amdgcn_readlane(vtchunk, t & 63);
         const bool has_next = t + 1 < Lt;
         if (has_next) {
             if (((t + 1) & 63) == 0) { nlo[0] = __builtin_amdgcn_readlane(nbQ, 0); nlo[1] = __builtin_amdgcn_readlane(nbR, 0); }
@@ -379,7 +401,12 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
                 bool ex = (x == hi[p] && hi[p] < Lp[p] - 1);
                 ex = ex || (has_next && (x < nlo[p] || (x + 1 <= Lp[p] - 1 && x + 1 > nhi[p])));
                 ex = ex || (has_next && z != FK_NONE24 && z < Lp[o] && (z < nlo[o] || z > nhi[o]));
-                exit_min = (valid && ex) ? min(exit_min, Dn) : exit_min;
+                // a path through an exit cell costs at least D + what the diagonal offset rho - tau still
+                // costs beyond the indel sizes ahead (see k_fwd_stripe)
+                const int2 e = Er[p][x & M];
+                const int doff = e.x - tau;
+                const int lb = max((doff < 0 ? -doff : doff) - e.y - vt, 0);
+                exit_min = (valid && ex) ? min(exit_min, Dn + lb) : exit_min;
                 endD[p] = (valid && t == Lt - 1 && x == Lp[p] - 1) ? Dn : endD[p];
             }
             if (x0 <= hi[p]) {
