@@ -107,9 +107,11 @@ def main():
     pr.upload(batch)                    # inputs resident in HBM before the timed region
     dev = torch.device("cuda", local_rank)
 
+    host_res = [None]
+
     def step():
         pr.execute()                    # K1..K5 on the device
-        res = pr.download()             # final per-variant / per-supercluster results to host memory
+        host_res[0] = res = pr.download(host_res[0])   # final results to (reused) host buffers
         t = torch.from_numpy(pr.tally()).to(dev)
         if dist is not None:
             dist.all_reduce(t)          # the one collective of the path: TP/FP/FN tallies (int64 sum)

@@ -191,3 +191,27 @@ def test_full_size_property_swapped_haps_swap_phase():
     # truth hap 1 results under swap slot w of run 1 == under slot 1-w of run 2
     for w in range(2):
         assert np.array_equal(r1.errtype[2][w], r2.errtype[2][1 - w])
+
+
+def test_gpu_matches_committed_regression_fixture():
+    """GPU results against tests/golden/regression_seed7.npz (oracle-generated, committed)."""
+    import importlib.util
+    import os
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_regression", os.path.join(gd, "make_regression.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(gd, "regression_seed7.npz"))
+    batch = api.Synth(**mod.PARAMS).batch()
+    r = api.PrecisionRecall().run(batch)
+    tied_sc = g["nonmax_tie"].reshape(-1, 4).sum(axis=1) > 0
+    assert np.array_equal(r.aln_dist, g["aln_dist"]) and np.array_equal(r.aln_end_plane, g["aln_end_plane"])
+    assert np.array_equal(r.sc_phase, g["sc_phase"])
+    for h in range(4):
+        keep = ~tied_sc[np.repeat(np.arange(batch.n_sc), np.diff(batch.var_off[h]))]
+        for w in range(2):
+            for name, dt in r.PER_VAR:
+                x, y = getattr(r, name)[h][w], g[f"{name}_{h}_{w}"]
+                if dt == np.float32:
+                    x, y = x.view(np.uint32), y.view(np.uint32)
+                assert np.array_equal(x[keep], y[keep]), (name, h, w)

@@ -146,3 +146,42 @@ def test_dropped_truth_variant_is_fp_and_missing_query_is_fn():
     assert r2.errtype[2][0].tolist() == [A.ERRTYPE_TP, A.ERRTYPE_FN]
     assert r2.callq[2][0].tolist() == [50.0, 60.0]
     assert r2.aln_dist.tolist() == [1, 1, 1, 1]
+
+
+def test_golden_toy_vector_file():
+    """tests/golden/toy_a1.json (reference-produced) against the oracle."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "toy_a1.json")))
+    T = {"SUB": S, "INS": I, "DEL": D}
+    qv = [(p, T[t], r, a, 30.0) for p, t, r, a in g["query_variants"]]
+    tv = [(p, T[t], r, a, 30.0) for p, t, r, a in g["truth_variants"]]
+    v = A.Variants.from_sites([g["ref"]], [dict(ctg=0, beg=g["region"][0], end=g["region"][1], vars=[qv, qv, tv, tv])])
+    b = O.generate(v)
+    assert bytes(b.hap_seq[0]).decode() == g["query_str"]
+    assert b.hap_ptr[0].tolist() == g["q2r_ptrs"] and b.hap_flag[0].tolist() == g["q2r_flags"]
+    assert b.ref_ptr[0].tolist() == g["r2q_ptrs"] and b.ref_flag[0].tolist() == g["r2q_flags"]
+    r = O.run(b)
+    assert r.aln_dist.tolist() == g["s"]
+    assert [("QUERY", "REF")[e] for e in r.aln_end_plane] == g["end_plane"]
+
+
+def test_oracle_regression_fixture():
+    """The oracle still produces tests/golden/regression_seed7.npz (guards the checker itself)."""
+    import os
+    sys_path = os.path.join(os.path.dirname(__file__), "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_regression", os.path.join(sys_path, "make_regression.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from vcfdist_amd import api
+    g = np.load(os.path.join(sys_path, "regression_seed7.npz"))
+    r = O.run(api.Synth(**mod.PARAMS).batch())
+    assert np.array_equal(r.aln_dist, g["aln_dist"]) and np.array_equal(r.sc_phase, g["sc_phase"])
+    for h in range(4):
+        for w in range(2):
+            for name, dt in r.PER_VAR:
+                x, y = getattr(r, name)[h][w], g[f"{name}_{h}_{w}"]
+                if dt == np.float32:
+                    x, y = x.view(np.uint32), y.view(np.uint32)
+                assert np.array_equal(x, y), (name, h, w)

@@ -192,8 +192,11 @@ class PrecisionRecall:
     def execute(self):
         self._chk(lib().vpr_execute(self._h), "vpr_execute")
 
-    def download(self) -> A.Results:
-        res = A.Results.for_batch(self._batch)
+    def download(self, res: A.Results = None) -> A.Results:
+        """Copy the results of the last execute to host memory.  Pass a previous Results to reuse its
+        buffers (every field is overwritten), which avoids re-allocating hundreds of MB per call."""
+        if res is None:
+            res = A.Results.for_batch(self._batch)
         s = res.as_struct()
         self._chk(lib().vpr_download(self._h, C.byref(s)), "vpr_download")
         return res

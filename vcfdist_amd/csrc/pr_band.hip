@@ -451,17 +451,48 @@ __global__ void k_fwd_band_finish(const int32_t *__restrict__ work, int n, AlnOu
 // the max-plus maps carrying the in-row INS chain is a *prefix* scan in lane order and can use the same
 // DPP pattern as the forward kernel.
 // ---------------------------------------------------------------------------
+// Inclusive prefix composition (lane order) of two independent sequences of max-plus maps
+//   x -> max(A, x + B)      (B < 0: "link broken", the map is the constant A; A = S_NEG: unreachable),
+// compose(cur, prev) = cur after prev.  Inside the scan the pairs are re-encoded so that 0 is the identity of
+// both operations and a DPP source that does not exist (bound_ctrl -> reads 0) needs no special case:
+//   A' = A + MP_OFF for a reachable score, a value < MP_OFF (0..64) for an unreachable one;
+//   B' = B for a live link, -2*MP_OFF for a broken one (64 of them still fit in an int32).
+// One step is then   t = dpp(A') + B';  B' += dpp(B');  A' = max(A', t)   = 3 VALU per sequence, written as
+// asm because hipcc expands the builtin form to 3-4x as many instructions (and, not seeing the DPP reads,
+// cannot place the two wait states a DPP read needs after a VALU write of the same register).
+#define MP_OFF (1 << 20)
 __device__ __forceinline__ void wave_prefix_mp2(MP &a, MP &b) {
-#define MP_STEP(CTRL, RM)                                                                          \
-    {                                                                                              \
-        MP ta, tb;                                                                                 \
-        ta.A = dpp_mov<CTRL, RM>(S_NEG, a.A); ta.B = dpp_mov<CTRL, RM>(0, a.B);                    \
-        tb.A = dpp_mov<CTRL, RM>(S_NEG, b.A); tb.B = dpp_mov<CTRL, RM>(0, b.B);                    \
-        a = mp_compose(a, ta); b = mp_compose(b, tb);                                              \
-    }
-    MP_STEP(0x111, 0xf) MP_STEP(0x112, 0xf) MP_STEP(0x114, 0xf) MP_STEP(0x118, 0xf)
-    MP_STEP(0x142, 0xa) MP_STEP(0x143, 0xc)
+    int Aq = (a.A < 0) ? 0 : a.A + MP_OFF, Bq = (a.B < 0) ? -2 * MP_OFF : a.B;
+    int Ar = (b.A < 0) ? 0 : b.A + MP_OFF, Br = (b.B < 0) ? -2 * MP_OFF : b.B;
+    int tq, tr;
+#define MP_STEP(CTRL)                                                                           \
+        "v_add_u32_dpp %4, %0, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
+        "v_add_u32_dpp %5, %2, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
+        "v_add_u32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
+        "v_add_u32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
+        "v_max_i32 %0, %0, %4\n\t"                                                              \
+        "v_max_i32 %2, %2, %5\n\t"                                                              \
+        "s_nop 0\n\t"
+    // row_bcast steps: lanes of the rows that are not selected are disabled; their stale t is <= A'
+    // (A' already absorbed it in the previous step), so the following v_max is a no-op for them
+#define MP_BCAST(CTRL, RM)                                                                      \
+        "v_add_u32_dpp %4, %0, %1 " CTRL " row_mask:" RM " bank_mask:0xf\n\t"                   \
+        "v_add_u32_dpp %5, %2, %3 " CTRL " row_mask:" RM " bank_mask:0xf\n\t"                   \
+        "v_add_u32_dpp %1, %1, %1 " CTRL " row_mask:" RM " bank_mask:0xf\n\t"                   \
+        "v_add_u32_dpp %3, %3, %3 " CTRL " row_mask:" RM " bank_mask:0xf\n\t"                   \
+        "v_max_i32 %0, %0, %4\n\t"                                                              \
+        "v_max_i32 %2, %2, %5\n\t"                                                              \
+        "s_nop 0\n\t"
+    asm volatile(
+        "s_nop 1\n\t"
+        MP_STEP("row_shr:1") MP_STEP("row_shr:2") MP_STEP("row_shr:4") MP_STEP("row_shr:8")
+        MP_BCAST("row_bcast:15", "0xa") MP_BCAST("row_bcast:31", "0xc")
+        "s_nop 0"
+        : "+v"(Aq), "+v"(Bq), "+v"(Ar), "+v"(Br), "=&v"(tq), "=&v"(tr));
 #undef MP_STEP
+#undef MP_BCAST
+    a.A = (Aq >= MP_OFF) ? Aq - MP_OFF : S_NEG; a.B = (Bq < 0) ? -1 : Bq;
+    b.A = (Ar >= MP_OFF) ? Ar - MP_OFF : S_NEG; b.B = (Br < 0) ? -1 : Br;
 }
 
 template <int C>
