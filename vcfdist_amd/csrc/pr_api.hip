@@ -721,7 +721,32 @@ int vpr_execute(vpr_handle *h) {
                 if (rc) return rc;
                 // long part (or a small launch of long retries): wave-per-alignment walk; windows up to 256
                 const bool wave_walk = C <= 4 && (part == 0 || cnt < 2048);
-                if ((rc = walk_launch(list, cnt, ks, wave_walk))) return rc;
+                const bool row_walk = C == 1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") &&
+                                      !getenv("VPR_NO_ROWWALK") && (wave_walk || getenv("VPR_ROWWALK_ALL"));
+                if (row_walk) {
+                    // striped layout, long alignments: row-sweep walk (phase A) + credit walk (phase B); for the
+                    // short ones the per-wave setup outweighs the pointer chase of the lane-per-alignment walk
+                    vpr_launch_stat ws_;
+                    memset(&ws_, 0, sizeof(ws_));
+                    ws_.threads = 64; ws_.n_units = cnt; ws_.cells_per_thread = 2;
+                    rc = timed(3, ws_, ks, [&] {
+                        hipLaunchKernelGGL(k_walk_rows, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                           h->d_arena, arena_i32, h->d_outs, arena_path);
+                    });
+                    if (rc) return rc;
+                    ws_.cells_per_thread = 3;
+                    rc = timed(3, ws_, ks, [&] {
+                        if (wave_walk)
+                            hipLaunchKernelGGL(k_credit<true>, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                               h->d_outs, arena_path, h->d_secs, h->d_fp_table, h->d_jobs, h->d_njobs,
+                                               h->jobs_cap);
+                        else
+                            hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
+                                               list, cnt, h->d_outs, arena_path, h->d_secs, h->d_fp_table, h->d_jobs,
+                                               h->d_njobs, h->jobs_cap);
+                    });
+                    if (rc) return rc;
+                } else if ((rc = walk_launch(list, cnt, ks, wave_walk))) return rc;
                 hipLaunchKernelGGL(k_collect_fails, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs,
                                    h->d_fail, h->d_cnt);
                 HIPCHK(h, hipEventRecord(h->ev_join[part], ks));

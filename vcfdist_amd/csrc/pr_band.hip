@@ -1149,3 +1149,165 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
     if (lane == 0) outs[a].beg_plane = (bs >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
     if (tie_used) atomicOr(&outs[a].status, VPR_ST_SWAP_TIE);
 }
+
+// ===========================================================================
+// K3r: the forward walk of get_prec_recall_path_sync (dist.cpp:865-998) as a sweep over truth rows, one
+// wavefront per alignment, for the striped 64-cell layout of k_fwd_stripe / k_bwd_stripe.
+//
+// Inside one row the walk can only take INS moves (every other move consumes a truth base), and it takes
+// one exactly when INS is the highest-priority move left in the cell's path_ptr byte (priority
+// REF-plane swap > MAT > SUB > INS > DEL > QUERY-plane swap, dist.cpp:907-935).  So the cells visited in row t
+// are the entry cell e plus the run of "INS-only" cells that follows it: a ballot over the window row and a
+// count-trailing-ones give the run, the lanes of the run store their path entries side by side (coalesced),
+// and one readlane of the run's last cell decides the move into row t+1.  Rows are read once, coalesced, from
+// the stripe's 16-byte LDS staging - no per-step pointer chase through HBM.
+// ===========================================================================
+__global__ void __launch_bounds__(64) k_walk_rows(DevBatch B, const AlnDesc *__restrict__ descs,
+                                                  const int32_t *__restrict__ work, int n_work,
+                                                  const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
+                                                  AlnOut *__restrict__ outs, PathEnt *__restrict__ paths) {
+    if (int(blockIdx.x) >= n_work) return;
+    const int a = work[blockIdx.x];
+    const AlnDesc d = descs[a];
+    AlnOut &O = outs[a];
+    if (!O.band_ok) return;
+    const int lane = threadIdx.x;
+    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
+    const int Lp[2] = {Lq, Lr};
+    const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
+    const uint8_t *qfl = B.hap_flag[d.qs] + d.q_off;
+    const int32_t *t2r = B.hap_ptr[d.ts] + d.t_off;
+    const uint8_t *tfl = B.hap_flag[d.ts] + d.t_off;
+    const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
+    const uint8_t *insQ = B.has_ins[d.qs] + d.r_off;
+    const uint8_t *insT = B.has_ins[d.ts] + d.r_off;
+    const uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
+    const int32_t *blo = blo_all + d.blo_off;
+    PathEnt *path = paths + d.path_off;
+    const int n_stripes = (Lt + FS_K - 1) / FS_K;
+    __shared__ __align__(16) uint8_t pin[2][2][FS_K * FS_W];   // [buffer][plane] path_ptr rows of a stripe
+
+    // ---- staging of the path_ptr rows, one stripe ahead (16 B per lane and plane)
+    uint4 pfv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    auto stage_load = [&](int s_) {
+        if (s_ >= n_stripes) return;
+        const int ta = s_ * FS_K, nr = min(ta + FS_K, Lt) - ta;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            if (lane * 16 < nr * d.pitch[p])
+                pfv[p] = *reinterpret_cast<const uint4 *>(mat[p] + size_t(ta) * d.pitch[p] + lane * 16);
+    };
+    auto stage_commit = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            if (lane * 16 < FS_K * FS_W) *reinterpret_cast<uint4 *>(&pin[buf][p][lane * 16]) = pfv[p];
+    };
+    // ---- per-row constants of 64 truth rows at a time (lane l <-> row (t & ~63) + l)
+    int tflc = 0, t2rc = 0, insc = 0;
+    auto load_rows = [&](int tb) {
+        tflc = 0; t2rc = 0; insc = 0;
+        const int tt = tb + lane;
+        if (tt < Lt) {
+            tflc = tfl[tt];
+            t2rc = t2r[tt];
+            insc = insQ[t2rc] | insT[t2rc];
+        }
+    };
+    // ---- per-column constants of the current stripe (lane l <-> column lo_p + l)
+    int cq2r = 0, cqfl = 0, cinsq = 0, cr2q = 0, cinsr = 0;
+    auto load_cols = [&](int loQ, int loR) {
+        cq2r = 0; cqfl = 0; cinsq = 0; cr2q = 0; cinsr = 0;
+        const int xq = loQ + lane, xr = loR + lane;
+        if (xq < Lq) { cq2r = q2r[xq]; cqfl = qfl[xq]; cinsq = insQ[cq2r] | insT[cq2r]; }
+        if (xr < Lr) { cr2q = r2q[xr]; cinsr = insQ[xr] | insT[xr]; }
+    };
+
+    stage_load(0);
+    stage_commit(0);
+    load_rows(0);
+    int lo[2] = {blo[0], blo[Lt]};
+    load_cols(lo[0], lo[1]);
+
+    int hi = O.beg_plane, e = 0;          // plane and column of the entry cell of the current row
+    int64_t n = 0;
+    uint32_t status = 0;
+    int mv_in = 0;                         // move that entered the current row (0: the start cell)
+    uint32_t edit_in = 0;
+    bool ok = true;
+
+    for (int s = 0; s < n_stripes && ok; s++) {
+        const int t0 = s * FS_K, rows = min(FS_K, Lt - t0);
+        stage_load(s + 1);                 // next stripe's rows into registers
+        int nlo[2] = {0, 0};
+        if (s + 1 < n_stripes) { nlo[0] = blo[(s + 1) * FS_K]; nlo[1] = blo[Lt + (s + 1) * FS_K]; }
+        asm volatile("" ::: "memory");
+        const uint8_t *pcurQ = pin[s & 1][0], *pcurR = pin[s & 1][1];
+        for (int r = 0; r < rows; r++) {
+            const int t = t0 + r;
+            if ((t & 63) == 0 && t > 0) load_rows(t);
+            const int el = e - lo[hi];
+            if (el < 0 || el > 63 || e >= Lp[hi]) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+            // sync flag of the entry cell, dist.cpp:949-968 (only a diagonal move can make a sync point)
+            uint32_t sync_in = 1;
+            if (mv_in != 0) {
+                const int tflv = __builtin_amdgcn_readlane(tflc, t & 63);
+                const int trv = __builtin_amdgcn_readlane(t2rc, t & 63);
+                const int insrow = __builtin_amdgcn_readlane(insc, t & 63);
+                int qflv = 0, qr, inscell;
+                if (hi == 0) {
+                    qflv = __builtin_amdgcn_readlane(cqfl, el);
+                    qr = __builtin_amdgcn_readlane(cq2r, el);
+                    inscell = __builtin_amdgcn_readlane(cinsq, el);
+                } else {
+                    qr = e;
+                    inscell = __builtin_amdgcn_readlane(cinsr, el);
+                }
+                const bool in_t = (tflv & PV) && !(tflv & PB);
+                const bool in_q = (qflv & PV) && !(qflv & PB);
+                sync_in = (!in_t && !in_q && !(insrow | inscell) && trv == qr && (mv_in & (F_MAT | F_SWP | F_SUB))) ? 1u : 0u;
+            }
+            // the run of INS-only cells that starts at the entry cell
+            const int pq = (lane < d.pitch[0]) ? int(pcurQ[r * d.pitch[0] + lane]) : 0;
+            const int pr = (lane < d.pitch[1]) ? int(pcurR[r * d.pitch[1] + lane]) : 0;
+            const int pc = (hi == 0) ? pq : pr;
+            const bool ins_only = (pc & F_INS) && !(pc & (F_MAT | F_SUB)) && !(hi == 1 && (pc & F_SWP));
+            const unsigned long long m = __ballot(ins_only) >> el;
+            const int k = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
+            const int c = e + k;                                  // last cell visited in this row
+            if (c - lo[hi] > 63 || c >= Lp[hi]) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+            if (n + k + 1 > d.path_cap) { status |= VPR_ST_ERR_LIMIT; ok = false; break; }
+            if (lane >= el && lane <= el + k) {
+                const int x = lo[hi] + lane;
+                PathEnt pe;
+                pe.a = uint32_t(x) | (uint32_t(hi) << 31);
+                pe.b = uint32_t(t) | ((lane == el) ? ((sync_in << 31) | (edit_in << 30)) : (1u << 30));
+                pe.qref = (hi == 0) ? cq2r : x;
+                pe.tref = __builtin_amdgcn_readlane(t2rc, t & 63);
+                path[n + (lane - el)] = pe;
+            }
+            n += k + 1;
+            if (t == Lt - 1) {                                    // the walk ends at the end cell of its plane
+                if (c != Lp[hi] - 1) { status |= VPR_ST_ERR_NO_PTR; ok = false; }
+                break;
+            }
+            // move out of the row from cell c, by priority
+            const int cl = c - lo[hi];
+            const int p = __builtin_amdgcn_readlane(pc, cl) & 31;
+            if (hi == 1 && (p & F_SWP)) { mv_in = F_SWP; e = __builtin_amdgcn_readlane(cr2q, cl) + 1; hi = 0; edit_in = 0; }
+            else if (p & F_MAT) { mv_in = F_MAT; e = c + 1; edit_in = 0; }
+            else if (p & F_SUB) { mv_in = F_SUB; e = c + 1; edit_in = 1; }
+            else if (p & F_DEL) { mv_in = F_DEL; e = c; edit_in = 1; }
+            else if (hi == 0 && (p & F_SWP)) { mv_in = F_SWP; e = __builtin_amdgcn_readlane(cq2r, cl) + 1; hi = 1; edit_in = 0; }
+            else { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+        }
+        // advance to the next stripe: commit its staged rows, reload the per-column constants
+        stage_commit((s + 1) & 1);
+        asm volatile("" ::: "memory");
+        if (s + 1 < n_stripes && (nlo[0] != lo[0] || nlo[1] != lo[1])) { lo[0] = nlo[0]; lo[1] = nlo[1]; load_cols(lo[0], lo[1]); }
+    }
+    if (lane == 0) {
+        O.path_len = int32_t(n);
+        if (!ok) { O.n_sec = 0; }
+        if (status) atomicOr(&O.status, status);
+    }
+}

@@ -611,110 +611,19 @@ __device__ int small_ed(const uint8_t *a, int m, const uint8_t *b, int n) {
     return row[n];
 }
 
-// WAVE = false: one lane per alignment (64 alignments per wave), flags read straight from HBM.
-// WAVE = true : one wavefront per alignment for the long ones; every lane runs the same (uniform) walk, the
-//               window rows of the path_ptr matrices are staged through an LDS tile with coalesced 16-byte
-//               loads, and lane 0 does the stores.  The walk is a chain of dependent steps, so the long
-//               alignments are latency-bound: an LDS hit per step instead of an HBM round trip.
-#define WALK_TR 32          // rows per LDS tile
-#define WALK_TW 256         // widest window staged (band C = 1 or 4)
+// Phase B of K3: the backward credit walk of calc_prec_recall (dist.cpp:1035-1400) over a stored path.
+// WAVE: every lane runs the same walk (one wavefront per alignment), lane 0 stores.
 template <bool WAVE>
-__global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restrict__ descs,
-                       const int32_t *__restrict__ work, int n_work,
-                       const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
-                       AlnOut *__restrict__ outs,
-                       PathEnt *__restrict__ paths, Section *__restrict__ secs,
-                       int32_t *const *__restrict__ fp_group /* [2 query haps * 2 swaps] */,
-                       EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap) {
-    __shared__ __align__(16) uint8_t tile[WAVE ? 2 * WALK_TR * WALK_TW : 16];
-    __shared__ int32_t tblo[WAVE ? 2 * WALK_TR : 2];
-    const int wi = WAVE ? int(blockIdx.x) : int(blockIdx.x * blockDim.x + threadIdx.x);
-    if (wi >= n_work) return;
-    const int lane = threadIdx.x & 63;
-    const bool lead = !WAVE || lane == 0;
-    const int a = work[wi];
-    const AlnDesc d = descs[a];
-    AlnOut &O = outs[a];
-    if (d.band_w > 0 && !O.band_ok) return;   // rejected banded attempt: re-run with a wider window
-    const int qi = 0, ri = 1;   // planes
+__device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d, AlnOut &O, const int a,
+                                            const PathEnt *__restrict__ path, const int64_t n, uint32_t status,
+                                            Section *__restrict__ secs, int32_t *const *__restrict__ fp_group,
+                                            EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap,
+                                            const bool lead) {
+    const int qi = 0, ri = 1;
     const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
-    const uint8_t *qfl = B.hap_flag[d.qs] + d.q_off;
     const int32_t *t2r = B.hap_ptr[d.ts] + d.t_off;
-    const uint8_t *tfl = B.hap_flag[d.ts] + d.t_off;
-    const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
-    const uint8_t *insQ = B.has_ins[d.qs] + d.r_off;
-    const uint8_t *insT = B.has_ins[d.ts] + d.r_off;
-    const uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     const int q_size = d.Lq, r_size = d.Lr, t_size = d.Lt;
-    const bool banded = d.band_w > 0;   // rows hold cells [blo[t], blo[t]+band_w) of each plane
-    const int32_t *blo = blo_all + d.blo_off;
-    PathEnt *path = paths + d.path_off;
-    uint32_t status = 0;
-    int tile_t0 = -(1 << 30);   // first truth row held by the LDS tile (WAVE only)
-
-    // ---- forward walk, dist.cpp:865-998
-    int hi = O.beg_plane, qri = 0, ti = 0;
-    int64_t n = 0;
-    if (lead) path[0] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31), uint32_t(ti) | (1u << 31),
-                                (hi == ri) ? 0 : q2r[0], t2r[0]};   // sync, no edit
-    n = 1;
-    bool ok = true;
-    while ((hi == ri && qri < r_size - 1) || (hi == qi && qri < q_size - 1) || ti < t_size - 1) {
-        int p;
-        if (WAVE) {
-            if (ti >= tile_t0 + WALK_TR) {   // stage the next WALK_TR rows of both planes (uniform branch)
-                tile_t0 = ti;
-                const int rows = min(WALK_TR, t_size - ti);
-#pragma unroll
-                for (int pl = 0; pl < 2; pl++) {
-                    const int nbytes = rows * d.pitch[pl];
-                    const uint8_t *src = mat[pl] + size_t(ti) * d.pitch[pl];
-                    for (int k = lane * 16; k < nbytes; k += 64 * 16)
-                        *reinterpret_cast<uint4 *>(tile + pl * WALK_TR * WALK_TW + k) = *reinterpret_cast<const uint4 *>(src + k);
-                    if (lane < rows) tblo[pl * WALK_TR + lane] = blo[pl * t_size + ti + lane];
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            }
-            const int r = ti - tile_t0;
-            const int col = qri - tblo[hi * WALK_TR + r];
-            if (col < 0 || col >= d.band_w) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
-            p = tile[hi * WALK_TR * WALK_TW + r * d.pitch[hi] + col] & 31;
-        } else {
-            const int col = banded ? qri - blo[hi * t_size + ti] : qri;
-            if (banded && (col < 0 || col >= d.band_w)) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
-            p = mat[hi][size_t(ti) * d.pitch[hi] + col] & 31;
-        }
-        int mv; uint32_t edit = 0;
-        if (hi == ri && (p & F_SWP)) { mv = F_SWP; hi = qi; qri = r2q[qri]; qri++; ti++; }
-        else if (p & F_MAT) { mv = F_MAT; qri++; ti++; }
-        else if (p & F_SUB) { mv = F_SUB; qri++; ti++; edit = 1; }
-        else if (p & F_INS) { mv = F_INS; qri++; edit = 1; }
-        else if (p & F_DEL) { mv = F_DEL; ti++; edit = 1; }
-        else if (hi == qi && (p & F_SWP)) { mv = F_SWP; hi = ri; qri = q2r[qri]; qri++; ti++; }
-        else { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
-        // dist.cpp:941 breaks out here with edits one entry longer than sync; a valid optimal path never
-        // leaves the matrix, so report it like the reference's other walk failure
-        if ((hi == qi && qri >= q_size) || (hi == ri && qri >= r_size) || ti >= t_size) {
-            status |= VPR_ST_ERR_NO_PTR; ok = false; break;
-        }
-        const int consumes = mv & (F_MAT | F_SWP | F_SUB | F_DEL);
-        bool in_t = tfl[ti] & PV;
-        if (consumes) in_t = in_t && !(tfl[ti] & PB);
-        bool in_q = (hi == ri) ? false : bool(qfl[qri] & PV);
-        if (hi == qi && consumes) in_q = in_q && !(qfl[qri] & PB);
-        const int tr = t2r[ti];
-        const int qr = (hi == ri) ? qri : q2r[qri];
-        const bool ins_loc = (insQ[tr] | insT[tr] | insQ[qr] | insT[qr]) != 0;
-        const bool sync = !in_t && !in_q && !ins_loc && tr == qr && (mv & (F_MAT | F_SWP | F_SUB));
-        if (n >= d.path_cap) { status |= VPR_ST_ERR_LIMIT; ok = false; break; }
-        if (lead) path[n] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31),
-                                    uint32_t(ti) | (uint32_t(sync) << 31) | (edit << 30), qr, tr};
-        n++;
-    }
-    if (lead) O.path_len = int32_t(n);
-    if (!ok) { if (lead) { atomicOr(&O.status, status); O.n_sec = 0; } return; }
-    if (WAVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // lane 0's path stores are read back below
-
+    (void)qi;
     // The reference keeps three parallel vectors: path (P entries), sync and edits (P+1 entries, the last
     // being the forced final sync with edit=false).  Here entry k carries sync[k], edits[k] for k < n = P;
     // the virtual entry n is (sync=1, edit=0).
@@ -829,6 +738,131 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
         O.n_sec = n_sec;
         if (status) atomicOr(&O.status, status);
     }
+}
+
+// WAVE = false: one lane per alignment (64 alignments per wave), flags read straight from HBM.
+// WAVE = true : one wavefront per alignment for the long ones; every lane runs the same (uniform) walk, the
+//               window rows of the path_ptr matrices are staged through an LDS tile with coalesced 16-byte
+//               loads, and lane 0 does the stores.  The walk is a chain of dependent steps, so the long
+//               alignments are latency-bound: an LDS hit per step instead of an HBM round trip.
+#define WALK_TR 32          // rows per LDS tile
+#define WALK_TW 256         // widest window staged (band C = 1 or 4)
+template <bool WAVE>
+__global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restrict__ descs,
+                       const int32_t *__restrict__ work, int n_work,
+                       const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
+                       AlnOut *__restrict__ outs,
+                       PathEnt *__restrict__ paths, Section *__restrict__ secs,
+                       int32_t *const *__restrict__ fp_group /* [2 query haps * 2 swaps] */,
+                       EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap) {
+    __shared__ __align__(16) uint8_t tile[WAVE ? 2 * WALK_TR * WALK_TW : 16];
+    __shared__ int32_t tblo[WAVE ? 2 * WALK_TR : 2];
+    const int wi = WAVE ? int(blockIdx.x) : int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (wi >= n_work) return;
+    const int lane = threadIdx.x & 63;
+    const bool lead = !WAVE || lane == 0;
+    const int a = work[wi];
+    const AlnDesc d = descs[a];
+    AlnOut &O = outs[a];
+    if (d.band_w > 0 && !O.band_ok) return;   // rejected banded attempt: re-run with a wider window
+    const int qi = 0, ri = 1;   // planes
+    const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
+    const uint8_t *qfl = B.hap_flag[d.qs] + d.q_off;
+    const int32_t *t2r = B.hap_ptr[d.ts] + d.t_off;
+    const uint8_t *tfl = B.hap_flag[d.ts] + d.t_off;
+    const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
+    const uint8_t *insQ = B.has_ins[d.qs] + d.r_off;
+    const uint8_t *insT = B.has_ins[d.ts] + d.r_off;
+    const uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
+    const int q_size = d.Lq, r_size = d.Lr, t_size = d.Lt;
+    const bool banded = d.band_w > 0;   // rows hold cells [blo[t], blo[t]+band_w) of each plane
+    const int32_t *blo = blo_all + d.blo_off;
+    PathEnt *path = paths + d.path_off;
+    uint32_t status = 0;
+    int tile_t0 = -(1 << 30);   // first truth row held by the LDS tile (WAVE only)
+
+    // ---- forward walk, dist.cpp:865-998
+    int hi = O.beg_plane, qri = 0, ti = 0;
+    int64_t n = 0;
+    if (lead) path[0] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31), uint32_t(ti) | (1u << 31),
+                                (hi == ri) ? 0 : q2r[0], t2r[0]};   // sync, no edit
+    n = 1;
+    bool ok = true;
+    while ((hi == ri && qri < r_size - 1) || (hi == qi && qri < q_size - 1) || ti < t_size - 1) {
+        int p;
+        if (WAVE) {
+            if (ti >= tile_t0 + WALK_TR) {   // stage the next WALK_TR rows of both planes (uniform branch)
+                tile_t0 = ti;
+                const int rows = min(WALK_TR, t_size - ti);
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                    const int nbytes = rows * d.pitch[pl];
+                    const uint8_t *src = mat[pl] + size_t(ti) * d.pitch[pl];
+                    for (int k = lane * 16; k < nbytes; k += 64 * 16)
+                        *reinterpret_cast<uint4 *>(tile + pl * WALK_TR * WALK_TW + k) = *reinterpret_cast<const uint4 *>(src + k);
+                    if (lane < rows) tblo[pl * WALK_TR + lane] = blo[pl * t_size + ti + lane];
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            const int r = ti - tile_t0;
+            const int col = qri - tblo[hi * WALK_TR + r];
+            if (col < 0 || col >= d.band_w) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+            p = tile[hi * WALK_TR * WALK_TW + r * d.pitch[hi] + col] & 31;
+        } else {
+            const int col = banded ? qri - blo[hi * t_size + ti] : qri;
+            if (banded && (col < 0 || col >= d.band_w)) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+            p = mat[hi][size_t(ti) * d.pitch[hi] + col] & 31;
+        }
+        int mv; uint32_t edit = 0;
+        if (hi == ri && (p & F_SWP)) { mv = F_SWP; hi = qi; qri = r2q[qri]; qri++; ti++; }
+        else if (p & F_MAT) { mv = F_MAT; qri++; ti++; }
+        else if (p & F_SUB) { mv = F_SUB; qri++; ti++; edit = 1; }
+        else if (p & F_INS) { mv = F_INS; qri++; edit = 1; }
+        else if (p & F_DEL) { mv = F_DEL; ti++; edit = 1; }
+        else if (hi == qi && (p & F_SWP)) { mv = F_SWP; hi = ri; qri = q2r[qri]; qri++; ti++; }
+        else { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+        // dist.cpp:941 breaks out here with edits one entry longer than sync; a valid optimal path never
+        // leaves the matrix, so report it like the reference's other walk failure
+        if ((hi == qi && qri >= q_size) || (hi == ri && qri >= r_size) || ti >= t_size) {
+            status |= VPR_ST_ERR_NO_PTR; ok = false; break;
+        }
+        const int consumes = mv & (F_MAT | F_SWP | F_SUB | F_DEL);
+        bool in_t = tfl[ti] & PV;
+        if (consumes) in_t = in_t && !(tfl[ti] & PB);
+        bool in_q = (hi == ri) ? false : bool(qfl[qri] & PV);
+        if (hi == qi && consumes) in_q = in_q && !(qfl[qri] & PB);
+        const int tr = t2r[ti];
+        const int qr = (hi == ri) ? qri : q2r[qri];
+        const bool ins_loc = (insQ[tr] | insT[tr] | insQ[qr] | insT[qr]) != 0;
+        const bool sync = !in_t && !in_q && !ins_loc && tr == qr && (mv & (F_MAT | F_SWP | F_SUB));
+        if (n >= d.path_cap) { status |= VPR_ST_ERR_LIMIT; ok = false; break; }
+        if (lead) path[n] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31),
+                                    uint32_t(ti) | (uint32_t(sync) << 31) | (edit << 30), qr, tr};
+        n++;
+    }
+    if (lead) O.path_len = int32_t(n);
+    if (!ok) { if (lead) { atomicOr(&O.status, status); O.n_sec = 0; } return; }
+    if (WAVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // lane 0's path stores are read back below
+
+    credit_walk<WAVE>(B, d, O, a, path, n, status, secs, fp_group, jobs, n_jobs, jobs_cap, lead);
+}
+
+// Phase B alone, for paths produced by k_walk_rows (pr_band.hip)
+template <bool WAVE>
+__global__ void __launch_bounds__(64) k_credit(DevBatch B, const AlnDesc *__restrict__ descs,
+                       const int32_t *__restrict__ work, int n_work, AlnOut *__restrict__ outs,
+                       const PathEnt *__restrict__ paths, Section *__restrict__ secs,
+                       int32_t *const *__restrict__ fp_group,
+                       EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap) {
+    const int wi = WAVE ? int(blockIdx.x) : int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (wi >= n_work) return;
+    const int a = work[wi];
+    const AlnDesc d = descs[a];
+    AlnOut &O = outs[a];
+    if (d.band_w > 0 && !O.band_ok) return;
+    if (O.status & (VPR_ST_ERR_NO_PTR | VPR_ST_ERR_LIMIT)) return;   // phase A failed: n_sec is already 0
+    const bool lead = !WAVE || (threadIdx.x & 63) == 0;
+    credit_walk<WAVE>(B, d, O, a, paths + d.path_off, int64_t(O.path_len), 0u, secs, fp_group, jobs, n_jobs, jobs_cap, lead);
 }
 
 // ---------------------------------------------------------------------------
