@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -244,24 +245,35 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int band_c, Plan 
     P = Plan();
     P.band_c = band_c;
     const int W = 64 * band_c;
-    std::vector<int32_t> order(alns);
     auto mat_bytes = [&](int32_t a) -> int64_t {
         const AlnDesc &d = h->descs[a];
         if (band_c) return int64_t(round_up(std::min(W, d.Lq), 16) + round_up(std::min(W, d.Lr), 16)) * d.Lt;
         return int64_t(round_up(d.Lq, 32) + round_up(d.Lr, 32)) * d.Lt;
     };
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return mat_bytes(x) > mat_bytes(y); });
+    // Order: the long alignments first, longest first (they are latency chains and must start early); the
+    // rest keeps its input order - sorting millions of short alignments buys nothing.
+    std::vector<int32_t> order;
+    order.reserve(alns.size());
+    {
+        std::vector<std::pair<int64_t, int32_t>> big;
+        for (int32_t a : alns)
+            if (!band_c || h->descs[a].Lt >= 512) big.emplace_back(-mat_bytes(a), a);
+        std::sort(big.begin(), big.end());
+        for (auto &b : big) order.push_back(b.second);
+        if (band_c)
+            for (int32_t a : alns)
+                if (h->descs[a].Lt < 512) order.push_back(a);
+    }
+    P.work.reserve(order.size());
+    P.descs.reserve(order.size());
     size_t k = 0;
     while (k < order.size()) {
         Chunk ch;
         ch.work_off = int64_t(P.work.size());
         int64_t used = 0;
-        std::vector<std::vector<int32_t>> by_cls(N_CLASSES);
-        std::vector<std::vector<AlnDesc>> desc_cls(N_CLASSES);
         const size_t k0 = k;
         while (k < order.size()) {
             AlnDesc d = h->descs[order[k]];
-            int cls = 0;
             if (band_c) {
                 d.band_w = W;
                 d.pitch[0] = int32_t(round_up(std::min(W, d.Lq), 16));
@@ -270,7 +282,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int band_c, Plan 
                 d.band_w = 0;
                 d.pitch[0] = int32_t(round_up(d.Lq, 32));
                 d.pitch[1] = int32_t(round_up(d.Lr, 32));
-                cls = class_of(std::max(d.Lq, d.Lr));
+                const int cls = class_of(std::max(d.Lq, d.Lr));
                 if (cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX || bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX)
                     return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d too long for the dense kernels (Lq=%d Lr=%d)",
                                 d.sc, d.aln, d.Lq, d.Lr);
@@ -290,17 +302,31 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int band_c, Plan 
             used += need;
             ch.cells += band_c ? int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt : int64_t(d.Lq + d.Lr) * d.Lt;
             ch.in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
-            by_cls[cls].push_back(order[k]);
-            desc_cls[cls].push_back(d);
+            P.work.push_back(order[k]);
+            P.descs.push_back(d);
             k++;
         }
-        for (int c = 0; c < N_CLASSES; c++) {
-            if (by_cls[c].empty()) continue;
-            if (!band_c) ch.launches.push_back(Launch{c, int64_t(P.work.size()), int32_t(by_cls[c].size())});
-            P.work.insert(P.work.end(), by_cls[c].begin(), by_cls[c].end());
-            P.descs.insert(P.descs.end(), desc_cls[c].begin(), desc_cls[c].end());
-        }
         ch.count = int32_t(P.work.size() - ch.work_off);
+        if (!band_c) {
+            // dense plan: group the chunk's alignments by kernel class (stable), one launch per class
+            std::vector<int32_t> idx(ch.count);
+            for (int32_t w = 0; w < ch.count; w++) idx[w] = w;
+            auto cls_of = [&](int32_t w) { const AlnDesc &d = P.descs[ch.work_off + w]; return class_of(std::max(d.Lq, d.Lr)); };
+            std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return cls_of(x) < cls_of(y); });
+            std::vector<int32_t> w2(ch.count);
+            std::vector<AlnDesc> d2(ch.count);
+            for (int32_t w = 0; w < ch.count; w++) { w2[w] = P.work[ch.work_off + idx[w]]; d2[w] = P.descs[ch.work_off + idx[w]]; }
+            std::copy(w2.begin(), w2.end(), P.work.begin() + ch.work_off);
+            std::copy(d2.begin(), d2.end(), P.descs.begin() + ch.work_off);
+            int32_t w = 0;
+            while (w < ch.count) {
+                const int c = cls_of(w);   // P.descs now in class order
+                int32_t e = w;
+                while (e < ch.count && class_of(std::max(P.descs[ch.work_off + e].Lq, P.descs[ch.work_off + e].Lr)) == c) e++;
+                ch.launches.push_back(Launch{c, ch.work_off + w, e - w});
+                w = e;
+            }
+        }
         P.chunks.push_back(std::move(ch));
     }
     return VPR_OK;
@@ -369,6 +395,10 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     free_batch(h);
     const int n = b->n_sc;
     h->n_sc = n;
+    const bool dbg = getenv("VPR_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double T0 = now();
+    auto lap = [&](const char *what) { if (dbg) { (void)hipDeviceSynchronize(); fprintf(stderr, "[vpr] upload %-28s %.3f s\n", what, now() - T0); } };
     DevBatch &D = h->dB;
     memset(&D, 0, sizeof(D));
     D.n_sc = n;
@@ -406,6 +436,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     }
     if ((rc = dev_alloc(h, &h->d_err, 1))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_err, 0, 4, h->stream));
+    lap("inputs copied");
 
     // ---- K0: position attributes
     hipEvent_t e0, e1;
@@ -431,6 +462,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
             hipLaunchKernelGGL(k_prep_suffix, dim3((n + 63) / 64), dim3(64), 0, h->stream, D, w);
     HIPCHK(h, hipEventRecord(e1, h->stream));
 
+    lap("prep kernels");
     // ---- base descriptors
     h->descs.resize(size_t(n) * 4);
     int64_t sec_total = 0, jobs_total = 0;
@@ -465,6 +497,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     h->timing.cells_dense = cells;
     h->timing.bytes_algorithmic = bytes_alg;
 
+    lap("descriptors");
     const size_t na = h->descs.size();
     if ((rc = dev_alloc(h, &h->d_descs, na))) return rc;
     if ((rc = dev_alloc(h, &h->d_outs, na))) return rc;
@@ -509,6 +542,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     if ((rc = dev_alloc(h, &h->d_fail, na))) return rc;
     if ((rc = dev_alloc(h, &h->d_cnt, 2))) return rc;
 
+    lap("result/aux allocations");
     // ---- arena for flag matrices, band origins and walks
     size_t free_b = 0, total_b = 0;
     HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
@@ -529,6 +563,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     h->arena_bytes = budget;
     if ((rc = dev_alloc(h, &h->d_arena, size_t(budget) + 256))) return rc;
 
+    lap("arena allocation");
     // ---- round-0 plan over all alignments, cached (descriptors + work list live on the device)
     std::vector<int32_t> all(na);
     for (size_t k = 0; k < na; k++) all[k] = int32_t(k);
@@ -543,6 +578,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
+    lap("plan + upload");
     uint32_t err = 0;
     HIPCHK(h, hipMemcpy(&err, h->d_err, 4, hipMemcpyDeviceToHost));
     if (err) return fail(h, VPR_ERR_ARG, "more than 4 swap sources map to one position (unsupported variant layout)");
