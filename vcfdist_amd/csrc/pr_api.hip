@@ -25,6 +25,7 @@
 #include "pr_device.h"
 #include "pr_kernels.hip"
 #include "pr_band.hip"
+#include "pr_q16.hip"
 
 namespace {
 
@@ -35,8 +36,11 @@ const KernelClass CLASSES[] = {
 };
 const int N_CLASSES = sizeof(CLASSES) / sizeof(CLASSES[0]);
 const size_t LDS_MAX = 160 * 1024;
-const int BAND_C[] = {1, 4, 16};          // banded rounds: windows of 64, 256, 1024 cells
-const int N_BAND = 3;
+// window levels an alignment climbs until its exit test passes: 16 cells (four alignments per wave, only
+// for alignments shorter than LONG_LT rows), 64, 256, 1024 cells (one wave per alignment), dense
+enum { LV_Q16 = 0, LV_C1 = 1, LV_C4 = 2, LV_C16 = 3, LV_DENSE = 4 };
+const int LV_WINDOW[] = {16, 64, 256, 1024, 0};
+const int LONG_LT = 512;                  // truth rows from which an alignment is a latency chain
 
 struct Launch { int cls; int64_t work_off; int32_t count; };   // dense: one k_fwd/k_bwd launch of a class
 struct Chunk {
@@ -44,9 +48,10 @@ struct Chunk {
     std::vector<Launch> launches;              // dense plans only
     int64_t cells = 0, in_bytes = 0;           // touched cells / input bytes of the chunk
 };
-// a set of alignments with workspace offsets assigned; band_c == 0 means dense kernels
+// a set of alignments with workspace offsets assigned, all at window level `lv` (a LV_Q16 plan holds its
+// long alignments, which start at LV_C1, in front)
 struct Plan {
-    int band_c = 0;
+    int lv = LV_DENSE;
     std::vector<AlnDesc> descs;     // compact, in work-list order
     std::vector<int32_t> work;      // alignment ids
     std::vector<Chunk> chunks;
@@ -73,6 +78,7 @@ struct vpr_handle {
     int64_t n_var[4] = {0, 0, 0, 0};
     std::vector<AlnDesc> descs;          // base descriptors (no workspace offsets)
     Plan plan0;                          // first round over all alignments, cached at upload
+    std::vector<uint8_t> level, level0;  // current / round-0 window level of every alignment
     std::vector<int32_t> dirty;          // alignments whose device descriptor was overwritten by a retry round
     // device side
     AlnDesc *d_descs = nullptr;
@@ -196,19 +202,19 @@ AlnKernel bwd_kernel(int cls) {
 }
 typedef void (*BandFwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, int32_t *, AlnOut *);
 typedef void (*BandBwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, const int32_t *, AlnOut *);
-BandFwd band_fwd_kernel(int c) {
-    switch (c) {
-        case 1:   // 64-cell window: striped, register-resident variant (VPR_NO_STRIPE=1 selects the ring variant)
+BandFwd band_fwd_kernel(int lv) {
+    switch (lv) {
+        case LV_C1:   // 64-cell window: striped, register-resident variant (VPR_NO_STRIPE=1 selects the ring variant)
             return getenv("VPR_NO_STRIPE") ? BandFwd(k_fwd_band<1, true>) : BandFwd(k_fwd_stripe);
-        case 4: return k_fwd_band<4, true>;
+        case LV_C4: return k_fwd_band<4, true>;
         default: return k_fwd_band<16, true>;
     }
 }
-BandBwd band_bwd_kernel(int c) {
-    switch (c) {
-        case 1:   // needs the stripe origins written by k_fwd_stripe
+BandBwd band_bwd_kernel(int lv) {
+    switch (lv) {
+        case LV_C1:   // needs the stripe origins written by k_fwd_stripe
             return (getenv("VPR_NO_STRIPE") || getenv("VPR_NO_STRIPE_BWD")) ? BandBwd(k_bwd_band<1>) : BandBwd(k_bwd_stripe);
-        case 4: return k_bwd_band<4>;
+        case LV_C4: return k_bwd_band<4>;
         default: return k_bwd_band<16>;
     }
 }
@@ -240,29 +246,40 @@ __global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc 
 }
 
 // Assign arena offsets (flag matrices, band origins, walk scratch) to `alns` and cut them into chunks
-// that fit the arena.  band_c > 0: banded layout with a 64*band_c window; 0: dense layout + kernel classes.
-int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int band_c, Plan &P) {
+// that fit the arena.  lv: window level of the plan (LV_DENSE: dense layout + kernel classes).
+int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P) {
     P = Plan();
-    P.band_c = band_c;
-    const int W = 64 * band_c;
+    P.lv = lv;
+    auto level_of = [&](const AlnDesc &d) { return (lv == LV_Q16 && d.Lt >= LONG_LT) ? int(LV_C1) : lv; };
     auto mat_bytes = [&](int32_t a) -> int64_t {
         const AlnDesc &d = h->descs[a];
-        if (band_c) return int64_t(round_up(std::min(W, d.Lq), 16) + round_up(std::min(W, d.Lr), 16)) * d.Lt;
+        const int W = LV_WINDOW[level_of(d)];
+        if (W) return int64_t(round_up(std::min(W, d.Lq), 16) + round_up(std::min(W, d.Lr), 16)) * d.Lt;
         return int64_t(round_up(d.Lq, 32) + round_up(d.Lr, 32)) * d.Lt;
     };
-    // Order: the long alignments first, longest first (they are latency chains and must start early); the
-    // rest keeps its input order - sorting millions of short alignments buys nothing.
+    // Order: the long alignments first, longest first (they are latency chains and must start early).  The
+    // rest keeps its input order, except at LV_Q16 where four alignments share a wave in lockstep and are
+    // therefore grouped by their number of truth rows (counting sort, longest first, stable).
     std::vector<int32_t> order;
     order.reserve(alns.size());
     {
         std::vector<std::pair<int64_t, int32_t>> big;
         for (int32_t a : alns)
-            if (!band_c || h->descs[a].Lt >= 512) big.emplace_back(-mat_bytes(a), a);
+            if (lv == LV_DENSE || h->descs[a].Lt >= LONG_LT) big.emplace_back(-mat_bytes(a), a);
         std::sort(big.begin(), big.end());
         for (auto &b : big) order.push_back(b.second);
-        if (band_c)
+        if (lv == LV_Q16) {
+            std::vector<int64_t> cnt(LONG_LT + 1, 0);
+            for (int32_t a : alns) if (h->descs[a].Lt < LONG_LT) cnt[LONG_LT - 1 - h->descs[a].Lt + 1]++;
+            for (int k = 0; k < LONG_LT; k++) cnt[k + 1] += cnt[k];
+            const size_t base = order.size();
+            order.resize(base + size_t(cnt[LONG_LT]));
             for (int32_t a : alns)
-                if (h->descs[a].Lt < 512) order.push_back(a);
+                if (h->descs[a].Lt < LONG_LT) order[base + size_t(cnt[LONG_LT - 1 - h->descs[a].Lt]++)] = a;
+        } else if (lv != LV_DENSE) {
+            for (int32_t a : alns)
+                if (h->descs[a].Lt < LONG_LT) order.push_back(a);
+        }
     }
     P.work.reserve(order.size());
     P.descs.reserve(order.size());
@@ -274,10 +291,22 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int band_c, Plan 
         const size_t k0 = k;
         while (k < order.size()) {
             AlnDesc d = h->descs[order[k]];
-            if (band_c) {
+            const int dl = level_of(d);
+            const int W = LV_WINDOW[dl];
+            int64_t m0, m1, bl;
+            if (dl == LV_Q16) {
+                // stripe-transposed records of 128 B per 4 truth rows (both planes) + int2 origins per stripe
+                const int64_t nstr = (int64_t(d.Lt) + 3) / 4;
+                d.band_w = 16;
+                d.pitch[0] = d.pitch[1] = 16;
+                m0 = nstr * 128; m1 = 0;
+                bl = round_up(nstr * 8, 64);
+            } else if (W) {
                 d.band_w = W;
                 d.pitch[0] = int32_t(round_up(std::min(W, d.Lq), 16));
                 d.pitch[1] = int32_t(round_up(std::min(W, d.Lr), 16));
+                m0 = round_up(int64_t(d.pitch[0]) * d.Lt, 64); m1 = round_up(int64_t(d.pitch[1]) * d.Lt, 64);
+                bl = round_up(int64_t(2) * d.Lt * 4, 64);
             } else {
                 d.band_w = 0;
                 d.pitch[0] = int32_t(round_up(d.Lq, 32));
@@ -286,9 +315,9 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int band_c, Plan 
                 if (cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX || bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX)
                     return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d too long for the dense kernels (Lq=%d Lr=%d)",
                                 d.sc, d.aln, d.Lq, d.Lr);
+                m0 = round_up(int64_t(d.pitch[0]) * d.Lt, 64); m1 = round_up(int64_t(d.pitch[1]) * d.Lt, 64);
+                bl = 0;
             }
-            const int64_t m0 = round_up(int64_t(d.pitch[0]) * d.Lt, 64), m1 = round_up(int64_t(d.pitch[1]) * d.Lt, 64);
-            const int64_t bl = band_c ? round_up(int64_t(2) * d.Lt * 4, 64) : 0;
             const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64);   // 16 B per step
             const int64_t need = m0 + m1 + bl + pb + 64;
             if (k > k0 && used + need > h->arena_bytes) break;
@@ -300,14 +329,15 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int band_c, Plan 
             d.blo_off = (used + m0 + m1) / 4;            // int index into the arena
             d.path_off = (used + m0 + m1 + bl) / int64_t(sizeof(PathEnt));
             used += need;
-            ch.cells += band_c ? int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt : int64_t(d.Lq + d.Lr) * d.Lt;
+            ch.cells += W ? int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt : int64_t(d.Lq + d.Lr) * d.Lt;
             ch.in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
+            h->level[size_t(order[k])] = uint8_t(dl);
             P.work.push_back(order[k]);
             P.descs.push_back(d);
             k++;
         }
         ch.count = int32_t(P.work.size() - ch.work_off);
-        if (!band_c) {
+        if (lv == LV_DENSE) {
             // dense plan: group the chunk's alignments by kernel class (stable), one launch per class
             std::vector<int32_t> idx(ch.count);
             for (int32_t w = 0; w < ch.count; w++) idx[w] = w;
@@ -431,6 +461,12 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if ((rc = dev_alloc(h, &D.bk_q[q], hap_len[q]))) return rc;
         if ((rc = dev_alloc(h, &D.bk_r[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.vs_ref[q], ref_len))) return rc;
+        if ((rc = dev_alloc(h, &D.fk4_q[q], hap_len[q]))) return rc;
+        if ((rc = dev_alloc(h, &D.fk4_r[q], ref_len))) return rc;
+        if ((rc = dev_alloc(h, &D.tk[q], hap_len[2 + q]))) return rc;
+        if ((rc = dev_alloc(h, &D.wk_q[q], hap_len[q]))) return rc;
+        if ((rc = dev_alloc(h, &D.wk_r[q], ref_len))) return rc;
+        if ((rc = dev_alloc(h, &D.wk_t[q], hap_len[2 + q]))) return rc;
         HIPCHK(h, hipMemsetAsync(D.cand_q[q], 0xff, std::max<int64_t>(hap_len[q], 1) * sizeof(int4), h->stream));
         HIPCHK(h, hipMemsetAsync(D.cand_r[q], 0xff, std::max<int64_t>(ref_len, 1) * sizeof(int4), h->stream));
     }
@@ -460,6 +496,11 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     if (n > 0)
         for (int w = 0; w < 6; w++)
             hipLaunchKernelGGL(k_prep_suffix, dim3((n + 63) / 64), dim3(64), 0, h->stream, D, w);
+    for (int w = 0; w < 6; w++) {
+        const int64_t np = w < 2 ? hap_len[w] : (w < 4 ? ref_len : hap_len[w - 2]);
+        if (np > 0) hipLaunchKernelGGL(k_prep_q16, blocks(np), dim3(256), 0, h->stream, D, w, np);
+        if (np > 0) hipLaunchKernelGGL(k_prep_wk, blocks(np), dim3(256), 0, h->stream, D, w, np);
+    }
     HIPCHK(h, hipEventRecord(e1, h->stream));
 
     lap("prep kernels");
@@ -567,7 +608,10 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     // ---- round-0 plan over all alignments, cached (descriptors + work list live on the device)
     std::vector<int32_t> all(na);
     for (size_t k = 0; k < na; k++) all[k] = int32_t(k);
-    if ((rc = make_plan(h, all, h->cfg.band_mode ? BAND_C[0] : 0, h->plan0))) return rc;
+    h->level.assign(na, uint8_t(LV_DENSE));
+    const int lv0 = h->cfg.band_mode == 0 ? LV_DENSE : ((h->cfg.band_mode == 2 || getenv("VPR_NO_Q16")) ? LV_C1 : LV_Q16);
+    if ((rc = make_plan(h, all, lv0, h->plan0))) return rc;
+    h->level0 = h->level;
     if ((rc = dev_alloc(h, &h->plan0.d_descs, na))) return rc;
     if ((rc = dev_alloc(h, &h->plan0.d_work, na))) return rc;
     if (na) {
@@ -717,24 +761,25 @@ int vpr_execute(vpr_handle *h) {
     // window failed the exit test, so there is no host round trip inside a round; the rejected ids are
     // collected on the device and read back once per round.
     auto run_band = [&](const Plan &P, const int32_t *d_work, std::vector<int32_t> &fails) -> int {
-        const int C = P.band_c;
         HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
         for (const Chunk &ch : P.chunks) {
             int32_t n_long = 0;
-            while (n_long < ch.count && P.descs[ch.work_off + n_long].Lt >= 512) n_long++;
-            if (n_long == ch.count || ch.count < 4096) n_long = 0;     // nothing to overlap with
+            while (n_long < ch.count && P.descs[ch.work_off + n_long].Lt >= LONG_LT) n_long++;
+            // a LV_Q16 plan's long alignments use the 64-cell layout and cannot share a launch with the rest
+            if (P.lv != LV_Q16 && (n_long == ch.count || ch.count < 4096)) n_long = 0;     // nothing to overlap with
             HIPCHK(h, hipEventRecord(h->ev_fork, st));
             for (int part = 0; part < 2; part++) {
                 const int32_t off = part == 0 ? 0 : n_long, cnt = part == 0 ? n_long : ch.count - n_long;
                 if (cnt <= 0) continue;
+                const int lv = (P.lv == LV_Q16 && part == 0) ? int(LV_C1) : P.lv;
+                const int W = LV_WINDOW[lv], C = W / 64;
                 hipStream_t ks = h->cls_stream[part];
                 HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
                 const int32_t *list = d_work + ch.work_off + off;
                 vpr_launch_stat ls;
                 memset(&ls, 0, sizeof(ls));
-                ls.threads = 64; ls.cells_per_thread = C; ls.n_units = cnt;
+                ls.threads = lv == LV_Q16 ? 16 : 64; ls.cells_per_thread = lv == LV_Q16 ? 1 : C; ls.n_units = cnt;
                 int64_t in_bytes = 0;
-                const int W = 64 * C;
                 for (int32_t w = 0; w < cnt; w++) {
                     const AlnDesc &d = P.descs[ch.work_off + off + w];
                     ls.cells += int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt;
@@ -743,23 +788,48 @@ int vpr_execute(vpr_handle *h) {
                 ls.bytes_algorithmic = ls.cells + in_bytes;
                 cells_touched += ls.cells;
                 int rc = timed(1, ls, ks, [&] {
-                    hipLaunchKernelGGL(band_fwd_kernel(C), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
-                                       h->d_arena, arena_i32, h->d_outs);
+                    if (lv == LV_Q16)
+                        hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                           h->d_arena, arena_i32, h->d_outs);
+                    else
+                        hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
+                                           h->d_arena, arena_i32, h->d_outs);
                     hipLaunchKernelGGL(k_fwd_band_finish, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs);
                 });
                 if (rc) return rc;
                 n_fwd++;
                 ls.bytes_algorithmic = ls.cells;
                 rc = timed(2, ls, ks, [&] {
-                    hipLaunchKernelGGL(band_bwd_kernel(C), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
-                                       h->d_arena, arena_i32, h->d_outs);
+                    if (lv == LV_Q16)
+                        hipLaunchKernelGGL(k_bwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                           h->d_arena, arena_i32, h->d_outs);
+                    else
+                        hipLaunchKernelGGL(band_bwd_kernel(lv), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
+                                           h->d_arena, arena_i32, h->d_outs);
                 });
                 if (rc) return rc;
                 // long part (or a small launch of long retries): wave-per-alignment walk; windows up to 256
-                const bool wave_walk = C <= 4 && (part == 0 || cnt < 2048);
-                const bool row_walk = C == 1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") &&
+                const bool wave_walk = lv != LV_Q16 && C <= 4 && (part == 0 || cnt < 2048);
+                const bool row_walk = lv == LV_C1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") &&
                                       !getenv("VPR_NO_ROWWALK") && (wave_walk || getenv("VPR_ROWWALK_ALL"));
-                if (row_walk) {
+                if (lv == LV_Q16 && !getenv("VPR_NO_Q16WALK")) {
+                    // 16-cell layout: row-sweep walk, four alignments per wave (phase A) + credit walk (phase B)
+                    vpr_launch_stat ws_;
+                    memset(&ws_, 0, sizeof(ws_));
+                    ws_.threads = 16; ws_.n_units = cnt; ws_.cells_per_thread = 2;
+                    rc = timed(3, ws_, ks, [&] {
+                        hipLaunchKernelGGL(k_walk_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                           h->d_arena, arena_i32, h->d_outs, arena_path);
+                    });
+                    if (rc) return rc;
+                    ws_.cells_per_thread = 3;
+                    rc = timed(3, ws_, ks, [&] {
+                        hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
+                                           list, cnt, h->d_outs, arena_path, h->d_secs, h->d_fp_table, h->d_jobs,
+                                           h->d_njobs, h->jobs_cap);
+                    });
+                    if (rc) return rc;
+                } else if (row_walk) {
                     // striped layout, long alignments: row-sweep walk (phase A) + credit walk (phase B); for the
                     // short ones the per-wave setup outweighs the pointer chase of the lane-per-alignment walk
                     vpr_launch_stat ws_;
@@ -793,16 +863,17 @@ int vpr_execute(vpr_handle *h) {
         HIPCHK(h, hipMemcpyAsync(&nf, h->d_cnt, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
         if (nf > 0) {
-            fails.resize(size_t(nf));
-            HIPCHK(h, hipMemcpy(fails.data(), h->d_fail, size_t(nf) * 4, hipMemcpyDeviceToHost));
-            std::sort(fails.begin(), fails.end());   // deterministic planning of the next round
-            if (getenv("VPR_DEBUG")) {
-                for (int32_t a : fails) {
+            const size_t f0 = fails.size();
+            fails.resize(f0 + size_t(nf));
+            HIPCHK(h, hipMemcpy(fails.data() + f0, h->d_fail, size_t(nf) * 4, hipMemcpyDeviceToHost));
+            if (getenv("VPR_DEBUG") && nf <= 64) {
+                for (size_t k = f0; k < fails.size(); k++) {
+                    const int32_t a = fails[k];
                     AlnOut o;
                     (void)hipMemcpy(&o, h->d_outs + a, sizeof(o), hipMemcpyDeviceToHost);
                     const AlnDesc &d = h->descs[a];
-                    fprintf(stderr, "[vpr] band C=%d rejected sc %d aln %d: Lq %d Lr %d Lt %d  s %d exit_min %d dq %d dr %d\n",
-                            C, d.sc, d.aln, d.Lq, d.Lr, d.Lt, o.s, o.exit_min, o.dist_q, o.dist_r);
+                    fprintf(stderr, "[vpr] level %d rejected sc %d aln %d: Lq %d Lr %d Lt %d  s %d exit_min %d dq %d dr %d\n",
+                            int(h->level[a]), d.sc, d.aln, d.Lq, d.Lr, d.Lt, o.s, o.exit_min, o.dist_q, o.dist_r);
                 }
             }
         }
@@ -833,35 +904,39 @@ int vpr_execute(vpr_handle *h) {
 
     int rc = VPR_OK;
     h->last_chunk.clear();
+    h->level = h->level0;
+    auto keep_last = [&](const Plan &P) {
+        if (P.chunks.empty()) return;
+        const Chunk &c = P.chunks.back();
+        h->last_chunk.assign(P.work.begin() + c.work_off, P.work.begin() + c.work_off + c.count);
+    };
     if (h->cfg.band_mode == 0) {
         if ((rc = run_dense(h->plan0, h->plan0.d_work))) return rc;
-        if (!h->plan0.chunks.empty()) {
-            const Chunk &c = h->plan0.chunks.back();
-            h->last_chunk.assign(h->plan0.work.begin() + c.work_off, h->plan0.work.begin() + c.work_off + c.count);
-        }
+        keep_last(h->plan0);
     } else {
         std::vector<int32_t> fails;
         if ((rc = run_band(h->plan0, h->plan0.d_work, fails))) return rc;
-        if (!h->plan0.chunks.empty()) {
-            const Chunk &c = h->plan0.chunks.back();
-            h->last_chunk.assign(h->plan0.work.begin() + c.work_off, h->plan0.work.begin() + c.work_off + c.count);
-        }
-        for (int r = 1; r <= N_BAND && !fails.empty(); r++) {
+        keep_last(h->plan0);
+        // retry rounds: every rejected alignment climbs one window level (16 -> 64 -> 256 -> 1024 -> dense)
+        while (!fails.empty()) {
             n_retry += int64_t(fails.size());
-            Plan P;
-            // windows wider than the alignment are pointless: go straight to the dense kernels
-            std::vector<int32_t> next;
-            const bool dense = (r == N_BAND);
-            if ((rc = make_plan(h, fails, dense ? 0 : BAND_C[r], P))) return rc;
-            const int32_t *d_work = nullptr;
-            if ((rc = stage_plan(P, &d_work))) return rc;
-            if (dense) { if ((rc = run_dense(P, d_work))) return rc; }
-            else { if ((rc = run_band(P, d_work, next))) return rc; }
-            if (!P.chunks.empty()) {
-                const Chunk &c = P.chunks.back();
-                h->last_chunk.assign(P.work.begin() + c.work_off, P.work.begin() + c.work_off + c.count);
+            std::sort(fails.begin(), fails.end());   // deterministic planning of the next round
+            std::vector<int32_t> by_lv[LV_DENSE + 1], next;
+            for (int32_t a : fails) by_lv[std::min<int>(h->level[size_t(a)] + 1, LV_DENSE)].push_back(a);
+            if (getenv("VPR_DEBUG"))
+                fprintf(stderr, "[vpr] retry round: %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n", by_lv[1].size(),
+                        by_lv[2].size(), by_lv[3].size(), by_lv[4].size());
+            for (int lv = LV_C1; lv <= LV_DENSE; lv++) {
+                if (by_lv[lv].empty()) continue;
+                Plan P;
+                if ((rc = make_plan(h, by_lv[lv], lv, P))) return rc;
+                const int32_t *d_work = nullptr;
+                if ((rc = stage_plan(P, &d_work))) return rc;
+                if (lv == LV_DENSE) { if ((rc = run_dense(P, d_work))) return rc; }
+                else { if ((rc = run_band(P, d_work, next))) return rc; }
+                keep_last(P);
+                HIPCHK(h, hipStreamSynchronize(st));
             }
-            HIPCHK(h, hipStreamSynchronize(st));
             fails.swap(next);
         }
     }

@@ -53,6 +53,19 @@ struct DevBatch {
     // path through it (pr_band.hip, k_fwd_stripe).
     int32_t *vs_hap[4];
     int32_t *vs_ref[2];
+    // packed constants of the 16-cell window kernels (pr_q16.hip, k_prep_q16):
+    //   fk4_*: {fk.x, fk.y, reference coordinate of the position, free-shift budget behind it}
+    //   tk[s]: truth slot 2+s: {t2r[t], base | fwd_allow(flag[t-1]) << 8 | vs_hap[t-1] << 9}
+    int4 *fk4_q[2];
+    int4 *fk4_r[2];
+    int2 *tk[2];
+    // packed constants of the row-sweep walk (k_walk_q16).  ins4(r) = bit s set iff an insertion of hap slot s
+    // sits at ref index r (has_ins[s][r]); an alignment looks at the bits of its query and truth slot.
+    //   wk_q[h]: {q2r[x], flag[x] | ins4(q2r[x]) << 8}     wk_r[h]: {r2q_h[x], ins4(x) << 8}
+    //   wk_t[s]: truth slot 2+s: {t2r[t], flag[t] | ins4(t2r[t]) << 8}
+    int2 *wk_q[2];
+    int2 *wk_r[2];
+    int2 *wk_t[2];
 };
 #define FK_MULTI (1 << 30)
 #define FK_NONE24 0xffffff

@@ -808,6 +808,12 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
             const int col = qri - tblo[hi * WALK_TR + r];
             if (col < 0 || col >= d.band_w) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
             p = tile[hi * WALK_TR * WALK_TW + r * d.pitch[hi] + col] & 31;
+        } else if (d.band_w == 16) {
+            // stripe-transposed 16-cell layout (pr_q16.hip): record ti>>2 = [plane][column][row & 3]
+            const int2 o = reinterpret_cast<const int2 *>(blo)[ti >> 2];
+            const int col = qri - (hi ? o.y : o.x);
+            if (col < 0 || col >= 16) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+            p = mat[0][size_t(ti >> 2) * 128 + hi * 64 + col * 4 + (ti & 3)] & 31;
         } else {
             const int col = banded ? qri - blo[hi * t_size + ti] : qri;
             if (banded && (col < 0 || col >= d.band_w)) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
