@@ -47,6 +47,9 @@ struct Chunk {
     int64_t work_off = 0; int32_t count = 0;   // slice of the plan's work list
     std::vector<Launch> launches;              // dense plans only
     int64_t cells = 0, in_bytes = 0;           // touched cells / input bytes of the chunk
+    // windowed plans: the leading n_long long alignments get their own launch sequence (part 0)
+    int32_t n_long = 0;
+    int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0};
 };
 // a set of alignments with workspace offsets assigned, all at window level `lv` (a LV_Q16 plan holds its
 // long alignments, which start at LV_C1, in front)
@@ -57,6 +60,7 @@ struct Plan {
     std::vector<Chunk> chunks;
     AlnDesc *d_descs = nullptr;     // device copy of `descs` (plan 0 only, cached)
     int32_t *d_work = nullptr;
+    uint8_t *arena = nullptr;       // workspace the offsets refer to
 };
 
 struct EvPair { hipEvent_t a, b; int kind; vpr_launch_stat st; };
@@ -83,7 +87,10 @@ struct vpr_handle {
     // device side
     AlnDesc *d_descs = nullptr;
     AlnOut *d_outs = nullptr;
-    uint8_t *d_arena = nullptr; int64_t arena_bytes = 0;
+    uint8_t *d_arena = nullptr; int64_t arena_bytes = 0;      // workspace of the round-0 plan
+    uint8_t *d_arena2 = nullptr; int64_t arena2_bytes = 0;    // workspace of the retry rounds (run beside round 0)
+    hipEvent_t ev_slot[4] = {nullptr, nullptr, nullptr, nullptr};   // "fail list of slot k is complete"
+    std::vector<std::pair<std::vector<int32_t>, uint8_t *>> resident;   // alignments whose walks are still in a workspace
     Section *d_secs = nullptr; int64_t n_secs_cap = 0;
     int32_t *d_fp[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t **d_fp_table = nullptr;
@@ -93,8 +100,6 @@ struct vpr_handle {
     AlnDesc *d_tmp_descs = nullptr; size_t tmp_descs_cap = 0;
     int32_t *d_tmp_work = nullptr; size_t tmp_work_cap = 0;
     int32_t *d_ed_scratch = nullptr; size_t ed_scratch_ints = 0;
-    int32_t last_path_a0 = -1;           // alignments of the last chunk (their walks are still in the arena)
-    std::vector<int32_t> last_chunk;
     std::vector<EvPair> events;
     DevResults dR;                       // final results, produced on the device
     vpr_timing timing;
@@ -152,7 +157,8 @@ void free_batch(vpr_handle *h) {
     h->descs.clear();
     h->plan0 = Plan();
     h->dirty.clear();
-    h->d_arena = nullptr; h->d_secs = nullptr;
+    h->d_arena = nullptr; h->d_arena2 = nullptr; h->d_secs = nullptr;
+    h->resident.clear();
     h->d_ed_scratch = nullptr; h->ed_scratch_ints = 0;
     h->d_tmp_descs = nullptr; h->tmp_descs_cap = 0;
     h->d_tmp_work = nullptr; h->tmp_work_cap = 0;
@@ -247,9 +253,10 @@ __global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc 
 
 // Assign arena offsets (flag matrices, band origins, walk scratch) to `alns` and cut them into chunks
 // that fit the arena.  lv: window level of the plan (LV_DENSE: dense layout + kernel classes).
-int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P) {
+int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, uint8_t *arena, int64_t arena_bytes) {
     P = Plan();
     P.lv = lv;
+    P.arena = arena;
     auto level_of = [&](const AlnDesc &d) { return (lv == LV_Q16 && d.Lt >= LONG_LT) ? int(LV_C1) : lv; };
     auto mat_bytes = [&](int32_t a) -> int64_t {
         const AlnDesc &d = h->descs[a];
@@ -320,10 +327,10 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P) 
             }
             const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64);   // 16 B per step
             const int64_t need = m0 + m1 + bl + pb + 64;
-            if (k > k0 && used + need > h->arena_bytes) break;
-            if (need > h->arena_bytes)
+            if (k > k0 && used + need > arena_bytes) break;
+            if (need > arena_bytes)
                 return fail(h, VPR_ERR_NOMEM, "workspace (%lld bytes) too small for supercluster %d alignment %d (%lld bytes)",
-                            (long long)h->arena_bytes, d.sc, d.aln, (long long)need);
+                            (long long)arena_bytes, d.sc, d.aln, (long long)need);
             d.mat_off[0] = used;
             d.mat_off[1] = used + m0;
             d.blo_off = (used + m0 + m1) / 4;            // int index into the arena
@@ -337,6 +344,18 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P) 
             k++;
         }
         ch.count = int32_t(P.work.size() - ch.work_off);
+        if (lv != LV_DENSE) {
+            while (ch.n_long < ch.count && P.descs[ch.work_off + ch.n_long].Lt >= LONG_LT) ch.n_long++;
+            // a LV_Q16 plan's long alignments use the 64-cell layout and cannot share a launch with the rest
+            if (lv != LV_Q16 && (ch.n_long == ch.count || ch.count < 4096)) ch.n_long = 0;     // nothing to overlap with
+            for (int32_t w = 0; w < ch.count; w++) {
+                const AlnDesc &d = P.descs[ch.work_off + w];
+                const int part = w < ch.n_long ? 0 : 1;
+                const int W = d.band_w;
+                ch.part_cells[part] += int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt;
+                ch.part_in[part] += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
+            }
+        }
         if (lv == LV_DENSE) {
             // dense plan: group the chunk's alignments by kernel class (stable), one launch per class
             std::vector<int32_t> idx(ch.count);
@@ -392,6 +411,9 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
             return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
         }
     }
+    for (int k = 0; k < 4; k++)
+        if (hipEventCreateWithFlags(&h->ev_slot[k], hipEventDisableTiming) != hipSuccess)
+            return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess)
         return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     // allow the big dense classes to use the whole 160 KiB LDS of a CU
@@ -415,6 +437,8 @@ void vpr_destroy(vpr_handle *h) {
         if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int k = 0; k < 4; k++)
+        if (h->ev_slot[k]) (void)hipEventDestroy(h->ev_slot[k]);
     delete h;
 }
 
@@ -580,8 +604,8 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     R.credit_threshold = h->cfg.credit_threshold;
     R.phase_threshold = h->cfg.phase_threshold;
     if ((rc = dev_alloc(h, &h->d_ok, na))) return rc;
-    if ((rc = dev_alloc(h, &h->d_fail, na))) return rc;
-    if ((rc = dev_alloc(h, &h->d_cnt, 2))) return rc;
+    if ((rc = dev_alloc(h, &h->d_fail, 2 * na + 64))) return rc;   // round-0 lists [0, na), retry rounds [na, 2 na)
+    if ((rc = dev_alloc(h, &h->d_cnt, 8))) return rc;
 
     lap("result/aux allocations");
     // ---- arena for flag matrices, band origins and walks
@@ -603,6 +627,15 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     }
     h->arena_bytes = budget;
     if ((rc = dev_alloc(h, &h->d_arena, size_t(budget) + 256))) return rc;
+    // second workspace for the retry rounds, which run beside round 0 (cfg.workspace_bytes bounds each of the two)
+    if (h->cfg.band_mode != 0) {
+        HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+        int64_t b2 = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes
+                                                : std::min<int64_t>(int64_t(double(free_b) * 0.5), std::max<int64_t>(budget, int64_t(2) << 30));
+        if (b2 < (8 << 20)) b2 = 8 << 20;
+        h->arena2_bytes = b2;
+        if ((rc = dev_alloc(h, &h->d_arena2, size_t(b2) + 256))) return rc;
+    }
 
     lap("arena allocation");
     // ---- round-0 plan over all alignments, cached (descriptors + work list live on the device)
@@ -610,7 +643,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     for (size_t k = 0; k < na; k++) all[k] = int32_t(k);
     h->level.assign(na, uint8_t(LV_DENSE));
     const int lv0 = h->cfg.band_mode == 0 ? LV_DENSE : ((h->cfg.band_mode == 2 || getenv("VPR_NO_Q16")) ? LV_C1 : LV_Q16);
-    if ((rc = make_plan(h, all, lv0, h->plan0))) return rc;
+    if ((rc = make_plan(h, all, lv0, h->plan0, h->d_arena, h->arena_bytes))) return rc;
     h->level0 = h->level;
     if ((rc = dev_alloc(h, &h->plan0.d_descs, na))) return rc;
     if ((rc = dev_alloc(h, &h->plan0.d_work, na))) return rc;
@@ -691,34 +724,35 @@ int vpr_execute(vpr_handle *h) {
     HIPCHK(h, hipEventCreate(&t1));
     HIPCHK(h, hipEventRecord(t0, st));
     int64_t n_fwd = 0, cells_touched = 0, n_retry = 0;
-    int32_t *arena_i32 = reinterpret_cast<int32_t *>(h->d_arena);
-    PathEnt *arena_path = reinterpret_cast<PathEnt *>(h->d_arena);
 
     // wave = true: one wavefront per alignment with LDS-staged window rows (long banded alignments)
-    auto walk_launch = [&](const int32_t *d_list, int32_t count, hipStream_t ks, bool wave) -> int {
+    auto walk_launch = [&](const Plan &P, const int32_t *d_list, int32_t count, hipStream_t ks, bool wave, int my_w) -> int {
         vpr_launch_stat ws_;
         memset(&ws_, 0, sizeof(ws_));
         ws_.threads = 64; ws_.n_units = count; ws_.cells_per_thread = wave ? 1 : 0;
+        int32_t *a_i32 = reinterpret_cast<int32_t *>(P.arena);
+        PathEnt *a_path = reinterpret_cast<PathEnt *>(P.arena);
         return timed(3, ws_, ks, [&] {
             if (wave)
                 hipLaunchKernelGGL(k_walk<true>, dim3(count), dim3(64), 0, ks, h->dB, h->d_descs, d_list, count,
-                                   h->d_arena, arena_i32, h->d_outs, arena_path, h->d_secs, h->d_fp_table,
-                                   h->d_jobs, h->d_njobs, h->jobs_cap);
+                                   P.arena, a_i32, h->d_outs, a_path, h->d_secs, h->d_fp_table,
+                                   h->d_jobs, h->d_njobs, h->jobs_cap, my_w);
             else
                 hipLaunchKernelGGL(k_walk<false>, dim3((count + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, d_list,
-                                   count, h->d_arena, arena_i32, h->d_outs, arena_path, h->d_secs, h->d_fp_table,
-                                   h->d_jobs, h->d_njobs, h->jobs_cap);
+                                   count, P.arena, a_i32, h->d_outs, a_path, h->d_secs, h->d_fp_table,
+                                   h->d_jobs, h->d_njobs, h->jobs_cap, my_w);
         });
     };
 
-    // ---- dense plan: per chunk, each kernel class runs K1 -> K2 -> K3 on its own stream
-    auto run_dense = [&](const Plan &P, const int32_t *d_work) -> int {
+    // ---- dense plan: per chunk, each kernel class runs K1 -> K2 -> K3 on its own stream (forked from and
+    // joined into `base`); one_stream: everything on `base` (retry rounds that run beside other work)
+    auto run_dense = [&](const Plan &P, const int32_t *d_work, hipStream_t base, bool one_stream) -> int {
         for (const Chunk &ch : P.chunks) {
-            HIPCHK(h, hipEventRecord(h->ev_fork, st));
+            if (!one_stream) HIPCHK(h, hipEventRecord(h->ev_fork, base));
             for (const Launch &L : ch.launches) {
                 const KernelClass &K = CLASSES[L.cls];
-                hipStream_t ks = h->cls_stream[L.cls];
-                HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
+                hipStream_t ks = one_stream ? base : h->cls_stream[L.cls];
+                if (!one_stream) HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
                 size_t lds_f = 0, lds_b = 0;
                 vpr_launch_stat ls;
                 memset(&ls, 0, sizeof(ls));
@@ -735,7 +769,7 @@ int vpr_execute(vpr_handle *h) {
                 ls.bytes_algorithmic = ls.cells + in_bytes;
                 int rc = timed(1, ls, ks, [&] {
                     hipLaunchKernelGGL(fwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_f, ks, h->dB, h->d_descs,
-                                       d_work + L.work_off, h->d_arena, h->d_outs);
+                                       d_work + L.work_off, P.arena, h->d_outs);
                     hipLaunchKernelGGL(k_fwd_finish, dim3((L.count + 255) / 256), dim3(256), 0, ks,
                                        d_work + L.work_off, L.count, h->d_outs);
                 });
@@ -744,133 +778,121 @@ int vpr_execute(vpr_handle *h) {
                 ls.bytes_algorithmic = ls.cells;
                 rc = timed(2, ls, ks, [&] {
                     hipLaunchKernelGGL(bwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
-                                       d_work + L.work_off, h->d_arena, h->d_outs);
+                                       d_work + L.work_off, P.arena, h->d_outs);
                 });
                 if (rc) return rc;
-                if ((rc = walk_launch(d_work + L.work_off, L.count, ks, false))) return rc;
-                HIPCHK(h, hipEventRecord(h->ev_join[L.cls], ks));
-                HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[L.cls], 0));
+                if ((rc = walk_launch(P, d_work + L.work_off, L.count, ks, false, 0))) return rc;
+                if (!one_stream) {
+                    HIPCHK(h, hipEventRecord(h->ev_join[L.cls], ks));
+                    HIPCHK(h, hipStreamWaitEvent(base, h->ev_join[L.cls], 0));
+                }
             }
         }
         return VPR_OK;
     };
 
-    // ---- banded plan.  Per chunk the work list (sorted longest first) is split into a long and a short
-    // part that run K1b -> K2b -> K3 on two streams: the long alignments are a latency chain (rows are
-    // sequential), the short ones a throughput problem, and they overlap.  K2b/K3 skip alignments whose
-    // window failed the exit test, so there is no host round trip inside a round; the rejected ids are
-    // collected on the device and read back once per round.
-    auto run_band = [&](const Plan &P, const int32_t *d_work, std::vector<int32_t> &fails) -> int {
-        HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
-        for (const Chunk &ch : P.chunks) {
-            int32_t n_long = 0;
-            while (n_long < ch.count && P.descs[ch.work_off + n_long].Lt >= LONG_LT) n_long++;
-            // a LV_Q16 plan's long alignments use the 64-cell layout and cannot share a launch with the rest
-            if (P.lv != LV_Q16 && (n_long == ch.count || ch.count < 4096)) n_long = 0;     // nothing to overlap with
-            HIPCHK(h, hipEventRecord(h->ev_fork, st));
-            for (int part = 0; part < 2; part++) {
-                const int32_t off = part == 0 ? 0 : n_long, cnt = part == 0 ? n_long : ch.count - n_long;
-                if (cnt <= 0) continue;
-                const int lv = (P.lv == LV_Q16 && part == 0) ? int(LV_C1) : P.lv;
-                const int W = LV_WINDOW[lv], C = W / 64;
-                hipStream_t ks = h->cls_stream[part];
-                HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
-                const int32_t *list = d_work + ch.work_off + off;
-                vpr_launch_stat ls;
-                memset(&ls, 0, sizeof(ls));
-                ls.threads = lv == LV_Q16 ? 16 : 64; ls.cells_per_thread = lv == LV_Q16 ? 1 : C; ls.n_units = cnt;
-                int64_t in_bytes = 0;
-                for (int32_t w = 0; w < cnt; w++) {
-                    const AlnDesc &d = P.descs[ch.work_off + off + w];
-                    ls.cells += int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt;
-                    in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
-                }
-                ls.bytes_algorithmic = ls.cells + in_bytes;
-                cells_touched += ls.cells;
-                int rc = timed(1, ls, ks, [&] {
-                    if (lv == LV_Q16)
-                        hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                           h->d_arena, arena_i32, h->d_outs);
-                    else
-                        hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
-                                           h->d_arena, arena_i32, h->d_outs);
-                    hipLaunchKernelGGL(k_fwd_band_finish, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs);
-                });
-                if (rc) return rc;
-                n_fwd++;
-                ls.bytes_algorithmic = ls.cells;
-                rc = timed(2, ls, ks, [&] {
-                    if (lv == LV_Q16)
-                        hipLaunchKernelGGL(k_bwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                           h->d_arena, arena_i32, h->d_outs);
-                    else
-                        hipLaunchKernelGGL(band_bwd_kernel(lv), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
-                                           h->d_arena, arena_i32, h->d_outs);
-                });
-                if (rc) return rc;
-                // long part (or a small launch of long retries): wave-per-alignment walk; windows up to 256
-                const bool wave_walk = lv != LV_Q16 && C <= 4 && (part == 0 || cnt < 2048);
-                const bool row_walk = lv == LV_C1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") &&
-                                      !getenv("VPR_NO_ROWWALK") && (wave_walk || getenv("VPR_ROWWALK_ALL"));
-                if (lv == LV_Q16 && !getenv("VPR_NO_Q16WALK")) {
-                    // 16-cell layout: row-sweep walk, four alignments per wave (phase A) + credit walk (phase B)
-                    vpr_launch_stat ws_;
-                    memset(&ws_, 0, sizeof(ws_));
-                    ws_.threads = 16; ws_.n_units = cnt; ws_.cells_per_thread = 2;
-                    rc = timed(3, ws_, ks, [&] {
-                        hipLaunchKernelGGL(k_walk_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                           h->d_arena, arena_i32, h->d_outs, arena_path);
-                    });
-                    if (rc) return rc;
-                    ws_.cells_per_thread = 3;
-                    rc = timed(3, ws_, ks, [&] {
-                        hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
-                                           list, cnt, h->d_outs, arena_path, h->d_secs, h->d_fp_table, h->d_jobs,
-                                           h->d_njobs, h->jobs_cap);
-                    });
-                    if (rc) return rc;
-                } else if (row_walk) {
-                    // striped layout, long alignments: row-sweep walk (phase A) + credit walk (phase B); for the
-                    // short ones the per-wave setup outweighs the pointer chase of the lane-per-alignment walk
-                    vpr_launch_stat ws_;
-                    memset(&ws_, 0, sizeof(ws_));
-                    ws_.threads = 64; ws_.n_units = cnt; ws_.cells_per_thread = 2;
-                    rc = timed(3, ws_, ks, [&] {
-                        hipLaunchKernelGGL(k_walk_rows, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                           h->d_arena, arena_i32, h->d_outs, arena_path);
-                    });
-                    if (rc) return rc;
-                    ws_.cells_per_thread = 3;
-                    rc = timed(3, ws_, ks, [&] {
-                        if (wave_walk)
-                            hipLaunchKernelGGL(k_credit<true>, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                               h->d_outs, arena_path, h->d_secs, h->d_fp_table, h->d_jobs, h->d_njobs,
-                                               h->jobs_cap);
-                        else
-                            hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
-                                               list, cnt, h->d_outs, arena_path, h->d_secs, h->d_fp_table, h->d_jobs,
-                                               h->d_njobs, h->jobs_cap);
-                    });
-                    if (rc) return rc;
-                } else if ((rc = walk_launch(list, cnt, ks, wave_walk))) return rc;
-                hipLaunchKernelGGL(k_collect_fails, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs,
-                                   h->d_fail, h->d_cnt);
-                HIPCHK(h, hipEventRecord(h->ev_join[part], ks));
-                HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[part], 0));
-            }
+    // ---- one launch sequence of a windowed plan: `cnt` alignments of the plan's work list from `off`, all at
+    // level lv, on stream ks:  K1 -> accept test -> rejected ids appended to fail slot `slot` (event
+    // ev_slot[slot] marks the list complete) -> K2 -> K3.  K2/K3 skip rejected alignments, so the host can
+    // start their retry round while this sequence is still running.
+    auto enqueue_part = [&](const Plan &P, const int32_t *d_work, int64_t off, int32_t cnt, int lv, hipStream_t ks,
+                            int slot, int64_t fail_off, bool long_part, int64_t part_cells, int64_t part_in) -> int {
+        const int W = LV_WINDOW[lv], C = W / 64;
+        const int32_t *list = d_work + off;
+        int32_t *a_i32 = reinterpret_cast<int32_t *>(P.arena);
+        PathEnt *a_path = reinterpret_cast<PathEnt *>(P.arena);
+        vpr_launch_stat ls;
+        memset(&ls, 0, sizeof(ls));
+        ls.threads = lv == LV_Q16 ? 16 : 64; ls.cells_per_thread = lv == LV_Q16 ? 1 : C; ls.n_units = cnt;
+        ls.cells = part_cells;
+        ls.bytes_algorithmic = ls.cells + part_in;
+        cells_touched += ls.cells;
+        int rc = timed(1, ls, ks, [&] {
+            if (lv == LV_Q16)
+                hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                   P.arena, a_i32, h->d_outs);
+            else
+                hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
+                                   P.arena, a_i32, h->d_outs);
+            hipLaunchKernelGGL(k_fwd_band_finish, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs, W);
+        });
+        if (rc) return rc;
+        n_fwd++;
+        hipLaunchKernelGGL(k_collect_fails, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs,
+                           h->d_fail + fail_off, h->d_cnt + slot);
+        HIPCHK(h, hipEventRecord(h->ev_slot[slot], ks));
+        ls.bytes_algorithmic = ls.cells;
+        rc = timed(2, ls, ks, [&] {
+            if (lv == LV_Q16)
+                hipLaunchKernelGGL(k_bwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                   P.arena, a_i32, h->d_outs);
+            else
+                hipLaunchKernelGGL(band_bwd_kernel(lv), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
+                                   P.arena, a_i32, h->d_outs);
+        });
+        if (rc) return rc;
+        // long part (or a small launch of long retries): wave-per-alignment walk; windows up to 256
+        const bool wave_walk = lv != LV_Q16 && C <= 4 && (long_part || cnt < 2048);
+        const bool row_walk = lv == LV_C1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") &&
+                              !getenv("VPR_NO_ROWWALK") && (wave_walk || getenv("VPR_ROWWALK_ALL"));
+        vpr_launch_stat ws_;
+        memset(&ws_, 0, sizeof(ws_));
+        ws_.threads = lv == LV_Q16 ? 16 : 64; ws_.n_units = cnt; ws_.cells_per_thread = 2;
+        if (lv == LV_Q16 && !getenv("VPR_NO_Q16WALK")) {
+            // 16-cell layout: row-sweep walk, four alignments per wave (phase A) + credit walk (phase B)
+            rc = timed(3, ws_, ks, [&] {
+                hipLaunchKernelGGL(k_walk_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                   P.arena, a_i32, h->d_outs, a_path);
+            });
+            if (rc) return rc;
+            ws_.cells_per_thread = 3;
+            rc = timed(3, ws_, ks, [&] {
+                hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
+                                   list, cnt, h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs,
+                                   h->d_njobs, h->jobs_cap, W);
+            });
+        } else if (row_walk) {
+            // striped 64-cell layout, long alignments: row-sweep walk (phase A) + credit walk (phase B); for the
+            // short ones the per-wave setup outweighs the pointer chase of the lane-per-alignment walk
+            rc = timed(3, ws_, ks, [&] {
+                hipLaunchKernelGGL(k_walk_rows, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                   P.arena, a_i32, h->d_outs, a_path);
+            });
+            if (rc) return rc;
+            ws_.cells_per_thread = 3;
+            rc = timed(3, ws_, ks, [&] {
+                if (wave_walk)
+                    hipLaunchKernelGGL(k_credit<true>, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                       h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs, h->d_njobs,
+                                       h->jobs_cap, W);
+                else
+                    hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
+                                       list, cnt, h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs,
+                                       h->d_njobs, h->jobs_cap, W);
+            });
+        } else {
+            rc = walk_launch(P, list, cnt, ks, wave_walk, W);
         }
+        return rc;
+    };
+
+    // read a fail slot once its list is complete (copies ride on stream `ls`, never the null stream)
+    auto read_fails = [&](int slot, int64_t fail_off, hipStream_t ls, std::vector<int32_t> &fails) -> int {
         int32_t nf = 0;
-        HIPCHK(h, hipMemcpyAsync(&nf, h->d_cnt, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipStreamWaitEvent(ls, h->ev_slot[slot], 0));
+        HIPCHK(h, hipMemcpyAsync(&nf, h->d_cnt + slot, 4, hipMemcpyDeviceToHost, ls));
+        HIPCHK(h, hipStreamSynchronize(ls));
         if (nf > 0) {
             const size_t f0 = fails.size();
             fails.resize(f0 + size_t(nf));
-            HIPCHK(h, hipMemcpy(fails.data() + f0, h->d_fail, size_t(nf) * 4, hipMemcpyDeviceToHost));
+            HIPCHK(h, hipMemcpyAsync(fails.data() + f0, h->d_fail + fail_off, size_t(nf) * 4, hipMemcpyDeviceToHost, ls));
+            HIPCHK(h, hipStreamSynchronize(ls));
             if (getenv("VPR_DEBUG") && nf <= 64) {
                 for (size_t k = f0; k < fails.size(); k++) {
                     const int32_t a = fails[k];
                     AlnOut o;
-                    (void)hipMemcpy(&o, h->d_outs + a, sizeof(o), hipMemcpyDeviceToHost);
+                    (void)hipMemcpyAsync(&o, h->d_outs + a, sizeof(o), hipMemcpyDeviceToHost, ls);
+                    (void)hipStreamSynchronize(ls);
                     const AlnDesc &d = h->descs[a];
                     fprintf(stderr, "[vpr] level %d rejected sc %d aln %d: Lq %d Lr %d Lt %d  s %d exit_min %d dq %d dr %d\n",
                             int(h->level[a]), d.sc, d.aln, d.Lq, d.Lr, d.Lt, o.s, o.exit_min, o.dist_q, o.dist_r);
@@ -880,8 +902,8 @@ int vpr_execute(vpr_handle *h) {
         return VPR_OK;
     };
 
-    // upload a retry plan's descriptors / work list
-    auto stage_plan = [&](const Plan &P, const int32_t **d_work) -> int {
+    // upload a retry plan's descriptors / work list (one retry plan is in flight at a time)
+    auto stage_plan = [&](const Plan &P, hipStream_t ls, const int32_t **d_work) -> int {
         const size_t n = P.work.size();
         if (h->tmp_descs_cap < n) {
             int rc = dev_alloc(h, &h->d_tmp_descs, n * 2);
@@ -893,31 +915,18 @@ int vpr_execute(vpr_handle *h) {
             if (rc) return rc;
             h->tmp_work_cap = n * 2;
         }
-        HIPCHK(h, hipMemcpyAsync(h->d_tmp_descs, P.descs.data(), n * sizeof(AlnDesc), hipMemcpyHostToDevice, st));
-        HIPCHK(h, hipMemcpyAsync(h->d_tmp_work, P.work.data(), n * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(n)), dim3(256), 0, st, h->d_tmp_descs, int(n), h->d_descs);
-        HIPCHK(h, hipStreamSynchronize(st));   // the staging buffers are reused by the next round
+        HIPCHK(h, hipMemcpyAsync(h->d_tmp_descs, P.descs.data(), n * sizeof(AlnDesc), hipMemcpyHostToDevice, ls));
+        HIPCHK(h, hipMemcpyAsync(h->d_tmp_work, P.work.data(), n * 4, hipMemcpyHostToDevice, ls));
+        hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(n)), dim3(256), 0, ls, h->d_tmp_descs, int(n), h->d_descs);
         h->dirty.insert(h->dirty.end(), P.work.begin(), P.work.end());
         *d_work = h->d_tmp_work;
         return VPR_OK;
     };
 
-    int rc = VPR_OK;
-    h->last_chunk.clear();
-    h->level = h->level0;
-    auto keep_last = [&](const Plan &P) {
-        if (P.chunks.empty()) return;
-        const Chunk &c = P.chunks.back();
-        h->last_chunk.assign(P.work.begin() + c.work_off, P.work.begin() + c.work_off + c.count);
-    };
-    if (h->cfg.band_mode == 0) {
-        if ((rc = run_dense(h->plan0, h->plan0.d_work))) return rc;
-        keep_last(h->plan0);
-    } else {
-        std::vector<int32_t> fails;
-        if ((rc = run_band(h->plan0, h->plan0.d_work, fails))) return rc;
-        keep_last(h->plan0);
-        // retry rounds: every rejected alignment climbs one window level (16 -> 64 -> 256 -> 1024 -> dense)
+    // retry rounds on stream `ls` (workspace: the second arena): every rejected alignment climbs one window
+    // level (16 -> 64 -> 256 -> 1024 -> dense) until its exit test passes.  The host blocks on `ls` only.
+    auto ladder = [&](std::vector<int32_t> &fails, hipStream_t ls) -> int {
+        const int64_t na_ = int64_t(h->descs.size());
         while (!fails.empty()) {
             n_retry += int64_t(fails.size());
             std::sort(fails.begin(), fails.end());   // deterministic planning of the next round
@@ -929,15 +938,85 @@ int vpr_execute(vpr_handle *h) {
             for (int lv = LV_C1; lv <= LV_DENSE; lv++) {
                 if (by_lv[lv].empty()) continue;
                 Plan P;
-                if ((rc = make_plan(h, by_lv[lv], lv, P))) return rc;
+                int rc = make_plan(h, by_lv[lv], lv, P, h->d_arena2, h->arena2_bytes);
+                if (rc) return rc;
                 const int32_t *d_work = nullptr;
-                if ((rc = stage_plan(P, &d_work))) return rc;
-                if (lv == LV_DENSE) { if ((rc = run_dense(P, d_work))) return rc; }
-                else { if ((rc = run_band(P, d_work, next))) return rc; }
-                keep_last(P);
-                HIPCHK(h, hipStreamSynchronize(st));
+                if ((rc = stage_plan(P, ls, &d_work))) return rc;
+                if (lv == LV_DENSE) {
+                    if ((rc = run_dense(P, d_work, ls, true))) return rc;
+                    HIPCHK(h, hipStreamSynchronize(ls));
+                } else {
+                    for (const Chunk &ch : P.chunks) {
+                        const int32_t n_long = ch.n_long;
+                        HIPCHK(h, hipMemsetAsync(h->d_cnt + 2, 0, 8, ls));
+                        if (n_long > 0 && (rc = enqueue_part(P, d_work, ch.work_off, n_long, lv, ls, 2, na_, true, ch.part_cells[0], ch.part_in[0]))) return rc;
+                        if (ch.count > n_long &&
+                            (rc = enqueue_part(P, d_work, ch.work_off + n_long, ch.count - n_long, lv, ls, 3, na_ + n_long, false,
+                                              ch.part_cells[1], ch.part_in[1])))
+                            return rc;
+                        if (n_long > 0 && (rc = read_fails(2, na_, ls, next))) return rc;
+                        if (ch.count > n_long && (rc = read_fails(3, na_ + n_long, ls, next))) return rc;
+                    }
+                }
+                h->resident.emplace_back(std::move(P.work), P.arena);
             }
             fails.swap(next);
+        }
+        return VPR_OK;
+    };
+
+    int rc = VPR_OK;
+    h->resident.clear();
+    h->level = h->level0;
+    if (h->cfg.band_mode == 0) {
+        if ((rc = run_dense(h->plan0, h->plan0.d_work, st, false))) return rc;
+        if (!h->plan0.chunks.empty()) {
+            const Chunk &c = h->plan0.chunks.back();
+            h->resident.emplace_back(std::vector<int32_t>(h->plan0.work.begin() + c.work_off,
+                                                          h->plan0.work.begin() + c.work_off + c.count), h->plan0.arena);
+        }
+    } else {
+        // Per chunk of the round-0 plan: the short alignments (a throughput problem) and the long ones (latency
+        // chains: rows are sequential) run on two streams; the ids rejected by the exit test are known right
+        // after each forward sweep, and their retry rounds run on a third stream beside the rest of the round.
+        const Plan &P0 = h->plan0;
+        hipStream_t s_long = h->cls_stream[0], s_short = h->cls_stream[1], s_retry = h->cls_stream[2];
+        for (size_t ci = 0; ci < P0.chunks.size(); ci++) {
+            const Chunk &ch = P0.chunks[ci];
+            const int32_t n_long = ch.n_long;
+            HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 16, st));
+            HIPCHK(h, hipEventRecord(h->ev_fork, st));
+            HIPCHK(h, hipStreamWaitEvent(s_long, h->ev_fork, 0));
+            HIPCHK(h, hipStreamWaitEvent(s_short, h->ev_fork, 0));
+            HIPCHK(h, hipStreamWaitEvent(s_retry, h->ev_fork, 0));
+            if (ch.count > n_long) {
+                const int lv = P0.lv;
+                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, ch.count - n_long, lv, s_short, 1, n_long, false,
+                                       ch.part_cells[1], ch.part_in[1]))) return rc;
+            }
+            if (n_long > 0) {
+                const int lv = P0.lv == LV_Q16 ? int(LV_C1) : P0.lv;
+                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0], ch.part_in[0]))) return rc;
+            }
+            std::vector<int32_t> fails;
+            if (n_long > 0) {
+                if ((rc = read_fails(0, 0, s_retry, fails))) return rc;
+                if ((rc = ladder(fails, s_retry))) return rc;
+            }
+            if (ch.count > n_long) {
+                fails.clear();
+                if ((rc = read_fails(1, n_long, s_retry, fails))) return rc;
+                if ((rc = ladder(fails, s_retry))) return rc;
+            }
+            // join: the next chunk reuses the arena
+            HIPCHK(h, hipEventRecord(h->ev_join[0], s_long));
+            HIPCHK(h, hipEventRecord(h->ev_join[1], s_short));
+            HIPCHK(h, hipEventRecord(h->ev_join[2], s_retry));
+            for (int k = 0; k < 3; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
+            if (ci + 1 < P0.chunks.size()) HIPCHK(h, hipStreamSynchronize(st));
+            if (ci + 1 == P0.chunks.size())
+                h->resident.emplace(h->resident.begin(), std::vector<int32_t>(P0.work.begin() + ch.work_off,
+                                                                              P0.work.begin() + ch.work_off + ch.count), P0.arena);
         }
     }
 
@@ -1073,16 +1152,20 @@ int vpr_run(vpr_handle *h, const vpr_batch *batch, vpr_results *res) {
 int64_t vpr_download_path(const vpr_handle *h, int32_t sc, int32_t aln, int64_t cap,
                           uint8_t *plane, int32_t *qri, int32_t *ti, uint8_t *sync, uint8_t *edit) {
     if (!h || !h->executed || sc < 0 || sc >= h->n_sc || aln < 0 || aln > 3) return VPR_ERR_ARG;
-    // the walk scratch lives in the arena and is reused per chunk: only the last chunk is still resident
+    // the walk scratch lives in a workspace that is reused per chunk: only the last chunk of round 0 and the
+    // retry plans are still resident (the most recent plan of an alignment holds its final walk)
     const int32_t a = sc * 4 + aln;
-    if (std::find(h->last_chunk.begin(), h->last_chunk.end(), a) == h->last_chunk.end()) return VPR_ERR_STATE;
+    const uint8_t *arena = nullptr;
+    for (auto it = h->resident.rbegin(); it != h->resident.rend() && !arena; ++it)
+        if (std::find(it->first.begin(), it->first.end(), a) != it->first.end()) arena = it->second;
+    if (!arena) return VPR_ERR_STATE;
     AlnOut O;
     AlnDesc d;
     if (hipMemcpy(&O, h->d_outs + a, sizeof(O), hipMemcpyDeviceToHost) != hipSuccess) return VPR_ERR_DEVICE;
     if (hipMemcpy(&d, h->d_descs + a, sizeof(d), hipMemcpyDeviceToHost) != hipSuccess) return VPR_ERR_DEVICE;
     const int64_t n = std::min<int64_t>(O.path_len, cap);
     std::vector<PathEnt> p(n);
-    if (n && hipMemcpy(p.data(), reinterpret_cast<const PathEnt *>(h->d_arena) + d.path_off, n * sizeof(PathEnt),
+    if (n && hipMemcpy(p.data(), reinterpret_cast<const PathEnt *>(arena) + d.path_off, n * sizeof(PathEnt),
                        hipMemcpyDeviceToHost) != hipSuccess)
         return VPR_ERR_DEVICE;
     for (int64_t k = 0; k < n; k++) {

@@ -435,14 +435,17 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
     }
 }
 
-// s, end plane (prefer QUERY, dist.cpp:436-439) and the band acceptance test
-__global__ void k_fwd_band_finish(const int32_t *__restrict__ work, int n, AlnOut *__restrict__ outs) {
+// s, end plane (prefer QUERY, dist.cpp:436-439) and the window acceptance test.  band_ok holds the window
+// width W the alignment was accepted at (0: rejected): the later kernels of a round process an alignment only
+// if band_ok and its descriptor both carry their own W, so a retry round that re-plans a rejected alignment
+// (new descriptor, wider window) may run concurrently with the rest of the round that rejected it.
+__global__ void k_fwd_band_finish(const int32_t *__restrict__ work, int n, AlnOut *__restrict__ outs, int W) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     AlnOut &o = outs[work[i]];
     o.s = min(o.dist_q, o.dist_r);
     o.end_plane = (o.dist_q <= o.dist_r) ? VPR_PLANE_QUERY : VPR_PLANE_REF;
-    o.band_ok = (o.s < D_INF / 2 && o.exit_min > o.s) ? 1 : 0;
+    o.band_ok = (o.s < D_INF / 2 && o.exit_min > o.s) ? W : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -511,7 +514,7 @@ __global__ void __launch_bounds__(64) k_bwd_band(DevBatch B, const AlnDesc *__re
     const int32_t *bk[2] = {B.bk_q[d.qs] + d.q_off, B.bk_r[d.qs] + d.r_off};
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     const int32_t *blo = blo_all + d.blo_off;
-    if (!outs[a].band_ok) return;   // window rejected by the exit test: this alignment is re-run wider
+    if (outs[a].band_ok != 64 * C || d.band_w != 64 * C) return;   // rejected by the exit test: re-run wider
     const int end_plane = outs[a].end_plane;
     const int off0 = (63 - lane) * C;
 
@@ -970,7 +973,7 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
                                                    const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
-    if (!outs[a].band_ok) return;   // window rejected by the exit test: this alignment is re-run wider
+    if (outs[a].band_ok != FS_W || d.band_w != FS_W) return;   // rejected by the exit test: re-run wider
     const int lane = threadIdx.x;
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int Lp[2] = {Lq, Lr};
@@ -1170,7 +1173,7 @@ __global__ void __launch_bounds__(64) k_walk_rows(DevBatch B, const AlnDesc *__r
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     AlnOut &O = outs[a];
-    if (!O.band_ok) return;
+    if (O.band_ok != FS_W || d.band_w != FS_W) return;
     const int lane = threadIdx.x;
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int Lp[2] = {Lq, Lr};

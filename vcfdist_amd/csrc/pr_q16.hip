@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
     const bool live = wi < n_work;
     const int a = work[live ? wi : n_work - 1];
     const AlnDesc *dp = descs + a;
-    const bool on = live && outs[a].band_ok;   // window rejected by the exit test: re-run wider
+    const bool on = live && outs[a].band_ok == Q_W && dp->band_w == Q_W;   // else rejected: re-run wider
     const int Lq = dp->Lq, Lr = dp->Lr, Lt = on ? dp->Lt : 0;
     const int qs = dp->qs;
     const int Lp[2] = {Lq, Lr};
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__re
     const bool live = wi < n_work;
     const int a = work[live ? wi : n_work - 1];
     const AlnDesc *dp = descs + a;
-    const bool on = live && outs[a].band_ok;
+    const bool on = live && outs[a].band_ok == Q_W && dp->band_w == Q_W;
     const int Lq = dp->Lq, Lr = dp->Lr, Lt = on ? dp->Lt : 0;
     const int qs = dp->qs, ts = dp->ts;
     const int path_cap = dp->path_cap;
