@@ -61,6 +61,21 @@ struct Plan {
     AlnDesc *d_descs = nullptr;     // device copy of `descs` (plan 0 only, cached)
     int32_t *d_work = nullptr;
     uint8_t *arena = nullptr;       // workspace the offsets refer to
+    int64_t arena_used = 0;         // bytes of it the largest chunk occupies
+};
+
+// a retry ladder's private resources (see vpr_execute)
+struct LadderCtx {
+    static const int N_SLOTS = 16;
+    hipStream_t ls = nullptr;
+    int slot0 = 0;                          // first of its N_SLOTS fail slots
+    int64_t fail_base = 0;                  // its region of the fail-list buffer
+    uint8_t *arena = nullptr; int64_t arena_bytes = 0;
+    AlnDesc *d_descs = nullptr; size_t descs_cap = 0;   // staging of the plans in flight
+    int32_t *d_work = nullptr; size_t work_cap = 0;
+    int slot_cur = 0; int64_t fail_cur = 0, arena_cur = 0; size_t stage_cur = 0;
+    std::vector<std::pair<int, int64_t>> pending;       // (slot, fail list offset) of the launches in flight
+    std::vector<Plan> plans;
 };
 
 struct EvPair { hipEvent_t a, b; int kind; vpr_launch_stat st; };
@@ -88,8 +103,8 @@ struct vpr_handle {
     AlnDesc *d_descs = nullptr;
     AlnOut *d_outs = nullptr;
     uint8_t *d_arena = nullptr; int64_t arena_bytes = 0;      // workspace of the round-0 plan
-    uint8_t *d_arena2 = nullptr; int64_t arena2_bytes = 0;    // workspace of the retry rounds (run beside round 0)
-    hipEvent_t ev_slot[4] = {nullptr, nullptr, nullptr, nullptr};   // "fail list of slot k is complete"
+    LadderCtx lad[2];                                         // retry ladders (their workspaces live beside the arena)
+    hipEvent_t ev_slot[2 + 2 * LadderCtx::N_SLOTS] = {};      // "fail list of slot k is complete"
     std::vector<std::pair<std::vector<int32_t>, uint8_t *>> resident;   // alignments whose walks are still in a workspace
     Section *d_secs = nullptr; int64_t n_secs_cap = 0;
     int32_t *d_fp[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -157,7 +172,8 @@ void free_batch(vpr_handle *h) {
     h->descs.clear();
     h->plan0 = Plan();
     h->dirty.clear();
-    h->d_arena = nullptr; h->d_arena2 = nullptr; h->d_secs = nullptr;
+    h->d_arena = nullptr; h->d_secs = nullptr;
+    for (int k = 0; k < 2; k++) h->lad[k] = LadderCtx();
     h->resident.clear();
     h->d_ed_scratch = nullptr; h->ed_scratch_ints = 0;
     h->d_tmp_descs = nullptr; h->tmp_descs_cap = 0;
@@ -376,6 +392,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
                 w = e;
             }
         }
+        P.arena_used = std::max(P.arena_used, used);
         P.chunks.push_back(std::move(ch));
     }
     return VPR_OK;
@@ -411,7 +428,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
             return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
         }
     }
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 2 + 2 * LadderCtx::N_SLOTS; k++)
         if (hipEventCreateWithFlags(&h->ev_slot[k], hipEventDisableTiming) != hipSuccess)
             return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess)
@@ -437,7 +454,7 @@ void vpr_destroy(vpr_handle *h) {
         if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 2 + 2 * LadderCtx::N_SLOTS; k++)
         if (h->ev_slot[k]) (void)hipEventDestroy(h->ev_slot[k]);
     delete h;
 }
@@ -605,7 +622,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     R.phase_threshold = h->cfg.phase_threshold;
     if ((rc = dev_alloc(h, &h->d_ok, na))) return rc;
     if ((rc = dev_alloc(h, &h->d_fail, 2 * na + 64))) return rc;   // round-0 lists [0, na), retry rounds [na, 2 na)
-    if ((rc = dev_alloc(h, &h->d_cnt, 8))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cnt, 2 + 2 * LadderCtx::N_SLOTS))) return rc;
 
     lap("result/aux allocations");
     // ---- arena for flag matrices, band origins and walks
@@ -627,14 +644,16 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     }
     h->arena_bytes = budget;
     if ((rc = dev_alloc(h, &h->d_arena, size_t(budget) + 256))) return rc;
-    // second workspace for the retry rounds, which run beside round 0 (cfg.workspace_bytes bounds each of the two)
+    // workspaces of the two retry ladders, which run beside round 0 (cfg.workspace_bytes bounds each workspace)
     if (h->cfg.band_mode != 0) {
         HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
         int64_t b2 = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes
-                                                : std::min<int64_t>(int64_t(double(free_b) * 0.5), std::max<int64_t>(budget, int64_t(2) << 30));
+                                                : std::min<int64_t>(int64_t(double(free_b) * 0.25), std::max<int64_t>(budget / 2, int64_t(4) << 30));
         if (b2 < (8 << 20)) b2 = 8 << 20;
-        h->arena2_bytes = b2;
-        if ((rc = dev_alloc(h, &h->d_arena2, size_t(b2) + 256))) return rc;
+        for (int k = 0; k < 2; k++) {
+            h->lad[k].arena_bytes = b2;
+            if ((rc = dev_alloc(h, &h->lad[k].arena, size_t(b2) + 256))) return rc;
+        }
     }
 
     lap("arena allocation");
@@ -902,65 +921,96 @@ int vpr_execute(vpr_handle *h) {
         return VPR_OK;
     };
 
-    // upload a retry plan's descriptors / work list (one retry plan is in flight at a time)
-    auto stage_plan = [&](const Plan &P, hipStream_t ls, const int32_t **d_work) -> int {
-        const size_t n = P.work.size();
-        if (h->tmp_descs_cap < n) {
-            int rc = dev_alloc(h, &h->d_tmp_descs, n * 2);
+    // ---- retry ladders.  Every rejected alignment climbs one window level (16 -> 64 -> 256 -> 1024 -> dense)
+    // until its exit test passes.  Two independent ladders (one fed by the long part of round 0, one by the
+    // short part) each own a stream, a workspace, staging buffers and fail slots, so their rounds run beside
+    // each other and beside the rest of round 0; the host only ever waits for a fail list it needs next.
+    auto lad_flush = [&](LadderCtx &c, std::vector<int32_t> &out) -> int {
+        for (const auto &pd : c.pending) {
+            int rc = read_fails(pd.first, pd.second, c.ls, out);
             if (rc) return rc;
-            h->tmp_descs_cap = n * 2;
         }
-        if (h->tmp_work_cap < n) {
-            int rc = dev_alloc(h, &h->d_tmp_work, n * 2);
-            if (rc) return rc;
-            h->tmp_work_cap = n * 2;
-        }
-        HIPCHK(h, hipMemcpyAsync(h->d_tmp_descs, P.descs.data(), n * sizeof(AlnDesc), hipMemcpyHostToDevice, ls));
-        HIPCHK(h, hipMemcpyAsync(h->d_tmp_work, P.work.data(), n * 4, hipMemcpyHostToDevice, ls));
-        hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(n)), dim3(256), 0, ls, h->d_tmp_descs, int(n), h->d_descs);
-        h->dirty.insert(h->dirty.end(), P.work.begin(), P.work.end());
-        *d_work = h->d_tmp_work;
+        c.pending.clear();
+        c.plans.clear();
+        c.slot_cur = 0; c.fail_cur = 0; c.stage_cur = 0; c.arena_cur = 0;
         return VPR_OK;
     };
-
-    // retry rounds on stream `ls` (workspace: the second arena): every rejected alignment climbs one window
-    // level (16 -> 64 -> 256 -> 1024 -> dense) until its exit test passes.  The host blocks on `ls` only.
-    auto ladder = [&](std::vector<int32_t> &fails, hipStream_t ls) -> int {
-        const int64_t na_ = int64_t(h->descs.size());
-        while (!fails.empty()) {
-            n_retry += int64_t(fails.size());
-            std::sort(fails.begin(), fails.end());   // deterministic planning of the next round
-            std::vector<int32_t> by_lv[LV_DENSE + 1], next;
-            for (int32_t a : fails) by_lv[std::min<int>(h->level[size_t(a)] + 1, LV_DENSE)].push_back(a);
-            if (getenv("VPR_DEBUG"))
-                fprintf(stderr, "[vpr] retry round: %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n", by_lv[1].size(),
-                        by_lv[2].size(), by_lv[3].size(), by_lv[4].size());
-            for (int lv = LV_C1; lv <= LV_DENSE; lv++) {
-                if (by_lv[lv].empty()) continue;
-                Plan P;
-                int rc = make_plan(h, by_lv[lv], lv, P, h->d_arena2, h->arena2_bytes);
-                if (rc) return rc;
-                const int32_t *d_work = nullptr;
-                if ((rc = stage_plan(P, ls, &d_work))) return rc;
-                if (lv == LV_DENSE) {
-                    if ((rc = run_dense(P, d_work, ls, true))) return rc;
-                    HIPCHK(h, hipStreamSynchronize(ls));
-                } else {
-                    for (const Chunk &ch : P.chunks) {
-                        const int32_t n_long = ch.n_long;
-                        HIPCHK(h, hipMemsetAsync(h->d_cnt + 2, 0, 8, ls));
-                        if (n_long > 0 && (rc = enqueue_part(P, d_work, ch.work_off, n_long, lv, ls, 2, na_, true, ch.part_cells[0], ch.part_in[0]))) return rc;
-                        if (ch.count > n_long &&
-                            (rc = enqueue_part(P, d_work, ch.work_off + n_long, ch.count - n_long, lv, ls, 3, na_ + n_long, false,
-                                              ch.part_cells[1], ch.part_in[1])))
-                            return rc;
-                        if (n_long > 0 && (rc = read_fails(2, na_, ls, next))) return rc;
-                        if (ch.count > n_long && (rc = read_fails(3, na_ + n_long, ls, next))) return rc;
+    auto lad_start = [&](LadderCtx &c, std::vector<int32_t> &fails, std::vector<int32_t> &carry) -> int {
+        if (fails.empty()) return VPR_OK;
+        n_retry += int64_t(fails.size());
+        std::sort(fails.begin(), fails.end());   // deterministic planning
+        std::vector<int32_t> by_lv[LV_DENSE + 1];
+        for (int32_t a : fails) by_lv[std::min<int>(h->level[size_t(a)] + 1, LV_DENSE)].push_back(a);
+        if (getenv("VPR_DEBUG"))
+            fprintf(stderr, "[vpr] retry round (ladder %d): %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n",
+                    int(&c - h->lad), by_lv[1].size(), by_lv[2].size(), by_lv[3].size(), by_lv[4].size());
+        const size_t nf = fails.size();
+        if (c.descs_cap < nf) {
+            int rc = dev_alloc(h, &c.d_descs, nf * 2);
+            if (rc) return rc;
+            c.descs_cap = nf * 2;
+        }
+        if (c.work_cap < nf) {
+            int rc = dev_alloc(h, &c.d_work, nf * 2);
+            if (rc) return rc;
+            c.work_cap = nf * 2;
+        }
+        HIPCHK(h, hipMemsetAsync(h->d_cnt + c.slot0, 0, LadderCtx::N_SLOTS * 4, c.ls));
+        for (int lv = LV_C1; lv <= LV_DENSE; lv++) {
+            if (by_lv[lv].empty()) continue;
+            c.plans.emplace_back();
+            Plan &P = c.plans.back();
+            int rc = make_plan(h, by_lv[lv], lv, P, c.arena + c.arena_cur, c.arena_bytes - c.arena_cur);
+            if (rc == VPR_OK && P.chunks.size() > 1 && c.arena_cur > 0) rc = VPR_ERR_NOMEM;   // retry with the whole workspace
+            if (rc == VPR_ERR_NOMEM && c.arena_cur > 0) {
+                HIPCHK(h, hipStreamSynchronize(c.ls));
+                c.arena_cur = 0;
+                rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes);
+            }
+            if (rc) return rc;
+            if (P.chunks.size() == 1) c.arena_cur += round_up(P.arena_used, 256);
+            else c.arena_cur = c.arena_bytes;    // multi-chunk plan: the whole workspace is in use
+            // stage descriptors / work list (bump allocation: all plans of the round are in flight together)
+            const size_t n = P.work.size();
+            AlnDesc *dd = c.d_descs + c.stage_cur;
+            int32_t *dw = c.d_work + c.stage_cur;
+            c.stage_cur += n;
+            HIPCHK(h, hipMemcpyAsync(dd, P.descs.data(), n * sizeof(AlnDesc), hipMemcpyHostToDevice, c.ls));
+            HIPCHK(h, hipMemcpyAsync(dw, P.work.data(), n * 4, hipMemcpyHostToDevice, c.ls));
+            hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(n)), dim3(256), 0, c.ls, dd, int(n), h->d_descs);
+            h->dirty.insert(h->dirty.end(), P.work.begin(), P.work.end());
+            if (lv == LV_DENSE) {
+                if ((rc = run_dense(P, dw, c.ls, true))) return rc;
+            } else {
+                for (const Chunk &ch : P.chunks) {
+                    if (c.slot_cur + 2 > LadderCtx::N_SLOTS) {   // out of fail slots: drain what is in flight
+                        std::vector<Plan> keep;
+                        keep.swap(c.plans);
+                        const int64_t ac = c.arena_cur;
+                        const size_t sc_ = c.stage_cur;
+                        if ((rc = lad_flush(c, carry))) return rc;
+                        c.plans.swap(keep);
+                        c.arena_cur = ac; c.stage_cur = sc_;
+                        HIPCHK(h, hipMemsetAsync(h->d_cnt + c.slot0, 0, LadderCtx::N_SLOTS * 4, c.ls));
+                    }
+                    const int32_t n_long = ch.n_long;
+                    if (n_long > 0) {
+                        const int slot = c.slot0 + c.slot_cur++;
+                        if ((rc = enqueue_part(P, dw, ch.work_off, n_long, lv, c.ls, slot, c.fail_base + c.fail_cur, true,
+                                               ch.part_cells[0], ch.part_in[0]))) return rc;
+                        c.pending.emplace_back(slot, c.fail_base + c.fail_cur);
+                        c.fail_cur += n_long;
+                    }
+                    if (ch.count > n_long) {
+                        const int slot = c.slot0 + c.slot_cur++;
+                        if ((rc = enqueue_part(P, dw, ch.work_off + n_long, ch.count - n_long, lv, c.ls, slot,
+                                               c.fail_base + c.fail_cur, false, ch.part_cells[1], ch.part_in[1]))) return rc;
+                        c.pending.emplace_back(slot, c.fail_base + c.fail_cur);
+                        c.fail_cur += ch.count - n_long;
                     }
                 }
-                h->resident.emplace_back(std::move(P.work), P.arena);
             }
-            fails.swap(next);
+            h->resident.emplace_back(P.work, P.arena);
         }
         return VPR_OK;
     };
@@ -978,41 +1028,65 @@ int vpr_execute(vpr_handle *h) {
     } else {
         // Per chunk of the round-0 plan: the short alignments (a throughput problem) and the long ones (latency
         // chains: rows are sequential) run on two streams; the ids rejected by the exit test are known right
-        // after each forward sweep, and their retry rounds run on a third stream beside the rest of the round.
+        // after each forward sweep, and their retry ladders run beside the rest of the round.
         const Plan &P0 = h->plan0;
-        hipStream_t s_long = h->cls_stream[0], s_short = h->cls_stream[1], s_retry = h->cls_stream[2];
+        const int64_t na_ = int64_t(h->descs.size());
+        hipStream_t s_long = h->cls_stream[0], s_short = h->cls_stream[1];
+        LadderCtx &LL = h->lad[0], &LS = h->lad[1];
+        // HIP maps streams onto 4 hardware queues: round 0 uses two, the ladders get the other two (the
+        // short ladder rides on the main stream, which has nothing else to do until the join)
+        LL.ls = h->cls_stream[2]; LS.ls = st;
+        LL.slot0 = 2; LS.slot0 = 2 + LadderCtx::N_SLOTS;
         for (size_t ci = 0; ci < P0.chunks.size(); ci++) {
             const Chunk &ch = P0.chunks[ci];
             const int32_t n_long = ch.n_long;
-            HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 16, st));
+            LL.fail_base = na_; LS.fail_base = na_ + n_long;
+            HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
             HIPCHK(h, hipEventRecord(h->ev_fork, st));
             HIPCHK(h, hipStreamWaitEvent(s_long, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(s_short, h->ev_fork, 0));
-            HIPCHK(h, hipStreamWaitEvent(s_retry, h->ev_fork, 0));
+            HIPCHK(h, hipStreamWaitEvent(LL.ls, h->ev_fork, 0));
+            HIPCHK(h, hipStreamWaitEvent(LS.ls, h->ev_fork, 0));
             if (ch.count > n_long) {
-                const int lv = P0.lv;
-                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, ch.count - n_long, lv, s_short, 1, n_long, false,
+                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, ch.count - n_long, P0.lv, s_short, 1, n_long, false,
                                        ch.part_cells[1], ch.part_in[1]))) return rc;
             }
             if (n_long > 0) {
                 const int lv = P0.lv == LV_Q16 ? int(LV_C1) : P0.lv;
-                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0], ch.part_in[0]))) return rc;
+                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0], ch.part_in[0])))
+                    return rc;
             }
-            std::vector<int32_t> fails;
+            std::vector<int32_t> fails, carry[2];
             if (n_long > 0) {
-                if ((rc = read_fails(0, 0, s_retry, fails))) return rc;
-                if ((rc = ladder(fails, s_retry))) return rc;
+                if ((rc = read_fails(0, 0, LL.ls, fails))) return rc;
+                if ((rc = lad_start(LL, fails, carry[0]))) return rc;
             }
             if (ch.count > n_long) {
                 fails.clear();
-                if ((rc = read_fails(1, n_long, s_retry, fails))) return rc;
-                if ((rc = ladder(fails, s_retry))) return rc;
+                if ((rc = read_fails(1, n_long, LS.ls, fails))) return rc;
+                if ((rc = lad_start(LS, fails, carry[1]))) return rc;
+            }
+            while (!LL.pending.empty() || !LS.pending.empty()) {
+                int pick = -1;
+                while (pick < 0) {
+                    for (int k = 1; k >= 0 && pick < 0; k--)       // a ladder whose round has finished goes first
+                        if (!h->lad[k].pending.empty() && hipStreamQuery(h->lad[k].ls) == hipSuccess) pick = k;
+                    if (pick < 0 && LL.pending.empty()) pick = 1;
+                    if (pick < 0 && LS.pending.empty()) pick = 0;
+                    if (pick < 0) std::this_thread::yield();
+                }
+                LadderCtx &c = h->lad[pick];
+                fails.clear();
+                fails.swap(carry[pick]);
+                if ((rc = lad_flush(c, fails))) return rc;
+                if ((rc = lad_start(c, fails, carry[pick]))) return rc;
             }
             // join: the next chunk reuses the arena
             HIPCHK(h, hipEventRecord(h->ev_join[0], s_long));
             HIPCHK(h, hipEventRecord(h->ev_join[1], s_short));
-            HIPCHK(h, hipEventRecord(h->ev_join[2], s_retry));
-            for (int k = 0; k < 3; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
+            HIPCHK(h, hipEventRecord(h->ev_join[2], LL.ls));
+            HIPCHK(h, hipEventRecord(h->ev_join[3], LS.ls));
+            for (int k = 0; k < 4; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
             if (ci + 1 < P0.chunks.size()) HIPCHK(h, hipStreamSynchronize(st));
             if (ci + 1 == P0.chunks.size())
                 h->resident.emplace(h->resident.begin(), std::vector<int32_t>(P0.work.begin() + ch.work_off,

@@ -652,6 +652,41 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
     int64_t prev_query_var_ptr = query_var_ptr, prev_truth_var_ptr = truth_var_ptr;
     int64_t sync_idx = n;   // index into the (P+1)-long sync/edit arrays; entry n is the virtual final one
 
+    // Path entries are consumed in descending order, one per step.  WAVE: the wavefront keeps 64 entries in
+    // registers (lane l <-> entry cbase + l, next-lower chunk prefetched) and broadcasts one per step, so the
+    // sequential walk of a long alignment pays no HBM round trip per step.  Lane mode: one entry ahead.
+    const int lane_ = threadIdx.x & 63;
+    int64_t cbase = 0;
+    PathEnt ccur = PathEnt{0, 0, 0, 0}, cpre = PathEnt{0, 0, 0, 0};
+    if (WAVE) {
+        cbase = (n > 0) ? ((n - 1) & ~int64_t(63)) : 0;
+        if (cbase + lane_ < n) ccur = path[cbase + lane_];
+        if (cbase >= 64) cpre = path[cbase - 64 + lane_];
+    } else if (n > 0) {
+        cpre = path[n - 1];
+    }
+    auto fetch = [&](int64_t i) -> PathEnt {
+        if (WAVE) {
+            if (i < cbase) {   // uniform
+                cbase -= 64;
+                ccur = cpre;
+                if (cbase >= 64) cpre = path[cbase - 64 + lane_];
+            }
+            const int l = int(i - cbase);
+            PathEnt e;
+            e.a = uint32_t(__builtin_amdgcn_readlane(int(ccur.a), l));
+            e.b = uint32_t(__builtin_amdgcn_readlane(int(ccur.b), l));
+            e.qref = __builtin_amdgcn_readlane(ccur.qref, l);
+            e.tref = __builtin_amdgcn_readlane(ccur.tref, l);
+            return e;
+        } else {
+            const PathEnt e = cpre;
+            if (i > 0) cpre = path[i - 1];
+            return e;
+        }
+    };
+    uint32_t cur_b = 0;     // .b of path[sync_idx]
+
     while (sync_idx >= 0) {
         const int query_ref_pos = prev_qref;
         while (query_ref_pos < query_var_pos && query_var_ptr >= d.qv_beg) {
@@ -667,8 +702,8 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
             truth_var_ptr--;
             truth_var_pos = (truth_var_ptr < d.tv_beg) ? -1 : tv_pos[truth_var_ptr];
         }
-        const bool is_sync = (sync_idx == n) ? true : bool(path[sync_idx].b >> 31);
-        const int is_edit = (sync_idx == n) ? 0 : int((path[sync_idx].b >> 30) & 1);
+        const bool is_sync = (sync_idx == n) ? true : bool(cur_b >> 31);
+        const int is_edit = (sync_idx == n) ? 0 : int((cur_b >> 30) & 1);
         if (is_sync) {
             const int sync_ref_idx = prev_qref + 1;
             const int sync_truth_idx = prev_ti + 1;
@@ -724,14 +759,14 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
         sync_idx--;
         if (sync_idx < 0) break;
         cur_hi = prev_hi;
-        const PathEnt e = path[sync_idx];
+        const PathEnt e = fetch(sync_idx);
+        cur_b = e.b;
         prev_qri = int(e.a & 0x7fffffffu);
         prev_hi = int(e.a >> 31);
         prev_ti = int(e.b & 0x3fffffffu);
         prev_qref = e.qref;
         prev_tref = e.tref;
-        query_var_pos = (query_var_ptr < d.qv_beg) ? -1 : qv_pos[query_var_ptr];
-        truth_var_pos = (truth_var_ptr < d.tv_beg) ? -1 : tv_pos[truth_var_ptr];
+        // (dist.cpp re-reads the two variant positions here; they only change in the loops above)
     }
     (void)prev_qri; (void)prev_ti;
     if (lead) {
@@ -782,6 +817,39 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
     uint32_t status = 0;
     int tile_t0 = -(1 << 30);   // first truth row held by the LDS tile (WAVE only)
 
+    // WAVE: the packed walk constants (k_prep_wk) of 64 truth rows and of 64 columns of each plane are kept in
+    // registers (lane l <-> element base + l) and broadcast per step, so a step of the sequential walk reads no
+    // HBM: rows advance monotonically (next chunk prefetched), a column chunk is re-centred on a miss.
+    const int2 *wq_ = B.wk_q[d.qs] + d.q_off, *wr_ = B.wk_r[d.qs] + d.r_off, *wt_ = B.wk_t[d.ts - 2] + d.t_off;
+    const int insmask = ((1 << d.qs) | (1 << d.ts)) << 8;
+    int rbase = 0, cbase_[2] = {-(1 << 30), -(1 << 30)};
+    int2 rcur = make_int2(0, 0), rnxt = make_int2(0, 0), ccol[2] = {make_int2(0, 0), make_int2(0, 0)};
+    if (WAVE) {
+        if (lane < t_size) rcur = wt_[lane];
+        if (64 + lane < t_size) rnxt = wt_[64 + lane];
+    }
+    auto row_get = [&](int t) -> int2 {
+        if (t >= rbase + 64) {   // uniform
+            rbase += 64;
+            rcur = rnxt;
+            rnxt = make_int2(0, 0);
+            if (rbase + 64 + lane < t_size) rnxt = wt_[rbase + 64 + lane];
+        }
+        return make_int2(__builtin_amdgcn_readlane(rcur.x, t - rbase), __builtin_amdgcn_readlane(rcur.y, t - rbase));
+    };
+    auto col_get = [&](int pl, int x) -> int2 {
+        if (x < cbase_[pl] || x >= cbase_[pl] + 64) {   // uniform
+            cbase_[pl] = max(0, x - 8);
+            const int xx = cbase_[pl] + lane;
+            ccol[pl] = make_int2(0, 0);
+            if (pl == 0) { if (xx < q_size) ccol[0] = wq_[xx]; }
+            else { if (xx < r_size) ccol[1] = wr_[xx]; }
+        }
+        const int l = x - cbase_[pl];
+        return pl == 0 ? make_int2(__builtin_amdgcn_readlane(ccol[0].x, l), __builtin_amdgcn_readlane(ccol[0].y, l))
+                       : make_int2(__builtin_amdgcn_readlane(ccol[1].x, l), __builtin_amdgcn_readlane(ccol[1].y, l));
+    };
+
     // ---- forward walk, dist.cpp:865-998
     int hi = O.beg_plane, qri = 0, ti = 0;
     int64_t n = 0;
@@ -821,12 +889,12 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
             p = mat[hi][size_t(ti) * d.pitch[hi] + col] & 31;
         }
         int mv; uint32_t edit = 0;
-        if (hi == ri && (p & F_SWP)) { mv = F_SWP; hi = qi; qri = r2q[qri]; qri++; ti++; }
+        if (hi == ri && (p & F_SWP)) { mv = F_SWP; hi = qi; qri = WAVE ? col_get(ri, qri).x : r2q[qri]; qri++; ti++; }
         else if (p & F_MAT) { mv = F_MAT; qri++; ti++; }
         else if (p & F_SUB) { mv = F_SUB; qri++; ti++; edit = 1; }
         else if (p & F_INS) { mv = F_INS; qri++; edit = 1; }
         else if (p & F_DEL) { mv = F_DEL; ti++; edit = 1; }
-        else if (hi == qi && (p & F_SWP)) { mv = F_SWP; hi = ri; qri = q2r[qri]; qri++; ti++; }
+        else if (hi == qi && (p & F_SWP)) { mv = F_SWP; hi = ri; qri = WAVE ? col_get(qi, qri).x : q2r[qri]; qri++; ti++; }
         else { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
         // dist.cpp:941 breaks out here with edits one entry longer than sync; a valid optimal path never
         // leaves the matrix, so report it like the reference's other walk failure
@@ -834,13 +902,23 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
             status |= VPR_ST_ERR_NO_PTR; ok = false; break;
         }
         const int consumes = mv & (F_MAT | F_SWP | F_SUB | F_DEL);
-        bool in_t = tfl[ti] & PV;
-        if (consumes) in_t = in_t && !(tfl[ti] & PB);
-        bool in_q = (hi == ri) ? false : bool(qfl[qri] & PV);
-        if (hi == qi && consumes) in_q = in_q && !(qfl[qri] & PB);
-        const int tr = t2r[ti];
-        const int qr = (hi == ri) ? qri : q2r[qri];
-        const bool ins_loc = (insQ[tr] | insT[tr] | insQ[qr] | insT[qr]) != 0;
+        int tflv, qflv, tr, qr;
+        bool ins_loc;
+        if (WAVE) {
+            const int2 rw = row_get(ti), cw = col_get(hi, qri);
+            tflv = rw.y & 0xff; tr = rw.x;
+            qflv = cw.y & 0xff; qr = (hi == ri) ? qri : cw.x;
+            ins_loc = ((rw.y | cw.y) & insmask) != 0;
+        } else {
+            tflv = tfl[ti]; tr = t2r[ti];
+            qflv = (hi == ri) ? 0 : int(qfl[qri]);
+            qr = (hi == ri) ? qri : q2r[qri];
+            ins_loc = (insQ[tr] | insT[tr] | insQ[qr] | insT[qr]) != 0;
+        }
+        bool in_t = tflv & PV;
+        if (consumes) in_t = in_t && !(tflv & PB);
+        bool in_q = (hi == ri) ? false : bool(qflv & PV);
+        if (hi == qi && consumes) in_q = in_q && !(qflv & PB);
         const bool sync = !in_t && !in_q && !ins_loc && tr == qr && (mv & (F_MAT | F_SWP | F_SUB));
         if (n >= d.path_cap) { status |= VPR_ST_ERR_LIMIT; ok = false; break; }
         if (lead) path[n] = PathEnt{uint32_t(qri) | (uint32_t(hi) << 31),
