@@ -167,9 +167,8 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
     int cbQ, cbR, nbQ, nbR;                 // origins of stripes c0 + gl (this 16-stripe chunk / the next)
     origin(gl, cbQ, cbR);
     origin(16 + gl, nbQ, nbR);
-    int2 tkc = make_int2(0, 0), tkn = make_int2(0, 0);   // truth constants of rows (t & ~15) + gl / the next 16
-    if (gl < Lt) tkc = tk[gl];
-    if (16 + gl < Lt) tkn = tk[16 + gl];
+    // truth constants of rows (t & ~15) + gl / the next 16 (clamped loads; rows past the end are masked)
+    int2 tkc = tk[max(min(gl, Lt - 1), 0)], tkn = tk[max(min(16 + gl, Lt - 1), 0)];
 
     int exit_min = D_INF;
     int Dp[2] = {gl, gl};                   // row 0: D = x along the INS chain (origin 0)
@@ -179,8 +178,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
     int4 kc[2], kn[2];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
-        kc[p] = make_int4(-1, int(0xffffffffu), gl, 0);
-        if (live && gl <= hi[p]) kc[p] = fk[p][gl];
+        kc[p] = fk[p][min(gl, Lp[p] - 1)];
     }
 
     for (int s = 0; s < smax; s++) {
@@ -192,16 +190,12 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
         if (!has_next) { nlo[0] = lo[0]; nlo[1] = lo[1]; }
         nhi[0] = min(Lq - 1, nlo[0] + Q_W - 1);
         nhi[1] = min(Lr - 1, nlo[1] + Q_W - 1);
+        // (unconditional, clamped loads: lanes outside the window / rows past the end are masked where used)
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
-            kn[p] = make_int4(-1, int(0xffffffffu), 0, 0);
-            if (has_next && nlo[p] + gl <= nhi[p]) kn[p] = fk[p][nlo[p] + gl];
-        }
+        for (int p = 0; p < 2; p++) kn[p] = fk[p][min(nlo[p] + gl, Lp[p] - 1)];
         if ((s & 3) == 0 && s > 0) {
             tkc = tkn;
-            tkn = make_int2(0, 0);
-            const int tt = s * Q_K + 16 + gl;
-            if (tt < Lt) tkn = tk[tt];
+            tkn = tk[max(min(s * Q_K + 16 + gl, Lt - 1), 0)];
         }
         // ---- per-lane constants of this stripe
         int s0[2];
@@ -211,16 +205,19 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
         for (int p = 0; p < 2; p++) {
             const int o = 1 - p;
             const int x = lo[p] + gl;
-            const bool valid = act && x <= hi[p];
+            const bool valid = act & (x <= hi[p]);
             s0[p] = (kc[p].x < 0) ? -1 : (kc[p].x & (FK_MULTI - 1));
-            multi[p] = kc[p].x >= 0 && (kc[p].x & FK_MULTI);
+            multi[p] = (kc[p].x >= 0) & ((kc[p].x & FK_MULTI) != 0);
             base[p] = valid ? (uint32_t(kc[p].y) >> 24) : 0xffu;
-            const int z = kc[p].y & 0xffffff;
-            const bool zok = valid && z != FK_NONE24 && z < Lp[o];
-            const bool ins_out = valid && x == hi[p] && hi[p] < Lp[p] - 1;
-            ex_in[p] = ins_out || (zok && (z < lo[o] || z > hi[o]));
-            ex_last[p] = ins_out || (has_next && valid && (x < nlo[p] || (x + 1 <= Lp[p] - 1 && x + 1 > nhi[p]))) ||
-                         (has_next && zok && (z < nlo[o] || z > nhi[o]));
+            // branch-free edge tests (bitwise on purpose: && / || make hipcc emit exec-mask branches)
+            const int z = kc[p].y & 0xffffff;                       // FK_NONE24 >= any string length
+            const bool zok = valid & (z < Lp[o]);
+            const bool ins_out = valid & (x == hi[p]) & (hi[p] < Lp[p] - 1);
+            const bool z_out = unsigned(z - lo[o]) > unsigned(hi[o] - lo[o]);
+            const bool z_out_n = unsigned(z - nlo[o]) > unsigned(nhi[o] - nlo[o]);
+            const bool x_out_n = (x < nlo[p]) | ((x + 1 < Lp[p]) & (x + 1 > nhi[p]));
+            ex_in[p] = ins_out | (zok & z_out);
+            ex_last[p] = ins_out | (has_next & ((valid & x_out_n) | (zok & z_out_n)));
         }
         uint32_t facc[2] = {0, 0};
         const int trow = (gbase | ((s & 3) * Q_K)) << 2;     // bpermute address of this stripe's first row constants
