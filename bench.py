@@ -141,9 +141,9 @@ def main():
         tm = pr.timing()
         kern_ms.append(tm.ms_total)
         for s in pr.launch_stats():
-            key = (s.kind, s.threads, s.cells_per_thread)
-            a = stats_acc.setdefault(key, [0, 0.0, 0, 0])
-            a[0] += 1; a[1] += s.ms; a[2] += s.bytes_algorithmic; a[3] += s.cells
+            key = (s.kind, s.kernel.decode())
+            a = stats_acc.setdefault(key, [0, 0.0, 0, 0, 0])
+            a[0] += 1; a[1] += s.ms; a[2] += s.bytes_algorithmic; a[3] += s.cells; a[4] += s.cells_dense
     sync()
     elapsed = time.perf_counter() - t0
     if rank == 0:       # the device tally must equal the one recomputed from the downloaded results
@@ -157,19 +157,39 @@ def main():
     value = total_aln / elapsed
     if rank == 0:
         tm = pr.timing()
-        names = {1: "k_fwd", 2: "k_bwd", 3: "k_walk", 4: "k_ed", 5: "k_finalize"}
-        dom = max(stats_acc.items(), key=lambda kv: kv[1][1])
-        (kind, nt, c), (nl, ms, byt, cells) = dom
-        # dominant kernel: algorithmic bytes per launch / average launch duration (HIP events on the library stream)
-        achieved = (byt / nl) / (ms / nl * 1e-3) / 1e9 if ms > 0 else 0.0
+        # dominant K1/K2 kernel (the DP sweeps the byte model of SURVEY 8(d) is about): algorithmic bytes per launch
+        # / average launch duration (HIP events on the stream the kernel is launched on)
+        sweeps = {k: v for k, v in stats_acc.items() if k[0] in (1, 2)}
+        (kind, kname), (nl, ms, byt, cells, dense) = max(sweeps.items(), key=lambda kv: kv[1][1])
+        # algorithmic bytes = 2 B per *dense* DP cell (1 B stored by the forward sweep, 1 B loaded by
+        # the backward sweep) + the input arrays; `achieved` follows that formula for the launch's alignments.
+        # The window kernels sweep (and move) far fewer cells than the dense matrix: `achieved_swept` counts only
+        # the flag bytes of the swept cells, and `traffic` is what the PMC counters saw.
+        in_b = (byt - cells) if kind == 1 else 0
+        dense_bytes = (dense + in_b) / nl
+        achieved = dense_bytes / (ms / nl * 1e-3) / 1e9 if ms > 0 else 0.0
+        swept = (byt / nl) / (ms / nl * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this very command (profiles/)
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            if prof["workload"] == args.workload and prof["superclusters_per_gpu"] == args.n_sc and kname in prof["kernels"]:
+                k = prof["kernels"][kname]
+                # FETCH_SIZE counts half of wide coalesced reads on gfx950 (MI355X_MICROARCH.md): x2; KB -> bytes
+                traffic = int((2 * k["fetch_kb"] + k["write_kb"]) * 1024)
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {
-            "bound": "hbm", "kernel": f"{names[kind]}<{nt},{c}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "launches": nl, "avg_launch_ms": round(ms / nl, 4), "algorithmic_bytes_per_launch": int(byt / nl),
-            "dense_cells_per_launch": int(cells / nl),
+            "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "launches": nl, "avg_launch_ms": round(ms / nl, 4), "algorithmic_bytes_per_launch": int(dense_bytes),
+            "dense_cells_per_launch": int(dense / nl), "swept_cells_per_launch": int(cells / nl),
+            "swept_bytes_per_launch": int(byt / nl), "achieved_swept": round(swept, 2),
+            "frac_swept": round(swept / HBM_PEAK_GBS, 5),
+            "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)" if traffic else None,
+            "note": "dense-equivalent bytes per SURVEY 8(d); the window kernels move only swept_bytes and are "
+                    "VALU-issue bound, not HBM bound (DESIGN.md section 3)",
         }
-        per_kernel = {f"{names[k[0]]}<{k[1]},{k[2]}>": {"launches": v[0], "ms": round(v[1], 3)}
-                      for k, v in sorted(stats_acc.items())}
+        per_kernel = {k[1]: {"launches": v[0], "ms": round(v[1], 3)} for k, v in sorted(stats_acc.items())}
         out = {
             "metric": "supercluster-alignments/sec", "value": round(value, 1), "unit": "supercluster-alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

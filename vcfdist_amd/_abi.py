@@ -85,6 +85,7 @@ class VprLaunchStat(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("threads", C.c_int32), ("cells_per_thread", C.c_int32), ("n_units", C.c_int32),
         ("cells", C.c_int64), ("bytes_algorithmic", C.c_int64), ("ms", C.c_double),
+        ("cells_dense", C.c_int64), ("kernel", C.c_char * 32),
     ]
 
 

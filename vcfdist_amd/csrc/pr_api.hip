@@ -49,7 +49,7 @@ struct Chunk {
     int64_t cells = 0, in_bytes = 0;           // touched cells / input bytes of the chunk
     // windowed plans: the leading n_long long alignments get their own launch sequence (part 0)
     int32_t n_long = 0;
-    int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0};
+    int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0};
 };
 // a set of alignments with workspace offsets assigned, all at window level `lv` (a LV_Q16 plan holds its
 // long alignments, which start at LV_C1, in front)
@@ -370,6 +370,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
                 const int W = d.band_w;
                 ch.part_cells[part] += int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt;
                 ch.part_in[part] += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
+                ch.part_dense[part] += int64_t(d.Lq + d.Lr) * d.Lt;
             }
         }
         if (lv == LV_DENSE) {
@@ -728,8 +729,9 @@ int vpr_execute(vpr_handle *h) {
     }
 
     // HIP events bracket each launch on the stream the kernel is launched on
-    auto timed = [&](int kind, const vpr_launch_stat &ls, hipStream_t ks, auto &&launch) -> int {
+    auto timed = [&](int kind, const vpr_launch_stat &ls, hipStream_t ks, const char *name, auto &&launch) -> int {
         EvPair ev; ev.kind = kind; ev.st = ls; ev.st.kind = kind;
+        snprintf(ev.st.kernel, sizeof(ev.st.kernel), "%s", name);
         HIPCHK(h, hipEventCreate(&ev.a));
         HIPCHK(h, hipEventCreate(&ev.b));
         HIPCHK(h, hipEventRecord(ev.a, ks));
@@ -751,7 +753,7 @@ int vpr_execute(vpr_handle *h) {
         ws_.threads = 64; ws_.n_units = count; ws_.cells_per_thread = wave ? 1 : 0;
         int32_t *a_i32 = reinterpret_cast<int32_t *>(P.arena);
         PathEnt *a_path = reinterpret_cast<PathEnt *>(P.arena);
-        return timed(3, ws_, ks, [&] {
+        return timed(3, ws_, ks, wave ? "k_walk<wave>" : "k_walk<lane>", [&] {
             if (wave)
                 hipLaunchKernelGGL(k_walk<true>, dim3(count), dim3(64), 0, ks, h->dB, h->d_descs, d_list, count,
                                    P.arena, a_i32, h->d_outs, a_path, h->d_secs, h->d_fp_table,
@@ -785,8 +787,9 @@ int vpr_execute(vpr_handle *h) {
                     in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
                 }
                 cells_touched += ls.cells;
+                ls.cells_dense = ls.cells;
                 ls.bytes_algorithmic = ls.cells + in_bytes;
-                int rc = timed(1, ls, ks, [&] {
+                int rc = timed(1, ls, ks, (std::string("k_fwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + ">").c_str(), [&] {
                     hipLaunchKernelGGL(fwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_f, ks, h->dB, h->d_descs,
                                        d_work + L.work_off, P.arena, h->d_outs);
                     hipLaunchKernelGGL(k_fwd_finish, dim3((L.count + 255) / 256), dim3(256), 0, ks,
@@ -795,7 +798,7 @@ int vpr_execute(vpr_handle *h) {
                 if (rc) return rc;
                 n_fwd++;
                 ls.bytes_algorithmic = ls.cells;
-                rc = timed(2, ls, ks, [&] {
+                rc = timed(2, ls, ks, (std::string("k_bwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + ">").c_str(), [&] {
                     hipLaunchKernelGGL(bwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
                                        d_work + L.work_off, P.arena, h->d_outs);
                 });
@@ -815,7 +818,8 @@ int vpr_execute(vpr_handle *h) {
     // ev_slot[slot] marks the list complete) -> K2 -> K3.  K2/K3 skip rejected alignments, so the host can
     // start their retry round while this sequence is still running.
     auto enqueue_part = [&](const Plan &P, const int32_t *d_work, int64_t off, int32_t cnt, int lv, hipStream_t ks,
-                            int slot, int64_t fail_off, bool long_part, int64_t part_cells, int64_t part_in) -> int {
+                            int slot, int64_t fail_off, bool long_part, int64_t part_cells, int64_t part_in,
+                            int64_t part_dense) -> int {
         const int W = LV_WINDOW[lv], C = W / 64;
         const int32_t *list = d_work + off;
         int32_t *a_i32 = reinterpret_cast<int32_t *>(P.arena);
@@ -824,9 +828,10 @@ int vpr_execute(vpr_handle *h) {
         memset(&ls, 0, sizeof(ls));
         ls.threads = lv == LV_Q16 ? 16 : 64; ls.cells_per_thread = lv == LV_Q16 ? 1 : C; ls.n_units = cnt;
         ls.cells = part_cells;
+        ls.cells_dense = part_dense;
         ls.bytes_algorithmic = ls.cells + part_in;
         cells_touched += ls.cells;
-        int rc = timed(1, ls, ks, [&] {
+        int rc = timed(1, ls, ks, lv == LV_Q16 ? "k_fwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") ? "k_fwd_stripe" : (lv == LV_C4 ? "k_fwd_band<4>" : (lv == LV_C1 ? "k_fwd_band<1>" : "k_fwd_band<16>"))), [&] {
             if (lv == LV_Q16)
                 hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs);
@@ -841,7 +846,7 @@ int vpr_execute(vpr_handle *h) {
                            h->d_fail + fail_off, h->d_cnt + slot);
         HIPCHK(h, hipEventRecord(h->ev_slot[slot], ks));
         ls.bytes_algorithmic = ls.cells;
-        rc = timed(2, ls, ks, [&] {
+        rc = timed(2, ls, ks, lv == LV_Q16 ? "k_bwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") ? "k_bwd_stripe" : (lv == LV_C4 ? "k_bwd_band<4>" : (lv == LV_C1 ? "k_bwd_band<1>" : "k_bwd_band<16>"))), [&] {
             if (lv == LV_Q16)
                 hipLaunchKernelGGL(k_bwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs);
@@ -859,13 +864,13 @@ int vpr_execute(vpr_handle *h) {
         ws_.threads = lv == LV_Q16 ? 16 : 64; ws_.n_units = cnt; ws_.cells_per_thread = 2;
         if (lv == LV_Q16 && !getenv("VPR_NO_Q16WALK")) {
             // 16-cell layout: row-sweep walk, four alignments per wave (phase A) + credit walk (phase B)
-            rc = timed(3, ws_, ks, [&] {
+            rc = timed(3, ws_, ks, "k_walk_q16", [&] {
                 hipLaunchKernelGGL(k_walk_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, a_path);
             });
             if (rc) return rc;
             ws_.cells_per_thread = 3;
-            rc = timed(3, ws_, ks, [&] {
+            rc = timed(3, ws_, ks, "k_credit<lane>", [&] {
                 hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
                                    list, cnt, h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs,
                                    h->d_njobs, h->jobs_cap, W);
@@ -873,13 +878,13 @@ int vpr_execute(vpr_handle *h) {
         } else if (row_walk) {
             // striped 64-cell layout, long alignments: row-sweep walk (phase A) + credit walk (phase B); for the
             // short ones the per-wave setup outweighs the pointer chase of the lane-per-alignment walk
-            rc = timed(3, ws_, ks, [&] {
+            rc = timed(3, ws_, ks, "k_walk_rows", [&] {
                 hipLaunchKernelGGL(k_walk_rows, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, a_path);
             });
             if (rc) return rc;
             ws_.cells_per_thread = 3;
-            rc = timed(3, ws_, ks, [&] {
+            rc = timed(3, ws_, ks, wave_walk ? "k_credit<wave>" : "k_credit<lane>", [&] {
                 if (wave_walk)
                     hipLaunchKernelGGL(k_credit<true>, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                        h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs, h->d_njobs,
@@ -997,14 +1002,14 @@ int vpr_execute(vpr_handle *h) {
                     if (n_long > 0) {
                         const int slot = c.slot0 + c.slot_cur++;
                         if ((rc = enqueue_part(P, dw, ch.work_off, n_long, lv, c.ls, slot, c.fail_base + c.fail_cur, true,
-                                               ch.part_cells[0], ch.part_in[0]))) return rc;
+                                               ch.part_cells[0], ch.part_in[0], ch.part_dense[0]))) return rc;
                         c.pending.emplace_back(slot, c.fail_base + c.fail_cur);
                         c.fail_cur += n_long;
                     }
                     if (ch.count > n_long) {
                         const int slot = c.slot0 + c.slot_cur++;
                         if ((rc = enqueue_part(P, dw, ch.work_off + n_long, ch.count - n_long, lv, c.ls, slot,
-                                               c.fail_base + c.fail_cur, false, ch.part_cells[1], ch.part_in[1]))) return rc;
+                                               c.fail_base + c.fail_cur, false, ch.part_cells[1], ch.part_in[1], ch.part_dense[1]))) return rc;
                         c.pending.emplace_back(slot, c.fail_base + c.fail_cur);
                         c.fail_cur += ch.count - n_long;
                     }
@@ -1049,11 +1054,11 @@ int vpr_execute(vpr_handle *h) {
             HIPCHK(h, hipStreamWaitEvent(LS.ls, h->ev_fork, 0));
             if (ch.count > n_long) {
                 if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, ch.count - n_long, P0.lv, s_short, 1, n_long, false,
-                                       ch.part_cells[1], ch.part_in[1]))) return rc;
+                                       ch.part_cells[1], ch.part_in[1], ch.part_dense[1]))) return rc;
             }
             if (n_long > 0) {
                 const int lv = P0.lv == LV_Q16 ? int(LV_C1) : P0.lv;
-                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0], ch.part_in[0])))
+                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0], ch.part_in[0], ch.part_dense[0])))
                     return rc;
             }
             std::vector<int32_t> fails, carry[2];
@@ -1118,7 +1123,7 @@ int vpr_execute(vpr_handle *h) {
             vpr_launch_stat es_;
             memset(&es_, 0, sizeof(es_));
             es_.threads = 64; es_.n_units = cnt;
-            rc = timed(4, es_, st, [&] {
+            rc = timed(4, es_, st, "k_ed", [&] {
                 hipLaunchKernelGGL(k_ed, dim3(cnt), dim3(64), 0, st, h->dB, h->d_descs, h->d_jobs + j0, cnt,
                                    h->d_secs, h->d_ed_scratch, stride);
             });
@@ -1131,7 +1136,7 @@ int vpr_execute(vpr_handle *h) {
         vpr_launch_stat fs_;
         memset(&fs_, 0, sizeof(fs_));
         fs_.threads = 128; fs_.n_units = na;
-        rc = timed(5, fs_, st, [&] {
+        rc = timed(5, fs_, st, "k_finalize+k_phase_tally", [&] {
             if (na) hipLaunchKernelGGL(k_finalize, dim3((na + 127) / 128), dim3(128), 0, st, h->d_descs, na, h->d_outs,
                                        h->d_secs, h->d_fp_table, h->dR);
             if (h->n_sc) hipLaunchKernelGGL(k_phase_tally, dim3((h->n_sc + 127) / 128), dim3(128), 0, st, h->d_descs,

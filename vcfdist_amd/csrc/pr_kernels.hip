@@ -662,9 +662,11 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
         cbase = (n > 0) ? ((n - 1) & ~int64_t(63)) : 0;
         if (cbase + lane_ < n) ccur = path[cbase + lane_];
         if (cbase >= 64) cpre = path[cbase - 64 + lane_];
-    } else if (n > 0) {
-        cpre = path[n - 1];
     }
+    // lane mode: four entries (one 64-byte line of the lane's own stream) per refill, so a line is fetched once
+    // instead of once per entry (thousands of waves in flight thrash L2: PMC showed 5x the path bytes)
+    PathEnt q0 = ccur, q1 = ccur, q2 = ccur, q3 = ccur;
+    int64_t qbase = int64_t(1) << 60;
     auto fetch = [&](int64_t i) -> PathEnt {
         if (WAVE) {
             if (i < cbase) {   // uniform
@@ -680,8 +682,20 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
             e.tref = __builtin_amdgcn_readlane(ccur.tref, l);
             return e;
         } else {
-            const PathEnt e = cpre;
-            if (i > 0) cpre = path[i - 1];
+            if (i < qbase) {
+                qbase = i & ~int64_t(3);
+                const uint4 *src = reinterpret_cast<const uint4 *>(path + qbase);
+                const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                q0 = PathEnt{v0.x, v0.y, int(v0.z), int(v0.w)};
+                q1 = PathEnt{v1.x, v1.y, int(v1.z), int(v1.w)};
+                q2 = PathEnt{v2.x, v2.y, int(v2.z), int(v2.w)};
+                q3 = PathEnt{v3.x, v3.y, int(v3.z), int(v3.w)};
+            }
+            const int k = int(i - qbase);
+            PathEnt e = q0;
+            if (k == 1) e = q1;
+            if (k == 2) e = q2;
+            if (k == 3) e = q3;
             return e;
         }
     };
