@@ -215,3 +215,25 @@ def test_gpu_matches_committed_regression_fixture():
                 if dt == np.float32:
                     x, y = x.view(np.uint32), y.view(np.uint32)
                 assert np.array_equal(x[keep], y[keep]), (name, h, w)
+
+
+def test_recluster_supercluster_end_to_end():
+    """rows (f1) -> (a): variants -> gap clustering -> superclustering (include/vcfdist_cluster.h) -> Level B ->
+    host marshalling -> HIP path, against the oracle on the same re-derived superclusters.  The synthetic spans
+    abut, so a 40-base gap chains many of them and the 400-base limit forces supercluster splits."""
+    from vcfdist_amd import cluster as K
+    v = api.Synth(n_sc=500, len_mode=1, len_a=30.0, len_b=0.8, len_min=8, len_max=400, seed=11).variants()
+    assert len(v.ctg_off) == 2
+    haps = [K.Hap(v.var_pos[i], v.var_ref_len[i], v.var_type[i], v.var_ref_len[i], v.var_alt_len[i]) for i in range(4)]
+    cl = [K.simple_cluster(h, 0, 40, 0) for h in haps]
+    s = K.supercluster(haps, cl, 400)
+    o = K.supercluster(haps, cl, 400, L=O.lib(), prefix="vco")
+    assert s == o and s.n > 20 and s.n_oversize > 0
+    v2 = A.Variants(v.ctg_off, v.ctg_seq, np.zeros(s.n, np.int32), s.beg, s.end, [s.var_off(i) for i in range(4)],
+                    v.var_pos, v.var_type, v.var_qual, v.var_ref_off, v.var_ref_len, v.var_alt_off, v.var_alt_len,
+                    v.allele_pool)
+    batch = api.batch_from_variants(v2)
+    assert batch.n_sc == s.n
+    got, want, ntie, pr = compare(batch)
+    print(f"{s.n} superclusters from 500 spans ({s.n_oversize} oversize), max span {int((s.end - s.beg).max())}, "
+          f"{ntie} order-defined ties skipped")
