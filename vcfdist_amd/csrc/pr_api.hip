@@ -26,6 +26,7 @@
 #include "pr_kernels.hip"
 #include "pr_band.hip"
 #include "pr_q16.hip"
+#include "pr_wide.hip"
 
 namespace {
 
@@ -228,16 +229,16 @@ BandFwd band_fwd_kernel(int lv) {
     switch (lv) {
         case LV_C1:   // 64-cell window: striped, register-resident variant (VPR_NO_STRIPE=1 selects the ring variant)
             return getenv("VPR_NO_STRIPE") ? BandFwd(k_fwd_band<1, true>) : BandFwd(k_fwd_stripe);
-        case LV_C4: return k_fwd_band<4, true>;
-        default: return k_fwd_band<16, true>;
+        case LV_C4: return getenv("VPR_NO_WIDE") ? BandFwd(k_fwd_band<4, true>) : BandFwd(k_fwd_wide<4>);
+        default: return getenv("VPR_NO_WIDE") ? BandFwd(k_fwd_band<16, true>) : BandFwd(k_fwd_wide<16>);
     }
 }
 BandBwd band_bwd_kernel(int lv) {
     switch (lv) {
         case LV_C1:   // needs the stripe origins written by k_fwd_stripe
             return (getenv("VPR_NO_STRIPE") || getenv("VPR_NO_STRIPE_BWD")) ? BandBwd(k_bwd_band<1>) : BandBwd(k_bwd_stripe);
-        case LV_C4: return k_bwd_band<4>;
-        default: return k_bwd_band<16>;
+        case LV_C4: return getenv("VPR_NO_WIDE") ? BandBwd(k_bwd_band<4>) : BandBwd(k_bwd_wide<4>);
+        default: return getenv("VPR_NO_WIDE") ? BandBwd(k_bwd_band<16>) : BandBwd(k_bwd_wide<16>);
     }
 }
 
@@ -831,13 +832,13 @@ int vpr_execute(vpr_handle *h) {
         ls.cells_dense = part_dense;
         ls.bytes_algorithmic = ls.cells + part_in;
         cells_touched += ls.cells;
-        int rc = timed(1, ls, ks, lv == LV_Q16 ? "k_fwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") ? "k_fwd_stripe" : (lv == LV_C4 ? "k_fwd_band<4>" : (lv == LV_C1 ? "k_fwd_band<1>" : "k_fwd_band<16>"))), [&] {
+        int rc = timed(1, ls, ks, lv == LV_Q16 ? "k_fwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") ? "k_fwd_stripe" : (lv == LV_C1 ? "k_fwd_band<1>" : (getenv("VPR_NO_WIDE") ? (lv == LV_C4 ? "k_fwd_band<4>" : "k_fwd_band<16>") : (lv == LV_C4 ? "k_fwd_wide<4>" : "k_fwd_wide<16>")))), [&] {
             if (lv == LV_Q16)
                 hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs);
             else
-                hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
-                                   P.arena, a_i32, h->d_outs);
+                hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3((lv >= LV_C4 && !getenv("VPR_NO_WIDE")) ? W : 64), 0,
+                                   ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs);
             hipLaunchKernelGGL(k_fwd_band_finish, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs, W);
         });
         if (rc) return rc;
@@ -846,13 +847,13 @@ int vpr_execute(vpr_handle *h) {
                            h->d_fail + fail_off, h->d_cnt + slot);
         HIPCHK(h, hipEventRecord(h->ev_slot[slot], ks));
         ls.bytes_algorithmic = ls.cells;
-        rc = timed(2, ls, ks, lv == LV_Q16 ? "k_bwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") ? "k_bwd_stripe" : (lv == LV_C4 ? "k_bwd_band<4>" : (lv == LV_C1 ? "k_bwd_band<1>" : "k_bwd_band<16>"))), [&] {
+        rc = timed(2, ls, ks, lv == LV_Q16 ? "k_bwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") ? "k_bwd_stripe" : (lv == LV_C1 ? "k_bwd_band<1>" : (getenv("VPR_NO_WIDE") ? (lv == LV_C4 ? "k_bwd_band<4>" : "k_bwd_band<16>") : (lv == LV_C4 ? "k_bwd_wide<4>" : "k_bwd_wide<16>")))), [&] {
             if (lv == LV_Q16)
                 hipLaunchKernelGGL(k_bwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs);
             else
-                hipLaunchKernelGGL(band_bwd_kernel(lv), dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list,
-                                   P.arena, a_i32, h->d_outs);
+                hipLaunchKernelGGL(band_bwd_kernel(lv), dim3(cnt), dim3((lv >= LV_C4 && !getenv("VPR_NO_WIDE")) ? W : 64), 0,
+                                   ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs);
         });
         if (rc) return rc;
         // long part (or a small launch of long retries): wave-per-alignment walk; windows up to 256
