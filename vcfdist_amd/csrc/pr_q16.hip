@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
         uint32_t facc[2] = {0, 0};
         const int trow = (gbase | ((s & 3) * Q_K)) << 2;     // bpermute address of this stripe's first row constants
 
-#pragma unroll
+#pragma unroll 1
         for (int r = 0; r < Q_K; r++) {
             const int t = s * Q_K + r;
             const bool ract = t < Lt;
