@@ -43,7 +43,7 @@ def compare(batch, cfg=None, expect_exact=False):
     return got, want, int(tied_sc.sum()), pr
 
 
-@pytest.mark.parametrize("band_mode", [1, 2, 0])
+@pytest.mark.parametrize("band_mode", [1, 3, 2, 0])
 @pytest.mark.parametrize("name,kw", [
     ("tiny_repeats", dict(n_sc=400, len_a=6, len_b=60, len_min=5, len_max=60, seed=1, var_per_base=0.08, p_snp=0.5, p_repeat=0.5)),
     ("c64x4", dict(n_sc=200, len_a=65, len_b=250, len_min=65, len_max=250, seed=2, var_per_base=0.03)),

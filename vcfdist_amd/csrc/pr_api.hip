@@ -39,8 +39,10 @@ const int N_CLASSES = sizeof(CLASSES) / sizeof(CLASSES[0]);
 const size_t LDS_MAX = 160 * 1024;
 // window levels an alignment climbs until its exit test passes: 16 cells (four alignments per wave, only
 // for alignments shorter than LONG_LT rows), 64, 256, 1024 cells (one wave per alignment), dense
-enum { LV_Q16 = 0, LV_C1 = 1, LV_C4 = 2, LV_C16 = 3, LV_DENSE = 4 };
-const int LV_WINDOW[] = {16, 64, 256, 1024, 0};
+// LV_Z: 16 cells, zero-distance variant (accepts only alignments with s = 0); LV_Q16: 16 cells, general.
+enum { LV_Z = 0, LV_Q16 = 1, LV_C1 = 2, LV_C4 = 3, LV_C16 = 4, LV_DENSE = 5 };
+const int LV_WINDOW[] = {16, 16, 64, 256, 1024, 0};   // window width = flag layout of the level
+const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnDesc::band_pad that marks the level
 const int LONG_LT = 512;                  // truth rows from which an alignment is a latency chain
 
 struct Launch { int cls; int64_t work_off; int32_t count; };   // dense: one k_fwd/k_bwd launch of a class
@@ -52,7 +54,7 @@ struct Chunk {
     int32_t n_long = 0;
     int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0};
 };
-// a set of alignments with workspace offsets assigned, all at window level `lv` (a LV_Q16 plan holds its
+// a set of alignments with workspace offsets assigned, all at window level `lv` (a 16-cell plan holds its
 // long alignments, which start at LV_C1, in front)
 struct Plan {
     int lv = LV_DENSE;
@@ -247,18 +249,25 @@ int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 // Append the alignments whose window was rejected to the round's fail list (wave-aggregated: one atomic
 // per wave; 800 k contended single-word atomics would cost more than the forward sweep itself).
 __global__ void k_collect_fails(const int32_t *__restrict__ work, int n, const AlnOut *__restrict__ outs,
-                                int32_t *__restrict__ fail_list, int32_t *__restrict__ cnt) {
+                                int32_t *__restrict__ fail_list, int32_t *__restrict__ cnt, int pad4,
+                                const int32_t *__restrict__ n_dev) {
+    if (n_dev) n = min(n, *n_dev);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
-    const int a = live ? work[i] : 0;
-    const bool bad = live && !outs[a].band_ok;
+    const int a = live ? work[i] : -1;
+    const bool bad = live && a >= 0 && !outs[a].band_ok;
     const unsigned long long mbad = __ballot(bad);
     if (!mbad) return;
     const int lane = threadIdx.x & 63;
+    // pad4: the list feeds a four-alignments-per-wave kernel directly.  A wave's rejected ids are consecutive in
+    // the (row-count sorted) work list, so they are kept together and padded with -1 to a multiple of four:
+    // groups of four then never mix alignments of very different lengths.
+    const int npop = __popcll(mbad), nres = pad4 ? ((npop + 3) & ~3) : npop;
     int base = 0;
-    if (lane == 0) base = atomicAdd(cnt, __popcll(mbad));
+    if (lane == 0) base = atomicAdd(cnt, nres);
     base = __shfl(base, 0);
     if (bad) fail_list[base + __popcll(mbad & ((1ull << lane) - 1ull))] = a;
+    if (lane < nres - npop) fail_list[base + npop + lane] = -1;
 }
 
 __global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc *__restrict__ dst) {
@@ -274,7 +283,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
     P = Plan();
     P.lv = lv;
     P.arena = arena;
-    auto level_of = [&](const AlnDesc &d) { return (lv == LV_Q16 && d.Lt >= LONG_LT) ? int(LV_C1) : lv; };
+    auto level_of = [&](const AlnDesc &d) { return (lv <= LV_Q16 && d.Lt >= LONG_LT) ? int(LV_C1) : lv; };
     auto mat_bytes = [&](int32_t a) -> int64_t {
         const AlnDesc &d = h->descs[a];
         const int W = LV_WINDOW[level_of(d)];
@@ -292,7 +301,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             if (lv == LV_DENSE || h->descs[a].Lt >= LONG_LT) big.emplace_back(-mat_bytes(a), a);
         std::sort(big.begin(), big.end());
         for (auto &b : big) order.push_back(b.second);
-        if (lv == LV_Q16) {
+        if (lv <= LV_Q16) {
             std::vector<int64_t> cnt(LONG_LT + 1, 0);
             for (int32_t a : alns) if (h->descs[a].Lt < LONG_LT) cnt[LONG_LT - 1 - h->descs[a].Lt + 1]++;
             for (int k = 0; k < LONG_LT; k++) cnt[k + 1] += cnt[k];
@@ -318,7 +327,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             const int dl = level_of(d);
             const int W = LV_WINDOW[dl];
             int64_t m0, m1, bl;
-            if (dl == LV_Q16) {
+            if (dl <= LV_Q16) {
                 // stripe-transposed records of 128 B per 4 truth rows (both planes) + int2 origins per stripe
                 const int64_t nstr = (int64_t(d.Lt) + 3) / 4;
                 d.band_w = 16;
@@ -348,6 +357,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             if (need > arena_bytes)
                 return fail(h, VPR_ERR_NOMEM, "workspace (%lld bytes) too small for supercluster %d alignment %d (%lld bytes)",
                             (long long)arena_bytes, d.sc, d.aln, (long long)need);
+            d.band_pad = LV_TAG[dl];
             d.mat_off[0] = used;
             d.mat_off[1] = used + m0;
             d.blo_off = (used + m0 + m1) / 4;            // int index into the arena
@@ -364,7 +374,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
         if (lv != LV_DENSE) {
             while (ch.n_long < ch.count && P.descs[ch.work_off + ch.n_long].Lt >= LONG_LT) ch.n_long++;
             // a LV_Q16 plan's long alignments use the 64-cell layout and cannot share a launch with the rest
-            if (lv != LV_Q16 && (ch.n_long == ch.count || ch.count < 4096)) ch.n_long = 0;     // nothing to overlap with
+            if (lv > LV_Q16 && (ch.n_long == ch.count || ch.count < 4096)) ch.n_long = 0;     // nothing to overlap with
             for (int32_t w = 0; w < ch.count; w++) {
                 const AlnDesc &d = P.descs[ch.work_off + w];
                 const int part = w < ch.n_long ? 0 : 1;
@@ -424,8 +434,13 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
         delete h;
         return fail(nullptr, VPR_ERR_DEVICE, "hipSetDevice/hipStreamCreate failed");
     }
+    // Streams 0, 2, 3 carry latency chains (long alignments, retry ladders) and get the highest priority, so their
+    // few workgroups are dispatched ahead of the millions of the bulk stream (1) instead of behind them.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     for (int k = 0; k < N_CLASSES; k++) {
-        if (hipStreamCreateWithFlags(&h->cls_stream[k], hipStreamNonBlocking) != hipSuccess ||
+        const int prio = (k == 0 || k == 2 || k == 3) ? prio_hi : prio_lo;
+        if (hipStreamCreateWithPriority(&h->cls_stream[k], hipStreamNonBlocking, prio) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming) != hipSuccess) {
             return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
         }
@@ -623,7 +638,8 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     R.credit_threshold = h->cfg.credit_threshold;
     R.phase_threshold = h->cfg.phase_threshold;
     if ((rc = dev_alloc(h, &h->d_ok, na))) return rc;
-    if ((rc = dev_alloc(h, &h->d_fail, 2 * na + 64))) return rc;   // round-0 lists [0, na), retry rounds [na, 2 na)
+    // fail lists: round 0 in [0, na + na/16 + 256) (a list that feeds a kernel directly is padded), retry rounds behind
+    if ((rc = dev_alloc(h, &h->d_fail, 2 * na + na / 16 + 512))) return rc;
     if ((rc = dev_alloc(h, &h->d_cnt, 2 + 2 * LadderCtx::N_SLOTS))) return rc;
 
     lap("result/aux allocations");
@@ -663,7 +679,9 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     std::vector<int32_t> all(na);
     for (size_t k = 0; k < na; k++) all[k] = int32_t(k);
     h->level.assign(na, uint8_t(LV_DENSE));
-    const int lv0 = h->cfg.band_mode == 0 ? LV_DENSE : ((h->cfg.band_mode == 2 || getenv("VPR_NO_Q16")) ? LV_C1 : LV_Q16);
+    const int lv0 = h->cfg.band_mode == 0 ? LV_DENSE
+                    : (h->cfg.band_mode == 2 || getenv("VPR_NO_Q16")) ? LV_C1
+                    : (h->cfg.band_mode == 3 || getenv("VPR_NO_Z")) ? LV_Q16 : LV_Z;
     if ((rc = make_plan(h, all, lv0, h->plan0, h->d_arena, h->arena_bytes))) return rc;
     h->level0 = h->level;
     if ((rc = dev_alloc(h, &h->plan0.d_descs, na))) return rc;
@@ -758,11 +776,11 @@ int vpr_execute(vpr_handle *h) {
             if (wave)
                 hipLaunchKernelGGL(k_walk<true>, dim3(count), dim3(64), 0, ks, h->dB, h->d_descs, d_list, count,
                                    P.arena, a_i32, h->d_outs, a_path, h->d_secs, h->d_fp_table,
-                                   h->d_jobs, h->d_njobs, h->jobs_cap, my_w);
+                                   h->d_jobs, h->d_njobs, h->jobs_cap, my_w, my_w);
             else
                 hipLaunchKernelGGL(k_walk<false>, dim3((count + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, d_list,
                                    count, P.arena, a_i32, h->d_outs, a_path, h->d_secs, h->d_fp_table,
-                                   h->d_jobs, h->d_njobs, h->jobs_cap, my_w);
+                                   h->d_jobs, h->d_njobs, h->jobs_cap, my_w, my_w);
         });
     };
 
@@ -820,61 +838,82 @@ int vpr_execute(vpr_handle *h) {
     // start their retry round while this sequence is still running.
     auto enqueue_part = [&](const Plan &P, const int32_t *d_work, int64_t off, int32_t cnt, int lv, hipStream_t ks,
                             int slot, int64_t fail_off, bool long_part, int64_t part_cells, int64_t part_in,
-                            int64_t part_dense) -> int {
-        const int W = LV_WINDOW[lv], C = W / 64;
+                            int64_t part_dense, int dtag_override = -1, int phases = 7,
+                            const int32_t *n_dev = nullptr, int32_t n_all = 0) -> int {
+        // phases: 1 = forward sweep + accept test + fail list, 2 = backward sweep, 4 = walk + credit.
+        // n_dev: device-side length of a device-built work list; cnt is then the cap of entries processed and
+        // n_all the most entries the list can hold (the fail list scans all of them).
+        const int W = LV_WINDOW[lv], C = W / 64, tag = LV_TAG[lv];
+        const bool q16 = lv <= LV_Q16, zero = lv == LV_Z;
+        const int dtag = dtag_override >= 0 ? dtag_override : tag;   // tag carried by the descriptors of the list
         const int32_t *list = d_work + off;
         int32_t *a_i32 = reinterpret_cast<int32_t *>(P.arena);
         PathEnt *a_path = reinterpret_cast<PathEnt *>(P.arena);
         vpr_launch_stat ls;
         memset(&ls, 0, sizeof(ls));
-        ls.threads = lv == LV_Q16 ? 16 : 64; ls.cells_per_thread = lv == LV_Q16 ? 1 : C; ls.n_units = cnt;
+        ls.threads = q16 ? 16 : 64; ls.cells_per_thread = q16 ? 1 : C; ls.n_units = cnt;
         ls.cells = part_cells;
         ls.cells_dense = part_dense;
         ls.bytes_algorithmic = ls.cells + part_in;
+        int rc = VPR_OK;
+        if (phases & 1) {
         cells_touched += ls.cells;
-        int rc = timed(1, ls, ks, lv == LV_Q16 ? "k_fwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") ? "k_fwd_stripe" : (lv == LV_C1 ? "k_fwd_band<1>" : (getenv("VPR_NO_WIDE") ? (lv == LV_C4 ? "k_fwd_band<4>" : "k_fwd_band<16>") : (lv == LV_C4 ? "k_fwd_wide<4>" : "k_fwd_wide<16>")))), [&] {
-            if (lv == LV_Q16)
-                hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                   P.arena, a_i32, h->d_outs);
+        rc = timed(1, ls, ks, zero ? "k_fwd_q16<zero>" : q16 ? "k_fwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") ? "k_fwd_stripe" : (lv == LV_C1 ? "k_fwd_band<1>" : (getenv("VPR_NO_WIDE") ? (lv == LV_C4 ? "k_fwd_band<4>" : "k_fwd_band<16>") : (lv == LV_C4 ? "k_fwd_wide<4>" : "k_fwd_wide<16>")))), [&] {
+            if (zero)
+                hipLaunchKernelGGL(k_fwd_q16<true>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                   P.arena, a_i32, h->d_outs, n_dev);
+            else if (q16)
+                hipLaunchKernelGGL(k_fwd_q16<false>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                   P.arena, a_i32, h->d_outs, n_dev);
             else
                 hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3((lv >= LV_C4 && !getenv("VPR_NO_WIDE")) ? W : 64), 0,
                                    ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs);
-            hipLaunchKernelGGL(k_fwd_band_finish, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs, W);
+            hipLaunchKernelGGL(k_fwd_band_finish, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs, tag, n_dev);
         });
         if (rc) return rc;
         n_fwd++;
-        hipLaunchKernelGGL(k_collect_fails, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs,
-                           h->d_fail + fail_off, h->d_cnt + slot);
+        {
+            const int32_t nc = n_dev ? n_all : cnt;
+            hipLaunchKernelGGL(k_collect_fails, dim3((nc + 255) / 256), dim3(256), 0, ks, list, nc, h->d_outs,
+                               h->d_fail + fail_off, h->d_cnt + slot, zero ? 1 : 0, n_dev);
+        }
         HIPCHK(h, hipEventRecord(h->ev_slot[slot], ks));
+        }
+        if (phases & 2) {
         ls.bytes_algorithmic = ls.cells;
-        rc = timed(2, ls, ks, lv == LV_Q16 ? "k_bwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") ? "k_bwd_stripe" : (lv == LV_C1 ? "k_bwd_band<1>" : (getenv("VPR_NO_WIDE") ? (lv == LV_C4 ? "k_bwd_band<4>" : "k_bwd_band<16>") : (lv == LV_C4 ? "k_bwd_wide<4>" : "k_bwd_wide<16>")))), [&] {
-            if (lv == LV_Q16)
-                hipLaunchKernelGGL(k_bwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                   P.arena, a_i32, h->d_outs);
+        rc = timed(2, ls, ks, zero ? "k_bwd_q16<zero>" : q16 ? "k_bwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") ? "k_bwd_stripe" : (lv == LV_C1 ? "k_bwd_band<1>" : (getenv("VPR_NO_WIDE") ? (lv == LV_C4 ? "k_bwd_band<4>" : "k_bwd_band<16>") : (lv == LV_C4 ? "k_bwd_wide<4>" : "k_bwd_wide<16>")))), [&] {
+            if (zero)
+                hipLaunchKernelGGL(k_bwd_q16<true>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                   P.arena, a_i32, h->d_outs, tag, dtag, n_dev);
+            else if (q16)
+                hipLaunchKernelGGL(k_bwd_q16<false>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                   P.arena, a_i32, h->d_outs, tag, dtag, n_dev);
             else
                 hipLaunchKernelGGL(band_bwd_kernel(lv), dim3(cnt), dim3((lv >= LV_C4 && !getenv("VPR_NO_WIDE")) ? W : 64), 0,
                                    ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs);
         });
         if (rc) return rc;
+        }
+        if (!(phases & 4)) return rc;
         // long part (or a small launch of long retries): wave-per-alignment walk; windows up to 256
-        const bool wave_walk = lv != LV_Q16 && C <= 4 && (long_part || cnt < 2048);
+        const bool wave_walk = !q16 && C <= 4 && (long_part || cnt < 2048);
         const bool row_walk = lv == LV_C1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") &&
                               !getenv("VPR_NO_ROWWALK") && (wave_walk || getenv("VPR_ROWWALK_ALL"));
         vpr_launch_stat ws_;
         memset(&ws_, 0, sizeof(ws_));
-        ws_.threads = lv == LV_Q16 ? 16 : 64; ws_.n_units = cnt; ws_.cells_per_thread = 2;
-        if (lv == LV_Q16 && !getenv("VPR_NO_Q16WALK")) {
+        ws_.threads = q16 ? 16 : 64; ws_.n_units = cnt; ws_.cells_per_thread = 2;
+        if (q16 && !getenv("VPR_NO_Q16WALK")) {
             // 16-cell layout: row-sweep walk, four alignments per wave (phase A) + credit walk (phase B)
             rc = timed(3, ws_, ks, "k_walk_q16", [&] {
                 hipLaunchKernelGGL(k_walk_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                   P.arena, a_i32, h->d_outs, a_path);
+                                   P.arena, a_i32, h->d_outs, a_path, tag, dtag, n_dev);
             });
             if (rc) return rc;
             ws_.cells_per_thread = 3;
             rc = timed(3, ws_, ks, "k_credit<lane>", [&] {
                 hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
                                    list, cnt, h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs,
-                                   h->d_njobs, h->jobs_cap, W);
+                                   h->d_njobs, h->jobs_cap, dtag, tag, n_dev);
             });
         } else if (row_walk) {
             // striped 64-cell layout, long alignments: row-sweep walk (phase A) + credit walk (phase B); for the
@@ -889,14 +928,14 @@ int vpr_execute(vpr_handle *h) {
                 if (wave_walk)
                     hipLaunchKernelGGL(k_credit<true>, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                        h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs, h->d_njobs,
-                                       h->jobs_cap, W);
+                                       h->jobs_cap, dtag, tag, n_dev);
                 else
                     hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
                                        list, cnt, h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs,
-                                       h->d_njobs, h->jobs_cap, W);
+                                       h->d_njobs, h->jobs_cap, dtag, tag, n_dev);
             });
         } else {
-            rc = walk_launch(P, list, cnt, ks, wave_walk, W);
+            rc = walk_launch(P, list, cnt, ks, wave_walk, tag);
         }
         return rc;
     };
@@ -948,8 +987,8 @@ int vpr_execute(vpr_handle *h) {
         std::vector<int32_t> by_lv[LV_DENSE + 1];
         for (int32_t a : fails) by_lv[std::min<int>(h->level[size_t(a)] + 1, LV_DENSE)].push_back(a);
         if (getenv("VPR_DEBUG"))
-            fprintf(stderr, "[vpr] retry round (ladder %d): %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n",
-                    int(&c - h->lad), by_lv[1].size(), by_lv[2].size(), by_lv[3].size(), by_lv[4].size());
+            fprintf(stderr, "[vpr] retry round (ladder %d): %zu -> 16, %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n",
+                    int(&c - h->lad), by_lv[1].size(), by_lv[2].size(), by_lv[3].size(), by_lv[4].size(), by_lv[5].size());
         const size_t nf = fails.size();
         if (c.descs_cap < nf) {
             int rc = dev_alloc(h, &c.d_descs, nf * 2);
@@ -962,7 +1001,7 @@ int vpr_execute(vpr_handle *h) {
             c.work_cap = nf * 2;
         }
         HIPCHK(h, hipMemsetAsync(h->d_cnt + c.slot0, 0, LadderCtx::N_SLOTS * 4, c.ls));
-        for (int lv = LV_C1; lv <= LV_DENSE; lv++) {
+        for (int lv = LV_Q16; lv <= LV_DENSE; lv++) {
             if (by_lv[lv].empty()) continue;
             c.plans.emplace_back();
             Plan &P = c.plans.back();
@@ -1041,24 +1080,47 @@ int vpr_execute(vpr_handle *h) {
         LadderCtx &LL = h->lad[0], &LS = h->lad[1];
         // HIP maps streams onto 4 hardware queues: round 0 uses two, the ladders get the other two (the
         // short ladder rides on the main stream, which has nothing else to do until the join)
-        LL.ls = h->cls_stream[2]; LS.ls = st;
+        LL.ls = h->cls_stream[2]; LS.ls = getenv("VPR_LS_MAIN") ? st : h->cls_stream[3];
         LL.slot0 = 2; LS.slot0 = 2 + LadderCtx::N_SLOTS;
         for (size_t ci = 0; ci < P0.chunks.size(); ci++) {
             const Chunk &ch = P0.chunks[ci];
             const int32_t n_long = ch.n_long;
-            LL.fail_base = na_; LS.fail_base = na_ + n_long;
+            const int64_t rbase = na_ + na_ / 16 + 256;                    // start of the retry rounds' fail region
+            LL.fail_base = rbase; LS.fail_base = rbase + n_long;
             HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
             HIPCHK(h, hipEventRecord(h->ev_fork, st));
             HIPCHK(h, hipStreamWaitEvent(s_long, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(s_short, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(LL.ls, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(LS.ls, h->ev_fork, 0));
-            if (ch.count > n_long) {
-                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, ch.count - n_long, P0.lv, s_short, 1, n_long, false,
+            // Round 0 of the short part.  At LV_Z, what the zero-distance sweep rejects (every alignment with s > 0)
+            // re-runs *in place* with the general 16-cell kernels on the same stream, phase by phase behind the
+            // zero-distance kernels: same layout and workspace slots, the device-built fail list is the work list and
+            // its length stays on the device, so the host plans and copies nothing.  (A separate stream would not
+            // help: the bulk kernels' millions of workgroups starve a concurrent launch until they drain.)
+            const int32_t n_short = ch.count - n_long;
+            const int SLOT_IP = LS.slot0 + LadderCtx::N_SLOTS - 1;          // fail slot of the in-place round
+            const int64_t foff_ip = rbase + na_ - n_short;                 // tail of the retry rounds' fail region
+            const int32_t cap_ip = std::min<int32_t>(n_short, std::max<int32_t>(4096, (n_short / 4 + 3) & ~3));
+            const bool inplace = P0.lv == LV_Z && n_short > 0;
+            if (n_short > 0 && !inplace) {
+                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, n_short, P0.lv, s_short, 1, n_long, false,
                                        ch.part_cells[1], ch.part_in[1], ch.part_dense[1]))) return rc;
             }
+            if (inplace) {
+                const int32_t *n_dev = h->d_cnt + 1;
+                const int ztag = LV_TAG[LV_Z];
+                HIPCHK(h, hipMemsetAsync(h->d_cnt + SLOT_IP, 0, 4, s_short));
+                for (int ph = 1; ph <= 4; ph <<= 1) {
+                    if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, n_short, LV_Z, s_short, 1, n_long, false,
+                                           ch.part_cells[1], ch.part_in[1], ch.part_dense[1], -1, ph))) return rc;
+                    // entries past cap_ip (more than a quarter of the part rejected) stay rejected and go to the ladder
+                    if ((rc = enqueue_part(P0, h->d_fail, n_long, cap_ip, LV_Q16, s_short, SLOT_IP, foff_ip, false, 0, 0, 0,
+                                           ztag, ph, n_dev, n_short + n_short / 16 + 64))) return rc;
+                }
+            }
             if (n_long > 0) {
-                const int lv = P0.lv == LV_Q16 ? int(LV_C1) : P0.lv;
+                const int lv = P0.lv <= LV_Q16 ? int(LV_C1) : P0.lv;
                 if ((rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0], ch.part_in[0], ch.part_dense[0])))
                     return rc;
             }
@@ -1069,7 +1131,16 @@ int vpr_execute(vpr_handle *h) {
             }
             if (ch.count > n_long) {
                 fails.clear();
-                if ((rc = read_fails(1, n_long, LS.ls, fails))) return rc;
+                if (inplace) {
+                    if ((rc = read_fails(SLOT_IP, foff_ip, LS.ls, fails))) return rc;
+                    for (int32_t a : fails) h->level[size_t(a)] = uint8_t(LV_Q16);
+                    int32_t nz = 0;
+                    HIPCHK(h, hipMemcpyAsync(&nz, h->d_cnt + 1, 4, hipMemcpyDeviceToHost, LS.ls));
+                    HIPCHK(h, hipStreamSynchronize(LS.ls));
+                    n_retry += nz;   // rejected by the zero-distance sweep (the count includes the list's -1 padding)
+                } else {
+                    if ((rc = read_fails(1, n_long, LS.ls, fails))) return rc;
+                }
                 if ((rc = lad_start(LS, fails, carry[1]))) return rc;
             }
             while (!LL.pending.empty() || !LS.pending.empty()) {

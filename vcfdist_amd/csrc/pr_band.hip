@@ -439,9 +439,11 @@ __global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__re
 // width W the alignment was accepted at (0: rejected): the later kernels of a round process an alignment only
 // if band_ok and its descriptor both carry their own W, so a retry round that re-plans a rejected alignment
 // (new descriptor, wider window) may run concurrently with the rest of the round that rejected it.
-__global__ void k_fwd_band_finish(const int32_t *__restrict__ work, int n, AlnOut *__restrict__ outs, int W) {
+__global__ void k_fwd_band_finish(const int32_t *__restrict__ work, int n, AlnOut *__restrict__ outs, int W /* level tag */,
+                                  const int32_t *__restrict__ n_dev) {
+    if (n_dev) n = min(n, *n_dev);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || work[i] < 0) return;   // (-1: padding of a device-built work list)
     AlnOut &o = outs[work[i]];
     o.s = min(o.dist_q, o.dist_r);
     o.end_plane = (o.dist_q <= o.dist_r) ? VPR_PLANE_QUERY : VPR_PLANE_REF;
@@ -514,7 +516,7 @@ __global__ void __launch_bounds__(64) k_bwd_band(DevBatch B, const AlnDesc *__re
     const int32_t *bk[2] = {B.bk_q[d.qs] + d.q_off, B.bk_r[d.qs] + d.r_off};
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     const int32_t *blo = blo_all + d.blo_off;
-    if (outs[a].band_ok != 64 * C || d.band_w != 64 * C) return;   // rejected by the exit test: re-run wider
+    if (outs[a].band_ok != 64 * C || d.band_pad != 64 * C) return;   // rejected by the exit test: re-run wider
     const int end_plane = outs[a].end_plane;
     const int off0 = (63 - lane) * C;
 
@@ -973,7 +975,7 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
                                                    const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
-    if (outs[a].band_ok != FS_W || d.band_w != FS_W) return;   // rejected by the exit test: re-run wider
+    if (outs[a].band_ok != FS_W || d.band_pad != FS_W) return;   // rejected by the exit test: re-run wider
     const int lane = threadIdx.x;
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int Lp[2] = {Lq, Lr};
@@ -1173,7 +1175,7 @@ __global__ void __launch_bounds__(64) k_walk_rows(DevBatch B, const AlnDesc *__r
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     AlnOut &O = outs[a];
-    if (O.band_ok != FS_W || d.band_w != FS_W) return;
+    if (O.band_ok != FS_W || d.band_pad != FS_W) return;
     const int lane = threadIdx.x;
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int Lp[2] = {Lq, Lr};

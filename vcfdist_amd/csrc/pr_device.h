@@ -83,7 +83,8 @@ struct AlnDesc {
     int32_t sec_cap;
     int32_t path_cap;
     int32_t band_w;                // 0: dense [Lt][pitch] matrices; >0: banded, row t holds cells [blo[t], blo[t]+band_w)
-    int32_t band_pad;
+    int32_t band_pad;              // level tag of the round this descriptor belongs to (= band_w, except 8 for the
+                                   // zero-distance 16-cell level); kernels of other rounds skip the alignment
     int64_t blo_off;               // int offset of this alignment's band origins: blo[plane*Lt + t]
     int64_t qv_beg, qv_end, tv_beg, tv_end;   // variant index ranges (batch-global, per hap slot)
 };

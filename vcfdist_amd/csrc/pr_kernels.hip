@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
                        AlnOut *__restrict__ outs,
                        PathEnt *__restrict__ paths, Section *__restrict__ secs,
                        int32_t *const *__restrict__ fp_group /* [2 query haps * 2 swaps] */,
-                       EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap, int my_w) {
+                       EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap, int my_w, int ok_tag) {
     __shared__ __align__(16) uint8_t tile[WAVE ? 2 * WALK_TR * WALK_TW : 16];
     __shared__ int32_t tblo[WAVE ? 2 * WALK_TR : 2];
     const int wi = WAVE ? int(blockIdx.x) : int(blockIdx.x * blockDim.x + threadIdx.x);
@@ -813,8 +813,9 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
     const int a = work[wi];
     const AlnDesc d = descs[a];
     AlnOut &O = outs[a];
-    // my_w: window width of the round this launch belongs to (0: dense); see k_fwd_band_finish
-    if (d.band_w != my_w || (my_w > 0 && O.band_ok != my_w)) return;
+    // my_w: level tag of the descriptors this launch may touch (0: dense), ok_tag: the tag its round's accept
+    // test stores in band_ok (they differ only when a round re-runs alignments in place); see k_fwd_band_finish
+    if (d.band_pad != my_w || (my_w > 0 && O.band_ok != ok_tag)) return;
     const int qi = 0, ri = 1;   // planes
     const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
     const uint8_t *qfl = B.hap_flag[d.qs] + d.q_off;
@@ -952,13 +953,16 @@ __global__ void __launch_bounds__(64) k_credit(DevBatch B, const AlnDesc *__rest
                        const int32_t *__restrict__ work, int n_work, AlnOut *__restrict__ outs,
                        const PathEnt *__restrict__ paths, Section *__restrict__ secs,
                        int32_t *const *__restrict__ fp_group,
-                       EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap, int my_w) {
+                       EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap, int my_w, int ok_tag,
+                       const int32_t *__restrict__ n_dev) {
+    if (n_dev) n_work = min(n_work, *n_dev);
     const int wi = WAVE ? int(blockIdx.x) : int(blockIdx.x * blockDim.x + threadIdx.x);
     if (wi >= n_work) return;
     const int a = work[wi];
+    if (a < 0) return;   // padding of a device-built work list
     const AlnDesc d = descs[a];
     AlnOut &O = outs[a];
-    if (d.band_w != my_w || (my_w > 0 && O.band_ok != my_w)) return;
+    if (d.band_pad != my_w || (my_w > 0 && O.band_ok != ok_tag)) return;
     if (O.status & (VPR_ST_ERR_NO_PTR | VPR_ST_ERR_LIMIT)) return;   // phase A failed: n_sec is already 0
     const bool lead = !WAVE || (threadIdx.x & 63) == 0;
     credit_walk<WAVE>(B, d, O, a, paths + d.path_off, int64_t(O.path_len), 0u, secs, fp_group, jobs, n_jobs, jobs_cap, lead);

@@ -130,14 +130,25 @@ __device__ __forceinline__ int wave_max4(int v) {   // max of the four row leade
 // ===========================================================================
 // K1q: forward sweep, 16-cell window, four alignments per wave (calc_prec_recall_aln, dist.cpp:251-443)
 // ===========================================================================
+// ZERO: the zero-distance variant.  Most whole-genome alignments have s = 0 (truth and query spell the same
+// string); then the only cells with D <= s are those reachable from the two start cells over MAT and swap edges, so
+// D is tracked as {0, unreachable}: no DEL / SUB candidates, no INS scan, no lower-bound arithmetic.  It accepts an
+// alignment only if an end cell is reachable at distance 0 and no reachable cell has a zero-cost edge leaving the
+// window; everything else climbs to the general 16-cell level.  The flag bytes of the cells with D = 0 (MAT / SWP,
+// swap choice, tie bit) are exactly those of the general kernel.
+template <bool ZERO>
 __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__restrict__ descs,
                                                 const int32_t *__restrict__ work, int n_work,
                                                 uint8_t *__restrict__ ws, int32_t *__restrict__ blo_all,
-                                                AlnOut *__restrict__ outs) {
+                                                AlnOut *__restrict__ outs, const int32_t *__restrict__ n_dev) {
+    // n_dev: optional device-side length of a device-built work list (at most n_work entries of it are processed)
+    if (n_dev) n_work = min(n_work, *n_dev);
+    if (int(blockIdx.x) * 4 >= n_work) return;
     const int lane = threadIdx.x, gl = lane & 15, gbase = lane & 48;
     const int wi = int(blockIdx.x) * 4 + (lane >> 4);
-    const bool live = wi < n_work;
-    const int a = work[live ? wi : n_work - 1];
+    const int a_ = work[min(wi, n_work - 1)];
+    const bool live = wi < n_work && a_ >= 0;      // (-1: padding of a device-built work list)
+    const int a = max(a_, 0);
     const AlnDesc *dp = descs + a;
     const int Lq = dp->Lq, Lr = dp->Lr, Lt = live ? dp->Lt : 0;
     const int qs = dp->qs, ts = dp->ts;
@@ -172,6 +183,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
 
     int exit_min = D_INF;
     int Dp[2] = {gl, gl};                   // row 0: D = x along the INS chain (origin 0)
+    if (ZERO) { Dp[0] = (gl == 0) ? 0 : D_INF; Dp[1] = Dp[0]; }
     int lo[2] = {0, 0}, hi[2] = {min(Lq, Q_W) - 1, min(Lr, Q_W) - 1};
     int dlo[2] = {0, 0};                    // origins the D registers are aligned to
     int nlo[2] = {0, 0}, nhi[2] = {0, 0};
@@ -234,11 +246,16 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
                     const bool valid = gl <= hi[p];
-                    facc[p] = valid ? ((gl == 0) ? F_MAT : F_INS) : 0;
                     const bool ex = last ? ex_last[p] : ex_in[p];
-                    const int off0_ = kc[p].z - tau;
-                    const int lb0 = max((off0_ < 0 ? -off0_ : off0_) - kc[p].w - vt, 0);
-                    exit_min = (ex && ract) ? min(exit_min, gl + lb0) : exit_min;
+                    if (ZERO) {
+                        facc[p] = (valid && gl == 0) ? F_MAT : 0;
+                        exit_min = (ex && ract && gl == 0) ? 0 : exit_min;
+                    } else {
+                        facc[p] = valid ? ((gl == 0) ? F_MAT : F_INS) : 0;
+                        const int off0_ = kc[p].z - tau;
+                        const int lb0 = max((off0_ < 0 ? -off0_ : off0_) - kc[p].w - vt, 0);
+                        exit_min = (ex && ract) ? min(exit_min, gl + lb0) : exit_min;
+                    }
                 }
                 continue;
             }
@@ -254,7 +271,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
                 const int o = 1 - p;
                 if (first) {
                     const int sh = lo[p] - dlo[p];
-                    up[p] = grp_get(gbase, gl + sh, Dp[p], D_INF);
+                    up[p] = ZERO ? 0 : grp_get(gbase, gl + sh, Dp[p], D_INF);
                     dg[p] = grp_get(gbase, gl + sh - 1, Dp[p], D_INF);
                 } else {
                     up[p] = Dp[p];
@@ -288,6 +305,21 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
                     }
                     swbits[p] = (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
                 }
+            }
+            if (ZERO) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const bool dz = match[p] & (dg[p] == 0), sz = sw[p] == 0;     // reached by MAT / by a swap
+                    const uint32_t f = (dz ? F_MAT : 0) | (sz ? (F_SWP | swbits[p]) : 0);
+                    const bool valid = lo[p] + gl <= hi[p];
+                    const bool reach = (dz | sz) & valid;
+                    facc[p] |= (ract && reach) ? (f << (8 * r)) : 0;
+                    const bool ex = last ? ex_last[p] : ex_in[p];
+                    exit_min = (ex && ract && reach) ? 0 : exit_min;
+                    Dp[p] = ract ? (reach ? 0 : D_INF) : Dp[p];
+                }
+                if (first) { dlo[0] = act ? lo[0] : dlo[0]; dlo[1] = act ? lo[1] : dlo[1]; }
+                continue;
             }
 #pragma unroll
             for (int p = 0; p < 2; p++) {
@@ -354,16 +386,25 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
 // and the suffix composition of the max-plus maps is a prefix scan in lane order.  The forward flags of a
 // stripe are one dword per lane and plane, replaced in place by the path_ptr bytes.
 // ===========================================================================
+// ZERO: the flags come from the zero-distance forward sweep (MAT / SWP only), so there is no in-row INS chain and
+// the max-plus scan is skipped.  tag: the level tag the accept test stored in band_ok (see k_fwd_band_finish).
+template <bool ZERO>
 __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__restrict__ descs,
                                                 const int32_t *__restrict__ work, int n_work,
                                                 uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
-                                                AlnOut *__restrict__ outs) {
+                                                AlnOut *__restrict__ outs, int tag, int dtag,
+                                                const int32_t *__restrict__ n_dev) {
+    if (n_dev) n_work = min(n_work, *n_dev);
+    if (int(blockIdx.x) * 4 >= n_work) return;
     const int lane = threadIdx.x, gl = lane & 15, gbase = lane & 48;
     const int wi = int(blockIdx.x) * 4 + (lane >> 4);
-    const bool live = wi < n_work;
-    const int a = work[live ? wi : n_work - 1];
+    const int a_ = work[min(wi, n_work - 1)];
+    const bool live = wi < n_work && a_ >= 0;      // (-1: padding of a device-built work list)
+    const int a = max(a_, 0);
     const AlnDesc *dp = descs + a;
-    const bool on = live && outs[a].band_ok == Q_W && dp->band_w == Q_W;   // else rejected: re-run wider
+    // tag: what this round's accept test stores in band_ok; dtag: level tag of the descriptors it runs on (they
+    // differ when the general 16-cell round re-runs, in place, what the zero-distance round rejected)
+    const bool on = live && outs[a].band_ok == tag && dp->band_pad == dtag;
     const int Lq = dp->Lq, Lr = dp->Lr, Lt = on ? dp->Lt : 0;
     const int qs = dp->qs;
     const int Lp[2] = {Lq, Lr};
@@ -482,12 +523,12 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
                 bm[p] = m;
                 f0[p] = int((fw[p] >> (8 * r)) & 0xff);           // forward flags of (x, t)
                 const int f0r = int((fwr[p] >> (8 * r)) & 0xff);  // forward flags of (x+1, t)
-                lk[p] = (f0r & F_INS) ? tp_right[p] : -1;
+                lk[p] = (!ZERO && (f0r & F_INS)) ? tp_right[p] : -1;
                 g[p].A = b; g[p].B = lk[p];
             }
             MP hq = g[0], hr = g[1];
-            row_prefix_mp2(hq, hr);
-            const int inc[2] = {row_shr1(hq.A, S_NEG), row_shr1(hr.A, S_NEG)};
+            if (!ZERO) row_prefix_mp2(hq, hr);
+            const int inc[2] = {ZERO ? S_NEG : row_shr1(hq.A, S_NEG), ZERO ? S_NEG : row_shr1(hr.A, S_NEG)};
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 int v = best[p];
@@ -535,13 +576,17 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
 __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__restrict__ descs,
                                                  const int32_t *__restrict__ work, int n_work,
                                                  const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
-                                                 AlnOut *__restrict__ outs, PathEnt *__restrict__ paths) {
+                                                 AlnOut *__restrict__ outs, PathEnt *__restrict__ paths, int tag, int dtag,
+                                                 const int32_t *__restrict__ n_dev) {
+    if (n_dev) n_work = min(n_work, *n_dev);
+    if (int(blockIdx.x) * 4 >= n_work) return;
     const int lane = threadIdx.x, gl = lane & 15, gbase = lane & 48;
     const int wi = int(blockIdx.x) * 4 + (lane >> 4);
-    const bool live = wi < n_work;
-    const int a = work[live ? wi : n_work - 1];
+    const int a_ = work[min(wi, n_work - 1)];
+    const bool live = wi < n_work && a_ >= 0;      // (-1: padding of a device-built work list)
+    const int a = max(a_, 0);
     const AlnDesc *dp = descs + a;
-    const bool on = live && outs[a].band_ok == Q_W && dp->band_w == Q_W;
+    const bool on = live && outs[a].band_ok == tag && dp->band_pad == dtag;
     const int Lq = dp->Lq, Lr = dp->Lr, Lt = on ? dp->Lt : 0;
     const int qs = dp->qs, ts = dp->ts;
     const int path_cap = dp->path_cap;

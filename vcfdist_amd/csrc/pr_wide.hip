@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
     constexpr int W = NW * 64;
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
-    if (outs[a].band_ok != W || d.band_w != W) return;   // rejected by the exit test: re-run wider (uniform)
+    if (outs[a].band_ok != W || d.band_pad != W) return;   // rejected by the exit test: re-run wider (uniform)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = W - 1 - tid;                   // window column of this thread
