@@ -157,6 +157,12 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
     const int2 *tk = (ts == 2 ? B.tk[0] : B.tk[1]) + dp->t_off;
     const int32_t *r2q = (qs == 0 ? B.ref_ptr[0] : B.ref_ptr[1]) + r_off;
     const int4 *fk[2] = {(qs == 0 ? B.fk4_q[0] : B.fk4_q[1]) + q_off, (qs == 0 ? B.fk4_r[0] : B.fk4_r[1]) + r_off};
+    // the zero-distance variant needs no reference coordinates / shift budgets: the 8-byte packs are enough
+    const int2 *fk2[2] = {(qs == 0 ? B.fk_q[0] : B.fk_q[1]) + q_off, (qs == 0 ? B.fk_r[0] : B.fk_r[1]) + r_off};
+    auto load_k = [&](int p, int idx) -> int4 {
+        if (ZERO) { const int2 k = fk2[p][idx]; return make_int4(k.x, k.y, 0, 0); }
+        return fk[p][idx];
+    };
     const int4 *cand[2] = {(qs == 0 ? B.cand_q[0] : B.cand_q[1]) + q_off, (qs == 0 ? B.cand_r[0] : B.cand_r[1]) + r_off};
     uint32_t *mat = reinterpret_cast<uint32_t *>(ws + dp->mat_off[0]);
     int2 *blo2 = reinterpret_cast<int2 *>(blo_all + dp->blo_off);
@@ -190,7 +196,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
     int4 kc[2], kn[2];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
-        kc[p] = fk[p][min(gl, Lp[p] - 1)];
+        kc[p] = load_k(p, min(gl, Lp[p] - 1));
     }
 
     for (int s = 0; s < smax; s++) {
@@ -204,7 +210,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
         nhi[1] = min(Lr - 1, nlo[1] + Q_W - 1);
         // (unconditional, clamped loads: lanes outside the window / rows past the end are masked where used)
 #pragma unroll
-        for (int p = 0; p < 2; p++) kn[p] = fk[p][min(nlo[p] + gl, Lp[p] - 1)];
+        for (int p = 0; p < 2; p++) kn[p] = load_k(p, min(nlo[p] + gl, Lp[p] - 1));
         if ((s & 3) == 0 && s > 0) {
             tkc = tkn;
             tkn = tk[max(min(s * Q_K + 16 + gl, Lt - 1), 0)];
@@ -239,7 +245,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
             const int t = s * Q_K + r;
             const bool ract = t < Lt;
             const bool last = (r == Q_K - 1) || (t == Lt - 1);
-            const int tau = __builtin_amdgcn_ds_bpermute(trow + 4 * r, tkc.x);
+            const int tau = ZERO ? 0 : __builtin_amdgcn_ds_bpermute(trow + 4 * r, tkc.x);
             const int tky = __builtin_amdgcn_ds_bpermute(trow + 4 * r, tkc.y);
             const int vt = int(uint32_t(tky) >> 9);
             if (r == 0 && s == 0) {   // row 0, dist.cpp:300-305,397-405
