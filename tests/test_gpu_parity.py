@@ -237,3 +237,16 @@ def test_recluster_supercluster_end_to_end():
     got, want, ntie, pr = compare(batch)
     print(f"{s.n} superclusters from 500 spans ({s.n_oversize} oversize), max span {int((s.end - s.beg).max())}, "
           f"{ntie} order-defined ties skipped")
+
+
+def test_zero_distance_level_mostly_rejects():
+    """A discordant callset (truth keeps only 40 % of the query's sites): most alignments have s > 0, so the
+    zero-distance sweep rejects more than the in-place round's cap (a quarter of the part) and the overflow goes to
+    the retry ladder; everything still has to come out bit-exact."""
+    batch = api.Synth(n_sc=6000, len_mode=1, len_a=25.0, len_b=0.9, len_min=4, len_max=300, seed=21,
+                      p_keep=0.4, p_drop=0.3, var_per_base=0.05).batch()
+    got, want, ntie, pr = compare(batch)
+    t = pr.timing()
+    frac_zero = float((want.aln_dist == 0).mean())
+    print(f"{batch.n_sc} sc, s=0 for {frac_zero:.2f} of the alignments, {t.n_band_retries} retries, {ntie} ties skipped")
+    assert frac_zero < 0.75 and t.n_band_retries > 6000      # > 25 % rejected: the in-place cap overflows
