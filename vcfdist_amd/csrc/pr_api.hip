@@ -101,6 +101,7 @@ struct vpr_handle {
     std::vector<AlnDesc> descs;          // base descriptors (no workspace offsets)
     Plan plan0;                          // first round over all alignments, cached at upload
     std::vector<uint8_t> level, level0;  // current / round-0 window level of every alignment
+    int64_t last_need = 0;               // workspace bytes of the alignment make_plan could not place
     std::vector<int32_t> dirty;          // alignments whose device descriptor was overwritten by a retry round
     // device side
     AlnDesc *d_descs = nullptr;
@@ -354,6 +355,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64);   // 16 B per step
             const int64_t need = m0 + m1 + bl + pb + 64;
             if (k > k0 && used + need > arena_bytes) break;
+            if (need > arena_bytes) h->last_need = need;
             if (need > arena_bytes)
                 return fail(h, VPR_ERR_NOMEM, "workspace (%lld bytes) too small for supercluster %d alignment %d (%lld bytes)",
                             (long long)arena_bytes, d.sc, d.aln, (long long)need);
@@ -648,25 +650,34 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
     int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes : int64_t(double(free_b) * 0.6);
     if (budget < (8 << 20)) budget = 8 << 20;
-    // do not allocate more than round 0 can use
+    // do not allocate more than round 0 can use (its layout per alignment: make_plan)
+    int64_t want = 0;
     {
-        int64_t want = 0;
-        const bool band = h->cfg.band_mode != 0;
+        const int bm = h->cfg.band_mode;
+        const bool q16ok = (bm == 1 || bm == 3) && !getenv("VPR_NO_Q16");
         for (const AlnDesc &d : h->descs) {
-            const int64_t pq = band ? round_up(std::min(64, d.Lq), 16) : round_up(d.Lq, 32);
-            const int64_t prr = band ? round_up(std::min(64, d.Lr), 16) : round_up(d.Lr, 32);
-            want += round_up(pq * d.Lt, 64) + round_up(prr * d.Lt, 64) + (band ? round_up(8 * int64_t(d.Lt), 64) : 0) +
-                    round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64) + 64;
+            int64_t flags;
+            if (bm != 0 && q16ok && d.Lt < LONG_LT) {
+                const int64_t nstr = (int64_t(d.Lt) + 3) / 4;
+                flags = nstr * 128 + round_up(nstr * 8, 64);
+            } else if (bm != 0) {
+                flags = round_up(round_up(std::min(64, d.Lq), 16) * int64_t(d.Lt), 64) +
+                        round_up(round_up(std::min(64, d.Lr), 16) * int64_t(d.Lt), 64) + round_up(8 * int64_t(d.Lt), 64);
+            } else {
+                flags = round_up(round_up(d.Lq, 32) * int64_t(d.Lt), 64) + round_up(round_up(d.Lr, 32) * int64_t(d.Lt), 64);
+            }
+            want += flags + round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64) + 64;
         }
         if (h->cfg.workspace_bytes <= 0) budget = std::min(budget, std::max<int64_t>(want, 256 << 20));
     }
     h->arena_bytes = budget;
     if ((rc = dev_alloc(h, &h->d_arena, size_t(budget) + 256))) return rc;
-    // workspaces of the two retry ladders, which run beside round 0 (cfg.workspace_bytes bounds each workspace)
+    // workspaces of the two retry ladders, which run beside round 0 (cfg.workspace_bytes bounds each workspace;
+    // otherwise they start small and grow on demand, vpr_execute)
     if (h->cfg.band_mode != 0) {
         HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
         int64_t b2 = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes
-                                                : std::min<int64_t>(int64_t(double(free_b) * 0.25), std::max<int64_t>(budget / 2, int64_t(4) << 30));
+                                                : std::min<int64_t>(int64_t(double(free_b) * 0.25), std::max<int64_t>(want / 16, int64_t(1) << 30));
         if (b2 < (8 << 20)) b2 = 8 << 20;
         for (int k = 0; k < 2; k++) {
             h->lad[k].arena_bytes = b2;
@@ -1011,6 +1022,16 @@ int vpr_execute(vpr_handle *h) {
                 HIPCHK(h, hipStreamSynchronize(c.ls));
                 c.arena_cur = 0;
                 rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes);
+            }
+            if (rc == VPR_ERR_NOMEM && h->cfg.workspace_bytes <= 0) {
+                // one alignment does not fit the ladder's workspace (it starts small): grow it to twice that need
+                HIPCHK(h, hipStreamSynchronize(c.ls));
+                const int64_t nb = std::max<int64_t>(2 * h->last_need, 2 * c.arena_bytes);
+                uint8_t *na2 = nullptr;
+                if (dev_alloc(h, &na2, size_t(nb) + 256) == VPR_OK) {   // (the old block is released with the batch)
+                    c.arena = na2; c.arena_bytes = nb; c.arena_cur = 0;
+                    rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes);
+                }
             }
             if (rc) return rc;
             if (P.chunks.size() == 1) c.arena_cur += round_up(P.arena_used, 256);
