@@ -10,6 +10,10 @@
  *                         split_large_supercluster / split_cluster /
  *                         get_next_variant_info / get_supercluster_split_location   src/cluster.cpp:601-808
  *   vcl_supercluster_cells  the size estimate of sort_superclusters          src/cluster.cpp:42-122
+ *   vcl_wfa_cluster       wf_swg_cluster(variantData*, ctg, hap, sub, open, extend)  src/cluster.cpp:954-1263
+ *                         with wf_swg_align (src/dist.cpp:1510), wf_swg_max_reach (src/dist.cpp:2150) and
+ *                         generate_str (src/dist.cpp:81): the default "-c biwfa" clustering.
+ *                         The alignments run on the GPU (HIP, no CPU fallback); the merge passes are host code.
  *
  * Host code (the reference's is host code too, O(#variants)); one contig per call; hap slot
  * i = 2*callset + hap with QUERY = 0, TRUTH = 1, the order of include/vcfdist_pr.h.
@@ -26,6 +30,7 @@ extern "C" {
 #define VCL_OK        0
 #define VCL_ERR_ARG  -1     /* null pointer, unsorted positions, inconsistent cluster table */
 #define VCL_ERR_TYPE -2     /* a variant type other than SUB/INS/DEL ("Variant type ... unexpected", cluster.cpp:873) */
+#define VCL_ERR_DEVICE -3   /* no HIP device / HIP error (vcl_wfa_cluster has no CPU fallback) */
 
 #define VCL_SENTINEL 0x7fffffff   /* std::numeric_limits<int>::max(): reach of the sentinel cluster */
 
@@ -67,6 +72,28 @@ typedef struct vcl_superclusters {
 int vcl_supercluster(const vcl_hap haps[4], const vcl_clusters *const clusters[4], int32_t max_supercluster_size,
                      vcl_superclusters **out);
 void vcl_superclusters_free(vcl_superclusters *s);
+
+/* ---- biWFA dependency clustering ---------------------------------------------------------------------- */
+/* a hap's variants with their allele strings (ctgVariants::{refs,alts}) */
+typedef struct vcl_hap_seq {
+    vcl_hap cols;
+    const int64_t *ref_off;   /* [n_var] start of the REF allele in pool (length cols.ref_len) */
+    const int64_t *alt_off;   /* [n_var] start of the ALT allele in pool (length cols.alt_len) */
+    const uint8_t *pool;
+} vcl_hap_seq;
+
+typedef struct vcl_wfa_stats {
+    int32_t iterations;       /* merge iterations run (<= max_cluster_itrs) */
+    int64_t align_calls;      /* wf_swg_align calls (one per active cluster and iteration) */
+    int64_t reach_calls;      /* wf_swg_max_reach calls (>= 2 per active cluster: iterative doubling) */
+    double  ms_device;        /* kernel time (HIP events), 0 for the oracle */
+} vcl_wfa_stats;
+
+/* Clusters of one (callset, hap) on one contig.  sub/open/extend: g.sub, g.open, g.extend (defaults 5, 6, 2);
+   max_cluster_itrs: g.max_cluster_itrs (4); reach_min_gap: g.reach_min_gap (10).  device: HIP device ordinal. */
+int vcl_wfa_cluster(const vcl_hap_seq *hap, const uint8_t *ctg_seq, int32_t ctg_len, int32_t sub, int32_t open,
+                    int32_t extend, int32_t max_cluster_itrs, int32_t reach_min_gap, int32_t device,
+                    vcl_clusters **out, vcl_wfa_stats *stats);
 
 /* max_query_len * max_truth_len of supercluster k (the factor in front of the 20 B/cell of cluster.cpp:99) */
 int64_t vcl_supercluster_cells(const vcl_hap haps[4], const vcl_superclusters *s, int32_t k);

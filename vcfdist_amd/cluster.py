@@ -24,8 +24,16 @@ class VclSuperclusters(C.Structure):
                 ("n_oversize", C.c_int32), ("n_unsplittable", C.c_int32), ("clusters", C.POINTER(VclClusters) * 4)]
 
 
+class VclHapSeq(C.Structure):
+    _fields_ = [("cols", VclHap), ("ref_off", A.P_i64), ("alt_off", A.P_i64), ("pool", A.P_u8)]
+
+
+class VclWfaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("align_calls", C.c_int64), ("reach_calls", C.c_int64), ("ms_device", C.c_double)]
+
+
 EXPORTED = ["vcl_simple_cluster", "vcl_clusters_free", "vcl_supercluster", "vcl_superclusters_free",
-            "vcl_supercluster_cells"]
+            "vcl_supercluster_cells", "vcl_wfa_cluster"]
 
 
 class Hap:
@@ -146,3 +154,58 @@ def supercluster(haps, clusters, max_supercluster_size=10000, L=None, prefix="vc
         L.vcl_superclusters_free.argtypes = [C.POINTER(VclSuperclusters)]
         L.vcl_superclusters_free(out)
     return res
+
+
+class HapSeq(Hap):
+    """A hap's variants with allele strings (for the biWFA clustering)."""
+
+    def __init__(self, pos, type, refs, alts):
+        refs = [r.encode() if isinstance(r, str) else bytes(r) for r in refs]
+        alts = [a.encode() if isinstance(a, str) else bytes(a) for a in alts]
+        ref_len = [len(r) for r in refs]
+        alt_len = [len(a) for a in alts]
+        super().__init__(pos, ref_len, type, ref_len, alt_len)
+        pool = bytearray()
+        self.ref_off, self.alt_off = [], []
+        for r, a in zip(refs, alts):
+            self.ref_off.append(len(pool)); pool += r
+            self.alt_off.append(len(pool)); pool += a
+        self.ref_off = np.ascontiguousarray(self.ref_off, dtype=np.int64)
+        self.alt_off = np.ascontiguousarray(self.alt_off, dtype=np.int64)
+        self.pool = np.frombuffer(bytes(pool) + b"\0", dtype=np.uint8).copy()
+
+    def as_seq_struct(self):
+        s = VclHapSeq()
+        s.cols = self.as_struct()
+        s.ref_off = A._ptr(self.ref_off, C.c_int64)
+        s.alt_off = A._ptr(self.alt_off, C.c_int64)
+        s.pool = A._ptr(self.pool, C.c_uint8)
+        return s
+
+
+def wfa_cluster(hap: HapSeq, ctg, sub=5, open=6, extend=2, max_cluster_itrs=4, reach_min_gap=10, device=0, L=None,
+                prefix="vcl"):
+    """defaults: vcfdist -c biwfa (globals.h:33-43).  Returns (Clusters, stats dict)."""
+    L = L or api.lib()
+    ctg = np.frombuffer(ctg.encode() if isinstance(ctg, str) else bytes(ctg), dtype=np.uint8).copy()
+    hs = hap.as_seq_struct()
+    out = C.POINTER(VclClusters)()
+    st = VclWfaStats()
+    f = getattr(L, prefix + "_wfa_cluster")
+    if prefix == "vcl":
+        f.argtypes = [C.POINTER(VclHapSeq), A.P_u8, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                      C.c_int32, C.POINTER(C.POINTER(VclClusters)), C.POINTER(VclWfaStats)]
+        rc = f(C.byref(hs), A._ptr(ctg, C.c_uint8), len(ctg), sub, open, extend, max_cluster_itrs, reach_min_gap, device,
+               C.byref(out), C.byref(st))
+    else:
+        f.argtypes = [C.POINTER(VclHapSeq), A.P_u8, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                      C.POINTER(C.POINTER(VclClusters)), C.POINTER(VclWfaStats)]
+        rc = f(C.byref(hs), A._ptr(ctg, C.c_uint8), len(ctg), sub, open, extend, max_cluster_itrs, reach_min_gap,
+               C.byref(out), C.byref(st))
+    if rc:
+        raise ValueError(f"{prefix}_wfa_cluster failed: {rc}")
+    res = Clusters.from_struct(out.contents)
+    if prefix == "vcl":
+        L.vcl_clusters_free.argtypes = [C.POINTER(VclClusters)]
+        L.vcl_clusters_free(out)
+    return res, dict(iterations=st.iterations, align_calls=st.align_calls, reach_calls=st.reach_calls, ms_device=st.ms_device)
