@@ -250,3 +250,29 @@ def test_zero_distance_level_mostly_rejects():
     frac_zero = float((want.aln_dist == 0).mean())
     print(f"{batch.n_sc} sc, s=0 for {frac_zero:.2f} of the alignments, {t.n_band_retries} retries, {ntie} ties skipped")
     assert frac_zero < 0.75 and t.n_band_retries > 6000      # > 25 % rejected: the in-place cap overflows
+
+
+def test_biwfa_cluster_supercluster_end_to_end():
+    """rows (f2) -> (f1) -> (a): variants -> biWFA clustering on the GPU -> superclustering -> Level B -> marshalling ->
+    HIP path, every stage against its oracle."""
+    from vcfdist_amd import cluster as K
+    v = api.Synth(n_sc=300, len_mode=1, len_a=30.0, len_b=0.8, len_min=8, len_max=300, seed=13, p_repeat=0.5).variants()
+    ctg = bytes(v.ctg_seq)
+    haps, cl = [], []
+    for i in range(4):
+        pool = v.allele_pool[i]
+        refs = [bytes(pool[o:o + n]) for o, n in zip(v.var_ref_off[i], v.var_ref_len[i])]
+        alts = [bytes(pool[o:o + n]) for o, n in zip(v.var_alt_off[i], v.var_alt_len[i])]
+        h = K.HapSeq(v.var_pos[i], v.var_type[i], refs, alts)
+        got, sg = K.wfa_cluster(h, ctg)
+        want, so = K.wfa_cluster(h, ctg, L=O.lib(), prefix="vco")
+        assert got == want, i
+        haps.append(h); cl.append(got)
+    s = K.supercluster(haps, cl, 2000)
+    assert s == K.supercluster(haps, cl, 2000, L=O.lib(), prefix="vco") and s.n > 5
+    v2 = A.Variants(v.ctg_off, v.ctg_seq, np.zeros(s.n, np.int32), s.beg, s.end, [s.var_off(i) for i in range(4)],
+                    v.var_pos, v.var_type, v.var_qual, v.var_ref_off, v.var_ref_len, v.var_alt_off, v.var_alt_len,
+                    v.allele_pool)
+    batch = api.batch_from_variants(v2)
+    got, want, ntie, pr = compare(batch)
+    print(f"{sum(c.n for c in cl)} biWFA clusters -> {s.n} superclusters (largest {int((s.end - s.beg).max())}), {ntie} ties skipped")

@@ -47,8 +47,41 @@ struct WfaJob {
     int64_t scratch;               // int offset of the job's scratch (strings first, then the offs ring)
 };
 
+extern __shared__ int32_t wfa_lds[];   // LDS variant: the job's strings and ring (one wave per workgroup)
+
+// A job's scratch: its two strings and the ring of wavefront rows.  LDS = true keeps it in LDS (jobs that fit:
+// almost all of them), LDS = false in a global region read and written with cache-bypassing (volatile) accesses.
+// A single wave owns the region, so ordering is program order plus this fence.
+template <bool LDS>
+struct Scratch {
+    volatile int32_t *g;      // global base (LDS = false)
+    int str_words;            // words taken by the two strings
+    int q_words;
+    __device__ __forceinline__ int ld(int i) const { if (LDS) return wfa_lds[str_words + i]; return g[str_words + i]; }
+    __device__ __forceinline__ void st(int i, int v) const { if (LDS) wfa_lds[str_words + i] = v; else g[str_words + i] = v; }
+    __device__ __forceinline__ uint8_t q(int i) const {
+        if (LDS) return reinterpret_cast<const uint8_t *>(wfa_lds)[i];
+        return reinterpret_cast<volatile const uint8_t *>(g)[i];
+    }
+    __device__ __forceinline__ uint8_t t(int i) const {
+        if (LDS) return reinterpret_cast<const uint8_t *>(wfa_lds)[q_words * 4 + i];
+        return reinterpret_cast<volatile const uint8_t *>(g)[q_words * 4 + i];
+    }
+    __device__ __forceinline__ void setq(int i, uint8_t v) const {
+        if (LDS) reinterpret_cast<uint8_t *>(wfa_lds)[i] = v; else reinterpret_cast<volatile uint8_t *>(g)[i] = v;
+    }
+    __device__ __forceinline__ void sett(int i, uint8_t v) const {
+        if (LDS) reinterpret_cast<uint8_t *>(wfa_lds)[q_words * 4 + i] = v; else reinterpret_cast<volatile uint8_t *>(g)[q_words * 4 + i] = v;
+    }
+    __device__ __forceinline__ void sync() const {
+        if (LDS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_s_waitcnt(0); }
+    }
+};
+
 // generate_str (dist.cpp:81-136) into dst; returns the length.  One lane writes a segment element each.
-__device__ int gen_str(const DevHap &H, int beg_idx, int end_idx, int beg_pos, int end_pos, volatile uint8_t *dst, int lane) {
+template <bool LDS>
+__device__ int gen_str(const DevHap &H, int beg_idx, int end_idx, int beg_pos, int end_pos, const Scratch<LDS> &S, int lane) {
     int var_idx = beg_idx, len = 0;
     while (var_idx < H.n && H.pos[var_idx] < beg_pos) var_idx++;
     for (int ref_pos = beg_pos; ref_pos < end_pos;) {
@@ -57,7 +90,7 @@ __device__ int gen_str(const DevHap &H, int beg_idx, int end_idx, int beg_pos, i
             if (t == 2 || t == 1) {   // INS / SUB: the ALT allele
                 const int al = H.alt_len[var_idx];
                 const uint8_t *src = H.pool + H.alt_off[var_idx];
-                for (int k = lane; k < al; k += 64) dst[len + k] = src[k];
+                for (int k = lane; k < al; k += 64) S.setq(len + k, src[k]);
                 len += al;
                 if (t == 1) ref_pos++;
             } else if (t == 3) {
@@ -68,7 +101,7 @@ __device__ int gen_str(const DevHap &H, int beg_idx, int end_idx, int beg_pos, i
             const int ref_end = (var_idx < end_idx) ? min(end_pos, H.pos[var_idx]) : end_pos;
             if (ref_end < ref_pos) break;   // overlapping variants: the reference ERRORs
             const int n = ref_end - ref_pos;
-            for (int k = lane; k < n; k += 64) dst[len + k] = H.ctg[ref_pos + k];
+            for (int k = lane; k < n; k += 64) S.setq(len + k, H.ctg[ref_pos + k]);
             len += n;
             ref_pos = ref_end;
         }
@@ -76,25 +109,22 @@ __device__ int gen_str(const DevHap &H, int beg_idx, int end_idx, int beg_pos, i
     return len;
 }
 
-__device__ __forceinline__ void wave_sync_mem() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-}
-
-// strings of a job: query (generated) and truth (reference substring), optionally reversed, in scratch bytes
-__device__ void load_strings(const DevHap &H, const WfaJob &J, volatile uint8_t *qs, volatile uint8_t *ts, int lane) {
-    gen_str(H, J.v_beg, J.v_end, J.q_beg, J.q_end, qs, lane);
-    for (int k = lane; k < J.r_len; k += 64) ts[k] = H.ctg[J.r_beg + k];
-    wave_sync_mem();
+// strings of a job: query (generated) and truth (reference substring), optionally reversed
+template <bool LDS>
+__device__ void load_strings(const DevHap &H, const WfaJob &J, const Scratch<LDS> &S, int lane) {
+    gen_str<LDS>(H, J.v_beg, J.v_end, J.q_beg, J.q_end, S, lane);
+    for (int k = lane; k < J.r_len; k += 64) S.sett(k, H.ctg[J.r_beg + k]);
+    S.sync();
     if (J.reverse) {   // std::reverse of both strings
-        for (int k = lane; k < J.q_len / 2; k += 64) { const uint8_t a = qs[k], b = qs[J.q_len - 1 - k]; qs[k] = b; qs[J.q_len - 1 - k] = a; }
-        for (int k = lane; k < J.r_len / 2; k += 64) { const uint8_t a = ts[k], b = ts[J.r_len - 1 - k]; ts[k] = b; ts[J.r_len - 1 - k] = a; }
-        wave_sync_mem();
+        for (int k = lane; k < J.q_len / 2; k += 64) { const uint8_t a = S.q(k), b = S.q(J.q_len - 1 - k); S.setq(k, b); S.setq(J.q_len - 1 - k, a); }
+        for (int k = lane; k < J.r_len / 2; k += 64) { const uint8_t a = S.t(k), b = S.t(J.r_len - 1 - k); S.sett(k, b); S.sett(J.r_len - 1 - k, a); }
+        S.sync();
     }
 }
 
 // wf_swg_align, dist.cpp:1510-1652: only the score is needed; rows older than max(x, o+e) are never read, so a ring
 // of `scores` freshly initialised rows replaces the reference's ever-growing vectors.
+template <bool LDS>
 __global__ void __launch_bounds__(64) k_wfa_align(DevHap H, const WfaJob *__restrict__ jobs, int n_jobs,
                                                   int32_t *__restrict__ scratch_all, int32_t *__restrict__ out,
                                                   int x, int o, int e) {
@@ -104,81 +134,83 @@ __global__ void __launch_bounds__(64) k_wfa_align(DevHap H, const WfaJob *__rest
     const int query_len = J.q_len, truth_len = J.r_len, mat_len = query_len + truth_len - 1;
     const int scores = max(x, o + e) + 1;
     const int y = mat_len, z = y * scores;
-    volatile uint8_t *qs = reinterpret_cast<volatile uint8_t *>(scratch_all + J.scratch);
-    volatile uint8_t *ts = qs + ((query_len + 3) & ~3);
-    volatile int32_t *offs = scratch_all + J.scratch + ((query_len + 3) >> 2) + ((truth_len + 3) >> 2);
-    load_strings(H, J, qs, ts, lane);
-    for (int k = lane; k < MATS * z; k += 64) offs[k] = -2;
-    wave_sync_mem();
+    Scratch<LDS> S;
+    S.g = scratch_all + J.scratch;
+    S.q_words = (query_len + 3) >> 2;
+    S.str_words = S.q_words + ((truth_len + 3) >> 2);
+    load_strings<LDS>(H, J, S, lane);
+    for (int k = lane; k < MATS * z; k += 64) S.st(k, -2);
+    S.sync();
     int s = 0, s2 = 0;
-    if (lane == 0) offs[M_SUB * z + query_len - 1] = -1;
-    wave_sync_mem();
+    if (lane == 0) S.st(M_SUB * z + query_len - 1, -1);
+    S.sync();
     while (true) {
         for (int m = M_INS; m < MATS; m++)
             for (int d = lane; d < mat_len; d += 64) {
-                const int off = offs[m * z + s2 * y + d], diag = d + 1 - query_len;
-                if (off >= 0 && off < query_len && diag + off >= 0 && diag + off < truth_len && off >= offs[M_SUB * z + s2 * y + d])
-                    offs[M_SUB * z + s2 * y + d] = off;
+                const int off = S.ld(m * z + s2 * y + d), diag = d + 1 - query_len;
+                if (off >= 0 && off < query_len && diag + off >= 0 && diag + off < truth_len && off >= S.ld(M_SUB * z + s2 * y + d))
+                    S.st(M_SUB * z + s2 * y + d, off);
             }
-        wave_sync_mem();
+        S.sync();
         bool done = false;
         for (int d0 = 0; d0 < mat_len && !done; d0 += 64) {
             const int d = d0 + lane;
             bool fin = false;
             if (d < mat_len) {
-                int off = offs[M_SUB * z + s2 * y + d];
+                int off = S.ld(M_SUB * z + s2 * y + d);
                 const int diag = d + 1 - query_len;
                 while (off != -2 && diag + off >= -1 && off < query_len - 1 && diag + off < truth_len - 1) {
-                    if (qs[off + 1] == ts[diag + off + 1]) off++;
+                    if (S.q(off + 1) == S.t(diag + off + 1)) off++;
                     else break;
                 }
-                offs[M_SUB * z + s2 * y + d] = off;
+                S.st(M_SUB * z + s2 * y + d, off);
                 fin = (off == query_len - 1 && off + diag == truth_len - 1);
             }
             done = __any(fin);
         }
         if (done) break;
-        wave_sync_mem();
+        S.sync();
         s++; s2++;
         if (s2 == scores) s2 = 0;
         for (int m = 0; m < MATS; m++)
-            for (int d = lane; d < mat_len; d += 64) offs[m * z + s2 * y + d] = -2;
-        wave_sync_mem();
+            for (int d = lane; d < mat_len; d += 64) S.st(m * z + s2 * y + d, -2);
+        S.sync();
         auto row = [&](int back) { int r = s2 - back; if (r < 0) r += scores; return r; };
         for (int d = lane; d < mat_len; d += 64) {
             const int diag = d + 1 - query_len;
             int vsub = -2, vdel = -2, vins = -2;
             if (s - x >= 0) {
-                const int p = offs[M_SUB * z + row(x) * y + d];
+                const int p = S.ld(M_SUB * z + row(x) * y + d);
                 if (p != -2 && p + 1 < query_len && diag + p + 1 < truth_len && p + 1 >= vsub) vsub = p + 1;
             }
             if (s - (o + e) >= 0 && d > 0) {
-                const int p = offs[M_SUB * z + row(o + e) * y + d - 1];
+                const int p = S.ld(M_SUB * z + row(o + e) * y + d - 1);
                 if (p != -2 && diag + p < truth_len && p >= vdel) vdel = p;
             }
             if (s - (o + e) >= 0 && d < mat_len - 1) {
-                const int p = offs[M_SUB * z + row(o + e) * y + d + 1];
+                const int p = S.ld(M_SUB * z + row(o + e) * y + d + 1);
                 if (p != -2 && p + 1 < query_len && diag + p + 1 < truth_len && diag + p + 1 >= 0 && p + 1 >= vins) vins = p + 1;
             }
             if (s - e >= 0 && d > 0) {
-                const int p = offs[M_DEL * z + row(e) * y + d - 1];
+                const int p = S.ld(M_DEL * z + row(e) * y + d - 1);
                 if (p != -2 && diag + p < truth_len && p >= vdel) vdel = p;
             }
             if (s - e >= 0 && d < mat_len - 1) {
-                const int p = offs[M_INS * z + row(e) * y + d + 1];
+                const int p = S.ld(M_INS * z + row(e) * y + d + 1);
                 if (p != -2 && p + 1 < query_len && diag + p + 1 < truth_len && diag + p + 1 >= 0 && p + 1 >= vins) vins = p + 1;
             }
-            offs[M_SUB * z + s2 * y + d] = vsub;
-            offs[M_DEL * z + s2 * y + d] = vdel;
-            offs[M_INS * z + s2 * y + d] = vins;
+            S.st(M_SUB * z + s2 * y + d, vsub);
+            S.st(M_DEL * z + s2 * y + d, vdel);
+            S.st(M_INS * z + s2 * y + d, vins);
         }
-        wave_sync_mem();
+        S.sync();
     }
     if (lane == 0) out[J.out] = s;
 }
 
 // wf_swg_max_reach, dist.cpp:2150-2333.  The ring keeps the reference's exact contents: the SUB row of a reused ring
 // slot is NOT reset (only INS / DEL are, :2215-2219), and the final maximum runs over every slot of the ring.
+template <bool LDS>
 __global__ void __launch_bounds__(64) k_wfa_reach(DevHap H, const WfaJob *__restrict__ jobs, int n_jobs,
                                                   int32_t *__restrict__ scratch_all, int32_t *__restrict__ out,
                                                   int x, int o, int e) {
@@ -190,25 +222,26 @@ __global__ void __launch_bounds__(64) k_wfa_reach(DevHap H, const WfaJob *__rest
     const bool reverse = J.reverse != 0;
     const int scores = max(x, o + e) + 1;
     const int y = mat_len, z = y * scores;
-    volatile uint8_t *qs = reinterpret_cast<volatile uint8_t *>(scratch_all + J.scratch);
-    volatile uint8_t *ts = qs + ((query_len + 3) & ~3);
-    volatile int32_t *offs = scratch_all + J.scratch + ((query_len + 3) >> 2) + ((truth_len + 3) >> 2);
-    load_strings(H, J, qs, ts, lane);
-    for (int k = lane; k < MATS * z; k += 64) offs[k] = -2;
-    wave_sync_mem();
+    Scratch<LDS> S;
+    S.g = scratch_all + J.scratch;
+    S.q_words = (query_len + 3) >> 2;
+    S.str_words = S.q_words + ((truth_len + 3) >> 2);
+    load_strings<LDS>(H, J, S, lane);
+    for (int k = lane; k < MATS * z; k += 64) S.st(k, -2);
+    S.sync();
     int s = 0, s2 = 0;
-    if (lane == 0) offs[M_SUB * z + query_len - 1] = -1;
-    wave_sync_mem();
+    if (lane == 0) S.st(M_SUB * z + query_len - 1, -1);
+    S.sync();
     int result = INT_MIN;
     while (true) {
         if (!reverse) {
             for (int m = M_INS; m < MATS; m++)
                 for (int d = lane; d < mat_len; d += 64) {
-                    const int off = offs[m * z + s2 * y + d], diag = d + 1 - query_len;
-                    if (off >= 0 && off < query_len && diag + off >= 0 && diag + off < truth_len && off >= offs[M_SUB * z + s2 * y + d])
-                        offs[M_SUB * z + s2 * y + d] = off;
+                    const int off = S.ld(m * z + s2 * y + d), diag = d + 1 - query_len;
+                    if (off >= 0 && off < query_len && diag + off >= 0 && diag + off < truth_len && off >= S.ld(M_SUB * z + s2 * y + d))
+                        S.st(M_SUB * z + s2 * y + d, off);
                 }
-            wave_sync_mem();
+            S.sync();
         }
         // extension; the reference returns at the first diagonal (ascending d) that reaches the last column of the
         // truth or the end of the query
@@ -216,14 +249,14 @@ __global__ void __launch_bounds__(64) k_wfa_reach(DevHap H, const WfaJob *__rest
             const int d = d0 + lane;
             int hit = INT_MIN;
             if (d < mat_len) {
-                int off = offs[M_SUB * z + s2 * y + d];
+                int off = S.ld(M_SUB * z + s2 * y + d);
                 const int diag = d + 1 - query_len;
                 while ((diag != main_diag || off + 1 < main_diag_off) && off != -2 && diag + off >= -1 &&
                        off < query_len - 1 && diag + off < truth_len - 1) {
-                    if (qs[off + 1] == ts[diag + off + 1]) off++;
+                    if (S.q(off + 1) == S.t(diag + off + 1)) off++;
                     else break;
                 }
-                offs[M_SUB * z + s2 * y + d] = off;
+                S.st(M_SUB * z + s2 * y + d, off);
                 if (off + diag == truth_len - 1) hit = truth_len - 1;
                 else if (off == query_len - 1 && off + diag >= 0 && off + diag < truth_len - 1) hit = off + diag;
             }
@@ -232,57 +265,57 @@ __global__ void __launch_bounds__(64) k_wfa_reach(DevHap H, const WfaJob *__rest
         }
         if (result != INT_MIN) break;
         if (s == max_score) break;
-        wave_sync_mem();
+        S.sync();
         s++; s2++;
         if (s2 == scores) s2 = 0;
         for (int m = M_INS; m < MATS; m++)
-            for (int d = lane; d < mat_len; d += 64) offs[m * z + s2 * y + d] = -2;
-        wave_sync_mem();
+            for (int d = lane; d < mat_len; d += 64) S.st(m * z + s2 * y + d, -2);
+        S.sync();
         auto row = [&](int back) { int r = s2 - back; if (r < 0) r += scores; return r; };
         for (int d = lane; d < mat_len; d += 64) {
             const int diag = d + 1 - query_len;
-            int vsub = offs[M_SUB * z + s2 * y + d];      // stale value of the reused ring slot
+            int vsub = S.ld(M_SUB * z + s2 * y + d);      // stale value of the reused ring slot
             int vdel = -2, vins = -2;
             if (s - x >= 0) {
-                const int p = offs[M_SUB * z + row(x) * y + d];
+                const int p = S.ld(M_SUB * z + row(x) * y + d);
                 if (p != -2 && p + 1 < query_len && diag + p + 1 < truth_len && p + 1 >= vsub) vsub = p + 1;
             }
             {
                 const int back = reverse ? e : (o + e);
                 if (s - back >= 0 && d > 0) {
-                    const int p = offs[M_SUB * z + row(back) * y + d - 1];
+                    const int p = S.ld(M_SUB * z + row(back) * y + d - 1);
                     if (p != -2 && diag + p < truth_len && p >= vdel) vdel = p;
                 }
                 if (s - back >= 0 && d < mat_len - 1) {
-                    const int p = offs[M_SUB * z + row(back) * y + d + 1];
+                    const int p = S.ld(M_SUB * z + row(back) * y + d + 1);
                     if (p != -2 && p + 1 < query_len && diag + p + 1 < truth_len && diag + p + 1 >= 0 && p + 1 >= vins) vins = p + 1;
                 }
             }
             if (reverse && s - o >= 0) {
                 for (int m = M_INS; m < MATS; m++) {
-                    const int p = offs[m * z + row(o) * y + d];
+                    const int p = S.ld(m * z + row(o) * y + d);
                     if (p >= 0 && p < query_len && diag + p >= 0 && diag + p < truth_len && p > vsub) vsub = p;
                 }
             }
             if (s - e >= 0 && d > 0) {
-                const int p = offs[M_DEL * z + row(e) * y + d - 1];
+                const int p = S.ld(M_DEL * z + row(e) * y + d - 1);
                 if (p != -2 && diag + p < truth_len && p >= vdel) vdel = p;
             }
             if (s - e >= 0 && d < mat_len - 1) {
-                const int p = offs[M_INS * z + row(e) * y + d + 1];
+                const int p = S.ld(M_INS * z + row(e) * y + d + 1);
                 if (p != -2 && p + 1 < query_len && diag + p + 1 < truth_len && diag + p + 1 >= 0 && p + 1 >= vins) vins = p + 1;
             }
-            offs[M_SUB * z + s2 * y + d] = vsub;
-            offs[M_DEL * z + s2 * y + d] = vdel;
-            offs[M_INS * z + s2 * y + d] = vins;
+            S.st(M_SUB * z + s2 * y + d, vsub);
+            S.st(M_DEL * z + s2 * y + d, vdel);
+            S.st(M_INS * z + s2 * y + d, vins);
         }
-        wave_sync_mem();
+        S.sync();
     }
     if (result == INT_MIN) {   // max reach over every slot of the ring, dist.cpp:2318-2331
-        wave_sync_mem();
+        S.sync();
         int mr = 0;
         for (int k = lane; k < MATS * z; k += 64) {
-            const int off = offs[k];
+            const int off = S.ld(k);
             const int d = k % y, diag = d + 1 - query_len;
             if (off >= 0 && off < query_len && diag + off >= 0 && diag + off < truth_len) mr = max(mr, diag + off);
         }
@@ -387,14 +420,31 @@ extern "C" int vcl_wfa_cluster(const vcl_hap_seq *hs, const uint8_t *ctg_seq, in
                 allocs.push_back(d_res);
                 res_cap = res.size() * 2;
             }
+            // jobs whose strings + ring fit in LDS run the LDS variant, bucketed by size (the dynamic LDS size of a
+            // launch bounds the waves per CU); the rest uses the global scratch
+            const int64_t LIM[4] = {8 << 10, 16 << 10, 32 << 10, 64 << 10};
+            auto need_bytes = [&](const WfaJob &j) {
+                return 4 * (int64_t((j.q_len + 3) >> 2) + ((j.r_len + 3) >> 2) + MATS * scores * (int64_t(j.q_len) + j.r_len - 1));
+            };
+            auto bucket_of = [&](const WfaJob &j) { const int64_t nb = need_bytes(j); for (int b = 0; b < 4; b++) if (nb <= LIM[b]) return b; return 4; };
+            std::stable_sort(jobs.begin(), jobs.end(), [&](const WfaJob &a, const WfaJob &b) { return bucket_of(a) < bucket_of(b); });
             if (hipMemcpy(d_jobs, jobs.data(), jobs.size() * sizeof(WfaJob), hipMemcpyHostToDevice) != hipSuccess) return false;
             (void)hipEventRecord(e0, nullptr);
-            if (align)
-                hipLaunchKernelGGL(k_wfa_align, dim3(unsigned(jobs.size())), dim3(64), 0, nullptr, H, d_jobs, int(jobs.size()),
-                                   d_scratch, d_res, sub, open, extend);
-            else
-                hipLaunchKernelGGL(k_wfa_reach, dim3(unsigned(jobs.size())), dim3(64), 0, nullptr, H, d_jobs, int(jobs.size()),
-                                   d_scratch, d_res, sub, open, extend);
+            for (size_t lo = 0; lo < jobs.size();) {
+                const int b = bucket_of(jobs[lo]);
+                size_t hi = lo;
+                while (hi < jobs.size() && bucket_of(jobs[hi]) == b) hi++;
+                const unsigned cnt = unsigned(hi - lo);
+                const size_t shm = b < 4 ? size_t(LIM[b]) : 0;
+                if (align) {
+                    if (b < 4) hipLaunchKernelGGL(k_wfa_align<true>, dim3(cnt), dim3(64), shm, nullptr, H, d_jobs + lo, int(cnt), d_scratch, d_res, sub, open, extend);
+                    else hipLaunchKernelGGL(k_wfa_align<false>, dim3(cnt), dim3(64), 0, nullptr, H, d_jobs + lo, int(cnt), d_scratch, d_res, sub, open, extend);
+                } else {
+                    if (b < 4) hipLaunchKernelGGL(k_wfa_reach<true>, dim3(cnt), dim3(64), shm, nullptr, H, d_jobs + lo, int(cnt), d_scratch, d_res, sub, open, extend);
+                    else hipLaunchKernelGGL(k_wfa_reach<false>, dim3(cnt), dim3(64), 0, nullptr, H, d_jobs + lo, int(cnt), d_scratch, d_res, sub, open, extend);
+                }
+                lo = hi;
+            }
             (void)hipEventRecord(e1, nullptr);
             if (hipMemcpy(res.data(), d_res, res.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
             float ms = 0;
