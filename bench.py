@@ -14,8 +14,9 @@ log-normal (median 20, sigma 1.2, clipped to [4, 10000]), Poisson(max(1, L/200))
 sites, 80 % SNP, 70 % homozygous, truth = query kept/dropped/perturbed 0.9/0.05/0.05,
 20 % tandem-repeat spans; real HG002 data is not available offline.  Each rank owns
 the same number of superclusters with a rank-specific seed (weak scaling: superclusters
-are independent, no data-path collective); the per-type TP/FP/FN tallies are summed
-with one all-reduce (RCCL) at the end of every step.
+are independent, no data-path collective); the precision/recall counters of SURVEY 8(e),
+counts[callset][SNP,INDEL,SV,ALL][TP,FP,FN][61 quality thresholds] (int64, computed on the
+device), are summed with one all-reduce (RCCL) at the end of every step.
 """
 import argparse
 import ctypes as C
@@ -101,7 +102,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from vcfdist_amd import api, shard, _abi as A
+    from vcfdist_amd import api, shard, summary, _abi as A
     if rank == 0:
         api.build()                 # no-op when the in-tree library is current (the driver builds it beforehand)
     if dist is not None:
@@ -113,6 +114,8 @@ def main():
     t_c = time.perf_counter()
     pr = api.PrecisionRecall(device=local_rank)
     pr.upload(batch)                    # inputs resident in HBM before the timed region (+ K0 prep kernels)
+    vv = syn.variants()                 # SNP / INDEL / SV class of every variant (print.cpp:362-372), resident too
+    summary.upload_var_class(pr, [summary.var_class(vv.var_type[s], vv.var_ref_len[s], vv.var_alt_len[s]) for s in range(4)])
     t_d = time.perf_counter()
     in_bytes = sum(a.nbytes for h in range(4) for a in (batch.hap_seq[h], batch.hap_ptr[h], batch.hap_flag[h],
                                                         batch.hap_off[h], batch.var_off[h], batch.var_pos[h],
@@ -125,9 +128,9 @@ def main():
     def step():
         pr.execute()                    # K1..K5 on the device
         host_res[0] = res = pr.download(host_res[0])   # final results to (reused) host buffers
-        t = torch.from_numpy(pr.tally()).to(dev)
+        t = torch.from_numpy(summary.pr_counts(pr, None, None)).to(dev)   # [2][4][3][61] int64, device histogram
         if dist is not None:
-            dist.all_reduce(t)          # the one collective of the path: TP/FP/FN tallies (int64 sum)
+            dist.all_reduce(t)          # the one collective of the path: the precision/recall counters (int64 sum)
         return res, t
 
     def sync():
@@ -153,6 +156,9 @@ def main():
     elapsed = time.perf_counter() - t0
     if rank == 0:       # the device tally must equal the one recomputed from the downloaded results
         assert np.array_equal(shard.tally_from_results(res, batch.var_off), pr.tally()), "device tally != host tally"
+        # after the timed region: per-contig phasing (host Viterbi) and the PRECISION-RECALL SUMMARY of this rank
+        pb, sw, fl = summary.phase(res.sc_phase, np.ones(batch.n_sc, np.int32))
+        rows = summary.pr_summary(summary.pr_counts(pr, None, pb))
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -210,7 +216,12 @@ def main():
                                 "pcie_inclusive_value": round(4 * args.n_sc / ((t_d - t_c) + elapsed / args.steps), 1)},
             "kernel_only_value": round(4 * args.n_sc / (float(np.mean(kern_ms)) * 1e-3), 1),
             "kernels": per_kernel,
-            "tally_TP_FP_FN": t.cpu().numpy().tolist(),
+            "counts_at_min_qual_TP_FP_FN": t.cpu().numpy()[:, 3, :, 0].tolist(),   # [callset][TP,FP,FN], type ALL, all ranks
+            "pr_summary_rank0": [{"type": summary.NAMES[r.vartype], "threshold": "BEST" if r.best else "NONE", "qual": r.qual,
+                                  "truth_tp": r.truth_tp, "query_tp": r.query_tp, "truth_fn": r.truth_fn, "query_fp": r.query_fp,
+                                  "precision": round(r.precision, 6), "recall": round(r.recall, 6), "f1": round(r.f1_score, 6)}
+                                 for r in rows if not r.best],
+            "phasing_rank0": {"switches": int(len(sw)), "flips": int(len(fl))},
             "order_defined_swap_ties": int((res.aln_status & 1).sum()),
             "roofline": roof,
         }

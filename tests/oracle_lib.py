@@ -28,7 +28,7 @@ class VpoExtra(C.Structure):
 
 def build():
     so = os.path.join(ORACLE_DIR, "libpr_oracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("pr_oracle.cpp", "cluster_oracle.cpp", "wfa_oracle.cpp", "pr_oracle.h")] + \
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("pr_oracle.cpp", "cluster_oracle.cpp", "wfa_oracle.cpp", "summary_oracle.cpp", "pr_oracle.h")] + \
            [os.path.join(ROOT, "include", "vcfdist_pr.h"), os.path.join(ROOT, "include", "vcfdist_cluster.h")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])

@@ -102,6 +102,7 @@ struct vpr_handle {
     Plan plan0;                          // first round over all alignments, cached at upload
     std::vector<uint8_t> level, level0;  // current / round-0 window level of every alignment
     int64_t last_need = 0;               // workspace bytes of the alignment make_plan could not place
+    uint8_t *d_cls[4] = {nullptr, nullptr, nullptr, nullptr};   // SNP / INDEL / SV class of every variant (vpr_upload_var_class)
     std::vector<int32_t> dirty;          // alignments whose device descriptor was overwritten by a retry round
     // device side
     AlnDesc *d_descs = nullptr;
@@ -177,6 +178,7 @@ void free_batch(vpr_handle *h) {
     h->plan0 = Plan();
     h->dirty.clear();
     h->d_arena = nullptr; h->d_secs = nullptr;
+    for (int k = 0; k < 4; k++) h->d_cls[k] = nullptr;
     for (int k = 0; k < 2; k++) h->lad[k] = LadderCtx();
     h->resident.clear();
     h->d_ed_scratch = nullptr; h->ed_scratch_ints = 0;
@@ -1311,6 +1313,106 @@ int vpr_get_tally(const vpr_handle *h, int64_t out[6]) {
     unsigned long long t[6];
     if (hipMemcpy(t, h->dR.tally, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) return VPR_ERR_DEVICE;
     for (int k = 0; k < 6; k++) out[k] = int64_t(t[k]);
+    return VPR_OK;
+}
+
+// histogram of floor(callq) per (class, errtype) of the phasing each supercluster selects, for one hap slot;
+// privatised per workgroup in LDS (a few thousand bins, heavily contended), flushed once
+__global__ void __launch_bounds__(256) k_pr_hist(const int64_t *__restrict__ var_off, int n_sc, int64_t n_var,
+                          const uint8_t *__restrict__ cls, const int32_t *__restrict__ sc_phase,
+                          const int32_t *__restrict__ pb_phase, VarCols c0, VarCols c1, int callset, int min_qual,
+                          int max_qual, unsigned long long *__restrict__ hist /* [2][3 classes][3][nq + 1] */) {
+    extern __shared__ unsigned int blk[];      // [3][3][nq + 1]
+    const int nq = max_qual - min_qual + 1, nb = 9 * (nq + 1);
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) blk[k] = 0;
+    __syncthreads();
+    const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (v < n_var) {
+        int lo = 0, hi = n_sc;   // supercluster of the variant: largest sc with var_off[sc] <= v
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (var_off[mid] <= v) lo = mid; else hi = mid; }
+        const int ph = sc_phase[lo];
+        const int swap = ph == VPR_PHASE_ORIG ? 0 : (ph == VPR_PHASE_SWAP ? 1 : (pb_phase ? (pb_phase[lo] != 0) : 0));
+        const VarCols &C = swap ? c1 : c0;
+        const int e = C.errtype[v];
+        if (e < 3) {                                         // ERRTYPE_UN etc.: skipped with a warning (print.cpp:374)
+            const float q = C.callq[v];
+            int b = (q < float(min_qual)) ? -1 : int(floorf(q)) - min_qual;   // last threshold index the variant counts at
+            if (b >= nq) b = nq - 1;
+            const int t = cls[v] > 2 ? 2 : cls[v];
+            // bin nq collects the variants that count at no threshold (callq < min_qual)
+            atomicAdd(&blk[(t * 3 + e) * (nq + 1) + (b < 0 ? nq : b)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb; k += blockDim.x)
+        if (blk[k]) atomicAdd(&hist[size_t(callset) * nb + k], (unsigned long long)blk[k]);
+}
+
+int vpr_upload_var_class(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS]) {
+    if (!h || !var_class) return VPR_ERR_ARG;
+    if (!h->uploaded) return fail(h, VPR_ERR_STATE, "vpr_upload_var_class before vpr_upload");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    for (int s = 0; s < VPR_HAPS; s++) {
+        int rc = dev_alloc(h, &h->d_cls[s], size_t(h->n_var[s]));
+        if (rc) return rc;
+        if (h->n_var[s]) HIPCHK(h, hipMemcpy(h->d_cls[s], var_class[s], size_t(h->n_var[s]), hipMemcpyHostToDevice));
+    }
+    return VPR_OK;
+}
+
+int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
+                  int32_t min_qual, int32_t max_qual, int64_t *counts) {
+    if (!h || !counts || max_qual < min_qual) return VPR_ERR_ARG;
+    if (!h->executed) return fail(h, VPR_ERR_STATE, "vpr_pr_counts before vpr_execute");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int nq = max_qual - min_qual + 1;
+    const size_t nh = size_t(2) * 3 * 3 * size_t(nq + 1);
+    unsigned long long *d_hist = nullptr;
+    int32_t *d_pb = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&d_hist), nh * 8));
+    HIPCHK(h, hipMemset(d_hist, 0, nh * 8));
+    if (pb_phase && h->n_sc) {
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&d_pb), size_t(h->n_sc) * 4));
+        HIPCHK(h, hipMemcpy(d_pb, pb_phase, size_t(h->n_sc) * 4, hipMemcpyHostToDevice));
+    }
+    if (var_class) { int rc = vpr_upload_var_class(h, var_class); if (rc) return rc; }
+    for (int s = 0; s < VPR_HAPS; s++) {
+        const int64_t nv = h->n_var[s];
+        if (!nv) continue;
+        if (!h->d_cls[s]) return fail(h, VPR_ERR_STATE, "vpr_pr_counts: no variant classes (pass var_class or call vpr_upload_var_class)");
+        hipLaunchKernelGGL(k_pr_hist, dim3(unsigned((nv + 255) / 256)), dim3(256), size_t(9) * (nq + 1) * 4, h->stream,
+                           h->dB.var_off[s], h->n_sc, nv, h->d_cls[s], h->dR.sc_phase, d_pb, h->dR.v[s][0], h->dR.v[s][1],
+                           s >> 1, min_qual, max_qual, d_hist);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> hist(nh);
+    HIPCHK(h, hipMemcpy(hist.data(), d_hist, nh * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_hist);
+    if (d_pb) (void)hipFree(d_pb);
+    // counts at threshold k: variants whose last threshold index is >= k (print.cpp:378-381, 425-428); a truth variant
+    // additionally counts as FN at every threshold above its own (print.cpp:429-432)
+    std::fill(counts, counts + size_t(2) * VPR_VARTYPES * 3 * size_t(nq), 0);
+    auto C = [&](int cs, int t, int e, int k) -> int64_t & { return counts[((size_t(cs) * VPR_VARTYPES + t) * 3 + e) * nq + k]; };
+    for (int cs = 0; cs < 2; cs++)
+        for (int t = 0; t < 3; t++) {
+            for (int e = 0; e < 3; e++) {
+                int64_t acc = 0;
+                for (int k = nq - 1; k >= 0; k--) {
+                    acc += int64_t(hist[((size_t(cs) * 3 + t) * 3 + e) * (nq + 1) + k]);
+                    C(cs, t, e, k) += acc;
+                    C(cs, VPR_VARTYPE_ALL, e, k) += acc;
+                }
+            }
+            if (cs == 1) {
+                int64_t below = 0;   // truth variants (any errtype) whose own threshold index is < k
+                for (int e = 0; e < 3; e++) below += int64_t(hist[((size_t(cs) * 3 + t) * 3 + e) * (nq + 1) + nq]);
+                for (int k = 0; k < nq; k++) {
+                    C(cs, t, VPR_ERRTYPE_FN, k) += below;
+                    C(cs, VPR_VARTYPE_ALL, VPR_ERRTYPE_FN, k) += below;
+                    for (int e = 0; e < 3; e++) below += int64_t(hist[((size_t(cs) * 3 + t) * 3 + e) * (nq + 1) + k]);
+                }
+            }
+        }
     return VPR_OK;
 }
 
