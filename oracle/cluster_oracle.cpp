@@ -11,8 +11,9 @@
 //       next_var()      <- get_next_variant_info               src/cluster.cpp:709-733
 //       split_where()   <- get_supercluster_split_location     src/cluster.cpp:738-808
 //
-// PARITY PIN: "parity unpinned" against a live reference (it cannot be built here, see pr_oracle.cpp); the
-// reference ships no tests for these functions.  Pins that exist: hand-worked cases in tests/test_cluster.py.
+// PARITY PIN: part of the chain that reproduces the published SNP / SV rows of the reference's demo/output.txt
+// (tests/test_demo_known_answer.py; see pr_oracle.cpp); the reference ships no unit tests for these functions, so
+// beyond that known answer there are hand-worked cases only.
 #include <algorithm>
 #include <climits>
 #include <cmath>

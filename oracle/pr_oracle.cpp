@@ -19,14 +19,17 @@
 // optimal swap predecessors is "last writer wins" and therefore depends on that
 // iteration order (dist.cpp:347,376).
 //
-// PARITY PIN -- "parity unpinned" against a live reference: the reference cannot be built in this
-// image (every translation unit on the path includes htslib/vcf.h through variant.h:9, htslib is not
-// installed, and writing a stand-in header is not allowed), and it ships no tests or golden vectors for
-// this path.  Partial pins that do exist (tests/test_oracle.py): (1) the reference-produced toy vector
-// recorded in SURVEY.md Appendix A.1 (strings, pointer/flag arrays, s = 0 x4, QUERY end plane),
-// (2) textbook Levenshtein for edit_distance, (3) an independent dense dynamic programme
-// (tests/dense_model.py) for distances, flags, backward scores and path pointers, (4) hand-derived
-// credit cases.  The demo known-answer (demo/output.txt) needs the rows of SURVEY 8(f).
+// PARITY PIN.  The reference cannot be built in this image (every translation unit on the path includes
+// htslib/vcf.h through variant.h:9, htslib is not installed, and writing a stand-in header is not allowed), and it
+// ships no unit tests or golden vectors for this path.  What it does ship is a known answer, demo/output.txt, and
+// the oracle chain is pinned on it (tests/test_demo_known_answer.py): the reference's demo
+// VCFs + BED through the VCF/BED front end, oracle biWFA clustering, superclustering, THIS file, phasing and the
+// summary reproduce the published SNP and SV rows exactly -- counts and the printed precision / recall / F1 /
+// Q-score -- on a surrogate FASTA (the demo's GRCh38 slice is not distributable), and the INDEL / ALL rows one count
+// lower in every column, which is what the real reference prints on a surrogate FASTA.  The real
+// FASTA would close that last count.  Further pins (tests/test_oracle.py): (1) the reference-produced toy vector of
+// SURVEY.md Appendix A.1, (2) textbook Levenshtein for edit_distance, (3) an independent dense dynamic programme
+// (tests/dense_model.py) for distances, flags, backward scores and path pointers, (4) hand-derived credit cases.
 // See DESIGN.md section 5.
 #include <algorithm>
 #include <cstdint>

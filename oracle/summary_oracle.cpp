@@ -3,8 +3,9 @@
 //   vso_phase      <- phaseblockData::phase        src/phase.cpp:271-355 (one contig)
 //   vso_pr_counts  <- write_precision_recall       src/print.cpp:324-441 (the float counters, one contig)
 //   vso_pr_summary <- write_precision_recall       src/print.cpp:444-566 (NONE / BEST rows)
-// PARITY PIN: "parity unpinned" against a live reference (see pr_oracle.cpp); hand-worked cases in
-// tests/test_summary.py.
+// PARITY PIN: part of the chain that reproduces the published SNP / SV rows of the reference's demo/output.txt
+// (tests/test_demo_known_answer.py; see pr_oracle.cpp); the reference ships no unit tests for these functions, so
+// beyond that known answer there are hand-worked cases only.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>

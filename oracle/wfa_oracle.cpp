@@ -7,8 +7,9 @@
 //   swg_max_reach()  <- wf_swg_max_reach    src/dist.cpp:2150-2333
 //   vco_wfa_cluster  <- wf_swg_cluster      src/cluster.cpp:954-1263
 //
-// PARITY PIN: "parity unpinned" against a live reference (it cannot be built here, see pr_oracle.cpp); the
-// reference ships no tests for these functions.  Pins that exist: hand-worked cases in tests/test_wfa_cluster.py.
+// PARITY PIN: part of the chain that reproduces the published SNP / SV rows of the reference's demo/output.txt
+// (tests/test_demo_known_answer.py; see pr_oracle.cpp); the reference ships no unit tests for these functions, so
+// beyond that known answer there are hand-worked cases only.
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
