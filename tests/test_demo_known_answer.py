@@ -58,3 +58,25 @@ def test_product_chain_equals_oracle_chain_on_demo():
                     x, y = x.view(np.uint32), y.view(np.uint32)
                 assert np.array_equal(x, y) or ties > 0, (name, h, w)
     print(f"demo: {det_p['n_sc']} superclusters, {sum(det_p['n_var'])} hap-variants, {ties} tie-flagged alignments")
+
+
+@pytest.mark.gpu
+def test_command_line_on_demo_files(tmp_path, capsys):
+    """python -m vcfdist_amd query.vcf truth.vcf.gz ref.fa -b bed: C++ readers + GPU chain, printed like the reference"""
+    import os
+    from vcfdist_amd.__main__ import main
+    fa = tmp_path / "surrogate.fa"
+    seq = D.surrogate_fasta(5_100_000)
+    with open(fa, "w") as fh:
+        fh.write(">chr1 surrogate\n")
+        s = bytes(seq).decode()
+        for i in range(0, len(s), 100000):
+            fh.write(s[i:i + 100000] + "\n")
+    rows = main([os.path.join(D.DEMO, "query.vcf"), os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.vcf.gz"), str(fa),
+                 "-b", os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.bed")])
+    out = capsys.readouterr().out
+    published = open(os.path.join(D.DEMO, "output.txt")).read().splitlines()
+    snp_lines = [l for l in published if l.startswith("SNP")]
+    assert all(l in out.splitlines() for l in snp_lines), out          # the two SNP lines are printed verbatim
+    rows_o, _ = D.run(product=False)
+    assert [r.key() for r in rows] == [r.key() for r in rows_o]
