@@ -23,7 +23,8 @@ class VprError(RuntimeError):
 def build(force=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
-    srcs.append(os.path.join(os.path.dirname(HERE), "include", "vcfdist_pr.h"))
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    srcs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
