@@ -206,8 +206,22 @@ def run(product, ctg_len=5_100_000):
         counts = S.oracle_pr_counts(lib, batch.var_off, res, cls, pb, G["min_qual"], G["max_qual"])
         rows = S.pr_summary(counts, G["min_qual"], G["max_qual"], L=lib, prefix="vso")
     det = dict(query_stats=qs, truth_stats=ts, n_var=[len(h.pos) for h in haps], n_clusters=[c.n for c in cl], n_sc=sc.n,
-               counts=counts, res=res, clusters=cl, sc=sc, batch=batch)
+               counts=counts, res=res, clusters=cl, sc=sc, batch=batch, slots=slots, pb=pb, switches=sw, flips=fl, fasta=fasta)
     return rows, det
+
+
+def report_view(det, name="chr1", length=0, ploidy=2):
+    """the oracle chain's results as the plain-data contig of tests/report_oracle.py (the demo has no PS tags)"""
+    import report_oracle as RO
+    sc = det["sc"]
+    slots = [dict(pos=s["pos"], type=s["type"], ref=s["ref"], alt=s["alt"], var_qual=s["qual"], phase_set=[0] * len(s["pos"]))
+             for s in det["slots"]]
+    clusters = [list(c.var_beg) if c.n else [] for c in sc.clusters]
+    res = det["res"]
+    return RO.Ctg(name=name, length=length, ploidy=ploidy, seq=bytes(det["fasta"]), slots=slots, clusters=clusters,
+                  sc_beg=list(sc.beg), sc_end=list(sc.end), sc_brk=[list(b) for b in sc.brk], sc_phase=res.sc_phase, pb_phase=det["pb"],
+                  orig_dist=res.orig_phase_dist, swap_dist=res.swap_phase_dist, sc_phase_set=[0] * sc.n,
+                  switches=list(det["switches"]), flips=list(det["flips"]), res=res)
 
 
 def known_answer():

@@ -72,11 +72,33 @@ def test_command_line_on_demo_files(tmp_path, capsys):
         s = bytes(seq).decode()
         for i in range(0, len(s), 100000):
             fh.write(s[i:i + 100000] + "\n")
-    rows = main([os.path.join(D.DEMO, "query.vcf"), os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.vcf.gz"), str(fa),
-                 "-b", os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.bed")])
+    prefix = str(tmp_path) + "/demo_"
+    argv = [os.path.join(D.DEMO, "query.vcf"), os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.vcf.gz"), str(fa),
+            "-b", os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.bed"), "-p", prefix]
+    rows = main(argv)
     out = capsys.readouterr().out
     published = open(os.path.join(D.DEMO, "output.txt")).read().splitlines()
     snp_lines = [l for l in published if l.startswith("SNP")]
     assert all(l in out.splitlines() for l in snp_lines), out          # the two SNP lines are printed verbatim
-    rows_o, _ = D.run(product=False)
+    rows_o, det = D.run(product=False)
     assert [r.key() for r in rows] == [r.key() for r in rows_o]
+    # the output tables ("P/R TSVs bit-identical"): files of the GPU chain == the Python restatement of the
+    # reference's writers fed with the CPU oracle chain's results
+    import report_oracle as RO
+    rd = lambda name: open(prefix + name, "rb").read().decode()
+    a, s = RO.precision_recall(det["counts"], D.G["min_qual"], D.G["max_qual"])
+    assert rd("precision-recall.tsv") == a
+    assert rd("precision-recall-summary.tsv") == s
+    from vcfdist_amd import _abi as A
+    ties = int(np.count_nonzero(det["res"].aln_status & A.ST_SWAP_TIE))
+    octg = [D.report_view(det, length=248956422)]       # ##contig length of the demo VCF headers
+    assert rd("phase-blocks.tsv") == RO.phase_blocks_tsv(octg)
+    assert rd("superclusters.tsv") == RO.superclusters_tsv(octg)
+    if ties == 0:                                # (order-defined ties may move single variant rows)
+        assert rd("query.tsv") == RO.variants_tsv(octg, 0)
+        assert rd("truth.tsv") == RO.variants_tsv(octg, 1)
+        got = rd("summary.vcf").split("\n")
+        want = RO.summary_vcf(octg, "vcfdist " + " ".join(argv), "00000000", D.G["credit_threshold"]).split("\n")
+        assert got[:1] + got[2:] == want[:1] + want[2:]      # all but the ##fileDate line
+    # the summary rows of the TSV carry the published SNP numbers
+    assert "SNP\tNONE\t0\t8222\t8222\t1\t2\t0.999757\t0.999878\t0.999818\t37.388565\n" in rd("precision-recall-summary.tsv")

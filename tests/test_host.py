@@ -27,6 +27,16 @@ def test_library_exports_every_declared_symbol():
     assert set(api.EXPORTED) <= declared
 
 
+@pytest.mark.parametrize("header,prefix", [("vcfdist_cluster.h", "vcl_"), ("vcfdist_io.h", "vio_"), ("vcfdist_report.h", "vrp_")])
+def test_library_exports_the_other_headers_too(header, prefix):
+    api.build()
+    hdr = open(os.path.join(ROOT, "include", header)).read()
+    declared = set(re.findall(r"\b(%s[a-z_0-9]+)\s*\(" % prefix, hdr))
+    assert len(declared) >= 4
+    L = api.lib()
+    assert not [n for n in sorted(declared) if not hasattr(L, n)]
+
+
 def test_struct_sizes_match_header():
     # spot-check the ctypes mirror against the C layout through a round trip of the synth params
     p = api.synth_params(n_sc=3, seed=9)

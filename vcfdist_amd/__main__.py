@@ -3,14 +3,16 @@
 The reference's command line for the precision/recall evaluation (vcfdist v2.6.4, main.cpp / globals.cpp) on top of
 the MI355X path: VCF / BED / FASTA readers (include/vcfdist_io.h), biWFA or distance clustering and superclustering
 (include/vcfdist_cluster.h), the precision/recall alignment on the GPU (include/vcfdist_pr.h), phasing, counters and
-the PRECISION-RECALL SUMMARY.  Realignment, the --distance metrics and the TSV / VCF writers are not part of it."""
+the PRECISION-RECALL SUMMARY and the output tables (include/vcfdist_report.h: precision-recall*.tsv, phase-blocks.tsv,
+superclusters.tsv, query.tsv, truth.tsv, summary.vcf under -p PREFIX; -n writes nothing).  Realignment and the --distance
+metrics are not part of it."""
 import argparse
 import sys
 
 import numpy as np
 
 from . import _abi as A
-from . import api, cluster as K, io as IO, summary as S
+from . import api, cluster as K, io as IO, report as RP, summary as S
 
 
 def transfer_phase_sets(slots, clusters, sc):
@@ -35,7 +37,8 @@ def transfer_phase_sets(slots, clusters, sc):
 
 
 def evaluate_contig(name, seq, slots, args, device=0):
-    """slots: [Q1, Q2, T1, T2] column dicts of include/vcfdist_io.h.  -> int64 counters [2][4][3][nq], n_sc"""
+    """slots: [Q1, Q2, T1, T2] column dicts of include/vcfdist_io.h.  -> int64 counters [2][4][3][nq], n_sc, and what the
+    writers need: (clusters after splitting, superclusters, results, phase sets, pb_phase, switches, flips)"""
     haps = []
     for s in slots:
         h = K.HapSeq.__new__(K.HapSeq)
@@ -50,7 +53,8 @@ def evaluate_contig(name, seq, slots, args, device=0):
     sc = K.supercluster(haps, cl, args.max_supercluster_size)
     nq = args.max_qual - args.min_qual + 1
     if sc.n == 0:
-        return np.zeros((2, 4, 3, nq), np.int64), 0, sc
+        z = np.zeros(0, np.int32)
+        return np.zeros((2, 4, 3, nq), np.int64), 0, (sc.clusters, sc, A.Results(0, [len(h.pos) for h in haps]), z, z, z, z)
     v = A.Variants(np.array([0, len(seq)], np.int64), seq, np.zeros(sc.n, np.int32), sc.beg, sc.end,
                    [sc.var_off(i) for i in range(4)], [h.pos for h in haps], [h.type for h in haps],
                    [s["var_qual"] for s in slots], [h.ref_off for h in haps], [h.ref_len for h in haps],
@@ -59,12 +63,13 @@ def evaluate_contig(name, seq, slots, args, device=0):
     cfg.max_qual = float(args.max_qual); cfg.credit_threshold = args.credit_threshold; cfg.phase_threshold = args.phase_threshold
     pr = api.PrecisionRecall(cfg)
     res = pr.run(api.batch_from_variants(v))
-    pb, sw, fl = S.phase(res.sc_phase, transfer_phase_sets(slots, cl, sc))
+    phase_sets = transfer_phase_sets(slots, cl, sc)
+    pb, sw, fl = S.phase(res.sc_phase, phase_sets)
     cls = [S.var_class(h.type, h.ref_len, h.alt_len, args.sv_threshold) for h in haps]
     counts = S.pr_counts(pr, cls, pb, args.min_qual, args.max_qual)
     print(f"[vcfdist_amd] {name}: {sum(len(h.pos) for h in haps)} hap-variants, {sum(c.n for c in cl)} clusters, {sc.n} superclusters, "
           f"{len(sw)} switch / {len(fl)} flip errors", file=sys.stderr)
-    return counts, sc.n, sc
+    return counts, sc.n, (sc.clusters, sc, res, phase_sets, pb, sw, fl)
 
 
 def main(argv=None):
@@ -85,6 +90,8 @@ def main(argv=None):
     ap.add_argument("-pt", "--phasing-threshold", type=float, default=0.6, dest="phase_threshold")
     ap.add_argument("-sv", "--sv-threshold", type=int, default=50)
     ap.add_argument("--reach-min-gap", type=int, default=10)
+    ap.add_argument("-p", "--prefix", default="./", help="prefix of the output files")
+    ap.add_argument("-n", "--no-output-files", action="store_true")
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args(argv)
     args.cluster_gap = 50
@@ -103,13 +110,22 @@ def main(argv=None):
     empty = dict(pos=np.zeros(0, np.int32), rlen=np.zeros(0, np.int32), type=np.zeros(0, np.uint8), var_qual=np.zeros(0, np.float32),
                  phase_set=np.zeros(0, np.int32), ref_len=np.zeros(0, np.int32), alt_len=np.zeros(0, np.int32),
                  ref_off=np.zeros(0, np.int64), alt_off=np.zeros(0, np.int64), pool=np.zeros(1, np.uint8))
+    reports = []
     for ctg in contigs:
         if ctg not in fasta:
             raise SystemExit(f"ERROR: contig '{ctg}' not in reference FASTA")
         qs = q["vars"][q["contigs"].index(ctg)] if ctg in q["contigs"] else [empty, empty]
         ts = t["vars"][t["contigs"].index(ctg)] if ctg in t["contigs"] else [empty, empty]
-        counts, n_sc, _ = evaluate_contig(ctg, fasta[ctg], [qs[0], qs[1], ts[0], ts[1]], args, device=args.device)
+        counts, n_sc, tables = evaluate_contig(ctg, fasta[ctg], [qs[0], qs[1], ts[0], ts[1]], args, device=args.device)
         total += counts
+        if not args.no_output_files:
+            src = q if ctg in q["contigs"] else t     # superclusterData ctor, cluster.cpp:134-157: query's header wins
+            k = src["contigs"].index(ctg)
+            reports.append(RP.Contig(ctg, src["lengths"][k], src["ploidy"][k], fasta[ctg], [qs[0], qs[1], ts[0], ts[1]], *tables))
+    if not args.no_output_files:
+        RP.write_precision_recall(args.prefix, total, args.min_qual, args.max_qual)
+        cmd = " ".join(["vcfdist"] + list(sys.argv[1:] if argv is None else argv))
+        RP.write_results(args.prefix, reports, cmd=cmd, credit_threshold=args.credit_threshold)
     rows = S.pr_summary(total, args.min_qual, args.max_qual)
     print("PRECISION-RECALL SUMMARY\n")
     print("TYPE\tTHRESHOLD\tTRUTH_TP\tQUERY_TP\tTRUTH_FN\tQUERY_FP\tPREC\t\tRECALL\t\tF1_SCORE\tF1_QSCORE")
