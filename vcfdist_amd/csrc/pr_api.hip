@@ -43,7 +43,8 @@ const size_t LDS_MAX = 160 * 1024;
 enum { LV_Z = 0, LV_Q16 = 1, LV_C1 = 2, LV_C4 = 3, LV_C16 = 4, LV_DENSE = 5 };
 const int LV_WINDOW[] = {16, 16, 64, 256, 1024, 0};   // window width = flag layout of the level
 const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnDesc::band_pad that marks the level
-const int LONG_LT = 512;                  // truth rows from which an alignment is a latency chain
+// truth rows from which an alignment is a latency chain (VPR_LONG_LT: experiments only)
+static const int LONG_LT = [] { const char *e = getenv("VPR_LONG_LT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
 
 struct Launch { int cls; int64_t work_off; int32_t count; };   // dense: one k_fwd/k_bwd launch of a class
 struct Chunk {
@@ -526,6 +527,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if ((rc = dev_alloc(h, &D.fk4_q[q], hap_len[q]))) return rc;
         if ((rc = dev_alloc(h, &D.fk4_r[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.tk[q], hap_len[2 + q]))) return rc;
+        if ((rc = dev_alloc(h, &D.tz[q], hap_len[2 + q] + 8))) return rc;
         if ((rc = dev_alloc(h, &D.wk_q[q], hap_len[q]))) return rc;
         if ((rc = dev_alloc(h, &D.wk_r[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.wk_t[q], hap_len[2 + q]))) return rc;
@@ -871,12 +873,12 @@ int vpr_execute(vpr_handle *h) {
         int rc = VPR_OK;
         if (phases & 1) {
         cells_touched += ls.cells;
-        rc = timed(1, ls, ks, zero ? "k_fwd_q16<zero>" : q16 ? "k_fwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") ? "k_fwd_stripe" : (lv == LV_C1 ? "k_fwd_band<1>" : (getenv("VPR_NO_WIDE") ? (lv == LV_C4 ? "k_fwd_band<4>" : "k_fwd_band<16>") : (lv == LV_C4 ? "k_fwd_wide<4>" : "k_fwd_wide<16>")))), [&] {
+        rc = timed(1, ls, ks, zero ? "k_fwd_z16" : q16 ? "k_fwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") ? "k_fwd_stripe" : (lv == LV_C1 ? "k_fwd_band<1>" : (getenv("VPR_NO_WIDE") ? (lv == LV_C4 ? "k_fwd_band<4>" : "k_fwd_band<16>") : (lv == LV_C4 ? "k_fwd_wide<4>" : "k_fwd_wide<16>")))), [&] {
             if (zero)
-                hipLaunchKernelGGL(k_fwd_q16<true>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                hipLaunchKernelGGL(k_fwd_z16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);
             else if (q16)
-                hipLaunchKernelGGL(k_fwd_q16<false>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);
             else
                 hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3((lv >= LV_C4 && !getenv("VPR_NO_WIDE")) ? W : 64), 0,
@@ -915,7 +917,7 @@ int vpr_execute(vpr_handle *h) {
         vpr_launch_stat ws_;
         memset(&ws_, 0, sizeof(ws_));
         ws_.threads = q16 ? 16 : 64; ws_.n_units = cnt; ws_.cells_per_thread = 2;
-        if (q16 && !getenv("VPR_NO_Q16WALK")) {
+        if (q16) {
             // 16-cell layout: row-sweep walk, four alignments per wave (phase A) + credit walk (phase B)
             rc = timed(3, ws_, ks, "k_walk_q16", [&] {
                 hipLaunchKernelGGL(k_walk_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,

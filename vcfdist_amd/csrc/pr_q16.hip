@@ -25,6 +25,7 @@
 //   which 0,1: fk4_q[which] (positions of query hap `which`)   {fk.x, fk.y, q2r[x], vs_hap[x-1]}
 //   which 2,3: fk4_r[which-2] (ref positions, query hap h)     {fk.x, fk.y, x,      vs_ref[x-1]}
 //   which 4,5: tk[which-4]    (positions of truth slot which-2) {t2r[t], base | fwd_allow(flag[t-1]) << 8 | vs[t-1] << 9}
+//              tz[which-4]    one byte per truth position: base | fwd_allow(flag[t-1]) << 7 (k_fwd_z16)
 __global__ void k_prep_q16(DevBatch B, int which, int64_t n_pos) {
     const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= n_pos) return;
@@ -46,6 +47,7 @@ __global__ void k_prep_q16(DevBatch B, int which, int64_t n_pos) {
         const int at = (!(f & PV) || (f & PE)) ? 1 : 0;
         B.tk[which - 4][g] = make_int2(B.hap_ptr[slot][g],
                                        int32_t(uint32_t(B.hap_seq[slot][g]) | (uint32_t(at) << 8) | (uint32_t(B.vs_hap[slot][gm1]) << 9)));
+        B.tz[which - 4][g] = uint8_t((B.hap_seq[slot][g] & 0x7f) | (at << 7));
     }
 }
 
@@ -130,13 +132,6 @@ __device__ __forceinline__ int wave_max4(int v) {   // max of the four row leade
 // ===========================================================================
 // K1q: forward sweep, 16-cell window, four alignments per wave (calc_prec_recall_aln, dist.cpp:251-443)
 // ===========================================================================
-// ZERO: the zero-distance variant.  Most whole-genome alignments have s = 0 (truth and query spell the same
-// string); then the only cells with D <= s are those reachable from the two start cells over MAT and swap edges, so
-// D is tracked as {0, unreachable}: no DEL / SUB candidates, no INS scan, no lower-bound arithmetic.  It accepts an
-// alignment only if an end cell is reachable at distance 0 and no reachable cell has a zero-cost edge leaving the
-// window; everything else climbs to the general 16-cell level.  The flag bytes of the cells with D = 0 (MAT / SWP,
-// swap choice, tie bit) are exactly those of the general kernel.
-template <bool ZERO>
 __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__restrict__ descs,
                                                 const int32_t *__restrict__ work, int n_work,
                                                 uint8_t *__restrict__ ws, int32_t *__restrict__ blo_all,
@@ -157,12 +152,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
     const int2 *tk = (ts == 2 ? B.tk[0] : B.tk[1]) + dp->t_off;
     const int32_t *r2q = (qs == 0 ? B.ref_ptr[0] : B.ref_ptr[1]) + r_off;
     const int4 *fk[2] = {(qs == 0 ? B.fk4_q[0] : B.fk4_q[1]) + q_off, (qs == 0 ? B.fk4_r[0] : B.fk4_r[1]) + r_off};
-    // the zero-distance variant needs no reference coordinates / shift budgets: the 8-byte packs are enough
-    const int2 *fk2[2] = {(qs == 0 ? B.fk_q[0] : B.fk_q[1]) + q_off, (qs == 0 ? B.fk_r[0] : B.fk_r[1]) + r_off};
-    auto load_k = [&](int p, int idx) -> int4 {
-        if (ZERO) { const int2 k = fk2[p][idx]; return make_int4(k.x, k.y, 0, 0); }
-        return fk[p][idx];
-    };
+    auto load_k = [&](int p, int idx) -> int4 { return fk[p][idx]; };
     const int4 *cand[2] = {(qs == 0 ? B.cand_q[0] : B.cand_q[1]) + q_off, (qs == 0 ? B.cand_r[0] : B.cand_r[1]) + r_off};
     uint32_t *mat = reinterpret_cast<uint32_t *>(ws + dp->mat_off[0]);
     int2 *blo2 = reinterpret_cast<int2 *>(blo_all + dp->blo_off);
@@ -189,7 +179,6 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
 
     int exit_min = D_INF;
     int Dp[2] = {gl, gl};                   // row 0: D = x along the INS chain (origin 0)
-    if (ZERO) { Dp[0] = (gl == 0) ? 0 : D_INF; Dp[1] = Dp[0]; }
     int lo[2] = {0, 0}, hi[2] = {min(Lq, Q_W) - 1, min(Lr, Q_W) - 1};
     int dlo[2] = {0, 0};                    // origins the D registers are aligned to
     int nlo[2] = {0, 0}, nhi[2] = {0, 0};
@@ -245,7 +234,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
             const int t = s * Q_K + r;
             const bool ract = t < Lt;
             const bool last = (r == Q_K - 1) || (t == Lt - 1);
-            const int tau = ZERO ? 0 : __builtin_amdgcn_ds_bpermute(trow + 4 * r, tkc.x);
+            const int tau = __builtin_amdgcn_ds_bpermute(trow + 4 * r, tkc.x);
             const int tky = __builtin_amdgcn_ds_bpermute(trow + 4 * r, tkc.y);
             const int vt = int(uint32_t(tky) >> 9);
             if (r == 0 && s == 0) {   // row 0, dist.cpp:300-305,397-405
@@ -253,15 +242,10 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
                 for (int p = 0; p < 2; p++) {
                     const bool valid = gl <= hi[p];
                     const bool ex = last ? ex_last[p] : ex_in[p];
-                    if (ZERO) {
-                        facc[p] = (valid && gl == 0) ? F_MAT : 0;
-                        exit_min = (ex && ract && gl == 0) ? 0 : exit_min;
-                    } else {
-                        facc[p] = valid ? ((gl == 0) ? F_MAT : F_INS) : 0;
-                        const int off0_ = kc[p].z - tau;
-                        const int lb0 = max((off0_ < 0 ? -off0_ : off0_) - kc[p].w - vt, 0);
-                        exit_min = (ex && ract) ? min(exit_min, gl + lb0) : exit_min;
-                    }
+                    facc[p] = valid ? ((gl == 0) ? F_MAT : F_INS) : 0;
+                    const int off0_ = kc[p].z - tau;
+                    const int lb0 = max((off0_ < 0 ? -off0_ : off0_) - kc[p].w - vt, 0);
+                    exit_min = (ex && ract) ? min(exit_min, gl + lb0) : exit_min;
                 }
                 continue;
             }
@@ -277,7 +261,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
                 const int o = 1 - p;
                 if (first) {
                     const int sh = lo[p] - dlo[p];
-                    up[p] = ZERO ? 0 : grp_get(gbase, gl + sh, Dp[p], D_INF);
+                    up[p] = grp_get(gbase, gl + sh, Dp[p], D_INF);
                     dg[p] = grp_get(gbase, gl + sh - 1, Dp[p], D_INF);
                 } else {
                     up[p] = Dp[p];
@@ -311,21 +295,6 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
                     }
                     swbits[p] = (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
                 }
-            }
-            if (ZERO) {
-#pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    const bool dz = match[p] & (dg[p] == 0), sz = sw[p] == 0;     // reached by MAT / by a swap
-                    const uint32_t f = (dz ? F_MAT : 0) | (sz ? (F_SWP | swbits[p]) : 0);
-                    const bool valid = lo[p] + gl <= hi[p];
-                    const bool reach = (dz | sz) & valid;
-                    facc[p] |= (ract && reach) ? (f << (8 * r)) : 0;
-                    const bool ex = last ? ex_last[p] : ex_in[p];
-                    exit_min = (ex && ract && reach) ? 0 : exit_min;
-                    Dp[p] = ract ? (reach ? 0 : D_INF) : Dp[p];
-                }
-                if (first) { dlo[0] = act ? lo[0] : dlo[0]; dlo[1] = act ? lo[1] : dlo[1]; }
-                continue;
             }
 #pragma unroll
             for (int p = 0; p < 2; p++) {
@@ -383,6 +352,201 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
         outs[a].dist_q = dq;
         outs[a].dist_r = dr;
         outs[a].exit_min = em;
+    }
+}
+
+// ===========================================================================
+// K1z: the zero-distance forward sweep, ballot formulation.  With D in {0, unreachable} a row of an alignment is 16 bits
+// per plane, so the reach state of the wave's four alignments is two wave-wide ballots held in scalar registers: a
+// lane reads its diagonal predecessor and its swap source as single bits of those masks (a shift by a per-lane
+// amount), and the new row is the next ballot.  No LDS permutes, no DPP, no loads inside the row loop: the truth row
+// constants of a stripe are one dword of tz (base | fwd_allow << 7 per row).  Same window, same exit test, same flag
+// bytes and the same outputs as k_fwd_q16<true>.
+// ===========================================================================
+__global__ void __launch_bounds__(64) k_fwd_z16(DevBatch B, const AlnDesc *__restrict__ descs,
+                                                const int32_t *__restrict__ work, int n_work,
+                                                uint8_t *__restrict__ ws, int32_t *__restrict__ blo_all,
+                                                AlnOut *__restrict__ outs, const int32_t *__restrict__ n_dev) {
+    if (n_dev) n_work = min(n_work, *n_dev);
+    if (int(blockIdx.x) * 4 >= n_work) return;
+    const int lane = threadIdx.x, gl = lane & 15, gbase = lane & 48;
+    const int wi = int(blockIdx.x) * 4 + (lane >> 4);
+    const int a_ = work[min(wi, n_work - 1)];
+    const bool live = wi < n_work && a_ >= 0;      // (-1: padding of a device-built work list)
+    const int a = max(a_, 0);
+    const AlnDesc *dp = descs + a;
+    const int Lq = dp->Lq, Lr = dp->Lr, Lt = live ? dp->Lt : 0;
+    const int qs = dp->qs, ts = dp->ts;
+    const int64_t q_off = dp->q_off, r_off = dp->r_off;
+    const int Lp[2] = {Lq, Lr};
+    const uint8_t *tz = (ts == 2 ? B.tz[0] : B.tz[1]) + dp->t_off;
+    const int2 *fk2[2] = {(qs == 0 ? B.fk_q[0] : B.fk_q[1]) + q_off, (qs == 0 ? B.fk_r[0] : B.fk_r[1]) + r_off};
+    uint32_t *mat = reinterpret_cast<uint32_t *>(ws + dp->mat_off[0]);
+    const int nstr = (Lt + Q_K - 1) / Q_K;
+    const int smax = wave_max4(nstr);
+
+    auto origin = [&](int s, int &oq, int &orr) {     // as in k_fwd_q16
+        const int2 *tk = (ts == 2 ? B.tk[0] : B.tk[1]) + dp->t_off;
+        const int32_t *r2q = (qs == 0 ? B.ref_ptr[0] : B.ref_ptr[1]) + r_off;
+        int2 *blo2 = reinterpret_cast<int2 *>(blo_all + dp->blo_off);
+        oq = 0; orr = 0;
+        if (s > 0 && s < nstr) {
+            const int ta = s * Q_K, tb = min(ta + Q_K - 1, Lt - 1);
+            const int ra = tk[ta].x, rb = tk[tb].x;
+            const int qa = r2q[min(max(ra, 0), Lr - 1)], qb = r2q[min(max(rb, 0), Lr - 1)];
+            orr = max(0, min((ra + rb) / 2 - Q_W / 2, Lr - min(Q_W, Lr)));
+            oq = max(0, min((qa + qb) / 2 - Q_W / 2, Lq - min(Q_W, Lq)));
+        }
+        if (s < nstr) blo2[s] = make_int2(oq, orr);    // read by K2 / K3
+    };
+    int cbQ, cbR, nbQ, nbR;
+    origin(gl, cbQ, cbR);
+    origin(16 + gl, nbQ, nbR);
+    // truth rows of a stripe: four bytes (unaligned dword; rows past the end are masked, the array is padded)
+    auto load_tz = [&](int s) -> uint32_t {
+        uint32_t w;
+        __builtin_memcpy(&w, tz + min(s, max(nstr - 1, 0)) * Q_K, 4);
+        return w;
+    };
+    uint32_t tzc = load_tz(0), tzn = 0;
+
+    // reach state: bit (gbase + j) = column j (relative to the origin the state is aligned to) of the group's alignment
+    unsigned long long RQ = __ballot(gl == 0), RR = RQ;     // row 0: the two start cells
+    uint32_t exitf = 0;
+    int lo[2] = {0, 0}, hi[2] = {min(Lq, Q_W) - 1, min(Lr, Q_W) - 1};
+    int dlo[2] = {0, 0};                    // origins the reach state is aligned to
+    int nlo[2] = {0, 0}, nhi[2] = {0, 0};
+    int2 kc[2], kn[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) kc[p] = fk2[p][min(gl, Lp[p] - 1)];
+
+    for (int s = 0; s < smax; s++) {
+        const bool act = s < nstr;
+        const bool has_next = s + 1 < nstr;
+        if (((s + 1) & 15) == 0) { nlo[0] = grp_get(gbase, 0, nbQ, 0); nlo[1] = grp_get(gbase, 0, nbR, 0); }
+        else { nlo[0] = grp_get(gbase, (s + 1) & 15, cbQ, 0); nlo[1] = grp_get(gbase, (s + 1) & 15, cbR, 0); }
+        if (!has_next) { nlo[0] = lo[0]; nlo[1] = lo[1]; }
+        nhi[0] = min(Lq - 1, nlo[0] + Q_W - 1);
+        nhi[1] = min(Lr - 1, nlo[1] + Q_W - 1);
+#pragma unroll
+        for (int p = 0; p < 2; p++) kn[p] = fk2[p][min(nlo[p] + gl, Lp[p] - 1)];
+        tzn = load_tz(s + 1);
+        // ---- per-lane constants of this stripe
+        int s0[2];
+        uint32_t base[2], vmask[2], swok[2], multi[2], ex_in[2], ex_last[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int o = 1 - p;
+            const int x = lo[p] + gl;
+            const bool valid = act & (x <= hi[p]);
+            s0[p] = (kc[p].x < 0) ? -1 : (kc[p].x & (FK_MULTI - 1));
+            swok[p] = kc[p].x >= 0;
+            multi[p] = (kc[p].x >= 0) & ((kc[p].x & FK_MULTI) != 0);
+            base[p] = valid ? (uint32_t(kc[p].y) >> 24) : 0xffu;
+            vmask[p] = valid;
+            const int z = kc[p].y & 0xffffff;                       // FK_NONE24 >= any string length
+            const bool zok = valid & (z < Lp[o]);
+            const bool ins_out = valid & (x == hi[p]) & (hi[p] < Lp[p] - 1);
+            const bool z_out = unsigned(z - lo[o]) > unsigned(hi[o] - lo[o]);
+            const bool z_out_n = unsigned(z - nlo[o]) > unsigned(nhi[o] - nlo[o]);
+            const bool x_out_n = (x < nlo[p]) | ((x + 1 < Lp[p]) & (x + 1 > nhi[p]));
+            ex_in[p] = ins_out | (zok & z_out);
+            ex_last[p] = ins_out | (has_next & ((valid & x_out_n) | (zok & z_out_n)));
+        }
+        uint32_t facc[2] = {0, 0};
+
+#pragma unroll
+        for (int r = 0; r < Q_K; r++) {
+            const int t = s * Q_K + r;
+            const uint32_t ract = t < Lt;
+            const bool last = (r == Q_K - 1) || (t == Lt - 1);
+            if (r == 0 && s == 0) {   // row 0, dist.cpp:300-305,397-405: the start cells, state unchanged
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const uint32_t ex = last ? ex_last[p] : ex_in[p];
+                    facc[p] = (vmask[p] & uint32_t(gl == 0)) ? F_MAT : 0;
+                    exitf |= ex & ract & uint32_t(gl == 0);
+                }
+                continue;
+            }
+            const uint32_t tzb = (tzc >> (8 * r)) & 0xff;
+            const uint32_t Tt = tzb & 0x7f, at = tzb >> 7;
+            const uint32_t G[2] = {uint32_t(RQ >> gbase) & 0xffffu, uint32_t(RR >> gbase) & 0xffffu};
+            uint32_t dz[2], sz[2], match[2], on[2], need_multi = 0;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int o = 1 - p;
+                // (the state is aligned to dlo: equal to lo except in the first row of a stripe)
+                const uint32_t dgbit = (G[p] >> min(unsigned(gl + lo[p] - dlo[p] - 1), 31u)) & 1u;
+                const uint32_t swbit = (G[o] >> min(unsigned(s0[p] - dlo[o]), 31u)) & 1u;
+                match[p] = base[p] == Tt;
+                on[p] = match[p] & at & swok[p];
+                dz[p] = match[p] & dgbit;
+                sz[p] = on[p] & swbit;
+                need_multi |= on[p] & multi[p];
+            }
+            uint32_t swbits[2] = {0, 0};
+            if (__builtin_expect(__any(need_multi), 0)) {
+                // rare: several allowed swap sources; the highest reachable index wins, ties are remembered
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const int o = 1 - p;
+                    const bool need = on[p] & multi[p];
+                    int4 cc = make_int4(-1, -1, -1, -1);
+                    if (need) {
+                        const int4 *cand = p == 0 ? (qs == 0 ? B.cand_q[0] : B.cand_q[1]) + q_off
+                                                  : (qs == 0 ? B.cand_r[0] : B.cand_r[1]) + r_off;
+                        cc = cand[lo[p] + gl];
+                    }
+                    const int srcs[3] = {cc.y, cc.z, cc.w};
+                    int sw = sz[p] ? 0 : D_INF, choice = 0;
+                    bool tie = false;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const uint32_t bit = (G[o] >> min(unsigned(srcs[k] - dlo[o]), 31u)) & 1u;
+                        const int val = (need && srcs[k] >= 0 && bit) ? 0 : D_INF;
+                        if (need && srcs[k] >= 0 && val <= sw) { tie = (val == sw); sw = val; choice = k + 1; }
+                    }
+                    sz[p] = (sw == 0);
+                    swbits[p] = (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
+                }
+            }
+            uint32_t nb[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const uint32_t reach = (dz[p] | sz[p]) & vmask[p];
+                const uint32_t f = (dz[p] ? F_MAT : 0) | (sz[p] ? (F_SWP | swbits[p]) : 0);
+                facc[p] |= (ract & reach) ? (f << (8 * r)) : 0;
+                const uint32_t ex = last ? ex_last[p] : ex_in[p];
+                exitf |= ex & ract & reach;
+                nb[p] = ract ? reach : ((G[p] >> gl) & 1u);
+            }
+            RQ = __ballot(nb[0] != 0);
+            RR = __ballot(nb[1] != 0);
+            if (r == 0) { dlo[0] = act ? lo[0] : dlo[0]; dlo[1] = act ? lo[1] : dlo[1]; }
+        }
+        if (act) {
+            mat[s * 32 + gl] = facc[0];
+            mat[s * 32 + 16 + gl] = facc[1];
+        }
+        if (has_next) {
+            lo[0] = nlo[0]; lo[1] = nlo[1]; hi[0] = nhi[0]; hi[1] = nhi[1];
+            kc[0] = kn[0]; kc[1] = kn[1];
+        }
+        tzc = tzn;
+        if (((s + 1) & 15) == 0) {
+            cbQ = nbQ; cbR = nbR;
+            origin(s + 1 + 16 + gl, nbQ, nbR);
+        }
+    }
+    const uint32_t gq = uint32_t(RQ >> gbase) & 0xffffu, gr = uint32_t(RR >> gbase) & 0xffffu;
+    const int dq = ((gq >> min(unsigned(Lq - 1 - dlo[0]), 31u)) & 1u) ? 0 : D_INF;
+    const int dr = ((gr >> min(unsigned(Lr - 1 - dlo[1]), 31u)) & 1u) ? 0 : D_INF;
+    const uint32_t eg = uint32_t(__ballot(exitf != 0) >> gbase) & 0xffffu;
+    if (live && gl == 15) {
+        outs[a].dist_q = dq;
+        outs[a].dist_r = dr;
+        outs[a].exit_min = eg ? 0 : D_INF;
     }
 }
 
