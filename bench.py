@@ -99,8 +99,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # VCFDIST_BENCH_ONE_GPU=1 (plumbing check on a one-GPU box only): every rank uses cuda:0 and the collective
+        # runs over gloo on host copies; the numbers of such a run mean nothing
+        if os.environ.get("VCFDIST_BENCH_ONE_GPU"):
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from vcfdist_amd import api, shard, summary, _abi as A
     if rank == 0:
@@ -129,7 +136,9 @@ def main():
         pr.execute()                    # K1..K5 on the device
         host_res[0] = res = pr.download(host_res[0])   # final results to (reused) host buffers
         t = torch.from_numpy(summary.pr_counts(pr, None, None)).to(dev)   # [2][4][3][61] int64, device histogram
-        if dist is not None:
+        if dist is not None and dist.get_backend() == "gloo":
+            tc = t.cpu(); dist.all_reduce(tc); t = tc.to(dev)
+        elif dist is not None:
             dist.all_reduce(t)          # the one collective of the path: the precision/recall counters (int64 sum)
         return res, t
 
@@ -160,7 +169,7 @@ def main():
         pb, sw, fl = summary.phase(res.sc_phase, np.ones(batch.n_sc, np.int32))
         rows = summary.pr_summary(summary.pr_counts(pr, None, pb))
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
