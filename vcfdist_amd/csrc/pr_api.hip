@@ -920,7 +920,7 @@ int vpr_execute(vpr_handle *h) {
         if (q16) {
             // 16-cell layout: row-sweep walk, four alignments per wave (phase A) + credit walk (phase B)
             rc = timed(3, ws_, ks, "k_walk_q16", [&] {
-                hipLaunchKernelGGL(k_walk_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                hipLaunchKernelGGL(zero ? k_walk_q16<true> : k_walk_q16<false>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, a_path, tag, dtag, n_dev);
             });
             if (rc) return rc;

@@ -656,11 +656,19 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
             int best[2], lk[2], f0[2];
             uint32_t bm[2];
             MP g[2];
+            // ZERO: score and forward flags of row t+1 cross lanes as one dword (score << 8 | flags, score -1 =
+            // not on a path to the end); there are no DEL edges at distance 0
+            const int pkv[2] = {((sc1[0] < 0 ? -1 : sc1[0]) << 8) | f1[0], ((sc1[1] < 0 ? -1 : sc1[1]) << 8) | f1[1]};
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 const int o = 1 - p;
                 int up_s, up_f, dn_s, dn_f;
-                if (first) {
+                if (ZERO) {
+                    const int u = first ? grp_get(gbase, gl + sh[p] - 1, pkv[p], -256) : row_shr1(pkv[p], -256);
+                    up_s = (u < 0) ? S_NEG : (u >> 8);
+                    up_f = u & 0xff;
+                    dn_s = S_NEG; dn_f = 0;
+                } else if (first) {
                     up_s = grp_get(gbase, gl + sh[p] - 1, sc1[p], S_NEG);
                     up_f = grp_get(gbase, gl + sh[p] - 1, f1[p], 0);
                     dn_s = grp_get(gbase, gl + sh[p], sc1[p], S_NEG);
@@ -680,8 +688,15 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
                 // swap successor z = (other plane, zl, t+1): its lane in the alignment of row t+1
                 const int olo = (first && s != nstr - 1) ? plo[o] : lo[o];
                 const int zsrc = (zl[p] == int(FK_NONE24)) ? -1 : 15 - (zl[p] - olo);
-                const int zf = grp_get(gbase, zsrc, f1[o], 0);
-                const int zs = grp_get(gbase, zsrc, sc1[o], S_NEG);
+                int zf, zs;
+                if (ZERO) {
+                    const int zz = grp_get(gbase, zsrc, pkv[o], -256);
+                    zf = zz & 0xff;
+                    zs = (zz < 0) ? S_NEG : (zz >> 8);
+                } else {
+                    zf = grp_get(gbase, zsrc, f1[o], 0);
+                    zs = grp_get(gbase, zsrc, sc1[o], S_NEG);
+                }
                 if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((bkc[p] >> 25) & 3)) {
                     const int v = zs + ((bkc[p] >> 27) & 1);
                     if (v >= 0 && (zf & F_TIE)) tie_used = 1;
@@ -743,6 +758,7 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
 // it - a ballot over the row, a count-trailing-ones, the lanes of the run store their path entries side by
 // side, and one cross-lane read of the run's last cell decides the move into row t+1.
 // ===========================================================================
+template <bool ZERO>
 __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__restrict__ descs,
                                                  const int32_t *__restrict__ work, int n_work,
                                                  const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
@@ -778,17 +794,23 @@ __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__re
     int cbQ, cbR, nbQ, nbR;
     load_chunk(0, cbQ, cbR);
     load_chunk(16, nbQ, nbR);
+    // ZERO (the walk behind the zero-distance sweeps: path_ptr bytes hold MAT / SWP only, so a row is its entry cell
+    // and nothing else): pointer and flags of a row / column travel as one dword (pointer in the low 24 bits, PTR_* flags
+    // in bits 24-27, the ins4 bits in 28-31) and a row costs three cross-lane reads instead of eight and a ballot
+    auto pack = [](int2 v) -> int2 { return ZERO ? make_int2((v.x & 0xffffff) | ((v.y & 15) << 24) | (((v.y >> 8) & 15) << 28), 0) : v; };
+    auto unpack_x = [](int v) -> int { return (v << 8) >> 8; };
+    auto unpack_y = [](int v) -> int { return ((v >> 24) & 15) | (((v >> 28) & 15) << 8); };
     int2 wtc = make_int2(0, 0), wtn = make_int2(0, 0);   // truth-row constants of rows (t & ~15) + gl / the next 16
-    if (gl < Lt) wtc = wt[gl];
-    if (16 + gl < Lt) wtn = wt[16 + gl];
+    if (gl < Lt) wtc = pack(wt[gl]);
+    if (16 + gl < Lt) wtn = pack(wt[16 + gl]);
     // per-stripe data of this lane's column (prefetched one stripe ahead): path_ptr dwords and column constants
     int lo[2] = {0, 0};
     uint32_t pp[2] = {0, 0}, ppn[2] = {0, 0};
     int2 cq = make_int2(0, 0), cr = make_int2(0, 0), cqn, crn;
     if (nstr > 0) {
         pp[0] = mat[gl]; pp[1] = mat[16 + gl];
-        if (gl < Lq) cq = wq[gl];
-        if (gl < Lr) cr = wr[gl];
+        if (gl < Lq) cq = pack(wq[gl]);
+        if (gl < Lr) cr = pack(wr[gl]);
     }
 
     int hi = outs[a].beg_plane, e = 0, n = 0, mv_in = 0;   // plane / column of the entry cell of the current row
@@ -803,14 +825,14 @@ __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__re
         ppn[0] = 0; ppn[1] = 0; cqn = make_int2(0, 0); crn = make_int2(0, 0);
         if (s + 1 < nstr) {
             ppn[0] = mat[(s + 1) * 32 + gl]; ppn[1] = mat[(s + 1) * 32 + 16 + gl];
-            if (nlo[0] + gl < Lq) cqn = wq[nlo[0] + gl];
-            if (nlo[1] + gl < Lr) crn = wr[nlo[1] + gl];
+            if (nlo[0] + gl < Lq) cqn = pack(wq[nlo[0] + gl]);
+            if (nlo[1] + gl < Lr) crn = pack(wr[nlo[1] + gl]);
         }
         if ((s & 3) == 0 && s > 0) {
             wtc = wtn;
             wtn = make_int2(0, 0);
             const int tt = s * Q_K + 16 + gl;
-            if (tt < Lt) wtn = wt[tt];
+            if (tt < Lt) wtn = pack(wt[tt]);
         }
         const int trow = (gbase | ((s & 3) * Q_K)) << 2;
 
@@ -818,17 +840,25 @@ __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__re
         for (int r = 0; r < Q_K; r++) {
             const int t = s * Q_K + r;
             bool ract = ok && t < Lt;
-            const int trv = __builtin_amdgcn_ds_bpermute(trow + 4 * r, wtc.x);
-            const int twy = __builtin_amdgcn_ds_bpermute(trow + 4 * r, wtc.y);
+            int trv, twy, ex, ey;
             const int lo_h = hi ? lo[1] : lo[0];
             const int Lh = hi ? Lr : Lq;
-            const int colx = hi ? cr.x : cq.x;          // r2q / q2r of this lane's column in the walk's plane
-            const int coly = hi ? cr.y : cq.y;          // flags | ins4 << 8 (REF plane: no flags)
             const int el = e - lo_h;
             if (ract && (el < 0 || el > 15 || e >= Lh)) { status |= VPR_ST_ERR_NO_PTR; ok = false; ract = false; }
+            const int colx = hi ? cr.x : cq.x;          // r2q / q2r of this lane's column in the walk's plane
+            if (ZERO) {
+                const int tp_ = __builtin_amdgcn_ds_bpermute(trow + 4 * r, wtc.x);
+                const int cp_ = grp_get(gbase, el, colx, 0);
+                trv = unpack_x(tp_); twy = unpack_y(tp_);
+                ex = unpack_x(cp_); ey = unpack_y(cp_);
+            } else {
+                trv = __builtin_amdgcn_ds_bpermute(trow + 4 * r, wtc.x);
+                twy = __builtin_amdgcn_ds_bpermute(trow + 4 * r, wtc.y);
+                const int coly = hi ? cr.y : cq.y;          // flags | ins4 << 8 (REF plane: no flags)
+                ex = grp_get(gbase, el, colx, 0);
+                ey = grp_get(gbase, el, coly, 0);
+            }
             // sync flag of the entry cell, dist.cpp:949-968 (only a diagonal move can make a sync point)
-            const int ex = grp_get(gbase, el, colx, 0);
-            const int ey = grp_get(gbase, el, coly, 0);
             uint32_t sync_in = 1;
             if (mv_in != 0) {
                 const int qr = hi ? e : ex;
@@ -838,26 +868,29 @@ __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__re
             }
             // the run of INS-only cells that starts at the entry cell
             const int pc = int(((hi ? pp[1] : pp[0]) >> (8 * r)) & 0xff);
-            const bool ins_only = (pc & F_INS) && !(pc & (F_MAT | F_SUB)) && !(hi == 1 && (pc & F_SWP));
-            const unsigned long long bal = __ballot(ins_only);
-            const uint32_t m16 = (uint32_t(bal >> gbase) & 0xffffu) >> (el & 15);
-            const int k = __builtin_ctz(~m16);                   // bits 16.. of ~m16 are ones: k <= 16
+            int k = 0;
+            if (!ZERO) {
+                const bool ins_only = (pc & F_INS) && !(pc & (F_MAT | F_SUB)) && !(hi == 1 && (pc & F_SWP));
+                const unsigned long long bal = __ballot(ins_only);
+                const uint32_t m16 = (uint32_t(bal >> gbase) & 0xffffu) >> (el & 15);
+                k = __builtin_ctz(~m16);                         // bits 16.. of ~m16 are ones: k <= 16
+            }
             const int c = e + k;                                 // last cell visited in this row
-            if (ract && (c - lo_h > 15 || c >= Lh)) { status |= VPR_ST_ERR_NO_PTR; ok = false; ract = false; }
+            if (!ZERO && ract && (c - lo_h > 15 || c >= Lh)) { status |= VPR_ST_ERR_NO_PTR; ok = false; ract = false; }
             if (ract && n + k + 1 > path_cap) { status |= VPR_ST_ERR_LIMIT; ok = false; ract = false; }
             if (ract && gl >= el && gl <= el + k) {
                 const int x = lo_h + gl;
                 PathEnt pe;
                 pe.a = uint32_t(x) | (uint32_t(hi) << 31);
                 pe.b = uint32_t(t) | ((gl == el) ? ((sync_in << 31) | (edit_in << 30)) : (1u << 30));
-                pe.qref = hi ? x : colx;
+                pe.qref = hi ? x : (ZERO ? ex : colx);
                 pe.tref = trv;
                 path[n + (gl - el)] = pe;
             }
             // move out of the row from cell c, by priority
             const int cl = c - lo_h;
             const int p = grp_get(gbase, cl, pc, 0) & 31;
-            const int cxv = grp_get(gbase, cl, colx, 0);
+            const int cxv = ZERO ? ex : grp_get(gbase, cl, colx, 0);
             if (ract) {
                 n += k + 1;
                 if (t == Lt - 1) {                               // the walk ends at the end cell of its plane
