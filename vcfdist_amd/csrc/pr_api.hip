@@ -77,6 +77,7 @@ struct LadderCtx {
     uint8_t *arena = nullptr; int64_t arena_bytes = 0;
     AlnDesc *d_descs = nullptr; size_t descs_cap = 0;   // staging of the plans in flight
     int32_t *d_work = nullptr; size_t work_cap = 0;
+    AlnDesc *hp_descs = nullptr; int32_t *hp_work = nullptr; size_t hp_cap = 0;   // host-pinned source of k_stage
     int slot_cur = 0; int64_t fail_cur = 0, arena_cur = 0; size_t stage_cur = 0;
     std::vector<std::pair<int, int64_t>> pending;       // (slot, fail list offset) of the launches in flight
     std::vector<Plan> plans;
@@ -118,6 +119,10 @@ struct vpr_handle {
     EdJob *d_jobs = nullptr; int32_t jobs_cap = 0; int32_t *d_njobs = nullptr;
     uint32_t *d_err = nullptr;
     int32_t *d_ok = nullptr, *d_fail = nullptr, *d_cnt = nullptr;   // partition lists + 2 counters
+    // host-pinned, device-visible mirrors of d_fail / d_cnt: a publish kernel on the producing stream fills them, so the
+    // host reads a fail list after an event wait and issues no copy that the bulk kernels of the round could starve
+    int32_t *hp_fail = nullptr, *hp_cnt = nullptr;
+    std::vector<void *> pinned;
     AlnDesc *d_tmp_descs = nullptr; size_t tmp_descs_cap = 0;
     int32_t *d_tmp_work = nullptr; size_t tmp_work_cap = 0;
     int32_t *d_ed_scratch = nullptr; size_t ed_scratch_ints = 0;
@@ -173,6 +178,9 @@ int dev_upload(vpr_handle *h, const T **dst, const T *src, size_t n) {
 void free_batch(vpr_handle *h) {
     for (void *p : h->allocs) (void)hipFree(p);
     h->allocs.clear();
+    for (void *p : h->pinned) (void)hipHostFree(p);
+    h->pinned.clear();
+    h->hp_fail = nullptr; h->hp_cnt = nullptr;
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     h->events.clear();
     h->descs.clear();
@@ -272,6 +280,29 @@ __global__ void k_collect_fails(const int32_t *__restrict__ work, int n, const A
     base = __shfl(base, 0);
     if (bad) fail_list[base + __popcll(mbad & ((1ull << lane) - 1ull))] = a;
     if (lane < nres - npop) fail_list[base + npop + lane] = -1;
+}
+
+// Mirror a fail list and its length into host-pinned memory (launched on the stream that produced them, right behind
+// k_collect_fails, so it is never queued behind another stream's bulk kernel).
+__global__ void k_publish_fails(const int32_t *__restrict__ list, const int32_t *__restrict__ cnt, int32_t *__restrict__ h_list,
+                                int32_t *__restrict__ h_cnt, int copy_list) {
+    const int n = *cnt;
+    if (copy_list)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) h_list[i] = list[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *h_cnt = n;
+    __threadfence_system();
+}
+
+// Stage a retry plan from host-pinned memory in one launch: descriptors scattered to their alignment's slot, the work
+// list copied, the ladder's fail counters cleared (n_zero > 0 on the first plan of a round).
+__global__ void k_stage(const AlnDesc *__restrict__ src, const int32_t *__restrict__ src_work, int n, AlnDesc *__restrict__ dst,
+                        int32_t *__restrict__ dst_work, int32_t *__restrict__ zero, int n_zero) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_zero) zero[i] = 0;
+    if (i >= n) return;
+    const AlnDesc d = src[i];
+    dst[d.sc * 4 + d.aln] = d;
+    dst_work[i] = src_work[i];
 }
 
 __global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc *__restrict__ dst) {
@@ -647,6 +678,16 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     // fail lists: round 0 in [0, na + na/16 + 256) (a list that feeds a kernel directly is padded), retry rounds behind
     if ((rc = dev_alloc(h, &h->d_fail, 2 * na + na / 16 + 512))) return rc;
     if ((rc = dev_alloc(h, &h->d_cnt, 2 + 2 * LadderCtx::N_SLOTS))) return rc;
+    {
+        void *pf = nullptr, *pc = nullptr;
+        HIPCHK(h, hipHostMalloc(&pf, (2 * na + na / 16 + 512) * sizeof(int32_t), hipHostMallocDefault));
+        h->pinned.push_back(pf);
+        HIPCHK(h, hipHostMalloc(&pc, (2 + 2 * LadderCtx::N_SLOTS) * sizeof(int32_t), hipHostMallocDefault));
+        h->pinned.push_back(pc);
+        h->hp_fail = static_cast<int32_t *>(pf);
+        h->hp_cnt = static_cast<int32_t *>(pc);
+        memset(h->hp_cnt, 0, (2 + 2 * LadderCtx::N_SLOTS) * sizeof(int32_t));
+    }
 
     lap("result/aux allocations");
     // ---- arena for flag matrices, band origins and walks
@@ -891,6 +932,9 @@ int vpr_execute(vpr_handle *h) {
             const int32_t nc = n_dev ? n_all : cnt;
             hipLaunchKernelGGL(k_collect_fails, dim3((nc + 255) / 256), dim3(256), 0, ks, list, nc, h->d_outs,
                                h->d_fail + fail_off, h->d_cnt + slot, zero ? 1 : 0, n_dev);
+            // (the zero-distance level's list is consumed on the device, in place: the host only wants its length)
+            hipLaunchKernelGGL(k_publish_fails, dim3(zero ? 1 : std::min((nc + 255) / 256, 1024)), dim3(256), 0, ks,
+                               h->d_fail + fail_off, h->d_cnt + slot, h->hp_fail + fail_off, h->hp_cnt + slot, zero ? 0 : 1);
         }
         HIPCHK(h, hipEventRecord(h->ev_slot[slot], ks));
         }
@@ -957,15 +1001,11 @@ int vpr_execute(vpr_handle *h) {
 
     // read a fail slot once its list is complete (copies ride on stream `ls`, never the null stream)
     auto read_fails = [&](int slot, int64_t fail_off, hipStream_t ls, std::vector<int32_t> &fails) -> int {
-        int32_t nf = 0;
-        HIPCHK(h, hipStreamWaitEvent(ls, h->ev_slot[slot], 0));
-        HIPCHK(h, hipMemcpyAsync(&nf, h->d_cnt + slot, 4, hipMemcpyDeviceToHost, ls));
-        HIPCHK(h, hipStreamSynchronize(ls));
+        HIPCHK(h, hipEventSynchronize(h->ev_slot[slot]));      // the list and its length are in pinned host memory by then
+        const int32_t nf = h->hp_cnt[slot];
         if (nf > 0) {
             const size_t f0 = fails.size();
-            fails.resize(f0 + size_t(nf));
-            HIPCHK(h, hipMemcpyAsync(fails.data() + f0, h->d_fail + fail_off, size_t(nf) * 4, hipMemcpyDeviceToHost, ls));
-            HIPCHK(h, hipStreamSynchronize(ls));
+            fails.insert(fails.end(), h->hp_fail + fail_off, h->hp_fail + fail_off + nf);
             if (getenv("VPR_DEBUG") && nf <= 64) {
                 for (size_t k = f0; k < fails.size(); k++) {
                     const int32_t a = fails[k];
@@ -1015,7 +1055,16 @@ int vpr_execute(vpr_handle *h) {
             if (rc) return rc;
             c.work_cap = nf * 2;
         }
-        HIPCHK(h, hipMemsetAsync(h->d_cnt + c.slot0, 0, LadderCtx::N_SLOTS * 4, c.ls));
+        if (c.hp_cap < nf) {
+            void *pd = nullptr, *pw = nullptr;
+            HIPCHK(h, hipStreamSynchronize(c.ls));           // (nothing may still read the old staging block)
+            HIPCHK(h, hipHostMalloc(&pd, nf * 2 * sizeof(AlnDesc), hipHostMallocDefault));
+            h->pinned.push_back(pd);
+            HIPCHK(h, hipHostMalloc(&pw, nf * 2 * sizeof(int32_t), hipHostMallocDefault));
+            h->pinned.push_back(pw);
+            c.hp_descs = static_cast<AlnDesc *>(pd); c.hp_work = static_cast<int32_t *>(pw); c.hp_cap = nf * 2;
+        }
+        bool zero_slots = true;
         for (int lv = LV_Q16; lv <= LV_DENSE; lv++) {
             if (by_lv[lv].empty()) continue;
             c.plans.emplace_back();
@@ -1045,9 +1094,13 @@ int vpr_execute(vpr_handle *h) {
             AlnDesc *dd = c.d_descs + c.stage_cur;
             int32_t *dw = c.d_work + c.stage_cur;
             c.stage_cur += n;
-            HIPCHK(h, hipMemcpyAsync(dd, P.descs.data(), n * sizeof(AlnDesc), hipMemcpyHostToDevice, c.ls));
-            HIPCHK(h, hipMemcpyAsync(dw, P.work.data(), n * 4, hipMemcpyHostToDevice, c.ls));
-            hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(n)), dim3(256), 0, c.ls, dd, int(n), h->d_descs);
+            (void)dd;
+            memcpy(c.hp_descs + (c.stage_cur - n), P.descs.data(), n * sizeof(AlnDesc));
+            memcpy(c.hp_work + (c.stage_cur - n), P.work.data(), n * 4);
+            hipLaunchKernelGGL(k_stage, blocks(int64_t(std::max<size_t>(n, LadderCtx::N_SLOTS))), dim3(256), 0, c.ls,
+                               c.hp_descs + (c.stage_cur - n), c.hp_work + (c.stage_cur - n), int(n), h->d_descs, dw,
+                               h->d_cnt + c.slot0, zero_slots ? LadderCtx::N_SLOTS : 0);
+            zero_slots = false;
             h->dirty.insert(h->dirty.end(), P.work.begin(), P.work.end());
             if (lv == LV_DENSE) {
                 if ((rc = run_dense(P, dw, c.ls, true))) return rc;
@@ -1159,9 +1212,7 @@ int vpr_execute(vpr_handle *h) {
                 if (inplace) {
                     if ((rc = read_fails(SLOT_IP, foff_ip, LS.ls, fails))) return rc;
                     for (int32_t a : fails) h->level[size_t(a)] = uint8_t(LV_Q16);
-                    int32_t nz = 0;
-                    HIPCHK(h, hipMemcpyAsync(&nz, h->d_cnt + 1, 4, hipMemcpyDeviceToHost, LS.ls));
-                    HIPCHK(h, hipStreamSynchronize(LS.ls));
+                    const int32_t nz = h->hp_cnt[1];   // (published before the in-place round's own list, same stream)
                     n_retry += nz;   // rejected by the zero-distance sweep (the count includes the list's -1 padding)
                 } else {
                     if ((rc = read_fails(1, n_long, LS.ls, fails))) return rc;
