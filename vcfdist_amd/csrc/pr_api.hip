@@ -1255,8 +1255,26 @@ int vpr_execute(vpr_handle *h) {
     if (n_jobs > 0) {
         std::vector<EdJob> jobs(n_jobs);
         HIPCHK(h, hipMemcpy(jobs.data(), h->d_jobs, size_t(n_jobs) * sizeof(EdJob), hipMemcpyDeviceToHost));
-        int64_t stride = 0;
-        for (const EdJob &j : jobs) stride = std::max<int64_t>(stride, std::max(j.ref_len, j.tru_len) + 1);
+        int64_t stride = 0, max_short = 0, max_sum = 0;
+        for (const EdJob &j : jobs) {
+            stride = std::max<int64_t>(stride, std::max(j.ref_len, j.tru_len) + 1);
+            max_short = std::max<int64_t>(max_short, std::min(j.ref_len, j.tru_len));
+            max_sum = std::max<int64_t>(max_sum, int64_t(j.ref_len) + j.tru_len);
+        }
+        // anti-diagonal kernel when the largest section fits LDS and 16-bit distances (VPR_ED_ROWS: the row-sweep one)
+        const int64_t pitch = (max_short + 2 + 7) & ~int64_t(7);
+        const size_t lds_diag = size_t(3 * pitch * 2 + max_sum + 16);
+        if (lds_diag <= 150 * 1024 && max_sum < 65000 && !getenv("VPR_ED_ROWS")) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ed_diag), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_diag));
+            vpr_launch_stat es_;
+            memset(&es_, 0, sizeof(es_));
+            es_.threads = ED_NT; es_.n_units = n_jobs;
+            rc = timed(4, es_, st, "k_ed_diag", [&] {
+                hipLaunchKernelGGL(k_ed_diag, dim3(n_jobs), dim3(ED_NT), lds_diag, st, h->dB, h->d_descs, h->d_jobs, n_jobs,
+                                   h->d_secs, int(max_short));
+            });
+            if (rc) return rc;
+        } else {
         stride = round_up(stride, 16);
         const int64_t max_ints = int64_t(1) << 28;   // 1 GiB of scratch per slice
         const int32_t per = int32_t(std::max<int64_t>(1, std::min<int64_t>(n_jobs, max_ints / stride)));
@@ -1276,6 +1294,7 @@ int vpr_execute(vpr_handle *h) {
                                    h->d_secs, h->d_ed_scratch, stride);
             });
             if (rc) return rc;
+        }
         }
     }
     // K5: per-variant results, phase, tally

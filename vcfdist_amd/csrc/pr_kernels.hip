@@ -1067,6 +1067,62 @@ __global__ void k_phase_tally(const AlnDesc *__restrict__ descs, int n_sc, DevRe
 // K4: edit distance of deferred sections; one wave per section, row sweep over
 // the shorter string with lanes over the longer one (same scan as K1, one plane).
 // ---------------------------------------------------------------------------
+// K4d: the same edit distance swept by ANTI-DIAGONALS, one workgroup per deferred section.  The cells of an
+// anti-diagonal are independent (no in-row scan), three diagonals of 16-bit distances and both strings live in LDS,
+// and a step costs one barrier: the longest section of a batch (its two strings are thousands of bases when a
+// supercluster holds an SV-sized indel) is a chain of nx + ny cheap steps instead of ny rows of nx / 64 scanned tiles.
+// LDS: 3 * (ny + 1) uint16 + nx + ny bytes (dynamic); the host falls back to k_ed when that does not fit.
+#define ED_NT 256
+__global__ void __launch_bounds__(ED_NT) k_ed_diag(DevBatch B, const AlnDesc *__restrict__ descs,
+                                                   const EdJob *__restrict__ jobs, int n_jobs, Section *__restrict__ secs,
+                                                   int max_short) {
+    extern __shared__ __align__(16) uint8_t ed_lds[];
+    const int j = blockIdx.x;
+    if (j >= n_jobs) return;
+    const EdJob J = jobs[j];
+    const AlnDesc d = descs[J.aln];
+    const uint8_t *Rs = B.ref_seq + d.r_off + J.ref_beg;
+    const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off + J.tru_beg;
+    // X = longer string (x = 0..nx), Y = shorter (y = 0..ny); a diagonal is indexed by y
+    const uint8_t *X = Rs, *Y = Ts;
+    int nx = J.ref_len, ny = J.tru_len;
+    if (nx < ny) { X = Ts; Y = Rs; const int tmp = nx; nx = ny; ny = tmp; }
+    const int pitch = (max_short + 2 + 7) & ~7;
+    uint16_t *dg = reinterpret_cast<uint16_t *>(ed_lds);          // [3][pitch]
+    uint8_t *sx = ed_lds + size_t(3) * pitch * 2;                 // X then Y
+    uint8_t *sy = sx + nx;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nx; i += ED_NT) sx[i] = X[i];
+    for (int i = tid; i < ny; i += ED_NT) sy[i] = Y[i];
+    if (tid == 0) dg[0] = 0;                                      // diagonal 0: the cell (0, 0)
+    __syncthreads();
+    // diagonal k holds the cells (x = k - y, y) for y in [max(0, k - nx), min(ny, k)], stored at index y
+    for (int k = 1; k <= nx + ny; k++) {
+        uint16_t *cur = dg + (k % 3) * pitch;
+        const uint16_t *p1 = dg + ((k + 2) % 3) * pitch, *p2 = dg + ((k + 1) % 3) * pitch;   // diagonals k-1, k-2
+        const int ylo = max(0, k - nx), yhi = min(ny, k);
+        for (int y = ylo + tid; y <= yhi; y += ED_NT) {
+            const int x = k - y;
+            int v;
+            if (y == 0) v = x;
+            else if (x == 0) v = y;
+            else {
+                const int left = p1[y] + 1;            // (x-1, y)   on diagonal k-1
+                const int up = p1[y - 1] + 1;          // (x, y-1)   on diagonal k-1
+                const int di = p2[y - 1] + (sx[x - 1] != sy[y - 1]);   // (x-1, y-1) on diagonal k-2
+                v = min(min(left, up), di);
+            }
+            cur[y] = uint16_t(v);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        Section &S = secs[d.sec_off + J.sec];
+        S.ref_ed = dg[((nx + ny) % 3) * pitch + ny];
+        S.flags &= ~SEC_DEFERRED;
+    }
+}
+
 __global__ void __launch_bounds__(64) k_ed(DevBatch B, const AlnDesc *__restrict__ descs,
                                            const EdJob *__restrict__ jobs, int n_jobs,
                                            Section *__restrict__ secs, int32_t *__restrict__ scratch,
