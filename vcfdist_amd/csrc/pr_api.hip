@@ -258,8 +258,8 @@ BandBwd band_bwd_kernel(int lv) {
 
 int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-// Append the alignments whose window was rejected to the round's fail list (wave-aggregated: one atomic
-// per wave; 800 k contended single-word atomics would cost more than the forward sweep itself).
+// Append the alignments whose window was rejected to the round's fail list (aggregated per workgroup of 256:
+// contended single-word atomics would cost more than the forward sweep itself).
 __global__ void k_collect_fails(const int32_t *__restrict__ work, int n, const AlnOut *__restrict__ outs,
                                 int32_t *__restrict__ fail_list, int32_t *__restrict__ cnt, int pad4,
                                 const int32_t *__restrict__ n_dev) {
@@ -269,15 +269,22 @@ __global__ void k_collect_fails(const int32_t *__restrict__ work, int n, const A
     const int a = live ? work[i] : -1;
     const bool bad = live && a >= 0 && !outs[a].band_ok;
     const unsigned long long mbad = __ballot(bad);
-    if (!mbad) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // pad4: the list feeds a four-alignments-per-wave kernel directly.  A wave's rejected ids are consecutive in
     // the (row-count sorted) work list, so they are kept together and padded with -1 to a multiple of four:
     // groups of four then never mix alignments of very different lengths.
     const int npop = __popcll(mbad), nres = pad4 ? ((npop + 3) & ~3) : npop;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(cnt, nres);
-    base = __shfl(base, 0);
+    // one atomic per workgroup (a single contended counter serialises in L2: ~10 ns each)
+    __shared__ int wcnt[4], wbase;
+    if (lane == 0) wcnt[wave] = nres;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        wbase = tot ? atomicAdd(cnt, tot) : 0;
+    }
+    __syncthreads();
+    int base = wbase;
+    for (int w = 0; w < wave; w++) base += wcnt[w];
     if (bad) fail_list[base + __popcll(mbad & ((1ull << lane) - 1ull))] = a;
     if (lane < nres - npop) fail_list[base + npop + lane] = -1;
 }
