@@ -1,6 +1,9 @@
-"""Differential fuzzing of the HIP path against the CPU oracle (test infrastructure, not collected by pytest):
-random workload shapes and seeds, every result array compared bit for bit with tests/test_gpu_parity.compare.
-usage: python tests/fuzz_parity.py [seconds] [first_seed]"""
+"""Differential fuzzing of the HIP path against the CPU oracle (test infrastructure): random workload shapes and
+seeds, every result array compared bit for bit with tests/test_gpu_parity.compare.
+
+    python tests/fuzz_parity.py [seconds] [first_seed]      # long runs, by hand on the GPU box
+
+tests/test_gpu_parity.py::test_fuzz_smoke runs a few seconds of it inside the GPU suite."""
 import os
 import sys
 import time
@@ -9,49 +12,67 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import test_gpu_parity as T          # noqa: E402
-from vcfdist_amd import _abi as A, api   # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-t_end = time.time() + budget
-n_run = n_sc = n_tie = 0
-seed = seed0
-while time.time() < t_end:
+
+def random_workload(seed):
+    """-> (Synth keyword arguments, band_mode) of one random batch"""
     rng = np.random.default_rng(seed)
-    shape = rng.integers(0, 6)
+    shape = int(rng.integers(0, 6))
     if shape == 0:      # WGS-like log-normal spans
-        kw = dict(n_sc=int(rng.integers(2000, 12000)), len_mode=1, len_a=float(rng.uniform(8, 40)), len_b=float(rng.uniform(0.8, 1.5)),
-                  len_min=4, len_max=int(rng.integers(200, 4000)))
+        kw = dict(n_sc=int(rng.integers(2000, 12000)), len_mode=1, len_a=float(rng.uniform(8, 40)),
+                  len_b=float(rng.uniform(0.8, 1.5)), len_min=4, len_max=int(rng.integers(200, 4000)))
     elif shape == 1:    # tiny, repeat-rich, indel-heavy
-        kw = dict(n_sc=int(rng.integers(500, 4000)), len_a=5, len_b=int(rng.integers(20, 120)), len_min=5, len_max=int(rng.integers(20, 120)),
-                  var_per_base=float(rng.uniform(0.02, 0.2)), p_snp=float(rng.uniform(0.1, 0.9)), p_repeat=float(rng.uniform(0.2, 1.0)))
-        kw["len_b"] = kw["len_max"]
+        hi = int(rng.integers(20, 120))
+        kw = dict(n_sc=int(rng.integers(500, 4000)), len_a=5, len_b=hi, len_min=5, len_max=hi,
+                  var_per_base=float(rng.uniform(0.02, 0.2)), p_snp=float(rng.uniform(0.1, 0.9)),
+                  p_repeat=float(rng.uniform(0.2, 1.0)))
     elif shape == 2:    # mid sizes (64 / 256 cell windows)
-        lo = int(rng.integers(60, 400)); hi = lo + int(rng.integers(10, 1500))
-        kw = dict(n_sc=int(rng.integers(40, 400)), len_a=lo, len_b=hi, len_min=lo, len_max=hi, var_per_base=float(rng.uniform(0.003, 0.05)),
-                  p_repeat=float(rng.uniform(0.0, 0.6)))
-    elif shape == 3:    # long alignments (latency chains, wide windows, dense fallback)
-        lo = int(rng.integers(1500, 4000)); hi = lo + int(rng.integers(10, 3000))
-        kw = dict(n_sc=int(rng.integers(4, 20)), len_a=lo, len_b=hi, len_min=lo, len_max=hi, var_per_base=float(rng.uniform(0.002, 0.02)),
-                  indel_mean=float(rng.uniform(2, 30)))
+        lo = int(rng.integers(60, 400))
+        hi = lo + int(rng.integers(10, 1500))
+        kw = dict(n_sc=int(rng.integers(40, 400)), len_a=lo, len_b=hi, len_min=lo, len_max=hi,
+                  var_per_base=float(rng.uniform(0.003, 0.05)), p_repeat=float(rng.uniform(0.0, 0.6)))
+    elif shape == 3:    # long alignments (latency chains, wide windows, dense fallback, deferred edit distances)
+        lo = int(rng.integers(1500, 4000))
+        hi = lo + int(rng.integers(10, 3000))
+        kw = dict(n_sc=int(rng.integers(4, 20)), len_a=lo, len_b=hi, len_min=lo, len_max=hi,
+                  var_per_base=float(rng.uniform(0.002, 0.02)), indel_mean=float(rng.uniform(2, 30)))
     elif shape == 4:    # mostly identical haplotypes (zero-distance level) with long indels
-        kw = dict(n_sc=int(rng.integers(1000, 8000)), len_a=10, len_b=300, len_min=10, len_max=300, p_keep=float(rng.uniform(0.9, 1.0)),
-                  p_drop=0.0, p_hom=float(rng.uniform(0.3, 1.0)), indel_mean=float(rng.uniform(1, 12)), p_snp=float(rng.uniform(0.2, 0.9)))
+        kw = dict(n_sc=int(rng.integers(1000, 8000)), len_a=10, len_b=300, len_min=10, len_max=300,
+                  p_keep=float(rng.uniform(0.9, 1.0)), p_drop=0.0, p_hom=float(rng.uniform(0.3, 1.0)),
+                  indel_mean=float(rng.uniform(1, 12)), p_snp=float(rng.uniform(0.2, 0.9)))
     else:               # everything perturbed (few zero-distance alignments)
-        kw = dict(n_sc=int(rng.integers(500, 3000)), len_a=8, len_b=400, len_min=8, len_max=400, p_keep=float(rng.uniform(0.3, 0.7)),
-                  p_drop=float(rng.uniform(0.1, 0.3)), var_per_base=float(rng.uniform(0.01, 0.08)))
+        kw = dict(n_sc=int(rng.integers(500, 3000)), len_a=8, len_b=400, len_min=8, len_max=400,
+                  p_keep=float(rng.uniform(0.3, 0.7)), p_drop=float(rng.uniform(0.1, 0.3)),
+                  var_per_base=float(rng.uniform(0.01, 0.08)))
     kw["seed"] = seed
-    band_mode = int(rng.choice([1, 1, 1, 3, 2, 0])) if shape != 3 else int(rng.choice([1, 1, 2]))
-    batch = api.Synth(**kw).batch()
-    try:
-        got, want, ntie, pr = T.compare(batch, A.default_config(band_mode=band_mode))
-    except AssertionError as e:
-        print(f"MISMATCH seed {seed} band_mode {band_mode} kw {kw}: {e}")
-        sys.exit(1)
-    t = pr.timing()
-    n_run += 1; n_sc += batch.n_sc; n_tie += ntie
-    print(f"seed {seed} shape {shape} band_mode {band_mode}: {batch.n_sc} sc, {batch.dense_cells():.2e} dense cells, "
-          f"{t.n_band_retries} retries, {ntie} ties skipped: ok", flush=True)
-    seed += 1
-print(f"fuzz: {n_run} batches, {n_sc} superclusters, {n_tie} tie-skipped superclusters, no mismatch")
+    band_mode = int(rng.choice([1, 1, 2])) if shape == 3 else int(rng.choice([1, 1, 1, 3, 2, 0]))
+    return shape, kw, band_mode
+
+
+def fuzz(budget_s, seed0, verbose=True, max_batches=None):
+    """Run random batches for budget_s seconds; raises AssertionError (with the seed) on the first mismatch."""
+    import test_gpu_parity as T
+    from vcfdist_amd import _abi as A, api
+    t_end = time.time() + budget_s
+    n_run = n_sc = n_tie = 0
+    seed = seed0
+    while time.time() < t_end and (max_batches is None or n_run < max_batches):
+        shape, kw, band_mode = random_workload(seed)
+        batch = api.Synth(**kw).batch()
+        try:
+            got, want, ntie, pr = T.compare(batch, A.default_config(band_mode=band_mode))
+        except AssertionError as e:
+            raise AssertionError(f"fuzz mismatch: seed {seed} band_mode {band_mode} kw {kw}: {e}") from e
+        n_run += 1
+        n_sc += batch.n_sc
+        n_tie += ntie
+        if verbose:
+            print(f"seed {seed} shape {shape} band_mode {band_mode}: {batch.n_sc} sc, {batch.dense_cells():.2e} dense cells, "
+                  f"{pr.timing().n_band_retries} retries, {ntie} ties skipped: ok", flush=True)
+        seed += 1
+    return n_run, n_sc, n_tie
+
+
+if __name__ == "__main__":
+    runs, scs, ties = fuzz(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1000)
+    print(f"fuzz: {runs} batches, {scs} superclusters, {ties} tie-skipped superclusters, no mismatch")

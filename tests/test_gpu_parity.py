@@ -276,3 +276,11 @@ def test_biwfa_cluster_supercluster_end_to_end():
     batch = api.batch_from_variants(v2)
     got, want, ntie, pr = compare(batch)
     print(f"{sum(c.n for c in cl)} biWFA clusters -> {s.n} superclusters (largest {int((s.end - s.beg).max())}), {ntie} ties skipped")
+
+
+def test_fuzz_smoke():
+    """a few seconds of tests/fuzz_parity.py (random workload shapes, fixed seeds) inside the suite; the long runs are
+    done by hand: `python tests/fuzz_parity.py 900`"""
+    import fuzz_parity
+    runs, scs, _ = fuzz_parity.fuzz(8.0, 777000, verbose=False, max_batches=12)
+    assert runs >= 3 and scs > 1000
