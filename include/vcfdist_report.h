@@ -23,7 +23,7 @@ extern "C" {
 
 #define VRP_OK        0
 #define VRP_ERR_ARG  -1     /* null pointer / inconsistent tables (the reference's "Out of bounds ..." ERRORs) */
-#define VRP_ERR_OPEN -2     /* output file cannot be created */
+#define VRP_ERR_OPEN -2     /* output file cannot be created, or a write to it failed (see vrp_last_error) */
 
 /* one (callset, hap) of one contig: ctgVariants (src/variant.h:17-77) as columns */
 typedef struct vrp_hap {

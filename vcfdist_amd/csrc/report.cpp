@@ -31,6 +31,14 @@ struct File {
     explicit File(const char *path) { if (path) f = fopen(path, "w"); }
     ~File() { if (f) fclose(f); }
     operator FILE *() const { return f; }
+    // flush and close now; false if any write failed (disk full, ...): the caller reports it instead of VRP_OK
+    bool finish() {
+        if (!f) return false;
+        const bool bad = fflush(f) != 0 || ferror(f) != 0;
+        const bool closed = fclose(f) == 0;
+        f = nullptr;
+        return !bad && closed;
+    }
 };
 
 struct Metrics { int query_tp, query_fp, truth_tp, truth_fn; float precision, recall, f1, f1_q; };
@@ -59,7 +67,8 @@ bool contig_ok(const vrp_contig &c) {
     if (c.n_sc > 0 && (!c.sc_beg || !c.sc_end || !c.sc_phase || !c.pb_phase)) return false;
     for (int i = 0; i < 4; i++) {
         const vrp_hap &h = c.hap[i];
-        if (h.n_var > 0 && (!h.pos || !h.type || !h.cluster_beg || !h.pool)) return false;
+        if (h.n_var > 0 && (!h.pos || !h.type || !h.cluster_beg || !h.pool || !h.ref_len || !h.alt_len || !h.ref_off || !h.alt_off))
+            return false;
     }
     return true;
 }
@@ -109,6 +118,7 @@ extern "C" int vrp_write_precision_recall(const char *prefix, const int64_t *cou
                     m.query_tp, m.truth_fn, m.query_fp, m.precision, m.recall, m.f1, m.f1_q);
         }
     }
+    if (!all.finish() || !sum.finish()) return fail(VRP_ERR_OPEN, "write error on " + fn_all + " / " + fn_sum);
     return VRP_OK;
 }
 
@@ -133,6 +143,7 @@ extern "C" int vrp_write_phase_blocks(const char *path, const vrp_contig *ctgs, 
                     inside(c.flips, c.n_flips), inside(c.switches, c.n_switches));
         }
     }
+    if (!out.finish()) return fail(VRP_ERR_OPEN, std::string("write error on ") + path);
     return VRP_OK;
 }
 
@@ -163,6 +174,7 @@ extern "C" int vrp_write_superclusters(const char *path, const vrp_contig *ctgs,
                     PHASE_STR[phase_sc], c.sc_phase_set[k], pb, flip_error);
         }
     }
+    if (!out.finish()) return fail(VRP_ERR_OPEN, std::string("write error on ") + path);
     return VRP_OK;
 }
 
@@ -198,6 +210,7 @@ extern "C" int vrp_write_variants(const char *path, const vrp_contig *ctgs, int3
             v[h]++;
         }
     }
+    if (!out.finish()) return fail(VRP_ERR_OPEN, std::string("write error on ") + path);
     return VRP_OK;
 }
 
@@ -366,5 +379,6 @@ extern "C" int vrp_write_summary_vcf(const char *path, const vrp_contig *ctgs, i
             if (!ok) return fail(VRP_ERR_ARG, "vrp_write_summary_vcf: variant type / anchor base unavailable");
         }
     }
+    if (!out.finish()) return fail(VRP_ERR_OPEN, std::string("write error on ") + path);
     return VRP_OK;
 }
