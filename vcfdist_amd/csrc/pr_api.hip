@@ -75,8 +75,7 @@ struct LadderCtx {
     int slot0 = 0;                          // first of its N_SLOTS fail slots
     int64_t fail_base = 0;                  // its region of the fail-list buffer
     uint8_t *arena = nullptr; int64_t arena_bytes = 0;
-    AlnDesc *d_descs = nullptr; size_t descs_cap = 0;   // staging of the plans in flight
-    int32_t *d_work = nullptr; size_t work_cap = 0;
+    int32_t *d_work = nullptr; size_t work_cap = 0;     // work lists of the plans in flight
     AlnDesc *hp_descs = nullptr; int32_t *hp_work = nullptr; size_t hp_cap = 0;   // host-pinned source of k_stage
     int slot_cur = 0; int64_t fail_cur = 0, arena_cur = 0; size_t stage_cur = 0;
     std::vector<std::pair<int, int64_t>> pending;       // (slot, fail list offset) of the launches in flight
@@ -1052,11 +1051,6 @@ int vpr_execute(vpr_handle *h) {
             fprintf(stderr, "[vpr] retry round (ladder %d): %zu -> 16, %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n",
                     int(&c - h->lad), by_lv[1].size(), by_lv[2].size(), by_lv[3].size(), by_lv[4].size(), by_lv[5].size());
         const size_t nf = fails.size();
-        if (c.descs_cap < nf) {
-            int rc = dev_alloc(h, &c.d_descs, nf * 2);
-            if (rc) return rc;
-            c.descs_cap = nf * 2;
-        }
         if (c.work_cap < nf) {
             int rc = dev_alloc(h, &c.d_work, nf * 2);
             if (rc) return rc;
@@ -1098,10 +1092,8 @@ int vpr_execute(vpr_handle *h) {
             else c.arena_cur = c.arena_bytes;    // multi-chunk plan: the whole workspace is in use
             // stage descriptors / work list (bump allocation: all plans of the round are in flight together)
             const size_t n = P.work.size();
-            AlnDesc *dd = c.d_descs + c.stage_cur;
             int32_t *dw = c.d_work + c.stage_cur;
             c.stage_cur += n;
-            (void)dd;
             memcpy(c.hp_descs + (c.stage_cur - n), P.descs.data(), n * sizeof(AlnDesc));
             memcpy(c.hp_work + (c.stage_cur - n), P.work.data(), n * 4);
             hipLaunchKernelGGL(k_stage, blocks(int64_t(std::max<size_t>(n, LadderCtx::N_SLOTS))), dim3(256), 0, c.ls,
