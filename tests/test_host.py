@@ -97,3 +97,31 @@ def test_batch_subset_roundtrip():
     r_all = O.run(b)
     r_sub = O.run(sub)
     assert r_sub.aln_dist.tolist() == np.concatenate([r_all.aln_dist[4 * i:4 * i + 4] for i in (3, 7, 7, 29)]).tolist()
+
+
+def test_region_past_the_contig_end_is_refused_by_product_and_oracle():
+    """A variant ending on the last base of a contig makes get_supercluster_range (cluster.cpp:595: pos + rlen + 1)
+    return end == contig length.  The reference has no defined result there (dist.cpp:232 substr one base short of its
+    pointer arrays, dist.cpp:539 start cell taken from the pointer arrays' size), so both the product marshalling and
+    the oracle restatement refuse it; the same variant one base further left is fine.  Found by tests/fuzz_chain.py."""
+    import numpy as np
+    import oracle_lib as O
+    from vcfdist_amd import _abi as A
+    ctg = np.frombuffer(b"ACGTACGTACGTACGTACGT", np.uint8)          # 20 bases
+    def variants(pos):
+        # one deletion of one base at `pos` on Q1 only; region = [pos - 1, pos + 1 + 1] as the reference computes it
+        n = [1, 0, 0, 0]
+        z32, z64 = np.zeros(0, np.int32), np.zeros(0, np.int64)
+        return A.Variants(np.array([0, 20], np.int64), ctg, np.zeros(1, np.int32), np.array([pos - 1], np.int32),
+                          np.array([pos + 2], np.int32), [np.array([0, k], np.int64) for k in n],
+                          [np.array([pos], np.int32), z32, z32, z32], [np.array([3], np.uint8)] + [np.zeros(0, np.uint8)] * 3,
+                          [np.array([30.0], np.float32)] + [np.zeros(0, np.float32)] * 3, [np.array([0], np.int64), z64, z64, z64],
+                          [np.array([1], np.int32), z32, z32, z32], [np.array([1], np.int64), z64, z64, z64],
+                          [np.array([0], np.int32), z32, z32, z32], [ctg[pos:pos + 1].copy()] + [np.zeros(1, np.uint8)] * 3)
+    ok = variants(17)                       # end = 19 = last base: fine
+    assert api.batch_from_variants(ok).lens(0)[4] == 4 and O.generate(ok).lens(0)[4] == 4
+    bad = variants(18)                      # deletes base 18, the variant ends on base 19, end = 20 = contig length
+    with pytest.raises(api.VprError):
+        api.batch_from_variants(bad)
+    with pytest.raises(ValueError):
+        O.generate(bad)

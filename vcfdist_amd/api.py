@@ -93,7 +93,10 @@ def batch_from_variants(variants: A.Variants) -> A.Batch:
     ob = C.c_void_p()
     rc = L.vpr_batch_from_variants(C.byref(vs), C.byref(ob))
     if rc:
-        raise VprError(f"vpr_batch_from_variants failed: {rc}")
+        raise VprError(f"vpr_batch_from_variants failed: {rc}" + (
+            " (input generate_ptrs_strs cannot process: unsorted / overlapping variants on a haplotype, a variant type other than "
+            "SUB/INS/DEL, or a supercluster region that leaves its contig -- a variant ending on the last base of a contig; see "
+            "include/vcfdist_pr.h)" if rc == -1 else ""))
     try:
         return A.Batch.from_struct(L.vpr_owned_batch_view(ob).contents)
     finally:
@@ -149,7 +152,10 @@ class Synth:
         ob = C.c_void_p()
         rc = L.vpr_batch_from_variants(L.vpr_synth_variants(self._h), C.byref(ob))
         if rc:
-            raise VprError(f"vpr_batch_from_variants failed: {rc}")
+            raise VprError(f"vpr_batch_from_variants failed: {rc}" + (
+            " (input generate_ptrs_strs cannot process: unsorted / overlapping variants on a haplotype, a variant type other than "
+            "SUB/INS/DEL, or a supercluster region that leaves its contig -- a variant ending on the last base of a contig; see "
+            "include/vcfdist_pr.h)" if rc == -1 else ""))
         if not copy:
             return A.Batch.from_struct(L.vpr_owned_batch_view(ob).contents, copy=False, owner=_Owned(ob))
         try:
