@@ -75,7 +75,7 @@ def fuzz(budget_s, seed0, verbose=True, max_batches=None, shape=None):
             # the one documented refusal: an alignment that needs the dense kernels with
             # Lq + Lr beyond their LDS rows.  Anything else, or that message on a batch that fits, is a failure.
             big = max(max(batch.lens(k)[q] for q in (0, 1)) + batch.lens(k)[4] for k in range(batch.n_sc))
-            if "too long for the dense kernels" in str(e) and big > 26000:
+            if "too long for the dense kernels" in str(e) and big > 39000:
                 n_limit += 1
                 if verbose:
                     print(f"seed {seed} shape {shape_}: refused, dense-level size limit (largest Lq + Lr = {big})", flush=True)

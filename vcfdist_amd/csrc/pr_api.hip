@@ -206,12 +206,15 @@ size_t fwd_lds_bytes(int cls, int Lq, int Lr) {
     const size_t PQ = (Lq + C - 1) / C * C, PR = (Lr + C - 1) / C * C;
     return (PQ + PR + 8 + 2 * (NT / 64)) * 4;
 }
-size_t bwd_lds_bytes(int cls, int Lq, int Lr) {
+// s16: score rows as int16 (k_bwd<NT, C, true>)
+size_t bwd_lds_bytes(int cls, int Lq, int Lr, bool s16 = false) {
     const int C = CLASSES[cls].c, NT = CLASSES[cls].nt;
     const size_t PQ = (Lq + C - 1) / C * C, PR = (Lr + C - 1) / C * C;
     const size_t FQ = (PQ + 16 + 15) & ~size_t(15), FR = (PR + 16 + 15) & ~size_t(15);
-    return (PQ + PR + 8) * 4 + 2 * (FQ + FR) + 4 * (NT / 64) * 4 + 16;
+    return (((PQ + PR + 8) * (s16 ? 2 : 4) + 15) & ~size_t(15)) + 2 * (FQ + FR) + 4 * (NT / 64) * 4 + 16;
 }
+// largest score the int16 rows must hold: query-variant entries on a path <= query variants of the alignment
+bool s16_ok(const AlnDesc &d) { return d.qv_end - d.qv_beg < 32000; }
 
 typedef void (*AlnKernel)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, AlnOut *);
 AlnKernel fwd_kernel(int cls) {
@@ -225,15 +228,26 @@ AlnKernel fwd_kernel(int cls) {
         default: return k_fwd<1024, 32>;
     }
 }
-AlnKernel bwd_kernel(int cls) {
+AlnKernel bwd_kernel(int cls, bool s16 = false) {
+    if (s16) {
+        switch (cls) {
+            case 0: return k_bwd<64, 1, true>;
+            case 1: return k_bwd<64, 4, true>;
+            case 2: return k_bwd<256, 4, true>;
+            case 3: return k_bwd<256, 8, true>;
+            case 4: return k_bwd<1024, 8, true>;
+            case 5: return k_bwd<1024, 16, true>;
+            default: return k_bwd<1024, 32, true>;
+        }
+    }
     switch (cls) {
-        case 0: return k_bwd<64, 1>;
-        case 1: return k_bwd<64, 4>;
-        case 2: return k_bwd<256, 4>;
-        case 3: return k_bwd<256, 8>;
-        case 4: return k_bwd<1024, 8>;
-        case 5: return k_bwd<1024, 16>;
-        default: return k_bwd<1024, 32>;
+        case 0: return k_bwd<64, 1, false>;
+        case 1: return k_bwd<64, 4, false>;
+        case 2: return k_bwd<256, 4, false>;
+        case 3: return k_bwd<256, 8, false>;
+        case 4: return k_bwd<1024, 8, false>;
+        case 5: return k_bwd<1024, 16, false>;
+        default: return k_bwd<1024, 32, false>;
     }
 }
 typedef void (*BandFwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, int32_t *, AlnOut *);
@@ -386,7 +400,9 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
                 d.pitch[0] = int32_t(round_up(d.Lq, 32));
                 d.pitch[1] = int32_t(round_up(d.Lr, 32));
                 const int cls = class_of(std::max(d.Lq, d.Lr));
-                if (cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX || bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX)
+                // (the backward kernel's int32 score rows may not fit: it then runs with int16 rows, 4 B per cell)
+                if (cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX ||
+                    (bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX && (!s16_ok(d) || bwd_lds_bytes(cls, d.Lq, d.Lr, true) > LDS_MAX)))
                     return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d too long for the dense kernels (Lq=%d Lr=%d)",
                                 d.sc, d.aln, d.Lq, d.Lr);
                 m0 = round_up(int64_t(d.pitch[0]) * d.Lt, 64); m1 = round_up(int64_t(d.pitch[1]) * d.Lt, 64);
@@ -497,6 +513,8 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_kernel(k)),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_MAX));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_kernel(k)),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_MAX));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_kernel(k, true)),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_MAX));
     }
     *out = h;
@@ -860,10 +878,21 @@ int vpr_execute(vpr_handle *h) {
                 memset(&ls, 0, sizeof(ls));
                 ls.threads = K.nt; ls.cells_per_thread = K.c; ls.n_units = L.count;
                 int64_t in_bytes = 0;
+                // the backward launch uses int16 score rows when a member's int32 rows do not fit LDS (make_plan
+                // has checked that the int16 rows do and that the scores are in range); VPR_DENSE_S16 forces it
+                bool s16 = getenv("VPR_DENSE_S16") != nullptr;
+                for (int32_t w = 0; w < L.count; w++) {
+                    const AlnDesc &d = P.descs[L.work_off + w];
+                    if (bwd_lds_bytes(L.cls, d.Lq, d.Lr) > LDS_MAX) s16 = true;
+                }
                 for (int32_t w = 0; w < L.count; w++) {   // the launch's dynamic LDS = its largest member
                     const AlnDesc &d = P.descs[L.work_off + w];
+                    if (s16 && !s16_ok(d)) s16 = false;    // (only reachable when forced: keep the int32 rows)
                     lds_f = std::max(lds_f, fwd_lds_bytes(L.cls, d.Lq, d.Lr));
-                    lds_b = std::max(lds_b, bwd_lds_bytes(L.cls, d.Lq, d.Lr));
+                }
+                for (int32_t w = 0; w < L.count; w++) {
+                    const AlnDesc &d = P.descs[L.work_off + w];
+                    lds_b = std::max(lds_b, bwd_lds_bytes(L.cls, d.Lq, d.Lr, s16));
                     ls.cells += int64_t(d.Lq + d.Lr) * d.Lt;
                     in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
                 }
@@ -879,8 +908,8 @@ int vpr_execute(vpr_handle *h) {
                 if (rc) return rc;
                 n_fwd++;
                 ls.bytes_algorithmic = ls.cells;
-                rc = timed(2, ls, ks, (std::string("k_bwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + ">").c_str(), [&] {
-                    hipLaunchKernelGGL(bwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
+                rc = timed(2, ls, ks, (std::string("k_bwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + (s16 ? ",s16>" : ">")).c_str(), [&] {
+                    hipLaunchKernelGGL(bwd_kernel(L.cls, s16), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
                                        d_work + L.work_off, P.arena, h->d_outs);
                 });
                 if (rc) return rc;

@@ -368,7 +368,10 @@ __device__ __forceinline__ void block_suffix_mp2(MP gq, MP gr, int &inq, int &in
     }
 }
 
-template <int NT, int C>
+// S16: the score rows in LDS are int16 (a score counts query-variant entries on a path, so it is bounded by the
+// supercluster's query variants; the host checks that bound).  4 B instead of 6 B of LDS per cell: the variant the
+// planner picks when the int32 rows of an alignment do not fit.  Registers, arithmetic and results are unchanged.
+template <int NT, int C, bool S16>
 __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restrict__ descs,
                                             const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
                                             AlnOut *__restrict__ outs) {
@@ -383,13 +386,21 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
     // score rows (int32) of row t+1, flag rows (bytes) of rows t+1 / t (double buffered)
     // All LDS accesses go through integer offsets from the one extern array so they stay ds_* instructions
     // (runtime-selected pointers degrade to flat_* loads, which wait on vmcnt as well).
-    const int SO[2] = {0, PQ + 4};                                    // score rows (int32 index into lds)
-    uint8_t *fbase = reinterpret_cast<uint8_t *>(lds + PQ + PR + 8);
+    const int SO[2] = {0, PQ + 4};                                    // score rows (element index into lds)
+    uint8_t *fbase = reinterpret_cast<uint8_t *>(lds) + ((size_t(PQ + PR + 8) * (S16 ? 2 : 4) + 15) & ~size_t(15));
+    int16_t *lds16 = reinterpret_cast<int16_t *>(lds);
+    // stored scores are S_NEG or >= 0 (the row loop cleans negatives before storing)
+    auto s_ld = [&](int p, int i) -> int {
+        if (S16) { const int x = lds16[SO[p] + i]; return x < 0 ? S_NEG : x; }
+        return lds[SO[p] + i];
+    };
+    auto s_st = [&](int p, int i, int v) {
+        if (S16) lds16[SO[p] + i] = int16_t(v < 0 ? -1 : v); else lds[SO[p] + i] = v;
+    };
     const int FQ = (PQ + 16 + 15) & ~15, FR = (PR + 16 + 15) & ~15;   // bytes per flag row incl. guard
     const int FP[2] = {0, FQ};                                        // plane offset inside one flag buffer
     const int FB = FQ + FR;                                           // bytes per flag buffer (two planes)
     int32_t *wsc = reinterpret_cast<int32_t *>(fbase + 2 * FB);
-#define SROW(p, i) lds[SO[p] + (i)]
 #define FROW(b, p, i) fbase[(b) * FB + FP[p] + (i)]
     const int32_t *ptr[2] = {B.hap_ptr[d.qs] + d.q_off, B.ref_ptr[d.qs] + d.r_off};
     const uint8_t *pfl[2] = {B.hap_flag[d.qs] + d.q_off, B.ref_flag[d.qs] + d.r_off};
@@ -448,7 +459,7 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
     for (int p = 0; p < 2; p++)
         if (q0 < Pp[p])
 #pragma unroll
-            for (int c = 0; c < C; c++) { SROW(p, q0 + c) = S_NEG; FROW(0, p, q0 + c) = 0; }
+            for (int c = 0; c < C; c++) { s_st(p, q0 + c, S_NEG); FROW(0, p, q0 + c) = 0; }
     // stage flags of row Lt-1 into flag buffer 1
     uint8_t f0[2][C];
 #pragma unroll
@@ -466,7 +477,7 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
         }
     }
     if (tid == 0) {   // guard cells right of each row (read by the last thread as "q+1")
-        for (int p = 0; p < 2; p++) { SROW(p, Pp[p]) = S_NEG; FROW(0, p, Pp[p]) = 0; FROW(1, p, Pp[p]) = 0; }
+        for (int p = 0; p < 2; p++) { s_st(p, Pp[p], S_NEG); FROW(0, p, Pp[p]) = 0; FROW(1, p, Pp[p]) = 0; }
     }
     lds_barrier<NT>();
     uint32_t tie_used = 0;
@@ -492,7 +503,7 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
             // values of the cell to the right of this chunk
             int xs_r = S_NEG; int xf_r = 0, xf0_r = 0, xtp_r = 0;
             if (q0 + C <= Pp[p]) {
-                xs_r = SROW(p, q0 + C);
+                xs_r = s_ld(p, q0 + C);
                 xf_r = FROW(nxt, p, q0 + C);
                 xf0_r = FROW(cur, p, q0 + C);
             }
@@ -520,7 +531,7 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
                 if (zq[p][c] >= 0) {
                     const int zf = FROW(nxt, o, zq[p][c]);
                     if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((kc[p][c] >> 1) & 3)) {
-                        const int v = SROW(o, zq[p][c]) + ((kc[p][c] >> 3) & 1);
+                        const int v = s_ld(o, zq[p][c]) + ((kc[p][c] >> 3) & 1);
                         if (v >= 0 && (zf & F_TIE)) tie_used = 1;
                         if (v > best) { best = v; m = F_SWP; } else if (v == best) m |= F_SWP;
                     }
@@ -561,7 +572,7 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
             }
             if (q0 < Lp[p]) {
 #pragma unroll
-                for (int c = 0; c < C; c++) SROW(p, q0 + c) = sc[p][c];
+                for (int c = 0; c < C; c++) s_st(p, q0 + c, sc[p][c]);
                 if (t > 0) {
                     unpack_flags<C>(pf[p], f0[p]);   // row t-1 flags (requested one row ago)
 #pragma unroll
@@ -587,7 +598,6 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
 }
 
 // ---------------------------------------------------------------------------
-#undef SROW
 #undef FROW
 
 // ---------------------------------------------------------------------------
