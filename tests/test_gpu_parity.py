@@ -284,3 +284,28 @@ def test_fuzz_smoke():
     import fuzz_parity
     runs, scs, _ = fuzz_parity.fuzz(8.0, 777000, verbose=False, max_batches=12)
     assert runs >= 3 and scs > 1000
+
+
+def _adjacent_deletions(k):
+    """one supercluster: k directly adjacent one-base deletions (separate records) on QUERY hap 1, nothing elsewhere"""
+    rng = np.random.default_rng(5)
+    ctg = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=60).astype(np.uint8)
+    pos = np.arange(20, 20 + k, dtype=np.int32)
+    z32, z64, zu8, zf = np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.uint8), np.zeros(0, np.float32)
+    return A.Variants(np.array([0, 60], np.int64), ctg, np.zeros(1, np.int32), np.array([19], np.int32),
+                      np.array([20 + k + 1], np.int32), [np.array([0, k], np.int64)] + [np.array([0, 0], np.int64)] * 3,
+                      [pos, z32, z32, z32], [np.full(k, 3, np.uint8), zu8, zu8, zu8], [np.full(k, 30.0, np.float32), zf, zf, zf],
+                      [np.arange(k, dtype=np.int64), z64, z64, z64], [np.ones(k, np.int32), z32, z32, z32],
+                      [np.full(k, k, np.int64), z64, z64, z64], [np.zeros(k, np.int32), z32, z32, z32],
+                      [ctg[20:20 + k].copy()] + [np.zeros(1, np.uint8)] * 3)
+
+
+def test_adjacent_deletion_records_up_to_the_swap_source_limit():
+    """Directly adjacent deletion records all point at the hap base in front of the first one; each contributes one
+    allowed swap source to the position behind them.  The library keeps four sources per position (int4 lists, 2-bit
+    rank in the flag byte): three adjacent records match the oracle, four are refused by vpr_upload with a message --
+    a documented limit, not a wrong result."""
+    batch = api.batch_from_variants(_adjacent_deletions(3))
+    compare(batch)
+    with pytest.raises(api.VprError, match="swap sources"):
+        api.PrecisionRecall().run(api.batch_from_variants(_adjacent_deletions(4)))
