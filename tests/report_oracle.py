@@ -2,6 +2,10 @@
 vcfdist_amd/csrc/report.cpp byte for byte.  Follows write_precision_recall / write_results (src/print.cpp:441-878),
 phaseblockData::write_summary_vcf (src/phase.cpp:8-222) and ctgVariants::print_var_* (src/variant.cpp:229-286).
 Python's % formatting of a float32 widened to double prints the same digits as C's printf.
+
+PARITY UNPINNED for the file formats: the reference ships no example of these files and cannot be built here, so the
+format strings, merge order and header text below are pinned only by reading the cited lines; the one piece of
+reference output that touches them (demo/output.txt, SNP rows) agrees with precision-recall-summary.tsv.
 """
 import math
 
