@@ -116,7 +116,10 @@ def main(argv=None):
             raise SystemExit(f"ERROR: contig '{ctg}' not in reference FASTA")
         qs = q["vars"][q["contigs"].index(ctg)] if ctg in q["contigs"] else [empty, empty]
         ts = t["vars"][t["contigs"].index(ctg)] if ctg in t["contigs"] else [empty, empty]
-        counts, n_sc, tables = evaluate_contig(ctg, fasta[ctg], [qs[0], qs[1], ts[0], ts[1]], args, device=args.device)
+        try:
+            counts, n_sc, tables = evaluate_contig(ctg, fasta[ctg], [qs[0], qs[1], ts[0], ts[1]], args, device=args.device)
+        except api.VprError as e:     # the library's explicit refusals end the run like the reference's ERROR()
+            raise SystemExit(f"ERROR: contig '{ctg}': {e}")
         total += counts
         if not args.no_output_files:
             src = q if ctg in q["contigs"] else t     # superclusterData ctor, cluster.cpp:134-157: query's header wins
