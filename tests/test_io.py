@@ -4,6 +4,7 @@ import gzip
 import os
 
 import numpy as np
+import pytest
 
 import demo_pipeline as D
 from vcfdist_amd import api, io as IO
@@ -108,3 +109,37 @@ def test_fasta_reader(tmp_path):
     p.write_text(">chr1 description here\nacgtNN\nACGT\n>chr2\nTTTT\n")
     f = IO.read_fasta(str(p))
     assert bytes(f["chr1"]) == b"ACGTNNACGT" and bytes(f["chr2"]) == b"TTTT"
+
+
+HDR = "##fileformat=VCFv4.2\n##contig=<ID=chr1,length=1000>\n##contig=<ID=chr2,length=1000>\n"
+COLS = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1"
+
+
+@pytest.mark.parametrize("name,text,needle", [
+    # the reference's ERROR() cases (variant.cpp:397-1004): each ends the run there, an IOError with the message here
+    ("two_samples", HDR + COLS + "\tS2\nchr1\t10\t.\tA\tG\t30\tPASS\t.\tGT\t1|1\t0|1\n", "1 sample"),
+    ("unsorted_contigs", HDR + COLS + "\nchr1\t10\t.\tA\tG\t30\tPASS\t.\tGT\t1|1\nchr2\t10\t.\tA\tG\t30\tPASS\t.\tGT\t1|1\n"
+                                      "chr1\t50\t.\tA\tG\t30\tPASS\t.\tGT\t1|1\n", "already parsed"),
+    ("polyploid", HDR + COLS + "\nchr1\t10\t.\tA\tG\t30\tPASS\t.\tGT\t0|1|1\n", "ploidy 3"),
+    ("record_before_header", HDR + "chr1\t10\t.\tA\tG\t30\tPASS\t.\tGT\t1|1\n", "before the #CHROM"),
+    ("short_record", HDR + COLS + "\nchr1\t10\t.\tA\tG\t30\n", "fields"),
+    ("allele_index", HDR + COLS + "\nchr1\t10\t.\tA\tG\t30\tPASS\t.\tGT\t1|2\n", "out of range"),
+])
+def test_vcf_format_errors_are_reported(tmp_path, name, text, needle):
+    p = tmp_path / (name + ".vcf")
+    p.write_text(text)
+    with pytest.raises(IOError, match=needle):
+        IO.read_vcf(str(p), None)
+
+
+def test_missing_files_and_short_bed_lines(tmp_path):
+    with pytest.raises(IOError):
+        IO.read_vcf(str(tmp_path / "nope.vcf"), None)
+    with pytest.raises(IOError):
+        IO.read_fasta(str(tmp_path / "nope.fa"))
+    with pytest.raises(IOError):
+        IO.Bed(str(tmp_path / "nope.bed"))
+    bad = tmp_path / "bad.bed"
+    bad.write_text("chr1\t10\n")
+    with pytest.raises(IOError, match="fewer than 3"):
+        IO.Bed(str(bad))
