@@ -29,7 +29,8 @@ extern "C" {
 
 #define VCL_OK        0
 #define VCL_ERR_ARG  -1     /* null pointer, unsorted positions, inconsistent cluster table */
-#define VCL_ERR_TYPE -2     /* a variant type other than SUB/INS/DEL ("Variant type ... unexpected", cluster.cpp:873) */
+#define VCL_ERR_TYPE -2     /* size mode: a variant type other than SUB/INS/DEL ("Variant type ... unexpected",
+                               cluster.cpp:873, where the size of a variant is computed; gap mode never looks at it) */
 #define VCL_ERR_DEVICE -3   /* no HIP device / HIP error (vcl_wfa_cluster has no CPU fallback) */
 
 #define VCL_SENTINEL 0x7fffffff   /* std::numeric_limits<int>::max(): reach of the sentinel cluster */

@@ -112,3 +112,17 @@ def test_oversize_split_counts():
     assert (s.end - s.beg).max() <= 500
     assert s.clusters[0].n > cl[0].n            # clusters were split in place
     assert np.all(s.cells > 0)
+
+
+def test_invalid_input():
+    """A variant type other than SUB/INS/DEL is the reference's "Variant type ... unexpected" ERROR, raised where the
+    size of a variant is computed (cluster.cpp:873), i.e. with `-c size` only: product and oracle return VCL_ERR_TYPE there
+    and, like the reference, do not look at the type with `-c gap`.  Unsorted positions violate a precondition the
+    reference relies on its VCF reader for; the product checks it (VCL_ERR_ARG), the oracle mirrors the reference."""
+    badtype = K.Hap([5, 10], [1, 1], [1, 4], [1, 1], [1, 1])
+    for L, pre in ((None, "vcl"), (O.lib(), "vco")):
+        with pytest.raises(ValueError, match="-2"):
+            K.simple_cluster(badtype, 1, 50, 10, L=L, prefix=pre)
+        assert K.simple_cluster(badtype, 0, 50, 10, L=L, prefix=pre).n == 1
+    with pytest.raises(ValueError, match="-1"):
+        K.simple_cluster(K.Hap([10, 5], [1, 1], [1, 1], [1, 1], [1, 1]), 0, 50, 10)

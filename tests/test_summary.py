@@ -74,3 +74,14 @@ def test_device_counts_and_summary_against_oracle():
              none_all.f1_score, len(sw), len(fl)))
     assert none_all.query_tp + none_all.query_fp > 0
     del tally
+
+
+def test_phase_rejects_an_unknown_phase_value():
+    """a supercluster phase other than ORIG / SWAP / NONE is the reference's "Unexpected phase" ERROR (phase.cpp:305)"""
+    import pytest
+    import oracle_lib as O
+    for L, pre in ((None, "vpr"), (O.lib(), "vso")):
+        with pytest.raises(ValueError):
+            S.phase([0, 3, 1], [0, 0, 0], L=L, prefix=pre)
+    pb, sw, fl = S.phase([], [])
+    assert len(pb) == 0 and len(sw) == 0 and len(fl) == 0
