@@ -65,9 +65,10 @@ extern "C" {
 
 /* per-alignment status bits (vpr_results.aln_status) */
 #define VPR_ST_OK            0u
-#define VPR_ST_SWAP_TIE      1u   /* a cell on the optimal DAG had >1 optimal swap predecessor:
-                                     the reference's choice is container-order defined
-                                     (src/dist.cpp:347,376); highest source index was used */
+#define VPR_ST_SWAP_TIE      1u   /* a cell on the optimal DAG had >1 optimal swap predecessor: the reference keeps the
+                                     last writer (src/dist.cpp:347,376), an order defined by its FIFO and
+                                     unordered_set iteration; the library replayed that order for this alignment
+                                     (informational: the results are the reference's) */
 #define VPR_ST_WARN_REF_ED   2u   /* "Nonzero reference edit distance with no truth variants" dist.cpp:1203 */
 #define VPR_ST_WARN_QUERY_ED 4u   /* "Query edit distance changed with no query variants"     dist.cpp:1207 */
 #define VPR_ST_WARN_EXCEEDS  8u   /* "Query edit distance exceeds reference edit distance"    dist.cpp:1211 */
@@ -188,12 +189,15 @@ typedef struct vpr_timing {
     int64_t cells_touched; /* cells actually computed by K1 (== dense when band_mode 0) */
     int64_t bytes_algorithmic; /* SURVEY 8(d) formula over the batch */
     int64_t n_band_retries;
+    int64_t n_tie_replays; /* alignments whose tied swap predecessors were resolved by replaying the reference's
+                              container order (VPR_ST_SWAP_TIE), counting second attempts */
+    double  ms_tie;        /* the replay kernel */
 } vpr_timing;
 
 /* one kernel launch of the last vpr_execute (HIP events around the launch) */
 typedef struct vpr_launch_stat {
     int32_t kind;          /* 1 = K1 forward, 2 = K2 backward, 3 = K3 walk, 4 = K4 section edit distance,
-                              5 = K5 finalise + phase + tally */
+                              5 = K5 finalise + phase + tally, 6 = container-order replay of tied alignments */
     int32_t threads;       /* workgroup size */
     int32_t cells_per_thread; /* C of the thread-chunk configuration (K1/K2) */
     int32_t n_units;       /* alignments (K1-K3) or sections (K4) in the launch */

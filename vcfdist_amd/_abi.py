@@ -78,6 +78,7 @@ class VprTiming(C.Structure):
         ("ms_bwd", C.c_double), ("ms_walk", C.c_double), ("ms_ed", C.c_double),
         ("n_fwd_launches", C.c_int64), ("cells_dense", C.c_int64), ("cells_touched", C.c_int64),
         ("bytes_algorithmic", C.c_int64), ("n_band_retries", C.c_int64),
+        ("n_tie_replays", C.c_int64), ("ms_tie", C.c_double),
     ]
 
 

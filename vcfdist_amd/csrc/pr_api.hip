@@ -27,6 +27,7 @@
 #include "pr_band.hip"
 #include "pr_q16.hip"
 #include "pr_wide.hip"
+#include "pr_tie.hip"
 
 namespace {
 
@@ -117,13 +118,17 @@ struct vpr_handle {
     int32_t **d_fp_table = nullptr;
     EdJob *d_jobs = nullptr; int32_t jobs_cap = 0; int32_t *d_njobs = nullptr;
     uint32_t *d_err = nullptr;
-    int32_t *d_ok = nullptr, *d_fail = nullptr, *d_cnt = nullptr;   // partition lists + 2 counters
+    int32_t *d_fail = nullptr, *d_cnt = nullptr;   // fail lists + their counters
+    // tie pass (pr_tie.hip): list of marked alignments {id, level tag}, counters {marked, replay overflows}, the jobs of
+    // the replay launches (host-pinned, read by the kernel directly) and the replay scratch (grown on demand)
+    int2 *d_tie_list = nullptr; int32_t tie_list_cap = 0;
+    int32_t *d_tie_cnt = nullptr;
+    TieJob *hp_tie_jobs = nullptr; size_t tie_jobs_cap = 0;
+    uint32_t *d_tie_scratch = nullptr; int64_t tie_scratch_bytes = 0;
     // host-pinned, device-visible mirrors of d_fail / d_cnt: a publish kernel on the producing stream fills them, so the
     // host reads a fail list after an event wait and issues no copy that the bulk kernels of the round could starve
     int32_t *hp_fail = nullptr, *hp_cnt = nullptr;
     std::vector<void *> pinned;
-    AlnDesc *d_tmp_descs = nullptr; size_t tmp_descs_cap = 0;
-    int32_t *d_tmp_work = nullptr; size_t tmp_work_cap = 0;
     int32_t *d_ed_scratch = nullptr; size_t ed_scratch_ints = 0;
     std::vector<EvPair> events;
     DevResults dR;                       // final results, produced on the device
@@ -190,8 +195,10 @@ void free_batch(vpr_handle *h) {
     for (int k = 0; k < 2; k++) h->lad[k] = LadderCtx();
     h->resident.clear();
     h->d_ed_scratch = nullptr; h->ed_scratch_ints = 0;
-    h->d_tmp_descs = nullptr; h->tmp_descs_cap = 0;
-    h->d_tmp_work = nullptr; h->tmp_work_cap = 0;
+    h->d_tie_list = nullptr; h->tie_list_cap = 0; h->d_tie_cnt = nullptr;
+    h->hp_tie_jobs = nullptr; h->tie_jobs_cap = 0;
+    if (h->d_tie_scratch) (void)hipFree(h->d_tie_scratch);
+    h->d_tie_scratch = nullptr; h->tie_scratch_bytes = 0;
     h->uploaded = h->executed = false;
 }
 
@@ -323,6 +330,16 @@ __global__ void k_stage(const AlnDesc *__restrict__ src, const int32_t *__restri
     const AlnDesc d = src[i];
     dst[d.sc * 4 + d.aln] = d;
     dst_work[i] = src_work[i];
+}
+
+// alignments the backward sweeps left to the tie pass: {alignment, level tag} (AlnOut::band_ok = TIE_MARK(tag))
+__global__ void k_collect_ties(const AlnOut *__restrict__ outs, int n, int2 *__restrict__ list, int32_t *__restrict__ cnt, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = outs[i].band_ok;
+    if (b >= 0) return;
+    const int k = atomicAdd(cnt, 1);
+    if (k < cap) list[k] = make_int2(i, -b - 1);
 }
 
 __global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc *__restrict__ dst) {
@@ -698,7 +715,9 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     R.max_qual = h->cfg.max_qual;
     R.credit_threshold = h->cfg.credit_threshold;
     R.phase_threshold = h->cfg.phase_threshold;
-    if ((rc = dev_alloc(h, &h->d_ok, na))) return rc;
+    h->tie_list_cap = int32_t(std::min<size_t>(std::max<size_t>(na, 1), size_t(1) << 20));
+    if ((rc = dev_alloc(h, &h->d_tie_list, size_t(h->tie_list_cap)))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tie_cnt, 2))) return rc;
     // fail lists: round 0 in [0, na + na/16 + 256) (a list that feeds a kernel directly is padded), retry rounds behind
     if ((rc = dev_alloc(h, &h->d_fail, 2 * na + na / 16 + 512))) return rc;
     if ((rc = dev_alloc(h, &h->d_cnt, 2 + 2 * LadderCtx::N_SLOTS))) return rc;
@@ -743,12 +762,12 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     if ((rc = dev_alloc(h, &h->d_arena, size_t(budget) + 256))) return rc;
     // workspaces of the two retry ladders, which run beside round 0 (cfg.workspace_bytes bounds each workspace;
     // otherwise they start small and grow on demand, vpr_execute)
-    if (h->cfg.band_mode != 0) {
+    {
         HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
         int64_t b2 = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes
                                                 : std::min<int64_t>(int64_t(double(free_b) * 0.25), std::max<int64_t>(want / 16, int64_t(1) << 30));
         if (b2 < (8 << 20)) b2 = 8 << 20;
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < (h->cfg.band_mode != 0 ? 2 : 1); k++) {   // (dense mode: only the tie pass needs one)
             h->lad[k].arena_bytes = b2;
             if ((rc = dev_alloc(h, &h->lad[k].arena, size_t(b2) + 256))) return rc;
         }
@@ -864,9 +883,74 @@ int vpr_execute(vpr_handle *h) {
         });
     };
 
+    // ---- tie pass only (pr_tie.hip): replay the reference's container order for `cnt` alignments of plan P from work
+    // list position `off`, whose forward sweep has just been re-run on stream ks; rewrites the choice of their tied cells.
+    // tie_full: FIFO logs sized for the worst case (second attempt, after a capped job overflowed).
+    bool tie_full = false;
+    size_t tie_job_cur = 0;
+    int64_t n_tie_jobs = 0;
+    auto tie_replay = [&](const Plan &P, int64_t off, int32_t cnt, hipStream_t ks) -> int {
+        if (tie_job_cur + size_t(cnt) > h->tie_jobs_cap) return fail(h, VPR_ERR_STATE, "tie pass: job buffer overflow");
+        int32_t k0 = 0;
+        while (k0 < cnt) {
+            // sub-batch [k0, k1) that fits the scratch (a single job larger than the scratch grows it)
+            int64_t words = 0;
+            int32_t k1 = k0;
+            TieJob *jobs = h->hp_tie_jobs + tie_job_cur;
+            while (k1 < cnt) {
+                const AlnDesc &d = P.descs[size_t(off) + k1];
+                const int64_t cells = int64_t(d.Lq + d.Lr) * d.Lt;
+                if (cells >= (int64_t(1) << 32) - 2)
+                    return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d: (Lq + Lr) * Lt = %lld cells exceed the tie replay's 32-bit cell index",
+                                d.sc, d.aln, (long long)cells);
+                int64_t cap = tie_full ? cells : std::min<int64_t>(cells, 16 * int64_t(d.Lq + d.Lr + d.Lt) + 4096);
+                cap = std::max<int64_t>(2, std::min<int64_t>(cap, int64_t(1) << 26));
+                int bi = 0;
+                while (bi + 1 < TIE_N_BUCKETS && int64_t(TIE_BUCKETS_HOST[bi]) < cap) bi++;
+                const int64_t bcap = TIE_BUCKETS_HOST[bi];
+                const int64_t w_st = (cells + 1) & ~int64_t(1), w_buf = TIE_BUF_WORDS * cap, w_bk = 2 * bcap;
+                const int64_t need = w_st + w_buf + w_bk;
+                if (k1 > k0 && (words + need) * 4 > h->tie_scratch_bytes) break;
+                if ((words + need) * 4 > h->tie_scratch_bytes) {   // first job of the sub-batch: grow
+                    HIPCHK(h, hipStreamSynchronize(ks));
+                    if (h->d_tie_scratch) (void)hipFree(h->d_tie_scratch);
+                    h->d_tie_scratch = nullptr;
+                    const int64_t nb = std::max<int64_t>(need * 4 + 256, int64_t(256) << 20);
+                    void *q = nullptr;
+                    if (hipMalloc(&q, size_t(nb)) != hipSuccess)
+                        return fail(h, VPR_ERR_NOMEM, "tie replay scratch (%lld bytes) for supercluster %d alignment %d", (long long)nb, d.sc, d.aln);
+                    h->d_tie_scratch = static_cast<uint32_t *>(q);
+                    h->tie_scratch_bytes = nb;
+                }
+                TieJob &J = jobs[k1 - k0];
+                J.a = P.work[size_t(off) + k1];
+                J.cap = int32_t(cap); J.bcap = int32_t(std::min<int64_t>(bcap, 0x7fffffff)); J.pad = 0;
+                J.stamp_off = words;
+                J.buf_off = words + w_st;
+                J.bkt_off = (words + w_st + w_buf) / 2;   // (all three terms are even)
+                words += need;
+                k1++;
+            }
+            const int32_t nj = k1 - k0;
+            tie_job_cur += size_t(nj);
+            n_tie_jobs += nj;
+            HIPCHK(h, hipMemsetAsync(h->d_tie_scratch, 0xff, size_t(words) * 4, ks));
+            vpr_launch_stat ts_;
+            memset(&ts_, 0, sizeof(ts_));
+            ts_.threads = 64; ts_.n_units = nj;
+            int rc = timed(6, ts_, ks, "k_tie_replay", [&] {
+                hipLaunchKernelGGL(k_tie_replay, dim3(nj), dim3(64), 0, ks, h->dB, h->d_descs, jobs, nj, P.arena,
+                                   reinterpret_cast<const int32_t *>(P.arena), h->d_outs, h->d_tie_scratch, h->d_tie_cnt + 1);
+            });
+            if (rc) return rc;
+            k0 = k1;
+        }
+        return VPR_OK;
+    };
+
     // ---- dense plan: per chunk, each kernel class runs K1 -> K2 -> K3 on its own stream (forked from and
     // joined into `base`); one_stream: everything on `base` (retry rounds that run beside other work)
-    auto run_dense = [&](const Plan &P, const int32_t *d_work, hipStream_t base, bool one_stream) -> int {
+    auto run_dense = [&](const Plan &P, const int32_t *d_work, hipStream_t base, bool one_stream, bool tie = false) -> int {
         for (const Chunk &ch : P.chunks) {
             if (!one_stream) HIPCHK(h, hipEventRecord(h->ev_fork, base));
             for (const Launch &L : ch.launches) {
@@ -907,6 +991,7 @@ int vpr_execute(vpr_handle *h) {
                 });
                 if (rc) return rc;
                 n_fwd++;
+                if (tie && (rc = tie_replay(P, L.work_off, L.count, ks))) return rc;
                 ls.bytes_algorithmic = ls.cells;
                 rc = timed(2, ls, ks, (std::string("k_bwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + (s16 ? ",s16>" : ">")).c_str(), [&] {
                     hipLaunchKernelGGL(bwd_kernel(L.cls, s16), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
@@ -1070,12 +1155,13 @@ int vpr_execute(vpr_handle *h) {
         c.slot_cur = 0; c.fail_cur = 0; c.stage_cur = 0; c.arena_cur = 0;
         return VPR_OK;
     };
-    auto lad_start = [&](LadderCtx &c, std::vector<int32_t> &fails, std::vector<int32_t> &carry) -> int {
+    // tie: the tie pass -- same level again, with the container-order replay between the forward and the backward sweep
+    auto lad_start = [&](LadderCtx &c, std::vector<int32_t> &fails, std::vector<int32_t> &carry, bool tie = false) -> int {
         if (fails.empty()) return VPR_OK;
-        n_retry += int64_t(fails.size());
+        if (!tie) n_retry += int64_t(fails.size());
         std::sort(fails.begin(), fails.end());   // deterministic planning
         std::vector<int32_t> by_lv[LV_DENSE + 1];
-        for (int32_t a : fails) by_lv[std::min<int>(h->level[size_t(a)] + 1, LV_DENSE)].push_back(a);
+        for (int32_t a : fails) by_lv[std::min<int>(h->level[size_t(a)] + (tie ? 0 : 1), LV_DENSE)].push_back(a);
         if (getenv("VPR_DEBUG"))
             fprintf(stderr, "[vpr] retry round (ladder %d): %zu -> 16, %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n",
                     int(&c - h->lad), by_lv[1].size(), by_lv[2].size(), by_lv[3].size(), by_lv[4].size(), by_lv[5].size());
@@ -1095,7 +1181,7 @@ int vpr_execute(vpr_handle *h) {
             c.hp_descs = static_cast<AlnDesc *>(pd); c.hp_work = static_cast<int32_t *>(pw); c.hp_cap = nf * 2;
         }
         bool zero_slots = true;
-        for (int lv = LV_Q16; lv <= LV_DENSE; lv++) {
+        for (int lv = tie ? LV_Z : LV_Q16; lv <= LV_DENSE; lv++) {
             if (by_lv[lv].empty()) continue;
             c.plans.emplace_back();
             Plan &P = c.plans.back();
@@ -1131,7 +1217,7 @@ int vpr_execute(vpr_handle *h) {
             zero_slots = false;
             h->dirty.insert(h->dirty.end(), P.work.begin(), P.work.end());
             if (lv == LV_DENSE) {
-                if ((rc = run_dense(P, dw, c.ls, true))) return rc;
+                if ((rc = run_dense(P, dw, c.ls, true, tie))) return rc;
             } else {
                 for (const Chunk &ch : P.chunks) {
                     if (c.slot_cur + 2 > LadderCtx::N_SLOTS) {   // out of fail slots: drain what is in flight
@@ -1147,15 +1233,21 @@ int vpr_execute(vpr_handle *h) {
                     const int32_t n_long = ch.n_long;
                     if (n_long > 0) {
                         const int slot = c.slot0 + c.slot_cur++;
-                        if ((rc = enqueue_part(P, dw, ch.work_off, n_long, lv, c.ls, slot, c.fail_base + c.fail_cur, true,
-                                               ch.part_cells[0], ch.part_in[0], ch.part_dense[0]))) return rc;
+                        for (int ph = tie ? 1 : 7; ph <= (tie ? 6 : 7); ph += 5) {   // tie: forward, replay, then the rest
+                            if ((rc = enqueue_part(P, dw, ch.work_off, n_long, lv, c.ls, slot, c.fail_base + c.fail_cur, true,
+                                                   ch.part_cells[0], ch.part_in[0], ch.part_dense[0], -1, ph))) return rc;
+                            if (tie && ph == 1 && (rc = tie_replay(P, ch.work_off, n_long, c.ls))) return rc;
+                        }
                         c.pending.emplace_back(slot, c.fail_base + c.fail_cur);
                         c.fail_cur += n_long;
                     }
                     if (ch.count > n_long) {
                         const int slot = c.slot0 + c.slot_cur++;
-                        if ((rc = enqueue_part(P, dw, ch.work_off + n_long, ch.count - n_long, lv, c.ls, slot,
-                                               c.fail_base + c.fail_cur, false, ch.part_cells[1], ch.part_in[1], ch.part_dense[1]))) return rc;
+                        for (int ph = tie ? 1 : 7; ph <= (tie ? 6 : 7); ph += 5) {
+                            if ((rc = enqueue_part(P, dw, ch.work_off + n_long, ch.count - n_long, lv, c.ls, slot,
+                                                   c.fail_base + c.fail_cur, false, ch.part_cells[1], ch.part_in[1], ch.part_dense[1], -1, ph))) return rc;
+                            if (tie && ph == 1 && (rc = tie_replay(P, ch.work_off + n_long, ch.count - n_long, c.ls))) return rc;
+                        }
                         c.pending.emplace_back(slot, c.fail_base + c.fail_cur);
                         c.fail_cur += ch.count - n_long;
                     }
@@ -1275,6 +1367,53 @@ int vpr_execute(vpr_handle *h) {
         }
     }
 
+    // ---- tie pass: alignments whose backward sweep consulted a tied swap cell were left without walk and credit
+    // (AlnOut::band_ok = TIE_MARK(level tag)).  Re-run their forward sweep at the level that accepted them, replay the
+    // reference's container order (pr_tie.hip) to fix the tied choices, then backward sweep, walk and credit as usual.
+    // A second attempt with worst-case FIFO logs takes whatever overflowed the capped ones.
+    {
+        const int na = int(h->descs.size());
+        LadderCtx &LT = h->lad[0];
+        for (int iter = 0; na > 0; iter++) {
+            HIPCHK(h, hipMemsetAsync(h->d_tie_cnt, 0, 8, st));
+            hipLaunchKernelGGL(k_collect_ties, blocks(na), dim3(256), 0, st, h->d_outs, na, h->d_tie_list, h->d_tie_cnt, h->tie_list_cap);
+            int32_t n_mark = 0;
+            HIPCHK(h, hipMemcpyAsync(&n_mark, h->d_tie_cnt, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            if (n_mark == 0) break;
+            if (iter >= 3) return fail(h, VPR_ERR_STATE, "tie pass: %d alignments still marked after %d attempts", n_mark, iter);
+            const int32_t n = std::min(n_mark, h->tie_list_cap);
+            std::vector<int2> lst;
+            lst.resize(size_t(n));
+            HIPCHK(h, hipMemcpy(lst.data(), h->d_tie_list, size_t(n) * sizeof(int2), hipMemcpyDeviceToHost));
+            std::sort(lst.begin(), lst.end(), [](const int2 &x, const int2 &y) { return x.x < y.x; });   // deterministic planning
+            std::vector<int32_t> marked, carry;
+            marked.reserve(size_t(n));
+            for (const int2 &e : lst) {
+                int lv = LV_DENSE;
+                for (int k = 0; k < LV_DENSE; k++) if (LV_TAG[k] == e.y) lv = k;
+                h->level[size_t(e.x)] = uint8_t(lv);
+                marked.push_back(e.x);
+            }
+            if (h->tie_jobs_cap < size_t(n)) {
+                void *pj = nullptr;
+                HIPCHK(h, hipHostMalloc(&pj, size_t(n) * 2 * sizeof(TieJob), hipHostMallocDefault));
+                h->pinned.push_back(pj);    // (an outgrown block stays until the batch is released: a launch may still read it)
+                h->hp_tie_jobs = static_cast<TieJob *>(pj);
+                h->tie_jobs_cap = size_t(n) * 2;
+            }
+            tie_job_cur = 0;
+            tie_full = iter > 0;
+            if (getenv("VPR_DEBUG")) fprintf(stderr, "[vpr] tie pass %d: %d alignments marked%s\n", iter, n_mark, tie_full ? " (full logs)" : "");
+            LT.ls = st; LT.slot0 = 2; LT.fail_base = int64_t(na) + na / 16 + 256;
+            if ((rc = lad_start(LT, marked, carry, true))) return rc;
+            std::vector<int32_t> rejected;
+            if ((rc = lad_flush(LT, rejected))) return rc;
+            if (!rejected.empty() || !carry.empty())
+                return fail(h, VPR_ERR_STATE, "tie pass: the re-run forward sweep rejected alignment %d", rejected.empty() ? carry[0] : rejected[0]);
+        }
+    }
+
     // K4: deferred section edit distances
     int32_t n_jobs = 0;
     HIPCHK(h, hipMemcpyAsync(&n_jobs, h->d_njobs, 4, hipMemcpyDeviceToHost, st));
@@ -1345,7 +1484,7 @@ int vpr_execute(vpr_handle *h) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, t0, t1);
     h->timing.ms_total = ms;
-    h->timing.ms_fwd = h->timing.ms_bwd = h->timing.ms_walk = h->timing.ms_ed = 0;
+    h->timing.ms_fwd = h->timing.ms_bwd = h->timing.ms_walk = h->timing.ms_ed = h->timing.ms_tie = 0;
     for (auto &e : h->events) {
         float m = 0;
         (void)hipEventElapsedTime(&m, e.a, e.b);
@@ -1354,10 +1493,12 @@ int vpr_execute(vpr_handle *h) {
         else if (e.kind == 2) h->timing.ms_bwd += m;
         else if (e.kind == 3) h->timing.ms_walk += m;
         else if (e.kind == 4) h->timing.ms_ed += m;
+        else if (e.kind == 6) h->timing.ms_tie += m;
     }
     h->timing.n_fwd_launches = n_fwd;
     h->timing.cells_touched = cells_touched;
     h->timing.n_band_retries = n_retry;
+    h->timing.n_tie_replays = n_tie_jobs;
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
     h->executed = true;

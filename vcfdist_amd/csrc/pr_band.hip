@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(64) k_bwd_band(DevBatch B, const AlnDesc *__re
     bs = -bs; dummy = D_INF;   // reuse the min scan: max(score) = -min(-score)
     wave_prefix_min2(bs, dummy);
     if (lane == 63) outs[a].beg_plane = (-bs >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
-    if (tie_used) atomicOr(&outs[a].status, VPR_ST_SWAP_TIE);
+    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(64 * C); }
 }
 
 // ===========================================================================
@@ -1152,7 +1152,7 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
     // (QUERY, 0, 0) is column 0 of row 0 = lane 63 (stripe 0 starts at the origin)
     const int bs = __builtin_amdgcn_readlane(sc1[0], 63);
     if (lane == 0) outs[a].beg_plane = (bs >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
-    if (tie_used) atomicOr(&outs[a].status, VPR_ST_SWAP_TIE);
+    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(FS_W); }
 }
 
 // ===========================================================================

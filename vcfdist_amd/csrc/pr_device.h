@@ -18,6 +18,10 @@
 #define PE 4   // PTR_VAR_END
 #define PI 8   // PTR_INS_LOC
 
+// AlnOut::band_ok of an alignment whose backward sweep consulted a tied swap cell (F_TIE): the walk / credit kernels of
+// the round skip it (they require band_ok == tag) and the host's tie pass (pr_tie.hip) picks it up
+#define TIE_MARK(tag) (-(int32_t(tag) + 1))
+
 #define D_INF 0x3f000000
 #define S_NEG (-(1 << 28))
 

@@ -316,6 +316,7 @@ __global__ void k_fwd_finish(const int32_t *__restrict__ work, int n, AlnOut *__
     AlnOut &o = outs[work[i]];
     o.s = min(o.dist_q, o.dist_r);
     o.end_plane = (o.dist_q <= o.dist_r) ? VPR_PLANE_QUERY : VPR_PLANE_REF;
+    o.band_ok = 0;   // dense level (and clears a tie mark when the tie pass re-runs the alignment)
 }
 
 // ---------------------------------------------------------------------------
@@ -594,7 +595,7 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
         lds_barrier<NT>();
     }
     if (tid == 0) outs[a].beg_plane = (sc[0][0] >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
-    if (tie_used) atomicOr(&outs[a].status, VPR_ST_SWAP_TIE);
+    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(0); }
 }
 
 // ---------------------------------------------------------------------------
@@ -825,7 +826,7 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
     AlnOut &O = outs[a];
     // my_w: level tag of the descriptors this launch may touch (0: dense), ok_tag: the tag its round's accept
     // test stores in band_ok (they differ only when a round re-runs alignments in place); see k_fwd_band_finish
-    if (d.band_pad != my_w || (my_w > 0 && O.band_ok != ok_tag)) return;
+    if (d.band_pad != my_w || (my_w > 0 ? O.band_ok != ok_tag : O.band_ok < 0)) return;   // (< 0: left to the tie pass)
     const int qi = 0, ri = 1;   // planes
     const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
     const uint8_t *qfl = B.hap_flag[d.qs] + d.q_off;
@@ -972,7 +973,7 @@ __global__ void __launch_bounds__(64) k_credit(DevBatch B, const AlnDesc *__rest
     if (a < 0) return;   // padding of a device-built work list
     const AlnDesc d = descs[a];
     AlnOut &O = outs[a];
-    if (d.band_pad != my_w || (my_w > 0 && O.band_ok != ok_tag)) return;
+    if (d.band_pad != my_w || (my_w > 0 ? O.band_ok != ok_tag : O.band_ok < 0)) return;   // (< 0: left to the tie pass)
     if (O.status & (VPR_ST_ERR_NO_PTR | VPR_ST_ERR_LIMIT)) return;   // phase A failed: n_sec is already 0
     const bool lead = !WAVE || (threadIdx.x & 63) == 0;
     credit_walk<WAVE>(B, d, O, a, paths + d.path_off, int64_t(O.path_len), 0u, secs, fp_group, jobs, n_jobs, jobs_cap, lead);

@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
     }
     // (QUERY, 0, 0) is column 0 of row 0 = lane 15 of the row (stripe 0 starts at the origin)
     if (on && gl == 15) outs[a].beg_plane = (sc1[0] >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
-    if (on && tie_used) atomicOr(&outs[a].status, VPR_ST_SWAP_TIE);
+    if (on && tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(tag); }
 }
 
 // ===========================================================================

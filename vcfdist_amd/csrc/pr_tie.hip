@@ -1,0 +1,317 @@
+// pr_tie.hip -- replay of the reference's container order for swap-predecessor ties.
+//
+// calc_prec_recall_aln keeps ONE swap predecessor per cell, "(*swap_pred_maps[i])[z] = x" (dist.cpp:347,376): when
+// several sources x reach z at the optimal cost, the last one popped from the FIFO wins.  The FIFO of wave s is seeded
+// by iterating std::unordered_set<idx1> prev_wave (dist.cpp:395; hash dist.h:42-50), so the pop order is a function
+// of libstdc++'s bucket counts, its insert-at-bucket-begin rule and its rehash history.  The window / dense forward
+// kernels cannot know that order; they keep the highest source index, set F_TIE on the cell, and the backward kernels
+// mark an alignment (AlnOut::band_ok = -(tag + 1), VPR_ST_SWAP_TIE) when such a cell is on the optimal DAG.  For those
+// alignments only, the host re-runs the forward sweep and then this kernel, which replays the reference's expansion
+// cell by cell and rewrites the choice field of every tied cell with the predecessor the reference keeps; the
+// backward sweep, walk and credit then run on the corrected flags.
+//
+// One wavefront per alignment.  What is replayed, exactly:
+//   * BFS of a wave (dist.cpp:317-381): the FIFO is a log in HBM; up to 64 entries are popped per step, lane l
+//     expands entry l (MAT child, then SWP child, as the reference pushes them).  "not done and not in curr_wave"
+//     == "never pushed before": every candidate push carries a running candidate id, an atomicMin on the cell's
+//     stamp keeps the first one, and the lanes whose id survived append their cell in id order (ballot prefix).
+//     A chunk never overtakes the FIFO: children go behind everything already queued.
+//   * pop order of two cells of one wave == order of their stamps (pushes are appended in candidate-id order), so
+//     "last writer of z" = the allowed source of z with the largest stamp among those popped in z's wave.
+//   * prev_wave iteration order (dist.cpp:395): libstdc++'s _Hashtable keeps one singly linked list; a node whose
+//     bucket is empty goes to the list head, otherwise right behind its bucket's head node; a rehash re-inserts the
+//     list in order into the new bucket array; clear() keeps the bucket count.  Inserting a_0..a_{m-1} into an empty
+//     table of B buckets therefore yields: buckets ordered by DEscending first insertion, inside a bucket
+//     DEscending insertion -- position(a_i) = #{j : first(bkt_j) > first(bkt_i)} + #{j > i : bkt_j == bkt_i} -- which
+//     is computed with two atomics passes and a suffix sum instead of chasing a list.  A wave that outgrows the
+//     bucket count B (max_load_factor 1) re-inserts the current list followed by the remaining elements into
+//     next_bkt(2 B) buckets: one more pass.  (tests/test_tie_order.py checks this model against std::unordered_set.)
+//   * seeding of the next wave (dist.cpp:395-424): INS, DEL, SUB targets of every prev_wave element in iteration order,
+//     deduplicated the same way.
+// Scratch per alignment (planned by the host): stamps, 4 B per cell of the dense (Lq + Lr) x Lt grid, preset to
+// 0xffffffff; two FIFO logs, two order buffers and three work arrays of `cap` entries; `bcap` 8-byte bucket words.
+#ifndef PR_TIE_HIP_
+#define PR_TIE_HIP_
+
+#define TIE_NEVER 0xffffffffu
+#define TIE_N_BUCKETS 26
+// bucket counts libstdc++'s _Prime_rehash_policy walks through from its first allocation when it doubles
+// (_M_next_bkt(2 * n)): measured on the image's libstdc++ (tests/test_tie_order.py re-derives it)
+#define TIE_BUCKET_LIST {13u, 29u, 59u, 127u, 257u, 541u, 1109u, 2357u, 5087u, 10273u, 20753u, 42043u, 85229u, 172933u, \
+                         351061u, 712697u, 1447153u, 2938679u, 5967347u, 12117689u, 24607243u, 49969847u, 101473717u,    \
+                         206062531u, 418451333u, 849749479u}
+__constant__ uint32_t TIE_BUCKETS[TIE_N_BUCKETS] = TIE_BUCKET_LIST;
+static const uint32_t TIE_BUCKETS_HOST[TIE_N_BUCKETS] = TIE_BUCKET_LIST;
+
+struct TieJob {
+    int32_t a;            // alignment id
+    int32_t cap;          // entries per FIFO log / order buffer (largest wave the job can hold)
+    int32_t bcap;         // bucket words available
+    int32_t pad;
+    int64_t stamp_off;    // uint32 index into the scratch: stamps[(Lq + Lr) * Lt]
+    int64_t buf_off;      // uint32 index (even): 10 * cap words
+    int64_t bkt_off;      // uint64 index: bcap words
+};
+#define TIE_BUF_WORDS 10
+
+__device__ __forceinline__ uint32_t tie_ld(const uint32_t *p) {   // coherent load (bypasses the CU's L1)
+    return __hip_atomic_load(const_cast<uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tie_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// address of the forward flag byte of cell (plane p, column x, truth row t) in the alignment's current layout,
+// nullptr outside the window
+__device__ __forceinline__ uint8_t *tie_flag_ptr(const AlnDesc &d, uint8_t *ws, const int32_t *blo_all, int p, int x, int t) {
+    if (d.band_w == 16) {   // stripe-transposed records (pr_q16.hip)
+        const int2 o = reinterpret_cast<const int2 *>(blo_all + d.blo_off)[t >> 2];
+        const int col = x - (p ? o.y : o.x);
+        if (col < 0 || col >= 16) return nullptr;
+        return ws + d.mat_off[0] + size_t(t >> 2) * 128 + p * 64 + col * 4 + (t & 3);
+    }
+    if (d.band_w > 0) {     // window rows with per-row origins (pr_band.hip, pr_wide.hip)
+        const int col = x - blo_all[d.blo_off + int64_t(p) * d.Lt + t];
+        if (col < 0 || col >= d.band_w) return nullptr;
+        return ws + d.mat_off[p] + size_t(t) * d.pitch[p] + col;
+    }
+    return ws + d.mat_off[p] + size_t(t) * d.pitch[p] + x;   // dense
+}
+
+__global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__restrict__ descs,
+                                                   const TieJob *__restrict__ jobs, int n_jobs, uint8_t *ws,
+                                                   const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs,
+                                                   uint32_t *scratch, int32_t *__restrict__ n_overflow) {
+    const int j = blockIdx.x;
+    if (j >= n_jobs) return;
+    const TieJob J = jobs[j];
+    const int a = J.a;
+    const AlnDesc d = descs[a];
+    const int lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
+    const int s_fin = outs[a].s;
+    const uint8_t *seq0 = B.hap_seq[d.qs] + d.q_off, *seq1 = B.ref_seq + d.r_off;
+    const int32_t *ptr0 = B.hap_ptr[d.qs] + d.q_off, *ptr1 = B.ref_ptr[d.qs] + d.r_off;
+    const uint8_t *flg0 = B.hap_flag[d.qs] + d.q_off, *flg1 = B.ref_flag[d.qs] + d.r_off;
+    const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off, *Tf = B.hap_flag[d.ts] + d.t_off;
+    const int4 *cand0 = B.cand_q[d.qs] + d.q_off, *cand1 = B.cand_r[d.qs] + d.r_off;
+
+    uint32_t *stamp = scratch + J.stamp_off;
+    uint32_t *buf = scratch + J.buf_off;
+    const int cap = J.cap;
+    uint2 *qc = reinterpret_cast<uint2 *>(buf), *qn = reinterpret_cast<uint2 *>(buf + 2 * size_t(cap));
+    uint32_t *oc = buf + 4 * size_t(cap), *on = buf + 5 * size_t(cap);
+    uint32_t *Fa = buf + 6 * size_t(cap), *Ha = buf + 7 * size_t(cap), *Ka = buf + 8 * size_t(cap);
+    unsigned long long *bfirst = reinterpret_cast<unsigned long long *>(scratch) + J.bkt_off;
+    const uint32_t sbase1 = uint32_t(Lq) * uint32_t(Lt);
+    auto sidx = [&](int p, int q, int t) -> uint32_t { return (p ? sbase1 : 0u) + uint32_t(q) * uint32_t(Lt) + uint32_t(t); };
+    const unsigned long long hi_q = (unsigned long long)(2 * d.aln) * 73856093ull + 0x517cc1b727220a95ull;       // dist.h:45
+    const unsigned long long hi_r = (unsigned long long)(2 * d.aln + 1) * 73856093ull + 0x517cc1b727220a95ull;
+
+    // wave 0: the two start cells (dist.cpp:300-305), candidate ids 0 and 1
+    if (lane == 0) {
+        qc[0] = make_uint2(0u, 0u);
+        qc[1] = make_uint2(0x80000000u, 0u);
+        stamp[0] = 0u;
+        stamp[sbase1] = 1u;
+    }
+    tie_wait();
+    uint32_t cid = 2;               // next candidate id
+    uint32_t n_bkt = TIE_BUCKETS[0];   // prev_wave's bucket count (the first insert allocates 13)
+    int bi = 0;
+    uint32_t tag = 0;               // order() invocation counter (tags the bucket words)
+    int n_cur = 2;
+    bool fail = (cap < 2);
+
+    uint32_t wave_lo = 0;           // candidate ids of the current wave start here
+    for (int w = 0; !fail; w++) {
+        // ---- BFS: pop up to 64 entries, expand, append (dist.cpp:317-381)
+        int head = 0;
+        while (head < n_cur) {
+            const int n = min(64, n_cur - head);
+            const bool act = lane < n;
+            uint2 x = make_uint2(0u, 0u);
+            if (act) { const uint32_t *px = reinterpret_cast<const uint32_t *>(qc + head + lane); x.x = tie_ld(px); x.y = tie_ld(px + 1); }
+            const int p = int(x.x >> 31), q = int(x.x & 0x7fffffffu), t = int(x.y);
+            const int Lme = p ? Lr : Lq, Loth = p ? Lq : Lr;
+            bool ty = false, tz = false;
+            uint32_t iy = 0, iz = 0;
+            int zq = 0;
+            if (act && t + 1 < Lt) {
+                const uint8_t tb = Ts[t + 1];
+                if (q + 1 < Lme && (p ? seq1 : seq0)[q + 1] == tb) { ty = true; iy = sidx(p, q + 1, t + 1); }
+                zq = (p ? ptr1 : ptr0)[q] + 1;
+                const int fx = (p ? flg1 : flg0)[q], ft = Tf[t];
+                if (fwd_allow(fx) && fwd_allow(ft) && zq >= 0 && zq < Loth && (p ? seq0 : seq1)[zq] == tb) {
+                    tz = true;
+                    iz = sidx(1 - p, zq, t + 1);
+                }
+            }
+            const uint32_t cy = cid + 2u * uint32_t(lane), cz = cy + 1u;
+            if (ty) (void)atomicMin(stamp + iy, cy);
+            if (tz) (void)atomicMin(stamp + iz, cz);
+            tie_wait();
+            const bool wy = ty && tie_ld(stamp + iy) == cy;
+            const bool wz = tz && tie_ld(stamp + iz) == cz;
+            const unsigned long long by = __ballot(wy), bz = __ballot(wz);
+            const int tot = __popcll(by) + __popcll(bz);
+            if (n_cur + tot > cap) { fail = true; break; }
+            const int py = n_cur + __popcll(by & lt_mask) + __popcll(bz & lt_mask);
+            if (wy) qc[py] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1));
+            if (wz) qc[py + (wy ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1));
+            tie_wait();
+            n_cur += tot;
+            head += n;
+            cid += 2u * uint32_t(n);
+            if (cid > 0xf0000000u) { fail = true; break; }
+        }
+        if (fail) break;
+        // ---- tied cells popped in this wave: the allowed source popped last wins (dist.cpp:347,376)
+        for (int i0 = 0; i0 < n_cur; i0 += 64) {
+            const int i = i0 + lane;
+            if (i >= n_cur) continue;
+            const uint2 z = qc[i];
+            const int p = int(z.x >> 31), xq = int(z.x & 0x7fffffffu), t = int(z.y);
+            if (t == 0) continue;
+            uint8_t *fp = tie_flag_ptr(d, ws, blo_all, p, xq, t);
+            if (!fp) continue;
+            const uint32_t f = *fp;
+            if ((f & (F_SWP | F_TIE)) != (F_SWP | F_TIE)) continue;
+            const int4 cc = (p ? cand1 : cand0)[xq];
+            const int srcs[4] = {cc.x, cc.y, cc.z, cc.w};
+            int best = -1;
+            uint32_t best_st = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (srcs[k] < 0) continue;
+                const uint32_t st = tie_ld(stamp + sidx(1 - p, srcs[k], t - 1));
+                if (st == TIE_NEVER || st < wave_lo) continue;       // not popped in z's wave
+                if (best < 0 || st > best_st) { best = k; best_st = st; }
+            }
+            if (best >= 0) *fp = uint8_t((f & ~uint32_t((3u << F_CHOICE_SHIFT) | F_TIE)) | (uint32_t(best) << F_CHOICE_SHIFT));
+        }
+        if (w >= s_fin) break;
+
+        // ---- iteration order of prev_wave = the n_cur cells of qc in pop order (see the header)
+        const int n = n_cur;
+        int done = 0;
+        bool have_lam = false;      // oc holds the list order of the first `done` elements
+        while (true) {
+            const int room = int(n_bkt) - done;
+            const int take = min(room, n - done);
+            const int m = done + take;
+            tag++;
+            const unsigned long long tagw = (unsigned long long)(~tag) << 32;
+            // pass A: bucket of every element, first insertion per bucket; H / K cleared
+            for (int i0 = 0; i0 < m; i0 += 64) {
+                const int i = i0 + lane;
+                if (i >= m) continue;
+                const uint32_t e = (have_lam && i < done) ? oc[i] : uint32_t(i);
+                const uint2 c = qc[e];
+                const unsigned long long hv = ((c.x >> 31) ? hi_r : hi_q) ^
+                                              ((unsigned long long)(c.x & 0x7fffffffu) * 19349669ull + 0xd15f392b3d4704a2ull) ^
+                                              ((unsigned long long)(c.y) * 83492791ull);
+                const uint32_t b = uint32_t(hv % (unsigned long long)n_bkt);
+                Fa[i] = b;
+                Ha[i] = 0u;
+                Ka[i] = 0u;
+                (void)atomicMin(bfirst + b, tagw | (unsigned long long)uint32_t(i));
+            }
+            tie_wait();
+            // pass B: F_i = first insertion index of the element's bucket; histogram of F
+            for (int i0 = 0; i0 < m; i0 += 64) {
+                const int i = i0 + lane;
+                if (i >= m) continue;
+                const uint32_t b = tie_ld(Fa + i);
+                const unsigned long long fw = __hip_atomic_load(bfirst + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t f = uint32_t(fw & 0xffffffffull);
+                Fa[i] = f;
+                (void)atomicAdd(Ha + f, 1u);
+            }
+            tie_wait();
+            // exclusive suffix sum over H: G[f] = elements in buckets created after f
+            {
+                uint32_t run = 0;
+                for (int i0 = (m - 1) & ~63; i0 >= 0; i0 -= 64) {
+                    const int i = i0 + lane;
+                    const uint32_t hcnt = (i < m) ? tie_ld(Ha + i) : 0u;
+                    uint32_t suf = hcnt;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t tv = uint32_t(__shfl_down(int(suf), o));
+                        if (lane + o < 64) suf += tv;
+                    }
+                    if (i < m) Ha[i] = run + suf - hcnt;
+                    run += uint32_t(__shfl(int(suf), 0));
+                }
+            }
+            tie_wait();
+            // pass C, descending: position = G[F_i] + elements of the same bucket inserted later
+            for (int i0 = (m - 1) & ~63; i0 >= 0; i0 -= 64) {
+                const int i = i0 + lane;
+                const bool act = i < m;
+                const uint32_t f = act ? tie_ld(Fa + i) : 0xffffffffu;
+                const uint32_t base = act ? tie_ld(Ka + f) : 0u;
+                const uint32_t g = act ? tie_ld(Ha + f) : 0u;
+                uint32_t intra = 0;
+                for (int l2 = 1; l2 < 64; l2++) {
+                    const uint32_t v = uint32_t(__builtin_amdgcn_readlane(int(f), l2));
+                    intra += (l2 > lane && v == f) ? 1u : 0u;
+                }
+                tie_wait();
+                if (act) {
+                    const uint32_t e = (have_lam && i < done) ? oc[i] : uint32_t(i);
+                    on[g + base + intra] = e;
+                    (void)atomicAdd(Ka + f, 1u);
+                }
+                tie_wait();
+            }
+            { uint32_t *tmp = oc; oc = on; on = tmp; }
+            have_lam = true;
+            done = m;
+            if (done == n) break;
+            if (bi + 1 >= TIE_N_BUCKETS || TIE_BUCKETS[bi + 1] > uint32_t(J.bcap)) { fail = true; break; }
+            n_bkt = TIE_BUCKETS[++bi];
+        }
+        if (fail) break;
+
+        // ---- next wave: INS, DEL, SUB targets of every popped cell, in iteration order (dist.cpp:395-424)
+        int n_next = 0;
+        wave_lo = cid;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            const bool act = k < n;
+            uint2 x = make_uint2(0u, 0u);
+            if (act) x = qc[tie_ld(oc + k)];
+            const int p = int(x.x >> 31), q = int(x.x & 0x7fffffffu), t = int(x.y);
+            const int Lme = p ? Lr : Lq;
+            const bool t0 = act && q + 1 < Lme, t1 = act && t + 1 < Lt, t2 = t0 && t1;
+            const uint32_t c0 = cid + 3u * uint32_t(lane);
+            const uint32_t i0_ = t0 ? sidx(p, q + 1, t) : 0u, i1_ = t1 ? sidx(p, q, t + 1) : 0u, i2_ = t2 ? sidx(p, q + 1, t + 1) : 0u;
+            if (t0) (void)atomicMin(stamp + i0_, c0);
+            if (t1) (void)atomicMin(stamp + i1_, c0 + 1u);
+            if (t2) (void)atomicMin(stamp + i2_, c0 + 2u);
+            tie_wait();
+            const bool w0 = t0 && tie_ld(stamp + i0_) == c0;
+            const bool w1 = t1 && tie_ld(stamp + i1_) == c0 + 1u;
+            const bool w2 = t2 && tie_ld(stamp + i2_) == c0 + 2u;
+            const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1), b2 = __ballot(w2);
+            const int tot = __popcll(b0) + __popcll(b1) + __popcll(b2);
+            if (n_next + tot > cap) { fail = true; break; }
+            int pos = n_next + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask);
+            if (w0) qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t));
+            if (w1) qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q), uint32_t(t + 1));
+            if (w2) qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1));
+            n_next += tot;
+            cid += 3u * uint32_t(min(64, n - k0));
+            if (cid > 0xf0000000u) { fail = true; break; }
+        }
+        if (fail) break;
+        tie_wait();
+        { uint2 *tmp = qc; qc = qn; qn = tmp; }
+        n_cur = n_next;
+        if (n_cur == 0) { fail = true; break; }   // "Empty queue" (dist.cpp:314): cannot happen for an accepted alignment
+    }
+    if (fail && lane == 0) atomicAdd(n_overflow, 1);
+}
+
+#endif

@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
     }
     // (QUERY, 0, 0) is column 0 of row 0 (stripe 0 starts at the origin): the last thread
     if (tid == W - 1) outs[a].beg_plane = (sc1[0] >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
-    if (tie_used) atomicOr(&outs[a].status, VPR_ST_SWAP_TIE);
+    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(W); }
 }
 
 #endif
