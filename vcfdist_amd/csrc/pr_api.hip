@@ -891,43 +891,58 @@ int vpr_execute(vpr_handle *h) {
     int64_t n_tie_jobs = 0;
     auto tie_replay = [&](const Plan &P, int64_t off, int32_t cnt, hipStream_t ks) -> int {
         if (tie_job_cur + size_t(cnt) > h->tie_jobs_cap) return fail(h, VPR_ERR_STATE, "tie pass: job buffer overflow");
+        // scratch words of every job; the scratch grows to hold the whole launch (all replays concurrent: a long one is a
+        // latency chain), bounded by half of the free memory -- beyond that the launch is cut into sub-batches
+        struct Need { int64_t cells, cap, bcap, w_st, w_buf, w_bk; };
+        std::vector<Need> needs{};
+        needs.resize(size_t(cnt));
+        int64_t total = 0, largest = 0;
+        for (int32_t k = 0; k < cnt; k++) {
+            const AlnDesc &d = P.descs[size_t(off) + k];
+            Need &N = needs[size_t(k)];
+            N.cells = int64_t(d.Lq + d.Lr) * d.Lt;
+            if (N.cells >= (int64_t(1) << 32) - 2)
+                return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d: (Lq + Lr) * Lt = %lld cells exceed the tie replay's 32-bit cell index",
+                            d.sc, d.aln, (long long)N.cells);
+            N.cap = tie_full ? N.cells : std::min<int64_t>(N.cells, 16 * int64_t(d.Lq + d.Lr + d.Lt) + 4096);
+            N.cap = std::max<int64_t>(2, std::min<int64_t>(N.cap, int64_t(1) << 26));
+            int bi = 0;
+            while (bi + 1 < TIE_N_BUCKETS && int64_t(TIE_BUCKETS_HOST[bi]) < N.cap) bi++;
+            N.bcap = TIE_BUCKETS_HOST[bi];
+            N.w_st = (N.cells + 1) & ~int64_t(1); N.w_buf = TIE_BUF_WORDS * N.cap; N.w_bk = 2 * N.bcap;
+            const int64_t need = N.w_st + N.w_buf + N.w_bk;
+            total += need;
+            largest = std::max(largest, need);
+        }
+        if (total * 4 > h->tie_scratch_bytes) {
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(h, hipStreamSynchronize(ks));
+            if (h->d_tie_scratch) (void)hipFree(h->d_tie_scratch);
+            h->d_tie_scratch = nullptr; h->tie_scratch_bytes = 0;
+            HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+            const int64_t nb = std::max<int64_t>(std::min<int64_t>(total * 4, int64_t(free_b / 2)), largest * 4) + 256;
+            void *q = nullptr;
+            if (hipMalloc(&q, size_t(nb)) != hipSuccess)
+                return fail(h, VPR_ERR_NOMEM, "tie replay scratch (%lld bytes)", (long long)nb);
+            h->d_tie_scratch = static_cast<uint32_t *>(q);
+            h->tie_scratch_bytes = nb;
+        }
         int32_t k0 = 0;
         while (k0 < cnt) {
-            // sub-batch [k0, k1) that fits the scratch (a single job larger than the scratch grows it)
+            // sub-batch [k0, k1) that fits the scratch
             int64_t words = 0;
             int32_t k1 = k0;
             TieJob *jobs = h->hp_tie_jobs + tie_job_cur;
             while (k1 < cnt) {
-                const AlnDesc &d = P.descs[size_t(off) + k1];
-                const int64_t cells = int64_t(d.Lq + d.Lr) * d.Lt;
-                if (cells >= (int64_t(1) << 32) - 2)
-                    return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d: (Lq + Lr) * Lt = %lld cells exceed the tie replay's 32-bit cell index",
-                                d.sc, d.aln, (long long)cells);
-                int64_t cap = tie_full ? cells : std::min<int64_t>(cells, 16 * int64_t(d.Lq + d.Lr + d.Lt) + 4096);
-                cap = std::max<int64_t>(2, std::min<int64_t>(cap, int64_t(1) << 26));
-                int bi = 0;
-                while (bi + 1 < TIE_N_BUCKETS && int64_t(TIE_BUCKETS_HOST[bi]) < cap) bi++;
-                const int64_t bcap = TIE_BUCKETS_HOST[bi];
-                const int64_t w_st = (cells + 1) & ~int64_t(1), w_buf = TIE_BUF_WORDS * cap, w_bk = 2 * bcap;
-                const int64_t need = w_st + w_buf + w_bk;
+                const Need &N = needs[size_t(k1)];
+                const int64_t need = N.w_st + N.w_buf + N.w_bk;
                 if (k1 > k0 && (words + need) * 4 > h->tie_scratch_bytes) break;
-                if ((words + need) * 4 > h->tie_scratch_bytes) {   // first job of the sub-batch: grow
-                    HIPCHK(h, hipStreamSynchronize(ks));
-                    if (h->d_tie_scratch) (void)hipFree(h->d_tie_scratch);
-                    h->d_tie_scratch = nullptr;
-                    const int64_t nb = std::max<int64_t>(need * 4 + 256, int64_t(256) << 20);
-                    void *q = nullptr;
-                    if (hipMalloc(&q, size_t(nb)) != hipSuccess)
-                        return fail(h, VPR_ERR_NOMEM, "tie replay scratch (%lld bytes) for supercluster %d alignment %d", (long long)nb, d.sc, d.aln);
-                    h->d_tie_scratch = static_cast<uint32_t *>(q);
-                    h->tie_scratch_bytes = nb;
-                }
                 TieJob &J = jobs[k1 - k0];
                 J.a = P.work[size_t(off) + k1];
-                J.cap = int32_t(cap); J.bcap = int32_t(std::min<int64_t>(bcap, 0x7fffffff)); J.pad = 0;
+                J.cap = int32_t(N.cap); J.bcap = int32_t(std::min<int64_t>(N.bcap, 0x7fffffff)); J.pad = 0;
                 J.stamp_off = words;
-                J.buf_off = words + w_st;
-                J.bkt_off = (words + w_st + w_buf) / 2;   // (all three terms are even)
+                J.buf_off = words + N.w_st;
+                J.bkt_off = (words + N.w_st + N.w_buf) / 2;   // (all three terms are even)
                 words += need;
                 k1++;
             }
@@ -1409,6 +1424,20 @@ int vpr_execute(vpr_handle *h) {
             if ((rc = lad_start(LT, marked, carry, true))) return rc;
             std::vector<int32_t> rejected;
             if ((rc = lad_flush(LT, rejected))) return rc;
+            if (getenv("VPR_DEBUG")) {   // the slowest replays
+                HIPCHK(h, hipStreamSynchronize(st));
+                std::vector<TieJob> js(h->hp_tie_jobs, h->hp_tie_jobs + tie_job_cur);
+                std::sort(js.begin(), js.end(), [](const TieJob &x, const TieJob &y) { return x.dbg_us > y.dbg_us; });
+                int64_t tot_us = 0;
+                for (const TieJob &J : js) tot_us += J.dbg_us;
+                fprintf(stderr, "[vpr] tie replay: %zu jobs, %.1f ms summed\n", js.size(), tot_us / 1000.0);
+                for (size_t k = 0; k < js.size() && k < 12; k++) {
+                    const AlnDesc &d = h->descs[size_t(js[k].a)];
+                    fprintf(stderr, "[vpr]   sc %d aln %d Lq %d Lr %d Lt %d level %d: %d us, %d waves, %d BFS steps, %d cells; wave 0: %d steps, %d tot!=n, %d unstable, %d single\n", d.sc, d.aln,
+                            d.Lq, d.Lr, d.Lt, int(h->level[size_t(js[k].a)]), js[k].dbg_us, js[k].dbg_waves, js[k].dbg_steps, js[k].dbg_cells,
+                            js[k].dbg_w0steps, js[k].dbg_totne, js[k].dbg_unstable, js[k].dbg_lev1);
+                }
+            }
             if (!rejected.empty() || !carry.empty())
                 return fail(h, VPR_ERR_STATE, "tie pass: the re-run forward sweep rejected alignment %d", rejected.empty() ? carry[0] : rejected[0]);
         }

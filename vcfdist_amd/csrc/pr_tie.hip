@@ -51,6 +51,7 @@ struct TieJob {
     int64_t stamp_off;    // uint32 index into the scratch: stamps[(Lq + Lr) * Lt]
     int64_t buf_off;      // uint32 index (even): 10 * cap words
     int64_t bkt_off;      // uint64 index: bcap words
+    int32_t dbg_us, dbg_steps, dbg_cells, dbg_waves, dbg_w0steps, dbg_totne, dbg_unstable, dbg_lev1;   // written by the kernel (the jobs live in host-pinned memory): VPR_DEBUG
 };
 #define TIE_BUF_WORDS 10
 
@@ -77,7 +78,7 @@ __device__ __forceinline__ uint8_t *tie_flag_ptr(const AlnDesc &d, uint8_t *ws, 
 }
 
 __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__restrict__ descs,
-                                                   const TieJob *__restrict__ jobs, int n_jobs, uint8_t *ws,
+                                                   TieJob *__restrict__ jobs, int n_jobs, uint8_t *ws,
                                                    const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs,
                                                    uint32_t *scratch, int32_t *__restrict__ n_overflow) {
     const int j = blockIdx.x;
@@ -89,6 +90,8 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int s_fin = outs[a].s;
+    const unsigned long long clk0 = wall_clock64();
+    int dbg_steps = 0, dbg_cells = 0, dbg_waves = 0, dbg_w0steps = 0, dbg_totne = 0, dbg_unstable = 0, dbg_lev1 = 0;
     const uint8_t *seq0 = B.hap_seq[d.qs] + d.q_off, *seq1 = B.ref_seq + d.r_off;
     const int32_t *ptr0 = B.hap_ptr[d.qs] + d.q_off, *ptr1 = B.ref_ptr[d.qs] + d.r_off;
     const uint8_t *flg0 = B.hap_flag[d.qs] + d.q_off, *flg1 = B.ref_flag[d.qs] + d.r_off;
@@ -128,15 +131,24 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
         int head = 0;
         while (head < n_cur) {
             const int n = min(64, n_cur - head);
-            const bool act = lane < n;
+            // Narrow stretches (a lone run of matches behind the last edit; all of wave 0) are chains of levels of a few
+            // cells each.  When the chunk is the whole queue and all its cells sit in one truth row, lanes j * n + i look
+            // ahead at slot i of level j (the slot's cell moved j steps down its diagonal).  Level j only touches row
+            // t + j + 1, which no earlier level of the batch touches, so if every slot's candidate pushes are valid /
+            // invalid / already pushed exactly as on level 0 and its swap target moves along, level j repeats level 0's
+            // outcome, and all those levels are committed at once.
+            const bool ff = (head + n == n_cur) && (n <= 32);
+            const int nk = ff ? 64 / n : 1;
+            const int jl = ff ? lane / n : 0, il = ff ? lane - jl * n : lane;
+            const bool act = lane < nk * n;
             uint2 x = make_uint2(0u, 0u);
-            if (act) { const uint32_t *px = reinterpret_cast<const uint32_t *>(qc + head + lane); x.x = tie_ld(px); x.y = tie_ld(px + 1); }
-            const int p = int(x.x >> 31), q = int(x.x & 0x7fffffffu), t = int(x.y);
+            if (act) { const uint32_t *px = reinterpret_cast<const uint32_t *>(qc + head + il); x.x = tie_ld(px); x.y = tie_ld(px + 1); }
+            const int p = int(x.x >> 31), q = int(x.x & 0x7fffffffu) + jl, t = int(x.y) + jl;
             const int Lme = p ? Lr : Lq, Loth = p ? Lq : Lr;
             bool ty = false, tz = false;
             uint32_t iy = 0, iz = 0;
             int zq = 0;
-            if (act && t + 1 < Lt) {
+            if (act && t + 1 < Lt && q < Lme) {
                 const uint8_t tb = Ts[t + 1];
                 if (q + 1 < Lme && (p ? seq1 : seq0)[q + 1] == tb) { ty = true; iy = sidx(p, q + 1, t + 1); }
                 zq = (p ? ptr1 : ptr0)[q] + 1;
@@ -146,22 +158,55 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                     iz = sidx(1 - p, zq, t + 1);
                 }
             }
+            const bool l0 = lane < n;                 // the lanes of the level actually popped now
             const uint32_t cy = cid + 2u * uint32_t(lane), cz = cy + 1u;
-            if (ty) (void)atomicMin(stamp + iy, cy);
-            if (tz) (void)atomicMin(stamp + iz, cz);
+            uint32_t oy = TIE_NEVER, oz = TIE_NEVER;
+            if (l0 && ty) oy = atomicMin(stamp + iy, cy);
+            if (l0 && tz) oz = atomicMin(stamp + iz, cz);
             tie_wait();
-            const bool wy = ty && tie_ld(stamp + iy) == cy;
-            const bool wz = tz && tie_ld(stamp + iz) == cz;
+            const uint32_t vy = ty ? tie_ld(stamp + iy) : 0u, vz = tz ? tie_ld(stamp + iz) : 0u;
+            const bool wy = l0 && ty && vy == cy;
+            const bool wz = l0 && tz && vz == cz;
             const unsigned long long by = __ballot(wy), bz = __ballot(wz);
             const int tot = __popcll(by) + __popcll(bz);
             if (n_cur + tot > cap) { fail = true; break; }
-            const int py = n_cur + __popcll(by & lt_mask) + __popcll(bz & lt_mask);
-            if (wy) qc[py] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1));
-            if (wz) qc[py + (wy ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1));
+            const int ry = __popcll(by & lt_mask) + __popcll(bz & lt_mask);    // rank of this lane's first winner
+            int nlev = 1;
+            const bool one_row = !__any(l0 && int(x.y) != __shfl(int(x.y), 0));
+            if (w == 0) { dbg_w0steps++; if (!ff || tot != n) dbg_totne++; }
+            if (ff && one_row && tot == n && n_cur + nk * n <= cap) {
+                // level 0 must reproduce the frontier, slot by slot, one step down the diagonals
+                const uint32_t ycode = x.x + 1u, zcode = (uint32_t(1 - p) << 31) | uint32_t(zq);
+                const uint32_t sy = uint32_t(__shfl(int(x.x), ry)) + 1u, sz = uint32_t(__shfl(int(x.x), ry + (wy ? 1 : 0))) + 1u;
+                const bool stable = !__any((wy && ycode != sy) || (wz && zcode != sz));
+                if (!stable) dbg_unstable++;
+                if (stable) {
+                    // outcome class of a candidate push: 0 invalid, 1 pushed, 2 same cell as an earlier candidate of the
+                    // level, 3 cell pushed before this level
+                    const int ky = !ty ? 0 : (wy ? 1 : (oy < cid ? 3 : 2)), kz = !tz ? 0 : (wz ? 1 : (oz < cid ? 3 : 2));
+                    const int ky0 = __shfl(ky, il), kz0 = __shfl(kz, il), zq0 = __shfl(zq, il);
+                    // a look-ahead lane has only read its targets' stamps: untouched (classes 1, 2) or not (class 3)
+                    const bool same = (ty == (ky0 != 0)) && (tz == (kz0 != 0)) && (!tz || zq == zq0 + jl) &&
+                                      (!ty || ((vy == TIE_NEVER) == (ky0 != 3))) && (!tz || ((vz == TIE_NEVER) == (kz0 != 3)));
+                    const unsigned long long bad = __ballot(act && !l0 && !same);
+                    nlev = bad ? int(__builtin_ctzll(bad)) / n : nk;
+                    if (nlev == 1) dbg_lev1++;
+                    const int ry0 = __shfl(ry, il);
+                    if (jl >= 1 && jl < nlev) {
+                        const uint32_t c0 = cid + 2u * uint32_t(n) * uint32_t(jl) + 2u * uint32_t(il);
+                        const int pos = n_cur + jl * n + ry0;
+                        if (ky0 == 1) { stamp[iy] = c0; qc[pos] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); }
+                        if (kz0 == 1) { stamp[iz] = c0 + 1u; qc[pos + (ky0 == 1 ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1)); }
+                    }
+                }
+            }
+            if (wy) qc[n_cur + ry] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1));
+            if (wz) qc[n_cur + ry + (wy ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1));
             tie_wait();
-            n_cur += tot;
-            head += n;
-            cid += 2u * uint32_t(n);
+            n_cur += tot * nlev;
+            head += n * nlev;
+            dbg_steps++;
+            cid += 2u * uint32_t(n) * uint32_t(nlev);
             if (cid > 0xf0000000u) { fail = true; break; }
         }
         if (fail) break;
@@ -189,6 +234,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             }
             if (best >= 0) *fp = uint8_t((f & ~uint32_t((3u << F_CHOICE_SHIFT) | F_TIE)) | (uint32_t(best) << F_CHOICE_SHIFT));
         }
+        dbg_cells += n_cur; dbg_waves++;
         if (w >= s_fin) break;
 
         // ---- iteration order of prev_wave = the n_cur cells of qc in pop order (see the header)
@@ -312,6 +358,11 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
         if (n_cur == 0) { fail = true; break; }   // "Empty queue" (dist.cpp:314): cannot happen for an accepted alignment
     }
     if (fail && lane == 0) atomicAdd(n_overflow, 1);
+    if (lane == 0) {
+        jobs[j].dbg_us = int32_t((wall_clock64() - clk0) / 100);   // 100 MHz counter
+        jobs[j].dbg_steps = dbg_steps; jobs[j].dbg_cells = dbg_cells; jobs[j].dbg_waves = dbg_waves;
+        jobs[j].dbg_w0steps = dbg_w0steps; jobs[j].dbg_totne = dbg_totne; jobs[j].dbg_unstable = dbg_unstable; jobs[j].dbg_lev1 = dbg_lev1;
+    }
 }
 
 #endif
