@@ -150,8 +150,9 @@ typedef struct vpr_config {
                                   2 = as 1 but starting at the 64-cell window; 3 = as 1 without the
                                   zero-distance first round.  1 (the default) first tries the 16-cell
                                   zero-distance sweep, which accepts alignments with s = 0 only */
-    int32_t reserved;
+    int32_t flags;             /* VPR_CFG_* (0 = defaults) */
 } vpr_config;
+#define VPR_CFG_DENSE_S16 1     /* test aid: the dense backward sweep always uses its int16 score rows */
 
 /* Results: the fields precision_recall_wrapper writes in place
    (ctgVariants::{errtypes,sync_group,credit,ref_ed,query_ed,callq}, src/variant.h:49-60;

@@ -58,7 +58,7 @@ class VprConfig(C.Structure):
     _fields_ = [
         ("device", C.c_int32), ("max_qual", C.c_float),
         ("credit_threshold", C.c_double), ("phase_threshold", C.c_double),
-        ("workspace_bytes", C.c_int64), ("band_mode", C.c_int32), ("reserved", C.c_int32),
+        ("workspace_bytes", C.c_int64), ("band_mode", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -70,6 +70,9 @@ class VprResults(C.Structure):
         ("credit", (P_f32 * 2) * HAPS), ("ref_ed", (P_i32 * 2) * HAPS),
         ("query_ed", (P_i32 * 2) * HAPS), ("callq", (P_f32 * 2) * HAPS),
     ]
+
+
+CFG_DENSE_S16 = 1   # VPR_CFG_DENSE_S16
 
 
 class VprTiming(C.Structure):
@@ -101,10 +104,10 @@ class VprSynthParams(C.Structure):
     ]
 
 
-def default_config(device=0, band_mode=1, workspace_bytes=0):
+def default_config(device=0, band_mode=1, workspace_bytes=0, flags=0):
     """The reference's defaults: globals.h:27 (max_qual), :49 (credit), :46 (phase)."""
     return VprConfig(device=device, max_qual=60.0, credit_threshold=0.7, phase_threshold=0.6,
-                     workspace_bytes=workspace_bytes, band_mode=band_mode, reserved=0)
+                     workspace_bytes=workspace_bytes, band_mode=band_mode, flags=flags)
 
 
 def _ptr(a, ctype):

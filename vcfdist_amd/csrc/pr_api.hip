@@ -19,6 +19,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/vcfdist_pr.h"
@@ -44,8 +45,8 @@ const size_t LDS_MAX = 160 * 1024;
 enum { LV_Z = 0, LV_Q16 = 1, LV_C1 = 2, LV_C4 = 3, LV_C16 = 4, LV_DENSE = 5 };
 const int LV_WINDOW[] = {16, 16, 64, 256, 1024, 0};   // window width = flag layout of the level
 const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnDesc::band_pad that marks the level
-// truth rows from which an alignment is a latency chain (VPR_LONG_LT: experiments only)
-static const int LONG_LT = [] { const char *e = getenv("VPR_LONG_LT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+// truth rows from which an alignment is a latency chain
+const int LONG_LT = 512;
 
 struct Launch { int cls; int64_t work_off; int32_t count; };   // dense: one k_fwd/k_bwd launch of a class
 struct Chunk {
@@ -84,12 +85,14 @@ struct LadderCtx {
 };
 
 struct EvPair { hipEvent_t a, b; int kind; vpr_launch_stat st; };
+const int TIE_DEC_SLOTS = 64;     // early-replay launches per execute that can keep a decision list
 
 }  // namespace
 
 struct vpr_handle {
     vpr_config cfg;
     std::string err;
+    bool debug = false;                  // VPR_DEBUG in the environment at vpr_create: progress lines on stderr
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -110,8 +113,10 @@ struct vpr_handle {
     AlnDesc *d_descs = nullptr;
     AlnOut *d_outs = nullptr;
     uint8_t *d_arena = nullptr; int64_t arena_bytes = 0;      // workspace of the round-0 plan
-    LadderCtx lad[2];                                         // retry ladders (their workspaces live beside the arena)
-    hipEvent_t ev_slot[2 + 2 * LadderCtx::N_SLOTS] = {};      // "fail list of slot k is complete"
+    LadderCtx lad[3];                                         // two retry ladders + the tie rounds (own workspaces, beside the arena)
+    hipEvent_t ev_slot[2 + 3 * LadderCtx::N_SLOTS] = {};      // "fail list of slot k is complete"
+    hipStream_t tie_stream = nullptr;                         // tie rounds (latency chains: high priority)
+    hipEvent_t ev_tie[2] = {nullptr, nullptr};                // "the tie list of the long / short part of round 0 is published"
     std::vector<std::pair<std::vector<int32_t>, uint8_t *>> resident;   // alignments whose walks are still in a workspace
     Section *d_secs = nullptr; int64_t n_secs_cap = 0;
     int32_t *d_fp[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -121,10 +126,16 @@ struct vpr_handle {
     int32_t *d_fail = nullptr, *d_cnt = nullptr;   // fail lists + their counters
     // tie pass (pr_tie.hip): list of marked alignments {id, level tag}, counters {marked, replay overflows}, the jobs of
     // the replay launches (host-pinned, read by the kernel directly) and the replay scratch (grown on demand)
-    int2 *d_tie_list = nullptr; int32_t tie_list_cap = 0;
-    int32_t *d_tie_cnt = nullptr;
+    int4 *d_tie_list = nullptr, *hp_tie_list = nullptr; int32_t tie_list_cap = 0;   // {alignment, level tag, consulted ties, 0}
+    // completion flags in host-pinned memory, written by one-thread kernels behind the work they stand for: the host
+    // polls plain memory instead of HIP events (hipEventQuery in a tight loop delays the very submissions it waits for)
+    int32_t *hp_flag = nullptr; int32_t flag_seq = 0;
+    int32_t *d_tie_cnt = nullptr, *hp_tie_cnt = nullptr;     // [0] final pass, [1] replay overflows, [2] long part, [3] short part
     TieJob *hp_tie_jobs = nullptr; size_t tie_jobs_cap = 0;
     uint32_t *d_tie_scratch = nullptr; int64_t tie_scratch_bytes = 0;
+    int4 *d_tie_dec = nullptr; int64_t tie_dec_cap = 0;       // decision lists of the early replays (one region per launch)
+    int32_t *d_tie_ndec = nullptr;                            // their lengths [TIE_DEC_SLOTS]
+    std::vector<int32_t> plan0_pos;                           // position of every alignment in plan0's work list
     // host-pinned, device-visible mirrors of d_fail / d_cnt: a publish kernel on the producing stream fills them, so the
     // host reads a fail list after an event wait and issues no copy that the bulk kernels of the round could starve
     int32_t *hp_fail = nullptr, *hp_cnt = nullptr;
@@ -184,7 +195,7 @@ void free_batch(vpr_handle *h) {
     h->allocs.clear();
     for (void *p : h->pinned) (void)hipHostFree(p);
     h->pinned.clear();
-    h->hp_fail = nullptr; h->hp_cnt = nullptr;
+    h->hp_fail = nullptr; h->hp_cnt = nullptr; h->hp_flag = nullptr;
     for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     h->events.clear();
     h->descs.clear();
@@ -192,13 +203,14 @@ void free_batch(vpr_handle *h) {
     h->dirty.clear();
     h->d_arena = nullptr; h->d_secs = nullptr;
     for (int k = 0; k < 4; k++) h->d_cls[k] = nullptr;
-    for (int k = 0; k < 2; k++) h->lad[k] = LadderCtx();
+    for (int k = 0; k < 3; k++) h->lad[k] = LadderCtx();
     h->resident.clear();
     h->d_ed_scratch = nullptr; h->ed_scratch_ints = 0;
-    h->d_tie_list = nullptr; h->tie_list_cap = 0; h->d_tie_cnt = nullptr;
+    h->d_tie_list = nullptr; h->hp_tie_list = nullptr; h->tie_list_cap = 0; h->d_tie_cnt = nullptr; h->hp_tie_cnt = nullptr;
     h->hp_tie_jobs = nullptr; h->tie_jobs_cap = 0;
     if (h->d_tie_scratch) (void)hipFree(h->d_tie_scratch);
     h->d_tie_scratch = nullptr; h->tie_scratch_bytes = 0;
+    h->d_tie_dec = nullptr; h->tie_dec_cap = 0; h->d_tie_ndec = nullptr; h->plan0_pos.clear();
     h->uploaded = h->executed = false;
 }
 
@@ -258,23 +270,12 @@ AlnKernel bwd_kernel(int cls, bool s16 = false) {
     }
 }
 typedef void (*BandFwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, int32_t *, AlnOut *);
-typedef void (*BandBwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, const int32_t *, AlnOut *);
-BandFwd band_fwd_kernel(int lv) {
-    switch (lv) {
-        case LV_C1:   // 64-cell window: striped, register-resident variant (VPR_NO_STRIPE=1 selects the ring variant)
-            return getenv("VPR_NO_STRIPE") ? BandFwd(k_fwd_band<1, true>) : BandFwd(k_fwd_stripe);
-        case LV_C4: return getenv("VPR_NO_WIDE") ? BandFwd(k_fwd_band<4, true>) : BandFwd(k_fwd_wide<4>);
-        default: return getenv("VPR_NO_WIDE") ? BandFwd(k_fwd_band<16, true>) : BandFwd(k_fwd_wide<16>);
-    }
-}
-BandBwd band_bwd_kernel(int lv) {
-    switch (lv) {
-        case LV_C1:   // needs the stripe origins written by k_fwd_stripe
-            return (getenv("VPR_NO_STRIPE") || getenv("VPR_NO_STRIPE_BWD")) ? BandBwd(k_bwd_band<1>) : BandBwd(k_bwd_stripe);
-        case LV_C4: return getenv("VPR_NO_WIDE") ? BandBwd(k_bwd_band<4>) : BandBwd(k_bwd_wide<4>);
-        default: return getenv("VPR_NO_WIDE") ? BandBwd(k_bwd_band<16>) : BandBwd(k_bwd_wide<16>);
-    }
-}
+typedef void (*BandBwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, const int32_t *, AlnOut *, int);
+// one-alignment-per-workgroup window kernels: 64 cells (one wave, striped), 256 and 1024 cells (4 / 16 waves)
+BandFwd band_fwd_kernel(int lv) { return lv == LV_C1 ? BandFwd(k_fwd_stripe) : lv == LV_C4 ? BandFwd(k_fwd_wide<4>) : BandFwd(k_fwd_wide<16>); }
+BandBwd band_bwd_kernel(int lv) { return lv == LV_C1 ? BandBwd(k_bwd_stripe) : lv == LV_C4 ? BandBwd(k_bwd_wide<4>) : BandBwd(k_bwd_wide<16>); }
+const char *band_fwd_name(int lv) { return lv == LV_Z ? "k_fwd_z16" : lv == LV_Q16 ? "k_fwd_q16" : lv == LV_C1 ? "k_fwd_stripe" : lv == LV_C4 ? "k_fwd_wide<4>" : "k_fwd_wide<16>"; }
+const char *band_bwd_name(int lv) { return lv == LV_Z ? "k_bwd_q16<zero>" : lv == LV_Q16 ? "k_bwd_q16" : lv == LV_C1 ? "k_bwd_stripe" : lv == LV_C4 ? "k_bwd_wide<4>" : "k_bwd_wide<16>"; }
 
 int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -333,13 +334,38 @@ __global__ void k_stage(const AlnDesc *__restrict__ src, const int32_t *__restri
 }
 
 // alignments the backward sweeps left to the tie pass: {alignment, level tag} (AlnOut::band_ok = TIE_MARK(tag))
-__global__ void k_collect_ties(const AlnOut *__restrict__ outs, int n, int2 *__restrict__ list, int32_t *__restrict__ cnt, int cap) {
+__global__ void k_collect_ties(const AlnOut *__restrict__ outs, int n, int4 *__restrict__ list, int32_t *__restrict__ cnt, int cap) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int b = outs[i].band_ok;
     if (b >= 0) return;
     const int k = atomicAdd(cnt, 1);
-    if (k < cap) list[k] = make_int2(i, -b - 1);
+    if (k < cap) list[k] = make_int4(i, -b - 1, outs[i].n_sec, 0);
+}
+
+// the same over a work list (the long / short part of round 0, right behind its backward sweep)
+__global__ void k_collect_ties_list(const int32_t *__restrict__ work, int n, const AlnOut *__restrict__ outs, int4 *__restrict__ list,
+                                    int32_t *__restrict__ cnt, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int a = work[i];
+    if (a < 0) return;
+    const int b = outs[a].band_ok;
+    if (b >= 0) return;
+    const int k = atomicAdd(cnt, 1);
+    if (k < cap) list[k] = make_int4(a, -b - 1, outs[a].n_sec, 0);
+}
+__global__ void k_publish_ties(const int4 *__restrict__ list, const int32_t *__restrict__ cnt, int4 *__restrict__ h_list,
+                               int32_t *__restrict__ h_cnt, int cap) {
+    const int n = min(*cnt, cap);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) h_list[i] = list[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *h_cnt = *cnt;
+    __threadfence_system();
+}
+
+__global__ void k_flag(int32_t *__restrict__ h_flag, int32_t v) {
+    *h_flag = v;
+    __threadfence_system();
 }
 
 __global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc *__restrict__ dst) {
@@ -351,7 +377,8 @@ __global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc 
 
 // Assign arena offsets (flag matrices, band origins, walk scratch) to `alns` and cut them into chunks
 // that fit the arena.  lv: window level of the plan (LV_DENSE: dense layout + kernel classes).
-int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, uint8_t *arena, int64_t arena_bytes) {
+// tag_or: TIE_TAG_BIT for the plan of a tie round (see pr_device.h), else 0
+int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, uint8_t *arena, int64_t arena_bytes, int tag_or = 0) {
     P = Plan();
     P.lv = lv;
     P.arena = arena;
@@ -432,7 +459,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             if (need > arena_bytes)
                 return fail(h, VPR_ERR_NOMEM, "workspace (%lld bytes) too small for supercluster %d alignment %d (%lld bytes)",
                             (long long)arena_bytes, d.sc, d.aln, (long long)need);
-            d.band_pad = LV_TAG[dl];
+            d.band_pad = LV_TAG[dl] | tag_or;
             d.mat_off[0] = used;
             d.mat_off[1] = used + m0;
             d.blo_off = (used + m0 + m1) / 4;            // int index into the arena
@@ -503,6 +530,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
         return fail(nullptr, VPR_ERR_ARG, "device %d out of range (have %d)", cfg->device, ndev);
     vpr_handle *h = new vpr_handle();
     h->cfg = *cfg;
+    h->debug = getenv("VPR_DEBUG") != nullptr;
     memset(&h->dB, 0, sizeof(h->dB));
     memset(&h->timing, 0, sizeof(h->timing));
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
@@ -520,9 +548,13 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
             return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
         }
     }
-    for (int k = 0; k < 2 + 2 * LadderCtx::N_SLOTS; k++)
+    for (int k = 0; k < 2 + 3 * LadderCtx::N_SLOTS; k++)
         if (hipEventCreateWithFlags(&h->ev_slot[k], hipEventDisableTiming) != hipSuccess)
             return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
+    if (hipStreamCreateWithPriority(&h->tie_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_tie[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_tie[1], hipEventDisableTiming) != hipSuccess)
+        return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess)
         return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     // allow the big dense classes to use the whole 160 KiB LDS of a CU
@@ -548,8 +580,10 @@ void vpr_destroy(vpr_handle *h) {
         if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (int k = 0; k < 2 + 2 * LadderCtx::N_SLOTS; k++)
+    for (int k = 0; k < 2 + 3 * LadderCtx::N_SLOTS; k++)
         if (h->ev_slot[k]) (void)hipEventDestroy(h->ev_slot[k]);
+    if (h->tie_stream) (void)hipStreamDestroy(h->tie_stream);
+    for (int k = 0; k < 2; k++) if (h->ev_tie[k]) (void)hipEventDestroy(h->ev_tie[k]);
     delete h;
 }
 
@@ -560,7 +594,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     free_batch(h);
     const int n = b->n_sc;
     h->n_sc = n;
-    const bool dbg = getenv("VPR_DEBUG") != nullptr;
+    const bool dbg = h->debug;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double T0 = now();
     auto lap = [&](const char *what) { if (dbg) { (void)hipDeviceSynchronize(); fprintf(stderr, "[vpr] upload %-28s %.3f s\n", what, now() - T0); } };
@@ -717,19 +751,30 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     R.phase_threshold = h->cfg.phase_threshold;
     h->tie_list_cap = int32_t(std::min<size_t>(std::max<size_t>(na, 1), size_t(1) << 20));
     if ((rc = dev_alloc(h, &h->d_tie_list, size_t(h->tie_list_cap)))) return rc;
-    if ((rc = dev_alloc(h, &h->d_tie_cnt, 2))) return rc;
-    // fail lists: round 0 in [0, na + na/16 + 256) (a list that feeds a kernel directly is padded), retry rounds behind
-    if ((rc = dev_alloc(h, &h->d_fail, 2 * na + na / 16 + 512))) return rc;
-    if ((rc = dev_alloc(h, &h->d_cnt, 2 + 2 * LadderCtx::N_SLOTS))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tie_cnt, 4))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tie_ndec, TIE_DEC_SLOTS))) return rc;
+    // fail lists: round 0 in [0, na + na/16 + 256) (a list that feeds a kernel directly is padded), the retry rounds of
+    // the two ladders behind, the tie rounds' (which reject nothing) last
+    const size_t n_fail = 3 * na + na / 16 + 768, n_slots = 2 + 3 * LadderCtx::N_SLOTS;
+    if ((rc = dev_alloc(h, &h->d_fail, n_fail))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cnt, n_slots))) return rc;
     {
-        void *pf = nullptr, *pc = nullptr;
-        HIPCHK(h, hipHostMalloc(&pf, (2 * na + na / 16 + 512) * sizeof(int32_t), hipHostMallocDefault));
+        void *pf = nullptr, *pc = nullptr, *pl = nullptr, *pt = nullptr;
+        HIPCHK(h, hipHostMalloc(&pf, n_fail * sizeof(int32_t), hipHostMallocDefault));
         h->pinned.push_back(pf);
-        HIPCHK(h, hipHostMalloc(&pc, (2 + 2 * LadderCtx::N_SLOTS) * sizeof(int32_t), hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc(&pc, n_slots * sizeof(int32_t), hipHostMallocDefault));
         h->pinned.push_back(pc);
+        HIPCHK(h, hipHostMalloc(&pl, size_t(h->tie_list_cap) * sizeof(int4), hipHostMallocDefault));
+        h->pinned.push_back(pl);
+        HIPCHK(h, hipHostMalloc(&pt, 16 * sizeof(int32_t), hipHostMallocDefault));
+        h->pinned.push_back(pt);
         h->hp_fail = static_cast<int32_t *>(pf);
         h->hp_cnt = static_cast<int32_t *>(pc);
-        memset(h->hp_cnt, 0, (2 + 2 * LadderCtx::N_SLOTS) * sizeof(int32_t));
+        h->hp_tie_list = static_cast<int4 *>(pl);
+        h->hp_tie_cnt = static_cast<int32_t *>(pt);
+        h->hp_flag = h->hp_tie_cnt + 4;     // [0..1] fail lists of round 0, [2..3] tie lists, [4..6] ladders + tie rounds idle
+        memset(h->hp_cnt, 0, n_slots * sizeof(int32_t));
+        memset(h->hp_tie_cnt, 0, 16 * sizeof(int32_t));
     }
 
     lap("result/aux allocations");
@@ -742,7 +787,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     int64_t want = 0;
     {
         const int bm = h->cfg.band_mode;
-        const bool q16ok = (bm == 1 || bm == 3) && !getenv("VPR_NO_Q16");
+        const bool q16ok = (bm == 1 || bm == 3);
         for (const AlnDesc &d : h->descs) {
             int64_t flags;
             if (bm != 0 && q16ok && d.Lt < LONG_LT) {
@@ -767,7 +812,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         int64_t b2 = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes
                                                 : std::min<int64_t>(int64_t(double(free_b) * 0.25), std::max<int64_t>(want / 16, int64_t(1) << 30));
         if (b2 < (8 << 20)) b2 = 8 << 20;
-        for (int k = 0; k < (h->cfg.band_mode != 0 ? 2 : 1); k++) {   // (dense mode: only the tie pass needs one)
+        for (int k = (h->cfg.band_mode != 0 ? 0 : 2); k < 3; k++) {   // (dense mode: only the tie rounds need one)
             h->lad[k].arena_bytes = b2;
             if ((rc = dev_alloc(h, &h->lad[k].arena, size_t(b2) + 256))) return rc;
         }
@@ -779,10 +824,12 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     for (size_t k = 0; k < na; k++) all[k] = int32_t(k);
     h->level.assign(na, uint8_t(LV_DENSE));
     const int lv0 = h->cfg.band_mode == 0 ? LV_DENSE
-                    : (h->cfg.band_mode == 2 || getenv("VPR_NO_Q16")) ? LV_C1
-                    : (h->cfg.band_mode == 3 || getenv("VPR_NO_Z")) ? LV_Q16 : LV_Z;
+                    : h->cfg.band_mode == 2 ? LV_C1
+                    : h->cfg.band_mode == 3 ? LV_Q16 : LV_Z;
     if ((rc = make_plan(h, all, lv0, h->plan0, h->d_arena, h->arena_bytes))) return rc;
     h->level0 = h->level;
+    h->plan0_pos.assign(na, 0);
+    for (size_t k = 0; k < na; k++) h->plan0_pos[size_t(h->plan0.work[k])] = int32_t(k);
     if ((rc = dev_alloc(h, &h->plan0.d_descs, na))) return rc;
     if ((rc = dev_alloc(h, &h->plan0.d_work, na))) return rc;
     if (na) {
@@ -858,6 +905,20 @@ int vpr_execute(vpr_handle *h) {
         h->events.push_back(ev);
         return VPR_OK;
     };
+    // (measured: without one blocking call here the runtime does not start this call's submissions for 0.1 - 2 s when the
+    // host goes straight to polling memory below, e.g. right behind another library's work on the device)
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const auto wall0 = std::chrono::steady_clock::now();
+    auto lapx = [&](const char *what) {
+        if (h->debug) fprintf(stderr, "[vpr] execute %-34s %8.3f ms\n", what,
+                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
+    };
+    int32_t flag_exp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto post_flag = [&](int idx, hipStream_t ks) {     // "everything enqueued on ks so far is complete" -> hp_flag[idx]
+        flag_exp[idx] = ++h->flag_seq;
+        hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, ks, h->hp_flag + idx, flag_exp[idx]);
+    };
+    auto flag_up = [&](int idx) -> bool { return *static_cast<volatile int32_t *>(h->hp_flag + idx) == flag_exp[idx]; };
     hipEvent_t t0, t1;
     HIPCHK(h, hipEventCreate(&t0));
     HIPCHK(h, hipEventCreate(&t1));
@@ -883,29 +944,40 @@ int vpr_execute(vpr_handle *h) {
         });
     };
 
-    // ---- tie pass only (pr_tie.hip): replay the reference's container order for `cnt` alignments of plan P from work
-    // list position `off`, whose forward sweep has just been re-run on stream ks; rewrites the choice of their tied cells.
-    // tie_full: FIFO logs sized for the worst case (second attempt, after a capped job overflowed).
+    // ---- tie rounds only (pr_tie.hip): replay the reference's container order for the `cnt` alignments of plan P from
+    // work list position `off`.  early = true: the jobs of the alignments in tie_early (still resident in the workspace
+    // of the round that marked them), launched BEFORE their forward sweep is repeated -- they read that round's
+    // backward-sweep bytes, decide only the consulted ties and stop early; their decisions are applied by tie_patch once
+    // the flags exist again.  early = false: all other alignments of the part, behind the repeated forward sweep, patched
+    // in place.  tie_full: FIFO logs sized for the worst case (second attempt, after a capped job overflowed).
     bool tie_full = false;
     size_t tie_job_cur = 0;
     int64_t n_tie_jobs = 0;
-    auto tie_replay = [&](const Plan &P, int64_t off, int32_t cnt, hipStream_t ks) -> int {
-        if (tie_job_cur + size_t(cnt) > h->tie_jobs_cap) return fail(h, VPR_ERR_STATE, "tie pass: job buffer overflow");
+    int tie_dec_slot = 0;                          // decision lists handed out in this execute
+    int64_t tie_dec_cur = 0;
+    struct TieEarly { int32_t n_used; int32_t pos; const Plan *plan; };
+    std::unordered_map<int32_t, TieEarly> tie_early;   // alignment -> where the bytes of its marking round are
+    int tie_patch_slot = -1; int64_t tie_patch_off = 0, tie_patch_cap = 0;   // decision list of the last early launch
+    auto tie_replay = [&](const Plan &P, int64_t off, int32_t cnt, hipStream_t ks, bool early) -> int {
+        if (early) tie_patch_slot = -1;
         // scratch words of every job; the scratch grows to hold the whole launch (all replays concurrent: a long one is a
         // latency chain), bounded by half of the free memory -- beyond that the launch is cut into sub-batches
-        struct Need { int64_t cells, cap, bcap, w_st, w_buf, w_bk; };
+        struct Need { int32_t k; int64_t cells, cap, bcap, w_st, w_buf, w_bk; };
         std::vector<Need> needs{};
-        needs.resize(size_t(cnt));
-        int64_t total = 0, largest = 0;
+        needs.reserve(size_t(cnt));
+        int64_t total = 0, largest = 0, dec_need = 0;
         for (int32_t k = 0; k < cnt; k++) {
             const AlnDesc &d = P.descs[size_t(off) + k];
-            Need &N = needs[size_t(k)];
+            const auto it = tie_early.find(P.work[size_t(off) + k]);
+            if ((it != tie_early.end()) != early) continue;
+            Need N;
+            N.k = k;
             N.cells = int64_t(d.Lq + d.Lr) * d.Lt;
             if (N.cells >= (int64_t(1) << 32) - 2)
                 return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d: (Lq + Lr) * Lt = %lld cells exceed the tie replay's 32-bit cell index",
                             d.sc, d.aln, (long long)N.cells);
             N.cap = tie_full ? N.cells : std::min<int64_t>(N.cells, 16 * int64_t(d.Lq + d.Lr + d.Lt) + 4096);
-            N.cap = std::max<int64_t>(2, std::min<int64_t>(N.cap, int64_t(1) << 26));
+            N.cap = (std::max<int64_t>(2, std::min<int64_t>(N.cap, int64_t(1) << 26)) + 1) & ~int64_t(1);   // even: 8-byte entries follow
             int bi = 0;
             while (bi + 1 < TIE_N_BUCKETS && int64_t(TIE_BUCKETS_HOST[bi]) < N.cap) bi++;
             N.bcap = TIE_BUCKETS_HOST[bi];
@@ -913,7 +985,11 @@ int vpr_execute(vpr_handle *h) {
             const int64_t need = N.w_st + N.w_buf + N.w_bk;
             total += need;
             largest = std::max(largest, need);
+            if (early) dec_need += it->second.n_used;
+            needs.push_back(N);
         }
+        if (needs.empty()) return VPR_OK;
+        if (tie_job_cur + needs.size() > h->tie_jobs_cap) return fail(h, VPR_ERR_STATE, "tie round: job buffer overflow");
         if (total * 4 > h->tie_scratch_bytes) {
             size_t free_b = 0, total_b = 0;
             HIPCHK(h, hipStreamSynchronize(ks));
@@ -927,45 +1003,83 @@ int vpr_execute(vpr_handle *h) {
             h->d_tie_scratch = static_cast<uint32_t *>(q);
             h->tie_scratch_bytes = nb;
         }
-        int32_t k0 = 0;
-        while (k0 < cnt) {
+        // decision list of an early launch: one region of the decision buffer, its length in a counter of its own
+        int4 *dec = nullptr;
+        int32_t *n_dec = h->d_tie_ndec;
+        int64_t dec_cap = 0;
+        if (early) {
+            dec_cap = dec_need + 64;
+            if (tie_dec_slot >= TIE_DEC_SLOTS) return fail(h, VPR_ERR_STATE, "tie round: out of decision lists");
+            if (tie_dec_cur + dec_cap > h->tie_dec_cap) {      // (a region handed out earlier may still be in use: keep the old block)
+                const int64_t nc = std::max<int64_t>(2 * (tie_dec_cur + dec_cap), 1 << 16);
+                int rc_ = dev_alloc(h, &h->d_tie_dec, size_t(nc));
+                if (rc_) return rc_;
+                h->tie_dec_cap = nc;
+                tie_dec_cur = 0;
+            }
+            dec = h->d_tie_dec + tie_dec_cur;
+            n_dec = h->d_tie_ndec + tie_dec_slot;
+            tie_patch_slot = tie_dec_slot++; tie_patch_off = tie_dec_cur; tie_patch_cap = dec_cap;
+            tie_dec_cur += dec_cap;
+        }
+        size_t k0 = 0;
+        while (k0 < needs.size()) {
             // sub-batch [k0, k1) that fits the scratch
             int64_t words = 0;
-            int32_t k1 = k0;
+            size_t k1 = k0;
             TieJob *jobs = h->hp_tie_jobs + tie_job_cur;
-            while (k1 < cnt) {
-                const Need &N = needs[size_t(k1)];
+            while (k1 < needs.size()) {
+                const Need &N = needs[k1];
                 const int64_t need = N.w_st + N.w_buf + N.w_bk;
                 if (k1 > k0 && (words + need) * 4 > h->tie_scratch_bytes) break;
                 TieJob &J = jobs[k1 - k0];
-                J.a = P.work[size_t(off) + k1];
-                J.cap = int32_t(N.cap); J.bcap = int32_t(std::min<int64_t>(N.bcap, 0x7fffffff)); J.pad = 0;
+                memset(&J, 0, sizeof(J));
+                J.a = P.work[size_t(off) + N.k];
+                J.cap = int32_t(N.cap); J.bcap = int32_t(std::min<int64_t>(N.bcap, 0x7fffffff));
                 J.stamp_off = words;
                 J.buf_off = words + N.w_st;
                 J.bkt_off = (words + N.w_st + N.w_buf) / 2;   // (all three terms are even)
+                if (early) {
+                    const TieEarly &E = tie_early[J.a];
+                    const AlnDesc &o = E.plan->descs[size_t(E.pos)];
+                    J.mode = 1; J.n_used = E.n_used;
+                    J.old_band_w = o.band_w; J.old_pitch[0] = o.pitch[0]; J.old_pitch[1] = o.pitch[1];
+                    J.old_mat_off[0] = o.mat_off[0]; J.old_mat_off[1] = o.mat_off[1]; J.old_blo_off = o.blo_off;
+                    J.old_arena = E.plan->arena;
+                }
                 words += need;
                 k1++;
             }
-            const int32_t nj = k1 - k0;
+            const int32_t nj = int32_t(k1 - k0);
             tie_job_cur += size_t(nj);
             n_tie_jobs += nj;
             HIPCHK(h, hipMemsetAsync(h->d_tie_scratch, 0xff, size_t(words) * 4, ks));
             vpr_launch_stat ts_;
             memset(&ts_, 0, sizeof(ts_));
-            ts_.threads = 64; ts_.n_units = nj;
-            int rc = timed(6, ts_, ks, "k_tie_replay", [&] {
+            ts_.threads = 64; ts_.n_units = nj; ts_.cells_per_thread = early ? 1 : 0;
+            int rc = timed(6, ts_, ks, early ? "k_tie_replay<early>" : "k_tie_replay", [&] {
                 hipLaunchKernelGGL(k_tie_replay, dim3(nj), dim3(64), 0, ks, h->dB, h->d_descs, jobs, nj, P.arena,
-                                   reinterpret_cast<const int32_t *>(P.arena), h->d_outs, h->d_tie_scratch, h->d_tie_cnt + 1);
+                                   reinterpret_cast<const int32_t *>(P.arena), h->d_outs, h->d_tie_scratch, h->d_tie_cnt + 1,
+                                   dec, n_dec, int(dec_cap));
             });
             if (rc) return rc;
             k0 = k1;
         }
         return VPR_OK;
     };
+    // apply the decisions of the part's early replays to the flags its repeated forward sweep has just written
+    auto tie_patch = [&](const Plan &P, hipStream_t ks) -> int {
+        if (tie_patch_slot < 0) return VPR_OK;
+        hipLaunchKernelGGL(k_tie_patch, blocks(tie_patch_cap), dim3(256), 0, ks, h->d_descs, h->d_tie_dec + tie_patch_off,
+                           h->d_tie_ndec + tie_patch_slot, int(tie_patch_cap), P.arena);
+        tie_patch_slot = -1;
+        return VPR_OK;
+    };
 
     // ---- dense plan: per chunk, each kernel class runs K1 -> K2 -> K3 on its own stream (forked from and
     // joined into `base`); one_stream: everything on `base` (retry rounds that run beside other work)
-    auto run_dense = [&](const Plan &P, const int32_t *d_work, hipStream_t base, bool one_stream, bool tie = false) -> int {
+    // tag_or: TIE_TAG_BIT when the plan belongs to a tie round (forward sweep, container-order replay, then the rest)
+    auto run_dense = [&](const Plan &P, const int32_t *d_work, hipStream_t base, bool one_stream, int tag_or = 0) -> int {
         for (const Chunk &ch : P.chunks) {
             if (!one_stream) HIPCHK(h, hipEventRecord(h->ev_fork, base));
             for (const Launch &L : ch.launches) {
@@ -978,8 +1092,8 @@ int vpr_execute(vpr_handle *h) {
                 ls.threads = K.nt; ls.cells_per_thread = K.c; ls.n_units = L.count;
                 int64_t in_bytes = 0;
                 // the backward launch uses int16 score rows when a member's int32 rows do not fit LDS (make_plan
-                // has checked that the int16 rows do and that the scores are in range); VPR_DENSE_S16 forces it
-                bool s16 = getenv("VPR_DENSE_S16") != nullptr;
+                // has checked that the int16 rows do and that the scores are in range); vpr_config.flags bit 0 forces it
+                bool s16 = (h->cfg.flags & VPR_CFG_DENSE_S16) != 0;
                 for (int32_t w = 0; w < L.count; w++) {
                     const AlnDesc &d = P.descs[L.work_off + w];
                     if (bwd_lds_bytes(L.cls, d.Lq, d.Lr) > LDS_MAX) s16 = true;
@@ -998,22 +1112,24 @@ int vpr_execute(vpr_handle *h) {
                 cells_touched += ls.cells;
                 ls.cells_dense = ls.cells;
                 ls.bytes_algorithmic = ls.cells + in_bytes;
-                int rc = timed(1, ls, ks, (std::string("k_fwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + ">").c_str(), [&] {
+                int rc = VPR_OK;
+                if (tag_or && (rc = tie_replay(P, L.work_off, L.count, ks, true))) return rc;
+                rc = timed(1, ls, ks, (std::string("k_fwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + ">").c_str(), [&] {
                     hipLaunchKernelGGL(fwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_f, ks, h->dB, h->d_descs,
                                        d_work + L.work_off, P.arena, h->d_outs);
                     hipLaunchKernelGGL(k_fwd_finish, dim3((L.count + 255) / 256), dim3(256), 0, ks,
-                                       d_work + L.work_off, L.count, h->d_outs);
+                                       d_work + L.work_off, L.count, h->d_outs, tag_or);
                 });
                 if (rc) return rc;
                 n_fwd++;
-                if (tie && (rc = tie_replay(P, L.work_off, L.count, ks))) return rc;
+                if (tag_or && ((rc = tie_replay(P, L.work_off, L.count, ks, false)) || (rc = tie_patch(P, ks)))) return rc;
                 ls.bytes_algorithmic = ls.cells;
                 rc = timed(2, ls, ks, (std::string("k_bwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + (s16 ? ",s16>" : ">")).c_str(), [&] {
                     hipLaunchKernelGGL(bwd_kernel(L.cls, s16), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
                                        d_work + L.work_off, P.arena, h->d_outs);
                 });
                 if (rc) return rc;
-                if ((rc = walk_launch(P, d_work + L.work_off, L.count, ks, false, 0))) return rc;
+                if ((rc = walk_launch(P, d_work + L.work_off, L.count, ks, false, tag_or))) return rc;
                 if (!one_stream) {
                     HIPCHK(h, hipEventRecord(h->ev_join[L.cls], ks));
                     HIPCHK(h, hipStreamWaitEvent(base, h->ev_join[L.cls], 0));
@@ -1030,11 +1146,12 @@ int vpr_execute(vpr_handle *h) {
     auto enqueue_part = [&](const Plan &P, const int32_t *d_work, int64_t off, int32_t cnt, int lv, hipStream_t ks,
                             int slot, int64_t fail_off, bool long_part, int64_t part_cells, int64_t part_in,
                             int64_t part_dense, int dtag_override = -1, int phases = 7,
-                            const int32_t *n_dev = nullptr, int32_t n_all = 0) -> int {
+                            const int32_t *n_dev = nullptr, int32_t n_all = 0, int tag_or = 0) -> int {
         // phases: 1 = forward sweep + accept test + fail list, 2 = backward sweep, 4 = walk + credit.
         // n_dev: device-side length of a device-built work list; cnt is then the cap of entries processed and
         // n_all the most entries the list can hold (the fail list scans all of them).
-        const int W = LV_WINDOW[lv], C = W / 64, tag = LV_TAG[lv];
+        // tag_or: TIE_TAG_BIT for a tie round (its descriptors and its accept test carry the level tag with that bit)
+        const int W = LV_WINDOW[lv], C = W / 64, tag = LV_TAG[lv] | tag_or;
         const bool q16 = lv <= LV_Q16, zero = lv == LV_Z;
         const int dtag = dtag_override >= 0 ? dtag_override : tag;   // tag carried by the descriptors of the list
         const int32_t *list = d_work + off;
@@ -1049,7 +1166,7 @@ int vpr_execute(vpr_handle *h) {
         int rc = VPR_OK;
         if (phases & 1) {
         cells_touched += ls.cells;
-        rc = timed(1, ls, ks, zero ? "k_fwd_z16" : q16 ? "k_fwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") ? "k_fwd_stripe" : (lv == LV_C1 ? "k_fwd_band<1>" : (getenv("VPR_NO_WIDE") ? (lv == LV_C4 ? "k_fwd_band<4>" : "k_fwd_band<16>") : (lv == LV_C4 ? "k_fwd_wide<4>" : "k_fwd_wide<16>")))), [&] {
+        rc = timed(1, ls, ks, band_fwd_name(lv), [&] {
             if (zero)
                 hipLaunchKernelGGL(k_fwd_z16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);
@@ -1057,7 +1174,7 @@ int vpr_execute(vpr_handle *h) {
                 hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);
             else
-                hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3((lv >= LV_C4 && !getenv("VPR_NO_WIDE")) ? W : 64), 0,
+                hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3(lv >= LV_C4 ? W : 64), 0,
                                    ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs);
             hipLaunchKernelGGL(k_fwd_band_finish, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs, tag, n_dev);
         });
@@ -1075,7 +1192,7 @@ int vpr_execute(vpr_handle *h) {
         }
         if (phases & 2) {
         ls.bytes_algorithmic = ls.cells;
-        rc = timed(2, ls, ks, zero ? "k_bwd_q16<zero>" : q16 ? "k_bwd_q16" : (lv == LV_C1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") ? "k_bwd_stripe" : (lv == LV_C1 ? "k_bwd_band<1>" : (getenv("VPR_NO_WIDE") ? (lv == LV_C4 ? "k_bwd_band<4>" : "k_bwd_band<16>") : (lv == LV_C4 ? "k_bwd_wide<4>" : "k_bwd_wide<16>")))), [&] {
+        rc = timed(2, ls, ks, band_bwd_name(lv), [&] {
             if (zero)
                 hipLaunchKernelGGL(k_bwd_q16<true>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, tag, dtag, n_dev);
@@ -1083,16 +1200,15 @@ int vpr_execute(vpr_handle *h) {
                 hipLaunchKernelGGL(k_bwd_q16<false>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, tag, dtag, n_dev);
             else
-                hipLaunchKernelGGL(band_bwd_kernel(lv), dim3(cnt), dim3((lv >= LV_C4 && !getenv("VPR_NO_WIDE")) ? W : 64), 0,
-                                   ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs);
+                hipLaunchKernelGGL(band_bwd_kernel(lv), dim3(cnt), dim3(lv >= LV_C4 ? W : 64), 0,
+                                   ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs, tag);
         });
         if (rc) return rc;
         }
         if (!(phases & 4)) return rc;
         // long part (or a small launch of long retries): wave-per-alignment walk; windows up to 256
         const bool wave_walk = !q16 && C <= 4 && (long_part || cnt < 2048);
-        const bool row_walk = lv == LV_C1 && !getenv("VPR_NO_STRIPE") && !getenv("VPR_NO_STRIPE_BWD") &&
-                              !getenv("VPR_NO_ROWWALK") && (wave_walk || getenv("VPR_ROWWALK_ALL"));
+        const bool row_walk = lv == LV_C1 && wave_walk;
         vpr_launch_stat ws_;
         memset(&ws_, 0, sizeof(ws_));
         ws_.threads = q16 ? 16 : 64; ws_.n_units = cnt; ws_.cells_per_thread = 2;
@@ -1114,7 +1230,7 @@ int vpr_execute(vpr_handle *h) {
             // short ones the per-wave setup outweighs the pointer chase of the lane-per-alignment walk
             rc = timed(3, ws_, ks, "k_walk_rows", [&] {
                 hipLaunchKernelGGL(k_walk_rows, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                   P.arena, a_i32, h->d_outs, a_path);
+                                   P.arena, a_i32, h->d_outs, a_path, tag);
             });
             if (rc) return rc;
             ws_.cells_per_thread = 3;
@@ -1141,7 +1257,7 @@ int vpr_execute(vpr_handle *h) {
         if (nf > 0) {
             const size_t f0 = fails.size();
             fails.insert(fails.end(), h->hp_fail + fail_off, h->hp_fail + fail_off + nf);
-            if (getenv("VPR_DEBUG") && nf <= 64) {
+            if (h->debug && nf <= 64) {
                 for (size_t k = f0; k < fails.size(); k++) {
                     const int32_t a = fails[k];
                     AlnOut o;
@@ -1177,10 +1293,14 @@ int vpr_execute(vpr_handle *h) {
         std::sort(fails.begin(), fails.end());   // deterministic planning
         std::vector<int32_t> by_lv[LV_DENSE + 1];
         for (int32_t a : fails) by_lv[std::min<int>(h->level[size_t(a)] + (tie ? 0 : 1), LV_DENSE)].push_back(a);
-        if (getenv("VPR_DEBUG"))
+        if (h->debug)
             fprintf(stderr, "[vpr] retry round (ladder %d): %zu -> 16, %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n",
                     int(&c - h->lad), by_lv[1].size(), by_lv[2].size(), by_lv[3].size(), by_lv[4].size(), by_lv[5].size());
         const size_t nf = fails.size();
+        if (c.work_cap < c.stage_cur + nf || c.hp_cap < c.stage_cur + nf) {   // (rounds still in flight hold the front)
+            HIPCHK(h, hipStreamSynchronize(c.ls));
+            c.stage_cur = 0;
+        }
         if (c.work_cap < nf) {
             int rc = dev_alloc(h, &c.d_work, nf * 2);
             if (rc) return rc;
@@ -1200,12 +1320,13 @@ int vpr_execute(vpr_handle *h) {
             if (by_lv[lv].empty()) continue;
             c.plans.emplace_back();
             Plan &P = c.plans.back();
-            int rc = make_plan(h, by_lv[lv], lv, P, c.arena + c.arena_cur, c.arena_bytes - c.arena_cur);
+            const int tag_or = tie ? TIE_TAG_BIT : 0;
+            int rc = make_plan(h, by_lv[lv], lv, P, c.arena + c.arena_cur, c.arena_bytes - c.arena_cur, tag_or);
             if (rc == VPR_OK && P.chunks.size() > 1 && c.arena_cur > 0) rc = VPR_ERR_NOMEM;   // retry with the whole workspace
             if (rc == VPR_ERR_NOMEM && c.arena_cur > 0) {
                 HIPCHK(h, hipStreamSynchronize(c.ls));
                 c.arena_cur = 0;
-                rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes);
+                rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes, tag_or);
             }
             if (rc == VPR_ERR_NOMEM && h->cfg.workspace_bytes <= 0) {
                 // one alignment does not fit the ladder's workspace (it starts small): grow it to twice that need
@@ -1214,7 +1335,7 @@ int vpr_execute(vpr_handle *h) {
                 uint8_t *na2 = nullptr;
                 if (dev_alloc(h, &na2, size_t(nb) + 256) == VPR_OK) {   // (the old block is released with the batch)
                     c.arena = na2; c.arena_bytes = nb; c.arena_cur = 0;
-                    rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes);
+                    rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes, tag_or);
                 }
             }
             if (rc) return rc;
@@ -1232,7 +1353,7 @@ int vpr_execute(vpr_handle *h) {
             zero_slots = false;
             h->dirty.insert(h->dirty.end(), P.work.begin(), P.work.end());
             if (lv == LV_DENSE) {
-                if ((rc = run_dense(P, dw, c.ls, true, tie))) return rc;
+                if ((rc = run_dense(P, dw, c.ls, true, tag_or))) return rc;
             } else {
                 for (const Chunk &ch : P.chunks) {
                     if (c.slot_cur + 2 > LadderCtx::N_SLOTS) {   // out of fail slots: drain what is in flight
@@ -1248,10 +1369,11 @@ int vpr_execute(vpr_handle *h) {
                     const int32_t n_long = ch.n_long;
                     if (n_long > 0) {
                         const int slot = c.slot0 + c.slot_cur++;
-                        for (int ph = tie ? 1 : 7; ph <= (tie ? 6 : 7); ph += 5) {   // tie: forward, replay, then the rest
+                        for (int ph = tie ? 1 : 7; ph <= (tie ? 6 : 7); ph += 5) {   // tie: (replay,) forward, replay, then the rest
+                            if (tie && ph == 1 && (rc = tie_replay(P, ch.work_off, n_long, c.ls, true))) return rc;
                             if ((rc = enqueue_part(P, dw, ch.work_off, n_long, lv, c.ls, slot, c.fail_base + c.fail_cur, true,
-                                                   ch.part_cells[0], ch.part_in[0], ch.part_dense[0], -1, ph))) return rc;
-                            if (tie && ph == 1 && (rc = tie_replay(P, ch.work_off, n_long, c.ls))) return rc;
+                                                   ch.part_cells[0], ch.part_in[0], ch.part_dense[0], -1, ph, nullptr, 0, tag_or))) return rc;
+                            if (tie && ph == 1 && ((rc = tie_replay(P, ch.work_off, n_long, c.ls, false)) || (rc = tie_patch(P, c.ls)))) return rc;
                         }
                         c.pending.emplace_back(slot, c.fail_base + c.fail_cur);
                         c.fail_cur += n_long;
@@ -1259,9 +1381,10 @@ int vpr_execute(vpr_handle *h) {
                     if (ch.count > n_long) {
                         const int slot = c.slot0 + c.slot_cur++;
                         for (int ph = tie ? 1 : 7; ph <= (tie ? 6 : 7); ph += 5) {
+                            if (tie && ph == 1 && (rc = tie_replay(P, ch.work_off + n_long, ch.count - n_long, c.ls, true))) return rc;
                             if ((rc = enqueue_part(P, dw, ch.work_off + n_long, ch.count - n_long, lv, c.ls, slot,
-                                                   c.fail_base + c.fail_cur, false, ch.part_cells[1], ch.part_in[1], ch.part_dense[1], -1, ph))) return rc;
-                            if (tie && ph == 1 && (rc = tie_replay(P, ch.work_off + n_long, ch.count - n_long, c.ls))) return rc;
+                                                   c.fail_base + c.fail_cur, false, ch.part_cells[1], ch.part_in[1], ch.part_dense[1], -1, ph, nullptr, 0, tag_or))) return rc;
+                            if (tie && ph == 1 && ((rc = tie_replay(P, ch.work_off + n_long, ch.count - n_long, c.ls, false)) || (rc = tie_patch(P, c.ls)))) return rc;
                         }
                         c.pending.emplace_back(slot, c.fail_base + c.fail_cur);
                         c.fail_cur += ch.count - n_long;
@@ -1270,6 +1393,61 @@ int vpr_execute(vpr_handle *h) {
             }
             h->resident.emplace_back(P.work, P.arena);
         }
+        post_flag(4 + int(&c - h->lad), c.ls);
+        (void)hipStreamQuery(c.ls);     // flush
+        return VPR_OK;
+    };
+
+    // ---- a tie round: the alignments of `lst` ({id, level tag}, marked by a backward sweep) are planned again at the level
+    // that accepted them (descriptors tagged TIE_TAG_BIT, fresh workspace slots in the tie ladder's workspace) and run
+    // forward sweep -> container-order replay -> backward sweep -> walk + credit on the tie stream
+    LadderCtx &LT = h->lad[2];
+    std::vector<std::pair<TieJob *, size_t>> tie_job_blocks;   // (debug) the job blocks of this execute
+    size_t tie_job_total = 0;
+    // resident: the chunk of plan0 whose workspace is still intact (early rounds), or nullptr.  An alignment that was
+    // accepted where plan0 placed it (also by the in-place 16-cell round) is replayed early, from that workspace.
+    auto tie_round = [&](const int4 *lst_in, int32_t n, bool full, const Chunk *resident) -> int {
+        std::vector<int4> lst(lst_in, lst_in + n);
+        std::sort(lst.begin(), lst.end(), [](const int4 &x, const int4 &y) { return x.x < y.x; });   // deterministic planning
+        std::vector<int32_t> marked, carry;
+        marked.reserve(size_t(n));
+        tie_early.clear();
+        for (const int4 &e : lst) {
+            int lv = LV_DENSE;
+            for (int k = 0; k < LV_DENSE; k++) if (LV_TAG[k] == e.y) lv = k;
+            h->level[size_t(e.x)] = uint8_t(lv);
+            marked.push_back(e.x);
+            if (resident && !full && e.z > 0) {
+                const int32_t pos = h->plan0_pos[size_t(e.x)];
+                const int dtag = h->plan0.descs[size_t(pos)].band_pad;
+                if (pos >= resident->work_off && pos < resident->work_off + resident->count &&
+                    (dtag == e.y || (dtag == LV_TAG[LV_Z] && e.y == LV_TAG[LV_Q16])))
+                    tie_early[e.x] = TieEarly{e.z, pos, &h->plan0};
+            }
+        }
+        if (h->tie_jobs_cap < tie_job_cur + size_t(n)) {
+            void *pj = nullptr;
+            HIPCHK(h, hipHostMalloc(&pj, size_t(n) * 4 * sizeof(TieJob), hipHostMallocDefault));
+            h->pinned.push_back(pj);    // (an outgrown block stays until the batch is released: a launch may still read it)
+            h->hp_tie_jobs = static_cast<TieJob *>(pj);
+            h->tie_jobs_cap = size_t(n) * 4;
+            tie_job_cur = 0;
+        }
+        const size_t j0 = tie_job_cur;
+        tie_full = full;
+        if (h->debug) fprintf(stderr, "[vpr] tie round: %d alignments%s, first ids %d %d %d, last %d\n", n, full ? " (full logs)" : "", marked[0], marked[size_t(n) / 3], marked[size_t(n) / 2], marked.back());
+        int rc_ = lad_start(LT, marked, carry, true);
+        if (rc_) return rc_;
+        if (!carry.empty()) return fail(h, VPR_ERR_STATE, "tie round: the re-run forward sweep rejected alignment %d", carry[0]);
+        tie_job_blocks.emplace_back(h->hp_tie_jobs + j0, tie_job_cur - j0);
+        tie_job_total += tie_job_cur - j0;
+        return VPR_OK;
+    };
+    auto tie_flush = [&]() -> int {
+        std::vector<int32_t> rejected;
+        int rc_ = lad_flush(LT, rejected);
+        if (rc_) return rc_;
+        if (!rejected.empty()) return fail(h, VPR_ERR_STATE, "tie round: the re-run forward sweep rejected alignment %d", rejected[0]);
         return VPR_OK;
     };
 
@@ -1286,26 +1464,41 @@ int vpr_execute(vpr_handle *h) {
     } else {
         // Per chunk of the round-0 plan: the short alignments (a throughput problem) and the long ones (latency
         // chains: rows are sequential) run on two streams; the ids rejected by the exit test are known right
-        // after each forward sweep, and their retry ladders run beside the rest of the round.
+        // after each forward sweep, and their retry ladders run beside the rest of the round; the alignments whose
+        // backward sweep met a tied swap cell are known right after that sweep, and their tie rounds run beside it too.
         const Plan &P0 = h->plan0;
         const int64_t na_ = int64_t(h->descs.size());
         hipStream_t s_long = h->cls_stream[0], s_short = h->cls_stream[1];
         LadderCtx &LL = h->lad[0], &LS = h->lad[1];
-        // HIP maps streams onto 4 hardware queues: round 0 uses two, the ladders get the other two (the
-        // short ladder rides on the main stream, which has nothing else to do until the join)
-        LL.ls = h->cls_stream[2]; LS.ls = getenv("VPR_LS_MAIN") ? st : h->cls_stream[3];
+        // HIP maps streams onto 4 hardware queues: round 0 uses two, the ladders and the tie rounds share the others
+        LL.ls = h->cls_stream[2]; LS.ls = h->cls_stream[3];
         LL.slot0 = 2; LS.slot0 = 2 + LadderCtx::N_SLOTS;
+        LT.ls = h->tie_stream; LT.slot0 = 2 + 2 * LadderCtx::N_SLOTS;
+        const int32_t tie_cap[2] = {h->tie_list_cap / 4, h->tie_list_cap - h->tie_list_cap / 4};   // long / short part's list
+        const int32_t tie_off[2] = {0, h->tie_list_cap / 4};
+        // part k's alignments left to a tie round -> pinned host memory; ev_tie[k] marks the list complete
+        auto collect_part = [&](int k, const int32_t *list, int32_t n, hipStream_t ks) -> int {
+            hipLaunchKernelGGL(k_collect_ties_list, blocks(n), dim3(256), 0, ks, list, n, h->d_outs, h->d_tie_list + tie_off[k],
+                               h->d_tie_cnt + 2 + k, tie_cap[k]);
+            hipLaunchKernelGGL(k_publish_ties, dim3(4), dim3(256), 0, ks, h->d_tie_list + tie_off[k], h->d_tie_cnt + 2 + k,
+                               h->hp_tie_list + tie_off[k], h->hp_tie_cnt + 2 + k, tie_cap[k]);
+            post_flag(2 + k, ks);
+            return VPR_OK;
+        };
         for (size_t ci = 0; ci < P0.chunks.size(); ci++) {
             const Chunk &ch = P0.chunks[ci];
             const int32_t n_long = ch.n_long;
             const int64_t rbase = na_ + na_ / 16 + 256;                    // start of the retry rounds' fail region
-            LL.fail_base = rbase; LS.fail_base = rbase + n_long;
+            LL.fail_base = rbase; LS.fail_base = rbase + n_long; LT.fail_base = rbase + na_;
             HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
+            HIPCHK(h, hipMemsetAsync(h->d_tie_cnt, 0, 16, st));
+            HIPCHK(h, hipMemsetAsync(h->d_tie_ndec, 0, TIE_DEC_SLOTS * 4, st));
             HIPCHK(h, hipEventRecord(h->ev_fork, st));
             HIPCHK(h, hipStreamWaitEvent(s_long, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(s_short, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(LL.ls, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(LS.ls, h->ev_fork, 0));
+            HIPCHK(h, hipStreamWaitEvent(LT.ls, h->ev_fork, 0));
             // Round 0 of the short part.  At LV_Z, what the zero-distance sweep rejects (every alignment with s > 0)
             // re-runs *in place* with the general 16-cell kernels on the same stream, phase by phase behind the
             // zero-distance kernels: same layout and workspace slots, the device-built fail list is the work list and
@@ -1313,12 +1506,17 @@ int vpr_execute(vpr_handle *h) {
             // help: the bulk kernels' millions of workgroups starve a concurrent launch until they drain.)
             const int32_t n_short = ch.count - n_long;
             const int SLOT_IP = LS.slot0 + LadderCtx::N_SLOTS - 1;          // fail slot of the in-place round
-            const int64_t foff_ip = rbase + na_ - n_short;                 // tail of the retry rounds' fail region
+            const int64_t foff_ip = rbase + na_ - n_short;                 // tail of the ladders' fail region
             const int32_t cap_ip = std::min<int32_t>(n_short, std::max<int32_t>(4096, (n_short / 4 + 3) & ~3));
             const bool inplace = P0.lv == LV_Z && n_short > 0;
+            const int32_t *short_list = P0.d_work + ch.work_off + n_long;
             if (n_short > 0 && !inplace) {
-                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, n_short, P0.lv, s_short, 1, n_long, false,
-                                       ch.part_cells[1], ch.part_in[1], ch.part_dense[1]))) return rc;
+                for (int ph = 1; ph <= 4; ph <<= 1) {   // forward sweep, the fail list, backward sweep, the tie list, walk + credit
+                    if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, n_short, P0.lv, s_short, 1, n_long, false,
+                                           ch.part_cells[1], ch.part_in[1], ch.part_dense[1], -1, ph))) return rc;
+                    if (ph == 1) post_flag(1, s_short);
+                    if (ph == 2 && (rc = collect_part(1, short_list, n_short, s_short))) return rc;
+                }
             }
             if (inplace) {
                 const int32_t *n_dev = h->d_cnt + 1;
@@ -1330,51 +1528,75 @@ int vpr_execute(vpr_handle *h) {
                     // entries past cap_ip (more than a quarter of the part rejected) stay rejected and go to the ladder
                     if ((rc = enqueue_part(P0, h->d_fail, n_long, cap_ip, LV_Q16, s_short, SLOT_IP, foff_ip, false, 0, 0, 0,
                                            ztag, ph, n_dev, n_short + n_short / 16 + 64))) return rc;
+                    if (ph == 1) post_flag(1, s_short);
+                    if (ph == 2 && (rc = collect_part(1, short_list, n_short, s_short))) return rc;
                 }
             }
             if (n_long > 0) {
                 const int lv = P0.lv <= LV_Q16 ? int(LV_C1) : P0.lv;
-                if ((rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0], ch.part_in[0], ch.part_dense[0])))
-                    return rc;
+                for (int ph = 1; ph <= 4; ph <<= 1) {
+                    if ((rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0],
+                                           ch.part_in[0], ch.part_dense[0], -1, ph))) return rc;
+                    if (ph == 1) post_flag(0, s_long);
+                    if (ph == 2 && (rc = collect_part(0, P0.d_work + ch.work_off, n_long, s_long))) return rc;
+                }
             }
+            // (the runtime submits a stream's trailing marker lazily: without these flushes the fork event on the main
+            // stream, on which everything above waits, is only submitted when the host next blocks on something)
+            lapx("round 0 enqueued");
+            // ---- the host serves whatever is ready: a fail list of round 0 starts a ladder, a finished ladder round
+            // starts the next, a published tie list starts a tie round; it never blocks on one while another is ready
             std::vector<int32_t> fails, carry[2];
-            if (n_long > 0) {
-                if ((rc = read_fails(0, 0, LL.ls, fails))) return rc;
-                if ((rc = lad_start(LL, fails, carry[0]))) return rc;
-            }
-            if (ch.count > n_long) {
-                fails.clear();
-                if (inplace) {
-                    if ((rc = read_fails(SLOT_IP, foff_ip, LS.ls, fails))) return rc;
-                    for (int32_t a : fails) h->level[size_t(a)] = uint8_t(LV_Q16);
-                    const int32_t nz = h->hp_cnt[1];   // (published before the in-place round's own list, same stream)
-                    n_retry += nz;   // rejected by the zero-distance sweep (the count includes the list's -1 padding)
-                } else {
-                    if ((rc = read_fails(1, n_long, LS.ls, fails))) return rc;
+            bool wait_fail[2] = {n_long > 0, n_short > 0}, wait_tie[2] = {n_long > 0, n_short > 0};
+            while (wait_fail[0] || wait_fail[1] || wait_tie[0] || wait_tie[1] || !LL.pending.empty() || !LS.pending.empty() ||
+                   !LT.pending.empty()) {
+                bool progressed = false;
+                for (int k = 0; k < 2; k++) {
+                    LadderCtx &c = h->lad[k];
+                    if (wait_fail[k] && flag_up(k)) {
+                        fails.clear();
+                        if (k == 1 && inplace) {
+                            if ((rc = read_fails(SLOT_IP, foff_ip, c.ls, fails))) return rc;
+                            for (int32_t a : fails) h->level[size_t(a)] = uint8_t(LV_Q16);
+                            n_retry += h->hp_cnt[1];   // rejected by the zero-distance sweep (published before the in-place
+                                                       // round's own list, same stream; the count includes the list's -1 padding)
+                        } else {
+                            if ((rc = read_fails(k, k == 0 ? 0 : n_long, c.ls, fails))) return rc;
+                        }
+                        if ((rc = lad_start(c, fails, carry[k]))) return rc;
+                        lapx(k ? "short fail list -> ladder" : "long fail list -> ladder");
+                        wait_fail[k] = false;
+                        progressed = true;
+                    } else if (!wait_fail[k] && !c.pending.empty() && flag_up(4 + k)) {
+                        fails.clear();
+                        fails.swap(carry[k]);
+                        if ((rc = lad_flush(c, fails))) return rc;
+                        if ((rc = lad_start(c, fails, carry[k]))) return rc;
+                        progressed = true;
+                    }
+                    if (wait_tie[k] && flag_up(2 + k)) {
+                        const int32_t n = std::min(h->hp_tie_cnt[2 + k], tie_cap[k]);
+                        if (n > 0 && (rc = tie_round(h->hp_tie_list + tie_off[k], n, false, &ch))) return rc;
+                        lapx(k ? "short tie list -> tie round" : "long tie list -> tie round");
+                        wait_tie[k] = false;
+                        progressed = true;
+                    }
                 }
-                if ((rc = lad_start(LS, fails, carry[1]))) return rc;
-            }
-            while (!LL.pending.empty() || !LS.pending.empty()) {
-                int pick = -1;
-                while (pick < 0) {
-                    for (int k = 1; k >= 0 && pick < 0; k--)       // a ladder whose round has finished goes first
-                        if (!h->lad[k].pending.empty() && hipStreamQuery(h->lad[k].ls) == hipSuccess) pick = k;
-                    if (pick < 0 && LL.pending.empty()) pick = 1;
-                    if (pick < 0 && LS.pending.empty()) pick = 0;
-                    if (pick < 0) std::this_thread::yield();
+                if (!wait_tie[0] && !wait_tie[1] && !LT.pending.empty() && flag_up(6)) {
+                    if ((rc = tie_flush())) return rc;
+                    progressed = true;
                 }
-                LadderCtx &c = h->lad[pick];
-                fails.clear();
-                fails.swap(carry[pick]);
-                if ((rc = lad_flush(c, fails))) return rc;
-                if ((rc = lad_start(c, fails, carry[pick]))) return rc;
+                // (no busy wait: a spinning host thread can exhaust the process's CPU quota, which stalls the runtime's threads)
+                if (!progressed) std::this_thread::sleep_for(std::chrono::microseconds(20));
             }
+            lapx("ladders and tie rounds drained");
             // join: the next chunk reuses the arena
             HIPCHK(h, hipEventRecord(h->ev_join[0], s_long));
             HIPCHK(h, hipEventRecord(h->ev_join[1], s_short));
             HIPCHK(h, hipEventRecord(h->ev_join[2], LL.ls));
             HIPCHK(h, hipEventRecord(h->ev_join[3], LS.ls));
-            for (int k = 0; k < 4; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
+            HIPCHK(h, hipEventRecord(h->ev_join[4], LT.ls));
+            for (int k = 0; k < 5; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
             if (ci + 1 < P0.chunks.size()) HIPCHK(h, hipStreamSynchronize(st));
             if (ci + 1 == P0.chunks.size())
                 h->resident.emplace(h->resident.begin(), std::vector<int32_t>(P0.work.begin() + ch.work_off,
@@ -1382,13 +1604,10 @@ int vpr_execute(vpr_handle *h) {
         }
     }
 
-    // ---- tie pass: alignments whose backward sweep consulted a tied swap cell were left without walk and credit
-    // (AlnOut::band_ok = TIE_MARK(level tag)).  Re-run their forward sweep at the level that accepted them, replay the
-    // reference's container order (pr_tie.hip) to fix the tied choices, then backward sweep, walk and credit as usual.
-    // A second attempt with worst-case FIFO logs takes whatever overflowed the capped ones.
+    // ---- final tie pass: whatever is still marked (ties met by the retry ladders' rounds, lists that outgrew their
+    // buffer, replays whose capped FIFO logs overflowed: those get worst-case logs now)
     {
         const int na = int(h->descs.size());
-        LadderCtx &LT = h->lad[0];
         for (int iter = 0; na > 0; iter++) {
             HIPCHK(h, hipMemsetAsync(h->d_tie_cnt, 0, 8, st));
             hipLaunchKernelGGL(k_collect_ties, blocks(na), dim3(256), 0, st, h->d_outs, na, h->d_tie_list, h->d_tie_cnt, h->tie_list_cap);
@@ -1398,51 +1617,32 @@ int vpr_execute(vpr_handle *h) {
             if (n_mark == 0) break;
             if (iter >= 3) return fail(h, VPR_ERR_STATE, "tie pass: %d alignments still marked after %d attempts", n_mark, iter);
             const int32_t n = std::min(n_mark, h->tie_list_cap);
-            std::vector<int2> lst;
+            std::vector<int4> lst;
             lst.resize(size_t(n));
-            HIPCHK(h, hipMemcpy(lst.data(), h->d_tie_list, size_t(n) * sizeof(int2), hipMemcpyDeviceToHost));
-            std::sort(lst.begin(), lst.end(), [](const int2 &x, const int2 &y) { return x.x < y.x; });   // deterministic planning
-            std::vector<int32_t> marked, carry;
-            marked.reserve(size_t(n));
-            for (const int2 &e : lst) {
-                int lv = LV_DENSE;
-                for (int k = 0; k < LV_DENSE; k++) if (LV_TAG[k] == e.y) lv = k;
-                h->level[size_t(e.x)] = uint8_t(lv);
-                marked.push_back(e.x);
-            }
-            if (h->tie_jobs_cap < size_t(n)) {
-                void *pj = nullptr;
-                HIPCHK(h, hipHostMalloc(&pj, size_t(n) * 2 * sizeof(TieJob), hipHostMallocDefault));
-                h->pinned.push_back(pj);    // (an outgrown block stays until the batch is released: a launch may still read it)
-                h->hp_tie_jobs = static_cast<TieJob *>(pj);
-                h->tie_jobs_cap = size_t(n) * 2;
-            }
-            tie_job_cur = 0;
-            tie_full = iter > 0;
-            if (getenv("VPR_DEBUG")) fprintf(stderr, "[vpr] tie pass %d: %d alignments marked%s\n", iter, n_mark, tie_full ? " (full logs)" : "");
-            LT.ls = st; LT.slot0 = 2; LT.fail_base = int64_t(na) + na / 16 + 256;
-            if ((rc = lad_start(LT, marked, carry, true))) return rc;
-            std::vector<int32_t> rejected;
-            if ((rc = lad_flush(LT, rejected))) return rc;
-            if (getenv("VPR_DEBUG")) {   // the slowest replays
-                HIPCHK(h, hipStreamSynchronize(st));
-                std::vector<TieJob> js(h->hp_tie_jobs, h->hp_tie_jobs + tie_job_cur);
-                std::sort(js.begin(), js.end(), [](const TieJob &x, const TieJob &y) { return x.dbg_us > y.dbg_us; });
-                int64_t tot_us = 0;
-                for (const TieJob &J : js) tot_us += J.dbg_us;
-                fprintf(stderr, "[vpr] tie replay: %zu jobs, %.1f ms summed\n", js.size(), tot_us / 1000.0);
-                for (size_t k = 0; k < js.size() && k < 12; k++) {
-                    const AlnDesc &d = h->descs[size_t(js[k].a)];
-                    fprintf(stderr, "[vpr]   sc %d aln %d Lq %d Lr %d Lt %d level %d: %d us, %d waves, %d BFS steps, %d cells; wave 0: %d steps, %d tot!=n, %d unstable, %d single\n", d.sc, d.aln,
-                            d.Lq, d.Lr, d.Lt, int(h->level[size_t(js[k].a)]), js[k].dbg_us, js[k].dbg_waves, js[k].dbg_steps, js[k].dbg_cells,
-                            js[k].dbg_w0steps, js[k].dbg_totne, js[k].dbg_unstable, js[k].dbg_lev1);
-                }
-            }
-            if (!rejected.empty() || !carry.empty())
-                return fail(h, VPR_ERR_STATE, "tie pass: the re-run forward sweep rejected alignment %d", rejected.empty() ? carry[0] : rejected[0]);
+            HIPCHK(h, hipMemcpy(lst.data(), h->d_tie_list, size_t(n) * sizeof(int4), hipMemcpyDeviceToHost));
+            if (h->debug) fprintf(stderr, "[vpr] final tie pass %d: %d alignments marked\n", iter, n_mark);
+            LT.ls = h->tie_stream; LT.slot0 = 2 + 2 * LadderCtx::N_SLOTS; LT.fail_base = 2 * int64_t(na) + na / 16 + 256;
+            if ((rc = tie_round(lst.data(), n, iter > 0, nullptr))) return rc;
+            if ((rc = tie_flush())) return rc;
+            HIPCHK(h, hipStreamSynchronize(LT.ls));
+        }
+    }
+    if (h->debug && tie_job_total > 0) {   // the slowest replays of the execute
+        std::vector<TieJob> js;
+        for (const auto &blk : tie_job_blocks) js.insert(js.end(), blk.first, blk.first + blk.second);
+        std::sort(js.begin(), js.end(), [](const TieJob &x, const TieJob &y) { return x.dbg_us > y.dbg_us; });
+        int64_t tot_us = 0;
+        for (const TieJob &J : js) tot_us += J.dbg_us;
+        fprintf(stderr, "[vpr] tie replay: %zu jobs, %.1f ms summed\n", js.size(), tot_us / 1000.0);
+        for (size_t k = 0; k < js.size() && k < 8; k++) {
+            const AlnDesc &d = h->descs[size_t(js[k].a)];
+            fprintf(stderr, "[vpr]   sc %d aln %d Lq %d Lr %d Lt %d level %d: %d us, %d waves, %d BFS steps, %d cells; mode %d, consulted %d, decided %d (last in wave %d)\n", d.sc, d.aln,
+                    d.Lq, d.Lr, d.Lt, int(h->level[size_t(js[k].a)]), js[k].dbg_us, js[k].dbg_waves, js[k].dbg_steps, js[k].dbg_cells,
+                    js[k].mode, js[k].n_used, js[k].dbg_nres, js[k].dbg_lastw);
         }
     }
 
+    lapx("final tie pass done");
     // K4: deferred section edit distances
     int32_t n_jobs = 0;
     HIPCHK(h, hipMemcpyAsync(&n_jobs, h->d_njobs, 4, hipMemcpyDeviceToHost, st));
@@ -1460,7 +1660,7 @@ int vpr_execute(vpr_handle *h) {
         // anti-diagonal kernel when the largest section fits LDS and 16-bit distances (VPR_ED_ROWS: the row-sweep one)
         const int64_t pitch = (max_short + 2 + 7) & ~int64_t(7);
         const size_t lds_diag = size_t(3 * pitch * 2 + max_sum + 16);
-        if (lds_diag <= 150 * 1024 && max_sum < 65000 && !getenv("VPR_ED_ROWS")) {
+        if (lds_diag <= 150 * 1024 && max_sum < 65000) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ed_diag), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_diag));
             vpr_launch_stat es_;
             memset(&es_, 0, sizeof(es_));
@@ -1509,6 +1709,7 @@ int vpr_execute(vpr_handle *h) {
     }
     HIPCHK(h, hipEventRecord(t1, st));
     HIPCHK(h, hipStreamSynchronize(st));
+    lapx("done");
     HIPCHK(h, hipGetLastError());
     float ms = 0;
     (void)hipEventElapsedTime(&ms, t0, t1);

@@ -141,300 +141,6 @@ __device__ __forceinline__ void band_origin(const int32_t *t2r, const int32_t *r
     }
 }
 
-// ---------------------------------------------------------------------------
-// K1b: banded forward sweep, one wavefront per alignment.
-// BANDMAT: flag rows stored band-relative ([t][x - lo(t)], pitch = band width); otherwise dense [t][x].
-// ---------------------------------------------------------------------------
-template <int C, bool BANDMAT>
-__global__ void __launch_bounds__(64) k_fwd_band(DevBatch B, const AlnDesc *__restrict__ descs,
-                                                 const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
-                                                 int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
-    constexpr int W = 64 * C, RS = 2 * W, M = RS - 1;
-    __shared__ int32_t Dr[2][2][RS];   // [row parity][plane][x & M]
-    __shared__ int2 Kr[2][RS];         // [plane][x & M] packed constants
-    __shared__ int2 Er[2][RS];         // [plane][x & M] {reference coordinate, free-shift budget ahead}
-    const int a = work[blockIdx.x];
-    const AlnDesc d = descs[a];
-    const int lane = threadIdx.x;
-    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
-    const int Lp[2] = {Lq, Lr};
-    const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off;
-    const uint8_t *Tf = B.hap_flag[d.ts] + d.t_off;
-    const int32_t *t2r = B.hap_ptr[d.ts] + d.t_off;
-    const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
-    const int2 *fk[2] = {B.fk_q[d.qs] + d.q_off, B.fk_r[d.qs] + d.r_off};
-    const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
-    const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
-    const int32_t *vsp[2] = {B.vs_hap[d.qs] + d.q_off, B.vs_ref[d.qs] + d.r_off};   // free-shift budget ahead
-    const int32_t *vst = B.vs_hap[d.ts] + d.t_off;
-    uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
-    int32_t *blo = blo_all + d.blo_off;
-
-    // band origins of rows [t0, t0+64) in lane (t - t0); next chunk kept one chunk ahead
-    int cbQ, cbR, nbQ, nbR;
-    band_origin<W>(t2r, r2q, lane, Lt, Lq, Lr, cbQ, cbR);
-    band_origin<W>(t2r, r2q, 64 + lane, Lt, Lq, Lr, nbQ, nbR);
-    if (lane < Lt) { blo[lane] = cbQ; blo[Lt + lane] = cbR; }
-    if (64 + lane < Lt) { blo[64 + lane] = nbQ; blo[Lt + 64 + lane] = nbR; }
-    uint32_t tchunk = 0, tlast = 0;
-    int tauchunk = 0, vtchunk = 0;
-    if (lane < Lt) {
-        tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
-        tauchunk = t2r[lane];
-        vtchunk = vst[max(lane - 1, 0)];
-    }
-
-    // constants ring: positions [0, khi] of each plane are resident
-    int khi[2] = {-1, -1};
-    auto fill = [&](int p, int upto) {
-        while (khi[p] < upto) {
-            const int x = khi[p] + 1 + lane;
-            if (x < Lp[p]) {
-                Kr[p][x & M] = fk[p][x];
-                Er[p][x & M] = make_int2(p == 0 ? q2r[x] : x, vsp[p][max(x - 1, 0)]);
-            }
-            khi[p] += 64;
-        }
-    };
-#pragma unroll
-    for (int p = 0; p < 2; p++) fill(p, min(Lp[p], W) - 1);
-
-    int lo[2] = {0, 0}, hi[2] = {min(Lq, W) - 1, min(Lr, W) - 1};
-    int exit_min = D_INF;
-    int endD[2] = {D_INF, D_INF};
-    const int off0 = lane * C;
-
-    // ---- row 0: D = x along the INS chain from the origin (dist.cpp:300-305, 397-405)
-    {
-        int nlo[2] = {0, 0}, nhi[2] = {0, 0};
-        if (Lt > 1) {
-            nlo[0] = __builtin_amdgcn_readlane(cbQ, 1); nlo[1] = __builtin_amdgcn_readlane(cbR, 1);
-            nhi[0] = min(Lq - 1, nlo[0] + W - 1); nhi[1] = min(Lr - 1, nlo[1] + W - 1);
-        }
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            uint8_t fl[C];
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const int x = off0 + c;
-                fl[c] = (x == 0) ? F_MAT : F_INS;
-                if (x <= hi[p]) {
-                    Dr[0][p][x & M] = x;
-                    bool ex = (x == hi[p] && hi[p] < Lp[p] - 1);
-                    if (Lt > 1) {
-                        ex = ex || x < nlo[p] || (x + 1 <= Lp[p] - 1 && x + 1 > nhi[p]);
-                        const uint32_t swt = uint32_t(Kr[p][x & M].y) & 0xffffffu;
-                        if (swt != FK_NONE24 && int(swt) < Lp[1 - p] && (int(swt) < nlo[1 - p] || int(swt) > nhi[1 - p])) ex = true;
-                    }
-                    if (ex) {
-                        const int2 e = Er[p][x & M];
-                        const int off = e.x - t2r[0];
-                        exit_min = min(exit_min, x + max((off < 0 ? -off : off) - e.y - vst[0], 0));
-                    }
-                    if (Lt == 1 && x == Lp[p] - 1) endD[p] = x;
-                }
-            }
-            if (off0 <= hi[p]) {
-                typename FlagVec<C>::T v;
-                __builtin_memcpy(&v, fl, C);
-                *reinterpret_cast<typename FlagVec<C>::T *>(mat[p] + off0) = v;
-            }
-        }
-    }
-    asm volatile("" ::: "memory");
-
-    // band of the next row, carried from iteration to iteration
-    int nlo[2] = {0, 0}, nhi[2] = {0, 0};
-    if (Lt > 1) {
-        nlo[0] = __builtin_amdgcn_readlane(cbQ, 1); nlo[1] = __builtin_amdgcn_readlane(cbR, 1);
-        nhi[0] = min(Lq - 1, nlo[0] + W - 1); nhi[1] = min(Lr - 1, nlo[1] + W - 1);
-    }
-    // The row loop is written branch-free: every LDS ring read is unconditional (any index & M is inside
-    // the ring) and out-of-window values are replaced by D_INF with selects, so a row is one straight
-    // line of VALU/LDS work apart from the rare multi-candidate swap and the 64-row chunk refills.
-    for (int t = 1; t < Lt; t++) {
-        const int plo[2] = {lo[0], lo[1]}, phi[2] = {hi[0], hi[1]};
-        lo[0] = nlo[0]; lo[1] = nlo[1]; hi[0] = nhi[0]; hi[1] = nhi[1];
-        if ((t & 63) == 0) {   // advance the truth / band chunks
-            tlast = __builtin_amdgcn_readlane(tchunk, 63);
-            const int tt = t + lane;
-            tchunk = 0; tauchunk = 0; vtchunk = 0;
-            if (tt < Lt) {
-                tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
-                tauchunk = t2r[tt];
-                vtchunk = vst[tt - 1];
-            }
-            cbQ = nbQ; cbR = nbR;
-            band_origin<W>(t2r, r2q, t + 64 + lane, Lt, Lq, Lr, nbQ, nbR);
-            if (t + 64 + lane < Lt) { blo[t + 64 + lane] = nbQ; blo[Lt + t + 64 + lane] = nbR; }
-        }
-        const uint32_t cur = __builtin_amdgcn_readlane(tchunk, t & 63);
-        const uint32_t prv = ((t & 63) == 0) ? tlast : uint32_t(__builtin_amdgcn_readlane(tchunk, (t - 1) & 63));
-        const uint32_t Tt = cur & 0xff;
-        const bool at = fwd_allow(int((prv >> 8) & 0xff));
-        const int tau = __builtin_amdgcn_readlane(tauchunk, t & 63);
-        const int vt = __builtin_amdgcn_readlane(vtchunk, t & 63);
-        const bool has_next = t + 1 < Lt;
-        if (has_next) {
-            if (((t + 1) & 63) == 0) { nlo[0] = __builtin_amdgcn_readlane(nbQ, 0); nlo[1] = __builtin_amdgcn_readlane(nbR, 0); }
-            else { nlo[0] = __builtin_amdgcn_readlane(cbQ, (t + 1) & 63); nlo[1] = __builtin_amdgcn_readlane(cbR, (t + 1) & 63); }
-            nhi[0] = min(Lq - 1, nlo[0] + W - 1);
-            nhi[1] = min(Lr - 1, nlo[1] + W - 1);
-        } else {   // last row: nothing below, only the INS edge can leave the window
-            nlo[0] = 0; nlo[1] = 0; nhi[0] = Lq; nhi[1] = Lr;
-        }
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-            if (khi[p] < hi[p]) fill(p, hi[p]);
-        asm volatile("" ::: "memory");
-
-        const int pb = (t - 1) & 1, cb = t & 1;
-        int bv[2][C];
-        uint32_t mk[2][C];
-        int swt[2][C];
-        int cmin[2];
-        bool any_multi = false;
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int o = 1 - p;
-            const int x0 = lo[p] + off0;
-            int diag = Dr[pb][p][(x0 - 1) & M];
-            diag = (x0 - 1 >= plo[p] && x0 - 1 <= phi[p]) ? diag : D_INF;
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const int x = x0 + c;
-                const bool valid = x <= hi[p];
-                const int2 k = Kr[p][x & M];
-                int up = Dr[pb][p][x & M];
-                up = (x >= plo[p] && x <= phi[p]) ? up : D_INF;
-                const bool match = valid && (uint32_t(k.y) >> 24) == Tt;
-                const int s0 = k.x & (FK_MULTI - 1);
-                int sw = Dr[pb][o][s0 & M];
-                const bool sw_on = match && at && k.x >= 0;
-                sw = (sw_on && s0 >= plo[o] && s0 <= phi[o]) ? sw : D_INF;
-                any_multi = any_multi || (sw_on && (k.x & FK_MULTI));
-                const int cm = match ? diag : diag + 1;
-                const int b = min(min(cm, up + 1), sw);
-                uint32_t m = 0;
-                m |= (match && diag == b) ? F_MAT : 0;
-                m |= (diag + 1 == b) ? F_SUB : 0;
-                m |= (up + 1 == b) ? F_DEL : 0;
-                m |= (sw == b && sw < D_INF) ? F_SWP : 0;
-                mk[p][c] = m;
-                swt[p][c] = k.y & 0xffffff;
-                bv[p][c] = valid ? b - x : D_INF;
-                diag = up;
-            }
-        }
-        if (__builtin_expect(__any(any_multi), 0)) {
-            // rare: a cell with several allowed swap sources (an insertion/deletion boundary) -- redo those cells
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                const int o = 1 - p;
-                const int x0 = lo[p] + off0;
-#pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const int x = x0 + c;
-                    const int2 k = Kr[p][x & M];
-                    const bool match = x <= hi[p] && (uint32_t(k.y) >> 24) == Tt;
-                    if (match && at && k.x >= 0 && (k.x & FK_MULTI)) {
-                        const int4 cc = cand[p][x];
-                        auto dval = [&](int src) { return (src >= plo[o] && src <= phi[o]) ? Dr[pb][o][src & M] : D_INF; };
-                        int sw = dval(cc.x), choice = 0;
-                        bool tie = false;
-                        const int v1 = dval(cc.y);
-                        if (v1 <= sw) { tie = (v1 == sw); sw = v1; choice = 1; }
-                        if (cc.z >= 0) {
-                            const int v2 = dval(cc.z);
-                            if (v2 <= sw) { tie = (v2 == sw); sw = v2; choice = 2; }
-                            if (cc.w >= 0) {
-                                const int v3 = dval(cc.w);
-                                if (v3 <= sw) { tie = (v3 == sw); sw = v3; choice = 3; }
-                            }
-                        }
-                        const int up = (x >= plo[p] && x <= phi[p]) ? Dr[pb][p][x & M] : D_INF;
-                        const int dg = (x - 1 >= plo[p] && x - 1 <= phi[p]) ? Dr[pb][p][(x - 1) & M] : D_INF;
-                        const int b = min(min(dg, up + 1), sw);   // match is true here
-                        uint32_t m = 0;
-                        if (dg == b) m |= F_MAT;
-                        if (dg + 1 == b) m |= F_SUB;
-                        if (up + 1 == b) m |= F_DEL;
-                        if (sw == b && sw < D_INF) m |= F_SWP | (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
-                        mk[p][c] = m;
-                        bv[p][c] = b - x;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            int run = D_INF;
-#pragma unroll
-            for (int c = 0; c < C; c++) run = min(run, bv[p][c]);
-            cmin[p] = run;
-        }
-        int iq = cmin[0], ir = cmin[1];
-        wave_prefix_min2(iq, ir);
-        const int carry[2] = {wave_shr1(iq, D_INF), wave_shr1(ir, D_INF)};
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int o = 1 - p;
-            const int x0 = lo[p] + off0;
-            uint8_t fl[C];
-            int run = carry[p];
-            int left = carry[p] + x0 - 1;
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const int x = x0 + c;
-                const int nb = bv[p][c];
-                const bool take = nb <= run;
-                run = min(run, nb);
-                uint32_t f = take ? mk[p][c] : 0;
-                const int Dn = run + x;
-                f |= (left + 1 == Dn && x > 0) ? F_INS : 0;
-                fl[c] = uint8_t(f);
-                left = Dn;
-                const bool valid = x <= hi[p];
-                if (valid) Dr[cb][p][x & M] = Dn;
-                // edges leaving the window: INS to the right, DEL / diagonal into row t+1, plane swap
-                const int z = swt[p][c];
-                bool ex = (x == hi[p] && hi[p] < Lp[p] - 1);
-                ex = ex || (has_next && (x < nlo[p] || (x + 1 <= Lp[p] - 1 && x + 1 > nhi[p])));
-                ex = ex || (has_next && z != FK_NONE24 && z < Lp[o] && (z < nlo[o] || z > nhi[o]));
-                // a path through an exit cell costs at least D + what the diagonal offset rho - tau still
-                // costs beyond the indel sizes ahead (see k_fwd_stripe)
-                const int2 e = Er[p][x & M];
-                const int doff = e.x - tau;
-                const int lb = max((doff < 0 ? -doff : doff) - e.y - vt, 0);
-                exit_min = (valid && ex) ? min(exit_min, Dn + lb) : exit_min;
-                endD[p] = (valid && t == Lt - 1 && x == Lp[p] - 1) ? Dn : endD[p];
-            }
-            if (x0 <= hi[p]) {
-                typename FlagVec<C>::T v;
-                __builtin_memcpy(&v, fl, C);
-                uint8_t *dst = BANDMAT ? mat[p] + size_t(t) * d.pitch[p] + off0 : mat[p] + size_t(t) * d.pitch[p] + x0;
-                if (BANDMAT || C == 1) {
-                    *reinterpret_cast<typename FlagVec<C>::T *>(dst) = v;
-                } else {   // dense layout: x0 is not C-aligned in general
-#pragma unroll
-                    for (int c = 0; c < C; c++) if (x0 + c <= hi[p]) dst[c] = fl[c];
-                }
-            }
-        }
-        asm volatile("" ::: "memory");
-    }
-    // reductions: exit_min (min over lanes), end distances (one lane holds each)
-    int e0 = endD[0], e1 = endD[1];
-    wave_prefix_min2(e0, e1);
-    int em = exit_min, dummy = D_INF;
-    wave_prefix_min2(em, dummy);
-    if (lane == 63) {
-        outs[a].dist_q = e0;
-        outs[a].dist_r = e1;
-        outs[a].exit_min = em;
-    }
-}
-
 // s, end plane (prefer QUERY, dist.cpp:436-439) and the window acceptance test.  band_ok holds the window
 // width W the alignment was accepted at (0: rejected): the later kernels of a round process an alignment only
 // if band_ok and its descriptor both carry their own W, so a retry round that re-plans a rejected alignment
@@ -498,194 +204,6 @@ __device__ __forceinline__ void wave_prefix_mp2(MP &a, MP &b) {
 #undef MP_BCAST
     a.A = (Aq >= MP_OFF) ? Aq - MP_OFF : S_NEG; a.B = (Bq < 0) ? -1 : Bq;
     b.A = (Ar >= MP_OFF) ? Ar - MP_OFF : S_NEG; b.B = (Br < 0) ? -1 : Br;
-}
-
-template <int C>
-__global__ void __launch_bounds__(64) k_bwd_band(DevBatch B, const AlnDesc *__restrict__ descs,
-                                                 const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
-                                                 const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
-    constexpr int W = 64 * C, RS = 2 * W, M = RS - 1;
-    __shared__ int32_t Sr[2][2][RS];   // scores      [row parity][plane][x & M]
-    __shared__ uint8_t Fr[2][2][RS];   // fwd flags   [row parity][plane][x & M]
-    __shared__ int32_t Br[2][RS];      // bk constants [plane][x & M]
-    const int a = work[blockIdx.x];
-    const AlnDesc d = descs[a];
-    const int lane = threadIdx.x;
-    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
-    const int Lp[2] = {Lq, Lr};
-    const int32_t *bk[2] = {B.bk_q[d.qs] + d.q_off, B.bk_r[d.qs] + d.r_off};
-    uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
-    const int32_t *blo = blo_all + d.blo_off;
-    if (outs[a].band_ok != 64 * C || d.band_pad != 64 * C) return;   // rejected by the exit test: re-run wider
-    const int end_plane = outs[a].end_plane;
-    const int off0 = (63 - lane) * C;
-
-    // band origins by 64-row chunk: cb = chunk of row t, hb = the chunk above it, lb = prefetched chunk below
-    auto load_chunk = [&](int t0, int &bq, int &br) {
-        bq = 0; br = 0;
-        const int tt = t0 + lane;
-        if (t0 >= 0 && tt < Lt) { bq = blo[tt]; br = blo[Lt + tt]; }
-    };
-    int cbQ, cbR, hbQ = 0, hbR = 0, lbQ, lbR;
-    const int tc0 = (Lt - 1) & ~63;
-    load_chunk(tc0, cbQ, cbR);
-    load_chunk(tc0 - 64, lbQ, lbR);
-
-    // constants ring: positions [klo, klo + RS) resident (filled downwards)
-    int klo[2] = {(Lq + 63) & ~63, (Lr + 63) & ~63};
-    auto fill = [&](int p, int downto) {
-        while (klo[p] > downto) {
-            const int x = klo[p] - 64 + lane;
-            if (x >= 0 && x < Lp[p]) Br[p][x & M] = bk[p][x];
-            klo[p] -= 64;
-        }
-    };
-
-    int lo[2], hi[2], nlo[2] = {0, 0}, nhi[2] = {-1, -1};
-    lo[0] = __builtin_amdgcn_readlane(cbQ, (Lt - 1) & 63);
-    lo[1] = __builtin_amdgcn_readlane(cbR, (Lt - 1) & 63);
-    FlagReg<C> pf[2];   // forward flags of the row below the current one, in flight
-    uint8_t f0[2][C];
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-        hi[p] = min(Lp[p] - 1, lo[p] + W - 1);
-        fill(p, lo[p]);
-#pragma unroll
-        for (int c = 0; c < C; c++) f0[p][c] = 0;
-        if (lo[p] + off0 <= hi[p]) {
-            FlagReg<C> r = load_flags<C>(mat[p] + size_t(Lt - 1) * d.pitch[p] + off0);
-            unpack_flags<C>(r, f0[p]);
-        }
-        if (Lt >= 2 && off0 < d.pitch[p]) pf[p] = load_flags<C>(mat[p] + size_t(Lt - 2) * d.pitch[p] + off0);
-    }
-    uint32_t tie_used = 0;
-    int beg_score = S_NEG;
-
-    for (int t = Lt - 1; t >= 0; t--) {
-        const int cb = t & 1, nb = cb ^ 1;
-        // stage row t's forward flags
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const int x = lo[p] + off0 + c;
-                if (x <= hi[p]) Fr[cb][p][x & M] = f0[p][c];
-            }
-        asm volatile("" ::: "memory");
-
-        int32_t base[2][C];
-        uint8_t bm[2][C];
-        int8_t lk[2][C];
-        MP g[2];
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int o = 1 - p;
-            const int xtop = lo[p] + off0 + C;   // cell right of this chunk
-            // (x+1, t+1) values for the top cell; afterwards they are handed down the chunk
-            int up_s = S_NEG, up_f = 0;
-            if (xtop >= nlo[p] && xtop <= nhi[p]) { up_s = Sr[nb][p][xtop & M]; up_f = Fr[nb][p][xtop & M]; }
-            int up_tp = (p == 0 && xtop < Lq) ? ((Br[0][xtop & M] >> 24) & 1) : 0;
-            int up_f0 = (xtop <= hi[p]) ? Fr[cb][p][xtop & M] : 0;
-            MP G; G.A = S_NEG; G.B = 0;
-            bool first = true;
-#pragma unroll
-            for (int c = C - 1; c >= 0; c--) {
-                const int x = lo[p] + off0 + c;
-                const bool valid = x <= hi[p];
-                const int bkx = Br[p][x & M];
-                int dn_s = S_NEG, dn_f = 0;
-                if (x >= nlo[p] && x <= nhi[p]) { dn_s = Sr[nb][p][x & M]; dn_f = Fr[nb][p][x & M]; }
-                int best = S_NEG; uint8_t m = 0;
-                if (up_f & (F_MAT | F_SUB)) { best = up_s + up_tp; m = up_f & (F_MAT | F_SUB); }
-                if (dn_f & F_DEL) {
-                    if (dn_s > best) { best = dn_s; m = F_DEL; } else if (dn_s == best) m |= F_DEL;
-                }
-                const int z = bkx & 0xffffff;
-                if (z != FK_NONE24 && z >= nlo[o] && z <= nhi[o]) {
-                    const int zf = Fr[nb][o][z & M];
-                    if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((bkx >> 25) & 3)) {
-                        const int v = Sr[nb][o][z & M] + ((bkx >> 27) & 1);
-                        if (v >= 0 && (zf & F_TIE)) tie_used = 1;
-                        if (v > best) { best = v; m = F_SWP; } else if (v == best) m |= F_SWP;
-                    }
-                }
-                if (t == Lt - 1 && p == end_plane && x == Lp[p] - 1) { best = 0; m = F_MAT; }   // dist.cpp:538-546
-                if (!valid) { best = S_NEG; m = 0; }
-                base[p][c] = best;
-                bm[p][c] = m;
-                const int l = (up_f0 & F_INS) ? up_tp : -1;
-                lk[p][c] = l;
-                MP F; F.A = best; F.B = l;
-                if (first) { G = F; first = false; } else G = mp_compose(F, G);
-                // hand this cell's values down as the (x+1) values of the next cell
-                up_s = dn_s; up_f = dn_f;
-                up_tp = (bkx >> 24) & 1;
-                up_f0 = f0[p][c];
-            }
-            g[p] = G;
-        }
-        MP hq = g[0], hr = g[1];
-        wave_prefix_mp2(hq, hr);
-        const int inc[2] = {wave_shr1(hq.A, S_NEG), wave_shr1(hr.A, S_NEG)};
-        uint8_t out[2][C];
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            int prev = inc[p];
-#pragma unroll
-            for (int c = C - 1; c >= 0; c--) {
-                const int x = lo[p] + off0 + c;
-                int v = base[p][c];
-                uint8_t m = bm[p][c];
-                if (lk[p][c] >= 0) {
-                    const int w = prev + lk[p][c];
-                    if (w > v) { v = w; m = F_INS; } else if (w == v) m |= F_INS;
-                }
-                if (v < 0) { v = S_NEG; m = 0; }
-                out[p][c] = m;
-                prev = v;
-                if (x <= hi[p]) Sr[cb][p][x & M] = v;
-                if (t == 0 && p == 0 && x == 0) beg_score = v;
-            }
-        }
-        // next row's band, constants, and the flag-row pipeline (loads before stores, see k_bwd)
-        nlo[0] = lo[0]; nlo[1] = lo[1]; nhi[0] = hi[0]; nhi[1] = hi[1];
-        if (t > 0) {
-            if ((t & 63) == 0) {   // row t-1 lives in the chunk below
-                hbQ = cbQ; hbR = cbR; cbQ = lbQ; cbR = lbR;
-                load_chunk(((t - 1) & ~63) - 64, lbQ, lbR);
-            }
-            lo[0] = __builtin_amdgcn_readlane(cbQ, (t - 1) & 63);
-            lo[1] = __builtin_amdgcn_readlane(cbR, (t - 1) & 63);
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                hi[p] = min(Lp[p] - 1, lo[p] + W - 1);
-                if (klo[p] > lo[p]) fill(p, lo[p]);
-                unpack_flags<C>(pf[p], f0[p]);
-                if (!(lo[p] + off0 <= hi[p])) {
-#pragma unroll
-                    for (int c = 0; c < C; c++) f0[p][c] = 0;
-                }
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-            if (t > 1 && off0 < d.pitch[p]) pf[p] = load_flags<C>(mat[p] + size_t(t - 2) * d.pitch[p] + off0);
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-            if (off0 < d.pitch[p]) {
-                typename FlagVec<C>::T v;
-                __builtin_memcpy(&v, out[p], C);
-                *reinterpret_cast<typename FlagVec<C>::T *>(mat[p] + size_t(t) * d.pitch[p] + off0) = v;
-            }
-        asm volatile("" ::: "memory");
-    }
-    (void)hbQ; (void)hbR;
-    // (QUERY, 0, 0) is owned by the lane holding window offset 0 of row 0
-    int bs = beg_score, dummy = S_NEG;
-    bs = -bs; dummy = D_INF;   // reuse the min scan: max(score) = -min(-score)
-    wave_prefix_min2(bs, dummy);
-    if (lane == 63) outs[a].beg_plane = (-bs >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
-    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(64 * C); }
 }
 
 // ===========================================================================
@@ -972,10 +490,10 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
 // ===========================================================================
 __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__restrict__ descs,
                                                    const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
-                                                   const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
+                                                   const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs, int tag) {
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
-    if (outs[a].band_ok != FS_W || d.band_pad != FS_W) return;   // rejected by the exit test: re-run wider
+    if (outs[a].band_ok != tag || d.band_pad != tag) return;   // rejected by the exit test (re-run wider) or another round's
     const int lane = threadIdx.x;
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int Lp[2] = {Lq, Lr};
@@ -1095,7 +613,7 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
                 const int zs = lane_get(zl[p] == int(FK_NONE24) ? -1 : zlane, sc1[o], S_NEG);
                 if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((bkc[p] >> 25) & 3)) {
                     const int v = zs + ((bkc[p] >> 27) & 1);
-                    if (v >= 0 && (zf & F_TIE)) tie_used = 1;
+                    if (v >= 0 && (zf & F_TIE)) tie_used++;
                     if (v > b) { b = v; m = F_SWP; } else if (v == b) m |= F_SWP;
                 }
                 if (t == Lt - 1 && p == end_plane && lo[p] + col == Lp[p] - 1) { b = 0; m = F_MAT; }   // dist.cpp:538-546
@@ -1123,7 +641,7 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
                 outm[p] = m;
                 sc1[p] = v;          // becomes the "row t+1" score of the next iteration
                 f1[p] = f0[p];       // ... and its forward flags
-                if (st_ok[p]) fout[p][rowo[p]] = uint8_t(m);
+                if (st_ok[p]) fout[p][rowo[p]] = m ? uint8_t(m | (uint32_t(f0[p]) & F_KEEP)) : uint8_t(0);
                 rowo[p] -= d.pitch[p];
             }
             (void)outm;
@@ -1152,7 +670,7 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
     // (QUERY, 0, 0) is column 0 of row 0 = lane 63 (stripe 0 starts at the origin)
     const int bs = __builtin_amdgcn_readlane(sc1[0], 63);
     if (lane == 0) outs[a].beg_plane = (bs >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
-    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(FS_W); }
+    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(tag); atomicAdd(&outs[a].n_sec, int(tie_used)); }
 }
 
 // ===========================================================================
@@ -1170,12 +688,12 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
 __global__ void __launch_bounds__(64) k_walk_rows(DevBatch B, const AlnDesc *__restrict__ descs,
                                                   const int32_t *__restrict__ work, int n_work,
                                                   const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
-                                                  AlnOut *__restrict__ outs, PathEnt *__restrict__ paths) {
+                                                  AlnOut *__restrict__ outs, PathEnt *__restrict__ paths, int tag) {
     if (int(blockIdx.x) >= n_work) return;
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     AlnOut &O = outs[a];
-    if (O.band_ok != FS_W || d.band_pad != FS_W) return;
+    if (O.band_ok != tag || d.band_pad != tag) return;
     const int lane = threadIdx.x;
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int Lp[2] = {Lq, Lr};

@@ -12,6 +12,11 @@
 #define F_SWP 16
 #define F_CHOICE_SHIFT 5      // bits 5-6: rank of the chosen swap source within the cell's candidate list
 #define F_TIE 128             // bit 7: more than one optimal swap source (order-defined in the reference)
+// The backward sweeps replace a cell's forward flags with its path_ptr byte (low 5 bits; 0 = not on an optimal path) and
+// keep bits 5-7 of the forward flags for cells that are on one: a "used" tied cell is then (byte & F_TIE) != 0 with
+// bwd_allow(the cell's pointer flag), which is what the container-order replay looks for (pr_tie.hip); their number is
+// added to AlnOut::n_sec of a marked alignment (its walk, which sets n_sec, has not run yet).
+#define F_KEEP 0xe0
 
 #define PV 1   // PTR_VARIANT
 #define PB 2   // PTR_VAR_BEG
@@ -20,7 +25,10 @@
 
 // AlnOut::band_ok of an alignment whose backward sweep consulted a tied swap cell (F_TIE): the walk / credit kernels of
 // the round skip it (they require band_ok == tag) and the host's tie pass (pr_tie.hip) picks it up
-#define TIE_MARK(tag) (-(int32_t(tag) + 1))
+#define TIE_MARK(tag) (-(int32_t((tag) & 0x3fff) + 1))
+// level tag of a tie round's descriptors and accept test: the level's own tag with this bit, so that the kernels of the
+// round that marked the alignment (which may still be running) never pick up its new descriptor
+#define TIE_TAG_BIT 0x4000
 
 #define D_INF 0x3f000000
 #define S_NEG (-(1 << 28))

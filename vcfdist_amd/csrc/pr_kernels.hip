@@ -310,13 +310,13 @@ __global__ void __launch_bounds__(NT) k_fwd(DevBatch B, const AlnDesc *__restric
 }
 
 // one thread per alignment: s, end plane (prefer QUERY, dist.cpp:436-439)
-__global__ void k_fwd_finish(const int32_t *__restrict__ work, int n, AlnOut *__restrict__ outs) {
+__global__ void k_fwd_finish(const int32_t *__restrict__ work, int n, AlnOut *__restrict__ outs, int tag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     AlnOut &o = outs[work[i]];
     o.s = min(o.dist_q, o.dist_r);
     o.end_plane = (o.dist_q <= o.dist_r) ? VPR_PLANE_QUERY : VPR_PLANE_REF;
-    o.band_ok = 0;   // dense level (and clears a tie mark when the tie pass re-runs the alignment)
+    o.band_ok = tag;   // 0: dense level; TIE_TAG_BIT: dense level, re-run by a tie round (clears the tie mark)
 }
 
 // ---------------------------------------------------------------------------
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
                     const int zf = FROW(nxt, o, zq[p][c]);
                     if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((kc[p][c] >> 1) & 3)) {
                         const int v = s_ld(o, zq[p][c]) + ((kc[p][c] >> 3) & 1);
-                        if (v >= 0 && (zf & F_TIE)) tie_used = 1;
+                        if (v >= 0 && (zf & F_TIE)) tie_used++;
                         if (v > best) { best = v; m = F_SWP; } else if (v == best) m |= F_SWP;
                     }
                 }
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
                 }
                 if (v < 0) { v = S_NEG; m = 0; }
                 sc[p][c] = v;
-                out[p][c] = m;
+                out[p][c] = m ? uint8_t(m | (f0[p][c] & F_KEEP)) : uint8_t(0);
                 prev = v;
                 f1[p][c] = f0[p][c];
             }
@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
         lds_barrier<NT>();
     }
     if (tid == 0) outs[a].beg_plane = (sc[0][0] >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
-    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(0); }
+    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(0); atomicAdd(&outs[a].n_sec, int(tie_used)); }
 }
 
 // ---------------------------------------------------------------------------

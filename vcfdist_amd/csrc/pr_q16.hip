@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
                 }
                 if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((bkc[p] >> 25) & 3)) {
                     const int v = zs + ((bkc[p] >> 27) & 1);
-                    if (v >= 0 && (zf & F_TIE)) tie_used = 1;
+                    if (v >= 0 && (zf & F_TIE)) tie_used++;
                     if (v > b) { b = v; m = F_SWP; } else if (v == b) m |= F_SWP;
                 }
                 if (t == Lt - 1 && p == end_plane && lo[p] + col == Lp[p] - 1) { b = 0; m = F_MAT; }   // dist.cpp:538-546
@@ -726,7 +726,7 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
                 if (ract) {
                     sc1[p] = v;          // becomes the "row t+1" score of the next iteration
                     f1[p] = f0[p];       // ... and its forward flags
-                    oacc[p] |= m << (8 * r);
+                    oacc[p] |= (m ? (m | (uint32_t(f0[p]) & F_KEEP)) : 0u) << (8 * r);
                 }
             }
         }
@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
     }
     // (QUERY, 0, 0) is column 0 of row 0 = lane 15 of the row (stripe 0 starts at the origin)
     if (on && gl == 15) outs[a].beg_plane = (sc1[0] >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
-    if (on && tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(tag); }
+    if (on && tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(tag); atomicAdd(&outs[a].n_sec, int(tie_used)); }
 }
 
 // ===========================================================================

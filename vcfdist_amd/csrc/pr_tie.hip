@@ -51,7 +51,15 @@ struct TieJob {
     int64_t stamp_off;    // uint32 index into the scratch: stamps[(Lq + Lr) * Lt]
     int64_t buf_off;      // uint32 index (even): 10 * cap words
     int64_t bkt_off;      // uint64 index: bcap words
-    int32_t dbg_us, dbg_steps, dbg_cells, dbg_waves, dbg_w0steps, dbg_totne, dbg_unstable, dbg_lev1;   // written by the kernel (the jobs live in host-pinned memory): VPR_DEBUG
+    // mode 1 ("early"): the job runs before the forward sweep is repeated, on the bytes the backward sweep of the round that
+    // marked the alignment left in that round's workspace (old_*): it decides only the n_used tied cells that sweep
+    // consulted (F_KEEP), appends {alignment, cell, row, choice} to the launch's decision list instead of patching, and
+    // stops behind the wave that decides the last of them.  mode 0: patches the repeated forward sweep's flags in place.
+    int32_t mode, n_used;
+    int32_t old_band_w, old_pitch[2], pad2;
+    int64_t old_mat_off[2], old_blo_off;
+    uint8_t *old_arena;
+    int32_t dbg_us, dbg_steps, dbg_cells, dbg_waves, dbg_nres, dbg_lastw;   // written by the kernel (the jobs live in host-pinned memory): VPR_DEBUG
 };
 #define TIE_BUF_WORDS 10
 
@@ -77,10 +85,16 @@ __device__ __forceinline__ uint8_t *tie_flag_ptr(const AlnDesc &d, uint8_t *ws, 
     return ws + d.mat_off[p] + size_t(t) * d.pitch[p] + x;   // dense
 }
 
+#define TIE_U 4    // chunks of 64 entries a wide pass keeps in flight (the passes are bound by memory round trips)
+
 __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__restrict__ descs,
                                                    TieJob *__restrict__ jobs, int n_jobs, uint8_t *ws,
                                                    const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs,
-                                                   uint32_t *scratch, int32_t *__restrict__ n_overflow) {
+                                                   uint32_t *scratch, int32_t *__restrict__ n_overflow,
+                                                   int4 *__restrict__ dec, int32_t *__restrict__ n_dec, int dec_cap) {
+    // positions with more than one allowed swap source (the only cells that can be tied), one bit per position and plane
+    __shared__ uint32_t mmask[2][1024];
+    __shared__ int lds_ntie, lds_nres;
     const int j = blockIdx.x;
     if (j >= n_jobs) return;
     const TieJob J = jobs[j];
@@ -91,7 +105,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int s_fin = outs[a].s;
     const unsigned long long clk0 = wall_clock64();
-    int dbg_steps = 0, dbg_cells = 0, dbg_waves = 0, dbg_w0steps = 0, dbg_totne = 0, dbg_unstable = 0, dbg_lev1 = 0;
+    int dbg_steps = 0, dbg_cells = 0, dbg_waves = 0, dbg_lastw = -1, dbg_nres0 = 0;
     const uint8_t *seq0 = B.hap_seq[d.qs] + d.q_off, *seq1 = B.ref_seq + d.r_off;
     const int32_t *ptr0 = B.hap_ptr[d.qs] + d.q_off, *ptr1 = B.ref_ptr[d.qs] + d.r_off;
     const uint8_t *flg0 = B.hap_flag[d.qs] + d.q_off, *flg1 = B.ref_flag[d.qs] + d.r_off;
@@ -104,14 +118,45 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     uint2 *qc = reinterpret_cast<uint2 *>(buf), *qn = reinterpret_cast<uint2 *>(buf + 2 * size_t(cap));
     uint32_t *oc = buf + 4 * size_t(cap), *on = buf + 5 * size_t(cap);
     uint32_t *Fa = buf + 6 * size_t(cap), *Ha = buf + 7 * size_t(cap), *Ka = buf + 8 * size_t(cap);
+    uint2 *Ta = reinterpret_cast<uint2 *>(buf + 9 * size_t(cap));    // cells of the current wave that may be tied
+    const int tcap = cap / 2;
     unsigned long long *bfirst = reinterpret_cast<unsigned long long *>(scratch) + J.bkt_off;
     const uint32_t sbase1 = uint32_t(Lq) * uint32_t(Lt);
     auto sidx = [&](int p, int q, int t) -> uint32_t { return (p ? sbase1 : 0u) + uint32_t(q) * uint32_t(Lt) + uint32_t(t); };
     const unsigned long long hi_q = (unsigned long long)(2 * d.aln) * 73856093ull + 0x517cc1b727220a95ull;       // dist.h:45
     const unsigned long long hi_r = (unsigned long long)(2 * d.aln + 1) * 73856093ull + 0x517cc1b727220a95ull;
 
+    bool fail = (cap < 2) || Lq > 32768 || Lr > 32768;
+    for (int p = 0; p < 2 && !fail; p++) {
+        const int L = p ? Lr : Lq;
+        const int4 *cd = p ? cand1 : cand0;
+        for (int x0 = 0; x0 < L; x0 += 64) {
+            const int x = x0 + lane;
+            const bool multi = x < L && cd[x].y >= 0;
+            const unsigned long long bal = __ballot(multi);
+            if (lane < 2) mmask[p][(x0 >> 5) + lane] = uint32_t(bal >> (32 * lane));
+        }
+    }
+    if (lane == 0) { lds_ntie = 0; lds_nres = 0; }
+    __syncthreads();
+    // the layout the tied cells' bytes are read from: the alignment's current descriptor, or (mode 1) the marking round's
+    AlnDesc dl = d;
+    uint8_t *wsl = ws;
+    if (J.mode) {
+        dl.band_w = J.old_band_w; dl.pitch[0] = J.old_pitch[0]; dl.pitch[1] = J.old_pitch[1];
+        dl.mat_off[0] = J.old_mat_off[0]; dl.mat_off[1] = J.old_mat_off[1]; dl.blo_off = J.old_blo_off;
+        wsl = J.old_arena;
+    }
+    const int32_t *blo_l = J.mode ? reinterpret_cast<const int32_t *>(J.old_arena) : blo_all;
+    auto is_multi = [&](int p, int x) -> bool { return (mmask[p][x >> 5] >> (x & 31)) & 1u; };
+    // remember a pushed cell that may be tied (order irrelevant); on overflow the whole wave is scanned instead
+    auto note_tie = [&](int p, int x, int t) {
+        const int k = atomicAdd(&lds_ntie, 1);
+        if (k < tcap) Ta[k] = make_uint2((uint32_t(p) << 31) | uint32_t(x), uint32_t(t));
+    };
+
     // wave 0: the two start cells (dist.cpp:300-305), candidate ids 0 and 1
-    if (lane == 0) {
+    if (lane == 0 && !fail) {
         qc[0] = make_uint2(0u, 0u);
         qc[1] = make_uint2(0x80000000u, 0u);
         stamp[0] = 0u;
@@ -123,21 +168,99 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     int bi = 0;
     uint32_t tag = 0;               // order() invocation counter (tags the bucket words)
     int n_cur = 2;
-    bool fail = (cap < 2);
 
     uint32_t wave_lo = 0;           // candidate ids of the current wave start here
     for (int w = 0; !fail; w++) {
-        // ---- BFS: pop up to 64 entries, expand, append (dist.cpp:317-381)
+        // ---- BFS: pop entries, expand, append (dist.cpp:317-381)
         int head = 0;
         while (head < n_cur) {
-            const int n = min(64, n_cur - head);
+            const int navail = n_cur - head;
+            if (navail > 64) {
+                // ---- wide: up to TIE_U chunks of 64 entries in flight, appended in entry order
+                const int n = min(64 * TIE_U, navail);
+                uint2 x[TIE_U];
+                bool ty[TIE_U], tz[TIE_U];
+                uint32_t iy[TIE_U], iz[TIE_U];
+                int zq[TIE_U];
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {
+                    const int e = u * 64 + lane;
+                    x[u] = make_uint2(0u, 0u);
+                    if (e < n) { const uint32_t *px = reinterpret_cast<const uint32_t *>(qc + head + e); x[u].x = tie_ld(px); x[u].y = tie_ld(px + 1); }
+                }
+                uint8_t tb[TIE_U], sq[TIE_U];
+                int fx[TIE_U], ft[TIE_U];
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {
+                    const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
+                    const bool in = (u * 64 + lane < n) && t + 1 < Lt;
+                    tb[u] = 0; sq[u] = 1; zq[u] = 0; fx[u] = PV; ft[u] = PV;
+                    if (in) {
+                        tb[u] = Ts[t + 1];
+                        ft[u] = Tf[t];
+                        if (q + 1 < (p ? Lr : Lq)) sq[u] = (p ? seq1 : seq0)[q + 1]; else sq[u] = 0xff;
+                        zq[u] = (p ? ptr1 : ptr0)[q] + 1;
+                        fx[u] = (p ? flg1 : flg0)[q];
+                    }
+                }
+                uint8_t so[TIE_U];
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {     // (clamped, unconditional: the four loads go out together)
+                    const int p = int(x[u].x >> 31);
+                    so[u] = (p ? seq0 : seq1)[min(max(zq[u], 0), (p ? Lq : Lr) - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {
+                    const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
+                    const bool in = (u * 64 + lane < n) && t + 1 < Lt;
+                    ty[u] = in && sq[u] == tb[u] && q + 1 < (p ? Lr : Lq);
+                    tz[u] = in && fwd_allow(fx[u]) && fwd_allow(ft[u]) && zq[u] >= 0 && zq[u] < (p ? Lq : Lr) && so[u] == tb[u];
+                    iy[u] = ty[u] ? sidx(p, q + 1, t + 1) : 0u;
+                    iz[u] = tz[u] ? sidx(1 - p, zq[u], t + 1) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {
+                    const uint32_t cy = cid + 2u * uint32_t(u * 64 + lane);
+                    if (ty[u]) (void)atomicMin(stamp + iy[u], cy);
+                    if (tz[u]) (void)atomicMin(stamp + iz[u], cy + 1u);
+                }
+                tie_wait();
+                bool wy[TIE_U], wz[TIE_U];
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {
+                    const uint32_t cy = cid + 2u * uint32_t(u * 64 + lane);
+                    wy[u] = ty[u] && tie_ld(stamp + iy[u]) == cy;
+                    wz[u] = tz[u] && tie_ld(stamp + iz[u]) == cy + 1u;
+                }
+                int base = n_cur;
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {
+                    const unsigned long long by = __ballot(wy[u]), bz = __ballot(wz[u]);
+                    const int tot = __popcll(by) + __popcll(bz);
+                    if (base + tot > cap) { fail = true; break; }
+                    const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
+                    const int py = base + __popcll(by & lt_mask) + __popcll(bz & lt_mask);
+                    if (wy[u]) { qc[py] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1); }
+                    if (wz[u]) { qc[py + (wy[u] ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq[u]), uint32_t(t + 1)); if (is_multi(1 - p, zq[u])) note_tie(1 - p, zq[u], t + 1); }
+                    base += tot;
+                }
+                if (fail) break;
+                tie_wait();
+                n_cur = base;
+                head += n;
+                dbg_steps++;
+                cid += 2u * uint32_t(n);
+                if (cid > 0xf0000000u) { fail = true; break; }
+                continue;
+            }
+            const int n = navail;
             // Narrow stretches (a lone run of matches behind the last edit; all of wave 0) are chains of levels of a few
             // cells each.  When the chunk is the whole queue and all its cells sit in one truth row, lanes j * n + i look
             // ahead at slot i of level j (the slot's cell moved j steps down its diagonal).  Level j only touches row
             // t + j + 1, which no earlier level of the batch touches, so if every slot's candidate pushes are valid /
             // invalid / already pushed exactly as on level 0 and its swap target moves along, level j repeats level 0's
             // outcome, and all those levels are committed at once.
-            const bool ff = (head + n == n_cur) && (n <= 32);
+            const bool ff = n <= 32;
             const int nk = ff ? 64 / n : 1;
             const int jl = ff ? lane / n : 0, il = ff ? lane - jl * n : lane;
             const bool act = lane < nk * n;
@@ -173,13 +296,11 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             const int ry = __popcll(by & lt_mask) + __popcll(bz & lt_mask);    // rank of this lane's first winner
             int nlev = 1;
             const bool one_row = !__any(l0 && int(x.y) != __shfl(int(x.y), 0));
-            if (w == 0) { dbg_w0steps++; if (!ff || tot != n) dbg_totne++; }
             if (ff && one_row && tot == n && n_cur + nk * n <= cap) {
                 // level 0 must reproduce the frontier, slot by slot, one step down the diagonals
                 const uint32_t ycode = x.x + 1u, zcode = (uint32_t(1 - p) << 31) | uint32_t(zq);
                 const uint32_t sy = uint32_t(__shfl(int(x.x), ry)) + 1u, sz = uint32_t(__shfl(int(x.x), ry + (wy ? 1 : 0))) + 1u;
                 const bool stable = !__any((wy && ycode != sy) || (wz && zcode != sz));
-                if (!stable) dbg_unstable++;
                 if (stable) {
                     // outcome class of a candidate push: 0 invalid, 1 pushed, 2 same cell as an earlier candidate of the
                     // level, 3 cell pushed before this level
@@ -190,18 +311,23 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                                       (!ty || ((vy == TIE_NEVER) == (ky0 != 3))) && (!tz || ((vz == TIE_NEVER) == (kz0 != 3)));
                     const unsigned long long bad = __ballot(act && !l0 && !same);
                     nlev = bad ? int(__builtin_ctzll(bad)) / n : nk;
-                    if (nlev == 1) dbg_lev1++;
                     const int ry0 = __shfl(ry, il);
                     if (jl >= 1 && jl < nlev) {
                         const uint32_t c0 = cid + 2u * uint32_t(n) * uint32_t(jl) + 2u * uint32_t(il);
                         const int pos = n_cur + jl * n + ry0;
-                        if (ky0 == 1) { stamp[iy] = c0; qc[pos] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); }
-                        if (kz0 == 1) { stamp[iz] = c0 + 1u; qc[pos + (ky0 == 1 ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1)); }
+                        if (ky0 == 1) {
+                            stamp[iy] = c0; qc[pos] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1));
+                            if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1);
+                        }
+                        if (kz0 == 1) {
+                            stamp[iz] = c0 + 1u; qc[pos + (ky0 == 1 ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1));
+                            if (is_multi(1 - p, zq)) note_tie(1 - p, zq, t + 1);
+                        }
                     }
                 }
             }
-            if (wy) qc[n_cur + ry] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1));
-            if (wz) qc[n_cur + ry + (wy ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1));
+            if (wy) { qc[n_cur + ry] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1); }
+            if (wz) { qc[n_cur + ry + (wy ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1)); if (is_multi(1 - p, zq)) note_tie(1 - p, zq, t + 1); }
             tie_wait();
             n_cur += tot * nlev;
             head += n * nlev;
@@ -211,28 +337,48 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
         }
         if (fail) break;
         // ---- tied cells popped in this wave: the allowed source popped last wins (dist.cpp:347,376)
-        for (int i0 = 0; i0 < n_cur; i0 += 64) {
-            const int i = i0 + lane;
-            if (i >= n_cur) continue;
-            const uint2 z = qc[i];
-            const int p = int(z.x >> 31), xq = int(z.x & 0x7fffffffu), t = int(z.y);
-            if (t == 0) continue;
-            uint8_t *fp = tie_flag_ptr(d, ws, blo_all, p, xq, t);
-            if (!fp) continue;
-            const uint32_t f = *fp;
-            if ((f & (F_SWP | F_TIE)) != (F_SWP | F_TIE)) continue;
-            const int4 cc = (p ? cand1 : cand0)[xq];
-            const int srcs[4] = {cc.x, cc.y, cc.z, cc.w};
-            int best = -1;
-            uint32_t best_st = 0;
+        {
+            __syncthreads();
+            const int ntie = lds_ntie;
+            __syncthreads();
+            if (lane == 0) lds_ntie = 0;
+            const bool scan_all = ntie > tcap;         // the list overflowed: look at every cell of the wave
+            const int nn = scan_all ? n_cur : ntie;
+            for (int i0 = 0; i0 < nn; i0 += 64) {
+                const int i = i0 + lane;
+                if (i >= nn) continue;
+                const uint2 z = scan_all ? qc[i] : Ta[i];
+                const int p = int(z.x >> 31), xq = int(z.x & 0x7fffffffu), t = int(z.y);
+                if (t == 0) continue;
+                uint8_t *fp = tie_flag_ptr(dl, wsl, blo_l, p, xq, t);
+                if (!fp) continue;
+                const uint32_t f = *fp;
+                if (J.mode) {      // consulted by the backward sweep: on an optimal path, tied, swap edge allowed (dist.cpp:600)
+                    if (!(f & F_TIE) || !(f & 31) || !bwd_allow((p ? flg1 : flg0)[xq])) continue;
+                } else if ((f & (F_SWP | F_TIE)) != (F_SWP | F_TIE)) continue;
+                const int4 cc = (p ? cand1 : cand0)[xq];
+                const int srcs[4] = {cc.x, cc.y, cc.z, cc.w};
+                int best = -1;
+                uint32_t best_st = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (srcs[k] < 0) continue;
-                const uint32_t st = tie_ld(stamp + sidx(1 - p, srcs[k], t - 1));
-                if (st == TIE_NEVER || st < wave_lo) continue;       // not popped in z's wave
-                if (best < 0 || st > best_st) { best = k; best_st = st; }
+                for (int k = 0; k < 4; k++) {
+                    if (srcs[k] < 0) continue;
+                    const uint32_t st = tie_ld(stamp + sidx(1 - p, srcs[k], t - 1));
+                    if (st == TIE_NEVER || st < wave_lo) continue;       // not popped in z's wave
+                    if (best < 0 || st > best_st) { best = k; best_st = st; }
+                }
+                if (best < 0) continue;
+                if (J.mode) {
+                    const int k = atomicAdd(n_dec, 1);
+                    if (k < dec_cap) dec[k] = make_int4(a, int(z.x), t, best);
+                    atomicAdd(&lds_nres, 1);
+                } else {
+                    *fp = uint8_t((f & ~uint32_t((3u << F_CHOICE_SHIFT) | F_TIE)) | (uint32_t(best) << F_CHOICE_SHIFT));
+                }
             }
-            if (best >= 0) *fp = uint8_t((f & ~uint32_t((3u << F_CHOICE_SHIFT) | F_TIE)) | (uint32_t(best) << F_CHOICE_SHIFT));
+            __syncthreads();
+            if (lds_nres != dbg_nres0) { dbg_nres0 = lds_nres; dbg_lastw = w; }
+            if (J.mode && lds_nres >= J.n_used) { dbg_cells += n_cur; dbg_waves++; break; }   // every consulted tie is decided
         }
         dbg_cells += n_cur; dbg_waves++;
         if (w >= s_fin) break;
@@ -248,68 +394,99 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             tag++;
             const unsigned long long tagw = (unsigned long long)(~tag) << 32;
             // pass A: bucket of every element, first insertion per bucket; H / K cleared
-            for (int i0 = 0; i0 < m; i0 += 64) {
-                const int i = i0 + lane;
-                if (i >= m) continue;
-                const uint32_t e = (have_lam && i < done) ? oc[i] : uint32_t(i);
-                const uint2 c = qc[e];
-                const unsigned long long hv = ((c.x >> 31) ? hi_r : hi_q) ^
-                                              ((unsigned long long)(c.x & 0x7fffffffu) * 19349669ull + 0xd15f392b3d4704a2ull) ^
-                                              ((unsigned long long)(c.y) * 83492791ull);
-                const uint32_t b = uint32_t(hv % (unsigned long long)n_bkt);
-                Fa[i] = b;
-                Ha[i] = 0u;
-                Ka[i] = 0u;
-                (void)atomicMin(bfirst + b, tagw | (unsigned long long)uint32_t(i));
+            for (int i0 = 0; i0 < m; i0 += 64 * TIE_U) {
+                uint32_t e[TIE_U];
+                uint2 c[TIE_U];
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {
+                    const int i = i0 + u * 64 + lane;
+                    e[u] = (i < m) ? ((have_lam && i < done) ? oc[i] : uint32_t(i)) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) c[u] = (i0 + u * 64 + lane < m) ? qc[e[u]] : make_uint2(0u, 0u);
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {
+                    const int i = i0 + u * 64 + lane;
+                    if (i >= m) continue;
+                    const unsigned long long hv = ((c[u].x >> 31) ? hi_r : hi_q) ^
+                                                  ((unsigned long long)(c[u].x & 0x7fffffffu) * 19349669ull + 0xd15f392b3d4704a2ull) ^
+                                                  ((unsigned long long)(c[u].y) * 83492791ull);
+                    const uint32_t b = uint32_t(hv % (unsigned long long)n_bkt);
+                    Fa[i] = b;
+                    Ha[i] = 0u;
+                    Ka[i] = 0u;
+                    (void)atomicMin(bfirst + b, tagw | (unsigned long long)uint32_t(i));
+                }
             }
             tie_wait();
             // pass B: F_i = first insertion index of the element's bucket; histogram of F
-            for (int i0 = 0; i0 < m; i0 += 64) {
-                const int i = i0 + lane;
-                if (i >= m) continue;
-                const uint32_t b = tie_ld(Fa + i);
-                const unsigned long long fw = __hip_atomic_load(bfirst + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t f = uint32_t(fw & 0xffffffffull);
-                Fa[i] = f;
-                (void)atomicAdd(Ha + f, 1u);
+            for (int i0 = 0; i0 < m; i0 += 64 * TIE_U) {
+                uint32_t b[TIE_U];
+                unsigned long long fw[TIE_U];
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) b[u] = (i0 + u * 64 + lane < m) ? tie_ld(Fa + i0 + u * 64 + lane) : 0u;
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++)
+                    fw[u] = (i0 + u * 64 + lane < m) ? __hip_atomic_load(bfirst + b[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {
+                    const int i = i0 + u * 64 + lane;
+                    if (i >= m) continue;
+                    const uint32_t f = uint32_t(fw[u] & 0xffffffffull);
+                    Fa[i] = f;
+                    (void)atomicAdd(Ha + f, 1u);
+                }
             }
             tie_wait();
             // exclusive suffix sum over H: G[f] = elements in buckets created after f
             {
                 uint32_t run = 0;
-                for (int i0 = (m - 1) & ~63; i0 >= 0; i0 -= 64) {
-                    const int i = i0 + lane;
-                    const uint32_t hcnt = (i < m) ? tie_ld(Ha + i) : 0u;
-                    uint32_t suf = hcnt;
+                const int top = ((m - 1) / (64 * TIE_U)) * (64 * TIE_U);
+                for (int i0 = top; i0 >= 0; i0 -= 64 * TIE_U) {
+                    uint32_t hcnt[TIE_U];
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const uint32_t tv = uint32_t(__shfl_down(int(suf), o));
-                        if (lane + o < 64) suf += tv;
+                    for (int u = 0; u < TIE_U; u++) hcnt[u] = (i0 + u * 64 + lane < m) ? tie_ld(Ha + i0 + u * 64 + lane) : 0u;
+#pragma unroll
+                    for (int u = TIE_U - 1; u >= 0; u--) {
+                        const int i = i0 + u * 64 + lane;
+                        uint32_t suf = hcnt[u];
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const uint32_t tv = uint32_t(__shfl_down(int(suf), o));
+                            if (lane + o < 64) suf += tv;
+                        }
+                        if (i < m) Ha[i] = run + suf - hcnt[u];
+                        run += uint32_t(__shfl(int(suf), 0));
                     }
-                    if (i < m) Ha[i] = run + suf - hcnt;
-                    run += uint32_t(__shfl(int(suf), 0));
                 }
             }
             tie_wait();
             // pass C, descending: position = G[F_i] + elements of the same bucket inserted later
-            for (int i0 = (m - 1) & ~63; i0 >= 0; i0 -= 64) {
-                const int i = i0 + lane;
-                const bool act = i < m;
-                const uint32_t f = act ? tie_ld(Fa + i) : 0xffffffffu;
-                const uint32_t base = act ? tie_ld(Ka + f) : 0u;
-                const uint32_t g = act ? tie_ld(Ha + f) : 0u;
-                uint32_t intra = 0;
-                for (int l2 = 1; l2 < 64; l2++) {
-                    const uint32_t v = uint32_t(__builtin_amdgcn_readlane(int(f), l2));
-                    intra += (l2 > lane && v == f) ? 1u : 0u;
+            {
+                const int top = (m - 1) & ~63;
+                uint32_t fn = (top + lane < m) ? tie_ld(Fa + top + lane) : 0xffffffffu;    // F of the chunk, one chunk ahead
+                uint32_t en = (top + lane < m) ? ((have_lam && top + lane < done) ? oc[top + lane] : uint32_t(top + lane)) : 0u;
+                for (int i0 = top; i0 >= 0; i0 -= 64) {
+                    const int i = i0 + lane;
+                    const bool act = i < m;
+                    const uint32_t f = fn, e = en;
+                    if (i0 >= 64) {
+                        fn = tie_ld(Fa + i - 64);
+                        en = (have_lam && i - 64 < done) ? oc[i - 64] : uint32_t(i - 64);
+                    }
+                    const uint32_t base = act ? tie_ld(Ka + f) : 0u;
+                    const uint32_t g = act ? tie_ld(Ha + f) : 0u;
+                    uint32_t intra = 0;
+                    for (int l2 = 1; l2 < 64; l2++) {
+                        const uint32_t v = uint32_t(__builtin_amdgcn_readlane(int(f), l2));
+                        intra += (l2 > lane && v == f) ? 1u : 0u;
+                    }
+                    if (act) {
+                        on[g + base + intra] = e;
+                        (void)atomicAdd(Ka + f, 1u);     // (issued behind this chunk's loads of K; the wait below orders it
+                    }                                    //  in front of the next chunk's)
+                    tie_wait();
                 }
-                tie_wait();
-                if (act) {
-                    const uint32_t e = (have_lam && i < done) ? oc[i] : uint32_t(i);
-                    on[g + base + intra] = e;
-                    (void)atomicAdd(Ka + f, 1u);
-                }
-                tie_wait();
             }
             { uint32_t *tmp = oc; oc = on; on = tmp; }
             have_lam = true;
@@ -323,33 +500,49 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
         // ---- next wave: INS, DEL, SUB targets of every popped cell, in iteration order (dist.cpp:395-424)
         int n_next = 0;
         wave_lo = cid;
-        for (int k0 = 0; k0 < n; k0 += 64) {
-            const int k = k0 + lane;
-            const bool act = k < n;
-            uint2 x = make_uint2(0u, 0u);
-            if (act) x = qc[tie_ld(oc + k)];
-            const int p = int(x.x >> 31), q = int(x.x & 0x7fffffffu), t = int(x.y);
-            const int Lme = p ? Lr : Lq;
-            const bool t0 = act && q + 1 < Lme, t1 = act && t + 1 < Lt, t2 = t0 && t1;
-            const uint32_t c0 = cid + 3u * uint32_t(lane);
-            const uint32_t i0_ = t0 ? sidx(p, q + 1, t) : 0u, i1_ = t1 ? sidx(p, q, t + 1) : 0u, i2_ = t2 ? sidx(p, q + 1, t + 1) : 0u;
-            if (t0) (void)atomicMin(stamp + i0_, c0);
-            if (t1) (void)atomicMin(stamp + i1_, c0 + 1u);
-            if (t2) (void)atomicMin(stamp + i2_, c0 + 2u);
+        for (int k0 = 0; k0 < n && !fail; k0 += 64 * TIE_U) {
+            uint32_t e[TIE_U];
+            uint2 x[TIE_U];
+            bool t0[TIE_U], t1[TIE_U], t2[TIE_U];
+            uint32_t j0[TIE_U], j1[TIE_U], j2[TIE_U];
+#pragma unroll
+            for (int u = 0; u < TIE_U; u++) e[u] = (k0 + u * 64 + lane < n) ? tie_ld(oc + k0 + u * 64 + lane) : 0u;
+#pragma unroll
+            for (int u = 0; u < TIE_U; u++) x[u] = (k0 + u * 64 + lane < n) ? qc[e[u]] : make_uint2(0u, 0u);
+#pragma unroll
+            for (int u = 0; u < TIE_U; u++) {
+                const bool act = k0 + u * 64 + lane < n;
+                const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
+                t0[u] = act && q + 1 < (p ? Lr : Lq); t1[u] = act && t + 1 < Lt; t2[u] = t0[u] && t1[u];
+                const uint32_t c0 = cid + 3u * uint32_t(u * 64 + lane);
+                j0[u] = t0[u] ? sidx(p, q + 1, t) : 0u; j1[u] = t1[u] ? sidx(p, q, t + 1) : 0u; j2[u] = t2[u] ? sidx(p, q + 1, t + 1) : 0u;
+                if (t0[u]) (void)atomicMin(stamp + j0[u], c0);
+                if (t1[u]) (void)atomicMin(stamp + j1[u], c0 + 1u);
+                if (t2[u]) (void)atomicMin(stamp + j2[u], c0 + 2u);
+            }
             tie_wait();
-            const bool w0 = t0 && tie_ld(stamp + i0_) == c0;
-            const bool w1 = t1 && tie_ld(stamp + i1_) == c0 + 1u;
-            const bool w2 = t2 && tie_ld(stamp + i2_) == c0 + 2u;
-            const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1), b2 = __ballot(w2);
-            const int tot = __popcll(b0) + __popcll(b1) + __popcll(b2);
-            if (n_next + tot > cap) { fail = true; break; }
-            int pos = n_next + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask);
-            if (w0) qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t));
-            if (w1) qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q), uint32_t(t + 1));
-            if (w2) qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1));
-            n_next += tot;
-            cid += 3u * uint32_t(min(64, n - k0));
-            if (cid > 0xf0000000u) { fail = true; break; }
+            bool w0[TIE_U], w1[TIE_U], w2[TIE_U];
+#pragma unroll
+            for (int u = 0; u < TIE_U; u++) {
+                const uint32_t c0 = cid + 3u * uint32_t(u * 64 + lane);
+                w0[u] = t0[u] && tie_ld(stamp + j0[u]) == c0;
+                w1[u] = t1[u] && tie_ld(stamp + j1[u]) == c0 + 1u;
+                w2[u] = t2[u] && tie_ld(stamp + j2[u]) == c0 + 2u;
+            }
+#pragma unroll
+            for (int u = 0; u < TIE_U; u++) {
+                const unsigned long long b0 = __ballot(w0[u]), b1 = __ballot(w1[u]), b2 = __ballot(w2[u]);
+                const int tot = __popcll(b0) + __popcll(b1) + __popcll(b2);
+                if (n_next + tot > cap) { fail = true; break; }
+                const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
+                int pos = n_next + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask);
+                if (w0[u]) { qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t); }
+                if (w1[u]) { qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q), uint32_t(t + 1)); if (is_multi(p, q)) note_tie(p, q, t + 1); }
+                if (w2[u]) { qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1); }
+                n_next += tot;
+            }
+            cid += 3u * uint32_t(min(64 * TIE_U, n - k0));
+            if (cid > 0xf0000000u) fail = true;
         }
         if (fail) break;
         tie_wait();
@@ -361,8 +554,21 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     if (lane == 0) {
         jobs[j].dbg_us = int32_t((wall_clock64() - clk0) / 100);   // 100 MHz counter
         jobs[j].dbg_steps = dbg_steps; jobs[j].dbg_cells = dbg_cells; jobs[j].dbg_waves = dbg_waves;
-        jobs[j].dbg_w0steps = dbg_w0steps; jobs[j].dbg_totne = dbg_totne; jobs[j].dbg_unstable = dbg_unstable; jobs[j].dbg_lev1 = dbg_lev1;
+        jobs[j].dbg_nres = lds_nres; jobs[j].dbg_lastw = dbg_lastw;
     }
+}
+
+// apply a launch's decision list to the flags the repeated forward sweep has just written (tie-round descriptors)
+__global__ void k_tie_patch(const AlnDesc *__restrict__ descs, const int4 *__restrict__ dec, const int32_t *__restrict__ n_dec,
+                            int dec_cap, uint8_t *ws) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(*n_dec, dec_cap)) return;
+    const int4 e = dec[i];
+    const AlnDesc d = descs[e.x];
+    uint8_t *fp = tie_flag_ptr(d, ws, reinterpret_cast<const int32_t *>(ws), int(uint32_t(e.y) >> 31), e.y & 0x7fffffff, e.z);
+    if (!fp) return;
+    const uint32_t f = *fp;
+    *fp = uint8_t((f & ~uint32_t((3u << F_CHOICE_SHIFT) | F_TIE)) | (uint32_t(e.w) << F_CHOICE_SHIFT));
 }
 
 #endif

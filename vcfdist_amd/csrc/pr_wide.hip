@@ -316,11 +316,11 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc *__restrict__ descs,
                                                       const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
-                                                      const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
+                                                      const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs, int tag) {
     constexpr int W = NW * 64;
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
-    if (outs[a].band_ok != W || d.band_pad != W) return;   // rejected by the exit test: re-run wider (uniform)
+    if (outs[a].band_ok != tag || d.band_pad != tag) return;   // rejected by the exit test: re-run wider (uniform)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = W - 1 - tid;                   // window column of this thread
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
                 const int zs = gather_s(pp, o, hasz ? zl[p] - (first ? plo[o] : lo[o]) : -1);
                 if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((bkc[p] >> 25) & 3)) {
                     const int v = zs + ((bkc[p] >> 27) & 1);
-                    if (v >= 0 && (zf & F_TIE)) tie_used = 1;
+                    if (v >= 0 && (zf & F_TIE)) tie_used++;
                     if (v > b) { b = v; m = F_SWP; } else if (v == b) m |= F_SWP;
                 }
                 if (t == Lt - 1 && p == end_plane && x == Lp[p] - 1) { b = 0; m = F_MAT; }   // dist.cpp:538-546
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
                 f1[p] = f0[p];
                 f1r[p] = f0rr[p];
                 carry_prev[p] = carry[p];
-                if (col < pitch[p]) fout[p][(t - t0) * pitch[p] + col] = uint8_t(m);
+                if (col < pitch[p]) fout[p][(t - t0) * pitch[p] + col] = m ? uint8_t(m | (uint32_t(f0[p]) & F_KEEP)) : uint8_t(0);
             }
         }
         // ---- stripe end: flush the path_ptr rows in place of the forward flags, park the prefetched rows below
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
     }
     // (QUERY, 0, 0) is column 0 of row 0 (stripe 0 starts at the origin): the last thread
     if (tid == W - 1) outs[a].beg_plane = (sc1[0] >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
-    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(W); }
+    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(tag); atomicAdd(&outs[a].n_sec, int(tie_used)); }
 }
 
 #endif
