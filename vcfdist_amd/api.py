@@ -31,6 +31,12 @@ def build(force=False):
     return LIB_PATH
 
 
+# The path keeps up to eight HIP streams busy at once (two parts of round 0, two retry ladders, two tie ladders and
+# their side streams); the runtime's default of four hardware queues would serialise them pairwise.  Read by the HIP
+# runtime when it initialises, so it has to be in the environment before the first HIP call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 def lib():
     global _LIB
     if _LIB is not None:

@@ -82,6 +82,13 @@ struct LadderCtx {
     int slot_cur = 0; int64_t fail_cur = 0, arena_cur = 0; size_t stage_cur = 0;
     std::vector<std::pair<int, int64_t>> pending;       // (slot, fail list offset) of the launches in flight
     std::vector<Plan> plans;
+    // tie ladders only: a side stream for the early replays (they run beside the repeated forward sweep), the event that
+    // joins it back, and the replay scratch of each of the two streams (grown on demand, released with the batch)
+    hipStream_t ls2 = nullptr; hipEvent_t ev2 = nullptr;
+    uint32_t *tie_scratch[2] = {nullptr, nullptr}; int64_t tie_scratch_bytes[2] = {0, 0};
+    // bytes at the front of each scratch that are preset (filled at the start of vpr_execute, beside round 0, with as much
+    // as the previous execute's first launch used) and the size of that first launch
+    int64_t tie_clean[2] = {0, 0}, tie_first[2] = {0, 0}; bool tie_first_seen[2] = {false, false};
 };
 
 struct EvPair { hipEvent_t a, b; int kind; vpr_launch_stat st; };
@@ -113,9 +120,11 @@ struct vpr_handle {
     AlnDesc *d_descs = nullptr;
     AlnOut *d_outs = nullptr;
     uint8_t *d_arena = nullptr; int64_t arena_bytes = 0;      // workspace of the round-0 plan
-    LadderCtx lad[3];                                         // two retry ladders + the tie rounds (own workspaces, beside the arena)
-    hipEvent_t ev_slot[2 + 3 * LadderCtx::N_SLOTS] = {};      // "fail list of slot k is complete"
-    hipStream_t tie_stream = nullptr;                         // tie rounds (latency chains: high priority)
+    LadderCtx lad[4];                                         // two retry ladders, two tie ladders (long / short part of round 0;
+                                                              // own workspaces, beside the arena)
+    hipEvent_t ev_slot[2 + 4 * LadderCtx::N_SLOTS] = {};      // "fail list of slot k is complete"
+    hipStream_t tie_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // tie ladder k: [2k] main, [2k+1] early replays (high priority)
+    hipEvent_t ev_tie2[2] = {nullptr, nullptr};
     hipEvent_t ev_tie[2] = {nullptr, nullptr};                // "the tie list of the long / short part of round 0 is published"
     std::vector<std::pair<std::vector<int32_t>, uint8_t *>> resident;   // alignments whose walks are still in a workspace
     Section *d_secs = nullptr; int64_t n_secs_cap = 0;
@@ -130,9 +139,10 @@ struct vpr_handle {
     // completion flags in host-pinned memory, written by one-thread kernels behind the work they stand for: the host
     // polls plain memory instead of HIP events (hipEventQuery in a tight loop delays the very submissions it waits for)
     int32_t *hp_flag = nullptr; int32_t flag_seq = 0;
-    int32_t *d_tie_cnt = nullptr, *hp_tie_cnt = nullptr;     // [0] final pass, [1] replay overflows, [2] long part, [3] short part
+    int32_t *d_tie_cnt = nullptr, *hp_tie_cnt = nullptr;     // [0] final pass, [1] replay overflows, [2] long part, [3] short part,
+                                                             // [4] speculative candidates of the long part
+    hipEvent_t ev_spec = nullptr;                            // the speculative replays of the long part are done
     TieJob *hp_tie_jobs = nullptr; size_t tie_jobs_cap = 0;
-    uint32_t *d_tie_scratch = nullptr; int64_t tie_scratch_bytes = 0;
     int4 *d_tie_dec = nullptr; int64_t tie_dec_cap = 0;       // decision lists of the early replays (one region per launch)
     int32_t *d_tie_ndec = nullptr;                            // their lengths [TIE_DEC_SLOTS]
     std::vector<int32_t> plan0_pos;                           // position of every alignment in plan0's work list
@@ -203,13 +213,14 @@ void free_batch(vpr_handle *h) {
     h->dirty.clear();
     h->d_arena = nullptr; h->d_secs = nullptr;
     for (int k = 0; k < 4; k++) h->d_cls[k] = nullptr;
-    for (int k = 0; k < 3; k++) h->lad[k] = LadderCtx();
+    for (int k = 0; k < 4; k++) {
+        for (int e = 0; e < 2; e++) if (h->lad[k].tie_scratch[e]) (void)hipFree(h->lad[k].tie_scratch[e]);
+        h->lad[k] = LadderCtx();
+    }
     h->resident.clear();
     h->d_ed_scratch = nullptr; h->ed_scratch_ints = 0;
     h->d_tie_list = nullptr; h->hp_tie_list = nullptr; h->tie_list_cap = 0; h->d_tie_cnt = nullptr; h->hp_tie_cnt = nullptr;
     h->hp_tie_jobs = nullptr; h->tie_jobs_cap = 0;
-    if (h->d_tie_scratch) (void)hipFree(h->d_tie_scratch);
-    h->d_tie_scratch = nullptr; h->tie_scratch_bytes = 0;
     h->d_tie_dec = nullptr; h->tie_dec_cap = 0; h->d_tie_ndec = nullptr; h->plan0_pos.clear();
     h->uploaded = h->executed = false;
 }
@@ -354,6 +365,19 @@ __global__ void k_collect_ties_list(const int32_t *__restrict__ work, int n, con
     if (b >= 0) return;
     const int k = atomicAdd(cnt, 1);
     if (k < cap) list[k] = make_int4(a, -b - 1, outs[a].n_sec, 0);
+}
+// long alignments accepted at `tag` whose forward sweep met a tied cell within the alignment's distance
+// (AlnOut::path_len = that cell's distance + 1, k_fwd_stripe): candidates for a speculative replay
+__global__ void k_collect_spec(const int32_t *__restrict__ work, int n, const AlnOut *__restrict__ outs, int tag, int4 *__restrict__ list,
+                               int32_t *__restrict__ cnt, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int a = work[i];
+    if (a < 0) return;
+    const AlnOut o = outs[a];
+    if (o.band_ok != tag || o.path_len <= 0 || o.path_len - 1 > o.s) return;
+    const int k = atomicAdd(cnt, 1);
+    if (k < cap) list[k] = make_int4(a, tag, 0, 0);
 }
 __global__ void k_publish_ties(const int4 *__restrict__ list, const int32_t *__restrict__ cnt, int4 *__restrict__ h_list,
                                int32_t *__restrict__ h_cnt, int cap) {
@@ -548,13 +572,17 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
             return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
         }
     }
-    for (int k = 0; k < 2 + 3 * LadderCtx::N_SLOTS; k++)
+    for (int k = 0; k < 2 + 4 * LadderCtx::N_SLOTS; k++)
         if (hipEventCreateWithFlags(&h->ev_slot[k], hipEventDisableTiming) != hipSuccess)
             return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
-    if (hipStreamCreateWithPriority(&h->tie_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_tie[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_tie[1], hipEventDisableTiming) != hipSuccess)
-        return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
+    for (int k = 0; k < 4; k++)
+        if (hipStreamCreateWithPriority(&h->tie_stream[k], hipStreamNonBlocking, prio_hi) != hipSuccess)
+            return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
+    for (int k = 0; k < 2; k++)
+        if (hipEventCreateWithFlags(&h->ev_tie[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_tie2[k], hipEventDisableTiming) != hipSuccess)
+            return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
+    if (hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming) != hipSuccess) return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess)
         return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     // allow the big dense classes to use the whole 160 KiB LDS of a CU
@@ -580,10 +608,14 @@ void vpr_destroy(vpr_handle *h) {
         if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (int k = 0; k < 2 + 3 * LadderCtx::N_SLOTS; k++)
+    for (int k = 0; k < 2 + 4 * LadderCtx::N_SLOTS; k++)
         if (h->ev_slot[k]) (void)hipEventDestroy(h->ev_slot[k]);
-    if (h->tie_stream) (void)hipStreamDestroy(h->tie_stream);
-    for (int k = 0; k < 2; k++) if (h->ev_tie[k]) (void)hipEventDestroy(h->ev_tie[k]);
+    for (int k = 0; k < 4; k++) if (h->tie_stream[k]) (void)hipStreamDestroy(h->tie_stream[k]);
+    for (int k = 0; k < 2; k++) {
+        if (h->ev_tie[k]) (void)hipEventDestroy(h->ev_tie[k]);
+        if (h->ev_tie2[k]) (void)hipEventDestroy(h->ev_tie2[k]);
+    }
+    if (h->ev_spec) (void)hipEventDestroy(h->ev_spec);
     delete h;
 }
 
@@ -751,11 +783,11 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     R.phase_threshold = h->cfg.phase_threshold;
     h->tie_list_cap = int32_t(std::min<size_t>(std::max<size_t>(na, 1), size_t(1) << 20));
     if ((rc = dev_alloc(h, &h->d_tie_list, size_t(h->tie_list_cap)))) return rc;
-    if ((rc = dev_alloc(h, &h->d_tie_cnt, 4))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tie_cnt, 8))) return rc;
     if ((rc = dev_alloc(h, &h->d_tie_ndec, TIE_DEC_SLOTS))) return rc;
     // fail lists: round 0 in [0, na + na/16 + 256) (a list that feeds a kernel directly is padded), the retry rounds of
     // the two ladders behind, the tie rounds' (which reject nothing) last
-    const size_t n_fail = 3 * na + na / 16 + 768, n_slots = 2 + 3 * LadderCtx::N_SLOTS;
+    const size_t n_fail = 4 * na + na / 16 + 1024, n_slots = 2 + 4 * LadderCtx::N_SLOTS;
     if ((rc = dev_alloc(h, &h->d_fail, n_fail))) return rc;
     if ((rc = dev_alloc(h, &h->d_cnt, n_slots))) return rc;
     {
@@ -766,15 +798,15 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         h->pinned.push_back(pc);
         HIPCHK(h, hipHostMalloc(&pl, size_t(h->tie_list_cap) * sizeof(int4), hipHostMallocDefault));
         h->pinned.push_back(pl);
-        HIPCHK(h, hipHostMalloc(&pt, 16 * sizeof(int32_t), hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc(&pt, 32 * sizeof(int32_t), hipHostMallocDefault));
         h->pinned.push_back(pt);
         h->hp_fail = static_cast<int32_t *>(pf);
         h->hp_cnt = static_cast<int32_t *>(pc);
         h->hp_tie_list = static_cast<int4 *>(pl);
         h->hp_tie_cnt = static_cast<int32_t *>(pt);
-        h->hp_flag = h->hp_tie_cnt + 4;     // [0..1] fail lists of round 0, [2..3] tie lists, [4..6] ladders + tie rounds idle
+        h->hp_flag = h->hp_tie_cnt + 8;     // [0..1] fail lists of round 0, [2..3] tie lists, [4..7] ladders idle, [8] speculative list
         memset(h->hp_cnt, 0, n_slots * sizeof(int32_t));
-        memset(h->hp_tie_cnt, 0, 16 * sizeof(int32_t));
+        memset(h->hp_tie_cnt, 0, 32 * sizeof(int32_t));
     }
 
     lap("result/aux allocations");
@@ -812,7 +844,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         int64_t b2 = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes
                                                 : std::min<int64_t>(int64_t(double(free_b) * 0.25), std::max<int64_t>(want / 16, int64_t(1) << 30));
         if (b2 < (8 << 20)) b2 = 8 << 20;
-        for (int k = (h->cfg.band_mode != 0 ? 0 : 2); k < 3; k++) {   // (dense mode: only the tie rounds need one)
+        for (int k = (h->cfg.band_mode != 0 ? 0 : 2); k < 4; k++) {   // (dense mode: only the tie rounds need one)
             h->lad[k].arena_bytes = b2;
             if ((rc = dev_alloc(h, &h->lad[k].arena, size_t(b2) + 256))) return rc;
         }
@@ -913,7 +945,7 @@ int vpr_execute(vpr_handle *h) {
         if (h->debug) fprintf(stderr, "[vpr] execute %-34s %8.3f ms\n", what,
                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
     };
-    int32_t flag_exp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t flag_exp[16] = {};
     auto post_flag = [&](int idx, hipStream_t ks) {     // "everything enqueued on ks so far is complete" -> hp_flag[idx]
         flag_exp[idx] = ++h->flag_seq;
         hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, ks, h->hp_flag + idx, flag_exp[idx]);
@@ -955,11 +987,19 @@ int vpr_execute(vpr_handle *h) {
     int64_t n_tie_jobs = 0;
     int tie_dec_slot = 0;                          // decision lists handed out in this execute
     int64_t tie_dec_cur = 0;
-    struct TieEarly { int32_t n_used; int32_t pos; const Plan *plan; };
+    struct TieEarly { int32_t n_used; int32_t pos; const Plan *plan; int mode; };   // mode 1 / 2: TieJob::mode; 3: decided speculatively
     std::unordered_map<int32_t, TieEarly> tie_early;   // alignment -> where the bytes of its marking round are
     int tie_patch_slot = -1; int64_t tie_patch_off = 0, tie_patch_cap = 0;   // decision list of the last early launch
-    auto tie_replay = [&](const Plan &P, int64_t off, int32_t cnt, hipStream_t ks, bool early) -> int {
-        if (early) tie_patch_slot = -1;
+    bool tie_patch_spec = false;                   // the part has alignments whose decisions are in the speculative list
+    int spec_slot = -1; int64_t spec_off = 0, spec_cap = 0;
+    std::unordered_map<int32_t, int> spec_set;     // alignments with a speculative replay in flight / done
+    LadderCtx *tie_ctx = &h->lad[2];               // the tie ladder whose round is being enqueued
+    auto tie_replay = [&](const Plan &P, int64_t off, int32_t cnt, hipStream_t ks_main, bool early) -> int {
+        if (early) { tie_patch_slot = -1; tie_patch_spec = false; }
+        LadderCtx &tc = *tie_ctx;
+        hipStream_t ks = early ? tc.ls2 : ks_main;
+        uint32_t *&scratch = tc.tie_scratch[early ? 1 : 0];
+        int64_t &scratch_bytes = tc.tie_scratch_bytes[early ? 1 : 0];
         // scratch words of every job; the scratch grows to hold the whole launch (all replays concurrent: a long one is a
         // latency chain), bounded by half of the free memory -- beyond that the launch is cut into sub-batches
         struct Need { int32_t k; int64_t cells, cap, bcap, w_st, w_buf, w_bk; };
@@ -970,38 +1010,40 @@ int vpr_execute(vpr_handle *h) {
             const AlnDesc &d = P.descs[size_t(off) + k];
             const auto it = tie_early.find(P.work[size_t(off) + k]);
             if ((it != tie_early.end()) != early) continue;
+            if (early && it->second.mode == 3) { tie_patch_spec = true; continue; }
             Need N;
             N.k = k;
-            N.cells = int64_t(d.Lq + d.Lr) * d.Lt;
+            N.cells = int64_t(d.Lq + d.Lr + 2 * d.Lt - 2) * d.Lt;     // stamp words: both planes, diagonal-major
             if (N.cells >= (int64_t(1) << 32) - 2)
-                return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d: (Lq + Lr) * Lt = %lld cells exceed the tie replay's 32-bit cell index",
+                return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d: (Lq + Lr + 2 Lt) * Lt = %lld stamps exceed the tie replay's 32-bit cell index",
                             d.sc, d.aln, (long long)N.cells);
             N.cap = tie_full ? N.cells : std::min<int64_t>(N.cells, 16 * int64_t(d.Lq + d.Lr + d.Lt) + 4096);
             N.cap = (std::max<int64_t>(2, std::min<int64_t>(N.cap, int64_t(1) << 26)) + 1) & ~int64_t(1);   // even: 8-byte entries follow
             int bi = 0;
             while (bi + 1 < TIE_N_BUCKETS && int64_t(TIE_BUCKETS_HOST[bi]) < N.cap) bi++;
             N.bcap = TIE_BUCKETS_HOST[bi];
-            N.w_st = (N.cells + 1) & ~int64_t(1); N.w_buf = TIE_BUF_WORDS * N.cap; N.w_bk = 2 * N.bcap;
+            N.w_st = (N.cells + 3) & ~int64_t(3); N.w_buf = TIE_BUF_WORDS * N.cap; N.w_bk = (TIE_BKT_WORDS * N.bcap + 8 + 3) & ~int64_t(3);
             const int64_t need = N.w_st + N.w_buf + N.w_bk;
             total += need;
             largest = std::max(largest, need);
-            if (early) dec_need += it->second.n_used;
+            if (early) dec_need += it->second.mode == 2 ? 256 : it->second.n_used;
             needs.push_back(N);
         }
         if (needs.empty()) return VPR_OK;
         if (tie_job_cur + needs.size() > h->tie_jobs_cap) return fail(h, VPR_ERR_STATE, "tie round: job buffer overflow");
-        if (total * 4 > h->tie_scratch_bytes) {
+        if (total * 4 > scratch_bytes) {
             size_t free_b = 0, total_b = 0;
             HIPCHK(h, hipStreamSynchronize(ks));
-            if (h->d_tie_scratch) (void)hipFree(h->d_tie_scratch);
-            h->d_tie_scratch = nullptr; h->tie_scratch_bytes = 0;
+            if (scratch) (void)hipFree(scratch);
+            scratch = nullptr; scratch_bytes = 0;
             HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
-            const int64_t nb = std::max<int64_t>(std::min<int64_t>(total * 4, int64_t(free_b / 2)), largest * 4) + 256;
+            const int64_t nb = std::max<int64_t>(std::min<int64_t>(total * 4, int64_t(free_b / 4)), largest * 4) + 256;
             void *q = nullptr;
             if (hipMalloc(&q, size_t(nb)) != hipSuccess)
                 return fail(h, VPR_ERR_NOMEM, "tie replay scratch (%lld bytes)", (long long)nb);
-            h->d_tie_scratch = static_cast<uint32_t *>(q);
-            h->tie_scratch_bytes = nb;
+            scratch = static_cast<uint32_t *>(q);
+            scratch_bytes = nb;
+            tc.tie_clean[early ? 1 : 0] = 0;
         }
         // decision list of an early launch: one region of the decision buffer, its length in a counter of its own
         int4 *dec = nullptr;
@@ -1031,18 +1073,18 @@ int vpr_execute(vpr_handle *h) {
             while (k1 < needs.size()) {
                 const Need &N = needs[k1];
                 const int64_t need = N.w_st + N.w_buf + N.w_bk;
-                if (k1 > k0 && (words + need) * 4 > h->tie_scratch_bytes) break;
+                if (k1 > k0 && (words + need) * 4 > scratch_bytes) break;
                 TieJob &J = jobs[k1 - k0];
                 memset(&J, 0, sizeof(J));
                 J.a = P.work[size_t(off) + N.k];
                 J.cap = int32_t(N.cap); J.bcap = int32_t(std::min<int64_t>(N.bcap, 0x7fffffff));
                 J.stamp_off = words;
                 J.buf_off = words + N.w_st;
-                J.bkt_off = (words + N.w_st + N.w_buf) / 2;   // (all three terms are even)
+                J.bkt_off = (words + N.w_st + N.w_buf) / 2;   // (all three terms are multiples of four words)
                 if (early) {
                     const TieEarly &E = tie_early[J.a];
                     const AlnDesc &o = E.plan->descs[size_t(E.pos)];
-                    J.mode = 1; J.n_used = E.n_used;
+                    J.mode = E.mode; J.n_used = E.n_used;
                     J.old_band_w = o.band_w; J.old_pitch[0] = o.pitch[0]; J.old_pitch[1] = o.pitch[1];
                     J.old_mat_off[0] = o.mat_off[0]; J.old_mat_off[1] = o.mat_off[1]; J.old_blo_off = o.blo_off;
                     J.old_arena = E.plan->arena;
@@ -1053,26 +1095,38 @@ int vpr_execute(vpr_handle *h) {
             const int32_t nj = int32_t(k1 - k0);
             tie_job_cur += size_t(nj);
             n_tie_jobs += nj;
-            HIPCHK(h, hipMemsetAsync(h->d_tie_scratch, 0xff, size_t(words) * 4, ks));
+            const int se = early ? 1 : 0;
+            if (!tc.tie_first_seen[se]) { tc.tie_first_seen[se] = true; tc.tie_first[se] = words * 4; }
+            if (words * 4 > tc.tie_clean[se]) HIPCHK(h, hipMemsetAsync(scratch, 0xff, size_t(words) * 4, ks));
+            tc.tie_clean[se] = 0;
             vpr_launch_stat ts_;
             memset(&ts_, 0, sizeof(ts_));
             ts_.threads = 64; ts_.n_units = nj; ts_.cells_per_thread = early ? 1 : 0;
             int rc = timed(6, ts_, ks, early ? "k_tie_replay<early>" : "k_tie_replay", [&] {
                 hipLaunchKernelGGL(k_tie_replay, dim3(nj), dim3(64), 0, ks, h->dB, h->d_descs, jobs, nj, P.arena,
-                                   reinterpret_cast<const int32_t *>(P.arena), h->d_outs, h->d_tie_scratch, h->d_tie_cnt + 1,
+                                   reinterpret_cast<const int32_t *>(P.arena), h->d_outs, scratch, h->d_tie_cnt + 1,
                                    dec, n_dec, int(dec_cap));
             });
             if (rc) return rc;
             k0 = k1;
         }
+        if (early) { HIPCHK(h, hipEventRecord(tc.ev2, ks)); (void)hipStreamQuery(ks); }
         return VPR_OK;
     };
     // apply the decisions of the part's early replays to the flags its repeated forward sweep has just written
-    auto tie_patch = [&](const Plan &P, hipStream_t ks) -> int {
-        if (tie_patch_slot < 0) return VPR_OK;
-        hipLaunchKernelGGL(k_tie_patch, blocks(tie_patch_cap), dim3(256), 0, ks, h->d_descs, h->d_tie_dec + tie_patch_off,
-                           h->d_tie_ndec + tie_patch_slot, int(tie_patch_cap), P.arena);
-        tie_patch_slot = -1;
+    auto tie_patch = [&](const Plan &P, hipStream_t ks, int tag) -> int {
+        if (tie_patch_slot >= 0) {
+            HIPCHK(h, hipStreamWaitEvent(ks, tie_ctx->ev2, 0));     // the early replays ran on the side stream
+            hipLaunchKernelGGL(k_tie_patch, blocks(tie_patch_cap), dim3(256), 0, ks, h->d_descs, h->d_tie_dec + tie_patch_off,
+                               h->d_tie_ndec + tie_patch_slot, int(tie_patch_cap), P.arena, tag);
+            tie_patch_slot = -1;
+        }
+        if (tie_patch_spec && spec_slot >= 0) {
+            HIPCHK(h, hipStreamWaitEvent(ks, h->ev_spec, 0));
+            hipLaunchKernelGGL(k_tie_patch, blocks(spec_cap), dim3(256), 0, ks, h->d_descs, h->d_tie_dec + spec_off,
+                               h->d_tie_ndec + spec_slot, int(spec_cap), P.arena, tag);
+            tie_patch_spec = false;
+        }
         return VPR_OK;
     };
 
@@ -1122,7 +1176,7 @@ int vpr_execute(vpr_handle *h) {
                 });
                 if (rc) return rc;
                 n_fwd++;
-                if (tag_or && ((rc = tie_replay(P, L.work_off, L.count, ks, false)) || (rc = tie_patch(P, ks)))) return rc;
+                if (tag_or && ((rc = tie_replay(P, L.work_off, L.count, ks, false)) || (rc = tie_patch(P, ks, tag_or)))) return rc;
                 ls.bytes_algorithmic = ls.cells;
                 rc = timed(2, ls, ks, (std::string("k_bwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + (s16 ? ",s16>" : ">")).c_str(), [&] {
                     hipLaunchKernelGGL(bwd_kernel(L.cls, s16), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
@@ -1286,6 +1340,19 @@ int vpr_execute(vpr_handle *h) {
         c.slot_cur = 0; c.fail_cur = 0; c.stage_cur = 0; c.arena_cur = 0;
         return VPR_OK;
     };
+    // what a retry round's backward sweep leaves to a tie round: appended to the ladder's region of the tie list buffer and
+    // published, with the flag, behind every part (the host acts on the flag of the round's last part)
+    bool lad_tie_wait[2] = {false, false};
+    auto lad_tie_off = [&](int k) { return h->tie_list_cap / 2 + k * (h->tie_list_cap / 8 * 3); };
+    auto lad_tie_cap = [&](int k) { (void)k; return h->tie_list_cap / 8 * 3; };
+    auto ladder_collect = [&](int k, const int32_t *list, int32_t n, hipStream_t ks) {
+        hipLaunchKernelGGL(k_collect_ties_list, blocks(n), dim3(256), 0, ks, list, n, h->d_outs, h->d_tie_list + lad_tie_off(k),
+                           h->d_tie_cnt + 5 + k, lad_tie_cap(k));
+        hipLaunchKernelGGL(k_publish_ties, dim3(4), dim3(256), 0, ks, h->d_tie_list + lad_tie_off(k), h->d_tie_cnt + 5 + k,
+                           h->hp_tie_list + lad_tie_off(k), h->hp_tie_cnt + 5 + k, lad_tie_cap(k));
+        post_flag(9 + k, ks);
+        lad_tie_wait[k] = true;
+    };
     // tie: the tie pass -- same level again, with the container-order replay between the forward and the backward sweep
     auto lad_start = [&](LadderCtx &c, std::vector<int32_t> &fails, std::vector<int32_t> &carry, bool tie = false) -> int {
         if (fails.empty()) return VPR_OK;
@@ -1316,6 +1383,7 @@ int vpr_execute(vpr_handle *h) {
             c.hp_descs = static_cast<AlnDesc *>(pd); c.hp_work = static_cast<int32_t *>(pw); c.hp_cap = nf * 2;
         }
         bool zero_slots = true;
+        if (!tie) hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, c.ls, h->d_tie_cnt + 5 + int(&c - h->lad), 0);   // the round's tie count
         for (int lv = tie ? LV_Z : LV_Q16; lv <= LV_DENSE; lv++) {
             if (by_lv[lv].empty()) continue;
             c.plans.emplace_back();
@@ -1369,22 +1437,28 @@ int vpr_execute(vpr_handle *h) {
                     const int32_t n_long = ch.n_long;
                     if (n_long > 0) {
                         const int slot = c.slot0 + c.slot_cur++;
-                        for (int ph = tie ? 1 : 7; ph <= (tie ? 6 : 7); ph += 5) {   // tie: (replay,) forward, replay, then the rest
-                            if (tie && ph == 1 && (rc = tie_replay(P, ch.work_off, n_long, c.ls, true))) return rc;
+                        // tie round: (early replays,) forward sweep, replays + patch, then the rest; retry round: forward +
+                        // backward sweep, the list of what that left to a tie round, walk + credit
+                        for (int pi = 0; pi < 2; pi++) {
+                            const int ph = tie ? (pi ? 6 : 1) : (pi ? 4 : 3);
+                            if (tie && pi == 0 && (rc = tie_replay(P, ch.work_off, n_long, c.ls, true))) return rc;
                             if ((rc = enqueue_part(P, dw, ch.work_off, n_long, lv, c.ls, slot, c.fail_base + c.fail_cur, true,
                                                    ch.part_cells[0], ch.part_in[0], ch.part_dense[0], -1, ph, nullptr, 0, tag_or))) return rc;
-                            if (tie && ph == 1 && ((rc = tie_replay(P, ch.work_off, n_long, c.ls, false)) || (rc = tie_patch(P, c.ls)))) return rc;
+                            if (tie && pi == 0 && ((rc = tie_replay(P, ch.work_off, n_long, c.ls, false)) || (rc = tie_patch(P, c.ls, LV_TAG[lv] | tag_or)))) return rc;
+                            if (!tie && pi == 0) ladder_collect(int(&c - h->lad), dw + ch.work_off, n_long, c.ls);
                         }
                         c.pending.emplace_back(slot, c.fail_base + c.fail_cur);
                         c.fail_cur += n_long;
                     }
                     if (ch.count > n_long) {
                         const int slot = c.slot0 + c.slot_cur++;
-                        for (int ph = tie ? 1 : 7; ph <= (tie ? 6 : 7); ph += 5) {
-                            if (tie && ph == 1 && (rc = tie_replay(P, ch.work_off + n_long, ch.count - n_long, c.ls, true))) return rc;
+                        for (int pi = 0; pi < 2; pi++) {
+                            const int ph = tie ? (pi ? 6 : 1) : (pi ? 4 : 3);
+                            if (tie && pi == 0 && (rc = tie_replay(P, ch.work_off + n_long, ch.count - n_long, c.ls, true))) return rc;
                             if ((rc = enqueue_part(P, dw, ch.work_off + n_long, ch.count - n_long, lv, c.ls, slot,
                                                    c.fail_base + c.fail_cur, false, ch.part_cells[1], ch.part_in[1], ch.part_dense[1], -1, ph, nullptr, 0, tag_or))) return rc;
-                            if (tie && ph == 1 && ((rc = tie_replay(P, ch.work_off + n_long, ch.count - n_long, c.ls, false)) || (rc = tie_patch(P, c.ls)))) return rc;
+                            if (tie && pi == 0 && ((rc = tie_replay(P, ch.work_off + n_long, ch.count - n_long, c.ls, false)) || (rc = tie_patch(P, c.ls, LV_TAG[lv] | tag_or)))) return rc;
+                            if (!tie && pi == 0) ladder_collect(int(&c - h->lad), dw + ch.work_off + n_long, ch.count - n_long, c.ls);
                         }
                         c.pending.emplace_back(slot, c.fail_base + c.fail_cur);
                         c.fail_cur += ch.count - n_long;
@@ -1401,12 +1475,18 @@ int vpr_execute(vpr_handle *h) {
     // ---- a tie round: the alignments of `lst` ({id, level tag}, marked by a backward sweep) are planned again at the level
     // that accepted them (descriptors tagged TIE_TAG_BIT, fresh workspace slots in the tie ladder's workspace) and run
     // forward sweep -> container-order replay -> backward sweep -> walk + credit on the tie stream
-    LadderCtx &LT = h->lad[2];
+    for (int k = 0; k < 2; k++) {     // tie ladder k: rounds of the long / short part of round 0 (the final pass uses 0)
+        LadderCtx &c = h->lad[2 + k];
+        c.ls = h->tie_stream[2 * k]; c.ls2 = h->tie_stream[2 * k + 1]; c.ev2 = h->ev_tie2[k];
+        c.slot0 = 2 + (2 + k) * LadderCtx::N_SLOTS;
+        c.fail_base = (2 + k) * int64_t(h->descs.size()) + int64_t(h->descs.size()) / 16 + 256;
+    }
     std::vector<std::pair<TieJob *, size_t>> tie_job_blocks;   // (debug) the job blocks of this execute
     size_t tie_job_total = 0;
     // resident: the chunk of plan0 whose workspace is still intact (early rounds), or nullptr.  An alignment that was
     // accepted where plan0 placed it (also by the in-place 16-cell round) is replayed early, from that workspace.
-    auto tie_round = [&](const int4 *lst_in, int32_t n, bool full, const Chunk *resident) -> int {
+    auto tie_round = [&](LadderCtx &LT, const int4 *lst_in, int32_t n, bool full, const Chunk *resident) -> int {
+        tie_ctx = &LT;
         std::vector<int4> lst(lst_in, lst_in + n);
         std::sort(lst.begin(), lst.end(), [](const int4 &x, const int4 &y) { return x.x < y.x; });   // deterministic planning
         std::vector<int32_t> marked, carry;
@@ -1422,7 +1502,7 @@ int vpr_execute(vpr_handle *h) {
                 const int dtag = h->plan0.descs[size_t(pos)].band_pad;
                 if (pos >= resident->work_off && pos < resident->work_off + resident->count &&
                     (dtag == e.y || (dtag == LV_TAG[LV_Z] && e.y == LV_TAG[LV_Q16])))
-                    tie_early[e.x] = TieEarly{e.z, pos, &h->plan0};
+                    tie_early[e.x] = TieEarly{e.z, pos, &h->plan0, spec_set.count(e.x) ? 3 : 1};
             }
         }
         if (h->tie_jobs_cap < tie_job_cur + size_t(n)) {
@@ -1443,7 +1523,7 @@ int vpr_execute(vpr_handle *h) {
         tie_job_total += tie_job_cur - j0;
         return VPR_OK;
     };
-    auto tie_flush = [&]() -> int {
+    auto tie_flush = [&](LadderCtx &LT) -> int {
         std::vector<int32_t> rejected;
         int rc_ = lad_flush(LT, rejected);
         if (rc_) return rc_;
@@ -1473,9 +1553,48 @@ int vpr_execute(vpr_handle *h) {
         // HIP maps streams onto 4 hardware queues: round 0 uses two, the ladders and the tie rounds share the others
         LL.ls = h->cls_stream[2]; LS.ls = h->cls_stream[3];
         LL.slot0 = 2; LS.slot0 = 2 + LadderCtx::N_SLOTS;
-        LT.ls = h->tie_stream; LT.slot0 = 2 + 2 * LadderCtx::N_SLOTS;
-        const int32_t tie_cap[2] = {h->tie_list_cap / 4, h->tie_list_cap - h->tie_list_cap / 4};   // long / short part's list
-        const int32_t tie_off[2] = {0, h->tie_list_cap / 4};
+        // regions of the tie list buffer: long part's marks, short part's marks, long part's speculative candidates
+        const int32_t tie_cap[3] = {h->tie_list_cap / 8, h->tie_list_cap / 4, h->tie_list_cap / 8};      // (the retry ladders' regions follow)
+        const int32_t tie_off[3] = {0, h->tie_list_cap / 4, h->tie_list_cap / 8};
+        // speculative replays (pr_tie.hip, mode 2) of the long alignments whose forward sweep met a tied cell within their
+        // distance: launched as soon as that sweep is done, so that the slowest part of a long alignment's tie round is
+        // under way long before its backward sweep says whether a tie is consulted at all
+        Plan spec_plan;
+        auto spec_round = [&](const int4 *lst, int32_t n) -> int {
+            LadderCtx &LT = h->lad[2];
+            tie_ctx = &LT;
+            spec_plan = Plan();
+            spec_plan.arena = P0.arena;
+            tie_early.clear();
+            for (int32_t k = 0; k < n; k++) {
+                const int32_t a = lst[k].x;
+                spec_plan.work.push_back(a);
+                spec_plan.descs.push_back(h->descs[size_t(a)]);
+                tie_early[a] = TieEarly{0, h->plan0_pos[size_t(a)], &h->plan0, 2};
+            }
+            if (h->tie_jobs_cap < tie_job_cur + size_t(n)) {
+                void *pj = nullptr;
+                HIPCHK(h, hipHostMalloc(&pj, size_t(n) * 4 * sizeof(TieJob), hipHostMallocDefault));
+                h->pinned.push_back(pj);
+                h->hp_tie_jobs = static_cast<TieJob *>(pj);
+                h->tie_jobs_cap = size_t(n) * 4;
+                tie_job_cur = 0;
+            }
+            const size_t j0 = tie_job_cur;
+            tie_full = false;
+            if (h->debug) fprintf(stderr, "[vpr] speculative replays: %d long alignments\n", n);
+            int rc_ = tie_replay(spec_plan, 0, n, LT.ls, true);
+            if (rc_) return rc_;
+            spec_slot = tie_patch_slot; spec_off = tie_patch_off; spec_cap = tie_patch_cap;
+            tie_patch_slot = -1;
+            HIPCHK(h, hipEventRecord(h->ev_spec, LT.ls2));
+            (void)hipStreamQuery(LT.ls2);
+            for (int32_t k = 0; k < n; k++) spec_set[lst[k].x] = 1;
+            tie_early.clear();
+            tie_job_blocks.emplace_back(h->hp_tie_jobs + j0, tie_job_cur - j0);
+            tie_job_total += tie_job_cur - j0;
+            return VPR_OK;
+        };
         // part k's alignments left to a tie round -> pinned host memory; ev_tie[k] marks the list complete
         auto collect_part = [&](int k, const int32_t *list, int32_t n, hipStream_t ks) -> int {
             hipLaunchKernelGGL(k_collect_ties_list, blocks(n), dim3(256), 0, ks, list, n, h->d_outs, h->d_tie_list + tie_off[k],
@@ -1489,22 +1608,34 @@ int vpr_execute(vpr_handle *h) {
             const Chunk &ch = P0.chunks[ci];
             const int32_t n_long = ch.n_long;
             const int64_t rbase = na_ + na_ / 16 + 256;                    // start of the retry rounds' fail region
-            LL.fail_base = rbase; LS.fail_base = rbase + n_long; LT.fail_base = rbase + na_;
+            LL.fail_base = rbase; LS.fail_base = rbase + n_long;
             HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
-            HIPCHK(h, hipMemsetAsync(h->d_tie_cnt, 0, 16, st));
+            HIPCHK(h, hipMemsetAsync(h->d_tie_cnt, 0, 32, st));
             HIPCHK(h, hipMemsetAsync(h->d_tie_ndec, 0, TIE_DEC_SLOTS * 4, st));
             HIPCHK(h, hipEventRecord(h->ev_fork, st));
             HIPCHK(h, hipStreamWaitEvent(s_long, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(s_short, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(LL.ls, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(LS.ls, h->ev_fork, 0));
-            HIPCHK(h, hipStreamWaitEvent(LT.ls, h->ev_fork, 0));
+            for (int k = 0; k < 4; k++) HIPCHK(h, hipStreamWaitEvent(h->tie_stream[k], h->ev_fork, 0));
+            for (int k = 2; k < 4; k++)          // preset the replay scratches beside round 0 (see LadderCtx::tie_clean)
+                for (int e = 0; e < 2; e++) {
+                    LadderCtx &c = h->lad[k];
+                    c.tie_clean[e] = 0;
+                    if (ci == 0 && c.tie_scratch[e] && c.tie_first[e] > 0 && c.tie_first[e] <= c.tie_scratch_bytes[e]) {
+                        HIPCHK(h, hipMemsetAsync(c.tie_scratch[e], 0xff, size_t(c.tie_first[e]), e ? c.ls2 : c.ls));
+                        c.tie_clean[e] = c.tie_first[e];
+                    }
+                    c.tie_first_seen[e] = false;
+                }
             // Round 0 of the short part.  At LV_Z, what the zero-distance sweep rejects (every alignment with s > 0)
             // re-runs *in place* with the general 16-cell kernels on the same stream, phase by phase behind the
             // zero-distance kernels: same layout and workspace slots, the device-built fail list is the work list and
             // its length stays on the device, so the host plans and copies nothing.  (A separate stream would not
             // help: the bulk kernels' millions of workgroups starve a concurrent launch until they drain.)
             const int32_t n_short = ch.count - n_long;
+            bool wait_spec = false;
+            spec_set.clear(); spec_slot = -1;
             const int SLOT_IP = LS.slot0 + LadderCtx::N_SLOTS - 1;          // fail slot of the in-place round
             const int64_t foff_ip = rbase + na_ - n_short;                 // tail of the ladders' fail region
             const int32_t cap_ip = std::min<int32_t>(n_short, std::max<int32_t>(4096, (n_short / 4 + 3) & ~3));
@@ -1537,7 +1668,17 @@ int vpr_execute(vpr_handle *h) {
                 for (int ph = 1; ph <= 4; ph <<= 1) {
                     if ((rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0],
                                            ch.part_in[0], ch.part_dense[0], -1, ph))) return rc;
-                    if (ph == 1) post_flag(0, s_long);
+                    if (ph == 1) {
+                        post_flag(0, s_long);
+                        if (lv == LV_C1) {
+                            hipLaunchKernelGGL(k_collect_spec, blocks(n_long), dim3(256), 0, s_long, P0.d_work + ch.work_off, n_long, h->d_outs,
+                                               LV_TAG[LV_C1], h->d_tie_list + tie_off[2], h->d_tie_cnt + 4, tie_cap[2]);
+                            hipLaunchKernelGGL(k_publish_ties, dim3(4), dim3(256), 0, s_long, h->d_tie_list + tie_off[2], h->d_tie_cnt + 4,
+                                               h->hp_tie_list + tie_off[2], h->hp_tie_cnt + 4, tie_cap[2]);
+                            post_flag(8, s_long);
+                            wait_spec = true;
+                        }
+                    }
                     if (ph == 2 && (rc = collect_part(0, P0.d_work + ch.work_off, n_long, s_long))) return rc;
                 }
             }
@@ -1548,11 +1689,24 @@ int vpr_execute(vpr_handle *h) {
             // starts the next, a published tie list starts a tie round; it never blocks on one while another is ready
             std::vector<int32_t> fails, carry[2];
             bool wait_fail[2] = {n_long > 0, n_short > 0}, wait_tie[2] = {n_long > 0, n_short > 0};
-            while (wait_fail[0] || wait_fail[1] || wait_tie[0] || wait_tie[1] || !LL.pending.empty() || !LS.pending.empty() ||
-                   !LT.pending.empty()) {
+            while (wait_fail[0] || wait_fail[1] || wait_tie[0] || wait_tie[1] || wait_spec || lad_tie_wait[0] || lad_tie_wait[1] || !LL.pending.empty() || !LS.pending.empty() ||
+                   !h->lad[2].pending.empty() || !h->lad[3].pending.empty()) {
                 bool progressed = false;
+                if (wait_spec && flag_up(8)) {
+                    const int32_t n = std::min(h->hp_tie_cnt[4], tie_cap[2]);
+                    if (n > 0 && (rc = spec_round(h->hp_tie_list + tie_off[2], n))) return rc;
+                    lapx("speculative list -> replays");
+                    wait_spec = false;
+                    progressed = true;
+                }
                 for (int k = 0; k < 2; k++) {
                     LadderCtx &c = h->lad[k];
+                    if (lad_tie_wait[k] && flag_up(9 + k)) {       // (before the ladder's next round reuses the region)
+                        const int32_t n = std::min(h->hp_tie_cnt[5 + k], lad_tie_cap(k));
+                        if (n > 0 && (rc = tie_round(h->lad[2 + k], h->hp_tie_list + lad_tie_off(k), n, false, nullptr))) return rc;
+                        lad_tie_wait[k] = false;
+                        progressed = true;
+                    }
                     if (wait_fail[k] && flag_up(k)) {
                         fails.clear();
                         if (k == 1 && inplace) {
@@ -1576,16 +1730,17 @@ int vpr_execute(vpr_handle *h) {
                     }
                     if (wait_tie[k] && flag_up(2 + k)) {
                         const int32_t n = std::min(h->hp_tie_cnt[2 + k], tie_cap[k]);
-                        if (n > 0 && (rc = tie_round(h->hp_tie_list + tie_off[k], n, false, &ch))) return rc;
+                        if (n > 0 && (rc = tie_round(h->lad[2 + k], h->hp_tie_list + tie_off[k], n, false, &ch))) return rc;
                         lapx(k ? "short tie list -> tie round" : "long tie list -> tie round");
                         wait_tie[k] = false;
                         progressed = true;
                     }
                 }
-                if (!wait_tie[0] && !wait_tie[1] && !LT.pending.empty() && flag_up(6)) {
-                    if ((rc = tie_flush())) return rc;
-                    progressed = true;
-                }
+                for (int k = 0; k < 2; k++)
+                    if (!wait_tie[k] && !lad_tie_wait[k] && !h->lad[2 + k].pending.empty() && flag_up(6 + k)) {
+                        if ((rc = tie_flush(h->lad[2 + k]))) return rc;
+                        progressed = true;
+                    }
                 // (no busy wait: a spinning host thread can exhaust the process's CPU quota, which stalls the runtime's threads)
                 if (!progressed) std::this_thread::sleep_for(std::chrono::microseconds(20));
             }
@@ -1595,8 +1750,9 @@ int vpr_execute(vpr_handle *h) {
             HIPCHK(h, hipEventRecord(h->ev_join[1], s_short));
             HIPCHK(h, hipEventRecord(h->ev_join[2], LL.ls));
             HIPCHK(h, hipEventRecord(h->ev_join[3], LS.ls));
-            HIPCHK(h, hipEventRecord(h->ev_join[4], LT.ls));
-            for (int k = 0; k < 5; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
+            HIPCHK(h, hipEventRecord(h->ev_join[4], h->lad[2].ls));
+            HIPCHK(h, hipEventRecord(h->ev_join[5], h->lad[3].ls));
+            for (int k = 0; k < 6; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
             if (ci + 1 < P0.chunks.size()) HIPCHK(h, hipStreamSynchronize(st));
             if (ci + 1 == P0.chunks.size())
                 h->resident.emplace(h->resident.begin(), std::vector<int32_t>(P0.work.begin() + ch.work_off,
@@ -1621,10 +1777,9 @@ int vpr_execute(vpr_handle *h) {
             lst.resize(size_t(n));
             HIPCHK(h, hipMemcpy(lst.data(), h->d_tie_list, size_t(n) * sizeof(int4), hipMemcpyDeviceToHost));
             if (h->debug) fprintf(stderr, "[vpr] final tie pass %d: %d alignments marked\n", iter, n_mark);
-            LT.ls = h->tie_stream; LT.slot0 = 2 + 2 * LadderCtx::N_SLOTS; LT.fail_base = 2 * int64_t(na) + na / 16 + 256;
-            if ((rc = tie_round(lst.data(), n, iter > 0, nullptr))) return rc;
-            if ((rc = tie_flush())) return rc;
-            HIPCHK(h, hipStreamSynchronize(LT.ls));
+            if ((rc = tie_round(h->lad[2], lst.data(), n, iter > 0, nullptr))) return rc;
+            if ((rc = tie_flush(h->lad[2]))) return rc;
+            HIPCHK(h, hipStreamSynchronize(h->lad[2].ls));
         }
     }
     if (h->debug && tie_job_total > 0) {   // the slowest replays of the execute
@@ -1639,6 +1794,8 @@ int vpr_execute(vpr_handle *h) {
             fprintf(stderr, "[vpr]   sc %d aln %d Lq %d Lr %d Lt %d level %d: %d us, %d waves, %d BFS steps, %d cells; mode %d, consulted %d, decided %d (last in wave %d)\n", d.sc, d.aln,
                     d.Lq, d.Lr, d.Lt, int(h->level[size_t(js[k].a)]), js[k].dbg_us, js[k].dbg_waves, js[k].dbg_steps, js[k].dbg_cells,
                     js[k].mode, js[k].n_used, js[k].dbg_nres, js[k].dbg_lastw);
+            fprintf(stderr, "[vpr]     us: BFS %d, patch %d, order A %d B %d suffix %d C %d, seeding %d, setup %d\n", js[k].dbg_t[0], js[k].dbg_t[1],
+                    js[k].dbg_t[2], js[k].dbg_t[3], js[k].dbg_t[4], js[k].dbg_t[5], js[k].dbg_t[6], js[k].dbg_t[7]);
         }
     }
 

@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
         vtchunk = vst[max(lane - 1, 0)];
     }
 
-    int exit_min = D_INF;
+    int exit_min = D_INF, min_tie = D_INF;
     int Dp[2] = {lane, lane};            // row 0: D = x along the INS chain (origin 0)
     int lo[2] = {0, 0}, hi[2] = {min(Lq, FS_W) - 1, min(Lr, FS_W) - 1};
     int plo[2] = {0, 0};                 // origins of the previous stripe
@@ -413,6 +413,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
                         if (need && srcs[k] >= 0 && val <= sw[p]) { tie = (val == sw[p]); sw[p] = val; choice = k + 1; }
                     }
                     swbits[p] = (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
+                    if (tie && sw[p] < D_INF) min_tie = min(min_tie, sw[p]);
                 }
             }
 #pragma unroll
@@ -472,12 +473,16 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
     const int eq = Lq - 1 - plo[0], er = Lr - 1 - plo[1];
     const int dq = (eq >= 0 && eq < 64) ? __builtin_amdgcn_readlane(Dp[0], eq & 63) : D_INF;
     const int dr = (er >= 0 && er < 64) ? __builtin_amdgcn_readlane(Dp[1], er & 63) : D_INF;
-    int em = exit_min, dummy = D_INF;
-    wave_prefix_min2(em, dummy);
+    int em = exit_min, mt = min_tie;
+    wave_prefix_min2(em, mt);
     if (lane == 63) {
         outs[a].dist_q = dq;
         outs[a].dist_r = dr;
         outs[a].exit_min = em;
+        // smallest distance of a cell with tied swap sources, + 1 (0: none): the host replays the container order of an
+        // alignment speculatively when this is <= s, before its backward sweep has said whether a tie is consulted
+        // (AlnOut::path_len is free until the walk)
+        outs[a].path_len = (mt < D_INF) ? mt + 1 : 0;
     }
 }
 

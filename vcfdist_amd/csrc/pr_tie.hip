@@ -28,7 +28,8 @@
 //     next_bkt(2 B) buckets: one more pass.  (tests/test_tie_order.py checks this model against std::unordered_set.)
 //   * seeding of the next wave (dist.cpp:395-424): INS, DEL, SUB targets of every prev_wave element in iteration order,
 //     deduplicated the same way.
-// Scratch per alignment (planned by the host): stamps, 4 B per cell of the dense (Lq + Lr) x Lt grid, preset to
+// Scratch per alignment (planned by the host): stamps, 4 B per cell of the two planes' diagonal-major grids
+// ((Lq + Lr + 2 Lt - 2) x Lt words), preset to
 // 0xffffffff; two FIFO logs, two order buffers and three work arrays of `cap` entries; `bcap` 8-byte bucket words.
 #ifndef PR_TIE_HIP_
 #define PR_TIE_HIP_
@@ -54,16 +55,24 @@ struct TieJob {
     // mode 1 ("early"): the job runs before the forward sweep is repeated, on the bytes the backward sweep of the round that
     // marked the alignment left in that round's workspace (old_*): it decides only the n_used tied cells that sweep
     // consulted (F_KEEP), appends {alignment, cell, row, choice} to the launch's decision list instead of patching, and
-    // stops behind the wave that decides the last of them.  mode 0: patches the repeated forward sweep's flags in place.
+    // stops behind the wave that decides the last of them.  mode 2 ("speculative"): launched right behind the forward
+    // sweep of a long alignment that has a tied cell within its distance, before anyone knows whether the backward sweep
+    // consults it; reads no flag bytes (a tie is a cell with two allowed sources popped in its wave) and lists every tied
+    // cell.  mode 0: behind the repeated forward sweep, patches its flags in place.
     int32_t mode, n_used;
     int32_t old_band_w, old_pitch[2], pad2;
     int64_t old_mat_off[2], old_blo_off;
     uint8_t *old_arena;
-    int32_t dbg_us, dbg_steps, dbg_cells, dbg_waves, dbg_nres, dbg_lastw;   // written by the kernel (the jobs live in host-pinned memory): VPR_DEBUG
+    int32_t dbg_us, dbg_steps, dbg_cells, dbg_waves, dbg_nres, dbg_lastw;
+    int32_t dbg_t[8];     // us in: BFS, patch, order A, B, suffix, C, seeding, setup   // written by the kernel (the jobs live in host-pinned memory): VPR_DEBUG
 };
 #define TIE_BUF_WORDS 10
+#define TIE_BLIST 8          // members a bucket's list holds (load factor <= 1: more is rare and takes the slow pass)
+#define TIE_BKT_WORDS (2 + 1 + TIE_BLIST)   // uint32 words per bucket: first-insertion word, member count, member list
 
-__device__ __forceinline__ uint32_t tie_ld(const uint32_t *p) {   // coherent load (bypasses the CU's L1)
+// coherent load (bypasses the CU's L1): for words other lanes modify with atomics, which execute in L2.  Arrays that are
+// only written with plain stores (queue logs, order buffers, F / K) are read with plain loads behind a tie_wait().
+__device__ __forceinline__ uint32_t tie_ld(const uint32_t *p) {
     return __hip_atomic_load(const_cast<uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void tie_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -85,7 +94,7 @@ __device__ __forceinline__ uint8_t *tie_flag_ptr(const AlnDesc &d, uint8_t *ws, 
     return ws + d.mat_off[p] + size_t(t) * d.pitch[p] + x;   // dense
 }
 
-#define TIE_U 4    // chunks of 64 entries a wide pass keeps in flight (the passes are bound by memory round trips)
+#define TIE_U 4    // chunks of 64 entries a wide pass keeps in flight (more does not help: a wave sustains about one scattered access per 10 cycles)
 
 __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__restrict__ descs,
                                                    TieJob *__restrict__ jobs, int n_jobs, uint8_t *ws,
@@ -97,6 +106,8 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     __shared__ int lds_ntie, lds_nres;
     const int j = blockIdx.x;
     if (j >= n_jobs) return;
+    // a replay is one long chain of dependent steps that shares its SIMD with the bulk kernels' issue-bound waves
+    __builtin_amdgcn_s_setprio(3);
     const TieJob J = jobs[j];
     const int a = J.a;
     const AlnDesc d = descs[a];
@@ -106,6 +117,8 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     const int s_fin = outs[a].s;
     const unsigned long long clk0 = wall_clock64();
     int dbg_steps = 0, dbg_cells = 0, dbg_waves = 0, dbg_lastw = -1, dbg_nres0 = 0;
+    unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = clk0;
+    auto lap = [&](int k) { const unsigned long long now = wall_clock64(); dbg_t[k] += now - tk; tk = now; };
     const uint8_t *seq0 = B.hap_seq[d.qs] + d.q_off, *seq1 = B.ref_seq + d.r_off;
     const int32_t *ptr0 = B.hap_ptr[d.qs] + d.q_off, *ptr1 = B.ref_ptr[d.qs] + d.r_off;
     const uint8_t *flg0 = B.hap_flag[d.qs] + d.q_off, *flg1 = B.ref_flag[d.qs] + d.r_off;
@@ -120,9 +133,13 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     uint32_t *Fa = buf + 6 * size_t(cap), *Ha = buf + 7 * size_t(cap), *Ka = buf + 8 * size_t(cap);
     uint2 *Ta = reinterpret_cast<uint2 *>(buf + 9 * size_t(cap));    // cells of the current wave that may be tied
     const int tcap = cap / 2;
-    unsigned long long *bfirst = reinterpret_cast<unsigned long long *>(scratch) + J.bkt_off;
-    const uint32_t sbase1 = uint32_t(Lq) * uint32_t(Lt);
-    auto sidx = [&](int p, int q, int t) -> uint32_t { return (p ? sbase1 : 0u) + uint32_t(q) * uint32_t(Lt) + uint32_t(t); };
+    unsigned long long *bfirst = reinterpret_cast<unsigned long long *>(scratch) + J.bkt_off;     // [bcap]
+    uint32_t *bcount = reinterpret_cast<uint32_t *>(bfirst + J.bcap);                                // [bcap] members per bucket
+    uint32_t *blist = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(bcount + J.bcap) + 15) & ~uintptr_t(15));   // [bcap][TIE_BLIST]
+    // stamps are stored diagonal-major, [plane][q - t + Lt - 1][t]: a run of matches walks consecutive words (the
+    // dense [q][t] order made every step of a run touch another page: the replay was bound by address translation)
+    const uint32_t sbase1 = uint32_t(Lq + Lt - 1) * uint32_t(Lt);
+    auto sidx = [&](int p, int q, int t) -> uint32_t { return (p ? sbase1 : 0u) + uint32_t(q - t + Lt - 1) * uint32_t(Lt) + uint32_t(t); };
     const unsigned long long hi_q = (unsigned long long)(2 * d.aln) * 73856093ull + 0x517cc1b727220a95ull;       // dist.h:45
     const unsigned long long hi_r = (unsigned long long)(2 * d.aln + 1) * 73856093ull + 0x517cc1b727220a95ull;
 
@@ -159,8 +176,8 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     if (lane == 0 && !fail) {
         qc[0] = make_uint2(0u, 0u);
         qc[1] = make_uint2(0x80000000u, 0u);
-        stamp[0] = 0u;
-        stamp[sbase1] = 1u;
+        stamp[sidx(0, 0, 0)] = 0u;
+        stamp[sidx(1, 0, 0)] = 1u;
     }
     tie_wait();
     uint32_t cid = 2;               // next candidate id
@@ -170,6 +187,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     int n_cur = 2;
 
     uint32_t wave_lo = 0;           // candidate ids of the current wave start here
+    lap(7);
     for (int w = 0; !fail; w++) {
         // ---- BFS: pop entries, expand, append (dist.cpp:317-381)
         int head = 0;
@@ -186,7 +204,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                 for (int u = 0; u < TIE_U; u++) {
                     const int e = u * 64 + lane;
                     x[u] = make_uint2(0u, 0u);
-                    if (e < n) { const uint32_t *px = reinterpret_cast<const uint32_t *>(qc + head + e); x[u].x = tie_ld(px); x[u].y = tie_ld(px + 1); }
+                    if (e < n) x[u] = qc[head + e];
                 }
                 uint8_t tb[TIE_U], sq[TIE_U];
                 int fx[TIE_U], ft[TIE_U];
@@ -265,7 +283,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             const int jl = ff ? lane / n : 0, il = ff ? lane - jl * n : lane;
             const bool act = lane < nk * n;
             uint2 x = make_uint2(0u, 0u);
-            if (act) { const uint32_t *px = reinterpret_cast<const uint32_t *>(qc + head + il); x.x = tie_ld(px); x.y = tie_ld(px + 1); }
+            if (act) x = qc[head + il];
             const int p = int(x.x >> 31), q = int(x.x & 0x7fffffffu) + jl, t = int(x.y) + jl;
             const int Lme = p ? Lr : Lq, Loth = p ? Lq : Lr;
             bool ty = false, tz = false;
@@ -336,6 +354,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             if (cid > 0xf0000000u) { fail = true; break; }
         }
         if (fail) break;
+        lap(0);
         // ---- tied cells popped in this wave: the allowed source popped last wins (dist.cpp:347,376)
         {
             __syncthreads();
@@ -350,24 +369,31 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                 const uint2 z = scan_all ? qc[i] : Ta[i];
                 const int p = int(z.x >> 31), xq = int(z.x & 0x7fffffffu), t = int(z.y);
                 if (t == 0) continue;
-                uint8_t *fp = tie_flag_ptr(dl, wsl, blo_l, p, xq, t);
-                if (!fp) continue;
-                const uint32_t f = *fp;
-                if (J.mode) {      // consulted by the backward sweep: on an optimal path, tied, swap edge allowed (dist.cpp:600)
-                    if (!(f & F_TIE) || !(f & 31) || !bwd_allow((p ? flg1 : flg0)[xq])) continue;
-                } else if ((f & (F_SWP | F_TIE)) != (F_SWP | F_TIE)) continue;
+                uint8_t *fp = nullptr;
+                uint32_t f = 0;
+                if (J.mode == 2) {  // speculative: no flag bytes yet; the swap edge into z must exist (dist.cpp:338-341)
+                    if (!fwd_allow(Tf[t - 1]) || (p ? seq1 : seq0)[xq] != Ts[t]) continue;
+                } else {
+                    fp = tie_flag_ptr(dl, wsl, blo_l, p, xq, t);
+                    if (!fp) continue;
+                    f = *fp;
+                    if (J.mode) {   // consulted by the backward sweep: on an optimal path, tied, swap edge allowed (dist.cpp:600)
+                        if (!(f & F_TIE) || !(f & 31) || !bwd_allow((p ? flg1 : flg0)[xq])) continue;
+                    } else if ((f & (F_SWP | F_TIE)) != (F_SWP | F_TIE)) continue;
+                }
                 const int4 cc = (p ? cand1 : cand0)[xq];
                 const int srcs[4] = {cc.x, cc.y, cc.z, cc.w};
-                int best = -1;
+                int best = -1, nsrc = 0;
                 uint32_t best_st = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if (srcs[k] < 0) continue;
                     const uint32_t st = tie_ld(stamp + sidx(1 - p, srcs[k], t - 1));
                     if (st == TIE_NEVER || st < wave_lo) continue;       // not popped in z's wave
+                    nsrc++;
                     if (best < 0 || st > best_st) { best = k; best_st = st; }
                 }
-                if (best < 0) continue;
+                if (best < 0 || (J.mode == 2 && nsrc < 2)) continue;     // (speculative: a tie is two writers in one wave)
                 if (J.mode) {
                     const int k = atomicAdd(n_dec, 1);
                     if (k < dec_cap) dec[k] = make_int4(a, int(z.x), t, best);
@@ -378,9 +404,10 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             }
             __syncthreads();
             if (lds_nres != dbg_nres0) { dbg_nres0 = lds_nres; dbg_lastw = w; }
-            if (J.mode && lds_nres >= J.n_used) { dbg_cells += n_cur; dbg_waves++; break; }   // every consulted tie is decided
+            if (J.mode == 1 && lds_nres >= J.n_used) { dbg_cells += n_cur; dbg_waves++; break; }   // every consulted tie is decided
         }
         dbg_cells += n_cur; dbg_waves++;
+        lap(1);
         if (w >= s_fin) break;
 
         // ---- iteration order of prev_wave = the n_cur cells of qc in pop order (see the header)
@@ -393,9 +420,13 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             const int m = done + take;
             tag++;
             const unsigned long long tagw = (unsigned long long)(~tag) << 32;
-            // pass A: bucket of every element, first insertion per bucket; H / K cleared
+            // pass 0: bucket member counts cleared
+            for (int b0 = lane; b0 < int(n_bkt); b0 += 64) bcount[b0] = 0u;
+            tie_wait();
+            // pass A: bucket of every element, first insertion per bucket, bucket member lists; H cleared
+            bool blist_full = false;
             for (int i0 = 0; i0 < m; i0 += 64 * TIE_U) {
-                uint32_t e[TIE_U];
+                uint32_t e[TIE_U], bk[TIE_U], slot[TIE_U];
                 uint2 c[TIE_U];
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
@@ -407,24 +438,33 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
                     const int i = i0 + u * 64 + lane;
+                    bk[u] = 0u; slot[u] = 0u;
                     if (i >= m) continue;
                     const unsigned long long hv = ((c[u].x >> 31) ? hi_r : hi_q) ^
                                                   ((unsigned long long)(c[u].x & 0x7fffffffu) * 19349669ull + 0xd15f392b3d4704a2ull) ^
                                                   ((unsigned long long)(c[u].y) * 83492791ull);
-                    const uint32_t b = uint32_t(hv % (unsigned long long)n_bkt);
-                    Fa[i] = b;
+                    bk[u] = uint32_t(hv % (unsigned long long)n_bkt);
+                    Ka[i] = bk[u];
                     Ha[i] = 0u;
-                    Ka[i] = 0u;
-                    (void)atomicMin(bfirst + b, tagw | (unsigned long long)uint32_t(i));
+                    (void)atomicMin(bfirst + bk[u], tagw | (unsigned long long)uint32_t(i));
+                    slot[u] = atomicAdd(bcount + bk[u], 1u);
+                }
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {
+                    const int i = i0 + u * 64 + lane;
+                    if (i >= m) continue;
+                    if (slot[u] < TIE_BLIST) blist[size_t(bk[u]) * TIE_BLIST + slot[u]] = uint32_t(i); else blist_full = true;
                 }
             }
+            blist_full = __any(blist_full);
             tie_wait();
+            lap(2);
             // pass B: F_i = first insertion index of the element's bucket; histogram of F
             for (int i0 = 0; i0 < m; i0 += 64 * TIE_U) {
                 uint32_t b[TIE_U];
                 unsigned long long fw[TIE_U];
 #pragma unroll
-                for (int u = 0; u < TIE_U; u++) b[u] = (i0 + u * 64 + lane < m) ? tie_ld(Fa + i0 + u * 64 + lane) : 0u;
+                for (int u = 0; u < TIE_U; u++) b[u] = (i0 + u * 64 + lane < m) ? Ka[i0 + u * 64 + lane] : 0u;
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++)
                     fw[u] = (i0 + u * 64 + lane < m) ? __hip_atomic_load(bfirst + b[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
@@ -438,6 +478,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                 }
             }
             tie_wait();
+            lap(3);
             // exclusive suffix sum over H: G[f] = elements in buckets created after f
             {
                 uint32_t run = 0;
@@ -461,19 +502,52 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                 }
             }
             tie_wait();
-            // pass C, descending: position = G[F_i] + elements of the same bucket inserted later
-            {
+            lap(4);
+            if (!blist_full) {
+                // pass C: position = G[F_i] + members of the element's bucket inserted later (from the bucket's member list)
+                for (int i0 = 0; i0 < m; i0 += 64 * TIE_U) {
+                    uint32_t f[TIE_U], bk[TIE_U], e[TIE_U], g[TIE_U], cn[TIE_U];
+                    uint4 ml[TIE_U], mh[TIE_U];
+#pragma unroll
+                    for (int u = 0; u < TIE_U; u++) {
+                        const int i = i0 + u * 64 + lane;
+                        const bool act = i < m;
+                        f[u] = act ? Fa[i] : 0u;
+                        bk[u] = act ? Ka[i] : 0u;
+                        e[u] = act ? ((have_lam && i < done) ? oc[i] : uint32_t(i)) : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < TIE_U; u++) {
+                        const bool act = i0 + u * 64 + lane < m;
+                        g[u] = act ? tie_ld(Ha + f[u]) : 0u;
+                        cn[u] = act ? tie_ld(bcount + bk[u]) : 0u;
+                        const uint4 *mp = reinterpret_cast<const uint4 *>(blist + size_t(bk[u]) * TIE_BLIST);
+                        ml[u] = act ? mp[0] : make_uint4(0u, 0u, 0u, 0u);
+                        mh[u] = act ? mp[1] : make_uint4(0u, 0u, 0u, 0u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < TIE_U; u++) {
+                        const int i = i0 + u * 64 + lane;
+                        if (i >= m) continue;
+                        const uint32_t mem[8] = {ml[u].x, ml[u].y, ml[u].z, ml[u].w, mh[u].x, mh[u].y, mh[u].z, mh[u].w};
+                        uint32_t rank = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) rank += (uint32_t(k) < cn[u] && mem[k] > uint32_t(i)) ? 1u : 0u;
+                        on[g[u] + rank] = e[u];
+                    }
+                }
+                tie_wait();
+            } else {
+                // (a bucket with more than TIE_BLIST members: the same positions from per-bucket counters, chunk by chunk
+                // from the back)
+                for (int i0 = lane; i0 < m; i0 += 64) Ka[i0] = 0u;
+                tie_wait();
                 const int top = (m - 1) & ~63;
-                uint32_t fn = (top + lane < m) ? tie_ld(Fa + top + lane) : 0xffffffffu;    // F of the chunk, one chunk ahead
-                uint32_t en = (top + lane < m) ? ((have_lam && top + lane < done) ? oc[top + lane] : uint32_t(top + lane)) : 0u;
                 for (int i0 = top; i0 >= 0; i0 -= 64) {
                     const int i = i0 + lane;
                     const bool act = i < m;
-                    const uint32_t f = fn, e = en;
-                    if (i0 >= 64) {
-                        fn = tie_ld(Fa + i - 64);
-                        en = (have_lam && i - 64 < done) ? oc[i - 64] : uint32_t(i - 64);
-                    }
+                    const uint32_t f = act ? tie_ld(Fa + i) : 0xffffffffu;
+                    const uint32_t e = act ? ((have_lam && i < done) ? oc[i] : uint32_t(i)) : 0u;
                     const uint32_t base = act ? tie_ld(Ka + f) : 0u;
                     const uint32_t g = act ? tie_ld(Ha + f) : 0u;
                     uint32_t intra = 0;
@@ -483,11 +557,12 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                     }
                     if (act) {
                         on[g + base + intra] = e;
-                        (void)atomicAdd(Ka + f, 1u);     // (issued behind this chunk's loads of K; the wait below orders it
-                    }                                    //  in front of the next chunk's)
+                        (void)atomicAdd(Ka + f, 1u);
+                    }
                     tie_wait();
                 }
             }
+            lap(5);
             { uint32_t *tmp = oc; oc = on; on = tmp; }
             have_lam = true;
             done = m;
@@ -506,7 +581,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             bool t0[TIE_U], t1[TIE_U], t2[TIE_U];
             uint32_t j0[TIE_U], j1[TIE_U], j2[TIE_U];
 #pragma unroll
-            for (int u = 0; u < TIE_U; u++) e[u] = (k0 + u * 64 + lane < n) ? tie_ld(oc + k0 + u * 64 + lane) : 0u;
+            for (int u = 0; u < TIE_U; u++) e[u] = (k0 + u * 64 + lane < n) ? oc[k0 + u * 64 + lane] : 0u;
 #pragma unroll
             for (int u = 0; u < TIE_U; u++) x[u] = (k0 + u * 64 + lane < n) ? qc[e[u]] : make_uint2(0u, 0u);
 #pragma unroll
@@ -546,6 +621,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
         }
         if (fail) break;
         tie_wait();
+        lap(6);
         { uint2 *tmp = qc; qc = qn; qn = tmp; }
         n_cur = n_next;
         if (n_cur == 0) { fail = true; break; }   // "Empty queue" (dist.cpp:314): cannot happen for an accepted alignment
@@ -555,16 +631,19 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
         jobs[j].dbg_us = int32_t((wall_clock64() - clk0) / 100);   // 100 MHz counter
         jobs[j].dbg_steps = dbg_steps; jobs[j].dbg_cells = dbg_cells; jobs[j].dbg_waves = dbg_waves;
         jobs[j].dbg_nres = lds_nres; jobs[j].dbg_lastw = dbg_lastw;
+        for (int k = 0; k < 8; k++) jobs[j].dbg_t[k] = int32_t(dbg_t[k] / 100);
     }
 }
 
 // apply a launch's decision list to the flags the repeated forward sweep has just written (tie-round descriptors)
+// (tag: the level tag of the part's tie-round descriptors; decisions of alignments that are not in it are left alone)
 __global__ void k_tie_patch(const AlnDesc *__restrict__ descs, const int4 *__restrict__ dec, const int32_t *__restrict__ n_dec,
-                            int dec_cap, uint8_t *ws) {
+                            int dec_cap, uint8_t *ws, int tag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(*n_dec, dec_cap)) return;
     const int4 e = dec[i];
     const AlnDesc d = descs[e.x];
+    if (d.band_pad != tag) return;
     uint8_t *fp = tie_flag_ptr(d, ws, reinterpret_cast<const int32_t *>(ws), int(uint32_t(e.y) >> 31), e.y & 0x7fffffff, e.z);
     if (!fp) return;
     const uint32_t f = *fp;
