@@ -153,6 +153,8 @@ typedef struct vpr_config {
     int32_t flags;             /* VPR_CFG_* (0 = defaults) */
 } vpr_config;
 #define VPR_CFG_DENSE_S16 1     /* test aid: the dense backward sweep always uses its int16 score rows */
+#define VPR_CFG_TIE_SMALL_LOGS 2 /* test aid: the container-order replays start with 32-entry FIFO logs, so that they overflow
+                                   and the second attempt (worst-case logs) has to decide the ties */
 
 /* Results: the fields precision_recall_wrapper writes in place
    (ctgVariants::{errtypes,sync_group,credit,ref_ed,query_ed,callq}, src/variant.h:49-60;
@@ -271,8 +273,8 @@ typedef struct vpr_pr_row {
 int vpr_pr_summary(const int64_t *counts, int32_t min_qual, int32_t max_qual, vpr_pr_row *rows);
 
 /* debug/parity aid: the walk of one alignment (path/sync/edits of
-   get_prec_recall_path_sync).  Returns the number of steps, or <0.
-   Arrays must hold cap entries. */
+   get_prec_recall_path_sync).  Returns the number of steps, or <0: VPR_ERR_STATE when the walk is no longer in a
+   workspace (workspaces are reused by later chunks and later retry rounds).  Arrays must hold cap entries. */
 int64_t vpr_download_path(const vpr_handle *h, int32_t sc, int32_t aln, int64_t cap,
         uint8_t *plane, int32_t *qri, int32_t *ti, uint8_t *sync, uint8_t *edit);
 

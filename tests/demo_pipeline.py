@@ -170,8 +170,9 @@ def surrogate_fasta(length, seed=0x5eed):
     return seq
 
 
-def run(product, ctg_len=5_100_000):
-    """-> (summary rows, details).  product = False: oracle chain on the CPU; True: HIP library (needs a GPU)."""
+def run(product, ctg_len=5_100_000, cluster="biwfa"):
+    """-> (summary rows, details).  product = False: oracle chain on the CPU; True: HIP library (needs a GPU).
+    cluster: "biwfa" (the reference's default) or ("gap", N) for `-c gap N` (simple_cluster, cluster.cpp:826-945)."""
     bed = Bed(os.path.join(DEMO, "nist-v4.2.1_chr1_5Mb.bed"))
     q, qs = parse_vcf(os.path.join(DEMO, "query.vcf"), bed)
     t, ts = parse_vcf(os.path.join(DEMO, "nist-v4.2.1_chr1_5Mb.vcf.gz"), bed)
@@ -180,8 +181,11 @@ def run(product, ctg_len=5_100_000):
     haps = [K.HapSeq(s["pos"], s["type"], s["ref"], s["alt"]) for s in slots]
     lib = None if product else O.lib()
     pre = "vcl" if product else "vco"
-    cl = [K.wfa_cluster(h, bytes(fasta), sub=G["sub"], open=G["open"], extend=G["extend"], max_cluster_itrs=G["max_cluster_itrs"],
-                        reach_min_gap=G["reach_min_gap"], L=lib, prefix=pre)[0] for h in haps]
+    if cluster == "biwfa":
+        cl = [K.wfa_cluster(h, bytes(fasta), sub=G["sub"], open=G["open"], extend=G["extend"], max_cluster_itrs=G["max_cluster_itrs"],
+                            reach_min_gap=G["reach_min_gap"], L=lib, prefix=pre)[0] for h in haps]
+    else:
+        cl = [K.simple_cluster(h, 0, int(cluster[1]), 0, L=lib, prefix=pre) for h in haps]
     sc = K.supercluster(haps, cl, G["max_supercluster_size"], L=lib, prefix=pre)
     pool, roff, aoff = [], [], []
     for h in haps:
@@ -203,7 +207,7 @@ def run(product, ctg_len=5_100_000):
         res = O.run(batch)
         res = res[0] if isinstance(res, tuple) else res
         pb, sw, fl = S.phase(res.sc_phase, np.zeros(sc.n, np.int32), L=lib, prefix="vso")
-        counts = S.oracle_pr_counts(lib, batch.var_off, res, cls, pb, G["min_qual"], G["max_qual"])
+        counts = O.oracle_pr_counts(lib, batch.var_off, res, cls, pb, G["min_qual"], G["max_qual"])
         rows = S.pr_summary(counts, G["min_qual"], G["max_qual"], L=lib, prefix="vso")
     det = dict(query_stats=qs, truth_stats=ts, n_var=[len(h.pos) for h in haps], n_clusters=[c.n for c in cl], n_sc=sc.n,
                counts=counts, res=res, clusters=cl, sc=sc, batch=batch, slots=slots, pb=pb, switches=sw, flips=fl, fasta=fasta)

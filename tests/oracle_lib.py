@@ -168,3 +168,27 @@ def run(batch: A.Batch, cfg=None, extra: Extra = None) -> A.Results:
     if rc:
         raise RuntimeError(f"oracle run failed: {rc}")
     return res
+
+
+def oracle_pr_counts(OL, batch_var_off, res, var_class_per_slot, pb_phase=None, min_qual=0, max_qual=60):
+    """the reference's nested counting loops (oracle/summary_oracle.cpp) on downloaded results"""
+    nq = max_qual - min_qual + 1
+    n_sc = len(res.sc_phase)
+    out = np.zeros((2, 4, 3, nq), np.int64)
+    voff = [np.ascontiguousarray(v, dtype=np.int64) for v in batch_var_off]
+    cls = [np.ascontiguousarray(c, dtype=np.uint8) for c in var_class_per_slot]
+    err = [[np.ascontiguousarray(res.errtype[s][w], dtype=np.uint8) for w in range(2)] for s in range(4)]
+    cq = [[np.ascontiguousarray(res.callq[s][w], dtype=np.float32) for w in range(2)] for s in range(4)]
+    P_f32 = C.POINTER(C.c_float)
+    a_voff = (A.P_i64 * 4)(*[A._ptr(v, C.c_int64) for v in voff])
+    a_err = ((A.P_u8 * 2) * 4)(*[(A.P_u8 * 2)(*[A._ptr(err[s][w], C.c_uint8) for w in range(2)]) for s in range(4)])
+    a_cq = ((P_f32 * 2) * 4)(*[(P_f32 * 2)(*[A._ptr(cq[s][w], C.c_float) for w in range(2)]) for s in range(4)])
+    a_cls = (A.P_u8 * 4)(*[A._ptr(c, C.c_uint8) for c in cls])
+    scp = np.ascontiguousarray(res.sc_phase, dtype=np.int32)
+    pb = None if pb_phase is None else np.ascontiguousarray(pb_phase, dtype=np.int32)
+    OL.vso_pr_counts.argtypes = [C.c_int32, A.P_i64 * 4, (A.P_u8 * 2) * 4, (P_f32 * 2) * 4, A.P_u8 * 4, A.P_i32, A.P_i32,
+                                 C.c_int32, C.c_int32, A.P_i64]
+    rc = OL.vso_pr_counts(n_sc, a_voff, a_err, a_cq, a_cls, A._ptr(scp, C.c_int32), None if pb is None else A._ptr(pb, C.c_int32),
+                          min_qual, max_qual, A._ptr(out, C.c_int64))
+    assert rc == 0
+    return out

@@ -1,0 +1,201 @@
+"""GPU parity tests beyond the WGS-like case: the container-order replay (pr_tie.hip) under every window mode and in its
+second attempt, the walk (path / sync / edits of get_prec_recall_path_sync, dist.cpp:842-999) at every window level, and
+the workloads of BASELINE.json configs 3 (`-l 10000 -s 10002`: SV-sized indels, long-sequence DP, wf_ed segments of
+thousands of bases; globals.cpp:478-481, dist.cpp:1406-1506) and 5 (hap lengths log-uniform 32-16384), against the CPU
+oracle where it finishes in seconds and through size-independent properties beyond that."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_gpu_parity import compare
+from vcfdist_amd import _abi as A
+from vcfdist_amd import api
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ties: the reference keeps the last writer of swap_pred (dist.cpp:347,376); repeat-rich, indel-heavy superclusters tie often
+# ----------------------------------------------------------------------------------------------------------------------
+TIE_RICH = dict(n_sc=1500, len_a=6, len_b=90, len_min=5, len_max=90, seed=41, var_per_base=0.12, p_snp=0.3, p_repeat=1.0,
+                p_keep=0.6, p_drop=0.2)
+
+
+@pytest.mark.parametrize("band_mode", [1, 3, 2, 0])
+def test_container_order_decides_ties_in_every_window_mode(band_mode):
+    batch = api.Synth(**TIE_RICH).batch()
+    got, want, n_nonmax, pr = compare(batch, A.default_config(band_mode=band_mode))
+    n_tie = int(((want.aln_status & A.ST_SWAP_TIE) != 0).sum())
+    print(f"band_mode {band_mode}: {n_tie} alignments with consulted ties, {n_nonmax} where the container order is not the "
+          f"highest index, {pr.timing().n_tie_replays} replays, {pr.timing().ms_tie:.2f} ms")
+    assert n_nonmax > 20          # the workload really depends on the replay
+
+
+def test_tie_replay_second_attempt_with_worst_case_logs():
+    """32-entry FIFO logs overflow on almost every replay; the alignments stay marked and the final pass repeats them with
+    logs sized for the worst case"""
+    batch = api.Synth(**dict(TIE_RICH, n_sc=600, seed=42)).batch()
+    got, want, n_nonmax, pr = compare(batch, A.default_config(flags=A.CFG_TIE_SMALL_LOGS))
+    n_tie = int(((want.aln_status & A.ST_SWAP_TIE) != 0).sum())
+    assert n_nonmax > 5 and pr.timing().n_tie_replays > n_tie     # (> : second attempts are counted)
+
+
+def test_ties_in_long_alignments_and_retried_ones():
+    """long alignments (one wave each, speculative replays behind the forward sweep) and alignments the retry ladders
+    accepted at a wider window (their ties are collected behind the ladder round's backward sweep)"""
+    batch = api.Synth(n_sc=160, len_a=520, len_b=1400, len_min=520, len_max=1400, seed=43, var_per_base=0.03, p_snp=0.3,
+                      p_repeat=1.0, indel_mean=6.0, p_keep=0.7, p_drop=0.15).batch()
+    got, want, n_nonmax, pr = compare(batch)
+    n_tie = int(((want.aln_status & A.ST_SWAP_TIE) != 0).sum())
+    print(f"{n_tie} alignments with consulted ties, {n_nonmax} decided by the container order, {pr.timing().n_band_retries} retries")
+    assert n_tie > 10 and pr.timing().n_band_retries > 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the walk at every window level
+# ----------------------------------------------------------------------------------------------------------------------
+def _check_paths(batch, cfg, pairs):
+    pr = api.PrecisionRecall(cfg)
+    pr.run(batch)
+    n_checked = 0
+    for sc, aln in pairs:
+        try:
+            pl, q, t, sy, ed = pr.path(sc, aln)
+        except api.VprError:      # the retry ladder reused the workspace of the round that accepted this alignment
+            continue
+        ex = O.Extra(batch, want=(sc, aln))
+        O.run(batch, extra=ex)
+        opl, oq, ot, osy, oed = ex.path_arrays()
+        assert np.array_equal(pl, opl) and np.array_equal(q, oq) and np.array_equal(t, ot), (sc, aln)
+        assert np.array_equal(sy, osy[:len(sy)]) and np.array_equal(ed, oed[:len(ed)]), (sc, aln)
+        n_checked += 1
+    assert n_checked >= max(1, len(pairs) // 2)
+    return pr
+
+
+@pytest.mark.parametrize("band_mode", [1, 3, 2, 0])
+def test_walk_matches_oracle_path_at_every_start_level(band_mode):
+    """zero-distance / 16-cell (k_walk_q16), 64-cell (k_walk_rows, k_walk<lane>) and dense (k_walk<lane>) walks"""
+    batch = api.Synth(n_sc=3, len_mode=2, len_a=150.0, len_min=150, len_max=150, seed=51, var_per_base=0.05, p_keep=0.7).batch()
+    _check_paths(batch, A.default_config(band_mode=band_mode), [(s, a) for s in range(3) for a in range(4)])
+
+
+@pytest.mark.parametrize("seed,indel_mean", [(52, 3.0), (53, 14.0), (54, 60.0), (55, 200.0), (56, 600.0)])
+def test_walk_matches_oracle_path_long_and_wide_levels(seed, indel_mean):
+    """long alignments (row-sweep walk of the 64-cell layout) and alignments that only the 256 / 1024-cell windows or the
+    dense level accept (k_walk<wave>, k_walk<lane> on window rows): one supercluster per case, truth missing most of the
+    query's indels, whose size decides the window that is needed.  (The walks of the round that finished last in its
+    ladder are checked; an earlier round's workspace has been reused.)"""
+    batch = api.Synth(n_sc=1, len_mode=2, len_a=1800.0, len_min=1800, len_max=1800, seed=seed, var_per_base=0.01, p_snp=0.3,
+                      indel_mean=indel_mean, p_keep=0.3, p_drop=0.6, p_hom=1.0).batch()
+    pr = _check_paths(batch, A.default_config(), [(0, a) for a in range(4)])
+    print(f"indel mean {indel_mean}: s = {pr.download().aln_dist.tolist()}, {pr.timing().n_band_retries} retries")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference-produced toy vector of SURVEY.md A.1 through the HIP path
+# ----------------------------------------------------------------------------------------------------------------------
+def test_reference_toy_vector_through_the_hip_path():
+    g = json.load(open(os.path.join(HERE, "golden", "toy_a1.json")))
+    T = {"SUB": A.TYPE_SUB, "INS": A.TYPE_INS, "DEL": A.TYPE_DEL}
+    qv = [(p, T[t], r, a, 30.0) for p, t, r, a in g["query_variants"]]
+    tv = [(p, T[t], r, a, 30.0) for p, t, r, a in g["truth_variants"]]
+    v = A.Variants.from_sites([g["ref"]], [dict(ctg=0, beg=g["region"][0], end=g["region"][1], vars=[qv, qv, tv, tv])])
+    b = api.batch_from_variants(v)          # the library's own generate_ptrs_strs (host C++)
+    assert bytes(b.hap_seq[0]).decode() == g["query_str"]
+    assert b.hap_ptr[0].tolist() == g["q2r_ptrs"] and b.hap_flag[0].tolist() == g["q2r_flags"]
+    assert b.ref_ptr[0].tolist() == g["r2q_ptrs"] and b.ref_flag[0].tolist() == g["r2q_flags"]
+    for band_mode in (1, 0):
+        r = api.PrecisionRecall(A.default_config(band_mode=band_mode)).run(b)
+        assert r.aln_dist.tolist() == g["s"]
+        assert [("QUERY", "REF")[e] for e in r.aln_end_plane] == g["end_plane"]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# config 3: SV-sized variants, long-sequence DP
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [64017, 64006])
+def test_sv_sized_indels_long_alignments_against_the_oracle(seed):
+    """the fuzzer's SV shape as fixed cases (picked with tools/scan_sv_seeds.py): 5-16 k base haplotypes, indels of hundreds
+    to thousands of bases on one side only -- the 256 / 1024-cell windows, the dense level (seed 64017: Lq + Lr = 28.5 k, so
+    its backward sweep takes the int16 score rows without being asked to), wf_ed on segments of more than a thousand bases"""
+    import fuzz_parity
+    shape, kw, band_mode = fuzz_parity.random_workload(seed, 6)
+    batch = api.Synth(**kw).batch()
+    got, want, n_nonmax, pr = compare(batch, A.default_config(band_mode=band_mode))
+    t = pr.timing()
+    big = max(max(batch.lens(k)[q] for q in (0, 1)) + batch.lens(k)[4] for k in range(batch.n_sc))
+    print(f"seed {seed}: {batch.n_sc} superclusters, largest Lq + Lr {big}, {batch.dense_cells():.2e} dense cells, "
+          f"{t.n_band_retries} retries, wf_ed {t.ms_ed:.2f} ms, largest ref_ed {int(max(got.ref_ed[2][0].max(), got.ref_ed[3][0].max()))}")
+    names = {s.kernel.decode() for s in pr.launch_stats()}
+    assert t.ms_ed > 0 and t.n_band_retries > 0 and any(n.startswith("k_fwd<") for n in names)
+    if seed == 64017:
+        assert any("s16" in n for n in names)
+
+
+def test_dense_backward_int16_rows_forced():
+    batch = api.Synth(n_sc=30, len_a=30, len_b=900, len_min=30, len_max=900, seed=61, var_per_base=0.03).batch()
+    compare(batch, A.default_config(band_mode=0, flags=A.CFG_DENSE_S16))
+
+
+def test_sv_property_identical_callsets():
+    """SV-sized variants carried by truth and query alike (the true positives of an SV evaluation), beyond what the oracle
+    does in seconds: truth == query and all homozygous, so every distance is 0 and every variant a TP with credit 1.
+    (A shared indel longer than the widest window still sends the alignment to the dense level -- the exit test is
+    evaluated at the cell a swap edge leaves from, where the bound is 0 -- so Lq + Lr has to stay below its 40 k.)"""
+    syn = api.Synth(n_sc=24, len_mode=0, len_a=4000.0, len_b=13000.0, len_min=4000, len_max=13000, seed=62, var_per_base=0.0005,
+                    p_snp=0.3, indel_mean=1500.0, p_keep=1.0, p_drop=0.0, p_hom=1.0)
+    batch = syn.batch()
+    pr = api.PrecisionRecall()
+    r = pr.run(batch)
+    assert (r.aln_dist == 0).all() and (r.sc_phase == A.PHASE_NONE).all() and not (r.aln_status & np.uint32(0xffffffff ^ A.ST_SWAP_TIE)).any()
+    v = syn.variants()
+    print(f"{batch.n_sc} superclusters, {batch.dense_cells():.2e} dense cells, kernels {pr.timing().ms_total:.1f} ms")
+    for h in range(4):
+        size = np.maximum(v.var_ref_len[h], v.var_alt_len[h])
+        assert size.max() > 2000
+        for w in range(2):
+            assert (r.errtype[h][w] == A.ERRTYPE_TP).all() and (r.credit[h][w] == 1.0).all() and (r.query_ed[h][w] == 0).all()
+            assert (r.ref_ed[h][w] >= 1).all()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# config 5: hap lengths log-uniform on [32, 16384]
+# ----------------------------------------------------------------------------------------------------------------------
+STRESS = dict(len_mode=0, len_a=32.0, len_b=16384.0, len_min=32, len_max=16384)
+
+
+def test_stress_workload_against_the_oracle():
+    batch = api.Synth(n_sc=48, seed=0x5eed, **STRESS).batch()
+    got, want, n_nonmax, pr = compare(batch)
+    lens = np.array([batch.lens(k)[4] for k in range(batch.n_sc)])
+    print(f"{batch.n_sc} superclusters, reference spans {lens.min()}..{lens.max()}, {batch.dense_cells():.2e} dense cells, "
+          f"kernels {pr.timing().ms_total:.1f} ms")
+    assert lens.max() > 8000 and lens.min() < 64
+
+
+def test_stress_workload_full_size_properties():
+    """a bench-sized slice of config 5 (beyond the oracle): results do not depend on the batch composition (a permuted batch
+    gives the permuted results), repeated executes are identical, and swapping the query haps swaps the phase distances"""
+    syn = api.Synth(n_sc=600, seed=0x5eed + 1, **STRESS)
+    b = syn.batch()
+    pr = api.PrecisionRecall()
+    r1 = pr.run(b)
+    perm = np.random.RandomState(3).permutation(b.n_sc)
+    r2 = api.PrecisionRecall().run(b.subset(perm))
+    assert np.array_equal(r1.aln_dist.reshape(-1, 4)[perm].ravel(), r2.aln_dist)
+    assert np.array_equal(r1.aln_status.reshape(-1, 4)[perm].ravel(), r2.aln_status)
+    assert np.array_equal(r1.sc_phase[perm], r2.sc_phase)
+    for h in range(4):
+        off = b.var_off[h]
+        idx = np.concatenate([np.arange(off[s], off[s + 1]) for s in perm]) if len(perm) else np.zeros(0, np.int64)
+        for w in range(2):
+            assert np.array_equal(r1.errtype[h][w][idx], r2.errtype[h][w])
+            assert np.array_equal(r1.credit[h][w][idx].view(np.uint32), r2.credit[h][w].view(np.uint32))
+            assert np.array_equal(r1.sync_group[h][w][idx], r2.sync_group[h][w])
+    pr.execute()
+    assert not r1.diff(pr.download())

@@ -61,7 +61,7 @@ def test_device_counts_and_summary_against_oracle():
     pb, sw, fl = S.phase(res.sc_phase, np.ones(batch.n_sc, np.int32))
     assert all(np.array_equal(x, y) for x, y in zip((pb, sw, fl), S.phase(res.sc_phase, np.ones(batch.n_sc), L=O.lib(), prefix="vso")))
     got = S.pr_counts(pr, cls, pb)
-    want = S.oracle_pr_counts(O.lib(), batch.var_off, res, cls, pb)
+    want = O.oracle_pr_counts(O.lib(), batch.var_off, res, cls, pb)
     assert np.array_equal(got, want)
     assert got[:, 3].sum() > 0 and got[1, 1, 2].max() > 0            # INDEL false negatives exist in this workload
     rows = S.pr_summary(got)

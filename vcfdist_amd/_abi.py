@@ -73,6 +73,7 @@ class VprResults(C.Structure):
 
 
 CFG_DENSE_S16 = 1   # VPR_CFG_DENSE_S16
+CFG_TIE_SMALL_LOGS = 2   # VPR_CFG_TIE_SMALL_LOGS
 
 
 class VprTiming(C.Structure):

@@ -126,7 +126,9 @@ struct vpr_handle {
     hipStream_t tie_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // tie ladder k: [2k] main, [2k+1] early replays (high priority)
     hipEvent_t ev_tie2[2] = {nullptr, nullptr};
     hipEvent_t ev_tie[2] = {nullptr, nullptr};                // "the tie list of the long / short part of round 0 is published"
-    std::vector<std::pair<std::vector<int32_t>, uint8_t *>> resident;   // alignments whose walks are still in a workspace
+    // plans of the last execute in launch order (the last one that holds an alignment has its final walk); second = the
+    // plan's workspace, nullptr once that workspace has been reused
+    std::vector<std::pair<std::vector<int32_t>, uint8_t *>> resident;
     Section *d_secs = nullptr; int64_t n_secs_cap = 0;
     int32_t *d_fp[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t **d_fp_table = nullptr;
@@ -666,6 +668,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if ((rc = dev_alloc(h, &D.fk4_r[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.tk[q], hap_len[2 + q]))) return rc;
         if ((rc = dev_alloc(h, &D.tz[q], hap_len[2 + q] + 8))) return rc;
+        if ((rc = dev_alloc(h, &D.tj[q], hap_len[2 + q] + 8))) return rc;
         if ((rc = dev_alloc(h, &D.wk_q[q], hap_len[q]))) return rc;
         if ((rc = dev_alloc(h, &D.wk_r[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.wk_t[q], hap_len[2 + q]))) return rc;
@@ -698,6 +701,8 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     if (n > 0)
         for (int w = 0; w < 6; w++)
             hipLaunchKernelGGL(k_prep_suffix, dim3((n + 63) / 64), dim3(64), 0, h->stream, D, w);
+    for (int s = 0; s < 2; s++)
+        if (hap_len[2 + s] > 0) hipLaunchKernelGGL(k_prep_tj, blocks(hap_len[2 + s]), dim3(256), 0, h->stream, D, s, hap_len[2 + s]);
     for (int w = 0; w < 6; w++) {
         const int64_t np = w < 2 ? hap_len[w] : (w < 4 ? ref_len : hap_len[w - 2]);
         if (np > 0) hipLaunchKernelGGL(k_prep_q16, blocks(np), dim3(256), 0, h->stream, D, w, np);
@@ -1018,6 +1023,7 @@ int vpr_execute(vpr_handle *h) {
                 return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d: (Lq + Lr + 2 Lt) * Lt = %lld stamps exceed the tie replay's 32-bit cell index",
                             d.sc, d.aln, (long long)N.cells);
             N.cap = tie_full ? N.cells : std::min<int64_t>(N.cells, 16 * int64_t(d.Lq + d.Lr + d.Lt) + 4096);
+            if (!tie_full && (h->cfg.flags & VPR_CFG_TIE_SMALL_LOGS)) N.cap = 32;
             N.cap = (std::max<int64_t>(2, std::min<int64_t>(N.cap, int64_t(1) << 26)) + 1) & ~int64_t(1);   // even: 8-byte entries follow
             int bi = 0;
             while (bi + 1 < TIE_N_BUCKETS && int64_t(TIE_BUCKETS_HOST[bi]) < N.cap) bi++;
@@ -1353,6 +1359,12 @@ int vpr_execute(vpr_handle *h) {
         post_flag(9 + k, ks);
         lad_tie_wait[k] = true;
     };
+    // a ladder that plans from the front of its workspace again overwrites the walks of its earlier rounds:
+    // vpr_download_path then reports "not resident" instead of reading what replaced them
+    auto drop_resident = [&](const LadderCtx &c) {
+        for (auto &r : h->resident)
+            if (r.second >= c.arena && r.second < c.arena + c.arena_bytes) r.second = nullptr;
+    };
     // tie: the tie pass -- same level again, with the container-order replay between the forward and the backward sweep
     auto lad_start = [&](LadderCtx &c, std::vector<int32_t> &fails, std::vector<int32_t> &carry, bool tie = false) -> int {
         if (fails.empty()) return VPR_OK;
@@ -1383,6 +1395,7 @@ int vpr_execute(vpr_handle *h) {
             c.hp_descs = static_cast<AlnDesc *>(pd); c.hp_work = static_cast<int32_t *>(pw); c.hp_cap = nf * 2;
         }
         bool zero_slots = true;
+        if (c.arena_cur == 0) drop_resident(c);
         if (!tie) hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, c.ls, h->d_tie_cnt + 5 + int(&c - h->lad), 0);   // the round's tie count
         for (int lv = tie ? LV_Z : LV_Q16; lv <= LV_DENSE; lv++) {
             if (by_lv[lv].empty()) continue;
@@ -1394,6 +1407,7 @@ int vpr_execute(vpr_handle *h) {
             if (rc == VPR_ERR_NOMEM && c.arena_cur > 0) {
                 HIPCHK(h, hipStreamSynchronize(c.ls));
                 c.arena_cur = 0;
+                drop_resident(c);
                 rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes, tag_or);
             }
             if (rc == VPR_ERR_NOMEM && h->cfg.workspace_bytes <= 0) {
@@ -2058,8 +2072,8 @@ int64_t vpr_download_path(const vpr_handle *h, int32_t sc, int32_t aln, int64_t 
     // retry plans are still resident (the most recent plan of an alignment holds its final walk)
     const int32_t a = sc * 4 + aln;
     const uint8_t *arena = nullptr;
-    for (auto it = h->resident.rbegin(); it != h->resident.rend() && !arena; ++it)
-        if (std::find(it->first.begin(), it->first.end(), a) != it->first.end()) arena = it->second;
+    for (auto it = h->resident.rbegin(); it != h->resident.rend(); ++it)
+        if (std::find(it->first.begin(), it->first.end(), a) != it->first.end()) { arena = it->second; break; }
     if (!arena) return VPR_ERR_STATE;
     AlnOut O;
     AlnDesc d;

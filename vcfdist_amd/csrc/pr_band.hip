@@ -75,6 +75,37 @@ __global__ void k_prep_pack(DevBatch B, int h, int dir, int64_t n_pos) {
     bk[g] = int32_t(z | (bits << 24));
 }
 
+// K0e: tj (see pr_device.h): t2r is non-decreasing inside a supercluster, so the first position with t's pointer is a
+// lower bound search
+__global__ void k_prep_tj(DevBatch B, int s, int64_t n_pos) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= n_pos) return;
+    const int32_t *ptr = B.hap_ptr[2 + s];
+    uint16_t j = 0;
+    if ((B.hap_flag[2 + s][g] & PV) && g > 0 && ptr[g - 1] == ptr[g]) {
+        const int64_t *off = B.hap_off[2 + s];
+        int lo = 0, hi = B.n_sc;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
+        int64_t a = off[lo], b = g;      // first position in [a, b] whose pointer equals ptr[g]
+        const int32_t p = ptr[g];
+        while (a < b) { const int64_t m = (a + b) >> 1; if (ptr[m] < p) a = m + 1; else b = m; }
+        j = uint16_t(min<int64_t>(g - a, 65535));
+    }
+    B.tj[s][g] = j;
+}
+
+// query-plane coordinate the optimal path is expected at when it is at truth position t: the query position of t's
+// reference base, plus t's offset inside a truth insertion as far as the query hap has inserted bases there too
+__device__ __forceinline__ int query_center(const int32_t *__restrict__ t2r, const uint16_t *__restrict__ tj, const int32_t *__restrict__ r2q,
+                                            int t, int Lr) {
+    const int r = min(max(t2r[t], 0), Lr - 1);
+    const int q = r2q[r];
+    const int j = tj[t];
+    if (j == 0) return q;
+    const int kq = (r + 1 < Lr) ? r2q[r + 1] - q - 1 : 0;      // bases the query hap inserts behind r
+    return q + min(j, max(kq, 0));
+}
+
 // suffix sums of |pointer step - 1| (an inserted base contributes 1, a crossed deletion its length):
 // which = 0..3: hap slot (hap -> ref pointers), 4..5: ref -> query hap (which - 4)
 __global__ void k_prep_suffix(DevBatch B, int which) {
@@ -227,13 +258,13 @@ __device__ __forceinline__ int lane_get(int src, int v, int fill) {
 
 // stripe origin: the window is centred between the reference coordinates of the stripe's first and last
 // truth row, so a jump of the diagonal inside the stripe (a truth indel) costs at most half its size of margin
-__device__ __forceinline__ void stripe_origin(const int32_t *t2r, const int32_t *r2q, int s, int n_stripes, int Lt,
+__device__ __forceinline__ void stripe_origin(const int32_t *t2r, const uint16_t *tj, const int32_t *r2q, int s, int n_stripes, int Lt,
                                               int Lq, int Lr, int &loQ, int &loR) {
     loQ = 0; loR = 0;
     if (s > 0 && s < n_stripes) {   // stripe 0 starts at the origin
         const int ta = s * FS_K, tb = min(ta + FS_K - 1, Lt - 1);
         const int ra = t2r[ta], rb = t2r[tb];
-        const int qa = r2q[min(max(ra, 0), Lr - 1)], qb = r2q[min(max(rb, 0), Lr - 1)];
+        const int qa = query_center(t2r, tj, r2q, ta, Lr), qb = query_center(t2r, tj, r2q, tb, Lr);
         loR = max(0, min((ra + rb) / 2 - FS_W / 2, Lr - min(FS_W, Lr)));
         loQ = max(0, min((qa + qb) / 2 - FS_W / 2, Lq - min(FS_W, Lq)));
     }
@@ -250,6 +281,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
     const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off;
     const uint8_t *Tf = B.hap_flag[d.ts] + d.t_off;
     const int32_t *t2r = B.hap_ptr[d.ts] + d.t_off;
+    const uint16_t *tjp = B.tj[d.ts - 2] + d.t_off;
     const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
     const int2 *fk[2] = {B.fk_q[d.qs] + d.q_off, B.fk_r[d.qs] + d.r_off};
     const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
@@ -264,8 +296,8 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
 
     // stripe origins, 64 stripes per register chunk (lane l <-> stripe c0 + l); next chunk prefetched
     int cbQ, cbR, nbQ, nbR;
-    stripe_origin(t2r, r2q, lane, n_stripes, Lt, Lq, Lr, cbQ, cbR);
-    stripe_origin(t2r, r2q, 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
+    stripe_origin(t2r, tjp, r2q, lane, n_stripes, Lt, Lq, Lr, cbQ, cbR);
+    stripe_origin(t2r, tjp, r2q, 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
     uint32_t tchunk = 0, tlast = 0;
     int tauchunk = 0, vtchunk = 0;       // t2r[t] and the truth hap's free-shift budget of rows (t & ~63) + lane
     if (lane < Lt) {
@@ -466,7 +498,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
         rhoc[0] = rhon[0]; rhoc[1] = rhon[1]; vac[0] = van[0]; vac[1] = van[1];
         if (((s + 1) & 63) == 0) {
             cbQ = nbQ; cbR = nbR;
-            stripe_origin(t2r, r2q, s + 1 + 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
+            stripe_origin(t2r, tjp, r2q, s + 1 + 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
         }
     }
     // end cells: row Lt-1 was computed with origins plo (the last stripe's)

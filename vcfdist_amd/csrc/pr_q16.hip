@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
     const int64_t q_off = dp->q_off, r_off = dp->r_off;
     const int Lp[2] = {Lq, Lr};
     const int2 *tk = (ts == 2 ? B.tk[0] : B.tk[1]) + dp->t_off;
+    const uint16_t *tjp = (ts == 2 ? B.tj[0] : B.tj[1]) + dp->t_off;
     const int32_t *r2q = (qs == 0 ? B.ref_ptr[0] : B.ref_ptr[1]) + r_off;
     const int4 *fk[2] = {(qs == 0 ? B.fk4_q[0] : B.fk4_q[1]) + q_off, (qs == 0 ? B.fk4_r[0] : B.fk4_r[1]) + r_off};
     auto load_k = [&](int p, int idx) -> int4 { return fk[p][idx]; };
@@ -165,7 +166,14 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
         if (s > 0 && s < nstr) {
             const int ta = s * Q_K, tb = min(ta + Q_K - 1, Lt - 1);
             const int ra = tk[ta].x, rb = tk[tb].x;
-            const int qa = r2q[min(max(ra, 0), Lr - 1)], qb = r2q[min(max(rb, 0), Lr - 1)];
+            // (query_center, pr_band.hip: follow the query hap's insertion while the truth rows are inside one)
+            const int ja = tjp[ta], jb = tjp[tb];
+            const int rac = min(max(ra, 0), Lr - 1), rbc = min(max(rb, 0), Lr - 1);
+            int qa = r2q[rac], qb = r2q[rbc];
+            if (ja | jb) {      // rare
+                if (ja) qa += min(ja, max((rac + 1 < Lr ? r2q[rac + 1] - qa - 1 : 0), 0));
+                if (jb) qb += min(jb, max((rbc + 1 < Lr ? r2q[rbc + 1] - qb - 1 : 0), 0));
+            }
             orr = max(0, min((ra + rb) / 2 - Q_W / 2, Lr - min(Q_W, Lr)));
             oq = max(0, min((qa + qb) / 2 - Q_W / 2, Lq - min(Q_W, Lq)));
         }
@@ -387,13 +395,21 @@ __global__ void __launch_bounds__(64) k_fwd_z16(DevBatch B, const AlnDesc *__res
 
     auto origin = [&](int s, int &oq, int &orr) {     // as in k_fwd_q16
         const int2 *tk = (ts == 2 ? B.tk[0] : B.tk[1]) + dp->t_off;
+        const uint16_t *tjp = (ts == 2 ? B.tj[0] : B.tj[1]) + dp->t_off;
         const int32_t *r2q = (qs == 0 ? B.ref_ptr[0] : B.ref_ptr[1]) + r_off;
         int2 *blo2 = reinterpret_cast<int2 *>(blo_all + dp->blo_off);
         oq = 0; orr = 0;
         if (s > 0 && s < nstr) {
             const int ta = s * Q_K, tb = min(ta + Q_K - 1, Lt - 1);
             const int ra = tk[ta].x, rb = tk[tb].x;
-            const int qa = r2q[min(max(ra, 0), Lr - 1)], qb = r2q[min(max(rb, 0), Lr - 1)];
+            // (query_center, pr_band.hip: follow the query hap's insertion while the truth rows are inside one)
+            const int ja = tjp[ta], jb = tjp[tb];
+            const int rac = min(max(ra, 0), Lr - 1), rbc = min(max(rb, 0), Lr - 1);
+            int qa = r2q[rac], qb = r2q[rbc];
+            if (ja | jb) {      // rare
+                if (ja) qa += min(ja, max((rac + 1 < Lr ? r2q[rac + 1] - qa - 1 : 0), 0));
+                if (jb) qb += min(jb, max((rbc + 1 < Lr ? r2q[rbc + 1] - qb - 1 : 0), 0));
+            }
             orr = max(0, min((ra + rb) / 2 - Q_W / 2, Lr - min(Q_W, Lr)));
             oq = max(0, min((qa + qb) / 2 - Q_W / 2, Lq - min(Q_W, Lq)));
         }

@@ -17,13 +17,13 @@
 #define WD_K 8
 
 template <int W>
-__device__ __forceinline__ void wide_origin(const int32_t *t2r, const int32_t *r2q, int s, int n_stripes, int Lt,
+__device__ __forceinline__ void wide_origin(const int32_t *t2r, const uint16_t *tj, const int32_t *r2q, int s, int n_stripes, int Lt,
                                             int Lq, int Lr, int &loQ, int &loR) {
     loQ = 0; loR = 0;
     if (s > 0 && s < n_stripes) {   // stripe 0 starts at the origin
         const int ta = s * WD_K, tb = min(ta + WD_K - 1, Lt - 1);
         const int ra = t2r[ta], rb = t2r[tb];
-        const int qa = r2q[min(max(ra, 0), Lr - 1)], qb = r2q[min(max(rb, 0), Lr - 1)];
+        const int qa = query_center(t2r, tj, r2q, ta, Lr), qb = query_center(t2r, tj, r2q, tb, Lr);
         loR = max(0, min((ra + rb) / 2 - W / 2, Lr - min(W, Lr)));
         loQ = max(0, min((qa + qb) / 2 - W / 2, Lq - min(W, Lq)));
     }
@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
     const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off;
     const uint8_t *Tf = B.hap_flag[d.ts] + d.t_off;
     const int32_t *t2r = B.hap_ptr[d.ts] + d.t_off;
+    const uint16_t *tjp = B.tj[d.ts - 2] + d.t_off;
     const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
     const int2 *fk[2] = {B.fk_q[d.qs] + d.q_off, B.fk_r[d.qs] + d.r_off};
     const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
@@ -60,8 +61,8 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
 
     // stripe origins, 64 stripes per register chunk (lane l <-> stripe c0 + l), replicated per wave
     int cbQ, cbR, nbQ, nbR;
-    wide_origin<W>(t2r, r2q, lane, n_stripes, Lt, Lq, Lr, cbQ, cbR);
-    wide_origin<W>(t2r, r2q, 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
+    wide_origin<W>(t2r, tjp, r2q, lane, n_stripes, Lt, Lq, Lr, cbQ, cbR);
+    wide_origin<W>(t2r, tjp, r2q, 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
     uint32_t tchunk = 0, tlast = 0;
     int tauchunk = 0, vtchunk = 0;       // t2r[t] and the truth hap's free-shift budget of rows (t & ~63) + lane
     if (lane < Lt) {
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
         rhoc[0] = rhon[0]; rhoc[1] = rhon[1]; vac[0] = van[0]; vac[1] = van[1];
         if (((s + 1) & 63) == 0) {
             cbQ = nbQ; cbR = nbR;
-            wide_origin<W>(t2r, r2q, s + 1 + 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
+            wide_origin<W>(t2r, tjp, r2q, s + 1 + 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
         }
     }
     // ---- end cells (row Lt-1 was computed with the last stripe's origins plo) and the window-wide exit minimum
