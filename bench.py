@@ -33,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_SIMD, SCLK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; shader clock of the committed SQ_BUSY_CYCLES counters
+PROFILE_TAG = "r02"    # profiles/<tag>_counters_<workload>.json: tools/make_profiles.sh
 
 
 def make_workload(api, n_sc, seed, workload):
@@ -40,6 +42,10 @@ def make_workload(api, n_sc, seed, workload):
         return api.Synth(n_sc=n_sc, seed=seed, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=10000)
     if workload == "stress_synth":   # configs[4]: log-uniform 32..16384
         return api.Synth(n_sc=n_sc, seed=seed, len_mode=0, len_a=32.0, len_b=16384.0, len_min=32, len_max=16384)
+    if workload == "sv_synth":       # configs[2] emulated (`-l 10000 -s 10002`, `-c size 100`): spans of thousands of bases with
+        # SV-sized indels (geometric, mean 600, capped at a quarter of the span), small variants in between
+        return api.Synth(n_sc=n_sc, seed=seed, len_mode=0, len_a=2000.0, len_b=12000.0, len_min=2000, len_max=12000,
+                         var_per_base=0.002, p_snp=0.7, indel_mean=600.0)
     raise SystemExit(f"unknown workload {workload}")
 
 
@@ -88,6 +94,10 @@ def main():
     ap.add_argument("--workload", default="wgs_synth")
     ap.add_argument("--seed", type=int, default=0x5eed)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --n-sc superclusters per GPU (own seed, own contigs); strong: --n-sc-total superclusters of one "
+                         "synthetic genome dealt over the ranks by estimated cells, phasing all-gathered every step")
+    ap.add_argument("--n-sc-total", type=int, default=3000000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,14 +127,26 @@ def main():
     if dist is not None:
         dist.barrier()
     t_a = time.perf_counter()
-    syn = make_workload(api, args.n_sc, shard.rank_seed(args.seed, rank), args.workload)
-    t_b = time.perf_counter()
-    batch = syn.batch(copy=False)       # host marshalling = the four generate_ptrs_strs calls per supercluster
+    strong = args.scaling == "strong"
+    if strong:      # every rank synthesises the same genome and keeps its share (dealt by estimated cells)
+        syn = make_workload(api, args.n_sc_total, args.seed, args.workload)
+        t_b = time.perf_counter()
+        whole = syn.batch(copy=False)
+        my_idx = shard.deal(shard.estimate_cells(whole), world)[rank]
+        batch = whole.subset(my_idx)
+        args.n_sc = batch.n_sc
+    else:
+        syn = make_workload(api, args.n_sc, shard.rank_seed(args.seed, rank), args.workload)
+        t_b = time.perf_counter()
+        batch = syn.batch(copy=False)       # host marshalling = the four generate_ptrs_strs calls per supercluster
     t_c = time.perf_counter()
     pr = api.PrecisionRecall(device=local_rank)
     pr.upload(batch)                    # inputs resident in HBM before the timed region (+ K0 prep kernels)
     vv = syn.variants()                 # SNP / INDEL / SV class of every variant (print.cpp:362-372), resident too
-    summary.upload_var_class(pr, [summary.var_class(vv.var_type[s], vv.var_ref_len[s], vv.var_alt_len[s]) for s in range(4)])
+    cls = [summary.var_class(vv.var_type[s], vv.var_ref_len[s], vv.var_alt_len[s]) for s in range(4)]
+    if strong:
+        cls = [shard.subset_per_variant(cls[s], whole.var_off[s], my_idx) for s in range(4)]
+    summary.upload_var_class(pr, cls)
     t_d = time.perf_counter()
     in_bytes = sum(a.nbytes for h in range(4) for a in (batch.hap_seq[h], batch.hap_ptr[h], batch.hap_flag[h],
                                                         batch.hap_off[h], batch.var_off[h], batch.var_pos[h],
@@ -133,11 +155,16 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     host_res = [None]
+    gloo = dist is not None and dist.get_backend() == "gloo"
 
     def step():
         pr.execute()                    # K1..K5 on the device
         host_res[0] = res = pr.download(host_res[0])   # final results to (reused) host buffers
-        t = torch.from_numpy(summary.pr_counts(pr, None, None)).to(dev)   # [2][4][3][61] int64, device histogram
+        pb = None
+        if strong:      # a contig's superclusters sit on all ranks: all-gather (sc_phase, orig, swap), phase redundantly
+            sc_phase, _, _ = shard.allgather_phase(res, my_idx, whole.n_sc, device=None if gloo else dev)
+            pb = summary.phase(sc_phase, np.ones(whole.n_sc, np.int32))[0][my_idx]
+        t = torch.from_numpy(summary.pr_counts(pr, None, pb)).to(dev)   # [2][4][3][61] int64, device histogram
         if dist is not None and dist.get_backend() == "gloo":
             tc = t.cpu(); dist.all_reduce(tc); t = tc.to(dev)
         elif dist is not None:
@@ -159,10 +186,21 @@ def main():
         res, t = step()
         tm = pr.timing()
         kern_ms.append(tm.ms_total)
-        for s in pr.launch_stats():
-            key = (s.kind, s.kernel.decode())
-            a = stats_acc.setdefault(key, [0, 0.0, 0, 0, 0])
-            a[0] += 1; a[1] += s.ms; a[2] += s.bytes_algorithmic; a[3] += s.cells; a[4] += s.cells_dense
+        # a kernel runs in several roles per step (round 0 over the whole part, retry and tie rounds over a few
+        # alignments): the launch of a step with the most units is the kernel's main launch, the rest is "other"
+        ls = pr.launch_stats()
+        top = {}
+        for s_ in ls:
+            k = (s_.kind, s_.kernel.decode())
+            top[k] = max(top.get(k, 0), s_.n_units)
+        for s_ in ls:
+            k = (s_.kind, s_.kernel.decode())
+            main = s_.n_units * 2 >= top[k]
+            a = stats_acc.setdefault(k, [0, 0.0, 0, 0, 0, 0, 0.0])
+            if main:
+                a[0] += 1; a[1] += s_.ms; a[2] += s_.bytes_algorithmic; a[3] += s_.cells; a[4] += s_.cells_dense
+            else:
+                a[5] += 1; a[6] += s_.ms
     sync()
     elapsed = time.perf_counter() - t0
     if rank == 0:       # the device tally must equal the one recomputed from the downloaded results
@@ -175,51 +213,70 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
-    total_aln = 4 * args.n_sc * world * args.steps
+    total_aln = 4 * (args.n_sc_total if strong else args.n_sc * world) * args.steps
     value = total_aln / elapsed
     if rank == 0:
         tm = pr.timing()
         # dominant K1/K2 kernel (the DP sweeps the byte model of SURVEY 8(d) is about): algorithmic bytes per launch
         # / average launch duration (HIP events on the stream the kernel is launched on)
-        sweeps = {k: v for k, v in stats_acc.items() if k[0] in (1, 2)}
-        (kind, kname), (nl, ms, byt, cells, dense) = max(sweeps.items(), key=lambda kv: kv[1][1])
-        # algorithmic bytes = 2 B per *dense* DP cell (1 B stored by the forward sweep, 1 B loaded by
-        # the backward sweep) + the input arrays; `achieved` follows that formula for the launch's alignments.
-        # The window kernels sweep (and move) far fewer cells than the dense matrix: `achieved_swept` counts only
-        # the flag bytes of the swept cells, and `traffic` is what the PMC counters saw.
+        sweeps = {k: v for k, v in stats_acc.items() if k[0] in (1, 2) and v[0] > 0}
+        (kind, kname), (nl, ms, byt, cells, dense, _, _) = max(sweeps.items(), key=lambda kv: kv[1][1])
+        avg_s = ms / nl * 1e-3
+        # Three byte counts for that launch: (1) what the PMC counters of the committed rocprofv3
+        # passes of this very command saw (FETCH_SIZE x 2 + WRITE_SIZE): `traffic`, and `achieved` = traffic / the
+        # launch duration measured here -- the fraction of the HBM roofline the kernel really uses; (2) the bytes of the
+        # cells it sweeps (1 B per swept cell + inputs): `swept`; (3) SURVEY 8(d)'s dense-equivalent figure, 1 B per cell
+        # of the dense matrices it does not have to sweep: `dense_equivalent` -- a measure of what the windows save,
+        # not of how busy HBM is.
         in_b = (byt - cells) if kind == 1 else 0
         dense_bytes = (dense + in_b) / nl
-        achieved = dense_bytes / (ms / nl * 1e-3) / 1e9 if ms > 0 else 0.0
-        swept = (byt / nl) / (ms / nl * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic = None
-        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this very command (profiles/)
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        dense_gbs = dense_bytes / avg_s / 1e9
+        swept_gbs = (byt / nl) / avg_s / 1e9
+        traffic = valu_frac = None
+        prof_src = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_counters_{args.workload}.json")))
             if prof["workload"] == args.workload and prof["superclusters_per_gpu"] == args.n_sc and kname in prof["kernels"]:
                 k = prof["kernels"][kname]
                 # FETCH_SIZE counts half of wide coalesced reads on gfx950 (MI355X_MICROARCH.md): x2; KB -> bytes
                 traffic = int((2 * k["fetch_kb"] + k["write_kb"]) * 1024)
+                # VALU issue: quad-cycles a wave spends issuing VALU instructions x waves, over the SIMD-quad-cycles of the
+                # launch (1024 SIMDs x its duration at the 2.4 GHz the counters' SQ_BUSY_CYCLES imply)
+                if k.get("valu_active_per_wave") and k.get("waves"):
+                    valu_frac = k["valu_active_per_wave"] * 4 * k["waves"] / (N_SIMD * avg_s * SCLK_HZ)
+                prof_src = f"profiles/{PROFILE_TAG}_counters_{args.workload}.json"
         except (OSError, KeyError, ValueError):
             pass
+        achieved = (traffic / avg_s / 1e9) if traffic else swept_gbs
+        hbm_frac = achieved / HBM_PEAK_GBS
         roof = {
-            "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "launches": nl, "avg_launch_ms": round(ms / nl, 4), "algorithmic_bytes_per_launch": int(dense_bytes),
-            "dense_cells_per_launch": int(dense / nl), "swept_cells_per_launch": int(cells / nl),
-            "swept_bytes_per_launch": int(byt / nl), "achieved_swept": round(swept, 2),
-            "frac_swept": round(swept / HBM_PEAK_GBS, 5),
-            "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)" if traffic else None,
-            "note": "dense-equivalent bytes per SURVEY 8(d); the window kernels move only swept_bytes and are "
-                    "VALU-issue bound, not HBM bound (DESIGN.md section 3)",
+            "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(hbm_frac, 5), "traffic": traffic,
+            "valu_issue_frac": None if valu_frac is None else round(valu_frac, 4),
+            "limiter": None if valu_frac is None else ("valu_issue" if valu_frac > hbm_frac else "hbm"),
+            "launches": nl, "avg_launch_ms": round(ms / nl, 4),
+            "swept": {"bytes_per_launch": int(byt / nl), "cells_per_launch": int(cells / nl), "GB/s": round(swept_gbs, 2),
+                      "frac": round(swept_gbs / HBM_PEAK_GBS, 5)},
+            "dense_equivalent": {"bytes_per_launch": int(dense_bytes), "cells_per_launch": int(dense / nl),
+                                 "GB/s": round(dense_gbs, 2), "frac": round(dense_gbs / HBM_PEAK_GBS, 5)},
+            "counters_source": prof_src,
+            "note": "frac = HBM traffic of the dominant sweep kernel (PMC counters) / its launch duration (HIP events, this run) / "
+                    "8 TB/s; the kernel is an integer scan that is issue- and latency-bound, not HBM-bound: see valu_issue_frac "
+                    "and DESIGN.md section 6" if traffic else
+                    "no committed counters for this workload / size: frac falls back to the bytes of the swept cells",
         }
-        per_kernel = {k[1]: {"launches": v[0], "ms": round(v[1], 3)} for k, v in sorted(stats_acc.items())}
+        per_kernel = {k[1]: {"launches": v[0], "ms": round(v[1], 3), "other_launches": v[5], "other_ms": round(v[6], 3)}
+                      for k, v in sorted(stats_acc.items())}
         out = {
             "metric": "supercluster-alignments/sec", "value": round(value, 1), "unit": "supercluster-alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": args.workload, "superclusters_per_gpu": args.n_sc,
-                       "span_dist": "lognormal(median 20, sigma 1.2) clip [4,10000]" if args.workload == "wgs_synth"
-                       else "loguniform [32,16384]", "sharding": f"{world} ranks x independent superclusters"},
+                       "span_dist": {"wgs_synth": "lognormal(median 20, sigma 1.2) clip [4,10000]", "stress_synth": "loguniform [32,16384]",
+                                     "sv_synth": "loguniform [2000,12000], indels geometric mean 600"}.get(args.workload),
+                       "sharding": (f"{args.n_sc_total} superclusters dealt over {world} ranks by estimated cells, phasing all-gathered"
+                                    if strong else f"{world} ranks x independent superclusters")},
             "dense_cells_per_s": round(tm.cells_dense * world * args.steps / elapsed, 1),
             "kernel_ms_per_step": round(float(np.mean(kern_ms)), 3),
             "setup_not_timed": {"generate_s": round(t_b - t_a, 2), "host_marshalling_s": round(t_c - t_b, 2),
@@ -233,7 +290,9 @@ def main():
                                   "precision": round(r.precision, 6), "recall": round(r.recall, 6), "f1": round(r.f1_score, 6)}
                                  for r in rows if not r.best],
             "phasing_rank0": {"switches": int(len(sw)), "flips": int(len(fl))},
-            "order_defined_swap_ties": int((res.aln_status & 1).sum()),
+            "tie_replays": {"alignments_with_consulted_ties": int((res.aln_status & 1).sum()), "replays_per_step": int(tm.n_tie_replays),
+                            "replay_kernel_ms_per_step": round(tm.ms_tie, 3),
+                            "note": "reference keeps the last writer of swap_pred (dist.cpp:347,376): replayed on the device, results exact"},
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

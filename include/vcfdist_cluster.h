@@ -98,6 +98,7 @@ int vcl_wfa_cluster(const vcl_hap_seq *hap, const uint8_t *ctg_seq, int32_t ctg_
 
 /* max_query_len * max_truth_len of supercluster k (the factor in front of the 20 B/cell of cluster.cpp:99) */
 int64_t vcl_supercluster_cells(const vcl_hap haps[4], const vcl_superclusters *s, int32_t k);
+int vcl_supercluster_cells_all(const vcl_hap haps[4], const vcl_superclusters *s, int64_t *out /* [s->n] */);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@
 #ifndef VCFDIST_PR_H_
 #define VCFDIST_PR_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -226,7 +227,11 @@ int vpr_run(vpr_handle *h, const vpr_batch *batch, vpr_results *res);
 int vpr_upload(vpr_handle *h, const vpr_batch *batch);          /* host -> HBM */
 int vpr_upload_variants(vpr_handle *h, const vpr_variants *v);  /* host marshalling + host -> HBM */
 int vpr_execute(vpr_handle *h);                                 /* K1..K4 on the resident batch */
-int vpr_download(vpr_handle *h, vpr_results *res);              /* HBM -> host + float finalisation */
+int vpr_download(vpr_handle *h, vpr_results *res);              /* HBM -> host (the results are final on the device) */
+/* Optional: page-locked host memory for result and batch buffers.  vpr_download into such buffers runs
+   at the link rate instead of the pageable-copy rate.  NULL when there is no HIP device or the allocation fails. */
+void *vpr_host_alloc(size_t bytes);
+void  vpr_host_free(void *p);
 int vpr_get_timing(const vpr_handle *h, vpr_timing *t);
 int vpr_get_launch_stats(const vpr_handle *h, vpr_launch_stat *out, int32_t cap);  /* returns #launches */
 /* TP/FP/FN counts [callset QUERY,TRUTH][TP,FP,FN] of the phasing each supercluster's distances select

@@ -1,6 +1,7 @@
-"""World-size-2 test (gloo, CPU) of the N>1 path: contiguous sharding of superclusters across ranks
-and the single tally all-reduce.  Per-rank results come from the oracle here (no GPU in this test);
-on GPUs bench.py runs the same shard/all-reduce helpers over RCCL."""
+"""World-size-2 tests (gloo, CPU) of the N > 1 path: superclusters dealt by the reference's size estimate,
+one all-reduce of the precision/recall counters, the all-gather of the per-supercluster phasing with the redundant per-rank
+Viterbi, and the gather of the per-variant records for the writers.  Per-rank results come from the oracle here (no GPU in
+this test); on GPUs bench.py and the command line run the same helpers over RCCL."""
 import os
 import socket
 import sys
@@ -9,6 +10,7 @@ import numpy as np
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SYN = dict(n_sc=301, len_a=8, len_b=200, len_max=200, seed=77)
 
 
 def _free_port():
@@ -22,23 +24,39 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     import oracle_lib as O
-    from vcfdist_amd import api, shard
+    from vcfdist_amd import api, shard, summary as S
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    batch = api.Synth(n_sc=301, len_a=8, len_b=200, len_max=200, seed=77).batch()
-    beg, end = shard.shard_range(batch.n_sc, rank, world)
-    mine = batch.subset(np.arange(beg, end))
+    syn = api.Synth(**SYN)
+    batch, v = syn.batch(), syn.variants()
+    cells = shard.estimate_cells(batch)
+    parts = shard.deal(cells, world)
+    idx = parts[rank]
+    mine = batch.subset(idx)
     res = O.run(mine)
     local = shard.tally_from_results(res, mine.var_off)
     total = shard.allreduce_tally(local)
-    q.put((rank, beg, end, local.tolist(), total.tolist()))
+    # item 1: every rank gets every supercluster's phasing and runs the contig's Viterbi itself
+    sc_phase, orig, swp = shard.allgather_phase(res, idx, batch.n_sc)
+    phase_set = (np.arange(batch.n_sc) // 40).astype(np.int32)
+    pb, sw, fl = S.phase(sc_phase, phase_set, L=O.lib(), prefix="vso")
+    # item 2: counters of this rank's superclusters under the global phasing, summed over ranks
+    cls = [S.var_class(v.var_type[s], v.var_ref_len[s], v.var_alt_len[s]) for s in range(4)]
+    cls_mine = [np.concatenate([c[batch.var_off[s][k]:batch.var_off[s][k + 1]] for k in idx]) if len(idx) else c[:0] for s, c in enumerate(cls)]
+    counts = O.oracle_pr_counts(O.lib(), mine.var_off, res, cls_mine, pb[idx])
+    counts_all = shard.allreduce_tally(counts)
+    # item 3: the per-variant records in supercluster order
+    whole = shard.gather_results(res, idx, batch.var_off)
+    q.put((rank, idx.tolist(), int(cells[idx].sum()), local.tolist(), total.tolist(), sc_phase.tolist(), pb.tolist(),
+           counts_all.tolist(), [whole.errtype[h][w].tolist() for h in range(4) for w in range(2)],
+           [whole.credit[h][w].view(np.uint32).tolist() for h in range(4) for w in range(2)], whole.aln_dist.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_and_tally_allreduce():
+def test_two_ranks_deal_allreduce_allgather_gather():
     sys.path.insert(0, ROOT)
     import oracle_lib as O
-    from vcfdist_amd import api, shard
+    from vcfdist_amd import api, shard, summary as S
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -50,13 +68,32 @@ def test_two_rank_sharding_and_tally_allreduce():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # shards are disjoint and cover everything
-    assert got[0][1] == 0 and got[0][2] == got[1][1] and got[1][2] == 301
+    syn = api.Synth(**SYN)
+    batch, v = syn.batch(), syn.variants()
+    res = O.run(batch)
+    # the deal: disjoint, complete, balanced in estimated cells
+    i0, i1 = got[0][1], got[1][1]
+    assert sorted(i0 + i1) == list(range(batch.n_sc)) and abs(len(i0) - len(i1)) <= 1
+    c0, c1 = got[0][2], got[1][2]
+    assert abs(c0 - c1) <= 0.02 * (c0 + c1)
     # every rank sees the same reduced tally, equal to the single-process tally of the whole batch
-    batch = api.Synth(n_sc=301, len_a=8, len_b=200, len_max=200, seed=77).batch()
-    whole = shard.tally_from_results(O.run(batch), batch.var_off)
+    whole = shard.tally_from_results(res, batch.var_off)
     assert got[0][4] == got[1][4] == whole.tolist()
     assert (np.array(got[0][3]) + np.array(got[1][3])).tolist() == whole.tolist()
+    # all-gathered phasing == single-process phasing on both ranks, and so is the Viterbi run on it
+    assert got[0][5] == got[1][5] == res.sc_phase.tolist()
+    phase_set = (np.arange(batch.n_sc) // 40).astype(np.int32)
+    pb, sw, fl = S.phase(res.sc_phase, phase_set, L=O.lib(), prefix="vso")
+    assert got[0][6] == got[1][6] == pb.tolist()
+    # summed counters == counters of the undivided batch
+    cls = [S.var_class(v.var_type[s], v.var_ref_len[s], v.var_alt_len[s]) for s in range(4)]
+    want = O.oracle_pr_counts(O.lib(), batch.var_off, res, cls, pb)
+    assert got[0][7] == got[1][7] == want.tolist()
+    # gathered per-variant records == single-process results
+    flat_e = [res.errtype[h][w].tolist() for h in range(4) for w in range(2)]
+    flat_c = [res.credit[h][w].view(np.uint32).tolist() for h in range(4) for w in range(2)]
+    assert got[0][8] == got[1][8] == flat_e and got[0][9] == got[1][9] == flat_c
+    assert got[0][10] == got[1][10] == res.aln_dist.tolist()
 
 
 def test_shard_ranges_are_balanced():
@@ -68,3 +105,17 @@ def test_shard_ranges_are_balanced():
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
             sizes = [e - b for b, e in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_deal_balances_estimated_cells():
+    sys.path.insert(0, ROOT)
+    from vcfdist_amd import shard
+    rng = np.random.RandomState(4)
+    cells = (np.exp(rng.normal(6, 2.0, size=100000))).astype(np.int64) + 1      # heavy tail, like supercluster sizes
+    for w in (2, 4, 8):
+        parts = shard.deal(cells, w)
+        assert sorted(np.concatenate(parts).tolist()) == list(range(len(cells)))
+        load = np.array([cells[p].sum() for p in parts], dtype=np.float64)
+        assert load.max() - load.min() <= cells.max()                             # as even as the largest item allows
+        big = np.argsort(-cells)[:w * 10]
+        assert all(abs(np.isin(big, p).sum() - 10) <= 4 for p in parts)           # the huge ones are spread over all ranks

@@ -125,3 +125,51 @@ def test_region_past_the_contig_end_is_refused_by_product_and_oracle():
         api.batch_from_variants(bad)
     with pytest.raises(ValueError):
         O.generate(bad)
+
+
+def test_transfer_phase_sets_matches_the_reference_walk():
+    """vcfdist_amd.__main__.transfer_phase_sets (candidate sweep) against a direct restatement of the reference's loop
+    (superclusterData::transfer_phase_sets, cluster.cpp:186-330) on random phase sets"""
+    from vcfdist_amd.__main__ import transfer_phase_sets
+
+    class SC:
+        def __init__(self, offs):
+            self.n = len(offs[0]) - 1
+            self._o = offs
+
+        def var_off(self, i):
+            return self._o[i]
+
+    def walk(slots, sc):
+        first_pos, phase_set = None, 0
+        for s in slots:
+            nz = np.nonzero(s["phase_set"])[0]
+            if len(nz) and (first_pos is None or s["pos"][nz[0]] < first_pos):
+                first_pos, phase_set = int(s["pos"][nz[0]]), int(s["phase_set"][nz[0]])
+        cur = [0, 0]
+        out = np.zeros(sc.n, np.int32)
+        for k in range(sc.n):
+            for i, s in enumerate(slots):
+                for v in range(int(sc.var_off(i)[k]), int(sc.var_off(i)[k + 1])):
+                    ps = int(s["phase_set"][v])
+                    if ps and ps > cur[i >> 1]:
+                        phase_set = cur[i >> 1] = ps
+            out[k] = phase_set
+        return out
+
+    rng = np.random.RandomState(11)
+    for trial in range(60):
+        n_sc = int(rng.randint(1, 40))
+        offs, slots = [], []
+        for i in range(4):
+            cnt = rng.randint(0, 4, size=n_sc) if rng.rand() > 0.1 else np.zeros(n_sc, int)
+            off = np.concatenate(([0], np.cumsum(cnt))).astype(np.int64)
+            n = int(off[-1])
+            pos = np.sort(rng.randint(0, 100000, size=n)).astype(np.int32)
+            # phase sets: mostly increasing along the hap (PS = position of the block's first variant), some zeros, some disorder
+            ps = np.where(rng.rand(n) < 0.2, 0, (pos // int(rng.randint(500, 20000))) * 1000 + 1).astype(np.int32)
+            if n and rng.rand() < 0.3:
+                ps[rng.randint(0, n)] = int(rng.randint(1, 100000))
+            offs.append(off); slots.append(dict(pos=pos, phase_set=ps))
+        sc = SC(offs)
+        assert np.array_equal(transfer_phase_sets(slots, None, sc), walk(slots, sc)), trial

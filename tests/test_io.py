@@ -143,3 +143,26 @@ def test_missing_files_and_short_bed_lines(tmp_path):
     bad.write_text("chr1\t10\n")
     with pytest.raises(IOError, match="fewer than 3"):
         IO.Bed(str(bad))
+
+
+@pytest.mark.parametrize("text,needle", [
+    ("chr1\t0\t100\nchr1\t50\t200\n", "BED overlap detected: regions chr1:0-100 and chr1:50-200"),
+    ("chr1\t300\t400\nchr1\t0\t100\n", "BED is unsorted; region chr1:300-400 precedes chr1:0-100"),
+    ("chr1\t10\t10\n", "BED region chr1:10-10 length zero"),
+    ("chr1\t20\t10\n", "BED region chr1:20-10 stop precedes start"),
+])
+def test_bed_check_refuses_what_the_reference_refuses(tmp_path, text, needle):
+    """bedData::check (bed.cpp:36-71): the reference ERRORs on empty, unsorted and overlapping regions -- the containment
+    test bisects the starts and stops, so silently accepting them would misclassify variants"""
+    p = tmp_path / "regions.bed"
+    p.write_text(text)
+    with pytest.raises(IOError, match=needle):
+        IO.Bed(str(p))
+
+
+def test_bed_abutting_regions_only_warn(tmp_path, capfd):
+    p = tmp_path / "abut.bed"
+    p.write_text("chr1\t0\t100\nchr1\t100\t200\nchr2\t5\t9\n")
+    b = IO.Bed(str(p))
+    assert "BED regions chr1:0-100 and chr1:100-200 should be merged." in capfd.readouterr().err
+    assert b.contains("chr1", 10, 20, 1) == 1      # VIO_BED_INSIDE

@@ -336,22 +336,43 @@ class Results:
     PER_VAR = (("errtype", np.uint8), ("sync_group", np.int32), ("credit", np.float32),
                ("ref_ed", np.int32), ("query_ed", np.int32), ("callq", np.float32))
 
-    def __init__(self, n_sc, n_vars):
+    def __init__(self, n_sc, n_vars, host_alloc=None, host_free=None):
+        """host_alloc / host_free: optional allocator of page-locked memory (vpr_host_alloc / vpr_host_free of the library);
+        without it the buffers are ordinary numpy arrays"""
         self.n_sc = n_sc
-        self.aln_dist = np.zeros(n_sc * 4, np.int32)
-        self.aln_end_plane = np.zeros(n_sc * 4, np.uint8)
-        self.aln_beg_plane = np.zeros(n_sc * 4, np.uint8)
-        self.aln_status = np.zeros(n_sc * 4, np.uint32)
-        self.sc_phase = np.full(n_sc, PHASE_NONE, np.int32)
-        self.orig_phase_dist = np.full(n_sc, -1, np.int32)
-        self.swap_phase_dist = np.full(n_sc, -1, np.int32)
+        self._blocks, self._free = [], host_free
+
+        def full(n, value, dt):
+            n = int(n)
+            if host_alloc is None or n == 0:
+                return np.full(n, value, dt)
+            p = host_alloc(n * np.dtype(dt).itemsize)
+            if not p:
+                return np.full(n, value, dt)
+            self._blocks.append(p)
+            a = np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(p), dtype=dt, count=n)
+            a[:] = value
+            return a
+        self.aln_dist = full(n_sc * 4, 0, np.int32)
+        self.aln_end_plane = full(n_sc * 4, 0, np.uint8)
+        self.aln_beg_plane = full(n_sc * 4, 0, np.uint8)
+        self.aln_status = full(n_sc * 4, 0, np.uint32)
+        self.sc_phase = full(n_sc, PHASE_NONE, np.int32)
+        self.orig_phase_dist = full(n_sc, -1, np.int32)
+        self.swap_phase_dist = full(n_sc, -1, np.int32)
         for name, dt in self.PER_VAR:
             init = ERRTYPE_UN if name == "errtype" else 0
-            setattr(self, name, [[np.full(n_vars[h], init, dt) for _ in range(2)] for h in range(HAPS)])
+            setattr(self, name, [[full(n_vars[h], init, dt) for _ in range(2)] for h in range(HAPS)])
+
+    def __del__(self):
+        if self._free is not None:
+            for p in self._blocks:
+                self._free(p)
+            self._blocks = []
 
     @classmethod
-    def for_batch(cls, batch):
-        return cls(batch.n_sc, [batch.n_vars(h) for h in range(HAPS)])
+    def for_batch(cls, batch, host_alloc=None, host_free=None):
+        return cls(batch.n_sc, [batch.n_vars(h) for h in range(HAPS)], host_alloc, host_free)
 
     def as_struct(self):
         s = VprResults()

@@ -56,6 +56,9 @@ def lib():
     L.vpr_upload_variants.argtypes = [H, C.POINTER(A.VprVariants)]
     L.vpr_execute.argtypes = [H]
     L.vpr_download.argtypes = [H, C.POINTER(A.VprResults)]
+    L.vpr_host_alloc.restype = C.c_void_p
+    L.vpr_host_alloc.argtypes = [C.c_size_t]
+    L.vpr_host_free.argtypes = [C.c_void_p]
     L.vpr_get_timing.argtypes = [H, C.POINTER(A.VprTiming)]
     L.vpr_get_launch_stats.argtypes = [H, C.POINTER(A.VprLaunchStat), C.c_int32]
     L.vpr_get_tally.argtypes = [H, C.POINTER(C.c_int64)]
@@ -78,7 +81,8 @@ def lib():
 
 EXPORTED = [
     "vpr_create", "vpr_destroy", "vpr_last_error", "vpr_version", "vpr_run", "vpr_upload",
-    "vpr_upload_variants", "vpr_execute", "vpr_download", "vpr_get_timing", "vpr_get_launch_stats", "vpr_get_tally",
+    "vpr_upload_variants", "vpr_execute", "vpr_download", "vpr_host_alloc", "vpr_host_free", "vpr_get_timing", "vpr_get_launch_stats",
+    "vpr_get_tally",
     "vpr_download_path", "vpr_phase", "vpr_upload_var_class", "vpr_pr_counts", "vpr_pr_summary",
     "vpr_store_phase", "vpr_batch_from_variants", "vpr_owned_batch_view", "vpr_owned_batch_free",
     "vpr_synth_default_params", "vpr_synth_create", "vpr_synth_variants", "vpr_synth_destroy",
@@ -208,8 +212,9 @@ class PrecisionRecall:
     def download(self, res: A.Results = None) -> A.Results:
         """Copy the results of the last execute to host memory.  Pass a previous Results to reuse its
         buffers (every field is overwritten), which avoids re-allocating hundreds of MB per call."""
-        if res is None:
-            res = A.Results.for_batch(self._batch)
+        if res is None:       # page-locked buffers: the copies then run at the link rate
+            L = lib()
+            res = A.Results.for_batch(self._batch, L.vpr_host_alloc, L.vpr_host_free)
         s = res.as_struct()
         self._chk(lib().vpr_download(self._h, C.byref(s)), "vpr_download")
         return res

@@ -33,7 +33,7 @@ class VclWfaStats(C.Structure):
 
 
 EXPORTED = ["vcl_simple_cluster", "vcl_clusters_free", "vcl_supercluster", "vcl_superclusters_free",
-            "vcl_supercluster_cells", "vcl_wfa_cluster"]
+            "vcl_supercluster_cells", "vcl_supercluster_cells_all", "vcl_wfa_cluster"]
 
 
 class Hap:
@@ -148,9 +148,9 @@ def supercluster(haps, clusters, max_supercluster_size=10000, L=None, prefix="vc
         raise ValueError(f"{prefix}_supercluster failed: {rc}")
     res = Superclusters(out.contents)
     if prefix == "vcl":
-        L.vcl_supercluster_cells.restype = C.c_int64
-        L.vcl_supercluster_cells.argtypes = [VclHap * 4, C.POINTER(VclSuperclusters), C.c_int32]
-        res.cells = np.array([L.vcl_supercluster_cells(hs, out, k) for k in range(res.n)], dtype=np.int64)
+        L.vcl_supercluster_cells_all.argtypes = [VclHap * 4, C.POINTER(VclSuperclusters), A.P_i64]
+        res.cells = np.zeros(res.n, dtype=np.int64)
+        L.vcl_supercluster_cells_all(hs, out, A._ptr(res.cells, C.c_int64))
         L.vcl_superclusters_free.argtypes = [C.POINTER(VclSuperclusters)]
         L.vcl_superclusters_free(out)
     return res

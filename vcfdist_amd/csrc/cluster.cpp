@@ -337,4 +337,11 @@ int64_t vcl_supercluster_cells(const vcl_hap haps[4], const vcl_superclusters *s
     return len[0] * len[1];
 }
 
+// the same for every supercluster in one call: out[s->n]
+int vcl_supercluster_cells_all(const vcl_hap haps[4], const vcl_superclusters *s, int64_t *out) {
+    if (!haps || !s || !out) return VCL_ERR_ARG;
+    for (int32_t k = 0; k < s->n; k++) out[k] = vcl_supercluster_cells(haps, s, k);
+    return VCL_OK;
+}
+
 }  // extern "C"

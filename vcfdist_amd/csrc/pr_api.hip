@@ -154,6 +154,7 @@ struct vpr_handle {
     std::vector<void *> pinned;
     int32_t *d_ed_scratch = nullptr; size_t ed_scratch_ints = 0;
     std::vector<EvPair> events;
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;   // timing events, reused by every execute
     DevResults dR;                       // final results, produced on the device
     vpr_timing timing;
     bool uploaded = false, executed = false;
@@ -208,7 +209,6 @@ void free_batch(vpr_handle *h) {
     for (void *p : h->pinned) (void)hipHostFree(p);
     h->pinned.clear();
     h->hp_fail = nullptr; h->hp_cnt = nullptr; h->hp_flag = nullptr;
-    for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     h->events.clear();
     h->descs.clear();
     h->plan0 = Plan();
@@ -387,6 +387,35 @@ __global__ void k_publish_ties(const int4 *__restrict__ list, const int32_t *__r
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) h_list[i] = list[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) *h_cnt = *cnt;
     __threadfence_system();
+}
+
+// everything vpr_execute starts from, in one launch: per-alignment scalars zeroed, "passed on the REF plane" groups unset,
+// the per-variant columns at the reference's initial values (ERRTYPE_UN, 0; variant.cpp:45-52), counters zeroed
+struct InitArgs { AlnOut *outs; int64_t na; int32_t *fp[4]; int64_t n_fp[4]; VarCols v[4][2]; int64_t n_var[4];
+                  unsigned long long *tally; int32_t *njobs; int32_t *cnt; int n_cnt; };
+__global__ void k_init_execute(InitArgs A) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < A.na) {
+        int4 *o = reinterpret_cast<int4 *>(A.outs + i);      // sizeof(AlnOut) == 40: two 16-byte stores + 8 bytes
+        int32_t *w = reinterpret_cast<int32_t *>(A.outs + i);
+#pragma unroll
+        for (int k = 0; k < int(sizeof(AlnOut) / 4); k++) w[k] = 0;
+        (void)o;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (i < A.n_fp[q]) A.fp[q][i] = -1;
+        if (i < A.n_var[q]) {
+#pragma unroll
+            for (int w = 0; w < 2; w++) {
+                const VarCols &V = A.v[q][w];
+                V.errtype[i] = VPR_ERRTYPE_UN; V.sync_group[i] = 0; V.credit[i] = 0.0f; V.ref_ed[i] = 0; V.query_ed[i] = 0; V.callq[i] = 0.0f;
+            }
+        }
+    }
+    if (i < 6) A.tally[i] = 0ull;
+    if (i == 0) *A.njobs = 0;
+    if (i < A.n_cnt) A.cnt[i] = 0;
 }
 
 __global__ void k_flag(int32_t *__restrict__ h_flag, int32_t v) {
@@ -610,6 +639,7 @@ void vpr_destroy(vpr_handle *h) {
         if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     for (int k = 0; k < 2 + 4 * LadderCtx::N_SLOTS; k++)
         if (h->ev_slot[k]) (void)hipEventDestroy(h->ev_slot[k]);
     for (int k = 0; k < 4; k++) if (h->tie_stream[k]) (void)hipStreamDestroy(h->tie_stream[k]);
@@ -904,26 +934,23 @@ int vpr_execute(vpr_handle *h) {
     if (!h) return VPR_ERR_ARG;
     if (!h->uploaded) return fail(h, VPR_ERR_STATE, "vpr_execute before vpr_upload");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    for (auto &e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     h->events.clear();
+    h->ev_used = 0;
     hipStream_t st = h->stream;
     auto blocks = [](int64_t n_) { return dim3(unsigned((n_ + 255) / 256)); };
-    HIPCHK(h, hipMemsetAsync(h->d_outs, 0, std::max<size_t>(h->descs.size(), 1) * sizeof(AlnOut), st));
-    for (int q = 0; q < 4; q++)
-        HIPCHK(h, hipMemsetAsync(h->d_fp[q], 0xff, std::max<int64_t>(h->n_var[q >> 1], 1) * 4, st));
-    HIPCHK(h, hipMemsetAsync(h->d_njobs, 0, 4, st));
-    for (int s = 0; s < 4; s++)      // the reference's initial values: ERRTYPE_UN, 0 (variant.cpp:45-52)
-        for (int w = 0; w < 2; w++) {
-            const size_t nv = std::max<size_t>(size_t(h->n_var[s]), 1);
-            const VarCols &V = h->dR.v[s][w];
-            HIPCHK(h, hipMemsetAsync(V.errtype, VPR_ERRTYPE_UN, nv, st));
-            HIPCHK(h, hipMemsetAsync(V.sync_group, 0, nv * 4, st));
-            HIPCHK(h, hipMemsetAsync(V.credit, 0, nv * 4, st));
-            HIPCHK(h, hipMemsetAsync(V.ref_ed, 0, nv * 4, st));
-            HIPCHK(h, hipMemsetAsync(V.query_ed, 0, nv * 4, st));
-            HIPCHK(h, hipMemsetAsync(V.callq, 0, nv * 4, st));
+    {
+        InitArgs IA;
+        IA.outs = h->d_outs; IA.na = int64_t(h->descs.size());
+        int64_t top = std::max<int64_t>(IA.na, 8);
+        for (int q = 0; q < 4; q++) {
+            IA.fp[q] = h->d_fp[q]; IA.n_fp[q] = h->n_var[q >> 1];
+            IA.n_var[q] = h->n_var[q];
+            for (int w = 0; w < 2; w++) IA.v[q][w] = h->dR.v[q][w];
+            top = std::max(top, std::max(IA.n_fp[q], IA.n_var[q]));
         }
-    HIPCHK(h, hipMemsetAsync(h->dR.tally, 0, 6 * sizeof(unsigned long long), st));
+        IA.tally = h->dR.tally; IA.njobs = h->d_njobs; IA.cnt = h->d_cnt; IA.n_cnt = 2;
+        hipLaunchKernelGGL(k_init_execute, blocks(top), dim3(256), 0, st, IA);
+    }
     if (!h->dirty.empty()) {   // restore the round-0 descriptors a previous execute's retry rounds replaced
         hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(h->descs.size())), dim3(256), 0, st, h->plan0.d_descs,
                            int(h->descs.size()), h->d_descs);
@@ -934,8 +961,13 @@ int vpr_execute(vpr_handle *h) {
     auto timed = [&](int kind, const vpr_launch_stat &ls, hipStream_t ks, const char *name, auto &&launch) -> int {
         EvPair ev; ev.kind = kind; ev.st = ls; ev.st.kind = kind;
         snprintf(ev.st.kernel, sizeof(ev.st.kernel), "%s", name);
-        HIPCHK(h, hipEventCreate(&ev.a));
-        HIPCHK(h, hipEventCreate(&ev.b));
+        while (h->ev_pool.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            HIPCHK(h, hipEventCreate(&e));
+            h->ev_pool.push_back(e);
+        }
+        ev.a = h->ev_pool[h->ev_used++];
+        ev.b = h->ev_pool[h->ev_used++];
         HIPCHK(h, hipEventRecord(ev.a, ks));
         launch();
         HIPCHK(h, hipEventRecord(ev.b, ks));
@@ -1925,29 +1957,44 @@ int vpr_download(vpr_handle *h, vpr_results *res) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const DevResults &R = h->dR;
     const size_t na = h->descs.size(), n = size_t(h->n_sc);
-    // results were finalised on the device (k_finalize / k_phase_tally): plain copies into the caller's buffers
+    hipStream_t st = h->stream;
+    // results were finalised on the device (k_finalize / k_phase_tally): plain copies into the caller's buffers, all
+    // enqueued before the one wait (page-locked destinations, vpr_host_alloc, are written by DMA at the link rate)
+    auto get = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
+    };
     if (na) {
-        HIPCHK(h, hipMemcpy(res->aln_dist, R.aln_dist, na * 4, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(res->aln_end_plane, R.aln_end_plane, na, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(res->aln_beg_plane, R.aln_beg_plane, na, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(res->aln_status, R.aln_status, na * 4, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(res->sc_phase, R.sc_phase, n * 4, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(res->orig_phase_dist, R.orig_phase_dist, n * 4, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(res->swap_phase_dist, R.swap_phase_dist, n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, get(res->aln_dist, R.aln_dist, na * 4));
+        HIPCHK(h, get(res->aln_end_plane, R.aln_end_plane, na));
+        HIPCHK(h, get(res->aln_beg_plane, R.aln_beg_plane, na));
+        HIPCHK(h, get(res->aln_status, R.aln_status, na * 4));
+        HIPCHK(h, get(res->sc_phase, R.sc_phase, n * 4));
+        HIPCHK(h, get(res->orig_phase_dist, R.orig_phase_dist, n * 4));
+        HIPCHK(h, get(res->swap_phase_dist, R.swap_phase_dist, n * 4));
     }
     for (int s = 0; s < 4; s++) {
         const size_t nv = size_t(h->n_var[s]);
-        if (!nv) continue;
         for (int w = 0; w < 2; w++) {
-            HIPCHK(h, hipMemcpy(res->errtype[s][w], R.v[s][w].errtype, nv, hipMemcpyDeviceToHost));
-            HIPCHK(h, hipMemcpy(res->sync_group[s][w], R.v[s][w].sync_group, nv * 4, hipMemcpyDeviceToHost));
-            HIPCHK(h, hipMemcpy(res->credit[s][w], R.v[s][w].credit, nv * 4, hipMemcpyDeviceToHost));
-            HIPCHK(h, hipMemcpy(res->ref_ed[s][w], R.v[s][w].ref_ed, nv * 4, hipMemcpyDeviceToHost));
-            HIPCHK(h, hipMemcpy(res->query_ed[s][w], R.v[s][w].query_ed, nv * 4, hipMemcpyDeviceToHost));
-            HIPCHK(h, hipMemcpy(res->callq[s][w], R.v[s][w].callq, nv * 4, hipMemcpyDeviceToHost));
+            HIPCHK(h, get(res->errtype[s][w], R.v[s][w].errtype, nv));
+            HIPCHK(h, get(res->sync_group[s][w], R.v[s][w].sync_group, nv * 4));
+            HIPCHK(h, get(res->credit[s][w], R.v[s][w].credit, nv * 4));
+            HIPCHK(h, get(res->ref_ed[s][w], R.v[s][w].ref_ed, nv * 4));
+            HIPCHK(h, get(res->query_ed[s][w], R.v[s][w].query_ed, nv * 4));
+            HIPCHK(h, get(res->callq[s][w], R.v[s][w].callq, nv * 4));
         }
     }
+    HIPCHK(h, hipStreamSynchronize(st));
     return VPR_OK;
+}
+
+void *vpr_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void vpr_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int vpr_get_tally(const vpr_handle *h, int64_t out[6]) {

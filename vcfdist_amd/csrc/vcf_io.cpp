@@ -115,6 +115,31 @@ int vio_read_bed(const char *path, vio_bed **out) {
         r.first.push_back(atoi(f[1].c_str()));
         r.second.push_back(atoi(f[2].c_str()));
     }
+    // bedData::check (bed.cpp:36-71, called from globals.cpp:118): the reference stops on empty, unsorted or overlapping
+    // regions (vio_bed_contains bisects starts and stops, so it relies on exactly that) and warns about abutting ones
+    for (const auto &kv : b->regions) {
+        const std::string &ctg = kv.first;
+        const std::vector<int32_t> &st = kv.second.first, &sp = kv.second.second;
+        for (size_t j = 0; j < st.size(); j++) {
+            if (sp[j] < st[j]) { const int rc = fail(VIO_ERR_FORMAT, "BED region %s:%d-%d stop precedes start.", ctg.c_str(), st[j], sp[j]); delete b; return rc; }
+            if (sp[j] == st[j]) { const int rc = fail(VIO_ERR_FORMAT, "BED region %s:%d-%d length zero.", ctg.c_str(), st[j], sp[j]); delete b; return rc; }
+            if (j) {
+                if (sp[j] < st[j - 1]) {
+                    const int rc = fail(VIO_ERR_FORMAT, "BED is unsorted; region %s:%d-%d precedes %s:%d-%d.", ctg.c_str(), st[j - 1], sp[j - 1],
+                                        ctg.c_str(), st[j], sp[j]);
+                    delete b; return rc;
+                }
+                if (st[j] < sp[j - 1]) {
+                    const int rc = fail(VIO_ERR_FORMAT, "BED overlap detected: regions %s:%d-%d and %s:%d-%d.", ctg.c_str(), st[j - 1], sp[j - 1],
+                                        ctg.c_str(), st[j], sp[j]);
+                    delete b; return rc;
+                }
+                if (sp[j - 1] == st[j])
+                    fprintf(stderr, "[WARN ] BED regions %s:%d-%d and %s:%d-%d should be merged.\n", ctg.c_str(), st[j - 1], sp[j - 1],
+                            ctg.c_str(), st[j], sp[j]);
+            }
+        }
+    }
     *out = b;
     return VIO_OK;
 }

@@ -51,6 +51,14 @@ class Bed:
         rc = L.vio_read_bed(path.encode(), C.byref(self._h))
         if rc:
             raise IOError(f"vio_read_bed failed ({rc}): {_err()}")
+        # contigs in the order the file first names them (bedData::contigs, bed.cpp:22-26)
+        import gzip
+        self.contigs = []
+        with (gzip.open(path, "rt") if path.endswith(".gz") else open(path)) as fh:
+            for line in fh:
+                c = line.split("\t", 1)[0].strip()
+                if c and c not in self.contigs:
+                    self.contigs.append(c)
 
     def contains(self, ctg, start, stop, typ):
         L = api.lib()
