@@ -329,6 +329,18 @@ class Variants:
         return s
 
 
+class _HostBlock:
+    """one page-locked allocation, released when the last array viewing it goes away"""
+
+    def __init__(self, ptr, free):
+        self.ptr, self.free = ptr, free
+
+    def __del__(self):
+        if self.ptr and self.free is not None:
+            self.free(self.ptr)
+            self.ptr = None
+
+
 class Results:
     """Result buffers, initialised to the reference's initial values
     (errtype UN, everything else 0; variant.cpp:45-52, cluster.cpp:26-29)."""
@@ -340,7 +352,6 @@ class Results:
         """host_alloc / host_free: optional allocator of page-locked memory (vpr_host_alloc / vpr_host_free of the library);
         without it the buffers are ordinary numpy arrays"""
         self.n_sc = n_sc
-        self._blocks, self._free = [], host_free
 
         def full(n, value, dt):
             n = int(n)
@@ -349,8 +360,9 @@ class Results:
             p = host_alloc(n * np.dtype(dt).itemsize)
             if not p:
                 return np.full(n, value, dt)
-            self._blocks.append(p)
-            a = np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(p), dtype=dt, count=n)
+            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(p)
+            buf._block = _HostBlock(p, host_free)     # the array (through its base) keeps the block alive, not this object
+            a = np.frombuffer(buf, dtype=dt, count=n)
             a[:] = value
             return a
         self.aln_dist = full(n_sc * 4, 0, np.int32)
@@ -363,12 +375,6 @@ class Results:
         for name, dt in self.PER_VAR:
             init = ERRTYPE_UN if name == "errtype" else 0
             setattr(self, name, [[full(n_vars[h], init, dt) for _ in range(2)] for h in range(HAPS)])
-
-    def __del__(self):
-        if self._free is not None:
-            for p in self._blocks:
-                self._free(p)
-            self._blocks = []
 
     @classmethod
     def for_batch(cls, batch, host_alloc=None, host_free=None):
