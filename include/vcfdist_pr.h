@@ -8,16 +8,19 @@
  * supercluster inside that loop:
  *     generate_ptrs_strs x4      src/dist.cpp:145-242    (vpr_generate / device K0)
  *     calc_prec_recall_aln       src/dist.cpp:251-443    (device K1)
- *     store_phase                src/dist.cpp:449-475    (host, float compare)
- *     calc_prec_recall_path      src/dist.cpp:486-834    (device K2)
+ *     store_phase                src/dist.cpp:449-475    (device K5, k_finalize)
+ *     calc_prec_recall_path      src/dist.cpp:486-834    (device K2, + the swap_pred
+ *                                                         tie replay, pr_tie.hip)
  *     get_prec_recall_path_sync  src/dist.cpp:842-999    (device K3)
- *     calc_prec_recall           src/dist.cpp:1005-1401  (device K3 ints, host floats)
+ *     calc_prec_recall           src/dist.cpp:1005-1401  (device K3 + K5)
  *     wf_ed                      src/dist.cpp:1406-1506  (device K4)
  *
  * Plain pointers and sizes only; the caller owns every buffer it passes in, the
- * library owns device memory, streams and events.  All integers are produced on
- * the device; the float expressions of the reference (credit, callq, phase
- * threshold) are evaluated on the host exactly as written there.
+ * library owns device memory, streams and events.  Everything is computed on the
+ * device, including the reference's float expressions (credit, callq, the phase
+ * threshold: IEEE single-precision division and compares in the reference's order,
+ * k_finalize); vpr_download only copies.  vpr_store_phase is the same expression
+ * as a host function for callers that hold four distances.
  *
  * Hap slots (the "4 haps" of a supercluster) are numbered
  *     0 = QUERY hap1, 1 = QUERY hap2, 2 = TRUTH hap1, 3 = TRUTH hap2

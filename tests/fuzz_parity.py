@@ -87,7 +87,7 @@ def fuzz(budget_s, seed0, verbose=True, max_batches=None, shape=None):
         n_tie += ntie
         if verbose:
             print(f"seed {seed} shape {shape_} band_mode {band_mode}: {batch.n_sc} sc, {batch.dense_cells():.2e} dense cells, "
-                  f"{pr.timing().n_band_retries} retries, {ntie} ties skipped: ok", flush=True)
+                  f"{pr.timing().n_band_retries} retries, {ntie} ties decided other than by the largest source: ok", flush=True)
         seed += 1
     if n_limit and verbose:
         print(f"{n_limit} batches refused at the documented dense-level size limit")
@@ -97,4 +97,4 @@ def fuzz(budget_s, seed0, verbose=True, max_batches=None, shape=None):
 if __name__ == "__main__":
     runs, scs, ties = fuzz(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1000,
                            shape=int(sys.argv[3]) if len(sys.argv) > 3 else None)
-    print(f"fuzz: {runs} batches, {scs} superclusters, {ties} tie-skipped superclusters, no mismatch")
+    print(f"fuzz: {runs} batches, {scs} superclusters, {ties} ties decided other than by the largest source, no mismatch")

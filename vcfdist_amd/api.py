@@ -155,6 +155,19 @@ class Synth:
     def variants(self) -> A.Variants:
         return A.Variants.from_struct(self.struct)
 
+    def var_class(self, sv_threshold=50):
+        """SNP / INDEL / SV class of every variant of the four hap slots (print.cpp:362-372), from views into the
+        generator's tables (variants() copies the allele pools and the contigs as well)"""
+        from . import summary
+        s = self.struct
+        out = []
+        for h in range(A.HAPS):
+            nv = int(s.var_off[h][s.n_sc])
+            view = lambda p, dt: np.ctypeslib.as_array(p, shape=(nv,)) if nv else np.zeros(0, dt)
+            out.append(summary.var_class(view(s.var_type[h], np.uint8), view(s.var_ref_len[h], np.int32),
+                                         view(s.var_alt_len[h], np.int32), sv_threshold))
+        return out
+
     def batch(self, copy=True) -> A.Batch:
         """Level A batch of the workload.  copy=False returns numpy views into the library-owned
         buffers (no second copy of a multi-GB batch); the Batch keeps them alive."""

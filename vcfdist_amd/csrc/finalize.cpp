@@ -1,6 +1,5 @@
-// finalize.cpp -- host-side scalar float logic of the path, evaluated exactly as
-// the reference writes it (SURVEY.md 7 "hard part 4"): device kernels return
-// integers only.
+// finalize.cpp -- store_phase as a plain host function for callers that hold four
+// distances (the device path evaluates the same expression in k_finalize), and the version string.
 #include <cstdint>
 
 #include "../../include/vcfdist_pr.h"

@@ -20,22 +20,72 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
 
 #include "../../include/vcfdist_pr.h"
 
+// The arrays of a marshalled batch live in two page-locked staging blocks (vpr_host_alloc: vpr_upload's copies then run
+// as DMA at the link rate, beside the host's planning, instead of through the driver's bounce buffers): `small` holds the
+// offsets and the variant tables, whose sizes are known up front, `big` the strings, pointers and flags sized by pass 1.
+// Freed blocks are kept (the two most recent) and reused by the next batch: page-locking costs about as much as filling.
 struct vpr_owned_batch {
-    std::vector<int64_t> hap_off[VPR_HAPS], ref_off, var_off[VPR_HAPS];
-    std::vector<uint8_t> hap_seq[VPR_HAPS], hap_flag[VPR_HAPS], ref_seq, ref_flag[2];
-    std::vector<int32_t> hap_ptr[VPR_HAPS], ref_ptr[2], var_pos[VPR_HAPS];
-    std::vector<float> var_qual[VPR_HAPS];
+    int64_t *hap_off[VPR_HAPS], *ref_off, *var_off[VPR_HAPS];
+    uint8_t *hap_seq[VPR_HAPS], *hap_flag[VPR_HAPS], *ref_seq, *ref_flag[2];
+    int32_t *hap_ptr[VPR_HAPS], *ref_ptr[2], *var_pos[VPR_HAPS];
+    float *var_qual[VPR_HAPS];
+    struct Block { void *p = nullptr; size_t bytes = 0; bool pinned = false; } small, big;
     vpr_batch view;
 };
 
 namespace {
+
+using Block = vpr_owned_batch::Block;
+std::mutex g_cache_mu;
+Block g_cache[2];
+
+Block block_get(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (Block &c : g_cache)
+            if (c.p && c.bytes >= bytes) { Block b = c; c = Block(); return b; }
+    }
+    Block b;
+    b.bytes = bytes ? bytes : 1;
+    static std::atomic<bool> no_device{false};      // (asking the runtime again after a failure costs ~10 ms per call)
+    if (!no_device) b.p = vpr_host_alloc(b.bytes);  // nullptr without a HIP device: plain memory (marshalling alone needs no GPU)
+    b.pinned = b.p != nullptr;
+    if (!b.p) no_device = true;
+    if (!b.p) b.p = malloc(b.bytes);
+    return b;
+}
+
+void block_release(Block &b) {
+    if (b.p) { if (b.pinned) vpr_host_free(b.p); else free(b.p); }
+    b = Block();
+}
+
+void block_put(Block &b) {
+    if (!b.p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        Block *slot = nullptr;
+        for (Block &c : g_cache) if (!c.p) { slot = &c; break; }
+        if (!slot) { slot = g_cache[0].bytes <= g_cache[1].bytes ? &g_cache[0] : &g_cache[1]; if (slot->bytes >= b.bytes) slot = nullptr; }
+        if (slot) { std::swap(*slot, b); }
+    }
+    block_release(b);       // whatever was not kept (the displaced block, or this one)
+}
+
+// carve `n` elements of T (64-byte aligned) from a block
+struct Carver {
+    uint8_t *base; size_t off = 0;
+    template <typename T> T *take(size_t n) { T *p = base ? reinterpret_cast<T *>(base + off) : nullptr; off += (n * sizeof(T) + 63) & ~size_t(63); return p; }
+};
 
 struct Lens { int64_t hap, ref; int err; };
 
@@ -143,8 +193,25 @@ int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
     vpr_owned_batch *B = new (std::nothrow) vpr_owned_batch();
     if (!B) return VPR_ERR_NOMEM;
     const int n = v->n_sc;
-    for (int h = 0; h < VPR_HAPS; h++) B->hap_off[h].assign(n + 1, 0);
-    B->ref_off.assign(n + 1, 0);
+    auto carve_small = [&](Carver &c) {
+        for (int h = 0; h < VPR_HAPS; h++) {
+            B->hap_off[h] = c.take<int64_t>(size_t(n) + 1);
+            B->var_off[h] = c.take<int64_t>(size_t(n) + 1);
+            B->var_pos[h] = c.take<int32_t>(size_t(v->var_off[h][n]));
+            B->var_qual[h] = c.take<float>(size_t(v->var_off[h][n]));
+        }
+        B->ref_off = c.take<int64_t>(size_t(n) + 1);
+    };
+    {
+        Carver measure{nullptr};
+        carve_small(measure);
+        B->small = block_get(measure.off);
+        if (!B->small.p) { delete B; return VPR_ERR_NOMEM; }
+        Carver c{static_cast<uint8_t *>(B->small.p)};
+        carve_small(c);
+    }
+    for (int h = 0; h < VPR_HAPS; h++) std::fill(B->hap_off[h], B->hap_off[h] + n + 1, int64_t(0));
+    std::fill(B->ref_off, B->ref_off + n + 1, int64_t(0));
 
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const int nthreads = int(std::min<unsigned>(hw, 32));
@@ -167,21 +234,31 @@ int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
         for (int t = 0; t < nthreads; t++) th.emplace_back(size_job, t);
         for (auto &x : th) x.join();
     }
-    if (err) { delete B; return err; }
+    if (err) { vpr_owned_batch_free(B); return err; }
     for (int h = 0; h < VPR_HAPS; h++)
         for (int sc = 0; sc < n; sc++) B->hap_off[h][sc + 1] += B->hap_off[h][sc];
     for (int sc = 0; sc < n; sc++) B->ref_off[sc + 1] += B->ref_off[sc];
 
-    for (int h = 0; h < VPR_HAPS; h++) {
-        const int64_t m = B->hap_off[h][n];
-        B->hap_seq[h].resize(m);
-        B->hap_ptr[h].resize(m);
-        B->hap_flag[h].resize(m);
-    }
-    B->ref_seq.resize(B->ref_off[n]);
-    for (int h = 0; h < 2; h++) {
-        B->ref_ptr[h].resize(B->ref_off[n]);
-        B->ref_flag[h].resize(B->ref_off[n]);
+    auto carve_big = [&](Carver &c) {
+        for (int h = 0; h < VPR_HAPS; h++) {
+            const size_t m = size_t(B->hap_off[h][n]);
+            B->hap_seq[h] = c.take<uint8_t>(m);
+            B->hap_ptr[h] = c.take<int32_t>(m);
+            B->hap_flag[h] = c.take<uint8_t>(m);
+        }
+        B->ref_seq = c.take<uint8_t>(size_t(B->ref_off[n]));
+        for (int h = 0; h < 2; h++) {
+            B->ref_ptr[h] = c.take<int32_t>(size_t(B->ref_off[n]));
+            B->ref_flag[h] = c.take<uint8_t>(size_t(B->ref_off[n]));
+        }
+    };
+    {
+        Carver measure{nullptr};
+        carve_big(measure);
+        B->big = block_get(measure.off);
+        if (!B->big.p) { vpr_owned_batch_free(B); return VPR_ERR_NOMEM; }
+        Carver c{static_cast<uint8_t *>(B->big.p)};
+        carve_big(c);
     }
 
     // pass 2: fill
@@ -189,11 +266,9 @@ int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
         for (int sc = int(int64_t(n) * t / nthreads), e = int(int64_t(n) * (t + 1) / nthreads); sc < e; sc++) {
             for (int h = 0; h < VPR_HAPS; h++) {
                 const int64_t ho = B->hap_off[h][sc], ro = B->ref_off[sc];
-                walk<true>(v, h, sc, B->hap_seq[h].data() + ho, B->hap_ptr[h].data() + ho,
-                           B->hap_flag[h].data() + ho,
-                           h == 0 ? B->ref_seq.data() + ro : nullptr,
-                           h < 2 ? B->ref_ptr[h].data() + ro : nullptr,
-                           h < 2 ? B->ref_flag[h].data() + ro : nullptr);
+                walk<true>(v, h, sc, B->hap_seq[h] + ho, B->hap_ptr[h] + ho, B->hap_flag[h] + ho,
+                           h == 0 ? B->ref_seq + ro : nullptr, h < 2 ? B->ref_ptr[h] + ro : nullptr,
+                           h < 2 ? B->ref_flag[h] + ro : nullptr);
             }
         }
     };
@@ -205,10 +280,9 @@ int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
 
     // variants: positions relative to the supercluster start (dist.cpp:1075-1080)
     for (int h = 0; h < VPR_HAPS; h++) {
-        B->var_off[h].assign(v->var_off[h], v->var_off[h] + n + 1);
+        std::copy(v->var_off[h], v->var_off[h] + n + 1, B->var_off[h]);
         const int64_t nv = v->var_off[h][n];
-        B->var_pos[h].resize(nv);
-        B->var_qual[h].assign(v->var_qual[h], v->var_qual[h] + nv);
+        std::copy(v->var_qual[h], v->var_qual[h] + nv, B->var_qual[h]);
         for (int sc = 0; sc < n; sc++)
             for (int64_t k = v->var_off[h][sc]; k < v->var_off[h][sc + 1]; k++)
                 B->var_pos[h][k] = v->var_pos[h][k] - v->sc_beg[sc];
@@ -218,25 +292,30 @@ int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
     memset(&b, 0, sizeof(b));
     b.n_sc = n;
     for (int h = 0; h < VPR_HAPS; h++) {
-        b.hap_off[h] = B->hap_off[h].data();
-        b.hap_seq[h] = B->hap_seq[h].data();
-        b.hap_ptr[h] = B->hap_ptr[h].data();
-        b.hap_flag[h] = B->hap_flag[h].data();
-        b.var_off[h] = B->var_off[h].data();
-        b.var_pos[h] = B->var_pos[h].data();
-        b.var_qual[h] = B->var_qual[h].data();
+        b.hap_off[h] = B->hap_off[h];
+        b.hap_seq[h] = B->hap_seq[h];
+        b.hap_ptr[h] = B->hap_ptr[h];
+        b.hap_flag[h] = B->hap_flag[h];
+        b.var_off[h] = B->var_off[h];
+        b.var_pos[h] = B->var_pos[h];
+        b.var_qual[h] = B->var_qual[h];
     }
-    b.ref_off = B->ref_off.data();
-    b.ref_seq = B->ref_seq.data();
+    b.ref_off = B->ref_off;
+    b.ref_seq = B->ref_seq;
     for (int h = 0; h < 2; h++) {
-        b.ref_ptr[h] = B->ref_ptr[h].data();
-        b.ref_flag[h] = B->ref_flag[h].data();
+        b.ref_ptr[h] = B->ref_ptr[h];
+        b.ref_flag[h] = B->ref_flag[h];
     }
     *out = B;
     return VPR_OK;
 }
 
 const vpr_batch *vpr_owned_batch_view(const vpr_owned_batch *b) { return b ? &b->view : nullptr; }
-void vpr_owned_batch_free(vpr_owned_batch *b) { delete b; }
+void vpr_owned_batch_free(vpr_owned_batch *b) {
+    if (!b) return;
+    block_put(b->small);
+    block_put(b->big);
+    delete b;
+}
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -48,6 +49,31 @@ const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnD
 // truth rows from which an alignment is a latency chain
 const int LONG_LT = 512;
 
+// std::vector whose resize() leaves trivially constructible elements uninitialised (the planner fills millions of
+// 96-byte descriptors from several threads; zero-filling them first costs as much as the fill)
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <typename U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <typename U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+using DescVec = std::vector<AlnDesc, NoInitAlloc<AlnDesc>>;
+
+// fn(begin, end, thread) over [0, n) on up to PAR_MAX host threads (planning a batch of a million superclusters is a few
+// passes over 4 M descriptors: memory-latency bound on one core)
+const int PAR_MAX = 32;
+template <typename F>
+void par_for(size_t n, F fn) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nt = std::min<size_t>(std::min<unsigned>(hw, PAR_MAX), n / 32768);
+    if (nt <= 1) { fn(size_t(0), n, 0); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++) th.emplace_back([=, &fn] { fn(n * t / nt, n * (t + 1) / nt, int(t)); });
+    for (auto &x : th) x.join();
+}
+
 struct Launch { int cls; int64_t work_off; int32_t count; };   // dense: one k_fwd/k_bwd launch of a class
 struct Chunk {
     int64_t work_off = 0; int32_t count = 0;   // slice of the plan's work list
@@ -61,13 +87,14 @@ struct Chunk {
 // long alignments, which start at LV_C1, in front)
 struct Plan {
     int lv = LV_DENSE;
-    std::vector<AlnDesc> descs;     // compact, in work-list order
+    DescVec descs;                  // compact, in work-list order
     std::vector<int32_t> work;      // alignment ids
     std::vector<Chunk> chunks;
     AlnDesc *d_descs = nullptr;     // device copy of `descs` (plan 0 only, cached)
     int32_t *d_work = nullptr;
     uint8_t *arena = nullptr;       // workspace the offsets refer to
     int64_t arena_used = 0;         // bytes of it the largest chunk occupies
+    int64_t total_need = 0;         // bytes all chunks together would occupy
 };
 
 // a retry ladder's private resources (see vpr_execute)
@@ -103,18 +130,23 @@ struct vpr_handle {
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    std::vector<void *> allocs;          // batch-lifetime device allocations
+    std::vector<void *> allocs;          // batch-lifetime device allocations: pool blocks, carved by dev_alloc
+    uint8_t *pool_cur = nullptr;         // bump pointer into the newest block
+    size_t pool_left = 0, pool_next = size_t(16) << 20;   // block sizes double up to 2 GiB (a batch needs ~150 arrays)
     DevBatch dB;
     // host mirrors needed for planning / finalisation
     int32_t n_sc = 0;
     std::vector<int64_t> var_off[4];
     std::vector<float> var_qual[4];
     int64_t n_var[4] = {0, 0, 0, 0};
-    std::vector<AlnDesc> descs;          // base descriptors (no workspace offsets)
+    DescVec descs;                       // base descriptors (no workspace offsets)
     Plan plan0;                          // first round over all alignments, cached at upload
     std::vector<uint8_t> level, level0;  // current / round-0 window level of every alignment
     int64_t last_need = 0;               // workspace bytes of the alignment make_plan could not place
     uint8_t *d_cls[4] = {nullptr, nullptr, nullptr, nullptr};   // SNP / INDEL / SV class of every variant (vpr_upload_var_class)
+    unsigned long long *d_hist = nullptr;   // vpr_pr_counts: histogram words (batch lifetime, grown on demand)
+    size_t hist_cap = 0;
+    int32_t *d_pb = nullptr;                // vpr_pr_counts: the caller's phase-block phasing per supercluster
     std::vector<int32_t> dirty;          // alignments whose device descriptor was overwritten by a retry round
     // device side
     AlnDesc *d_descs = nullptr;
@@ -185,11 +217,26 @@ template <typename T>
 int dev_alloc(vpr_handle *h, T **p, size_t n) {
     *p = nullptr;
     if (n == 0) n = 1;
-    void *q = nullptr;
-    hipError_t e = hipMalloc(&q, n * sizeof(T));
-    if (e != hipSuccess) return fail(h, VPR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
-    h->allocs.push_back(q);
-    *p = static_cast<T *>(q);
+    const size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+    if (bytes > h->pool_left) {
+        // a new block: the request alone when it is large (the remainder of the old block stays usable for nothing: blocks
+        // double, so at most half of what was allocated is ever lost), else the next pool size
+        const size_t blk = std::max(bytes, h->pool_next);
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, blk);
+        if (e != hipSuccess) return fail(h, VPR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", blk, hipGetErrorString(e));
+        h->allocs.push_back(q);
+        if (bytes >= h->pool_next) {        // dedicated block; keep carving the previous one
+            *p = static_cast<T *>(q);
+            return VPR_OK;
+        }
+        h->pool_cur = static_cast<uint8_t *>(q);
+        h->pool_left = blk;
+        h->pool_next = std::min(h->pool_next * 2, size_t(2) << 30);
+    }
+    *p = reinterpret_cast<T *>(h->pool_cur);
+    h->pool_cur += bytes;
+    h->pool_left -= bytes;
     return VPR_OK;
 }
 
@@ -206,6 +253,7 @@ int dev_upload(vpr_handle *h, const T **dst, const T *src, size_t n) {
 void free_batch(vpr_handle *h) {
     for (void *p : h->allocs) (void)hipFree(p);
     h->allocs.clear();
+    h->pool_cur = nullptr; h->pool_left = 0; h->pool_next = size_t(16) << 20;
     for (void *p : h->pinned) (void)hipHostFree(p);
     h->pinned.clear();
     h->hp_fail = nullptr; h->hp_cnt = nullptr; h->hp_flag = nullptr;
@@ -215,6 +263,7 @@ void free_batch(vpr_handle *h) {
     h->dirty.clear();
     h->d_arena = nullptr; h->d_secs = nullptr;
     for (int k = 0; k < 4; k++) h->d_cls[k] = nullptr;
+    h->d_hist = nullptr; h->hist_cap = 0; h->d_pb = nullptr;
     for (int k = 0; k < 4; k++) {
         for (int e = 0; e < 2; e++) if (h->lad[k].tie_scratch[e]) (void)hipFree(h->lad[k].tie_scratch[e]);
         h->lad[k] = LadderCtx();
@@ -447,100 +496,171 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
     // Order: the long alignments first, longest first (they are latency chains and must start early).  The
     // rest keeps its input order, except at LV_Q16 where four alignments share a wave in lockstep and are
     // therefore grouped by their number of truth rows (counting sort, longest first, stable).
+    const size_t n_al = alns.size();
+    const bool dbg = h->debug && n_al >= 1000000;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double T0 = now();
+    auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[vpr]   make_plan %-24s %.3f s\n", what, now() - T0); };
     std::vector<int32_t> order;
-    order.reserve(alns.size());
+    size_t n_big = 0;                       // long alignments, in front of the plan
     {
+        std::vector<int32_t> lt(n_al);      // (compact copy: the descriptors are 96 bytes apart)
+        par_for(n_al, [&](size_t b, size_t e, int) { for (size_t i = b; i < e; i++) lt[i] = h->descs[size_t(alns[i])].Lt; });
         std::vector<std::pair<int64_t, int32_t>> big;
-        for (int32_t a : alns)
-            if (lv == LV_DENSE || h->descs[a].Lt >= LONG_LT) big.emplace_back(-mat_bytes(a), a);
+        for (size_t i = 0; i < n_al; i++)
+            if (lv == LV_DENSE || lt[i] >= LONG_LT) big.emplace_back(-mat_bytes(alns[i]), alns[i]);
         std::sort(big.begin(), big.end());
+        order.reserve(n_al);
         for (auto &b : big) order.push_back(b.second);
+        n_big = big.size();
         if (lv <= LV_Q16) {
             std::vector<int64_t> cnt(LONG_LT + 1, 0);
-            for (int32_t a : alns) if (h->descs[a].Lt < LONG_LT) cnt[LONG_LT - 1 - h->descs[a].Lt + 1]++;
+            for (size_t i = 0; i < n_al; i++) if (lt[i] < LONG_LT) cnt[LONG_LT - 1 - lt[i] + 1]++;
             for (int k = 0; k < LONG_LT; k++) cnt[k + 1] += cnt[k];
             const size_t base = order.size();
             order.resize(base + size_t(cnt[LONG_LT]));
-            for (int32_t a : alns)
-                if (h->descs[a].Lt < LONG_LT) order[base + size_t(cnt[LONG_LT - 1 - h->descs[a].Lt]++)] = a;
+            for (size_t i = 0; i < n_al; i++)
+                if (lt[i] < LONG_LT) order[base + size_t(cnt[LONG_LT - 1 - lt[i]]++)] = alns[i];
         } else if (lv != LV_DENSE) {
-            for (int32_t a : alns)
-                if (h->descs[a].Lt < LONG_LT) order.push_back(a);
+            for (size_t i = 0; i < n_al; i++)
+                if (lt[i] < LONG_LT) order.push_back(alns[i]);
         }
     }
-    P.work.reserve(order.size());
-    P.descs.reserve(order.size());
-    size_t k = 0;
-    while (k < order.size()) {
-        Chunk ch;
-        ch.work_off = int64_t(P.work.size());
-        int64_t used = 0;
-        const size_t k0 = k;
-        while (k < order.size()) {
-            AlnDesc d = h->descs[order[k]];
-            const int dl = level_of(d);
-            const int W = LV_WINDOW[dl];
-            int64_t m0, m1, bl;
-            if (dl <= LV_Q16) {
-                // stripe-transposed records of 128 B per 4 truth rows (both planes) + int2 origins per stripe
-                const int64_t nstr = (int64_t(d.Lt) + 3) / 4;
-                d.band_w = 16;
-                d.pitch[0] = d.pitch[1] = 16;
-                m0 = nstr * 128; m1 = 0;
-                bl = round_up(nstr * 8, 64);
-            } else if (W) {
-                d.band_w = W;
-                d.pitch[0] = int32_t(round_up(std::min(W, d.Lq), 16));
-                d.pitch[1] = int32_t(round_up(std::min(W, d.Lr), 16));
-                m0 = round_up(int64_t(d.pitch[0]) * d.Lt, 64); m1 = round_up(int64_t(d.pitch[1]) * d.Lt, 64);
-                bl = round_up(int64_t(2) * d.Lt * 4, 64);
-            } else {
-                d.band_w = 0;
-                d.pitch[0] = int32_t(round_up(d.Lq, 32));
-                d.pitch[1] = int32_t(round_up(d.Lr, 32));
-                const int cls = class_of(std::max(d.Lq, d.Lr));
-                // (the backward kernel's int32 score rows may not fit: it then runs with int16 rows, 4 B per cell)
-                if (cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX ||
-                    (bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX && (!s16_ok(d) || bwd_lds_bytes(cls, d.Lq, d.Lr, true) > LDS_MAX)))
-                    return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d too long for the dense kernels (Lq=%d Lr=%d)",
-                                d.sc, d.aln, d.Lq, d.Lr);
-                m0 = round_up(int64_t(d.pitch[0]) * d.Lt, 64); m1 = round_up(int64_t(d.pitch[1]) * d.Lt, 64);
-                bl = 0;
-            }
-            const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64);   // 16 B per step
-            const int64_t need = m0 + m1 + bl + pb + 64;
-            if (k > k0 && used + need > arena_bytes) break;
-            if (need > arena_bytes) h->last_need = need;
-            if (need > arena_bytes)
-                return fail(h, VPR_ERR_NOMEM, "workspace (%lld bytes) too small for supercluster %d alignment %d (%lld bytes)",
-                            (long long)arena_bytes, d.sc, d.aln, (long long)need);
-            d.band_pad = LV_TAG[dl] | tag_or;
-            d.mat_off[0] = used;
-            d.mat_off[1] = used + m0;
-            d.blo_off = (used + m0 + m1) / 4;            // int index into the arena
-            d.path_off = (used + m0 + m1 + bl) / int64_t(sizeof(PathEnt));
-            used += need;
-            ch.cells += W ? int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt : int64_t(d.Lq + d.Lr) * d.Lt;
-            ch.in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
-            h->level[size_t(order[k])] = uint8_t(dl);
-            P.work.push_back(order[k]);
-            P.descs.push_back(d);
-            k++;
+    lap("order");
+    // layout of one alignment at its level: flag matrices, window origins, walk scratch
+    struct Layout { int dl, band_w, pitch0, pitch1; int64_t m0, m1, bl, need; bool too_long; };
+    auto layout = [&](const AlnDesc &d) -> Layout {
+        Layout L;
+        L.dl = level_of(d);
+        L.too_long = false;
+        const int W = LV_WINDOW[L.dl];
+        if (L.dl <= LV_Q16) {
+            // stripe-transposed records of 128 B per 4 truth rows (both planes) + int2 origins per stripe
+            const int64_t nstr = (int64_t(d.Lt) + 3) / 4;
+            L.band_w = 16;
+            L.pitch0 = L.pitch1 = 16;
+            L.m0 = nstr * 128; L.m1 = 0;
+            L.bl = round_up(nstr * 8, 64);
+        } else if (W) {
+            L.band_w = W;
+            L.pitch0 = int32_t(round_up(std::min(W, d.Lq), 16));
+            L.pitch1 = int32_t(round_up(std::min(W, d.Lr), 16));
+            L.m0 = round_up(int64_t(L.pitch0) * d.Lt, 64); L.m1 = round_up(int64_t(L.pitch1) * d.Lt, 64);
+            L.bl = round_up(int64_t(2) * d.Lt * 4, 64);
+        } else {
+            L.band_w = 0;
+            L.pitch0 = int32_t(round_up(d.Lq, 32));
+            L.pitch1 = int32_t(round_up(d.Lr, 32));
+            const int cls = class_of(std::max(d.Lq, d.Lr));
+            // (the backward kernel's int32 score rows may not fit: it then runs with int16 rows, 4 B per cell)
+            L.too_long = cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX ||
+                         (bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX && (!s16_ok(d) || bwd_lds_bytes(cls, d.Lq, d.Lr, true) > LDS_MAX));
+            L.m0 = round_up(int64_t(L.pitch0) * d.Lt, 64); L.m1 = round_up(int64_t(L.pitch1) * d.Lt, 64);
+            L.bl = 0;
         }
-        ch.count = int32_t(P.work.size() - ch.work_off);
-        if (lv != LV_DENSE) {
-            while (ch.n_long < ch.count && P.descs[ch.work_off + ch.n_long].Lt >= LONG_LT) ch.n_long++;
+        const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64);   // 16 B per step
+        L.need = L.m0 + L.m1 + L.bl + pb + 64;
+        return L;
+    };
+    // pass 1 (parallel): workspace bytes of every alignment; pass 2 (one thread, 8 bytes per alignment): offsets and the cut
+    // into chunks that fit the workspace; pass 3 (parallel): the descriptors
+    const size_t n = order.size();
+    std::vector<int64_t> off(n);            // pass 1: need, pass 2: offset inside the chunk
+    std::atomic<size_t> bad{n};             // first alignment (in plan order) that cannot be placed
+    par_for(n, [&](size_t b, size_t e, int) {
+        for (size_t k = b; k < e; k++) {
+            const Layout L = layout(h->descs[size_t(order[k])]);
+            off[k] = L.need;
+            if (L.too_long || L.need > arena_bytes) {
+                size_t cur = bad.load();
+                while (k < cur && !bad.compare_exchange_weak(cur, k)) {}
+            }
+        }
+    });
+    lap("pass 1 (need)");
+    if (bad.load() < n) {
+        const AlnDesc &d = h->descs[size_t(order[bad.load()])];
+        const Layout L = layout(d);
+        if (L.too_long)
+            return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d too long for the dense kernels (Lq=%d Lr=%d)", d.sc, d.aln, d.Lq, d.Lr);
+        h->last_need = L.need;
+        return fail(h, VPR_ERR_NOMEM, "workspace (%lld bytes) too small for supercluster %d alignment %d (%lld bytes)",
+                    (long long)arena_bytes, d.sc, d.aln, (long long)L.need);
+    }
+    std::vector<int32_t> chunk_of;          // only for multi-chunk plans
+    {
+        int64_t used = 0;
+        size_t k0 = 0;
+        for (size_t k = 0; k < n; k++) {
+            const int64_t need = off[k];
+            P.total_need += need;
+            if (k > k0 && used + need > arena_bytes) {
+                Chunk ch;
+                ch.work_off = int64_t(k0); ch.count = int32_t(k - k0);
+                P.chunks.push_back(std::move(ch));
+                P.arena_used = std::max(P.arena_used, used);
+                k0 = k; used = 0;
+            }
+            off[k] = used;
+            used += need;
+        }
+        if (n > k0) {
+            Chunk ch;
+            ch.work_off = int64_t(k0); ch.count = int32_t(n - k0);
+            P.chunks.push_back(std::move(ch));
+            P.arena_used = std::max(P.arena_used, used);
+        }
+    }
+    lap("pass 2 (offsets)");
+    P.work = order;
+    P.descs.resize(n);
+    const size_t n_ch = P.chunks.size();
+    if (lv != LV_DENSE)
+        for (Chunk &ch : P.chunks) {
+            ch.n_long = int32_t(std::min<int64_t>(std::max<int64_t>(int64_t(n_big) - ch.work_off, 0), ch.count));
             // a LV_Q16 plan's long alignments use the 64-cell layout and cannot share a launch with the rest
             if (lv > LV_Q16 && (ch.n_long == ch.count || ch.count < 4096)) ch.n_long = 0;     // nothing to overlap with
-            for (int32_t w = 0; w < ch.count; w++) {
-                const AlnDesc &d = P.descs[ch.work_off + w];
-                const int part = w < ch.n_long ? 0 : 1;
-                const int W = d.band_w;
-                ch.part_cells[part] += int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt;
-                ch.part_in[part] += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
-                ch.part_dense[part] += int64_t(d.Lq + d.Lr) * d.Lt;
-            }
         }
+    struct Sums { int64_t cells = 0, in_bytes = 0, part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}; };
+    std::vector<Sums> sums(size_t(PAR_MAX) * n_ch);
+    par_for(n, [&](size_t b, size_t e, int tid) {
+        size_t ci = 0;
+        while (ci + 1 < n_ch && size_t(P.chunks[ci + 1].work_off) <= b) ci++;       // (chunks are few)
+        for (size_t k = b; k < e; k++) {
+            while (ci + 1 < n_ch && size_t(P.chunks[ci + 1].work_off) <= k) ci++;
+            AlnDesc d = h->descs[size_t(order[k])];
+            const Layout L = layout(d);
+            const int64_t used = off[k];
+            d.band_w = L.band_w; d.pitch[0] = L.pitch0; d.pitch[1] = L.pitch1;
+            d.band_pad = LV_TAG[L.dl] | tag_or;
+            d.mat_off[0] = used;
+            d.mat_off[1] = used + L.m0;
+            d.blo_off = (used + L.m0 + L.m1) / 4;            // int index into the arena
+            d.path_off = (used + L.m0 + L.m1 + L.bl) / int64_t(sizeof(PathEnt));
+            const int W = LV_WINDOW[L.dl];
+            Sums &S = sums[size_t(tid) * n_ch + ci];
+            S.cells += W ? int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt : int64_t(d.Lq + d.Lr) * d.Lt;
+            S.in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
+            if (lv != LV_DENSE) {
+                const int part = int64_t(k) - P.chunks[ci].work_off < P.chunks[ci].n_long ? 0 : 1;
+                S.part_cells[part] += int64_t(std::min(L.band_w, d.Lq) + std::min(L.band_w, d.Lr)) * d.Lt;
+                S.part_in[part] += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
+                S.part_dense[part] += int64_t(d.Lq + d.Lr) * d.Lt;
+            }
+            h->level[size_t(order[k])] = uint8_t(L.dl);
+            P.descs[k] = d;
+        }
+    });
+    lap("pass 3 (descriptors)");
+    for (size_t ci = 0; ci < n_ch; ci++)
+        for (int t = 0; t < PAR_MAX; t++) {
+            const Sums &S = sums[size_t(t) * n_ch + ci];
+            Chunk &ch = P.chunks[ci];
+            ch.cells += S.cells;
+            ch.in_bytes += S.in_bytes;
+            for (int q = 0; q < 2; q++) { ch.part_cells[q] += S.part_cells[q]; ch.part_in[q] += S.part_in[q]; ch.part_dense[q] += S.part_dense[q]; }
+        }
+    for (Chunk &ch : P.chunks) {
         if (lv == LV_DENSE) {
             // dense plan: group the chunk's alignments by kernel class (stable), one launch per class
             std::vector<int32_t> idx(ch.count);
@@ -561,8 +681,6 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
                 w = e;
             }
         }
-        P.arena_used = std::max(P.arena_used, used);
-        P.chunks.push_back(std::move(ch));
     }
     return VPR_OK;
 }
@@ -702,6 +820,8 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if ((rc = dev_alloc(h, &D.wk_q[q], hap_len[q]))) return rc;
         if ((rc = dev_alloc(h, &D.wk_r[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.wk_t[q], hap_len[2 + q]))) return rc;
+        if ((rc = dev_alloc(h, &D.xb_q[q], hap_len[q]))) return rc;
+        if ((rc = dev_alloc(h, &D.xb_r[q], ref_len))) return rc;
         HIPCHK(h, hipMemsetAsync(D.cand_q[q], 0xff, std::max<int64_t>(hap_len[q], 1) * sizeof(int4), h->stream));
         HIPCHK(h, hipMemsetAsync(D.cand_r[q], 0xff, std::max<int64_t>(ref_len, 1) * sizeof(int4), h->stream));
     }
@@ -731,6 +851,10 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     if (n > 0)
         for (int w = 0; w < 6; w++)
             hipLaunchKernelGGL(k_prep_suffix, dim3((n + 63) / 64), dim3(64), 0, h->stream, D, w);
+    for (int q = 0; q < 2; q++) {
+        if (hap_len[q] > 0) hipLaunchKernelGGL(k_prep_xb, blocks(hap_len[q]), dim3(256), 0, h->stream, D, q, 0, hap_len[q]);
+        if (ref_len > 0) hipLaunchKernelGGL(k_prep_xb, blocks(ref_len), dim3(256), 0, h->stream, D, q, 1, ref_len);
+    }
     for (int s = 0; s < 2; s++)
         if (hap_len[2 + s] > 0) hipLaunchKernelGGL(k_prep_tj, blocks(hap_len[2 + s]), dim3(256), 0, h->stream, D, s, hap_len[2 + s]);
     for (int w = 0; w < 6; w++) {
@@ -745,31 +869,54 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     h->descs.resize(size_t(n) * 4);
     int64_t sec_total = 0, jobs_total = 0;
     int64_t cells = 0, bytes_alg = 0;
-    for (int sc = 0; sc < n; sc++) {
-        const int64_t Lr = b->ref_off[sc + 1] - b->ref_off[sc];
-        int64_t Lh[4];
-        for (int s = 0; s < 4; s++) Lh[s] = b->hap_off[s][sc + 1] - b->hap_off[s][sc];
-        int64_t nv = 0;
-        for (int s = 0; s < 4; s++) nv += b->var_off[s][sc + 1] - b->var_off[s][sc];
-        bytes_alg += 6 * (Lh[0] + Lh[1] + Lh[2] + Lh[3]) + 11 * Lr + 26 * nv;
-        for (int i = 0; i < 4; i++) {
-            AlnDesc &d = h->descs[size_t(sc) * 4 + i];
-            memset(&d, 0, sizeof(d));
-            d.qs = i >> 1; d.ts = 2 + (i & 1);
-            d.sc = sc; d.aln = i;
-            d.q_off = b->hap_off[d.qs][sc]; d.t_off = b->hap_off[d.ts][sc]; d.r_off = b->ref_off[sc];
-            d.Lq = int32_t(Lh[d.qs]); d.Lt = int32_t(Lh[d.ts]); d.Lr = int32_t(Lr);
-            if (d.Lq < 1 || d.Lt < 1 || d.Lr < 1)
-                return fail(h, VPR_ERR_ARG, "supercluster %d has an empty string", sc);
-            d.qv_beg = b->var_off[d.qs][sc]; d.qv_end = b->var_off[d.qs][sc + 1];
-            d.tv_beg = b->var_off[d.ts][sc]; d.tv_end = b->var_off[d.ts][sc + 1];
-            d.sec_cap = int32_t((d.qv_end - d.qv_beg) + (d.tv_end - d.tv_beg) + 4);
-            d.sec_off = sec_total;
-            sec_total += d.sec_cap;
-            jobs_total += std::min(d.Lr, d.Lt) / 33;
-            d.path_cap = d.Lq + d.Lr + d.Lt + 4;
-            cells += int64_t(d.Lq + d.Lr) * d.Lt;
+    {
+        // section-table offsets: every supercluster's four alignments take 2 * (its variants) + 16 entries
+        std::vector<int64_t> sec_base(size_t(n) + 1);
+        sec_base[0] = 0;
+        for (int sc = 0; sc < n; sc++) {
+            int64_t nv = 0;
+            for (int s = 0; s < 4; s++) nv += b->var_off[s][sc + 1] - b->var_off[s][sc];
+            sec_base[size_t(sc) + 1] = sec_base[size_t(sc)] + 2 * nv + 16;
         }
+        sec_total = sec_base[size_t(n)];
+        struct Acc { int64_t jobs = 0, cells = 0, bytes = 0; int bad = -1; };
+        std::vector<Acc> acc(PAR_MAX);
+        par_for(size_t(n), [&](size_t b0, size_t e0, int tid) {
+            Acc &A = acc[size_t(tid)];
+            for (size_t scu = b0; scu < e0; scu++) {
+                const int sc = int(scu);
+                const int64_t Lr = b->ref_off[sc + 1] - b->ref_off[sc];
+                int64_t Lh[4];
+                for (int s = 0; s < 4; s++) Lh[s] = b->hap_off[s][sc + 1] - b->hap_off[s][sc];
+                int64_t nv = 0;
+                for (int s = 0; s < 4; s++) nv += b->var_off[s][sc + 1] - b->var_off[s][sc];
+                A.bytes += 6 * (Lh[0] + Lh[1] + Lh[2] + Lh[3]) + 11 * Lr + 26 * nv;
+                int64_t sec = sec_base[scu];
+                for (int i = 0; i < 4; i++) {
+                    AlnDesc &d = h->descs[scu * 4 + i];
+                    memset(&d, 0, sizeof(d));
+                    d.qs = i >> 1; d.ts = 2 + (i & 1);
+                    d.sc = sc; d.aln = i;
+                    d.q_off = b->hap_off[d.qs][sc]; d.t_off = b->hap_off[d.ts][sc]; d.r_off = b->ref_off[sc];
+                    d.Lq = int32_t(Lh[d.qs]); d.Lt = int32_t(Lh[d.ts]); d.Lr = int32_t(Lr);
+                    if ((d.Lq < 1 || d.Lt < 1 || d.Lr < 1) && A.bad < 0) A.bad = sc;
+                    d.qv_beg = b->var_off[d.qs][sc]; d.qv_end = b->var_off[d.qs][sc + 1];
+                    d.tv_beg = b->var_off[d.ts][sc]; d.tv_end = b->var_off[d.ts][sc + 1];
+                    d.sec_cap = int32_t((d.qv_end - d.qv_beg) + (d.tv_end - d.tv_beg) + 4);
+                    d.sec_off = sec;
+                    sec += d.sec_cap;
+                    A.jobs += std::min(d.Lr, d.Lt) / 33;
+                    d.path_cap = d.Lq + d.Lr + d.Lt + 4;
+                    A.cells += int64_t(d.Lq + d.Lr) * d.Lt;
+                }
+            }
+        });
+        int bad = -1;
+        for (const Acc &A : acc) {
+            jobs_total += A.jobs; cells += A.cells; bytes_alg += A.bytes;
+            if (A.bad >= 0 && (bad < 0 || A.bad < bad)) bad = A.bad;
+        }
+        if (bad >= 0) return fail(h, VPR_ERR_ARG, "supercluster %d has an empty string", bad);
     }
     bytes_alg += 2 * cells;
     h->timing.cells_dense = cells;
@@ -855,7 +1002,11 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     {
         const int bm = h->cfg.band_mode;
         const bool q16ok = (bm == 1 || bm == 3);
-        for (const AlnDesc &d : h->descs) {
+        std::vector<int64_t> wants(PAR_MAX, 0);
+        par_for(h->descs.size(), [&](size_t b0, size_t e0, int tid) {
+          int64_t want = 0;
+          for (size_t k = b0; k < e0; k++) {
+            const AlnDesc &d = h->descs[k];
             int64_t flags;
             if (bm != 0 && q16ok && d.Lt < LONG_LT) {
                 const int64_t nstr = (int64_t(d.Lt) + 3) / 4;
@@ -867,7 +1018,10 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
                 flags = round_up(round_up(d.Lq, 32) * int64_t(d.Lt), 64) + round_up(round_up(d.Lr, 32) * int64_t(d.Lt), 64);
             }
             want += flags + round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64) + 64;
-        }
+          }
+          wants[size_t(tid)] = want;
+        });
+        for (int64_t w : wants) want += w;
         if (h->cfg.workspace_bytes <= 0) budget = std::min(budget, std::max<int64_t>(want, 256 << 20));
     }
     h->arena_bytes = budget;
@@ -877,7 +1031,9 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     {
         HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
         int64_t b2 = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes
-                                                : std::min<int64_t>(int64_t(double(free_b) * 0.25), std::max<int64_t>(want / 16, int64_t(1) << 30));
+                                                // (four of them: together at most half of what round 0 left, the rest is for the
+                                                //  result columns, the tie replays' scratch and the deferred edit distances)
+                                                : std::min<int64_t>(int64_t(double(free_b) * 0.125), std::max<int64_t>(want / 16, int64_t(1) << 30));
         if (b2 < (8 << 20)) b2 = 8 << 20;
         for (int k = (h->cfg.band_mode != 0 ? 0 : 2); k < 4; k++) {   // (dense mode: only the tie rounds need one)
             h->lad[k].arena_bytes = b2;
@@ -888,17 +1044,19 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     lap("arena allocation");
     // ---- round-0 plan over all alignments, cached (descriptors + work list live on the device)
     std::vector<int32_t> all(na);
-    for (size_t k = 0; k < na; k++) all[k] = int32_t(k);
+    par_for(na, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) all[k] = int32_t(k); });
     h->level.assign(na, uint8_t(LV_DENSE));
     const int lv0 = h->cfg.band_mode == 0 ? LV_DENSE
                     : h->cfg.band_mode == 2 ? LV_C1
                     : h->cfg.band_mode == 3 ? LV_Q16 : LV_Z;
     if ((rc = make_plan(h, all, lv0, h->plan0, h->d_arena, h->arena_bytes))) return rc;
+    lap("make_plan");
     h->level0 = h->level;
     h->plan0_pos.assign(na, 0);
-    for (size_t k = 0; k < na; k++) h->plan0_pos[size_t(h->plan0.work[k])] = int32_t(k);
+    par_for(na, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) h->plan0_pos[size_t(h->plan0.work[k])] = int32_t(k); });
     if ((rc = dev_alloc(h, &h->plan0.d_descs, na))) return rc;
     if ((rc = dev_alloc(h, &h->plan0.d_work, na))) return rc;
+    lap("plan0_pos");
     if (na) {
         HIPCHK(h, hipMemcpyAsync(h->plan0.d_descs, h->plan0.descs.data(), na * sizeof(AlnDesc), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->plan0.d_work, h->plan0.work.data(), na * 4, hipMemcpyHostToDevice, h->stream));
@@ -1442,8 +1600,26 @@ int vpr_execute(vpr_handle *h) {
                 drop_resident(c);
                 rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes, tag_or);
             }
+            if (rc == VPR_OK && P.chunks.size() > 1 && h->cfg.workspace_bytes <= 0) {
+                // the plan needs several passes through the ladder's workspace (it starts small), i.e. its launches run one
+                // after the other with a few alignments each -- at the dense level that is one workgroup per alignment on a
+                // 256-CU device.  Grow the workspace to hold the plan, as far as half of the free memory allows.
+                size_t free_b = 0, total_b = 0;
+                HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+                const int64_t nb = std::min<int64_t>(P.total_need + (1 << 20), int64_t(free_b / 2));
+                if (nb > c.arena_bytes + c.arena_bytes / 2) {
+                    HIPCHK(h, hipStreamSynchronize(c.ls));
+                    uint8_t *na2 = nullptr;
+                    if (dev_alloc(h, &na2, size_t(nb) + 256) == VPR_OK) {   // (the old block is released with the batch)
+                        c.arena = na2; c.arena_bytes = nb; c.arena_cur = 0;
+                        rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes, tag_or);
+                    } else {
+                        h->err.clear();
+                    }
+                }
+            }
             if (rc == VPR_ERR_NOMEM && h->cfg.workspace_bytes <= 0) {
-                // one alignment does not fit the ladder's workspace (it starts small): grow it to twice that need
+                // one alignment does not fit the ladder's workspace: grow it to twice that need
                 HIPCHK(h, hipStreamSynchronize(c.ls));
                 const int64_t nb = std::max<int64_t>(2 * h->last_need, 2 * c.arena_bytes);
                 uint8_t *na2 = nullptr;
@@ -2042,10 +2218,13 @@ int vpr_upload_var_class(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS]
     if (!h->uploaded) return fail(h, VPR_ERR_STATE, "vpr_upload_var_class before vpr_upload");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     for (int s = 0; s < VPR_HAPS; s++) {
-        int rc = dev_alloc(h, &h->d_cls[s], size_t(h->n_var[s]));
-        if (rc) return rc;
-        if (h->n_var[s]) HIPCHK(h, hipMemcpy(h->d_cls[s], var_class[s], size_t(h->n_var[s]), hipMemcpyHostToDevice));
+        if (!h->d_cls[s]) {
+            int rc = dev_alloc(h, &h->d_cls[s], size_t(h->n_var[s]));
+            if (rc) return rc;
+        }
+        if (h->n_var[s]) HIPCHK(h, hipMemcpyAsync(h->d_cls[s], var_class[s], size_t(h->n_var[s]), hipMemcpyHostToDevice, h->stream));
     }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return VPR_OK;
 }
 
@@ -2056,13 +2235,18 @@ int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int nq = max_qual - min_qual + 1;
     const size_t nh = size_t(2) * 3 * 3 * size_t(nq + 1);
-    unsigned long long *d_hist = nullptr;
+    int rc;
+    if (nh > h->hist_cap) {
+        if ((rc = dev_alloc(h, &h->d_hist, nh))) return rc;
+        h->hist_cap = nh;
+    }
+    unsigned long long *d_hist = h->d_hist;
     int32_t *d_pb = nullptr;
-    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&d_hist), nh * 8));
-    HIPCHK(h, hipMemset(d_hist, 0, nh * 8));
+    HIPCHK(h, hipMemsetAsync(d_hist, 0, nh * 8, h->stream));
     if (pb_phase && h->n_sc) {
-        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&d_pb), size_t(h->n_sc) * 4));
-        HIPCHK(h, hipMemcpy(d_pb, pb_phase, size_t(h->n_sc) * 4, hipMemcpyHostToDevice));
+        if (!h->d_pb && (rc = dev_alloc(h, &h->d_pb, size_t(h->n_sc)))) return rc;
+        d_pb = h->d_pb;
+        HIPCHK(h, hipMemcpyAsync(d_pb, pb_phase, size_t(h->n_sc) * 4, hipMemcpyHostToDevice, h->stream));
     }
     if (var_class) { int rc = vpr_upload_var_class(h, var_class); if (rc) return rc; }
     for (int s = 0; s < VPR_HAPS; s++) {
@@ -2073,11 +2257,9 @@ int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const
                            h->dB.var_off[s], h->n_sc, nv, h->d_cls[s], h->dR.sc_phase, d_pb, h->dR.v[s][0], h->dR.v[s][1],
                            s >> 1, min_qual, max_qual, d_hist);
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<unsigned long long> hist(nh);
-    HIPCHK(h, hipMemcpy(hist.data(), d_hist, nh * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(d_hist);
-    if (d_pb) (void)hipFree(d_pb);
+    HIPCHK(h, hipMemcpyAsync(hist.data(), d_hist, nh * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     // counts at threshold k: variants whose last threshold index is >= k (print.cpp:378-381, 425-428); a truth variant
     // additionally counts as FN at every threshold above its own (print.cpp:429-432)
     std::fill(counts, counts + size_t(2) * VPR_VARTYPES * 3 * size_t(nq), 0);

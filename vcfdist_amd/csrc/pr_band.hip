@@ -122,6 +122,32 @@ __global__ void k_prep_suffix(DevBatch B, int which) {
     }
 }
 
+// exact budgets of the exit test (pr_device.h: xb_q / xb_r), needs vs_hap of k_prep_suffix.  dir 0: hap positions of
+// query hap h, dir 1: ref positions
+__global__ void k_prep_xb(DevBatch B, int h, int dir, int64_t n_pos) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= n_pos) return;
+    const int64_t *off = dir == 0 ? B.hap_off[h] : B.ref_off;
+    int lo = 0, hi = B.n_sc;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
+    const int sc = lo;
+    const int64_t qo = B.hap_off[h][sc], ro = B.ref_off[sc];
+    const int Lq = int(B.hap_off[h][sc + 1] - qo), Lr = int(B.ref_off[sc + 1] - ro);
+    const int32_t *W = B.vs_hap[h] + qo, *q2r = B.hap_ptr[h] + qo, *r2q = B.ref_ptr[h] + ro;
+    const uint8_t *rflag = B.ref_flag[h] + ro;
+    auto Wq = [&](int i) -> int { return i >= Lq ? 0 : W[max(i, 0)]; };
+    auto Bref = [&](int x) -> int {
+        if (x >= Lr) return 0;
+        x = max(x, 0);
+        const int hq = r2q[x];
+        const bool deleted = (rflag[x] & PV) && (hq < 0 || hq >= Lq || q2r[hq] != x);
+        return Wq(hq + 1 + (deleted ? 1 : 0));
+    };
+    const int x = int(g - off[sc]);
+    if (dir == 0) B.xb_q[h][g] = make_int2(Wq(x + 1), Bref(q2r[x] + 1));
+    else B.xb_r[h][g] = make_int2(Bref(x), Bref(x + 1));
+}
+
 // ---------------------------------------------------------------------------
 // DPP wave scans (gfx9 row_shr / row_bcast / wave_shr): ~12 VALU ops instead of six ds_bpermute hops
 // ---------------------------------------------------------------------------
@@ -270,6 +296,38 @@ __device__ __forceinline__ void stripe_origin(const int32_t *t2r, const uint16_t
     }
 }
 
+// Exit test of the window kernels (see the header).  An optimal path that leaves the window does so over an edge from an
+// in-window cell b (distance D inside the window) to a cell c outside; it costs at least D + cost(edge) + LB(c), where
+//     LB(c) = max(0, |rho(c) - tau(c)| - BUD(c) - W_t(t_c + 1))
+// bounds every continuation from c to an end cell (where rho = tau): rho / tau are the reference coordinates of c's plane
+// position and truth row, a unit-cost edge changes rho - tau by at most 1 plus the sizes of the indel steps it crosses, a
+// zero-cost edge only by the steps it crosses; a path crosses every truth step behind t_c at most once (W_t) and every
+// query-hap step at most once, and only steps it can still reach: behind x_c from the QUERY plane (W(x_c + 1)), and from the
+// REF plane those behind the hap position a swap from x_c or later lands on -- a deletion is crossed only by the swap in
+// front of it, so a path that stands on one of its bases (or walks into it along the REF plane, as the successors of the
+// cell in front of a deletion shared with the truth do) cannot use it (Bref, k_prep_xb).  Successors, with b = (p, x, t),
+// rho = rho(b), taun / vtn = tau and W_t of row t + 1, bud = {own, other} of xb_q / xb_r:
+//     INS   (p, x + 1, t)        cost 1   |rho + 1 - tau|  - (p ? bud.y : bud.x) - vt
+//     diag  (p, x + 1, t + 1)    cost 0   |rho + 1 - taun| - (p ? bud.y : bud.x) - vtn    (QUERY: rho(x + 1) = rho + 1 + w, W(x + 2) = W(x + 1) - |w|)
+//     DEL   (p, x, t + 1)        cost 1   |rho - taun|     - bud.x - vtn
+//     swap  (1 - p, z, t + 1)    cost 0   |rho + 1 - taun| - (p ? bud.x : bud.y) - vtn    (REF -> QUERY lands on rho + 1 + w with W(z + 1) = Bref(x) - |w|)
+// ex: which of the four leave the window (bits 1, 2, 4, 8).  Returns the smallest D + cost + LB over them, D_INF for none.
+__device__ __forceinline__ int exit_key(int ex, int p, int D, int rho, int2 bud, int tau, int vt, int taun, int vtn) {
+    const int b_same = p ? bud.y : bud.x, b_swap = p ? bud.x : bud.y;
+    const int a1 = rho + 1 - tau, a2 = rho + 1 - taun, a3 = rho - taun;
+    const int m2 = (a2 < 0 ? -a2 : a2) - vtn;
+    const int k_ins = 1 + max((a1 < 0 ? -a1 : a1) - b_same - vt, 0);
+    const int k_dg = max(m2 - b_same, 0);
+    const int k_del = 1 + max((a3 < 0 ? -a3 : a3) - bud.x - vtn, 0);
+    const int k_sw = max(m2 - b_swap, 0);
+    int k = D_INF;
+    k = (ex & 1) ? min(k, k_ins) : k;
+    k = (ex & 2) ? min(k, k_dg) : k;
+    k = (ex & 4) ? min(k, k_del) : k;
+    k = (ex & 8) ? min(k, k_sw) : k;
+    return ex ? D + k : D_INF;
+}
+
 __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__restrict__ descs,
                                                    const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
                                                    int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
@@ -286,8 +344,8 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
     const int2 *fk[2] = {B.fk_q[d.qs] + d.q_off, B.fk_r[d.qs] + d.r_off};
     const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
     const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
-    const int32_t *vsp[2] = {B.vs_hap[d.qs] + d.q_off, B.vs_ref[d.qs] + d.r_off};   // free-shift budget ahead
-    const int32_t *vst = B.vs_hap[d.ts] + d.t_off;
+    const int2 *xbp[2] = {B.xb_q[d.qs] + d.q_off, B.xb_r[d.qs] + d.r_off};   // free-shift budgets of the exit test (pr_device.h)
+    const int32_t *vst = B.vs_hap[d.ts] + d.t_off;                             // W_t(i): truth steps >= i
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     int32_t *blo = blo_all + d.blo_off;
     const int n_stripes = (Lt + FS_K - 1) / FS_K;
@@ -299,11 +357,14 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
     stripe_origin(t2r, tjp, r2q, lane, n_stripes, Lt, Lq, Lr, cbQ, cbR);
     stripe_origin(t2r, tjp, r2q, 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
     uint32_t tchunk = 0, tlast = 0;
-    int tauchunk = 0, vtchunk = 0;       // t2r[t] and the truth hap's free-shift budget of rows (t & ~63) + lane
+    // rows (t & ~63) + lane: tau = t2r[t] and W_t(t + 1), the truth hap's budget behind row t; the same of row t + 1
+    int tauchunk = 0, vtchunk = 0, taunchunk = 0, vtnchunk = 0;
     if (lane < Lt) {
         tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
         tauchunk = t2r[lane];
-        vtchunk = vst[max(lane - 1, 0)];
+        vtchunk = lane + 1 < Lt ? vst[lane + 1] : 0;
+        taunchunk = lane + 1 < Lt ? t2r[lane + 1] : tauchunk;
+        vtnchunk = lane + 2 < Lt ? vst[lane + 2] : 0;
     }
 
     int exit_min = D_INF, min_tie = D_INF;
@@ -312,15 +373,16 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
     int plo[2] = {0, 0};                 // origins of the previous stripe
     int nlo[2] = {0, 0}, nhi[2] = {0, 0};
     int2 kc[2], kn[2];                   // packed constants of this / the next stripe
-    int rhoc[2], rhon[2], vac[2], van[2];   // reference coordinate and free-shift budget of the lane's cell
+    int rhoc[2], rhon[2];                // reference coordinate of the lane's cell
+    int2 vac[2], van[2];                 // its free-shift budgets (xb_q / xb_r)
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         kc[p] = make_int2(-1, int(0xffffffffu));
-        rhoc[p] = lane; vac[p] = 0;
+        rhoc[p] = lane; vac[p] = make_int2(0, 0);
         if (lane <= hi[p]) {
             kc[p] = fk[p][lane];
             rhoc[p] = (p == 0) ? q2r[lane] : lane;
-            vac[p] = vsp[p][max(lane - 1, 0)];
+            vac[p] = xbp[p][lane];
         }
     }
 
@@ -338,12 +400,12 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             kn[p] = make_int2(-1, int(0xffffffffu));
-            rhon[p] = 0; van[p] = 0;
+            rhon[p] = 0; van[p] = make_int2(0, 0);
             if (has_next && nlo[p] + lane <= nhi[p]) {
                 const int xn = nlo[p] + lane;
                 kn[p] = fk[p][xn];
                 rhon[p] = (p == 0) ? q2r[xn] : xn;
-                van[p] = vsp[p][max(xn - 1, 0)];
+                van[p] = xbp[p][xn];
             }
         }
         if (lane < rows) { blo[t0 + lane] = lo[0]; blo[Lt + t0 + lane] = lo[1]; }   // read by K2 / K3
@@ -351,7 +413,10 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
         // ---- per-lane constants of this stripe
         int s0[2];
         uint32_t base[2];
-        bool multi[2], ex_in[2], ex_last[2];
+        bool multi[2];
+        // which edges of the lane's cell leave the window (bits: 1 INS, 2 diagonal, 4 DEL, 8 swap): towards a row of this
+        // stripe / from the stripe's last row towards the next stripe's window
+        int ex_in[2], ex_last[2];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int o = 1 - p;
@@ -363,9 +428,11 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
             const int z = kc[p].y & 0xffffff;
             const bool zok = valid && z != FK_NONE24 && z < Lp[o];
             const bool ins_out = valid && x == hi[p] && hi[p] < Lp[p] - 1;
-            ex_in[p] = ins_out || (zok && (z < lo[o] || z > hi[o]));
-            ex_last[p] = ins_out || (has_next && valid && (x < nlo[p] || (x + 1 <= Lp[p] - 1 && x + 1 > nhi[p]))) ||
-                         (has_next && zok && (z < nlo[o] || z > nhi[o]));
+            ex_in[p] = (ins_out ? 3 : 0) | ((zok && (z < lo[o] || z > hi[o])) ? 8 : 0);
+            ex_last[p] = (ins_out ? 1 : 0) |
+                         ((has_next && valid && x + 1 <= Lp[p] - 1 && (x + 1 < nlo[p] || x + 1 > nhi[p])) ? 2 : 0) |
+                         ((has_next && valid && (x < nlo[p] || x > nhi[p])) ? 4 : 0) |
+                         ((has_next && zok && (z < nlo[o] || z > nhi[o])) ? 8 : 0);
         }
         int rowo[2] = {lane, lane};   // byte offset of this lane's cell inside the stripe's LDS block
         const bool st_ok[2] = {lane < d.pitch[0], lane < d.pitch[1]};
@@ -378,26 +445,28 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
                 for (int p = 0; p < 2; p++) {
                     if (st_ok[p]) fbuf[p][rowo[p]] = (lane == 0) ? F_MAT : F_INS;
                     rowo[p] += d.pitch[p];
-                    const bool ex = last ? ex_last[p] : ex_in[p];
-                    // lower bound of any path through this exit cell: D + what the diagonal offset still costs
-                    const int off0_ = rhoc[p] - __builtin_amdgcn_readlane(tauchunk, 0);
-                    const int lb0 = max((off0_ < 0 ? -off0_ : off0_) - vac[p] - __builtin_amdgcn_readlane(vtchunk, 0), 0);
-                    exit_min = ex ? min(exit_min, lane + lb0) : exit_min;
+                    exit_min = min(exit_min, exit_key(last ? ex_last[p] : ex_in[p], p, lane, rhoc[p], vac[p],
+                                                      __builtin_amdgcn_readlane(tauchunk, 0), __builtin_amdgcn_readlane(vtchunk, 0),
+                                                      __builtin_amdgcn_readlane(taunchunk, 0), __builtin_amdgcn_readlane(vtnchunk, 0)));
                 }
                 continue;
             }
             if ((t & 63) == 0) {
                 tlast = __builtin_amdgcn_readlane(tchunk, 63);
                 const int tt = t + lane;
-                tchunk = 0; tauchunk = 0; vtchunk = 0;
+                tchunk = 0; tauchunk = 0; vtchunk = 0; taunchunk = 0; vtnchunk = 0;
                 if (tt < Lt) {
                     tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
                     tauchunk = t2r[tt];
-                    vtchunk = vst[tt - 1];
+                    vtchunk = tt + 1 < Lt ? vst[tt + 1] : 0;
+                    taunchunk = tt + 1 < Lt ? t2r[tt + 1] : tauchunk;
+                    vtnchunk = tt + 2 < Lt ? vst[tt + 2] : 0;
                 }
             }
             const int tau = __builtin_amdgcn_readlane(tauchunk, t & 63);
             const int vt = __builtin_amdgcn_readlane(vtchunk, t & 63);
+            const int taun = __builtin_amdgcn_readlane(taunchunk, t & 63);
+            const int vtn = __builtin_amdgcn_readlane(vtnchunk, t & 63);
             const uint32_t cur = __builtin_amdgcn_readlane(tchunk, t & 63);
             const uint32_t prv = ((t & 63) == 0) ? tlast : uint32_t(__builtin_amdgcn_readlane(tchunk, (t - 1) & 63));
             const uint32_t Tt = cur & 0xff;
@@ -471,13 +540,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
                 f |= (left + 1 == Dn) ? F_INS : 0;
                 if (st_ok[p]) fbuf[p][rowo[p]] = uint8_t(f);
                 rowo[p] += d.pitch[p];
-                // Exit test (see the header): a path through an exit cell costs at least D plus what it takes
-                // to bring the diagonal offset rho - tau back to zero, minus the indel sizes still ahead (each
-                // unit-cost edge moves the offset by at most 1 + the variants it crosses).
-                const bool ex = last ? ex_last[p] : ex_in[p];
-                const int doff = rhoc[p] - tau;
-                const int lb = max((doff < 0 ? -doff : doff) - vac[p] - vt, 0);
-                exit_min = ex ? min(exit_min, Dn + lb) : exit_min;
+                exit_min = min(exit_min, exit_key(last ? ex_last[p] : ex_in[p], p, Dn, rhoc[p], vac[p], tau, vt, taun, vtn));
                 Dp[p] = Dn;
             }
         }

@@ -65,6 +65,14 @@ struct DevBatch {
     // path through it (pr_band.hip, k_fwd_stripe).
     int32_t *vs_hap[4];
     int32_t *vs_ref[2];
+    // Exact free-shift budgets of the exit test of the 64-cell and wider window kernels (k_prep_xb; the derivation is at
+    // the exit test of k_fwd_stripe).  W(i) = vs_hap[h][i] = sum of |q2r step - 1| over query-hap steps k >= i.
+    //   Bref(x) = W(r2q[x] + 1), or W(r2q[x] + 2) when x is a deleted base: what a path that is on the REF plane at x can
+    //             still cross on the QUERY plane (a deletion is only crossed by a swap from in front of it)
+    //   xb_q[h][x] = {W(x + 1), Bref(q2r[x] + 1)}     a QUERY cell's own budget / its swap target's
+    //   xb_r[h][x] = {Bref(x), Bref(x + 1)}           a REF cell's own budget / its diagonal successor's
+    int2 *xb_q[2];
+    int2 *xb_r[2];
     // packed constants of the 16-cell window kernels (pr_q16.hip, k_prep_q16):
     //   fk4_*: {fk.x, fk.y, reference coordinate of the position, free-shift budget behind it}
     //   tk[s]: truth slot 2+s: {t2r[t], base | fwd_allow(flag[t-1]) << 8 | vs_hap[t-1] << 9}

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
     const int2 *fk[2] = {B.fk_q[d.qs] + d.q_off, B.fk_r[d.qs] + d.r_off};
     const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
     const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
-    const int32_t *vsp[2] = {B.vs_hap[d.qs] + d.q_off, B.vs_ref[d.qs] + d.r_off};
+    const int2 *xbp[2] = {B.xb_q[d.qs] + d.q_off, B.xb_r[d.qs] + d.r_off};     // budgets of the exit test (pr_device.h)
     const int32_t *vst = B.vs_hap[d.ts] + d.t_off;
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     int32_t *blo = blo_all + d.blo_off;
@@ -64,11 +64,14 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
     wide_origin<W>(t2r, tjp, r2q, lane, n_stripes, Lt, Lq, Lr, cbQ, cbR);
     wide_origin<W>(t2r, tjp, r2q, 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
     uint32_t tchunk = 0, tlast = 0;
-    int tauchunk = 0, vtchunk = 0;       // t2r[t] and the truth hap's free-shift budget of rows (t & ~63) + lane
+    // rows (t & ~63) + lane: tau = t2r[t] and W_t(t + 1), the truth hap's budget behind row t; the same of row t + 1
+    int tauchunk = 0, vtchunk = 0, taunchunk = 0, vtnchunk = 0;
     if (lane < Lt) {
         tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
         tauchunk = t2r[lane];
-        vtchunk = vst[max(lane - 1, 0)];
+        vtchunk = lane + 1 < Lt ? vst[lane + 1] : 0;
+        taunchunk = lane + 1 < Lt ? t2r[lane + 1] : tauchunk;
+        vtnchunk = lane + 2 < Lt ? vst[lane + 2] : 0;
     }
 
     int exit_min = D_INF;
@@ -77,17 +80,18 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
     int plo[2] = {0, 0};                 // origins of the previous stripe
     int nlo[2] = {0, 0}, nhi[2] = {0, 0};
     int2 kc[2], kn[2];
-    int rhoc[2], rhon[2], vac[2], van[2];
+    int rhoc[2], rhon[2];
+    int2 vac[2], van[2];
     int pin[2] = {D_INF, D_INF};         // lane l < NW: min of the scan totals of waves 0..l of the previous row
     int carry_prev[2] = {D_INF, D_INF};  // this wave's carry of the previous row (uniform)
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         kc[p] = make_int2(-1, int(0xffffffffu));
-        rhoc[p] = c; vac[p] = 0;
+        rhoc[p] = c; vac[p] = make_int2(0, 0);
         if (c <= hi[p]) {
             kc[p] = fk[p][c];
             rhoc[p] = (p == 0) ? q2r[c] : c;
-            vac[p] = vsp[p][max(c - 1, 0)];
+            vac[p] = xbp[p][c];
         }
     }
     // D of window column cs (columns of the origin the previous row was computed with) in the previous row
@@ -114,12 +118,12 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             kn[p] = make_int2(-1, int(0xffffffffu));
-            rhon[p] = 0; van[p] = 0;
+            rhon[p] = 0; van[p] = make_int2(0, 0);
             if (has_next && nlo[p] + c <= nhi[p]) {
                 const int xn = nlo[p] + c;
                 kn[p] = fk[p][xn];
                 rhon[p] = (p == 0) ? q2r[xn] : xn;
-                van[p] = vsp[p][max(xn - 1, 0)];
+                van[p] = xbp[p][xn];
             }
         }
         if (wave == 0 && lane < rows) { blo[t0 + lane] = lo[0]; blo[Lt + t0 + lane] = lo[1]; }   // read by K2 / K3
@@ -127,7 +131,8 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
         // ---- per-thread constants of this stripe
         int s0[2];
         uint32_t base[2];
-        bool multi[2], ex_in[2], ex_last[2];
+        bool multi[2];
+        int ex_in[2], ex_last[2];          // edges of the cell that leave the window (bits as in exit_key, k_fwd_stripe)
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int o = 1 - p;
@@ -141,9 +146,11 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
             const bool ins_out = valid & (x == hi[p]) & (hi[p] < Lp[p] - 1);
             const bool z_out = unsigned(z - lo[o]) > unsigned(hi[o] - lo[o]);
             const bool z_out_n = unsigned(z - nlo[o]) > unsigned(nhi[o] - nlo[o]);
-            const bool x_out_n = (x < nlo[p]) | ((x + 1 < Lp[p]) & (x + 1 > nhi[p]));
-            ex_in[p] = ins_out | (zok & z_out);
-            ex_last[p] = ins_out | (has_next & ((valid & x_out_n) | (zok & z_out_n)));
+            const bool dg_out_n = (x + 1 < Lp[p]) & ((x + 1 < nlo[p]) | (x + 1 > nhi[p]));
+            const bool del_out_n = (x < nlo[p]) | (x > nhi[p]);
+            ex_in[p] = (ins_out ? 3 : 0) | ((zok & z_out) ? 8 : 0);
+            ex_last[p] = (ins_out ? 1 : 0) | ((has_next & valid & dg_out_n) ? 2 : 0) | ((has_next & valid & del_out_n) ? 4 : 0) |
+                         ((has_next & zok & z_out_n) ? 8 : 0);
         }
         int rowo = lane;                   // byte offset of this thread's cell inside its wave's slab
         const bool st_ok[2] = {c < d.pitch[0], c < d.pitch[1]};
@@ -155,15 +162,19 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
             if ((t & 63) == 0 && t > 0) {
                 tlast = __builtin_amdgcn_readlane(tchunk, 63);
                 const int tt = t + lane;
-                tchunk = 0; tauchunk = 0; vtchunk = 0;
+                tchunk = 0; tauchunk = 0; vtchunk = 0; taunchunk = 0; vtnchunk = 0;
                 if (tt < Lt) {
                     tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
                     tauchunk = t2r[tt];
-                    vtchunk = vst[tt - 1];
+                    vtchunk = tt + 1 < Lt ? vst[tt + 1] : 0;
+                    taunchunk = tt + 1 < Lt ? t2r[tt + 1] : tauchunk;
+                    vtnchunk = tt + 2 < Lt ? vst[tt + 2] : 0;
                 }
             }
             const int tau = __builtin_amdgcn_readlane(tauchunk, t & 63);
             const int vt = __builtin_amdgcn_readlane(vtchunk, t & 63);
+            const int taun = __builtin_amdgcn_readlane(taunchunk, t & 63);
+            const int vtn = __builtin_amdgcn_readlane(vtnchunk, t & 63);
             int v[2] = {0, 0}, incl[2] = {0, 0};
             uint32_t mk[2] = {0, 0};
             if (t > 0) {
@@ -256,10 +267,7 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
                 }
                 if (st_ok[p]) fbuf[p][wave][rowo] = uint8_t(f);
                 // exit test, see k_fwd_stripe
-                const bool ex = last ? ex_last[p] : ex_in[p];
-                const int doff = rhoc[p] - tau;
-                const int lb = max((doff < 0 ? -doff : doff) - vac[p] - vt, 0);
-                exit_min = ex ? min(exit_min, Dn + lb) : exit_min;
+                exit_min = min(exit_min, exit_key(last ? ex_last[p] : ex_in[p], p, Dn, rhoc[p], vac[p], tau, vt, taun, vtn));
                 Dp[p] = Dn;
                 carry_prev[p] = carry[p];
             }
