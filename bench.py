@@ -59,12 +59,18 @@ def cpu_baseline(batch, target_s=15.0):
     import oracle_lib
     rng = np.random.RandomState(1234)
     n = batch.n_sc
-    # probe on 2000 random superclusters (1 thread), then size the threaded sample for ~target_s of wall time
-    probe = np.sort(rng.choice(n, size=min(n, 2000), replace=False))
-    sub = batch.subset(probe)
-    t0 = time.perf_counter()
-    oracle_lib.run(sub)
-    dt1 = time.perf_counter() - t0
+    # probe on random superclusters (1 thread; grown until it takes a second or reaches 2000, so that a workload of huge
+    # superclusters does not spend minutes here), then size the threaded sample for ~target_s of wall time
+    m0 = min(n, 16)
+    while True:
+        probe = np.sort(rng.choice(n, size=m0, replace=False))
+        sub = batch.subset(probe)
+        t0 = time.perf_counter()
+        oracle_lib.run(sub)
+        dt1 = time.perf_counter() - t0
+        if dt1 >= 1.0 or m0 >= min(n, 2000):
+            break
+        m0 = min(n, 2000, max(2 * m0, int(m0 * 1.5 / max(dt1, 1e-3))))
     per = dt1 / len(probe)
     threads = max(1, min(os.cpu_count() or 1, 64))
     m = int(min(n, max(len(probe), threads * target_s / max(per, 1e-9))))
@@ -303,6 +309,13 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch)
             out["cpu_baseline"]["host"] = f"{os.cpu_count()} logical cores visible"
+            try:    # how the port compares with the reference binary: its time on the reference's own demo workloads over the
+                # times BASELINE.md publishes for them (tools/calibrate_cpu.py, measured in the build container)
+                cal = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_cpu_calibration.json")))
+                out["cpu_baseline"]["calibration_port_over_reference_time"] = {k: v["oracle_over_reference"] for k, v in cal.items()}
+                out["cpu_baseline"]["calibration_source"] = f"profiles/{PROFILE_TAG}_cpu_calibration.json"
+            except (OSError, KeyError, ValueError):
+                pass
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -144,6 +144,7 @@ struct vpr_handle {
     std::vector<uint8_t> level, level0;  // current / round-0 window level of every alignment
     int64_t last_need = 0;               // workspace bytes of the alignment make_plan could not place
     uint8_t *d_cls[4] = {nullptr, nullptr, nullptr, nullptr};   // SNP / INDEL / SV class of every variant (vpr_upload_var_class)
+    int2 *hp_dspan[4] = {nullptr, nullptr, nullptr, nullptr};   // host copy of DevBatch::dspan (page-locked)
     unsigned long long *d_hist = nullptr;   // vpr_pr_counts: histogram words (batch lifetime, grown on demand)
     size_t hist_cap = 0;
     int32_t *d_pb = nullptr;                // vpr_pr_counts: the caller's phase-block phasing per supercluster
@@ -257,6 +258,7 @@ void free_batch(vpr_handle *h) {
     for (void *p : h->pinned) (void)hipHostFree(p);
     h->pinned.clear();
     h->hp_fail = nullptr; h->hp_cnt = nullptr; h->hp_flag = nullptr;
+    for (int s = 0; s < 4; s++) h->hp_dspan[s] = nullptr;
     h->events.clear();
     h->descs.clear();
     h->plan0 = Plan();
@@ -402,7 +404,7 @@ __global__ void k_collect_ties(const AlnOut *__restrict__ outs, int n, int4 *__r
     const int b = outs[i].band_ok;
     if (b >= 0) return;
     const int k = atomicAdd(cnt, 1);
-    if (k < cap) list[k] = make_int4(i, -b - 1, outs[i].n_sec, 0);
+    if (k < cap) list[k] = make_int4(i, -b - 1, outs[i].n_sec, outs[i].s);
 }
 
 // the same over a work list (the long / short part of round 0, right behind its backward sweep)
@@ -415,7 +417,7 @@ __global__ void k_collect_ties_list(const int32_t *__restrict__ work, int n, con
     const int b = outs[a].band_ok;
     if (b >= 0) return;
     const int k = atomicAdd(cnt, 1);
-    if (k < cap) list[k] = make_int4(a, -b - 1, outs[a].n_sec, 0);
+    if (k < cap) list[k] = make_int4(a, -b - 1, outs[a].n_sec, outs[a].s);
 }
 // long alignments accepted at `tag` whose forward sweep met a tied cell within the alignment's distance
 // (AlnOut::path_len = that cell's distance + 1, k_fwd_stripe): candidates for a speculative replay
@@ -428,7 +430,7 @@ __global__ void k_collect_spec(const int32_t *__restrict__ work, int n, const Al
     const AlnOut o = outs[a];
     if (o.band_ok != tag || o.path_len <= 0 || o.path_len - 1 > o.s) return;
     const int k = atomicAdd(cnt, 1);
-    if (k < cap) list[k] = make_int4(a, tag, 0, 0);
+    if (k < cap) list[k] = make_int4(a, tag, 0, o.s);
 }
 __global__ void k_publish_ties(const int4 *__restrict__ list, const int32_t *__restrict__ cnt, int4 *__restrict__ h_list,
                                int32_t *__restrict__ h_cnt, int cap) {
@@ -798,6 +800,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         h->var_qual[s].assign(b->var_qual[s], b->var_qual[s] + h->n_var[s]);
         if ((rc = dev_alloc(h, &D.has_ins[s], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.vs_hap[s], hap_len[s]))) return rc;
+        if ((rc = dev_alloc(h, &D.dspan[s], size_t(n)))) return rc;
         HIPCHK(h, hipMemsetAsync(D.has_ins[s], 0, std::max<int64_t>(ref_len, 1), h->stream));
     }
     if ((rc = dev_upload(h, &D.ref_off, b->ref_off, n + 1))) return rc;
@@ -851,6 +854,15 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     if (n > 0)
         for (int w = 0; w < 6; w++)
             hipLaunchKernelGGL(k_prep_suffix, dim3((n + 63) / 64), dim3(64), 0, h->stream, D, w);
+    {
+        void *pd = nullptr;
+        HIPCHK(h, hipHostMalloc(&pd, size_t(std::max(n, 1)) * 4 * sizeof(int2), hipHostMallocDefault));
+        h->pinned.push_back(pd);
+        for (int s = 0; s < 4; s++) {
+            h->hp_dspan[s] = static_cast<int2 *>(pd) + size_t(s) * size_t(n);
+            if (n > 0) HIPCHK(h, hipMemcpyAsync(h->hp_dspan[s], D.dspan[s], size_t(n) * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
+        }
+    }
     for (int q = 0; q < 2; q++) {
         if (hap_len[q] > 0) hipLaunchKernelGGL(k_prep_xb, blocks(hap_len[q]), dim3(256), 0, h->stream, D, q, 0, hap_len[q]);
         if (ref_len > 0) hipLaunchKernelGGL(k_prep_xb, blocks(ref_len), dim3(256), 0, h->stream, D, q, 1, ref_len);
@@ -1184,6 +1196,7 @@ int vpr_execute(vpr_handle *h) {
     int64_t tie_dec_cur = 0;
     struct TieEarly { int32_t n_used; int32_t pos; const Plan *plan; int mode; };   // mode 1 / 2: TieJob::mode; 3: decided speculatively
     std::unordered_map<int32_t, TieEarly> tie_early;   // alignment -> where the bytes of its marking round are
+    std::unordered_map<int32_t, int32_t> tie_s;        // alignment -> its distance (from the tie lists): bounds the stamp grids
     int tie_patch_slot = -1; int64_t tie_patch_off = 0, tie_patch_cap = 0;   // decision list of the last early launch
     bool tie_patch_spec = false;                   // the part has alignments whose decisions are in the speculative list
     int spec_slot = -1; int64_t spec_off = 0, spec_cap = 0;
@@ -1197,7 +1210,7 @@ int vpr_execute(vpr_handle *h) {
         int64_t &scratch_bytes = tc.tie_scratch_bytes[early ? 1 : 0];
         // scratch words of every job; the scratch grows to hold the whole launch (all replays concurrent: a long one is a
         // latency chain), bounded by half of the free memory -- beyond that the launch is cut into sub-batches
-        struct Need { int32_t k; int64_t cells, cap, bcap, w_st, w_buf, w_bk; };
+        struct Need { int32_t k; int64_t cells, cap, bcap, w_st, w_buf, w_bk; int32_t dlo[2], dn[2]; };
         std::vector<Need> needs{};
         needs.reserve(size_t(cnt));
         int64_t total = 0, largest = 0, dec_need = 0;
@@ -1208,7 +1221,27 @@ int vpr_execute(vpr_handle *h) {
             if (early && it->second.mode == 3) { tie_patch_spec = true; continue; }
             Need N;
             N.k = k;
-            N.cells = int64_t(d.Lq + d.Lr + 2 * d.Lt - 2) * d.Lt;     // stamp words: both planes, diagonal-major
+            // stamp words: both planes, diagonal-major; the diagonals a cell within the alignment's distance of the
+            // "same reference base" track can be on (DevBatch::dspan), or all of them on a second attempt
+            {
+                const int2 A = h->hp_dspan[d.qs][d.sc], T = h->hp_dspan[d.ts][d.sc];
+                const auto its = tie_s.find(P.work[size_t(off) + k]);
+                // (+ the haps' own ranges: inside a repeat a hap matches shifted by an indel just as well, and a swap carries
+                // that shift to the other plane)
+                const int64_t M = (h->cfg.flags & VPR_CFG_TIE_SMALL_LOGS) ? 0
+                                  : (its != tie_s.end() ? int64_t(its->second) + 4 + (int64_t(A.y) - A.x) + (int64_t(T.y) - T.x) : int64_t(1) << 30);
+                const int64_t lo_all = -(int64_t(d.Lt) - 1);
+                int64_t lo0 = lo_all, hi0 = d.Lq - 1, lo1 = lo_all, hi1 = d.Lr - 1;
+                if (!tie_full) {
+                    lo0 = std::max<int64_t>(lo0, int64_t(A.x) - T.y - M); hi0 = std::min<int64_t>(hi0, int64_t(A.y) - T.x + M);
+                    lo1 = std::max<int64_t>(lo1, -int64_t(T.y) - M); hi1 = std::min<int64_t>(hi1, -int64_t(T.x) + M);
+                    if (hi0 < lo0) hi0 = lo0;
+                    if (hi1 < lo1) hi1 = lo1;
+                }
+                N.dlo[0] = int32_t(lo0); N.dn[0] = int32_t(hi0 - lo0 + 1);
+                N.dlo[1] = int32_t(lo1); N.dn[1] = int32_t(hi1 - lo1 + 1);
+            }
+            N.cells = int64_t(N.dn[0] + N.dn[1]) * d.Lt + 4;
             if (N.cells >= (int64_t(1) << 32) - 2)
                 return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d: (Lq + Lr + 2 Lt) * Lt = %lld stamps exceed the tie replay's 32-bit cell index",
                             d.sc, d.aln, (long long)N.cells);
@@ -1227,13 +1260,15 @@ int vpr_execute(vpr_handle *h) {
         }
         if (needs.empty()) return VPR_OK;
         if (tie_job_cur + needs.size() > h->tie_jobs_cap) return fail(h, VPR_ERR_STATE, "tie round: job buffer overflow");
-        if (total * 4 > scratch_bytes) {
-            size_t free_b = 0, total_b = 0;
+        size_t free_b = 0, total_b = 0;
+        if (total * 4 > scratch_bytes) HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+        // (the block a launch outgrew is released first, so what it holds counts as free; a block already at the bound stays)
+        const int64_t nb_want = std::max<int64_t>(std::min<int64_t>(total * 4, int64_t((free_b + size_t(scratch_bytes)) / 4)), largest * 4) + 256;
+        if (total * 4 > scratch_bytes && nb_want > scratch_bytes + scratch_bytes / 8) {
             HIPCHK(h, hipStreamSynchronize(ks));
             if (scratch) (void)hipFree(scratch);
             scratch = nullptr; scratch_bytes = 0;
-            HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
-            const int64_t nb = std::max<int64_t>(std::min<int64_t>(total * 4, int64_t(free_b / 4)), largest * 4) + 256;
+            const int64_t nb = nb_want;
             void *q = nullptr;
             if (hipMalloc(&q, size_t(nb)) != hipSuccess)
                 return fail(h, VPR_ERR_NOMEM, "tie replay scratch (%lld bytes)", (long long)nb);
@@ -1275,6 +1310,7 @@ int vpr_execute(vpr_handle *h) {
                 J.a = P.work[size_t(off) + N.k];
                 J.cap = int32_t(N.cap); J.bcap = int32_t(std::min<int64_t>(N.bcap, 0x7fffffff));
                 J.stamp_off = words;
+                J.dlo[0] = N.dlo[0]; J.dlo[1] = N.dlo[1]; J.dn[0] = N.dn[0]; J.dn[1] = N.dn[1];
                 J.buf_off = words + N.w_st;
                 J.bkt_off = (words + N.w_st + N.w_buf) / 2;   // (all three terms are multiples of four words)
                 if (early) {
@@ -1715,6 +1751,7 @@ int vpr_execute(vpr_handle *h) {
         marked.reserve(size_t(n));
         tie_early.clear();
         for (const int4 &e : lst) {
+            tie_s[e.x] = e.w;
             int lv = LV_DENSE;
             for (int k = 0; k < LV_DENSE; k++) if (LV_TAG[k] == e.y) lv = k;
             h->level[size_t(e.x)] = uint8_t(lv);
@@ -1790,6 +1827,7 @@ int vpr_execute(vpr_handle *h) {
             tie_early.clear();
             for (int32_t k = 0; k < n; k++) {
                 const int32_t a = lst[k].x;
+                tie_s[a] = lst[k].w;
                 spec_plan.work.push_back(a);
                 spec_plan.descs.push_back(h->descs[size_t(a)]);
                 tie_early[a] = TieEarly{0, h->plan0_pos[size_t(a)], &h->plan0, 2};
@@ -1916,7 +1954,9 @@ int vpr_execute(vpr_handle *h) {
                 bool progressed = false;
                 if (wait_spec && flag_up(8)) {
                     const int32_t n = std::min(h->hp_tie_cnt[4], tie_cap[2]);
-                    if (n > 0 && (rc = spec_round(h->hp_tie_list + tie_off[2], n))) return rc;
+                    // (a speculative replay pays off as a head start for a few long chains; when thousands of alignments carry
+                    // tied cells most of them are never consulted, and the round waits for the backward sweep's marks instead)
+                    if (n > 0 && n <= 1024 && (rc = spec_round(h->hp_tie_list + tie_off[2], n))) return rc;
                     lapx("speculative list -> replays");
                     wait_spec = false;
                     progressed = true;
@@ -2010,7 +2050,16 @@ int vpr_execute(vpr_handle *h) {
         std::sort(js.begin(), js.end(), [](const TieJob &x, const TieJob &y) { return x.dbg_us > y.dbg_us; });
         int64_t tot_us = 0;
         for (const TieJob &J : js) tot_us += J.dbg_us;
-        fprintf(stderr, "[vpr] tie replay: %zu jobs, %.1f ms summed\n", js.size(), tot_us / 1000.0);
+        size_t nf1 = 0, nf2 = 0;
+        for (const TieJob &J : js) { nf1 += J.pad == 1; nf2 += J.pad == 2; }
+        fprintf(stderr, "[vpr] tie replay: %zu jobs, %.1f ms summed; gave up: %zu (logs), %zu (stamp grid)\n", js.size(), tot_us / 1000.0, nf1, nf2);
+        for (const TieJob &J : js)
+            if (J.pad == 2 && nf2-- < 4) {
+                const AlnDesc &d = h->descs[size_t(J.a)];
+                fprintf(stderr, "[vpr]   grid too small: sc %d aln %d Lq %d Lr %d Lt %d, diagonals [%d, +%d) [%d, +%d), spans q (%d, %d) t (%d, %d)\n", d.sc, d.aln, d.Lq, d.Lr, d.Lt,
+                        J.dlo[0], J.dn[0], J.dlo[1], J.dn[1], h->hp_dspan[d.qs][d.sc].x, h->hp_dspan[d.qs][d.sc].y, h->hp_dspan[d.ts][d.sc].x, h->hp_dspan[d.ts][d.sc].y);
+                fprintf(stderr, "[vpr]     first cell outside: plane %d position %d row %d (wave %d), mode %d\n", J.dbg_oob[0], J.dbg_oob[1], J.dbg_oob[2], J.dbg_oob[3], J.mode);
+            }
         for (size_t k = 0; k < js.size() && k < 8; k++) {
             const AlnDesc &d = h->descs[size_t(js[k].a)];
             fprintf(stderr, "[vpr]   sc %d aln %d Lq %d Lr %d Lt %d level %d: %d us, %d waves, %d BFS steps, %d cells; mode %d, consulted %d, decided %d (last in wave %d)\n", d.sc, d.aln,

@@ -116,10 +116,14 @@ __global__ void k_prep_suffix(DevBatch B, int which) {
     int32_t *out = which < 4 ? B.vs_hap[which] : B.vs_ref[which - 4];
     const int64_t b = off[sc], e = off[sc + 1];
     int32_t acc = 0;
+    int dmin = 0x7fffffff, dmax = -0x7fffffff;
     for (int64_t i = e - 1; i >= b; i--) {
         if (i > b) { const int w = ptr[i] - ptr[i - 1] - 1; acc += w < 0 ? -w : w; }
         out[i] = acc;
+        const int dd = int(i - b) - ptr[i];
+        dmin = min(dmin, dd); dmax = max(dmax, dd);
     }
+    if (which < 4) B.dspan[which][sc] = make_int2(dmin, dmax);
 }
 
 // exact budgets of the exit test (pr_device.h: xb_q / xb_r), needs vs_hap of k_prep_suffix.  dir 0: hap positions of

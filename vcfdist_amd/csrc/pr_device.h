@@ -73,6 +73,10 @@ struct DevBatch {
     //   xb_r[h][x] = {Bref(x), Bref(x + 1)}           a REF cell's own budget / its diagonal successor's
     int2 *xb_q[2];
     int2 *xb_r[2];
+    // per supercluster and hap slot: {min, max} of position - pointer over the hap's positions (k_prep_suffix).  A cell
+    // whose plane and truth positions map to the same reference base sits on diagonal q - t = (q - q2r[q]) - (t - t2r[t]):
+    // the host sizes the stamp grids of the tie replay (pr_tie.hip) from these ranges
+    int2 *dspan[4];
     // packed constants of the 16-cell window kernels (pr_q16.hip, k_prep_q16):
     //   fk4_*: {fk.x, fk.y, reference coordinate of the position, free-shift budget behind it}
     //   tk[s]: truth slot 2+s: {t2r[t], base | fwd_allow(flag[t-1]) << 8 | vs_hap[t-1] << 9}

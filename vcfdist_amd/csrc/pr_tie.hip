@@ -60,10 +60,14 @@ struct TieJob {
     // consults it; reads no flag bytes (a tie is a cell with two allowed sources popped in its wave) and lists every tied
     // cell.  mode 0: behind the repeated forward sweep, patches its flags in place.
     int32_t mode, n_used;
+    // stamp grids: per plane the diagonals q - t in [dlo, dlo + dn), dn x Lt words each (the host bounds them from the
+    // haps' pointer ranges and the alignment's distance; a push outside fails the job, which then runs again with all)
+    int32_t dlo[2], dn[2];
     int32_t old_band_w, old_pitch[2], pad2;
     int64_t old_mat_off[2], old_blo_off;
     uint8_t *old_arena;
     int32_t dbg_us, dbg_steps, dbg_cells, dbg_waves, dbg_nres, dbg_lastw;
+    int32_t dbg_oob[4];   // (debug) first cell outside the stamp grids: plane, position, row, wave
     int32_t dbg_t[8];     // us in: BFS, patch, order A, B, suffix, C, seeding, setup   // written by the kernel (the jobs live in host-pinned memory): VPR_DEBUG
 };
 #define TIE_BUF_WORDS 10
@@ -138,12 +142,19 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     uint32_t *blist = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(bcount + J.bcap) + 15) & ~uintptr_t(15));   // [bcap][TIE_BLIST]
     // stamps are stored diagonal-major, [plane][q - t + Lt - 1][t]: a run of matches walks consecutive words (the
     // dense [q][t] order made every step of a run touch another page: the replay was bound by address translation)
-    const uint32_t sbase1 = uint32_t(Lq + Lt - 1) * uint32_t(Lt);
-    auto sidx = [&](int p, int q, int t) -> uint32_t { return (p ? sbase1 : 0u) + uint32_t(q - t + Lt - 1) * uint32_t(Lt) + uint32_t(t); };
+    const uint32_t sbase1 = uint32_t(J.dn[0]) * uint32_t(Lt);
+    const uint32_t s_dummy = sbase1 + uint32_t(J.dn[1]) * uint32_t(Lt);     // a word behind the grids, for cells outside them
+    bool oob = false;
+    int oob_p = 0, oob_q = 0, oob_t = 0;
+    auto sidx = [&](int p, int q, int t) -> uint32_t {
+        const uint32_t dg = uint32_t(q - t - J.dlo[p]);
+        if (dg >= uint32_t(J.dn[p])) { if (!oob) { oob_p = p; oob_q = q; oob_t = t; } oob = true; return s_dummy; }
+        return (p ? sbase1 : 0u) + dg * uint32_t(Lt) + uint32_t(t);
+    };
     const unsigned long long hi_q = (unsigned long long)(2 * d.aln) * 73856093ull + 0x517cc1b727220a95ull;       // dist.h:45
     const unsigned long long hi_r = (unsigned long long)(2 * d.aln + 1) * 73856093ull + 0x517cc1b727220a95ull;
 
-    bool fail = (cap < 2) || Lq > 32768 || Lr > 32768;
+    bool fail = (cap < 2) || Lq > 32768 || Lr > 32768 || J.dn[0] <= 0 || J.dn[1] <= 0;
     for (int p = 0; p < 2 && !fail; p++) {
         const int L = p ? Lr : Lq;
         const int4 *cd = p ? cand1 : cand0;
@@ -262,7 +273,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                     if (wz[u]) { qc[py + (wy[u] ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq[u]), uint32_t(t + 1)); if (is_multi(1 - p, zq[u])) note_tie(1 - p, zq[u], t + 1); }
                     base += tot;
                 }
-                if (fail) break;
+                if (fail || __any(oob)) { fail = true; break; }
                 tie_wait();
                 n_cur = base;
                 head += n;
@@ -289,6 +300,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             bool ty = false, tz = false;
             uint32_t iy = 0, iz = 0;
             int zq = 0;
+            const bool oob_before = oob;
             if (act && t + 1 < Lt && q < Lme) {
                 const uint8_t tb = Ts[t + 1];
                 if (q + 1 < Lme && (p ? seq1 : seq0)[q + 1] == tb) { ty = true; iy = sidx(p, q + 1, t + 1); }
@@ -300,6 +312,9 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                 }
             }
             const bool l0 = lane < n;                 // the lanes of the level actually popped now
+            // (a look-ahead lane whose hypothetical target lies outside the stamp grids only ends the batch of levels)
+            const bool la_oob = !l0 && oob && !oob_before;
+            if (la_oob) oob = false;
             const uint32_t cy = cid + 2u * uint32_t(lane), cz = cy + 1u;
             uint32_t oy = TIE_NEVER, oz = TIE_NEVER;
             if (l0 && ty) oy = atomicMin(stamp + iy, cy);
@@ -325,7 +340,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                     const int ky = !ty ? 0 : (wy ? 1 : (oy < cid ? 3 : 2)), kz = !tz ? 0 : (wz ? 1 : (oz < cid ? 3 : 2));
                     const int ky0 = __shfl(ky, il), kz0 = __shfl(kz, il), zq0 = __shfl(zq, il);
                     // a look-ahead lane has only read its targets' stamps: untouched (classes 1, 2) or not (class 3)
-                    const bool same = (ty == (ky0 != 0)) && (tz == (kz0 != 0)) && (!tz || zq == zq0 + jl) &&
+                    const bool same = !la_oob && (ty == (ky0 != 0)) && (tz == (kz0 != 0)) && (!tz || zq == zq0 + jl) &&
                                       (!ty || ((vy == TIE_NEVER) == (ky0 != 3))) && (!tz || ((vz == TIE_NEVER) == (kz0 != 3)));
                     const unsigned long long bad = __ballot(act && !l0 && !same);
                     nlev = bad ? int(__builtin_ctzll(bad)) / n : nk;
@@ -347,6 +362,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             if (wy) { qc[n_cur + ry] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1); }
             if (wz) { qc[n_cur + ry + (wy ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1)); if (is_multi(1 - p, zq)) note_tie(1 - p, zq, t + 1); }
             tie_wait();
+            if (__any(oob)) { fail = true; break; }
             n_cur += tot * nlev;
             head += n * nlev;
             dbg_steps++;
@@ -403,6 +419,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                 }
             }
             __syncthreads();
+            if (__any(oob)) { fail = true; break; }
             if (lds_nres != dbg_nres0) { dbg_nres0 = lds_nres; dbg_lastw = w; }
             if (J.mode == 1 && lds_nres >= J.n_used) { dbg_cells += n_cur; dbg_waves++; break; }   // every consulted tie is decided
         }
@@ -617,7 +634,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                 n_next += tot;
             }
             cid += 3u * uint32_t(min(64 * TIE_U, n - k0));
-            if (cid > 0xf0000000u) fail = true;
+            if (cid > 0xf0000000u || __any(oob)) fail = true;
         }
         if (fail) break;
         tie_wait();
@@ -627,6 +644,9 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
         if (n_cur == 0) { fail = true; break; }   // "Empty queue" (dist.cpp:314): cannot happen for an accepted alignment
     }
     if (fail && lane == 0) atomicAdd(n_overflow, 1);
+    const bool any_oob = __any(oob);
+    if (any_oob && lane == int(__builtin_ctzll(__ballot(oob)))) { jobs[j].dbg_oob[0] = oob_p; jobs[j].dbg_oob[1] = oob_q; jobs[j].dbg_oob[2] = oob_t; jobs[j].dbg_oob[3] = dbg_waves; }
+    if (lane == 0) jobs[j].pad = fail ? (any_oob ? 2 : 1) : 0;       // (debug) why the job gave up: 1 logs / buckets, 2 stamp grid
     if (lane == 0) {
         jobs[j].dbg_us = int32_t((wall_clock64() - clk0) / 100);   // 100 MHz counter
         jobs[j].dbg_steps = dbg_steps; jobs[j].dbg_cells = dbg_cells; jobs[j].dbg_waves = dbg_waves;
