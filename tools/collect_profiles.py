@@ -17,11 +17,15 @@ def one(pattern):
     g = glob.glob(os.path.join(out, pattern), recursive=True)
     if not g:
         raise SystemExit("missing " + pattern)
-    return g[0]
+    return max(g, key=os.path.getmtime)      # (a directory may hold the files of an earlier, failed run)
 
 
 def bench_name(k):      # bench.py's names for the kernels (vpr_launch_stat.kernel)
-    k = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+    k = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace(", ", ",")
+    if k.startswith("k_bwd<") and k.endswith(",false>"):      # dense classes: bench.py says k_bwd<NT,C> / k_bwd<NT,C,s16>
+        k = k[:-len(",false>")] + ">"
+    elif k.startswith("k_bwd<") and k.endswith(",true>") and k.count(",") == 2:
+        k = k[:-len(",true>")] + ",s16>"
     return {"k_bwd_q16<true>": "k_bwd_q16<zero>", "k_bwd_q16<false>": "k_bwd_q16", "k_credit<false>": "k_credit<lane>",
             "k_credit<true>": "k_credit<wave>", "k_walk<false>": "k_walk<lane>", "k_walk<true>": "k_walk<wave>"}.get(k, k)
 

@@ -1100,35 +1100,60 @@ int vpr_upload_variants(vpr_handle *h, const vpr_variants *v) {
     return rc;
 }
 
-int vpr_execute(vpr_handle *h) {
-    if (!h) return VPR_ERR_ARG;
-    if (!h->uploaded) return fail(h, VPR_ERR_STATE, "vpr_execute before vpr_upload");
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    h->events.clear();
-    h->ev_used = 0;
-    hipStream_t st = h->stream;
-    auto blocks = [](int64_t n_) { return dim3(unsigned((n_ + 255) / 256)); };
-    {
-        InitArgs IA;
-        IA.outs = h->d_outs; IA.na = int64_t(h->descs.size());
-        int64_t top = std::max<int64_t>(IA.na, 8);
-        for (int q = 0; q < 4; q++) {
-            IA.fp[q] = h->d_fp[q]; IA.n_fp[q] = h->n_var[q >> 1];
-            IA.n_var[q] = h->n_var[q];
-            for (int w = 0; w < 2; w++) IA.v[q][w] = h->dR.v[q][w];
-            top = std::max(top, std::max(IA.n_fp[q], IA.n_var[q]));
-        }
-        IA.tally = h->dR.tally; IA.njobs = h->d_njobs; IA.cnt = h->d_cnt; IA.n_cnt = 2;
-        hipLaunchKernelGGL(k_init_execute, blocks(top), dim3(256), 0, st, IA);
-    }
-    if (!h->dirty.empty()) {   // restore the round-0 descriptors a previous execute's retry rounds replaced
-        hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(h->descs.size())), dim3(256), 0, st, h->plan0.d_descs,
-                           int(h->descs.size()), h->d_descs);
-        h->dirty.clear();
+}  // extern "C"
+
+namespace {
+
+// One vpr_execute call: the state its phases share and the phases themselves.  Round 0 (round0_windowed / run_dense), the
+// retry ladders (lad_start / lad_flush), the tie rounds (tie_round, tie_replay, tie_patch, spec_round), the final tie pass,
+// the deferred edit distances (K4) and the finalisation (K5) all enqueue on the handle's streams; run() is the sequence.
+struct Exec {
+    vpr_handle *h;
+    hipStream_t st;
+    std::chrono::steady_clock::time_point wall0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;      // bracket the whole call on the main stream
+    int32_t flag_exp[16] = {};                  // value post_flag asked the device to write into hp_flag[idx]
+    int64_t n_fwd = 0, cells_touched = 0, n_retry = 0;
+    // ---- tie rounds (pr_tie.hip).  tie_full: FIFO logs and stamp grids sized for the worst case (second attempt, after a
+    // capped job gave up)
+    bool tie_full = false;
+    size_t tie_job_cur = 0;
+    int64_t n_tie_jobs = 0;
+    int tie_dec_slot = 0;                          // decision lists handed out in this execute
+    int64_t tie_dec_cur = 0;
+    struct TieEarly { int32_t n_used; int32_t pos; const Plan *plan; int mode; };   // mode 1 / 2: TieJob::mode; 3: decided speculatively
+    std::unordered_map<int32_t, TieEarly> tie_early;   // alignment -> where the bytes of its marking round are
+    std::unordered_map<int32_t, int32_t> tie_s;        // alignment -> its distance (from the tie lists): bounds the stamp grids
+    int tie_patch_slot = -1; int64_t tie_patch_off = 0, tie_patch_cap = 0;   // decision list of the last early launch
+    bool tie_patch_spec = false;                   // the part has alignments whose decisions are in the speculative list
+    int spec_slot = -1; int64_t spec_off = 0, spec_cap = 0;
+    std::unordered_map<int32_t, int> spec_set;     // alignments with a speculative replay in flight / done
+    LadderCtx *tie_ctx;                            // the tie ladder whose round is being enqueued
+    bool lad_tie_wait[2] = {false, false};         // a retry ladder's tie list is on its way
+    std::vector<std::pair<TieJob *, size_t>> tie_job_blocks;   // (debug) the job blocks of this execute
+    size_t tie_job_total = 0;
+    // ---- round 0 of a windowed plan
+    const Plan &P0;
+    const int64_t na_;
+    hipStream_t s_long, s_short;
+    LadderCtx &LL, &LS;                            // the retry ladders of the long / short part
+    // regions of the tie list buffer: long part's marks, short part's marks, long part's speculative candidates (the retry
+    // ladders' regions follow)
+    int32_t tie_cap[3], tie_off[3];
+    Plan spec_plan;
+
+    explicit Exec(vpr_handle *h_)
+        : h(h_), st(h_->stream), tie_ctx(&h_->lad[2]), P0(h_->plan0), na_(int64_t(h_->descs.size())), s_long(h_->cls_stream[0]),
+          s_short(h_->cls_stream[1]), LL(h_->lad[0]), LS(h_->lad[1]) {
+        tie_cap[0] = h->tie_list_cap / 8; tie_cap[1] = h->tie_list_cap / 4; tie_cap[2] = h->tie_list_cap / 8;
+        tie_off[0] = 0; tie_off[1] = h->tie_list_cap / 4; tie_off[2] = h->tie_list_cap / 8;
     }
 
+    static dim3 blocks(int64_t n_) { return dim3(unsigned((n_ + 255) / 256)); }
+
     // HIP events bracket each launch on the stream the kernel is launched on
-    auto timed = [&](int kind, const vpr_launch_stat &ls, hipStream_t ks, const char *name, auto &&launch) -> int {
+    template <typename F>
+    int timed(int kind, const vpr_launch_stat &ls, hipStream_t ks, const char *name, F &&launch) {
         EvPair ev; ev.kind = kind; ev.st = ls; ev.st.kind = kind;
         snprintf(ev.st.kernel, sizeof(ev.st.kernel), "%s", name);
         while (h->ev_pool.size() < h->ev_used + 2) {
@@ -1143,29 +1168,22 @@ int vpr_execute(vpr_handle *h) {
         HIPCHK(h, hipEventRecord(ev.b, ks));
         h->events.push_back(ev);
         return VPR_OK;
-    };
-    // (measured: without one blocking call here the runtime does not start this call's submissions for 0.1 - 2 s when the
-    // host goes straight to polling memory below, e.g. right behind another library's work on the device)
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const auto wall0 = std::chrono::steady_clock::now();
-    auto lapx = [&](const char *what) {
+    }
+
+    void lapx(const char *what) {
         if (h->debug) fprintf(stderr, "[vpr] execute %-34s %8.3f ms\n", what,
                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
-    };
-    int32_t flag_exp[16] = {};
-    auto post_flag = [&](int idx, hipStream_t ks) {     // "everything enqueued on ks so far is complete" -> hp_flag[idx]
+    }
+
+    void post_flag(int idx, hipStream_t ks) {     // "everything enqueued on ks so far is complete" -> hp_flag[idx]
         flag_exp[idx] = ++h->flag_seq;
         hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, ks, h->hp_flag + idx, flag_exp[idx]);
-    };
-    auto flag_up = [&](int idx) -> bool { return *static_cast<volatile int32_t *>(h->hp_flag + idx) == flag_exp[idx]; };
-    hipEvent_t t0, t1;
-    HIPCHK(h, hipEventCreate(&t0));
-    HIPCHK(h, hipEventCreate(&t1));
-    HIPCHK(h, hipEventRecord(t0, st));
-    int64_t n_fwd = 0, cells_touched = 0, n_retry = 0;
+    }
+
+    bool flag_up(int idx) { return *static_cast<volatile int32_t *>(h->hp_flag + idx) == flag_exp[idx]; }
 
     // wave = true: one wavefront per alignment with LDS-staged window rows (long banded alignments)
-    auto walk_launch = [&](const Plan &P, const int32_t *d_list, int32_t count, hipStream_t ks, bool wave, int my_w) -> int {
+    int walk_launch(const Plan &P, const int32_t *d_list, int32_t count, hipStream_t ks, bool wave, int my_w) {
         vpr_launch_stat ws_;
         memset(&ws_, 0, sizeof(ws_));
         ws_.threads = 64; ws_.n_units = count; ws_.cells_per_thread = wave ? 1 : 0;
@@ -1181,28 +1199,9 @@ int vpr_execute(vpr_handle *h) {
                                    count, P.arena, a_i32, h->d_outs, a_path, h->d_secs, h->d_fp_table,
                                    h->d_jobs, h->d_njobs, h->jobs_cap, my_w, my_w);
         });
-    };
+    }
 
-    // ---- tie rounds only (pr_tie.hip): replay the reference's container order for the `cnt` alignments of plan P from
-    // work list position `off`.  early = true: the jobs of the alignments in tie_early (still resident in the workspace
-    // of the round that marked them), launched BEFORE their forward sweep is repeated -- they read that round's
-    // backward-sweep bytes, decide only the consulted ties and stop early; their decisions are applied by tie_patch once
-    // the flags exist again.  early = false: all other alignments of the part, behind the repeated forward sweep, patched
-    // in place.  tie_full: FIFO logs sized for the worst case (second attempt, after a capped job overflowed).
-    bool tie_full = false;
-    size_t tie_job_cur = 0;
-    int64_t n_tie_jobs = 0;
-    int tie_dec_slot = 0;                          // decision lists handed out in this execute
-    int64_t tie_dec_cur = 0;
-    struct TieEarly { int32_t n_used; int32_t pos; const Plan *plan; int mode; };   // mode 1 / 2: TieJob::mode; 3: decided speculatively
-    std::unordered_map<int32_t, TieEarly> tie_early;   // alignment -> where the bytes of its marking round are
-    std::unordered_map<int32_t, int32_t> tie_s;        // alignment -> its distance (from the tie lists): bounds the stamp grids
-    int tie_patch_slot = -1; int64_t tie_patch_off = 0, tie_patch_cap = 0;   // decision list of the last early launch
-    bool tie_patch_spec = false;                   // the part has alignments whose decisions are in the speculative list
-    int spec_slot = -1; int64_t spec_off = 0, spec_cap = 0;
-    std::unordered_map<int32_t, int> spec_set;     // alignments with a speculative replay in flight / done
-    LadderCtx *tie_ctx = &h->lad[2];               // the tie ladder whose round is being enqueued
-    auto tie_replay = [&](const Plan &P, int64_t off, int32_t cnt, hipStream_t ks_main, bool early) -> int {
+    int tie_replay(const Plan &P, int64_t off, int32_t cnt, hipStream_t ks_main, bool early) {
         if (early) { tie_patch_slot = -1; tie_patch_spec = false; }
         LadderCtx &tc = *tie_ctx;
         hipStream_t ks = early ? tc.ls2 : ks_main;
@@ -1259,11 +1258,14 @@ int vpr_execute(vpr_handle *h) {
             needs.push_back(N);
         }
         if (needs.empty()) return VPR_OK;
+        // largest first: a launch lasts as long as its largest job, so when the scratch forces sub-batches the big jobs
+        // should share theirs with each other, not spread over all of them
+        std::stable_sort(needs.begin(), needs.end(), [](const Need &x, const Need &y) { return x.cells > y.cells; });
         if (tie_job_cur + needs.size() > h->tie_jobs_cap) return fail(h, VPR_ERR_STATE, "tie round: job buffer overflow");
         size_t free_b = 0, total_b = 0;
         if (total * 4 > scratch_bytes) HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
         // (the block a launch outgrew is released first, so what it holds counts as free; a block already at the bound stays)
-        const int64_t nb_want = std::max<int64_t>(std::min<int64_t>(total * 4, int64_t((free_b + size_t(scratch_bytes)) / 4)), largest * 4) + 256;
+        const int64_t nb_want = std::max<int64_t>(std::min<int64_t>(total * 4, int64_t((free_b + size_t(scratch_bytes)) / 3)), largest * 4) + 256;
         if (total * 4 > scratch_bytes && nb_want > scratch_bytes + scratch_bytes / 8) {
             HIPCHK(h, hipStreamSynchronize(ks));
             if (scratch) (void)hipFree(scratch);
@@ -1344,9 +1346,10 @@ int vpr_execute(vpr_handle *h) {
         }
         if (early) { HIPCHK(h, hipEventRecord(tc.ev2, ks)); (void)hipStreamQuery(ks); }
         return VPR_OK;
-    };
+    }
+
     // apply the decisions of the part's early replays to the flags its repeated forward sweep has just written
-    auto tie_patch = [&](const Plan &P, hipStream_t ks, int tag) -> int {
+    int tie_patch(const Plan &P, hipStream_t ks, int tag) {
         if (tie_patch_slot >= 0) {
             HIPCHK(h, hipStreamWaitEvent(ks, tie_ctx->ev2, 0));     // the early replays ran on the side stream
             hipLaunchKernelGGL(k_tie_patch, blocks(tie_patch_cap), dim3(256), 0, ks, h->d_descs, h->d_tie_dec + tie_patch_off,
@@ -1360,12 +1363,12 @@ int vpr_execute(vpr_handle *h) {
             tie_patch_spec = false;
         }
         return VPR_OK;
-    };
+    }
 
     // ---- dense plan: per chunk, each kernel class runs K1 -> K2 -> K3 on its own stream (forked from and
     // joined into `base`); one_stream: everything on `base` (retry rounds that run beside other work)
     // tag_or: TIE_TAG_BIT when the plan belongs to a tie round (forward sweep, container-order replay, then the rest)
-    auto run_dense = [&](const Plan &P, const int32_t *d_work, hipStream_t base, bool one_stream, int tag_or = 0) -> int {
+    int run_dense(const Plan &P, const int32_t *d_work, hipStream_t base, bool one_stream, int tag_or = 0) {
         for (const Chunk &ch : P.chunks) {
             if (!one_stream) HIPCHK(h, hipEventRecord(h->ev_fork, base));
             for (const Launch &L : ch.launches) {
@@ -1423,16 +1426,16 @@ int vpr_execute(vpr_handle *h) {
             }
         }
         return VPR_OK;
-    };
+    }
 
     // ---- one launch sequence of a windowed plan: `cnt` alignments of the plan's work list from `off`, all at
     // level lv, on stream ks:  K1 -> accept test -> rejected ids appended to fail slot `slot` (event
     // ev_slot[slot] marks the list complete) -> K2 -> K3.  K2/K3 skip rejected alignments, so the host can
     // start their retry round while this sequence is still running.
-    auto enqueue_part = [&](const Plan &P, const int32_t *d_work, int64_t off, int32_t cnt, int lv, hipStream_t ks,
+    int enqueue_part(const Plan &P, const int32_t *d_work, int64_t off, int32_t cnt, int lv, hipStream_t ks,
                             int slot, int64_t fail_off, bool long_part, int64_t part_cells, int64_t part_in,
                             int64_t part_dense, int dtag_override = -1, int phases = 7,
-                            const int32_t *n_dev = nullptr, int32_t n_all = 0, int tag_or = 0) -> int {
+                            const int32_t *n_dev = nullptr, int32_t n_all = 0, int tag_or = 0) {
         // phases: 1 = forward sweep + accept test + fail list, 2 = backward sweep, 4 = walk + credit.
         // n_dev: device-side length of a device-built work list; cnt is then the cap of entries processed and
         // n_all the most entries the list can hold (the fail list scans all of them).
@@ -1534,10 +1537,10 @@ int vpr_execute(vpr_handle *h) {
             rc = walk_launch(P, list, cnt, ks, wave_walk, tag);
         }
         return rc;
-    };
+    }
 
     // read a fail slot once its list is complete (copies ride on stream `ls`, never the null stream)
-    auto read_fails = [&](int slot, int64_t fail_off, hipStream_t ls, std::vector<int32_t> &fails) -> int {
+    int read_fails(int slot, int64_t fail_off, hipStream_t ls, std::vector<int32_t> &fails) {
         HIPCHK(h, hipEventSynchronize(h->ev_slot[slot]));      // the list and its length are in pinned host memory by then
         const int32_t nf = h->hp_cnt[slot];
         if (nf > 0) {
@@ -1556,13 +1559,13 @@ int vpr_execute(vpr_handle *h) {
             }
         }
         return VPR_OK;
-    };
+    }
 
     // ---- retry ladders.  Every rejected alignment climbs one window level (16 -> 64 -> 256 -> 1024 -> dense)
     // until its exit test passes.  Two independent ladders (one fed by the long part of round 0, one by the
     // short part) each own a stream, a workspace, staging buffers and fail slots, so their rounds run beside
     // each other and beside the rest of round 0; the host only ever waits for a fail list it needs next.
-    auto lad_flush = [&](LadderCtx &c, std::vector<int32_t> &out) -> int {
+    int lad_flush(LadderCtx &c, std::vector<int32_t> &out) {
         for (const auto &pd : c.pending) {
             int rc = read_fails(pd.first, pd.second, c.ls, out);
             if (rc) return rc;
@@ -1571,28 +1574,30 @@ int vpr_execute(vpr_handle *h) {
         c.plans.clear();
         c.slot_cur = 0; c.fail_cur = 0; c.stage_cur = 0; c.arena_cur = 0;
         return VPR_OK;
-    };
-    // what a retry round's backward sweep leaves to a tie round: appended to the ladder's region of the tie list buffer and
-    // published, with the flag, behind every part (the host acts on the flag of the round's last part)
-    bool lad_tie_wait[2] = {false, false};
-    auto lad_tie_off = [&](int k) { return h->tie_list_cap / 2 + k * (h->tie_list_cap / 8 * 3); };
-    auto lad_tie_cap = [&](int k) { (void)k; return h->tie_list_cap / 8 * 3; };
-    auto ladder_collect = [&](int k, const int32_t *list, int32_t n, hipStream_t ks) {
+    }
+
+    int lad_tie_off(int k) { return h->tie_list_cap / 2 + k * (h->tie_list_cap / 8 * 3); }
+
+    int lad_tie_cap(int k) { (void)k; return h->tie_list_cap / 8 * 3; }
+
+    void ladder_collect(int k, const int32_t *list, int32_t n, hipStream_t ks) {
         hipLaunchKernelGGL(k_collect_ties_list, blocks(n), dim3(256), 0, ks, list, n, h->d_outs, h->d_tie_list + lad_tie_off(k),
                            h->d_tie_cnt + 5 + k, lad_tie_cap(k));
         hipLaunchKernelGGL(k_publish_ties, dim3(4), dim3(256), 0, ks, h->d_tie_list + lad_tie_off(k), h->d_tie_cnt + 5 + k,
                            h->hp_tie_list + lad_tie_off(k), h->hp_tie_cnt + 5 + k, lad_tie_cap(k));
         post_flag(9 + k, ks);
         lad_tie_wait[k] = true;
-    };
+    }
+
     // a ladder that plans from the front of its workspace again overwrites the walks of its earlier rounds:
     // vpr_download_path then reports "not resident" instead of reading what replaced them
-    auto drop_resident = [&](const LadderCtx &c) {
+    void drop_resident(const LadderCtx &c) {
         for (auto &r : h->resident)
             if (r.second >= c.arena && r.second < c.arena + c.arena_bytes) r.second = nullptr;
-    };
+    }
+
     // tie: the tie pass -- same level again, with the container-order replay between the forward and the backward sweep
-    auto lad_start = [&](LadderCtx &c, std::vector<int32_t> &fails, std::vector<int32_t> &carry, bool tie = false) -> int {
+    int lad_start(LadderCtx &c, std::vector<int32_t> &fails, std::vector<int32_t> &carry, bool tie = false) {
         if (fails.empty()) return VPR_OK;
         if (!tie) n_retry += int64_t(fails.size());
         std::sort(fails.begin(), fails.end());   // deterministic planning
@@ -1728,22 +1733,11 @@ int vpr_execute(vpr_handle *h) {
         post_flag(4 + int(&c - h->lad), c.ls);
         (void)hipStreamQuery(c.ls);     // flush
         return VPR_OK;
-    };
-
-    // ---- a tie round: the alignments of `lst` ({id, level tag}, marked by a backward sweep) are planned again at the level
-    // that accepted them (descriptors tagged TIE_TAG_BIT, fresh workspace slots in the tie ladder's workspace) and run
-    // forward sweep -> container-order replay -> backward sweep -> walk + credit on the tie stream
-    for (int k = 0; k < 2; k++) {     // tie ladder k: rounds of the long / short part of round 0 (the final pass uses 0)
-        LadderCtx &c = h->lad[2 + k];
-        c.ls = h->tie_stream[2 * k]; c.ls2 = h->tie_stream[2 * k + 1]; c.ev2 = h->ev_tie2[k];
-        c.slot0 = 2 + (2 + k) * LadderCtx::N_SLOTS;
-        c.fail_base = (2 + k) * int64_t(h->descs.size()) + int64_t(h->descs.size()) / 16 + 256;
     }
-    std::vector<std::pair<TieJob *, size_t>> tie_job_blocks;   // (debug) the job blocks of this execute
-    size_t tie_job_total = 0;
+
     // resident: the chunk of plan0 whose workspace is still intact (early rounds), or nullptr.  An alignment that was
     // accepted where plan0 placed it (also by the in-place 16-cell round) is replayed early, from that workspace.
-    auto tie_round = [&](LadderCtx &LT, const int4 *lst_in, int32_t n, bool full, const Chunk *resident) -> int {
+    int tie_round(LadderCtx &LT, const int4 *lst_in, int32_t n, bool full, const Chunk *resident) {
         tie_ctx = &LT;
         std::vector<int4> lst(lst_in, lst_in + n);
         std::sort(lst.begin(), lst.end(), [](const int4 &x, const int4 &y) { return x.x < y.x; });   // deterministic planning
@@ -1781,89 +1775,73 @@ int vpr_execute(vpr_handle *h) {
         tie_job_blocks.emplace_back(h->hp_tie_jobs + j0, tie_job_cur - j0);
         tie_job_total += tie_job_cur - j0;
         return VPR_OK;
-    };
-    auto tie_flush = [&](LadderCtx &LT) -> int {
+    }
+
+    int tie_flush(LadderCtx &LT) {
         std::vector<int32_t> rejected;
         int rc_ = lad_flush(LT, rejected);
         if (rc_) return rc_;
         if (!rejected.empty()) return fail(h, VPR_ERR_STATE, "tie round: the re-run forward sweep rejected alignment %d", rejected[0]);
         return VPR_OK;
-    };
+    }
 
-    int rc = VPR_OK;
-    h->resident.clear();
-    h->level = h->level0;
-    if (h->cfg.band_mode == 0) {
-        if ((rc = run_dense(h->plan0, h->plan0.d_work, st, false))) return rc;
-        if (!h->plan0.chunks.empty()) {
-            const Chunk &c = h->plan0.chunks.back();
-            h->resident.emplace_back(std::vector<int32_t>(h->plan0.work.begin() + c.work_off,
-                                                          h->plan0.work.begin() + c.work_off + c.count), h->plan0.arena);
+    int spec_round(const int4 *lst, int32_t n) {
+        LadderCtx &LT = h->lad[2];
+        tie_ctx = &LT;
+        spec_plan = Plan();
+        spec_plan.arena = P0.arena;
+        tie_early.clear();
+        for (int32_t k = 0; k < n; k++) {
+            const int32_t a = lst[k].x;
+            tie_s[a] = lst[k].w;
+            spec_plan.work.push_back(a);
+            spec_plan.descs.push_back(h->descs[size_t(a)]);
+            tie_early[a] = TieEarly{0, h->plan0_pos[size_t(a)], &h->plan0, 2};
         }
-    } else {
+        if (h->tie_jobs_cap < tie_job_cur + size_t(n)) {
+            void *pj = nullptr;
+            HIPCHK(h, hipHostMalloc(&pj, size_t(n) * 4 * sizeof(TieJob), hipHostMallocDefault));
+            h->pinned.push_back(pj);
+            h->hp_tie_jobs = static_cast<TieJob *>(pj);
+            h->tie_jobs_cap = size_t(n) * 4;
+            tie_job_cur = 0;
+        }
+        const size_t j0 = tie_job_cur;
+        tie_full = false;
+        if (h->debug) fprintf(stderr, "[vpr] speculative replays: %d long alignments\n", n);
+        int rc_ = tie_replay(spec_plan, 0, n, LT.ls, true);
+        if (rc_) return rc_;
+        spec_slot = tie_patch_slot; spec_off = tie_patch_off; spec_cap = tie_patch_cap;
+        tie_patch_slot = -1;
+        HIPCHK(h, hipEventRecord(h->ev_spec, LT.ls2));
+        (void)hipStreamQuery(LT.ls2);
+        for (int32_t k = 0; k < n; k++) spec_set[lst[k].x] = 1;
+        tie_early.clear();
+        tie_job_blocks.emplace_back(h->hp_tie_jobs + j0, tie_job_cur - j0);
+        tie_job_total += tie_job_cur - j0;
+        return VPR_OK;
+    }
+
+    // part k's alignments left to a tie round -> pinned host memory; ev_tie[k] marks the list complete
+    int collect_part(int k, const int32_t *list, int32_t n, hipStream_t ks) {
+        hipLaunchKernelGGL(k_collect_ties_list, blocks(n), dim3(256), 0, ks, list, n, h->d_outs, h->d_tie_list + tie_off[k],
+                           h->d_tie_cnt + 2 + k, tie_cap[k]);
+        hipLaunchKernelGGL(k_publish_ties, dim3(4), dim3(256), 0, ks, h->d_tie_list + tie_off[k], h->d_tie_cnt + 2 + k,
+                           h->hp_tie_list + tie_off[k], h->hp_tie_cnt + 2 + k, tie_cap[k]);
+        post_flag(2 + k, ks);
+        return VPR_OK;
+    }
+
+    // ---- round 0 of a windowed plan and everything that runs beside it
+    int round0_windowed() {
+        int rc = VPR_OK;
         // Per chunk of the round-0 plan: the short alignments (a throughput problem) and the long ones (latency
         // chains: rows are sequential) run on two streams; the ids rejected by the exit test are known right
         // after each forward sweep, and their retry ladders run beside the rest of the round; the alignments whose
         // backward sweep met a tied swap cell are known right after that sweep, and their tie rounds run beside it too.
-        const Plan &P0 = h->plan0;
-        const int64_t na_ = int64_t(h->descs.size());
-        hipStream_t s_long = h->cls_stream[0], s_short = h->cls_stream[1];
-        LadderCtx &LL = h->lad[0], &LS = h->lad[1];
         // HIP maps streams onto 4 hardware queues: round 0 uses two, the ladders and the tie rounds share the others
         LL.ls = h->cls_stream[2]; LS.ls = h->cls_stream[3];
         LL.slot0 = 2; LS.slot0 = 2 + LadderCtx::N_SLOTS;
-        // regions of the tie list buffer: long part's marks, short part's marks, long part's speculative candidates
-        const int32_t tie_cap[3] = {h->tie_list_cap / 8, h->tie_list_cap / 4, h->tie_list_cap / 8};      // (the retry ladders' regions follow)
-        const int32_t tie_off[3] = {0, h->tie_list_cap / 4, h->tie_list_cap / 8};
-        // speculative replays (pr_tie.hip, mode 2) of the long alignments whose forward sweep met a tied cell within their
-        // distance: launched as soon as that sweep is done, so that the slowest part of a long alignment's tie round is
-        // under way long before its backward sweep says whether a tie is consulted at all
-        Plan spec_plan;
-        auto spec_round = [&](const int4 *lst, int32_t n) -> int {
-            LadderCtx &LT = h->lad[2];
-            tie_ctx = &LT;
-            spec_plan = Plan();
-            spec_plan.arena = P0.arena;
-            tie_early.clear();
-            for (int32_t k = 0; k < n; k++) {
-                const int32_t a = lst[k].x;
-                tie_s[a] = lst[k].w;
-                spec_plan.work.push_back(a);
-                spec_plan.descs.push_back(h->descs[size_t(a)]);
-                tie_early[a] = TieEarly{0, h->plan0_pos[size_t(a)], &h->plan0, 2};
-            }
-            if (h->tie_jobs_cap < tie_job_cur + size_t(n)) {
-                void *pj = nullptr;
-                HIPCHK(h, hipHostMalloc(&pj, size_t(n) * 4 * sizeof(TieJob), hipHostMallocDefault));
-                h->pinned.push_back(pj);
-                h->hp_tie_jobs = static_cast<TieJob *>(pj);
-                h->tie_jobs_cap = size_t(n) * 4;
-                tie_job_cur = 0;
-            }
-            const size_t j0 = tie_job_cur;
-            tie_full = false;
-            if (h->debug) fprintf(stderr, "[vpr] speculative replays: %d long alignments\n", n);
-            int rc_ = tie_replay(spec_plan, 0, n, LT.ls, true);
-            if (rc_) return rc_;
-            spec_slot = tie_patch_slot; spec_off = tie_patch_off; spec_cap = tie_patch_cap;
-            tie_patch_slot = -1;
-            HIPCHK(h, hipEventRecord(h->ev_spec, LT.ls2));
-            (void)hipStreamQuery(LT.ls2);
-            for (int32_t k = 0; k < n; k++) spec_set[lst[k].x] = 1;
-            tie_early.clear();
-            tie_job_blocks.emplace_back(h->hp_tie_jobs + j0, tie_job_cur - j0);
-            tie_job_total += tie_job_cur - j0;
-            return VPR_OK;
-        };
-        // part k's alignments left to a tie round -> pinned host memory; ev_tie[k] marks the list complete
-        auto collect_part = [&](int k, const int32_t *list, int32_t n, hipStream_t ks) -> int {
-            hipLaunchKernelGGL(k_collect_ties_list, blocks(n), dim3(256), 0, ks, list, n, h->d_outs, h->d_tie_list + tie_off[k],
-                               h->d_tie_cnt + 2 + k, tie_cap[k]);
-            hipLaunchKernelGGL(k_publish_ties, dim3(4), dim3(256), 0, ks, h->d_tie_list + tie_off[k], h->d_tie_cnt + 2 + k,
-                               h->hp_tie_list + tie_off[k], h->hp_tie_cnt + 2 + k, tie_cap[k]);
-            post_flag(2 + k, ks);
-            return VPR_OK;
-        };
         for (size_t ci = 0; ci < P0.chunks.size(); ci++) {
             const Chunk &ch = P0.chunks[ci];
             const int32_t n_long = ch.n_long;
@@ -2020,147 +1998,231 @@ int vpr_execute(vpr_handle *h) {
                 h->resident.emplace(h->resident.begin(), std::vector<int32_t>(P0.work.begin() + ch.work_off,
                                                                               P0.work.begin() + ch.work_off + ch.count), P0.arena);
         }
+        return VPR_OK;
     }
 
-    // ---- final tie pass: whatever is still marked (ties met by the retry ladders' rounds, lists that outgrew their
-    // buffer, replays whose capped FIFO logs overflowed: those get worst-case logs now)
-    {
-        const int na = int(h->descs.size());
-        for (int iter = 0; na > 0; iter++) {
-            HIPCHK(h, hipMemsetAsync(h->d_tie_cnt, 0, 8, st));
-            hipLaunchKernelGGL(k_collect_ties, blocks(na), dim3(256), 0, st, h->d_outs, na, h->d_tie_list, h->d_tie_cnt, h->tie_list_cap);
-            int32_t n_mark = 0;
-            HIPCHK(h, hipMemcpyAsync(&n_mark, h->d_tie_cnt, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(h, hipStreamSynchronize(st));
-            if (n_mark == 0) break;
-            if (iter >= 3) return fail(h, VPR_ERR_STATE, "tie pass: %d alignments still marked after %d attempts", n_mark, iter);
-            const int32_t n = std::min(n_mark, h->tie_list_cap);
-            std::vector<int4> lst;
-            lst.resize(size_t(n));
-            HIPCHK(h, hipMemcpy(lst.data(), h->d_tie_list, size_t(n) * sizeof(int4), hipMemcpyDeviceToHost));
-            if (h->debug) fprintf(stderr, "[vpr] final tie pass %d: %d alignments marked\n", iter, n_mark);
-            if ((rc = tie_round(h->lad[2], lst.data(), n, iter > 0, nullptr))) return rc;
-            if ((rc = tie_flush(h->lad[2]))) return rc;
-            HIPCHK(h, hipStreamSynchronize(h->lad[2].ls));
-        }
-    }
-    if (h->debug && tie_job_total > 0) {   // the slowest replays of the execute
-        std::vector<TieJob> js;
-        for (const auto &blk : tie_job_blocks) js.insert(js.end(), blk.first, blk.first + blk.second);
-        std::sort(js.begin(), js.end(), [](const TieJob &x, const TieJob &y) { return x.dbg_us > y.dbg_us; });
-        int64_t tot_us = 0;
-        for (const TieJob &J : js) tot_us += J.dbg_us;
-        size_t nf1 = 0, nf2 = 0;
-        for (const TieJob &J : js) { nf1 += J.pad == 1; nf2 += J.pad == 2; }
-        fprintf(stderr, "[vpr] tie replay: %zu jobs, %.1f ms summed; gave up: %zu (logs), %zu (stamp grid)\n", js.size(), tot_us / 1000.0, nf1, nf2);
-        for (const TieJob &J : js)
-            if (J.pad == 2 && nf2-- < 4) {
-                const AlnDesc &d = h->descs[size_t(J.a)];
-                fprintf(stderr, "[vpr]   grid too small: sc %d aln %d Lq %d Lr %d Lt %d, diagonals [%d, +%d) [%d, +%d), spans q (%d, %d) t (%d, %d)\n", d.sc, d.aln, d.Lq, d.Lr, d.Lt,
-                        J.dlo[0], J.dn[0], J.dlo[1], J.dn[1], h->hp_dspan[d.qs][d.sc].x, h->hp_dspan[d.qs][d.sc].y, h->hp_dspan[d.ts][d.sc].x, h->hp_dspan[d.ts][d.sc].y);
-                fprintf(stderr, "[vpr]     first cell outside: plane %d position %d row %d (wave %d), mode %d\n", J.dbg_oob[0], J.dbg_oob[1], J.dbg_oob[2], J.dbg_oob[3], J.mode);
+    int final_tie_pass() {
+        int rc = VPR_OK;
+        // ---- final tie pass: whatever is still marked (ties met by the retry ladders' rounds, lists that outgrew their
+        // buffer, replays whose capped FIFO logs overflowed: those get worst-case logs now)
+        {
+            const int na = int(h->descs.size());
+            for (int iter = 0; na > 0; iter++) {
+                HIPCHK(h, hipMemsetAsync(h->d_tie_cnt, 0, 8, st));
+                hipLaunchKernelGGL(k_collect_ties, blocks(na), dim3(256), 0, st, h->d_outs, na, h->d_tie_list, h->d_tie_cnt, h->tie_list_cap);
+                int32_t n_mark = 0;
+                HIPCHK(h, hipMemcpyAsync(&n_mark, h->d_tie_cnt, 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(h, hipStreamSynchronize(st));
+                if (n_mark == 0) break;
+                if (iter >= 3) return fail(h, VPR_ERR_STATE, "tie pass: %d alignments still marked after %d attempts", n_mark, iter);
+                const int32_t n = std::min(n_mark, h->tie_list_cap);
+                std::vector<int4> lst;
+                lst.resize(size_t(n));
+                HIPCHK(h, hipMemcpy(lst.data(), h->d_tie_list, size_t(n) * sizeof(int4), hipMemcpyDeviceToHost));
+                if (h->debug) fprintf(stderr, "[vpr] final tie pass %d: %d alignments marked\n", iter, n_mark);
+                if ((rc = tie_round(h->lad[2], lst.data(), n, iter > 0, nullptr))) return rc;
+                if ((rc = tie_flush(h->lad[2]))) return rc;
+                HIPCHK(h, hipStreamSynchronize(h->lad[2].ls));
             }
-        for (size_t k = 0; k < js.size() && k < 8; k++) {
-            const AlnDesc &d = h->descs[size_t(js[k].a)];
-            fprintf(stderr, "[vpr]   sc %d aln %d Lq %d Lr %d Lt %d level %d: %d us, %d waves, %d BFS steps, %d cells; mode %d, consulted %d, decided %d (last in wave %d)\n", d.sc, d.aln,
-                    d.Lq, d.Lr, d.Lt, int(h->level[size_t(js[k].a)]), js[k].dbg_us, js[k].dbg_waves, js[k].dbg_steps, js[k].dbg_cells,
-                    js[k].mode, js[k].n_used, js[k].dbg_nres, js[k].dbg_lastw);
-            fprintf(stderr, "[vpr]     us: BFS %d, patch %d, order A %d B %d suffix %d C %d, seeding %d, setup %d\n", js[k].dbg_t[0], js[k].dbg_t[1],
-                    js[k].dbg_t[2], js[k].dbg_t[3], js[k].dbg_t[4], js[k].dbg_t[5], js[k].dbg_t[6], js[k].dbg_t[7]);
+        }
+        return rc;
+    }
+
+    void debug_replays() {
+        if (h->debug && tie_job_total > 0) {   // the slowest replays of the execute
+            std::vector<TieJob> js;
+            for (const auto &blk : tie_job_blocks) js.insert(js.end(), blk.first, blk.first + blk.second);
+            std::sort(js.begin(), js.end(), [](const TieJob &x, const TieJob &y) { return x.dbg_us > y.dbg_us; });
+            int64_t tot_us = 0;
+            for (const TieJob &J : js) tot_us += J.dbg_us;
+            size_t nf1 = 0, nf2 = 0;
+            for (const TieJob &J : js) { nf1 += J.pad == 1; nf2 += J.pad == 2; }
+            fprintf(stderr, "[vpr] tie replay: %zu jobs, %.1f ms summed; gave up: %zu (logs), %zu (stamp grid)\n", js.size(), tot_us / 1000.0, nf1, nf2);
+            for (const TieJob &J : js)
+                if (J.pad == 2 && nf2-- < 4) {
+                    const AlnDesc &d = h->descs[size_t(J.a)];
+                    fprintf(stderr, "[vpr]   grid too small: sc %d aln %d Lq %d Lr %d Lt %d, diagonals [%d, +%d) [%d, +%d), spans q (%d, %d) t (%d, %d)\n", d.sc, d.aln, d.Lq, d.Lr, d.Lt,
+                            J.dlo[0], J.dn[0], J.dlo[1], J.dn[1], h->hp_dspan[d.qs][d.sc].x, h->hp_dspan[d.qs][d.sc].y, h->hp_dspan[d.ts][d.sc].x, h->hp_dspan[d.ts][d.sc].y);
+                    fprintf(stderr, "[vpr]     first cell outside: plane %d position %d row %d (wave %d), mode %d\n", J.dbg_oob[0], J.dbg_oob[1], J.dbg_oob[2], J.dbg_oob[3], J.mode);
+                }
+            for (size_t k = 0; k < js.size() && k < 8; k++) {
+                const AlnDesc &d = h->descs[size_t(js[k].a)];
+                fprintf(stderr, "[vpr]   sc %d aln %d Lq %d Lr %d Lt %d level %d: %d us, %d waves, %d BFS steps, %d cells; mode %d, consulted %d, decided %d (last in wave %d)\n", d.sc, d.aln,
+                        d.Lq, d.Lr, d.Lt, int(h->level[size_t(js[k].a)]), js[k].dbg_us, js[k].dbg_waves, js[k].dbg_steps, js[k].dbg_cells,
+                        js[k].mode, js[k].n_used, js[k].dbg_nres, js[k].dbg_lastw);
+                fprintf(stderr, "[vpr]     us: BFS %d, patch %d, order A %d B %d suffix %d C %d, seeding %d, setup %d\n", js[k].dbg_t[0], js[k].dbg_t[1],
+                        js[k].dbg_t[2], js[k].dbg_t[3], js[k].dbg_t[4], js[k].dbg_t[5], js[k].dbg_t[6], js[k].dbg_t[7]);
+            }
         }
     }
 
-    lapx("final tie pass done");
     // K4: deferred section edit distances
-    int32_t n_jobs = 0;
-    HIPCHK(h, hipMemcpyAsync(&n_jobs, h->d_njobs, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    n_jobs = std::min(n_jobs, h->jobs_cap);
-    if (n_jobs > 0) {
-        std::vector<EdJob> jobs(n_jobs);
-        HIPCHK(h, hipMemcpy(jobs.data(), h->d_jobs, size_t(n_jobs) * sizeof(EdJob), hipMemcpyDeviceToHost));
-        int64_t stride = 0, max_short = 0, max_sum = 0;
-        for (const EdJob &j : jobs) {
-            stride = std::max<int64_t>(stride, std::max(j.ref_len, j.tru_len) + 1);
-            max_short = std::max<int64_t>(max_short, std::min(j.ref_len, j.tru_len));
-            max_sum = std::max<int64_t>(max_sum, int64_t(j.ref_len) + j.tru_len);
+    int deferred_edit_distances() {
+        int rc = VPR_OK;
+        // K4: deferred section edit distances
+        int32_t n_jobs = 0;
+        HIPCHK(h, hipMemcpyAsync(&n_jobs, h->d_njobs, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        n_jobs = std::min(n_jobs, h->jobs_cap);
+        if (n_jobs > 0) {
+            std::vector<EdJob> jobs(n_jobs);
+            HIPCHK(h, hipMemcpy(jobs.data(), h->d_jobs, size_t(n_jobs) * sizeof(EdJob), hipMemcpyDeviceToHost));
+            int64_t stride = 0, max_short = 0, max_sum = 0;
+            for (const EdJob &j : jobs) {
+                stride = std::max<int64_t>(stride, std::max(j.ref_len, j.tru_len) + 1);
+                max_short = std::max<int64_t>(max_short, std::min(j.ref_len, j.tru_len));
+                max_sum = std::max<int64_t>(max_sum, int64_t(j.ref_len) + j.tru_len);
+            }
+            // anti-diagonal kernel when the largest section fits LDS and 16-bit distances (VPR_ED_ROWS: the row-sweep one)
+            const int64_t pitch = (max_short + 2 + 7) & ~int64_t(7);
+            const size_t lds_diag = size_t(3 * pitch * 2 + max_sum + 16);
+            if (lds_diag <= 150 * 1024 && max_sum < 65000) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ed_diag), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_diag));
+                vpr_launch_stat es_;
+                memset(&es_, 0, sizeof(es_));
+                es_.threads = ED_NT; es_.n_units = n_jobs;
+                rc = timed(4, es_, st, "k_ed_diag", [&] {
+                    hipLaunchKernelGGL(k_ed_diag, dim3(n_jobs), dim3(ED_NT), lds_diag, st, h->dB, h->d_descs, h->d_jobs, n_jobs,
+                                       h->d_secs, int(max_short));
+                });
+                if (rc) return rc;
+            } else {
+            stride = round_up(stride, 16);
+            const int64_t max_ints = int64_t(1) << 28;   // 1 GiB of scratch per slice
+            const int32_t per = int32_t(std::max<int64_t>(1, std::min<int64_t>(n_jobs, max_ints / stride)));
+            if (h->ed_scratch_ints < size_t(per * stride)) {
+                int32_t *p;
+                if ((rc = dev_alloc(h, &p, size_t(per * stride)))) return rc;
+                h->d_ed_scratch = p;
+                h->ed_scratch_ints = size_t(per * stride);
+            }
+            for (int32_t j0 = 0; j0 < n_jobs; j0 += per) {
+                const int32_t cnt = std::min(per, n_jobs - j0);
+                vpr_launch_stat es_;
+                memset(&es_, 0, sizeof(es_));
+                es_.threads = 64; es_.n_units = cnt;
+                rc = timed(4, es_, st, "k_ed", [&] {
+                    hipLaunchKernelGGL(k_ed, dim3(cnt), dim3(64), 0, st, h->dB, h->d_descs, h->d_jobs + j0, cnt,
+                                       h->d_secs, h->d_ed_scratch, stride);
+                });
+                if (rc) return rc;
+            }
+            }
         }
-        // anti-diagonal kernel when the largest section fits LDS and 16-bit distances (VPR_ED_ROWS: the row-sweep one)
-        const int64_t pitch = (max_short + 2 + 7) & ~int64_t(7);
-        const size_t lds_diag = size_t(3 * pitch * 2 + max_sum + 16);
-        if (lds_diag <= 150 * 1024 && max_sum < 65000) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ed_diag), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_diag));
-            vpr_launch_stat es_;
-            memset(&es_, 0, sizeof(es_));
-            es_.threads = ED_NT; es_.n_units = n_jobs;
-            rc = timed(4, es_, st, "k_ed_diag", [&] {
-                hipLaunchKernelGGL(k_ed_diag, dim3(n_jobs), dim3(ED_NT), lds_diag, st, h->dB, h->d_descs, h->d_jobs, n_jobs,
-                                   h->d_secs, int(max_short));
+        return rc;
+    }
+
+    // K5 (per-variant results, phase, tally) and the call's timing record
+    int finish() {
+        int rc = VPR_OK;
+        // K5: per-variant results, phase, tally
+        {
+            const int na = int(h->descs.size());
+            vpr_launch_stat fs_;
+            memset(&fs_, 0, sizeof(fs_));
+            fs_.threads = 128; fs_.n_units = na;
+            rc = timed(5, fs_, st, "k_finalize+k_phase_tally", [&] {
+                if (na) hipLaunchKernelGGL(k_finalize, dim3((na + 127) / 128), dim3(128), 0, st, h->d_descs, na, h->d_outs,
+                                           h->d_secs, h->d_fp_table, h->dR);
+                if (h->n_sc) hipLaunchKernelGGL(k_phase_tally, dim3((h->n_sc + 127) / 128), dim3(128), 0, st, h->d_descs,
+                                                h->n_sc, h->dR);
             });
             if (rc) return rc;
-        } else {
-        stride = round_up(stride, 16);
-        const int64_t max_ints = int64_t(1) << 28;   // 1 GiB of scratch per slice
-        const int32_t per = int32_t(std::max<int64_t>(1, std::min<int64_t>(n_jobs, max_ints / stride)));
-        if (h->ed_scratch_ints < size_t(per * stride)) {
-            int32_t *p;
-            if ((rc = dev_alloc(h, &p, size_t(per * stride)))) return rc;
-            h->d_ed_scratch = p;
-            h->ed_scratch_ints = size_t(per * stride);
         }
-        for (int32_t j0 = 0; j0 < n_jobs; j0 += per) {
-            const int32_t cnt = std::min(per, n_jobs - j0);
-            vpr_launch_stat es_;
-            memset(&es_, 0, sizeof(es_));
-            es_.threads = 64; es_.n_units = cnt;
-            rc = timed(4, es_, st, "k_ed", [&] {
-                hipLaunchKernelGGL(k_ed, dim3(cnt), dim3(64), 0, st, h->dB, h->d_descs, h->d_jobs + j0, cnt,
-                                   h->d_secs, h->d_ed_scratch, stride);
-            });
-            if (rc) return rc;
+        HIPCHK(h, hipEventRecord(t1, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        lapx("done");
+        HIPCHK(h, hipGetLastError());
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, t0, t1);
+        h->timing.ms_total = ms;
+        h->timing.ms_fwd = h->timing.ms_bwd = h->timing.ms_walk = h->timing.ms_ed = h->timing.ms_tie = 0;
+        for (auto &e : h->events) {
+            float m = 0;
+            (void)hipEventElapsedTime(&m, e.a, e.b);
+            e.st.ms = m;
+            if (e.kind == 1) h->timing.ms_fwd += m;
+            else if (e.kind == 2) h->timing.ms_bwd += m;
+            else if (e.kind == 3) h->timing.ms_walk += m;
+            else if (e.kind == 4) h->timing.ms_ed += m;
+            else if (e.kind == 6) h->timing.ms_tie += m;
         }
+        h->timing.n_fwd_launches = n_fwd;
+        h->timing.cells_touched = cells_touched;
+        h->timing.n_band_retries = n_retry;
+        h->timing.n_tie_replays = n_tie_jobs;
+        return VPR_OK;
+    }
+
+    int run() {
+        HIPCHK(h, hipSetDevice(h->cfg.device));
+        h->events.clear();
+        h->ev_used = 0;
+        {
+            InitArgs IA;
+            IA.outs = h->d_outs; IA.na = int64_t(h->descs.size());
+            int64_t top = std::max<int64_t>(IA.na, 8);
+            for (int q = 0; q < 4; q++) {
+                IA.fp[q] = h->d_fp[q]; IA.n_fp[q] = h->n_var[q >> 1];
+                IA.n_var[q] = h->n_var[q];
+                for (int w = 0; w < 2; w++) IA.v[q][w] = h->dR.v[q][w];
+                top = std::max(top, std::max(IA.n_fp[q], IA.n_var[q]));
+            }
+            IA.tally = h->dR.tally; IA.njobs = h->d_njobs; IA.cnt = h->d_cnt; IA.n_cnt = 2;
+            hipLaunchKernelGGL(k_init_execute, blocks(top), dim3(256), 0, st, IA);
         }
+        if (!h->dirty.empty()) {   // restore the round-0 descriptors a previous execute's retry rounds replaced
+            hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(h->descs.size())), dim3(256), 0, st, h->plan0.d_descs,
+                               int(h->descs.size()), h->d_descs);
+            h->dirty.clear();
+        }
+        // (measured: without one blocking call here the runtime does not start this call's submissions for 0.1 - 2 s when the
+        // host goes straight to polling memory below, e.g. right behind another library's work on the device)
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        wall0 = std::chrono::steady_clock::now();
+        HIPCHK(h, hipEventCreate(&t0));
+        HIPCHK(h, hipEventCreate(&t1));
+        HIPCHK(h, hipEventRecord(t0, st));
+        for (int k = 0; k < 2; k++) {     // tie ladder k: rounds of the long / short part of round 0 (the final pass uses 0)
+            LadderCtx &c = h->lad[2 + k];
+            c.ls = h->tie_stream[2 * k]; c.ls2 = h->tie_stream[2 * k + 1]; c.ev2 = h->ev_tie2[k];
+            c.slot0 = 2 + (2 + k) * LadderCtx::N_SLOTS;
+            c.fail_base = (2 + k) * int64_t(h->descs.size()) + int64_t(h->descs.size()) / 16 + 256;
+        }
+        int rc = VPR_OK;
+        h->resident.clear();
+        h->level = h->level0;
+        if (h->cfg.band_mode == 0) {
+            if ((rc = run_dense(h->plan0, h->plan0.d_work, st, false))) return rc;
+            if (!h->plan0.chunks.empty()) {
+                const Chunk &c = h->plan0.chunks.back();
+                h->resident.emplace_back(std::vector<int32_t>(h->plan0.work.begin() + c.work_off,
+                                                              h->plan0.work.begin() + c.work_off + c.count), h->plan0.arena);
+            }
+        } else if ((rc = round0_windowed())) {
+            return rc;
+        }
+        if ((rc = final_tie_pass())) return rc;
+        debug_replays();
+        lapx("final tie pass done");
+        if ((rc = deferred_edit_distances())) return rc;
+        return finish();
     }
-    // K5: per-variant results, phase, tally
-    {
-        const int na = int(h->descs.size());
-        vpr_launch_stat fs_;
-        memset(&fs_, 0, sizeof(fs_));
-        fs_.threads = 128; fs_.n_units = na;
-        rc = timed(5, fs_, st, "k_finalize+k_phase_tally", [&] {
-            if (na) hipLaunchKernelGGL(k_finalize, dim3((na + 127) / 128), dim3(128), 0, st, h->d_descs, na, h->d_outs,
-                                       h->d_secs, h->d_fp_table, h->dR);
-            if (h->n_sc) hipLaunchKernelGGL(k_phase_tally, dim3((h->n_sc + 127) / 128), dim3(128), 0, st, h->d_descs,
-                                            h->n_sc, h->dR);
-        });
-        if (rc) return rc;
-    }
-    HIPCHK(h, hipEventRecord(t1, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    lapx("done");
-    HIPCHK(h, hipGetLastError());
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, t0, t1);
-    h->timing.ms_total = ms;
-    h->timing.ms_fwd = h->timing.ms_bwd = h->timing.ms_walk = h->timing.ms_ed = h->timing.ms_tie = 0;
-    for (auto &e : h->events) {
-        float m = 0;
-        (void)hipEventElapsedTime(&m, e.a, e.b);
-        e.st.ms = m;
-        if (e.kind == 1) h->timing.ms_fwd += m;
-        else if (e.kind == 2) h->timing.ms_bwd += m;
-        else if (e.kind == 3) h->timing.ms_walk += m;
-        else if (e.kind == 4) h->timing.ms_ed += m;
-        else if (e.kind == 6) h->timing.ms_tie += m;
-    }
-    h->timing.n_fwd_launches = n_fwd;
-    h->timing.cells_touched = cells_touched;
-    h->timing.n_band_retries = n_retry;
-    h->timing.n_tie_replays = n_tie_jobs;
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
-    h->executed = true;
-    return VPR_OK;
+};
+
+}  // namespace
+
+extern "C" {
+
+int vpr_execute(vpr_handle *h) {
+    if (!h) return VPR_ERR_ARG;
+    if (!h->uploaded) return fail(h, VPR_ERR_STATE, "vpr_execute before vpr_upload");
+    Exec x(h);
+    const int rc = x.run();
+    if (x.t0) (void)hipEventDestroy(x.t0);
+    if (x.t1) (void)hipEventDestroy(x.t1);
+    if (rc == VPR_OK) h->executed = true;
+    return rc;
 }
 
 int vpr_get_launch_stats(const vpr_handle *h, vpr_launch_stat *out, int32_t cap) {
