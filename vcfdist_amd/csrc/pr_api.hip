@@ -1335,9 +1335,9 @@ struct Exec {
             tc.tie_clean[se] = 0;
             vpr_launch_stat ts_;
             memset(&ts_, 0, sizeof(ts_));
-            ts_.threads = 64; ts_.n_units = nj; ts_.cells_per_thread = early ? 1 : 0;
+            ts_.threads = TIE_NT; ts_.n_units = nj; ts_.cells_per_thread = early ? 1 : 0;
             int rc = timed(6, ts_, ks, early ? "k_tie_replay<early>" : "k_tie_replay", [&] {
-                hipLaunchKernelGGL(k_tie_replay, dim3(nj), dim3(64), 0, ks, h->dB, h->d_descs, jobs, nj, P.arena,
+                hipLaunchKernelGGL(k_tie_replay, dim3(nj), dim3(TIE_NT), 0, ks, h->dB, h->d_descs, jobs, nj, P.arena,
                                    reinterpret_cast<const int32_t *>(P.arena), h->d_outs, scratch, h->d_tie_cnt + 1,
                                    dec, n_dec, int(dec_cap));
             });

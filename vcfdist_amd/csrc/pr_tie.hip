@@ -10,9 +10,9 @@
 // cell by cell and rewrites the choice field of every tied cell with the predecessor the reference keeps; the
 // backward sweep, walk and credit then run on the corrected flags.
 //
-// One wavefront per alignment.  What is replayed, exactly:
-//   * BFS of a wave (dist.cpp:317-381): the FIFO is a log in HBM; up to 64 entries are popped per step, lane l
-//     expands entry l (MAT child, then SWP child, as the reference pushes them).  "not done and not in curr_wave"
+// One workgroup (TIE_NW waves) per alignment.  What is replayed, exactly:
+//   * BFS of a wave (dist.cpp:317-381): the FIFO is a log in HBM; up to TIE_U x TIE_NT entries are popped per step, thread e
+//     expands entry e (MAT child, then SWP child, as the reference pushes them).  "not done and not in curr_wave"
 //     == "never pushed before": every candidate push carries a running candidate id, an atomicMin on the cell's
 //     stamp keeps the first one, and the lanes whose id survived append their cell in id order (ballot prefix).
 //     A chunk never overtakes the FIFO: children go behind everything already queued.
@@ -98,9 +98,16 @@ __device__ __forceinline__ uint8_t *tie_flag_ptr(const AlnDesc &d, uint8_t *ws, 
     return ws + d.mat_off[p] + size_t(t) * d.pitch[p] + x;   // dense
 }
 
-#define TIE_U 4    // chunks of 64 entries a wide pass keeps in flight (more does not help: a wave sustains about one scattered access per 10 cycles)
+#define TIE_U 4    // chunks a wide pass keeps in flight per wave (more does not help: a wave sustains about one scattered access per 10 cycles)
+// One workgroup of TIE_NW waves per alignment.  Every pass over a wave's cells (expansion of a wide frontier, the order
+// passes, the seeding of the next wave) is strided over the workgroup: entry e of a pass belongs to thread e mod TIE_NT of
+// chunk e / TIE_NT, candidate ids and append positions are functions of e alone (appends: ballot prefix inside a wave,
+// per-wave counts through LDS across waves), so the result does not depend on the number of waves.  A narrow frontier
+// (<= 64 entries: a chain of dependent steps) is expanded by wave 0 alone, which publishes the queue state to the others.
+#define TIE_NW 4
+#define TIE_NT (64 * TIE_NW)
 
-__global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__restrict__ descs,
+__global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc *__restrict__ descs,
                                                    TieJob *__restrict__ jobs, int n_jobs, uint8_t *ws,
                                                    const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs,
                                                    uint32_t *scratch, int32_t *__restrict__ n_overflow,
@@ -108,6 +115,10 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     // positions with more than one allowed swap source (the only cells that can be tied), one bit per position and plane
     __shared__ uint32_t mmask[2][1024];
     __shared__ int lds_ntie, lds_nres;
+    __shared__ int lds_cnt[3 * TIE_U][TIE_NW];      // per-wave append counts of a pass (one row per in-flight chunk)
+    __shared__ int lds_or[2][TIE_NW];               // per-wave flags of a workgroup-wide "any"
+    __shared__ int lds_state[2][6];                 // queue state after a narrow step of wave 0 (double buffered)
+    __shared__ uint32_t lds_tot[TIE_NW];
     const int j = blockIdx.x;
     if (j >= n_jobs) return;
     // a replay is one long chain of dependent steps that shares its SIMD with the bulk kernels' issue-bound waves
@@ -115,8 +126,21 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     const TieJob J = jobs[j];
     const int a = J.a;
     const AlnDesc d = descs[a];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int or_par = 0, st_par = 0;
+    // workgroup-wide OR of a per-thread flag (two barriers; callers are at points every wave reaches)
+    auto wg_any = [&](bool x) -> bool {
+        const bool w_any = __any(x);
+        if (lane == 0) lds_or[or_par][wv] = w_any ? 1 : 0;
+        __syncthreads();
+        bool r = false;
+#pragma unroll
+        for (int k = 0; k < TIE_NW; k++) r = r || lds_or[or_par][k];
+        or_par ^= 1;
+        return r;
+    };
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int s_fin = outs[a].s;
     const unsigned long long clk0 = wall_clock64();
@@ -158,14 +182,14 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     for (int p = 0; p < 2 && !fail; p++) {
         const int L = p ? Lr : Lq;
         const int4 *cd = p ? cand1 : cand0;
-        for (int x0 = 0; x0 < L; x0 += 64) {
+        for (int x0 = wv * 64; x0 < L; x0 += TIE_NT) {
             const int x = x0 + lane;
             const bool multi = x < L && cd[x].y >= 0;
             const unsigned long long bal = __ballot(multi);
             if (lane < 2) mmask[p][(x0 >> 5) + lane] = uint32_t(bal >> (32 * lane));
         }
     }
-    if (lane == 0) { lds_ntie = 0; lds_nres = 0; }
+    if (tid == 0) { lds_ntie = 0; lds_nres = 0; }
     __syncthreads();
     // the layout the tied cells' bytes are read from: the alignment's current descriptor, or (mode 1) the marking round's
     AlnDesc dl = d;
@@ -184,13 +208,14 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
     };
 
     // wave 0: the two start cells (dist.cpp:300-305), candidate ids 0 and 1
-    if (lane == 0 && !fail) {
+    if (tid == 0 && !fail) {
         qc[0] = make_uint2(0u, 0u);
         qc[1] = make_uint2(0x80000000u, 0u);
         stamp[sidx(0, 0, 0)] = 0u;
         stamp[sidx(1, 0, 0)] = 1u;
     }
     tie_wait();
+    fail = wg_any(fail || oob);
     uint32_t cid = 2;               // next candidate id
     uint32_t n_bkt = TIE_BUCKETS[0];   // prev_wave's bucket count (the first insert allocates 13)
     int bi = 0;
@@ -205,15 +230,15 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
         while (head < n_cur) {
             const int navail = n_cur - head;
             if (navail > 64) {
-                // ---- wide: up to TIE_U chunks of 64 entries in flight, appended in entry order
-                const int n = min(64 * TIE_U, navail);
+                // ---- wide: up to TIE_U chunks of TIE_NT entries in flight, appended in entry order
+                const int n = min(TIE_NT * TIE_U, navail);
                 uint2 x[TIE_U];
                 bool ty[TIE_U], tz[TIE_U];
                 uint32_t iy[TIE_U], iz[TIE_U];
                 int zq[TIE_U];
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const int e = u * 64 + lane;
+                    const int e = u * TIE_NT + tid;
                     x[u] = make_uint2(0u, 0u);
                     if (e < n) x[u] = qc[head + e];
                 }
@@ -222,7 +247,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
                     const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
-                    const bool in = (u * 64 + lane < n) && t + 1 < Lt;
+                    const bool in = (u * TIE_NT + tid < n) && t + 1 < Lt;
                     tb[u] = 0; sq[u] = 1; zq[u] = 0; fx[u] = PV; ft[u] = PV;
                     if (in) {
                         tb[u] = Ts[t + 1];
@@ -241,7 +266,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
                     const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
-                    const bool in = (u * 64 + lane < n) && t + 1 < Lt;
+                    const bool in = (u * TIE_NT + tid < n) && t + 1 < Lt;
                     ty[u] = in && sq[u] == tb[u] && q + 1 < (p ? Lr : Lq);
                     tz[u] = in && fwd_allow(fx[u]) && fwd_allow(ft[u]) && zq[u] >= 0 && zq[u] < (p ? Lq : Lr) && so[u] == tb[u];
                     iy[u] = ty[u] ? sidx(p, q + 1, t + 1) : 0u;
@@ -249,32 +274,48 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                 }
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const uint32_t cy = cid + 2u * uint32_t(u * 64 + lane);
+                    const uint32_t cy = cid + 2u * uint32_t(u * TIE_NT + tid);
                     if (ty[u]) (void)atomicMin(stamp + iy[u], cy);
                     if (tz[u]) (void)atomicMin(stamp + iz[u], cy + 1u);
                 }
                 tie_wait();
+                __syncthreads();            // every wave's candidate ids are in the stamps
                 bool wy[TIE_U], wz[TIE_U];
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const uint32_t cy = cid + 2u * uint32_t(u * 64 + lane);
+                    const uint32_t cy = cid + 2u * uint32_t(u * TIE_NT + tid);
                     wy[u] = ty[u] && tie_ld(stamp + iy[u]) == cy;
                     wz[u] = tz[u] && tie_ld(stamp + iz[u]) == cy + 1u;
                 }
+                unsigned long long by_[TIE_U], bz_[TIE_U];
+#pragma unroll
+                for (int u = 0; u < TIE_U; u++) {
+                    by_[u] = __ballot(wy[u]); bz_[u] = __ballot(wz[u]);
+                    if (lane == 0) lds_cnt[u][wv] = __popcll(by_[u]) + __popcll(bz_[u]);
+                }
+                if (lane == 0) lds_or[or_par][wv] = __any(oob) ? 1 : 0;
+                __syncthreads();
+                bool any_oob_ = false;
+#pragma unroll
+                for (int k = 0; k < TIE_NW; k++) any_oob_ = any_oob_ || lds_or[or_par][k];
+                or_par ^= 1;
                 int base = n_cur;
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const unsigned long long by = __ballot(wy[u]), bz = __ballot(wz[u]);
-                    const int tot = __popcll(by) + __popcll(bz);
+                    const unsigned long long by = by_[u], bz = bz_[u];
+                    int tot = 0, below = 0;
+#pragma unroll
+                    for (int k = 0; k < TIE_NW; k++) { const int c_ = lds_cnt[u][k]; tot += c_; below += (k < wv) ? c_ : 0; }
                     if (base + tot > cap) { fail = true; break; }
                     const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
-                    const int py = base + __popcll(by & lt_mask) + __popcll(bz & lt_mask);
+                    const int py = base + below + __popcll(by & lt_mask) + __popcll(bz & lt_mask);
                     if (wy[u]) { qc[py] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1); }
                     if (wz[u]) { qc[py + (wy[u] ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq[u]), uint32_t(t + 1)); if (is_multi(1 - p, zq[u])) note_tie(1 - p, zq[u], t + 1); }
                     base += tot;
                 }
-                if (fail || __any(oob)) { fail = true; break; }
+                if (fail || any_oob_) { fail = true; break; }
                 tie_wait();
+                __syncthreads();            // the appended entries are visible to every wave; lds_cnt may be reused
                 n_cur = base;
                 head += n;
                 dbg_steps++;
@@ -283,91 +324,104 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                 continue;
             }
             const int n = navail;
-            // Narrow stretches (a lone run of matches behind the last edit; all of wave 0) are chains of levels of a few
-            // cells each.  When the chunk is the whole queue and all its cells sit in one truth row, lanes j * n + i look
-            // ahead at slot i of level j (the slot's cell moved j steps down its diagonal).  Level j only touches row
-            // t + j + 1, which no earlier level of the batch touches, so if every slot's candidate pushes are valid /
-            // invalid / already pushed exactly as on level 0 and its swap target moves along, level j repeats level 0's
-            // outcome, and all those levels are committed at once.
-            const bool ff = n <= 32;
-            const int nk = ff ? 64 / n : 1;
-            const int jl = ff ? lane / n : 0, il = ff ? lane - jl * n : lane;
-            const bool act = lane < nk * n;
-            uint2 x = make_uint2(0u, 0u);
-            if (act) x = qc[head + il];
-            const int p = int(x.x >> 31), q = int(x.x & 0x7fffffffu) + jl, t = int(x.y) + jl;
-            const int Lme = p ? Lr : Lq, Loth = p ? Lq : Lr;
-            bool ty = false, tz = false;
-            uint32_t iy = 0, iz = 0;
-            int zq = 0;
-            const bool oob_before = oob;
-            if (act && t + 1 < Lt && q < Lme) {
-                const uint8_t tb = Ts[t + 1];
-                if (q + 1 < Lme && (p ? seq1 : seq0)[q + 1] == tb) { ty = true; iy = sidx(p, q + 1, t + 1); }
-                zq = (p ? ptr1 : ptr0)[q] + 1;
-                const int fx = (p ? flg1 : flg0)[q], ft = Tf[t];
-                if (fwd_allow(fx) && fwd_allow(ft) && zq >= 0 && zq < Loth && (p ? seq0 : seq1)[zq] == tb) {
-                    tz = true;
-                    iz = sidx(1 - p, zq, t + 1);
+            // (wave 0 alone; the others wait for the queue state it publishes)
+            if (wv == 0) {
+                // Narrow stretches (a lone run of matches behind the last edit; all of wave 0) are chains of levels of a few
+                // cells each.  When the chunk is the whole queue and all its cells sit in one truth row, lanes j * n + i look
+                // ahead at slot i of level j (the slot's cell moved j steps down its diagonal).  Level j only touches row
+                // t + j + 1, which no earlier level of the batch touches, so if every slot's candidate pushes are valid /
+                // invalid / already pushed exactly as on level 0 and its swap target moves along, level j repeats level 0's
+                // outcome, and all those levels are committed at once.
+                const bool ff = n <= 32;
+                const int nk = ff ? 64 / n : 1;
+                const int jl = ff ? lane / n : 0, il = ff ? lane - jl * n : lane;
+                const bool act = lane < nk * n;
+                uint2 x = make_uint2(0u, 0u);
+                if (act) x = qc[head + il];
+                const int p = int(x.x >> 31), q = int(x.x & 0x7fffffffu) + jl, t = int(x.y) + jl;
+                const int Lme = p ? Lr : Lq, Loth = p ? Lq : Lr;
+                bool ty = false, tz = false;
+                uint32_t iy = 0, iz = 0;
+                int zq = 0;
+                const bool oob_before = oob;
+                if (act && t + 1 < Lt && q < Lme) {
+                    const uint8_t tb = Ts[t + 1];
+                    if (q + 1 < Lme && (p ? seq1 : seq0)[q + 1] == tb) { ty = true; iy = sidx(p, q + 1, t + 1); }
+                    zq = (p ? ptr1 : ptr0)[q] + 1;
+                    const int fx = (p ? flg1 : flg0)[q], ft = Tf[t];
+                    if (fwd_allow(fx) && fwd_allow(ft) && zq >= 0 && zq < Loth && (p ? seq0 : seq1)[zq] == tb) {
+                        tz = true;
+                        iz = sidx(1 - p, zq, t + 1);
+                    }
                 }
-            }
-            const bool l0 = lane < n;                 // the lanes of the level actually popped now
-            // (a look-ahead lane whose hypothetical target lies outside the stamp grids only ends the batch of levels)
-            const bool la_oob = !l0 && oob && !oob_before;
-            if (la_oob) oob = false;
-            const uint32_t cy = cid + 2u * uint32_t(lane), cz = cy + 1u;
-            uint32_t oy = TIE_NEVER, oz = TIE_NEVER;
-            if (l0 && ty) oy = atomicMin(stamp + iy, cy);
-            if (l0 && tz) oz = atomicMin(stamp + iz, cz);
-            tie_wait();
-            const uint32_t vy = ty ? tie_ld(stamp + iy) : 0u, vz = tz ? tie_ld(stamp + iz) : 0u;
-            const bool wy = l0 && ty && vy == cy;
-            const bool wz = l0 && tz && vz == cz;
-            const unsigned long long by = __ballot(wy), bz = __ballot(wz);
-            const int tot = __popcll(by) + __popcll(bz);
-            if (n_cur + tot > cap) { fail = true; break; }
-            const int ry = __popcll(by & lt_mask) + __popcll(bz & lt_mask);    // rank of this lane's first winner
-            int nlev = 1;
-            const bool one_row = !__any(l0 && int(x.y) != __shfl(int(x.y), 0));
-            if (ff && one_row && tot == n && n_cur + nk * n <= cap) {
-                // level 0 must reproduce the frontier, slot by slot, one step down the diagonals
-                const uint32_t ycode = x.x + 1u, zcode = (uint32_t(1 - p) << 31) | uint32_t(zq);
-                const uint32_t sy = uint32_t(__shfl(int(x.x), ry)) + 1u, sz = uint32_t(__shfl(int(x.x), ry + (wy ? 1 : 0))) + 1u;
-                const bool stable = !__any((wy && ycode != sy) || (wz && zcode != sz));
-                if (stable) {
-                    // outcome class of a candidate push: 0 invalid, 1 pushed, 2 same cell as an earlier candidate of the
-                    // level, 3 cell pushed before this level
-                    const int ky = !ty ? 0 : (wy ? 1 : (oy < cid ? 3 : 2)), kz = !tz ? 0 : (wz ? 1 : (oz < cid ? 3 : 2));
-                    const int ky0 = __shfl(ky, il), kz0 = __shfl(kz, il), zq0 = __shfl(zq, il);
-                    // a look-ahead lane has only read its targets' stamps: untouched (classes 1, 2) or not (class 3)
-                    const bool same = !la_oob && (ty == (ky0 != 0)) && (tz == (kz0 != 0)) && (!tz || zq == zq0 + jl) &&
-                                      (!ty || ((vy == TIE_NEVER) == (ky0 != 3))) && (!tz || ((vz == TIE_NEVER) == (kz0 != 3)));
-                    const unsigned long long bad = __ballot(act && !l0 && !same);
-                    nlev = bad ? int(__builtin_ctzll(bad)) / n : nk;
-                    const int ry0 = __shfl(ry, il);
-                    if (jl >= 1 && jl < nlev) {
-                        const uint32_t c0 = cid + 2u * uint32_t(n) * uint32_t(jl) + 2u * uint32_t(il);
-                        const int pos = n_cur + jl * n + ry0;
-                        if (ky0 == 1) {
-                            stamp[iy] = c0; qc[pos] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1));
-                            if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1);
-                        }
-                        if (kz0 == 1) {
-                            stamp[iz] = c0 + 1u; qc[pos + (ky0 == 1 ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1));
-                            if (is_multi(1 - p, zq)) note_tie(1 - p, zq, t + 1);
+                const bool l0 = lane < n;                 // the lanes of the level actually popped now
+                // (a look-ahead lane whose hypothetical target lies outside the stamp grids only ends the batch of levels)
+                const bool la_oob = !l0 && oob && !oob_before;
+                if (la_oob) oob = false;
+                const uint32_t cy = cid + 2u * uint32_t(lane), cz = cy + 1u;
+                uint32_t oy = TIE_NEVER, oz = TIE_NEVER;
+                if (l0 && ty) oy = atomicMin(stamp + iy, cy);
+                if (l0 && tz) oz = atomicMin(stamp + iz, cz);
+                tie_wait();
+                const uint32_t vy = ty ? tie_ld(stamp + iy) : 0u, vz = tz ? tie_ld(stamp + iz) : 0u;
+                const bool wy = l0 && ty && vy == cy;
+                const bool wz = l0 && tz && vz == cz;
+                const unsigned long long by = __ballot(wy), bz = __ballot(wz);
+                const int tot = __popcll(by) + __popcll(bz);
+                int nlev = 1;
+                const bool over = n_cur + tot > cap;
+                if (over) fail = true;
+                if (!over) {
+                const int ry = __popcll(by & lt_mask) + __popcll(bz & lt_mask);    // rank of this lane's first winner
+                const bool one_row = !__any(l0 && int(x.y) != __shfl(int(x.y), 0));
+                if (ff && one_row && tot == n && n_cur + nk * n <= cap) {
+                    // level 0 must reproduce the frontier, slot by slot, one step down the diagonals
+                    const uint32_t ycode = x.x + 1u, zcode = (uint32_t(1 - p) << 31) | uint32_t(zq);
+                    const uint32_t sy = uint32_t(__shfl(int(x.x), ry)) + 1u, sz = uint32_t(__shfl(int(x.x), ry + (wy ? 1 : 0))) + 1u;
+                    const bool stable = !__any((wy && ycode != sy) || (wz && zcode != sz));
+                    if (stable) {
+                        // outcome class of a candidate push: 0 invalid, 1 pushed, 2 same cell as an earlier candidate of the
+                        // level, 3 cell pushed before this level
+                        const int ky = !ty ? 0 : (wy ? 1 : (oy < cid ? 3 : 2)), kz = !tz ? 0 : (wz ? 1 : (oz < cid ? 3 : 2));
+                        const int ky0 = __shfl(ky, il), kz0 = __shfl(kz, il), zq0 = __shfl(zq, il);
+                        // a look-ahead lane has only read its targets' stamps: untouched (classes 1, 2) or not (class 3)
+                        const bool same = !la_oob && (ty == (ky0 != 0)) && (tz == (kz0 != 0)) && (!tz || zq == zq0 + jl) &&
+                                          (!ty || ((vy == TIE_NEVER) == (ky0 != 3))) && (!tz || ((vz == TIE_NEVER) == (kz0 != 3)));
+                        const unsigned long long bad = __ballot(act && !l0 && !same);
+                        nlev = bad ? int(__builtin_ctzll(bad)) / n : nk;
+                        const int ry0 = __shfl(ry, il);
+                        if (jl >= 1 && jl < nlev) {
+                            const uint32_t c0 = cid + 2u * uint32_t(n) * uint32_t(jl) + 2u * uint32_t(il);
+                            const int pos = n_cur + jl * n + ry0;
+                            if (ky0 == 1) {
+                                stamp[iy] = c0; qc[pos] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1));
+                                if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1);
+                            }
+                            if (kz0 == 1) {
+                                stamp[iz] = c0 + 1u; qc[pos + (ky0 == 1 ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1));
+                                if (is_multi(1 - p, zq)) note_tie(1 - p, zq, t + 1);
+                            }
                         }
                     }
                 }
+                if (wy) { qc[n_cur + ry] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1); }
+                if (wz) { qc[n_cur + ry + (wy ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1)); if (is_multi(1 - p, zq)) note_tie(1 - p, zq, t + 1); }
+                }
+                tie_wait();
+                if (__any(oob)) fail = true;
+                if (!fail) {
+                    n_cur += tot * nlev;
+                    head += n * nlev;
+                    cid += 2u * uint32_t(n) * uint32_t(nlev);
+                    if (cid > 0xf0000000u) fail = true;
+                }
+                if (lane == 0) { lds_state[st_par][0] = n_cur; lds_state[st_par][1] = head; lds_state[st_par][2] = int(cid); lds_state[st_par][3] = fail ? 1 : 0; }
             }
-            if (wy) { qc[n_cur + ry] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1); }
-            if (wz) { qc[n_cur + ry + (wy ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1)); if (is_multi(1 - p, zq)) note_tie(1 - p, zq, t + 1); }
-            tie_wait();
-            if (__any(oob)) { fail = true; break; }
-            n_cur += tot * nlev;
-            head += n * nlev;
+            __syncthreads();
+            n_cur = lds_state[st_par][0]; head = lds_state[st_par][1]; cid = uint32_t(lds_state[st_par][2]); fail = lds_state[st_par][3] != 0;
+            st_par ^= 1;
             dbg_steps++;
-            cid += 2u * uint32_t(n) * uint32_t(nlev);
-            if (cid > 0xf0000000u) { fail = true; break; }
+            if (fail) break;
         }
         if (fail) break;
         lap(0);
@@ -376,11 +430,11 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             __syncthreads();
             const int ntie = lds_ntie;
             __syncthreads();
-            if (lane == 0) lds_ntie = 0;
+            if (tid == 0) lds_ntie = 0;
             const bool scan_all = ntie > tcap;         // the list overflowed: look at every cell of the wave
             const int nn = scan_all ? n_cur : ntie;
-            for (int i0 = 0; i0 < nn; i0 += 64) {
-                const int i = i0 + lane;
+            for (int i0 = 0; i0 < nn; i0 += TIE_NT) {
+                const int i = i0 + tid;
                 if (i >= nn) continue;
                 const uint2 z = scan_all ? qc[i] : Ta[i];
                 const int p = int(z.x >> 31), xq = int(z.x & 0x7fffffffu), t = int(z.y);
@@ -418,8 +472,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                     *fp = uint8_t((f & ~uint32_t((3u << F_CHOICE_SHIFT) | F_TIE)) | (uint32_t(best) << F_CHOICE_SHIFT));
                 }
             }
-            __syncthreads();
-            if (__any(oob)) { fail = true; break; }
+            if (wg_any(oob)) { fail = true; break; }
             if (lds_nres != dbg_nres0) { dbg_nres0 = lds_nres; dbg_lastw = w; }
             if (J.mode == 1 && lds_nres >= J.n_used) { dbg_cells += n_cur; dbg_waves++; break; }   // every consulted tie is decided
         }
@@ -438,23 +491,24 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             tag++;
             const unsigned long long tagw = (unsigned long long)(~tag) << 32;
             // pass 0: bucket member counts cleared
-            for (int b0 = lane; b0 < int(n_bkt); b0 += 64) bcount[b0] = 0u;
+            for (int b0 = tid; b0 < int(n_bkt); b0 += TIE_NT) bcount[b0] = 0u;
             tie_wait();
+            __syncthreads();
             // pass A: bucket of every element, first insertion per bucket, bucket member lists; H cleared
             bool blist_full = false;
-            for (int i0 = 0; i0 < m; i0 += 64 * TIE_U) {
+            for (int i0 = 0; i0 < m; i0 += TIE_NT * TIE_U) {
                 uint32_t e[TIE_U], bk[TIE_U], slot[TIE_U];
                 uint2 c[TIE_U];
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const int i = i0 + u * 64 + lane;
+                    const int i = i0 + u * TIE_NT + tid;
                     e[u] = (i < m) ? ((have_lam && i < done) ? oc[i] : uint32_t(i)) : 0u;
                 }
 #pragma unroll
-                for (int u = 0; u < TIE_U; u++) c[u] = (i0 + u * 64 + lane < m) ? qc[e[u]] : make_uint2(0u, 0u);
+                for (int u = 0; u < TIE_U; u++) c[u] = (i0 + u * TIE_NT + tid < m) ? qc[e[u]] : make_uint2(0u, 0u);
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const int i = i0 + u * 64 + lane;
+                    const int i = i0 + u * TIE_NT + tid;
                     bk[u] = 0u; slot[u] = 0u;
                     if (i >= m) continue;
                     const unsigned long long hv = ((c[u].x >> 31) ? hi_r : hi_q) ^
@@ -468,26 +522,26 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                 }
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const int i = i0 + u * 64 + lane;
+                    const int i = i0 + u * TIE_NT + tid;
                     if (i >= m) continue;
                     if (slot[u] < TIE_BLIST) blist[size_t(bk[u]) * TIE_BLIST + slot[u]] = uint32_t(i); else blist_full = true;
                 }
             }
-            blist_full = __any(blist_full);
             tie_wait();
+            blist_full = wg_any(blist_full);     // (its barrier also ends pass A for every wave)
             lap(2);
             // pass B: F_i = first insertion index of the element's bucket; histogram of F
-            for (int i0 = 0; i0 < m; i0 += 64 * TIE_U) {
+            for (int i0 = 0; i0 < m; i0 += TIE_NT * TIE_U) {
                 uint32_t b[TIE_U];
                 unsigned long long fw[TIE_U];
 #pragma unroll
-                for (int u = 0; u < TIE_U; u++) b[u] = (i0 + u * 64 + lane < m) ? Ka[i0 + u * 64 + lane] : 0u;
+                for (int u = 0; u < TIE_U; u++) b[u] = (i0 + u * TIE_NT + tid < m) ? Ka[i0 + u * TIE_NT + tid] : 0u;
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++)
-                    fw[u] = (i0 + u * 64 + lane < m) ? __hip_atomic_load(bfirst + b[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    fw[u] = (i0 + u * TIE_NT + tid < m) ? __hip_atomic_load(bfirst + b[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const int i = i0 + u * 64 + lane;
+                    const int i = i0 + u * TIE_NT + tid;
                     if (i >= m) continue;
                     const uint32_t f = uint32_t(fw[u] & 0xffffffffull);
                     Fa[i] = f;
@@ -495,39 +549,56 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                 }
             }
             tie_wait();
+            __syncthreads();
             lap(3);
-            // exclusive suffix sum over H: G[f] = elements in buckets created after f
+            // exclusive suffix sum over H: G[f] = elements in buckets created after f.  Each wave owns a contiguous segment
+            // (a multiple of the chunk size): its total first, then the running sums from the segment's top with the totals
+            // of the segments above as the start value
             {
+                const int CH = 64 * TIE_U;
+                const int seg = ((m + TIE_NW * CH - 1) / (TIE_NW * CH)) * CH;       // elements per wave
+                const int s_lo = wv * seg, s_hi = min(m, s_lo + seg);
+                uint32_t mine = 0;
+                for (int i0 = s_lo; i0 < s_hi; i0 += 64) { const int i = i0 + lane; mine += (i < s_hi) ? tie_ld(Ha + i) : 0u; }
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) mine += uint32_t(__shfl_xor(int(mine), o));
+                if (lane == 0) lds_tot[wv] = mine;
+                __syncthreads();
                 uint32_t run = 0;
-                const int top = ((m - 1) / (64 * TIE_U)) * (64 * TIE_U);
-                for (int i0 = top; i0 >= 0; i0 -= 64 * TIE_U) {
-                    uint32_t hcnt[TIE_U];
 #pragma unroll
-                    for (int u = 0; u < TIE_U; u++) hcnt[u] = (i0 + u * 64 + lane < m) ? tie_ld(Ha + i0 + u * 64 + lane) : 0u;
+                for (int k = 0; k < TIE_NW; k++) run += (k > wv) ? lds_tot[k] : 0u;
+                if (s_hi > s_lo) {
+                    const int top = s_lo + ((s_hi - s_lo - 1) / CH) * CH;
+                    for (int i0 = top; i0 >= s_lo; i0 -= CH) {
+                        uint32_t hcnt[TIE_U];
 #pragma unroll
-                    for (int u = TIE_U - 1; u >= 0; u--) {
-                        const int i = i0 + u * 64 + lane;
-                        uint32_t suf = hcnt[u];
+                        for (int u = 0; u < TIE_U; u++) hcnt[u] = (i0 + u * 64 + lane < s_hi) ? tie_ld(Ha + i0 + u * 64 + lane) : 0u;
 #pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) {
-                            const uint32_t tv = uint32_t(__shfl_down(int(suf), o));
-                            if (lane + o < 64) suf += tv;
+                        for (int u = TIE_U - 1; u >= 0; u--) {
+                            const int i = i0 + u * 64 + lane;
+                            uint32_t suf = hcnt[u];
+#pragma unroll
+                            for (int o = 1; o < 64; o <<= 1) {
+                                const uint32_t tv = uint32_t(__shfl_down(int(suf), o));
+                                if (lane + o < 64) suf += tv;
+                            }
+                            if (i < s_hi) Ha[i] = run + suf - hcnt[u];
+                            run += uint32_t(__shfl(int(suf), 0));
                         }
-                        if (i < m) Ha[i] = run + suf - hcnt[u];
-                        run += uint32_t(__shfl(int(suf), 0));
                     }
                 }
             }
             tie_wait();
+            __syncthreads();
             lap(4);
             if (!blist_full) {
                 // pass C: position = G[F_i] + members of the element's bucket inserted later (from the bucket's member list)
-                for (int i0 = 0; i0 < m; i0 += 64 * TIE_U) {
+                for (int i0 = 0; i0 < m; i0 += TIE_NT * TIE_U) {
                     uint32_t f[TIE_U], bk[TIE_U], e[TIE_U], g[TIE_U], cn[TIE_U];
                     uint4 ml[TIE_U], mh[TIE_U];
 #pragma unroll
                     for (int u = 0; u < TIE_U; u++) {
-                        const int i = i0 + u * 64 + lane;
+                        const int i = i0 + u * TIE_NT + tid;
                         const bool act = i < m;
                         f[u] = act ? Fa[i] : 0u;
                         bk[u] = act ? Ka[i] : 0u;
@@ -535,7 +606,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                     }
 #pragma unroll
                     for (int u = 0; u < TIE_U; u++) {
-                        const bool act = i0 + u * 64 + lane < m;
+                        const bool act = i0 + u * TIE_NT + tid < m;
                         g[u] = act ? tie_ld(Ha + f[u]) : 0u;
                         cn[u] = act ? tie_ld(bcount + bk[u]) : 0u;
                         const uint4 *mp = reinterpret_cast<const uint4 *>(blist + size_t(bk[u]) * TIE_BLIST);
@@ -544,7 +615,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                     }
 #pragma unroll
                     for (int u = 0; u < TIE_U; u++) {
-                        const int i = i0 + u * 64 + lane;
+                        const int i = i0 + u * TIE_NT + tid;
                         if (i >= m) continue;
                         const uint32_t mem[8] = {ml[u].x, ml[u].y, ml[u].z, ml[u].w, mh[u].x, mh[u].y, mh[u].z, mh[u].w};
                         uint32_t rank = 0;
@@ -557,10 +628,11 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
             } else {
                 // (a bucket with more than TIE_BLIST members: the same positions from per-bucket counters, chunk by chunk
                 // from the back)
-                for (int i0 = lane; i0 < m; i0 += 64) Ka[i0] = 0u;
+                for (int i0 = tid; i0 < m; i0 += TIE_NT) Ka[i0] = 0u;
                 tie_wait();
+                __syncthreads();
                 const int top = (m - 1) & ~63;
-                for (int i0 = top; i0 >= 0; i0 -= 64) {
+                for (int i0 = top; i0 >= 0 && wv == 0; i0 -= 64) {
                     const int i = i0 + lane;
                     const bool act = i < m;
                     const uint32_t f = act ? tie_ld(Fa + i) : 0xffffffffu;
@@ -579,6 +651,7 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
                     tie_wait();
                 }
             }
+            __syncthreads();     // `on` is complete (pass C ended with a wait of every wave's stores)
             lap(5);
             { uint32_t *tmp = oc; oc = on; on = tmp; }
             have_lam = true;
@@ -592,62 +665,78 @@ __global__ void __launch_bounds__(64) k_tie_replay(DevBatch B, const AlnDesc *__
         // ---- next wave: INS, DEL, SUB targets of every popped cell, in iteration order (dist.cpp:395-424)
         int n_next = 0;
         wave_lo = cid;
-        for (int k0 = 0; k0 < n && !fail; k0 += 64 * TIE_U) {
+        for (int k0 = 0; k0 < n && !fail; k0 += TIE_NT * TIE_U) {
             uint32_t e[TIE_U];
             uint2 x[TIE_U];
             bool t0[TIE_U], t1[TIE_U], t2[TIE_U];
             uint32_t j0[TIE_U], j1[TIE_U], j2[TIE_U];
 #pragma unroll
-            for (int u = 0; u < TIE_U; u++) e[u] = (k0 + u * 64 + lane < n) ? oc[k0 + u * 64 + lane] : 0u;
+            for (int u = 0; u < TIE_U; u++) e[u] = (k0 + u * TIE_NT + tid < n) ? oc[k0 + u * TIE_NT + tid] : 0u;
 #pragma unroll
-            for (int u = 0; u < TIE_U; u++) x[u] = (k0 + u * 64 + lane < n) ? qc[e[u]] : make_uint2(0u, 0u);
+            for (int u = 0; u < TIE_U; u++) x[u] = (k0 + u * TIE_NT + tid < n) ? qc[e[u]] : make_uint2(0u, 0u);
 #pragma unroll
             for (int u = 0; u < TIE_U; u++) {
-                const bool act = k0 + u * 64 + lane < n;
+                const bool act = k0 + u * TIE_NT + tid < n;
                 const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
                 t0[u] = act && q + 1 < (p ? Lr : Lq); t1[u] = act && t + 1 < Lt; t2[u] = t0[u] && t1[u];
-                const uint32_t c0 = cid + 3u * uint32_t(u * 64 + lane);
+                const uint32_t c0 = cid + 3u * uint32_t(u * TIE_NT + tid);
                 j0[u] = t0[u] ? sidx(p, q + 1, t) : 0u; j1[u] = t1[u] ? sidx(p, q, t + 1) : 0u; j2[u] = t2[u] ? sidx(p, q + 1, t + 1) : 0u;
                 if (t0[u]) (void)atomicMin(stamp + j0[u], c0);
                 if (t1[u]) (void)atomicMin(stamp + j1[u], c0 + 1u);
                 if (t2[u]) (void)atomicMin(stamp + j2[u], c0 + 2u);
             }
             tie_wait();
+            __syncthreads();
             bool w0[TIE_U], w1[TIE_U], w2[TIE_U];
 #pragma unroll
             for (int u = 0; u < TIE_U; u++) {
-                const uint32_t c0 = cid + 3u * uint32_t(u * 64 + lane);
+                const uint32_t c0 = cid + 3u * uint32_t(u * TIE_NT + tid);
                 w0[u] = t0[u] && tie_ld(stamp + j0[u]) == c0;
                 w1[u] = t1[u] && tie_ld(stamp + j1[u]) == c0 + 1u;
                 w2[u] = t2[u] && tie_ld(stamp + j2[u]) == c0 + 2u;
             }
+            unsigned long long b0_[TIE_U], b1_[TIE_U], b2_[TIE_U];
 #pragma unroll
             for (int u = 0; u < TIE_U; u++) {
-                const unsigned long long b0 = __ballot(w0[u]), b1 = __ballot(w1[u]), b2 = __ballot(w2[u]);
-                const int tot = __popcll(b0) + __popcll(b1) + __popcll(b2);
+                b0_[u] = __ballot(w0[u]); b1_[u] = __ballot(w1[u]); b2_[u] = __ballot(w2[u]);
+                if (lane == 0) lds_cnt[u][wv] = __popcll(b0_[u]) + __popcll(b1_[u]) + __popcll(b2_[u]);
+            }
+            if (lane == 0) lds_or[or_par][wv] = __any(oob) ? 1 : 0;
+            __syncthreads();
+            bool any_oob_ = false;
+#pragma unroll
+            for (int k = 0; k < TIE_NW; k++) any_oob_ = any_oob_ || lds_or[or_par][k];
+            or_par ^= 1;
+#pragma unroll
+            for (int u = 0; u < TIE_U; u++) {
+                const unsigned long long b0 = b0_[u], b1 = b1_[u], b2 = b2_[u];
+                int tot = 0, below = 0;
+#pragma unroll
+                for (int k = 0; k < TIE_NW; k++) { const int c_ = lds_cnt[u][k]; tot += c_; below += (k < wv) ? c_ : 0; }
                 if (n_next + tot > cap) { fail = true; break; }
                 const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
-                int pos = n_next + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask);
+                int pos = n_next + below + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask);
                 if (w0[u]) { qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t); }
                 if (w1[u]) { qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q), uint32_t(t + 1)); if (is_multi(p, q)) note_tie(p, q, t + 1); }
                 if (w2[u]) { qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1); }
                 n_next += tot;
             }
-            cid += 3u * uint32_t(min(64 * TIE_U, n - k0));
-            if (cid > 0xf0000000u || __any(oob)) fail = true;
+            cid += 3u * uint32_t(min(TIE_NT * TIE_U, n - k0));
+            if (cid > 0xf0000000u || any_oob_) fail = true;
+            tie_wait();
+            __syncthreads();            // (lds_cnt is reused by the next chunk)
         }
         if (fail) break;
-        tie_wait();
         lap(6);
         { uint2 *tmp = qc; qc = qn; qn = tmp; }
         n_cur = n_next;
         if (n_cur == 0) { fail = true; break; }   // "Empty queue" (dist.cpp:314): cannot happen for an accepted alignment
     }
-    if (fail && lane == 0) atomicAdd(n_overflow, 1);
-    const bool any_oob = __any(oob);
-    if (any_oob && lane == int(__builtin_ctzll(__ballot(oob)))) { jobs[j].dbg_oob[0] = oob_p; jobs[j].dbg_oob[1] = oob_q; jobs[j].dbg_oob[2] = oob_t; jobs[j].dbg_oob[3] = dbg_waves; }
-    if (lane == 0) jobs[j].pad = fail ? (any_oob ? 2 : 1) : 0;       // (debug) why the job gave up: 1 logs / buckets, 2 stamp grid
-    if (lane == 0) {
+    if (fail && tid == 0) atomicAdd(n_overflow, 1);
+    const bool any_oob = wg_any(oob);
+    if (oob && lane == int(__builtin_ctzll(__ballot(oob)))) { jobs[j].dbg_oob[0] = oob_p; jobs[j].dbg_oob[1] = oob_q; jobs[j].dbg_oob[2] = oob_t; jobs[j].dbg_oob[3] = dbg_waves; }
+    if (tid == 0) jobs[j].pad = fail ? (any_oob ? 2 : 1) : 0;       // (debug) why the job gave up: 1 logs / buckets, 2 stamp grid
+    if (tid == 0) {
         jobs[j].dbg_us = int32_t((wall_clock64() - clk0) / 100);   // 100 MHz counter
         jobs[j].dbg_steps = dbg_steps; jobs[j].dbg_cells = dbg_cells; jobs[j].dbg_waves = dbg_waves;
         jobs[j].dbg_nres = lds_nres; jobs[j].dbg_lastw = dbg_lastw;
