@@ -124,12 +124,22 @@ COLS = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1"
     ("record_before_header", HDR + "chr1\t10\t.\tA\tG\t30\tPASS\t.\tGT\t1|1\n", "before the #CHROM"),
     ("short_record", HDR + COLS + "\nchr1\t10\t.\tA\tG\t30\n", "fields"),
     ("allele_index", HDR + COLS + "\nchr1\t10\t.\tA\tG\t30\tPASS\t.\tGT\t1|2\n", "out of range"),
+    # GT declared in the header but absent from a record (variant.cpp:637-640)
+    ("missing_gt", HDR + '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n' + COLS +
+                   "\nchr1\t10\t.\tA\tG\t30\tPASS\t.\tGQ\t20\n", "Failed to read GT"),
 ])
 def test_vcf_format_errors_are_reported(tmp_path, name, text, needle):
     p = tmp_path / (name + ".vcf")
     p.write_text(text)
     with pytest.raises(IOError, match=needle):
         IO.read_vcf(str(p), None)
+
+
+def test_record_without_gt_is_monoploid_when_the_header_declares_no_gt(tmp_path):
+    p = tmp_path / "nogt.vcf"
+    p.write_text(HDR + COLS + "\nchr1\t10\t.\tA\tG\t30\tPASS\t.\tGQ\t20\n")
+    c = IO.read_vcf(str(p), None)                      # variant.cpp:631-636: a warning, ploidy 1
+    assert sum(len(columns(c["vars"][0][k])[0]) for k in range(2)) >= 1
 
 
 def test_missing_files_and_short_bed_lines(tmp_path):

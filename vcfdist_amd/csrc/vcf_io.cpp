@@ -172,7 +172,7 @@ int vio_read_vcf(const char *path, const vio_bed *bed, const vio_params *prm, co
     std::vector<int32_t> ploidy;
     std::vector<std::vector<HapBuild>> build;      // [ctg][hap]
     std::string sample, line, prev_ctg;
-    bool have_ps = false, have_gt = true, saw_header = false;
+    bool have_ps = false, have_gt = false, saw_header = false;
     vio_callset S;
     memset(&S, 0, sizeof(S));
     int prev_end[2] = {0, 0}, prev_type[2] = {T_SUB, T_SUB};
@@ -187,13 +187,13 @@ int vio_read_vcf(const char *path, const vio_bed *bed, const vio_params *prm, co
                 }
             } else if (line.compare(0, 9, "##FORMAT=") == 0) {
                 if (line.find("ID=PS,") != std::string::npos || line.find("ID=PS>") != std::string::npos) have_ps = true;
+                if (line.find("ID=GT,") != std::string::npos || line.find("ID=GT>") != std::string::npos) have_gt = true;
             } else if (line.compare(0, 6, "#CHROM") == 0) {
                 const std::vector<std::string> f = split(line, '\t');
                 if (f.size() != 10)
                     return fail(VIO_ERR_FORMAT, "Expected 1 sample but found %d in VCF '%s'", int(f.size()) - 9, path);
                 sample = f[9];
                 saw_header = true;
-                have_gt = true;   // (the reference only warns when GT is undeclared; undeclared GT is handled per record)
             }
             continue;
         }
@@ -251,7 +251,10 @@ int vio_read_vcf(const char *path, const vio_bed *bed, const vio_params *prm, co
             if (ngt > 2)
                 return fail(VIO_ERR_FORMAT, "Expected monoploid/diploid VCF, found variant with ploidy %d at %s:%s", ngt, ctg.c_str(), f[1].c_str());
         }
-        (void)have_gt;
+        // a record without GT: monoploid when the header does not declare GT either (the reference warns once and goes on,
+        // variant.cpp:631-636), an error when it does (variant.cpp:637-640)
+        if (ngt == -1 && have_gt)
+            return fail(VIO_ERR_FORMAT, "Failed to read GT at %s:%s in VCF '%s'", ctg.c_str(), f[1].c_str(), path);
         if (ploidy[ci] != 0) {
             if (std::abs(ngt) != ploidy[ci] && ctg.back() != 'X') S.n_wrong_ploidy++;
         } else ploidy[ci] = std::abs(ngt);

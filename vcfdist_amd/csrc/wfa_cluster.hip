@@ -372,7 +372,8 @@ extern "C" int vcl_wfa_cluster(const vcl_hap_seq *hs, const uint8_t *ctg_seq, in
     memset(&st, 0, sizeof(st));
     std::vector<int> left_reach, right_reach, prev_clusters;
     std::vector<void *> allocs;
-    auto cleanup = [&] { for (void *p : allocs) (void)hipFree(p); };
+    hipEvent_t ev_done[2] = {nullptr, nullptr};      // destroyed by cleanup() on every return path
+    auto cleanup = [&] { for (void *p : allocs) (void)hipFree(p); for (hipEvent_t e : ev_done) if (e) (void)hipEventDestroy(e); };
     if (n) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess)
@@ -389,9 +390,13 @@ extern "C" int vcl_wfa_cluster(const vcl_hap_seq *hs, const uint8_t *ctg_seq, in
         H.pool = dev_copy(hs->pool, size_t(pool_len), allocs);
         H.ctg = dev_copy(ctg_seq, size_t(ctg_len), allocs);
         if (!H.pos || !H.type || !H.ref_len || !H.alt_len || !H.alt_off || !H.pool || !H.ctg) { cleanup(); return VCL_ERR_DEVICE; }
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+            if (e0) (void)hipEventDestroy(e0);
+            cleanup();
+            return VCL_ERR_DEVICE;
+        }
+        ev_done[0] = e0; ev_done[1] = e1;
         const int scores = std::max(sub, open + extend) + 1;
         // one launch of `kern` over `jobs` (scratch offsets assigned here); results into res[job.out]
         int32_t *d_scratch = nullptr; size_t scratch_cap = 0;
@@ -406,6 +411,9 @@ extern "C" int vcl_wfa_cluster(const vcl_hap_seq *hs, const uint8_t *ctg_seq, in
                 total += ((j.q_len + 3) >> 2) + ((j.r_len + 3) >> 2) + MATS * scores * mat_len + 16;
             }
             if (size_t(total) > scratch_cap) {
+                auto drop = [&](void *q) { if (q) { allocs.erase(std::remove(allocs.begin(), allocs.end(), q), allocs.end()); (void)hipFree(q); } };
+                (void)hipDeviceSynchronize();     // (an outgrown buffer is released at once, not at the end of the call)
+                drop(d_scratch); d_scratch = nullptr;
                 if (hipMalloc(reinterpret_cast<void **>(&d_scratch), size_t(total) * 4 * 3 / 2) != hipSuccess) return false;
                 allocs.push_back(d_scratch);
                 scratch_cap = size_t(total) * 3 / 2;
@@ -576,8 +584,6 @@ extern "C" int vcl_wfa_cluster(const vcl_hap_seq *hs, const uint8_t *ctg_seq, in
                 right_reach.push_back(it->hi);
             }
         }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
         cleanup();
     }
     vcl_clusters *c = static_cast<vcl_clusters *>(calloc(1, sizeof(vcl_clusters)));
