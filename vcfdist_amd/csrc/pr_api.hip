@@ -1263,10 +1263,10 @@ struct Exec {
         std::stable_sort(needs.begin(), needs.end(), [](const Need &x, const Need &y) { return x.cells > y.cells; });
         if (tie_job_cur + needs.size() > h->tie_jobs_cap) return fail(h, VPR_ERR_STATE, "tie round: job buffer overflow");
         size_t free_b = 0, total_b = 0;
-        if (total * 4 > scratch_bytes) HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+        if (total * 4 + 256 > scratch_bytes) HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
         // (the block a launch outgrew is released first, so what it holds counts as free; a block already at the bound stays)
         const int64_t nb_want = std::max<int64_t>(std::min<int64_t>(total * 4, int64_t((free_b + size_t(scratch_bytes)) / 3)), largest * 4) + 256;
-        if (total * 4 > scratch_bytes && nb_want > scratch_bytes + scratch_bytes / 8) {
+        if (largest * 4 + 256 > scratch_bytes || (total * 4 > scratch_bytes && nb_want > scratch_bytes + scratch_bytes / 8)) {
             HIPCHK(h, hipStreamSynchronize(ks));
             if (scratch) (void)hipFree(scratch);
             scratch = nullptr; scratch_bytes = 0;
