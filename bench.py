@@ -164,9 +164,15 @@ def main():
     host_res = [None]
     gloo = dist is not None and dist.get_backend() == "gloo"
 
+    parts = [0.0, 0.0, 0.0]            # host-side seconds in execute / download / counters + collective, summed over the timed steps
+
     def step():
+        ta = time.perf_counter()
         pr.execute()                    # K1..K5 on the device
+        tb = time.perf_counter()
         host_res[0] = res = pr.download(host_res[0])   # final results to (reused) host buffers
+        tc = time.perf_counter()
+        parts[0] += tb - ta; parts[1] += tc - tb
         pb = None
         if strong:      # a contig's superclusters sit on all ranks: all-gather (sc_phase, orig, swap), phase redundantly
             sc_phase, _, _ = shard.allgather_phase(res, my_idx, whole.n_sc, device=None if gloo else dev)
@@ -176,6 +182,7 @@ def main():
             tc = t.cpu(); dist.all_reduce(tc); t = tc.to(dev)
         elif dist is not None:
             dist.all_reduce(t)          # the one collective of the path: the precision/recall counters (int64 sum)
+        parts[2] += time.perf_counter() - tc
         return res, t
 
     def sync():
@@ -185,6 +192,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    parts[:] = [0.0, 0.0, 0.0]
     kern_ms = []
     stats_acc = {}
     sync()
@@ -286,6 +294,8 @@ def main():
                                     if strong else f"{world} ranks x independent superclusters")},
             "dense_cells_per_s": round(tm.cells_dense * world * args.steps / elapsed, 1),
             "kernel_ms_per_step": round(float(np.mean(kern_ms)), 3),
+            "step_parts_ms": {"vpr_execute": round(parts[0] / args.steps * 1e3, 3), "vpr_download": round(parts[1] / args.steps * 1e3, 3),
+                              "counters_and_collective": round(parts[2] / args.steps * 1e3, 3)},
             "setup_not_timed": {"generate_s": round(t_b - t_a, 2), "host_marshalling_s": round(t_c - t_b, 2),
                                 "upload_and_prep_s": round(t_d - t_c, 2),
                                 "upload_and_prep_parts_s": {"vpr_create": round(t_c1 - t_c, 3), "vpr_upload": round(t_c2 - t_c1, 3),

@@ -264,6 +264,10 @@ int vpr_phase(const int32_t *sc_phase, const int32_t *phase_set, int32_t n, int3
    threshold.  var_class[slot][v] in {SNP, INDEL, SV} (INDEL iff the allele is shorter than g.sv_threshold,
    print.cpp:362-372); pb_phase[n_sc] is consulted for superclusters whose sc_phase is NONE (may be NULL: phase 0).
    The reference accumulates these in `float`; the int64 values are identical below 2^24 per cell. */
+/* SNP / INDEL / SV class (VPR_VARTYPE_*) of n variants, src/print.cpp:362-372: a SUB is a SNP, an INS / DEL shorter than
+   sv_threshold an INDEL, anything else an SV.  Host code. */
+void vpr_var_class(const uint8_t *var_type, const int32_t *ref_len, const int32_t *alt_len, int64_t n, int32_t sv_threshold,
+                   uint8_t *out);
 /* var_class may be NULL after vpr_upload_var_class (classes stay resident for the batch) */
 int vpr_upload_var_class(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS]);
 int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,

@@ -83,7 +83,7 @@ EXPORTED = [
     "vpr_create", "vpr_destroy", "vpr_last_error", "vpr_version", "vpr_run", "vpr_upload",
     "vpr_upload_variants", "vpr_execute", "vpr_download", "vpr_host_alloc", "vpr_host_free", "vpr_get_timing", "vpr_get_launch_stats",
     "vpr_get_tally",
-    "vpr_download_path", "vpr_phase", "vpr_upload_var_class", "vpr_pr_counts", "vpr_pr_summary",
+    "vpr_download_path", "vpr_phase", "vpr_var_class", "vpr_upload_var_class", "vpr_pr_counts", "vpr_pr_summary",
     "vpr_store_phase", "vpr_batch_from_variants", "vpr_owned_batch_view", "vpr_owned_batch_free",
     "vpr_synth_default_params", "vpr_synth_create", "vpr_synth_variants", "vpr_synth_destroy",
 ]
@@ -158,14 +158,18 @@ class Synth:
     def var_class(self, sv_threshold=50):
         """SNP / INDEL / SV class of every variant of the four hap slots (print.cpp:362-372), from views into the
         generator's tables (variants() copies the allele pools and the contigs as well)"""
-        from . import summary
         s = self.struct
+        L = lib()
+        L.vpr_var_class.restype = None
+        L.vpr_var_class.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         out = []
         for h in range(A.HAPS):
             nv = int(s.var_off[h][s.n_sc])
-            view = lambda p, dt: np.ctypeslib.as_array(p, shape=(nv,)) if nv else np.zeros(0, dt)
-            out.append(summary.var_class(view(s.var_type[h], np.uint8), view(s.var_ref_len[h], np.int32),
-                                         view(s.var_alt_len[h], np.int32), sv_threshold))
+            o = np.zeros(nv, np.uint8)
+            if nv:
+                L.vpr_var_class(C.cast(s.var_type[h], C.c_void_p), C.cast(s.var_ref_len[h], C.c_void_p),
+                                C.cast(s.var_alt_len[h], C.c_void_p), nv, sv_threshold, o.ctypes.data)
+            out.append(o)
         return out
 
     def batch(self, copy=True) -> A.Batch:

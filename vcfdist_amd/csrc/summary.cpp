@@ -8,6 +8,15 @@
 
 #include "../../include/vcfdist_pr.h"
 
+extern "C" void vpr_var_class(const uint8_t *var_type, const int32_t *ref_len, const int32_t *alt_len, int64_t n,
+                              int32_t sv_threshold, uint8_t *out) {
+    for (int64_t i = 0; i < n; i++) {
+        const int t = var_type[i];
+        const bool small = (t == VPR_TYPE_INS && alt_len[i] < sv_threshold) || (t == VPR_TYPE_DEL && ref_len[i] < sv_threshold);
+        out[i] = uint8_t(t == VPR_TYPE_SUB ? 0 : (small ? 1 : 2));
+    }
+}
+
 extern "C" int vpr_phase(const int32_t *sc_phase, const int32_t *phase_set, int32_t n, int32_t *pb_phase,
                          int32_t *switches, int32_t *n_switches, int32_t *flips, int32_t *n_flips) {
     if (n < 0 || (n && (!sc_phase || !phase_set || !pb_phase))) return VPR_ERR_ARG;
