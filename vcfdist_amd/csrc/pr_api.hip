@@ -162,6 +162,9 @@ struct vpr_handle {
     // plans of the last execute in launch order (the last one that holds an alignment has its final walk); second = the
     // plan's workspace, nullptr once that workspace has been reused
     std::vector<std::pair<std::vector<int32_t>, uint8_t *>> resident;
+    // the last chunk of the round-0 plan, whose walks are still in the round-0 workspace: a view into plan0.work (searched
+    // last: a later plan of an alignment holds its final walk)
+    int64_t res0_off = 0; int32_t res0_cnt = 0;
     Section *d_secs = nullptr; int64_t n_secs_cap = 0;
     int32_t *d_fp[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t **d_fp_table = nullptr;
@@ -271,6 +274,7 @@ void free_batch(vpr_handle *h) {
         h->lad[k] = LadderCtx();
     }
     h->resident.clear();
+    h->res0_cnt = 0;
     h->d_ed_scratch = nullptr; h->ed_scratch_ints = 0;
     h->d_tie_list = nullptr; h->hp_tie_list = nullptr; h->tie_list_cap = 0; h->d_tie_cnt = nullptr; h->hp_tie_cnt = nullptr;
     h->hp_tie_jobs = nullptr; h->tie_jobs_cap = 0;
@@ -2011,9 +2015,7 @@ struct Exec {
             HIPCHK(h, hipEventRecord(h->ev_join[5], h->lad[3].ls));
             for (int k = 0; k < 6; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
             if (ci + 1 < P0.chunks.size()) HIPCHK(h, hipStreamSynchronize(st));
-            if (ci + 1 == P0.chunks.size())
-                h->resident.emplace(h->resident.begin(), std::vector<int32_t>(P0.work.begin() + ch.work_off,
-                                                                              P0.work.begin() + ch.work_off + ch.count), P0.arena);
+            if (ci + 1 == P0.chunks.size()) { h->res0_off = ch.work_off; h->res0_cnt = ch.count; }
         }
         return VPR_OK;
     }
@@ -2188,9 +2190,10 @@ struct Exec {
             IA.tally = h->dR.tally; IA.njobs = h->d_njobs; IA.cnt = h->d_cnt; IA.n_cnt = 2;
             hipLaunchKernelGGL(k_init_execute, blocks(top), dim3(256), 0, st, IA);
         }
-        if (!h->dirty.empty()) {   // restore the round-0 descriptors a previous execute's retry rounds replaced
+        if (!h->dirty.empty()) {   // restore the round-0 descriptors and levels a previous execute's retry rounds replaced
             hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(h->descs.size())), dim3(256), 0, st, h->plan0.d_descs,
                                int(h->descs.size()), h->d_descs);
+            for (int32_t a : h->dirty) h->level[size_t(a)] = h->level0[size_t(a)];     // (every level change goes through a plan)
             h->dirty.clear();
         }
         // (measured: without one blocking call here the runtime does not start this call's submissions for 0.1 - 2 s when the
@@ -2208,13 +2211,12 @@ struct Exec {
         }
         int rc = VPR_OK;
         h->resident.clear();
-        h->level = h->level0;
+        h->res0_cnt = 0;
         if (h->cfg.band_mode == 0) {
             if ((rc = run_dense(h->plan0, h->plan0.d_work, st, false))) return rc;
             if (!h->plan0.chunks.empty()) {
                 const Chunk &c = h->plan0.chunks.back();
-                h->resident.emplace_back(std::vector<int32_t>(h->plan0.work.begin() + c.work_off,
-                                                              h->plan0.work.begin() + c.work_off + c.count), h->plan0.arena);
+                h->res0_off = c.work_off; h->res0_cnt = c.count;
             }
         } else if ((rc = round0_windowed())) {
             return rc;
@@ -2429,8 +2431,13 @@ int64_t vpr_download_path(const vpr_handle *h, int32_t sc, int32_t aln, int64_t 
     // retry plans are still resident (the most recent plan of an alignment holds its final walk)
     const int32_t a = sc * 4 + aln;
     const uint8_t *arena = nullptr;
-    for (auto it = h->resident.rbegin(); it != h->resident.rend(); ++it)
-        if (std::find(it->first.begin(), it->first.end(), a) != it->first.end()) { arena = it->second; break; }
+    bool found = false;
+    for (auto it = h->resident.rbegin(); it != h->resident.rend() && !found; ++it)
+        if (std::find(it->first.begin(), it->first.end(), a) != it->first.end()) { arena = it->second; found = true; }
+    if (!found && h->res0_cnt > 0) {
+        const int64_t pos = h->plan0_pos[size_t(a)];
+        if (pos >= h->res0_off && pos < h->res0_off + h->res0_cnt) arena = h->plan0.arena;
+    }
     if (!arena) return VPR_ERR_STATE;
     AlnOut O;
     AlnDesc d;
