@@ -405,10 +405,15 @@ __global__ void __launch_bounds__(256) k_stage(const AlnDesc *__restrict__ src, 
     if (base >= n) return;
     const int cnt = min(64, n - base);
     const uint2 *s4 = reinterpret_cast<const uint2 *>(src + base);
+    uint2 r[W16];                                       // (all reads in flight before the first use: each is a trip over the link)
+#pragma unroll
     for (int k = 0; k < W16; k++) {
         const int w = k * 64 + lane;
-        if (w < cnt * W16) buf[wv][w] = s4[w];
+        r[k] = make_uint2(0u, 0u);
+        if (w < cnt * W16) r[k] = s4[w];
     }
+#pragma unroll
+    for (int k = 0; k < W16; k++) buf[wv][k * 64 + lane] = r[k];
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     if (lane < cnt) {
