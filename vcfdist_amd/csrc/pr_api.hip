@@ -391,36 +391,16 @@ __global__ void k_publish_fails(const int32_t *__restrict__ list, const int32_t 
 
 // Stage a retry plan from host-pinned memory in one launch: descriptors scattered to their alignment's slot, the work
 // list copied, the ladder's fail counters cleared (n_zero > 0 on the first plan of a round).
-// (`src` is host memory read over the link: a wave fetches its 64 descriptors as 8-byte words in linear order and hands
-// them out through LDS -- with one whole descriptor per thread the reads were strided, 36 ms for 10 MB)
-static_assert(sizeof(AlnDesc) % 8 == 0, "k_stage copies descriptors as 8-byte words");
-__global__ void __launch_bounds__(256) k_stage(const AlnDesc *__restrict__ src, const int32_t *__restrict__ src_work, int n, AlnDesc *__restrict__ dst,
-                                               int32_t *__restrict__ dst_work, int32_t *__restrict__ zero, int n_zero) {
-    constexpr int W16 = int(sizeof(AlnDesc) / 8);
-    __shared__ uint2 buf[4][64 * W16];
+__global__ void k_stage(const AlnDesc *__restrict__ src, const int32_t *__restrict__ src_work, int n, AlnDesc *__restrict__ dst,
+                        int32_t *__restrict__ dst_work, int32_t *__restrict__ zero, int n_zero) {
+    // (one descriptor per thread, read straight from host memory.  Beside the bulk kernels a launch takes 1 - 6 ms, and just
+    // as long when a wave fetches its 64 descriptors in linear order through LDS: it waits for workgroup slots, not for the link)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (i < n_zero) zero[i] = 0;
-    const int base = (blockIdx.x * 4 + wv) * 64;       // the wave's first descriptor
-    if (base >= n) return;
-    const int cnt = min(64, n - base);
-    const uint2 *s4 = reinterpret_cast<const uint2 *>(src + base);
-    uint2 r[W16];                                       // (all reads in flight before the first use: each is a trip over the link)
-#pragma unroll
-    for (int k = 0; k < W16; k++) {
-        const int w = k * 64 + lane;
-        r[k] = make_uint2(0u, 0u);
-        if (w < cnt * W16) r[k] = s4[w];
-    }
-#pragma unroll
-    for (int k = 0; k < W16; k++) buf[wv][k * 64 + lane] = r[k];
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    if (lane < cnt) {
-        const AlnDesc d = reinterpret_cast<const AlnDesc *>(buf[wv])[lane];
-        dst[d.sc * 4 + d.aln] = d;
-        dst_work[base + lane] = src_work[base + lane];
-    }
+    if (i >= n) return;
+    const AlnDesc d = src[i];
+    dst[d.sc * 4 + d.aln] = d;
+    dst_work[i] = src_work[i];
 }
 
 // alignments the backward sweeps left to the tie pass: {alignment, level tag} (AlnOut::band_ok = TIE_MARK(tag))
