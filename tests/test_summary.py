@@ -85,3 +85,21 @@ def test_phase_rejects_an_unknown_phase_value():
             S.phase([0, 3, 1], [0, 0, 0], L=L, prefix=pre)
     pb, sw, fl = S.phase([], [])
     assert len(pb) == 0 and len(sw) == 0 and len(fl) == 0
+
+
+def test_var_class_helper_matches_the_numpy_rule():
+    """vpr_var_class (host helper of the C ABI) against summary.var_class, print.cpp:362-372"""
+    import ctypes as C
+    from vcfdist_amd import api
+    rng = np.random.RandomState(5)
+    n = 5000
+    t = rng.randint(1, 4, size=n).astype(np.uint8)
+    rl = rng.choice([0, 1, 2, 49, 50, 51, 400], size=n).astype(np.int32)
+    al = rng.choice([0, 1, 2, 49, 50, 51, 400], size=n).astype(np.int32)
+    L = api.lib()
+    L.vpr_var_class.restype = None
+    L.vpr_var_class.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    for thr in (50, 2, 1000):
+        out = np.zeros(n, np.uint8)
+        L.vpr_var_class(t.ctypes.data, rl.ctypes.data, al.ctypes.data, n, thr, out.ctypes.data)
+        assert np.array_equal(out, S.var_class(t, rl, al, thr))
