@@ -4,8 +4,9 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`, one process per GPU
 (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE), rank 0 prints ONE JSON line.
 
-A "step" is one pass of the hot path (K1 forward sweep, K2 backward sweep, K3 walk +
-credit sections, K4 section edit distances, result download + float finalisation)
+A "step" is one pass of the hot path (K1 forward sweep, K2 backward sweep incl. the replay of the
+reference's container order where swap predecessors tie, K3 walk + credit sections, K4 section edit
+distances, K5 finalisation; result download; device histogram + all-reduce of the counters)
 over one batch of synthetic superclusters that is already resident in HBM.
 
 Workload (config.workload = "wgs_synth"): BASELINE.json configs[1] (HG002 WGS small
@@ -16,7 +17,13 @@ sites, 80 % SNP, 70 % homozygous, truth = query kept/dropped/perturbed 0.9/0.05/
 the same number of superclusters with a rank-specific seed (weak scaling: superclusters
 are independent, no data-path collective); the precision/recall counters of SURVEY 8(e),
 counts[callset][SNP,INDEL,SV,ALL][TP,FP,FN][61 quality thresholds] (int64, computed on the
-device), are summed with one all-reduce (RCCL) at the end of every step.
+device), are summed with one all-reduce (RCCL) at the end of every step.  `--scaling strong`
+deals one synthetic genome over the ranks instead (vcfdist_amd/shard.py), `--workload
+stress_synth | sv_synth` select BASELINE configs[4] (125 000 superclusters per GPU) and an
+emulation of configs[2].  The line also carries `roofline` (counter-based HBM fraction and VALU
+issue fraction of the dominant sweep kernel), `cpu_baseline` (the CPU port
+on the host cores, with its calibration against the reference's published timings),
+`step_parts_ms` and `setup_not_timed` (upload, one-shot rate).
 """
 import argparse
 import ctypes as C
