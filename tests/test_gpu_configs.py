@@ -44,6 +44,19 @@ def test_tie_replay_second_attempt_with_worst_case_logs():
     assert n_nonmax > 5 and pr.timing().n_tie_replays > n_tie     # (> : second attempts are counted)
 
 
+def test_many_ties_met_by_a_retry_round():
+    """dense variants in repeats, short haps: most alignments are retried at 64 cells and a third of those meet a tie there,
+    i.e. one retry round hands hundreds of alignments to a tie round (tests/fuzz_chain.py seed 9362: the retry ladders'
+    regions of the tie list buffer overlapped its end, and whatever was allocated behind it lost its contents)"""
+    for seed in (9362, 9363):
+        syn = api.Synth(n_sc=320, len_mode=1, len_a=200.0, len_b=0.4, len_min=8, len_max=583, seed=seed, p_repeat=0.9,
+                        var_per_base=0.05, p_snp=0.30, indel_mean=4.1)
+        got, want, n_nonmax, pr = compare(syn.batch())
+        t = pr.timing()
+        print(f"seed {seed}: {t.n_band_retries} retries, {t.n_tie_replays} tie replays, {n_nonmax} decided other than by the largest source")
+        assert t.n_tie_replays > 250 and t.n_band_retries > 1500
+
+
 def test_ties_in_long_alignments_and_retried_ones():
     """long alignments (one wave each, speculative replays behind the forward sweep) and alignments the retry ladders
     accepted at a wider window (their ties are collected behind the ladder round's backward sweep)"""

@@ -380,6 +380,34 @@ class Results:
     def for_batch(cls, batch, host_alloc=None, host_free=None):
         return cls(batch.n_sc, [batch.n_vars(h) for h in range(HAPS)], host_alloc, host_free)
 
+    @classmethod
+    def mirror(cls, s, n_sc, n_vars, block, host_free):
+        """Results whose arrays are views into ONE page-locked block laid out like the device's result columns
+        (vpr_results_alloc filled the struct `s`): vpr_download then moves everything with a single copy.  Every array keeps
+        the block alive."""
+        self = cls.__new__(cls)
+        self.n_sc = n_sc
+        owner = _HostBlock(block, host_free)
+
+        def view(p, n, dt):
+            n = int(n)
+            if n == 0:
+                return np.zeros(0, dt)
+            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(C.cast(p, C.c_void_p).value)
+            buf._block = owner
+            return np.frombuffer(buf, dtype=dt, count=n)
+        self.aln_dist = view(s.aln_dist, n_sc * 4, np.int32)
+        self.aln_end_plane = view(s.aln_end_plane, n_sc * 4, np.uint8)
+        self.aln_beg_plane = view(s.aln_beg_plane, n_sc * 4, np.uint8)
+        self.aln_status = view(s.aln_status, n_sc * 4, np.uint32)
+        self.sc_phase = view(s.sc_phase, n_sc, np.int32)
+        self.orig_phase_dist = view(s.orig_phase_dist, n_sc, np.int32)
+        self.swap_phase_dist = view(s.swap_phase_dist, n_sc, np.int32)
+        for name, dt in cls.PER_VAR:
+            field = getattr(s, name)
+            setattr(self, name, [[view(field[h][w], n_vars[h], dt) for w in range(2)] for h in range(HAPS)])
+        return self
+
     def as_struct(self):
         s = VprResults()
         s.aln_dist = _ptr(self.aln_dist, C.c_int32)

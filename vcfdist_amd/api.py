@@ -59,6 +59,7 @@ def lib():
     L.vpr_host_alloc.restype = C.c_void_p
     L.vpr_host_alloc.argtypes = [C.c_size_t]
     L.vpr_host_free.argtypes = [C.c_void_p]
+    L.vpr_results_alloc.argtypes = [H, C.POINTER(A.VprResults), C.POINTER(C.c_void_p)]
     L.vpr_get_timing.argtypes = [H, C.POINTER(A.VprTiming)]
     L.vpr_get_launch_stats.argtypes = [H, C.POINTER(A.VprLaunchStat), C.c_int32]
     L.vpr_get_tally.argtypes = [H, C.POINTER(C.c_int64)]
@@ -83,7 +84,7 @@ EXPORTED = [
     "vpr_create", "vpr_destroy", "vpr_last_error", "vpr_version", "vpr_run", "vpr_upload",
     "vpr_upload_variants", "vpr_execute", "vpr_download", "vpr_host_alloc", "vpr_host_free", "vpr_get_timing", "vpr_get_launch_stats",
     "vpr_get_tally",
-    "vpr_download_path", "vpr_phase", "vpr_var_class", "vpr_upload_var_class", "vpr_pr_counts", "vpr_pr_summary",
+    "vpr_download_path", "vpr_phase", "vpr_var_class", "vpr_upload_var_class", "vpr_results_alloc", "vpr_pr_counts", "vpr_pr_summary",
     "vpr_store_phase", "vpr_batch_from_variants", "vpr_owned_batch_view", "vpr_owned_batch_free",
     "vpr_synth_default_params", "vpr_synth_create", "vpr_synth_variants", "vpr_synth_destroy",
 ]
@@ -231,7 +232,13 @@ class PrecisionRecall:
         buffers (every field is overwritten), which avoids re-allocating hundreds of MB per call."""
         if res is None:       # page-locked buffers: the copies then run at the link rate
             L = lib()
-            res = A.Results.for_batch(self._batch, L.vpr_host_alloc, L.vpr_host_free)
+            s = A.VprResults()
+            blk = C.c_void_p()
+            # one block laid out like the device's result columns: a single copy per download
+            if L.vpr_results_alloc(self._h, C.byref(s), C.byref(blk)) == 0 and blk.value:
+                res = A.Results.mirror(s, self._batch.n_sc, [self._batch.n_vars(h) for h in range(A.HAPS)], blk.value, L.vpr_host_free)
+            else:
+                res = A.Results.for_batch(self._batch, L.vpr_host_alloc, L.vpr_host_free)
         s = res.as_struct()
         self._chk(lib().vpr_download(self._h, C.byref(s)), "vpr_download")
         return res

@@ -145,6 +145,8 @@ struct vpr_handle {
     int64_t last_need = 0;               // workspace bytes of the alignment make_plan could not place
     uint8_t *d_cls[4] = {nullptr, nullptr, nullptr, nullptr};   // SNP / INDEL / SV class of every variant (vpr_upload_var_class)
     int2 *hp_dspan[4] = {nullptr, nullptr, nullptr, nullptr};   // host copy of DevBatch::dspan (page-locked)
+    uint8_t *res_dev = nullptr; size_t res_bytes = 0;           // the device region of the result columns (vpr_upload)
+    uint8_t *res_mirror = nullptr;                              // the caller's block that mirrors it (vpr_results_alloc), if any
     unsigned long long *d_hist = nullptr;   // vpr_pr_counts: histogram words (batch lifetime, grown on demand)
     size_t hist_cap = 0;
     int32_t *d_pb = nullptr;                // vpr_pr_counts: the caller's phase-block phasing per supercluster
@@ -262,6 +264,7 @@ void free_batch(vpr_handle *h) {
     h->pinned.clear();
     h->hp_fail = nullptr; h->hp_cnt = nullptr; h->hp_flag = nullptr;
     for (int s = 0; s < 4; s++) h->hp_dspan[s] = nullptr;
+    h->res_dev = nullptr; h->res_bytes = 0; h->res_mirror = nullptr;     // (a mirror block belongs to the caller: it just stops matching)
     h->events.clear();
     h->descs.clear();
     h->plan0 = Plan();
@@ -960,28 +963,38 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         const float *vq = nullptr;
         if ((rc = dev_upload(h, &vq, b->var_qual[s], size_t(h->n_var[s])))) return rc;
         R.var_qual[s] = vq;
-        for (int w = 0; w < 2; w++) {
-            const size_t nv = size_t(h->n_var[s]);
-            if ((rc = dev_alloc(h, &R.v[s][w].errtype, nv))) return rc;
-            if ((rc = dev_alloc(h, &R.v[s][w].sync_group, nv))) return rc;
-            if ((rc = dev_alloc(h, &R.v[s][w].credit, nv))) return rc;
-            if ((rc = dev_alloc(h, &R.v[s][w].ref_ed, nv))) return rc;
-            if ((rc = dev_alloc(h, &R.v[s][w].query_ed, nv))) return rc;
-            if ((rc = dev_alloc(h, &R.v[s][w].callq, nv))) return rc;
+    }
+    // every column vpr_download returns lives in ONE device region (256-byte aligned pieces), so that a caller whose
+    // result block mirrors it (vpr_results_alloc) gets everything with a single copy
+    {
+        uint8_t *base = nullptr;
+        size_t off = 0;
+        auto place = [&](auto *&p, size_t cnt) {
+            using T = std::remove_reference_t<decltype(*p)>;
+            if (base) p = reinterpret_cast<T *>(base + off);
+            off += (std::max<size_t>(cnt, 1) * sizeof(T) + 255) & ~size_t(255);
+        };
+        for (int pass = 0; pass < 2; pass++) {
+            off = 0;
+            for (int s = 0; s < 4; s++)
+                for (int w = 0; w < 2; w++) {
+                    const size_t nv = size_t(h->n_var[s]);
+                    place(R.v[s][w].errtype, nv); place(R.v[s][w].sync_group, nv); place(R.v[s][w].credit, nv);
+                    place(R.v[s][w].ref_ed, nv); place(R.v[s][w].query_ed, nv); place(R.v[s][w].callq, nv);
+                }
+            place(R.aln_dist, na); place(R.aln_end_plane, na); place(R.aln_beg_plane, na); place(R.aln_status, na);
+            place(R.sc_phase, size_t(n)); place(R.orig_phase_dist, size_t(n)); place(R.swap_phase_dist, size_t(n));
+            if (pass == 0) {
+                if ((rc = dev_alloc(h, &base, off))) return rc;
+                h->res_dev = base; h->res_bytes = off;
+            }
         }
     }
-    if ((rc = dev_alloc(h, &R.aln_dist, na))) return rc;
-    if ((rc = dev_alloc(h, &R.aln_end_plane, na))) return rc;
-    if ((rc = dev_alloc(h, &R.aln_beg_plane, na))) return rc;
-    if ((rc = dev_alloc(h, &R.aln_status, na))) return rc;
-    if ((rc = dev_alloc(h, &R.sc_phase, size_t(n)))) return rc;
-    if ((rc = dev_alloc(h, &R.orig_phase_dist, size_t(n)))) return rc;
-    if ((rc = dev_alloc(h, &R.swap_phase_dist, size_t(n)))) return rc;
     if ((rc = dev_alloc(h, &R.tally, 6))) return rc;
     R.max_qual = h->cfg.max_qual;
     R.credit_threshold = h->cfg.credit_threshold;
     R.phase_threshold = h->cfg.phase_threshold;
-    h->tie_list_cap = int32_t(std::min<size_t>(std::max<size_t>(na, 1), size_t(1) << 20));
+    h->tie_list_cap = int32_t(std::min<size_t>(std::max<size_t>(na, 4096), size_t(1) << 20));
     if ((rc = dev_alloc(h, &h->d_tie_list, size_t(h->tie_list_cap)))) return rc;
     if ((rc = dev_alloc(h, &h->d_tie_cnt, 8))) return rc;
     if ((rc = dev_alloc(h, &h->d_tie_ndec, TIE_DEC_SLOTS))) return rc;
@@ -1582,9 +1595,12 @@ struct Exec {
         return VPR_OK;
     }
 
-    int lad_tie_off(int k) { return h->tie_list_cap / 2 + k * (h->tie_list_cap / 8 * 3); }
+    // (regions of the tie list buffer: [0, 1/2) round 0 -- tie_off / tie_cap --, [1/2, 3/4) and [3/4, 1) the two retry ladders.
+    //  Until the end of round 2 ladder 1's region ran to 5/4 of the buffer: more than cap / 8 marked alignments from one
+    //  retry round wrote behind it; found by the chain fuzzer once the pooled allocator had put other arrays there)
+    int lad_tie_off(int k) { return h->tie_list_cap / 2 + k * (h->tie_list_cap / 4); }
 
-    int lad_tie_cap(int k) { (void)k; return h->tie_list_cap / 8 * 3; }
+    int lad_tie_cap(int k) { (void)k; return h->tie_list_cap / 4; }
 
     void ladder_collect(int k, const int32_t *list, int32_t n, hipStream_t ks) {
         hipLaunchKernelGGL(k_collect_ties_list, blocks(n), dim3(256), 0, ks, list, n, h->d_outs, h->d_tie_list + lad_tie_off(k),
@@ -2254,6 +2270,24 @@ int vpr_download(vpr_handle *h, vpr_results *res) {
     auto get = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
         return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
     };
+    if (h->res_mirror && h->res_bytes) {       // a block of vpr_results_alloc: one copy when every pointer is the mirror's
+        auto at = [&](const void *dst, const void *src) {
+            return static_cast<const uint8_t *>(dst) - h->res_mirror == static_cast<const uint8_t *>(src) - h->res_dev;
+        };
+        bool all = at(res->aln_dist, R.aln_dist) && at(res->aln_end_plane, R.aln_end_plane) && at(res->aln_beg_plane, R.aln_beg_plane) &&
+                   at(res->aln_status, R.aln_status) && at(res->sc_phase, R.sc_phase) && at(res->orig_phase_dist, R.orig_phase_dist) &&
+                   at(res->swap_phase_dist, R.swap_phase_dist);
+        for (int s = 0; s < 4 && all; s++)
+            for (int w = 0; w < 2; w++)
+                all = all && at(res->errtype[s][w], R.v[s][w].errtype) && at(res->sync_group[s][w], R.v[s][w].sync_group) &&
+                      at(res->credit[s][w], R.v[s][w].credit) && at(res->ref_ed[s][w], R.v[s][w].ref_ed) &&
+                      at(res->query_ed[s][w], R.v[s][w].query_ed) && at(res->callq[s][w], R.v[s][w].callq);
+        if (all) {
+            HIPCHK(h, get(h->res_mirror, h->res_dev, h->res_bytes));
+            HIPCHK(h, hipStreamSynchronize(st));
+            return VPR_OK;
+        }
+    }
     if (na) {
         HIPCHK(h, get(res->aln_dist, R.aln_dist, na * 4));
         HIPCHK(h, get(res->aln_end_plane, R.aln_end_plane, na));
@@ -2275,6 +2309,38 @@ int vpr_download(vpr_handle *h, vpr_results *res) {
         }
     }
     HIPCHK(h, hipStreamSynchronize(st));
+    return VPR_OK;
+}
+
+int vpr_results_alloc(vpr_handle *h, vpr_results *res, void **block) {
+    if (!h || !res || !block) return VPR_ERR_ARG;
+    if (!h->uploaded || !h->res_dev) return fail(h, VPR_ERR_STATE, "vpr_results_alloc before vpr_upload");
+    void *p = nullptr;
+    if (hipHostMalloc(&p, h->res_bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(h, VPR_ERR_NOMEM, "vpr_results_alloc: %zu page-locked bytes", h->res_bytes);
+    }
+    uint8_t *m = static_cast<uint8_t *>(p);
+    const DevResults &R = h->dR;
+    auto mir = [&](const void *dev) { return m + (static_cast<const uint8_t *>(dev) - h->res_dev); };
+    res->aln_dist = reinterpret_cast<int32_t *>(mir(R.aln_dist));
+    res->aln_end_plane = reinterpret_cast<uint8_t *>(mir(R.aln_end_plane));
+    res->aln_beg_plane = reinterpret_cast<uint8_t *>(mir(R.aln_beg_plane));
+    res->aln_status = reinterpret_cast<uint32_t *>(mir(R.aln_status));
+    res->sc_phase = reinterpret_cast<int32_t *>(mir(R.sc_phase));
+    res->orig_phase_dist = reinterpret_cast<int32_t *>(mir(R.orig_phase_dist));
+    res->swap_phase_dist = reinterpret_cast<int32_t *>(mir(R.swap_phase_dist));
+    for (int s = 0; s < 4; s++)
+        for (int w = 0; w < 2; w++) {
+            res->errtype[s][w] = reinterpret_cast<uint8_t *>(mir(R.v[s][w].errtype));
+            res->sync_group[s][w] = reinterpret_cast<int32_t *>(mir(R.v[s][w].sync_group));
+            res->credit[s][w] = reinterpret_cast<float *>(mir(R.v[s][w].credit));
+            res->ref_ed[s][w] = reinterpret_cast<int32_t *>(mir(R.v[s][w].ref_ed));
+            res->query_ed[s][w] = reinterpret_cast<int32_t *>(mir(R.v[s][w].query_ed));
+            res->callq[s][w] = reinterpret_cast<float *>(mir(R.v[s][w].callq));
+        }
+    h->res_mirror = m;
+    *block = p;
     return VPR_OK;
 }
 
