@@ -159,6 +159,8 @@ typedef struct vpr_config {
 #define VPR_CFG_DENSE_S16 1     /* test aid: the dense backward sweep always uses its int16 score rows */
 #define VPR_CFG_TIE_SMALL_LOGS 2 /* test aid: the container-order replays start with 32-entry FIFO logs, so that they overflow
                                    and the second attempt (worst-case logs) has to decide the ties */
+#define VPR_CFG_GUARD_ALLOC 4   /* test aid: every device array gets an allocation of its own instead of a slice of a pooled
+                                   block, so that an access far behind an array faults instead of reading its neighbour */
 
 /* Results: the fields precision_recall_wrapper writes in place
    (ctgVariants::{errtypes,sync_group,credit,ref_ed,query_ed,callq}, src/variant.h:49-60;

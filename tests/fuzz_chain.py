@@ -61,7 +61,7 @@ def one(seed):
             raise AssertionError(f"{f.__name__} accepted a region that leaves the contig")
         return sum(c.n for c in cl), 0, -1
     batch = api.batch_from_variants(v2)
-    _, _, ntie, _ = T.compare(batch)
+    _, _, ntie, _ = T.compare(batch, A.default_config(flags=int(os.environ.get("VCFDIST_FUZZ_FLAGS", "0"))))
     return sum(c.n for c in cl), s.n, s.n_oversize
 
 

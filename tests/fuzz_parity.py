@@ -68,7 +68,7 @@ def fuzz(budget_s, seed0, verbose=True, max_batches=None, shape=None):
         shape_, kw, band_mode = random_workload(seed, shape)
         batch = api.Synth(**kw).batch()
         try:
-            got, want, ntie, pr = T.compare(batch, A.default_config(band_mode=band_mode))
+            got, want, ntie, pr = T.compare(batch, A.default_config(band_mode=band_mode, flags=int(os.environ.get("VCFDIST_FUZZ_FLAGS", "0"))))
         except AssertionError as e:
             raise AssertionError(f"fuzz mismatch: seed {seed} band_mode {band_mode} kw {kw}: {e}") from e
         except api.VprError as e:

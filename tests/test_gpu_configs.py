@@ -57,6 +57,19 @@ def test_many_ties_met_by_a_retry_round():
         assert t.n_tie_replays > 250 and t.n_band_retries > 1500
 
 
+def test_guarded_allocations_no_access_behind_an_array():
+    """every device array in an allocation of its own (VPR_CFG_GUARD_ALLOC): a write or read far behind an array is a GPU
+    fault here, not a silent hit on whatever the pooled allocator placed there.  Tie-rich retries, long alignments, a
+    WGS-like mix."""
+    cfg = A.default_config(flags=A.CFG_GUARD_ALLOC)
+    for kw in (dict(n_sc=320, len_mode=1, len_a=200.0, len_b=0.4, len_min=8, len_max=583, seed=9364, p_repeat=0.9, var_per_base=0.05,
+                    p_snp=0.30, indel_mean=4.1),
+               dict(n_sc=60, len_a=520, len_b=1400, len_min=520, len_max=1400, seed=44, var_per_base=0.03, p_snp=0.3, p_repeat=1.0,
+                    indel_mean=6.0, p_keep=0.7, p_drop=0.15),
+               dict(n_sc=3000, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=10000, seed=11)):
+        compare(api.Synth(**kw).batch(), cfg)
+
+
 def test_ties_in_long_alignments_and_retried_ones():
     """long alignments (one wave each, speculative replays behind the forward sweep) and alignments the retry ladders
     accepted at a wider window (their ties are collected behind the ladder round's backward sweep)"""

@@ -224,6 +224,14 @@ int dev_alloc(vpr_handle *h, T **p, size_t n) {
     *p = nullptr;
     if (n == 0) n = 1;
     const size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+    if (h->cfg.flags & VPR_CFG_GUARD_ALLOC) {      // debugging aid: every array its own allocation (an access far behind one faults)
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) return fail(h, VPR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        h->allocs.push_back(q);
+        *p = static_cast<T *>(q);
+        return VPR_OK;
+    }
     if (bytes > h->pool_left) {
         // a new block: the request alone when it is large (the remainder of the old block stays usable for nothing: blocks
         // double, so at most half of what was allocated is ever lost), else the next pool size
