@@ -104,3 +104,50 @@ def test_command_line_on_demo_files(tmp_path, capsys):
     assert got[:1] + got[2:] == want[:1] + want[2:]      # all but the ##fileDate line
     # the summary rows of the TSV carry the published SNP numbers
     assert "SNP\tNONE\t0\t8222\t8222\t1\t2\t0.999757\t0.999878\t0.999818\t37.388565\n" in rd("precision-recall-summary.tsv")
+
+
+@pytest.mark.gpu
+def test_command_line_two_ranks_deal_contigs(tmp_path):
+    """two contigs (the demo callsets twice, as chr1 and chr2) through the command line as one process and as two ranks
+    under torch.distributed.run (both on the one GPU of the test box, gloo): contigs dealt over the ranks, counters
+    all-reduced, per-contig tables gathered on rank 0 -- the files must be the same"""
+    import gzip
+    import os
+    import socket
+    import subprocess
+    import sys
+    seq = bytes(D.surrogate_fasta(5_100_000)).decode()
+    fa = tmp_path / "two.fa"
+    with open(fa, "w") as fh:
+        for c in ("chr1", "chr2"):
+            fh.write(f">{c}\n")
+            for i in range(0, len(seq), 100000):
+                fh.write(seq[i:i + 100000] + "\n")
+
+    def twice(lines):
+        head = [l for l in lines if l.startswith("#")]
+        body = [l for l in lines if l and not l.startswith("#")]
+        head = [l for l in head if not l.startswith("##contig")] or head
+        ctg = ["##contig=<ID=chr1,length=5100000>", "##contig=<ID=chr2,length=5100000>"]
+        return "\n".join(head[:1] + ctg + head[1:] + body + ["chr2" + l[4:] for l in body if l.startswith("chr1\t")]) + "\n"
+    qv, tv, bed = tmp_path / "q.vcf", tmp_path / "t.vcf", tmp_path / "r.bed"
+    qv.write_text(twice(open(os.path.join(D.DEMO, "query.vcf")).read().split("\n")))
+    tv.write_text(twice(gzip.open(os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.vcf.gz"), "rt").read().split("\n")))
+    b = [l for l in open(os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.bed")).read().split("\n") if l]
+    bed.write_text("\n".join(b + ["chr2" + l[4:] for l in b]) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), VCFDIST_ONE_GPU="1")
+    base = [str(qv), str(tv), str(fa), "-b", str(bed)]
+    (tmp_path / "one").mkdir(); (tmp_path / "two").mkdir()
+    subprocess.run([sys.executable, "-m", "vcfdist_amd"] + base + ["-p", str(tmp_path / "one") + "/"], check=True, env=env, cwd=root,
+                   stdout=subprocess.DEVNULL, timeout=600)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), "-m", "vcfdist_amd"] + base + ["-p", str(tmp_path / "two") + "/"], check=True, env=env,
+                   cwd=root, stdout=subprocess.DEVNULL, timeout=900)
+    for name in ("precision-recall.tsv", "precision-recall-summary.tsv", "phase-blocks.tsv", "superclusters.tsv", "query.tsv", "truth.tsv"):
+        one, two = (tmp_path / "one" / name).read_bytes(), (tmp_path / "two" / name).read_bytes()
+        assert one == two and len(one) > 100, name
+    assert b"chr2" in (tmp_path / "two" / "query.tsv").read_bytes()

@@ -185,12 +185,15 @@ def main(argv=None):
     import os
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     device = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    one_gpu = bool(os.environ.get("VCFDIST_ONE_GPU"))      # plumbing check on a one-GPU box: every rank uses device 0, gloo
+    if one_gpu and args.device is None:
+        device = 0
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if torch.cuda.is_available() and torch.cuda.device_count() > device else "gloo"
+        backend = "nccl" if not one_gpu and torch.cuda.is_available() and torch.cuda.device_count() > device else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(device)
         dist.init_process_group(backend=backend)
