@@ -173,3 +173,35 @@ def test_transfer_phase_sets_matches_the_reference_walk():
             offs.append(off); slots.append(dict(pos=pos, phase_set=ps))
         sc = SC(offs)
         assert np.array_equal(transfer_phase_sets(slots, None, sc), walk(slots, sc)), trial
+
+
+def _build_caller(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "caller")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "caller.cpp"),
+                    "-L", os.path.join(ROOT, "vcfdist_amd", "lib"), "-lvcfdist_pr", "-Wl,-rpath," + os.path.join(ROOT, "vcfdist_amd", "lib"),
+                    "-o", exe], check=True)
+    return exe
+
+
+def test_compiled_cpp_caller_builds_and_refuses_without_a_gpu(tmp_path):
+    """examples/caller.cpp (a plain g++ program against include/vcfdist_pr.h + the shared library): builds, and without a
+    HIP device stops at vpr_create with the library's "no CPU fallback" error; on a GPU box it prints the known answer"""
+    import subprocess
+    api.build()
+    r = subprocess.run([_build_caller(tmp_path)], capture_output=True, text=True, timeout=120)
+    if r.returncode == 2:
+        assert "no CPU fallback" in r.stderr
+    else:
+        assert r.returncode == 0 and "alignment 0: s 0 end plane QUERY" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_compiled_cpp_caller_known_answer(tmp_path):
+    """the reference-produced toy vector through a compiled C++ caller of the C ABI"""
+    import subprocess
+    r = subprocess.run([_build_caller(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for i in range(4):
+        assert f"alignment {i}: s 0 end plane QUERY" in r.stdout
+    assert "hap slot 2 variant 0: TP" in r.stdout
