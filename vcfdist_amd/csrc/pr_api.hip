@@ -559,13 +559,13 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             L.band_w = 16;
             L.pitch0 = L.pitch1 = 16;
             L.m0 = nstr * 128; L.m1 = 0;
-            L.bl = round_up(nstr * 8, 64);
+            L.bl = round_up(nstr * 8, 128);
         } else if (W) {
             L.band_w = W;
             L.pitch0 = int32_t(round_up(std::min(W, d.Lq), 16));
             L.pitch1 = int32_t(round_up(std::min(W, d.Lr), 16));
-            L.m0 = round_up(int64_t(L.pitch0) * d.Lt, 64); L.m1 = round_up(int64_t(L.pitch1) * d.Lt, 64);
-            L.bl = round_up(int64_t(2) * d.Lt * 4, 64);
+            L.m0 = round_up(int64_t(L.pitch0) * d.Lt, 128); L.m1 = round_up(int64_t(L.pitch1) * d.Lt, 128);
+            L.bl = round_up(int64_t(2) * d.Lt * 4, 128);
         } else {
             L.band_w = 0;
             L.pitch0 = int32_t(round_up(d.Lq, 32));
@@ -574,11 +574,13 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             // (the backward kernel's int32 score rows may not fit: it then runs with int16 rows, 4 B per cell)
             L.too_long = cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX ||
                          (bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX && (!s16_ok(d) || bwd_lds_bytes(cls, d.Lq, d.Lr, true) > LDS_MAX));
-            L.m0 = round_up(int64_t(L.pitch0) * d.Lt, 64); L.m1 = round_up(int64_t(L.pitch1) * d.Lt, 64);
+            L.m0 = round_up(int64_t(L.pitch0) * d.Lt, 128); L.m1 = round_up(int64_t(L.pitch1) * d.Lt, 128);
             L.bl = 0;
         }
-        const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64);   // 16 B per step
-        L.need = L.m0 + L.m1 + L.bl + pb + 64;
+        // (every piece a multiple of 128 bytes: the path block of an alignment starts on a 128-byte line, which the credit
+        // walk's refills rely on -- the path reads past path_cap inside the block's padding)
+        const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)) + 128, 128);   // 16 B per step
+        L.need = L.m0 + L.m1 + L.bl + pb + 128;
         return L;
     };
     // pass 1 (parallel): workspace bytes of every alignment; pass 2 (one thread, 8 bytes per alignment): offsets and the cut
@@ -1056,7 +1058,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
             } else {
                 flags = round_up(round_up(d.Lq, 32) * int64_t(d.Lt), 64) + round_up(round_up(d.Lr, 32) * int64_t(d.Lt), 64);
             }
-            want += flags + round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)), 64) + 64;
+            want += flags + round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)) + 128, 128) + 256;
           }
           wants[size_t(tid)] = want;
         });

@@ -674,9 +674,10 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
         if (cbase + lane_ < n) ccur = path[cbase + lane_];
         if (cbase >= 64) cpre = path[cbase - 64 + lane_];
     }
-    // lane mode: four entries (one 64-byte line of the lane's own stream) per refill, so a line is fetched once
-    // instead of once per entry (thousands of waves in flight thrash L2: PMC showed 5x the path bytes)
-    PathEnt q0 = ccur, q1 = ccur, q2 = ccur, q3 = ccur;
+    // lane mode: eight entries (one 128-byte line of the lane's own stream: path blocks are 128-byte aligned, make_plan) per
+    // refill, so a line is fetched once instead of once per entry or per half (thousands of waves in flight thrash L2: PMC
+    // showed 5x the path bytes with single entries, 3x with 64-byte refills)
+    PathEnt q0 = ccur, q1 = ccur, q2 = ccur, q3 = ccur, q4 = ccur, q5 = ccur, q6 = ccur, q7 = ccur;
     int64_t qbase = int64_t(1) << 60;
     auto fetch = [&](int64_t i) -> PathEnt {
         if (WAVE) {
@@ -694,19 +695,27 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
             return e;
         } else {
             if (i < qbase) {
-                qbase = i & ~int64_t(3);
+                qbase = i & ~int64_t(7);
                 const uint4 *src = reinterpret_cast<const uint4 *>(path + qbase);
-                const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6], v7 = src[7];
                 q0 = PathEnt{v0.x, v0.y, int(v0.z), int(v0.w)};
                 q1 = PathEnt{v1.x, v1.y, int(v1.z), int(v1.w)};
                 q2 = PathEnt{v2.x, v2.y, int(v2.z), int(v2.w)};
                 q3 = PathEnt{v3.x, v3.y, int(v3.z), int(v3.w)};
+                q4 = PathEnt{v4.x, v4.y, int(v4.z), int(v4.w)};
+                q5 = PathEnt{v5.x, v5.y, int(v5.z), int(v5.w)};
+                q6 = PathEnt{v6.x, v6.y, int(v6.z), int(v6.w)};
+                q7 = PathEnt{v7.x, v7.y, int(v7.z), int(v7.w)};
             }
             const int k = int(i - qbase);
             PathEnt e = q0;
             if (k == 1) e = q1;
             if (k == 2) e = q2;
             if (k == 3) e = q3;
+            if (k == 4) e = q4;
+            if (k == 5) e = q5;
+            if (k == 6) e = q6;
+            if (k == 7) e = q7;
             return e;
         }
     };
