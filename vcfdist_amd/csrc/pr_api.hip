@@ -1161,6 +1161,7 @@ struct Exec {
     bool lad_tie_wait[2] = {false, false};         // a retry ladder's tie list is on its way
     std::vector<std::pair<TieJob *, size_t>> tie_job_blocks;   // (debug) the job blocks of this execute
     size_t tie_job_total = 0;
+    int32_t n_jobs_pre = 0; bool n_jobs_final = false;        // deferred edit distances, as read with the final tie pass's count
     // ---- round 0 of a windowed plan
     const Plan &P0;
     const int64_t na_;
@@ -2042,7 +2043,10 @@ struct Exec {
                 hipLaunchKernelGGL(k_collect_ties, blocks(na), dim3(256), 0, st, h->d_outs, na, h->d_tie_list, h->d_tie_cnt, h->tie_list_cap);
                 int32_t n_mark = 0;
                 HIPCHK(h, hipMemcpyAsync(&n_mark, h->d_tie_cnt, 4, hipMemcpyDeviceToHost, st));
+                // (the number of deferred edit distances rides along: when nothing is marked it is final, and K4 needs no wait of its own)
+                HIPCHK(h, hipMemcpyAsync(&n_jobs_pre, h->d_njobs, 4, hipMemcpyDeviceToHost, st));
                 HIPCHK(h, hipStreamSynchronize(st));
+                n_jobs_final = (n_mark == 0);
                 if (n_mark == 0) break;
                 if (iter >= 3) return fail(h, VPR_ERR_STATE, "tie pass: %d alignments still marked after %d attempts", n_mark, iter);
                 const int32_t n = std::min(n_mark, h->tie_list_cap);
@@ -2090,9 +2094,11 @@ struct Exec {
     int deferred_edit_distances() {
         int rc = VPR_OK;
         // K4: deferred section edit distances
-        int32_t n_jobs = 0;
-        HIPCHK(h, hipMemcpyAsync(&n_jobs, h->d_njobs, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
+        int32_t n_jobs = n_jobs_pre;
+        if (!n_jobs_final) {
+            HIPCHK(h, hipMemcpyAsync(&n_jobs, h->d_njobs, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+        }
         n_jobs = std::min(n_jobs, h->jobs_cap);
         if (n_jobs > 0) {
             std::vector<EdJob> jobs(n_jobs);
