@@ -2090,6 +2090,31 @@ struct Exec {
         }
     }
 
+    // (VPR_DEBUG) where the alignments ended up: per final level, how many, their dense cells, and their distances
+    void debug_levels() {
+        if (!h->debug || h->descs.empty()) return;
+        std::vector<AlnOut> outs(h->descs.size());
+        if (hipMemcpy(outs.data(), h->d_outs, outs.size() * sizeof(AlnOut), hipMemcpyDeviceToHost) != hipSuccess) return;
+        static const int32_t edge[6] = {0, 4, 16, 64, 256, 1024};
+        for (int lv = 0; lv <= LV_DENSE; lv++) {
+            int64_t n[7] = {0, 0, 0, 0, 0, 0, 0};
+            double cells[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (size_t a = 0; a < outs.size(); a++) {
+                if (h->level[a] != lv) continue;
+                const AlnDesc &d = h->descs[a];
+                int b = 0;
+                while (b < 6 && outs[a].s > edge[b]) b++;
+                n[b]++;
+                cells[b] += double(d.Lq + d.Lr) * d.Lt;
+            }
+            int64_t tot = 0;
+            for (int b = 0; b < 7; b++) tot += n[b];
+            if (!tot) continue;
+            fprintf(stderr, "[vpr] level %d: %lld alignments; by distance (<=0, <=4, <=16, <=64, <=256, <=1024, more): ", lv, (long long)tot);
+            for (int b = 0; b < 7; b++) fprintf(stderr, "%lld (%.2e cells)%s", (long long)n[b], cells[b], b < 6 ? ", " : "\n");
+        }
+    }
+
     // K4: deferred section edit distances
     int deferred_edit_distances() {
         int rc = VPR_OK;
@@ -2240,6 +2265,7 @@ struct Exec {
         }
         if ((rc = final_tie_pass())) return rc;
         debug_replays();
+        debug_levels();
         lapx("final tie pass done");
         if ((rc = deferred_edit_distances())) return rc;
         return finish();
