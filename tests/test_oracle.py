@@ -117,6 +117,60 @@ def test_dense_model_equals_sparse_oracle(seed, lmax, rate):
                 assert (0 if SC[0][0, 0] >= 0 else 1) == r.aln_beg_plane[aln]
 
 
+def _forward_of(one, aln):
+    ex = O.Extra(one, want=(0, aln), dump_matrices=True)
+    r = O.run(one, extra=ex)
+    qs, ts = aln >> 1, 2 + (aln & 1)
+    Q, T, R = bytes(one.hap_seq[qs]), bytes(one.hap_seq[ts]), bytes(one.ref_seq)
+    Dm, FL, _, _ = M.forward(Q, R, T, one.hap_ptr[qs], one.hap_flag[qs], one.ref_ptr[qs], one.ref_flag[qs], one.hap_flag[ts])
+    n_src = max(len(x) for x in M.swap_sources(one.ref_ptr[qs], one.ref_flag[qs], len(Q)) +
+                M.swap_sources(one.hap_ptr[qs], one.hap_flag[qs], len(R)))
+    return ex, r, Dm, FL, (len(Q), len(R), len(T)), n_src
+
+
+def test_dense_model_equals_sparse_oracle_with_many_swap_sources():
+    """runs of up to seven directly adjacent deletion records: up to eight allowed swap sources on the position behind
+    the run (the library's candidate lists hold four today); the dense formulation still gives the
+    oracle's distance, end plane and flag bytes"""
+    from vcfdist_amd import api
+    import indel_runs
+    B = api.batch_from_variants(indel_runs.indel_run_superclusters(21, n_sc=30))
+    most = 0
+    for sc in range(B.n_sc):
+        one = B.subset([sc])
+        for aln in range(4):
+            ex, r, Dm, FL, (lq, lr, lt), n_src = _forward_of(one, aln)
+            s = min(Dm[0][lq - 1, lt - 1], Dm[1][lr - 1, lt - 1])
+            assert s == r.aln_dist[aln]
+            for pl in range(2):
+                mask = Dm[pl] <= s
+                assert (FL[pl][mask] == ex.flags[pl][mask]).all()
+            most = max(most, n_src)
+    assert most == 8
+
+
+def test_forward_flags_never_hold_substitution_and_swap():
+    """A swap needs equal bases at its target cell (dist.cpp:335-350), and where the bases are equal the diagonal move is a
+    match: PTR_SUB and PTR_SWP_MAT never meet in one flag byte of the reference's forward pass.  (The kernels may
+    therefore reuse one of the two bits when the other is set.)"""
+    from vcfdist_amd import api
+    import indel_runs
+    batches = [api.Synth(n_sc=40, len_a=6, len_b=40, len_min=5, len_max=40, var_per_base=0.2, p_repeat=0.5, p_snp=0.5, seed=9).batch(),
+               api.batch_from_variants(indel_runs.indel_run_superclusters(22, n_sc=20))]
+    cells = 0
+    for B in batches:
+        for sc in range(B.n_sc):
+            one = B.subset([sc])
+            for aln in range(4):
+                ex = O.Extra(one, want=(0, aln), dump_matrices=True)
+                O.run(one, extra=ex)
+                for pl in range(2):
+                    f = ex.flags[pl]
+                    assert not (((f & M.F_SUB) != 0) & ((f & M.F_SWP) != 0)).any()
+                    cells += int((f != 0).sum())
+    assert cells > 10000
+
+
 def test_identical_haps_are_all_tp():
     """truth == query: every alignment has distance 0 (ORIG and SWAP both 0 for homozygous sets),
     every variant TP with credit 1."""
