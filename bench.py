@@ -323,7 +323,7 @@ def main():
                             "note": "reference keeps the last writer of swap_pred (dist.cpp:347,376): replayed on the device, results exact"},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only: the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(batch)
             out["cpu_baseline"]["host"] = f"{os.cpu_count()} logical cores visible"
             try:    # how the port compares with the reference binary: its time on the reference's own demo workloads over the
