@@ -66,9 +66,16 @@ class Bed:
         return BED_BORDER
 
 
-def parse_vcf(path, bed, ctg="chr1"):
+def parse_vcf(path, bed, ctg="chr1", bed_policy="v2.6.4"):
     """variantData::variantData, variant.cpp:556-875, for single-sample diploid records without PS tags.
-    Returns per hap a dict of lists (pos, rlen, type, ref, alt, qual)."""
+    Returns per hap a dict of lists (pos, rlen, type, ref, alt, qual).
+
+    bed_policy "v2.6.4": the reference as it is (variant.cpp:826-840): the ORIGINAL record span (anchor base included) must
+    be INSIDE, BORDER records are dropped.  bed_policy "v2.3": what docs/v2.3.3 and docs/v2.3.4/03-Variant-Filtering.md
+    describe ("Variants on the border of BED regions are currently included (to match with vcfeval)", the anchor base
+    not counted -- changed in v2.4.0, whose page reads "are excluded ... including if the preceding reference base in
+    the VCF overlaps"): the TRIMMED span is tested and BORDER records are kept.  demo/output.txt's FASTA-independent
+    totals are those of the "v2.3" rule (tests/test_demo_known_answer.py)."""
     haps = [dict(pos=[], rlen=[], type=[], ref=[], alt=[], qual=[]) for _ in range(2)]
     prev_end = [-2 * G["cluster_min_gap"]] * 2
     prev_type = [TYPE_SUB] * 2
@@ -134,7 +141,13 @@ def parse_vcf(path, bed, ctg="chr1"):
                 else:
                     typ = TYPE_CPX
             rlen = {TYPE_INS: 0, TYPE_SUB: 1}.get(typ, len(ref))
-            loc = bed.contains(ctg, rpos, rpos + reflen, typ)
+            if bed_policy == "v2.6.4":
+                loc = bed.contains(ctg, rpos, rpos + reflen, typ)
+            else:
+                loc = bed.contains(ctg, pos, pos + rlen, typ)
+                if loc == BED_BORDER:
+                    stats["border_kept"] = stats.get("border_kept", 0) + 1
+                    loc = BED_INSIDE
             if loc != BED_INSIDE:
                 stats["border" if loc == BED_BORDER else "outside"] += 1
                 continue
@@ -170,12 +183,12 @@ def surrogate_fasta(length, seed=0x5eed):
     return seq
 
 
-def run(product, ctg_len=5_100_000, cluster="biwfa"):
+def run(product, ctg_len=5_100_000, cluster="biwfa", bed_policy="v2.6.4"):
     """-> (summary rows, details).  product = False: oracle chain on the CPU; True: HIP library (needs a GPU).
     cluster: "biwfa" (the reference's default) or ("gap", N) for `-c gap N` (simple_cluster, cluster.cpp:826-945)."""
     bed = Bed(os.path.join(DEMO, "nist-v4.2.1_chr1_5Mb.bed"))
-    q, qs = parse_vcf(os.path.join(DEMO, "query.vcf"), bed)
-    t, ts = parse_vcf(os.path.join(DEMO, "nist-v4.2.1_chr1_5Mb.vcf.gz"), bed)
+    q, qs = parse_vcf(os.path.join(DEMO, "query.vcf"), bed, bed_policy=bed_policy)
+    t, ts = parse_vcf(os.path.join(DEMO, "nist-v4.2.1_chr1_5Mb.vcf.gz"), bed, bed_policy=bed_policy)
     fasta = surrogate_fasta(ctg_len)
     slots = [q[0], q[1], t[0], t[1]]
     haps = [K.HapSeq(s["pos"], s["type"], s["ref"], s["alt"]) for s in slots]
@@ -185,7 +198,8 @@ def run(product, ctg_len=5_100_000, cluster="biwfa"):
         cl = [K.wfa_cluster(h, bytes(fasta), sub=G["sub"], open=G["open"], extend=G["extend"], max_cluster_itrs=G["max_cluster_itrs"],
                             reach_min_gap=G["reach_min_gap"], L=lib, prefix=pre)[0] for h in haps]
     else:
-        cl = [K.simple_cluster(h, 0, int(cluster[1]), 0, L=lib, prefix=pre) for h in haps]
+        # simple_cluster adds g.reach_min_gap in both of its merge passes (cluster.cpp:895, 918; globals.h:33)
+        cl = [K.simple_cluster(h, 0, int(cluster[1]), G["reach_min_gap"], L=lib, prefix=pre) for h in haps]
     sc = K.supercluster(haps, cl, G["max_supercluster_size"], L=lib, prefix=pre)
     pool, roff, aoff = [], [], []
     for h in haps:

@@ -3,10 +3,31 @@ nist-v4.2.1_chr1_5Mb.vcf.gz, the BED file and the published result demo/output.t
 VCF/BED front end (tests/demo_pipeline.py) -> biWFA clustering -> superclustering -> precision/recall alignment ->
 phasing -> counters -> summary.
 
-The demo's FASTA is not distributable here, so a seeded surrogate carries the VCFs' REF alleles.  SURVEY.md 8(c)
-records what the *real* reference prints with a surrogate FASTA: the SNP and SV rows of demo/output.txt exactly, the
-INDEL and ALL rows one count lower (indel equivalence depends on the real repeat context).  The oracle chain
-reproduces exactly that."""
+What of demo/output.txt can be checked without the demo's FASTA (not distributable here; a seeded surrogate carries the
+VCFs' REF alleles), and how it comes out:
+
+1. TP + FN per type on the truth side and TP + FP per type on the query side do not depend on the FASTA at all:
+   write_precision_recall counts every parsed hap-variant exactly once at Q >= 0 (print.cpp:342-433).  Published:
+   truth SNP 8222+1, INDEL 876+51 = 927; query SNP 8222+2, INDEL 876+12 = 888.
+2. The front end as v2.6.4 has it (variant.cpp:826-840: the ORIGINAL record span must be INSIDE the BED regions,
+   BORDER records dropped) parses truth INDEL 925 and query INDEL 886: two hap-variants per callset fewer.  They are
+   the record chr1:1722626 AGCG>A (truth 1|1, query 1/1: two hap-variants each), whose deleted bases
+   [1722626, 1722629) straddle the start of the BED region [1722628, 1722830).  demo/output.txt (and README.md:121-137)
+   was produced under the rule docs/v2.3.3 and docs/v2.3.4/03-Variant-Filtering.md describe -- "Variants on the border
+   of BED regions are currently included (to match with vcfeval)", anchor base not counted; v2.4.0 changed it to
+   "excluded ... including if the preceding reference base in the VCF overlaps" -- and was not regenerated.  Under that
+   rule (demo_pipeline.parse_vcf(bed_policy="v2.3")) the other border record, chr1:1706067 ACT>A (1 hap-variant per
+   callset), is OUTSIDE (its deleted bases [1706067, 1706069) lie behind the region end 1706067) and chr1:1722626 is
+   kept: **all eight FASTA-independent totals equal the published file exactly.**
+3. SNP and SV rows: exact under either rule, printed floats included.
+4. INDEL TP/FN and TP/FP split under the published file's rule: 877/50 and 877/11 on the surrogate FASTA against the
+   published 876/51 and 876/12 -- ONE truth and ONE query hap-variant are TP here and FN / FP there.  Which one cannot be
+   told without GRCh38 (indel credit depends on the repeat context around it); it is the only number of output.txt
+   this chain does not reproduce.
+5. Superclusters of `-c gap 50 / 200 / 1000` (clustering and superclustering never read the FASTA): 4 624 / 2 484 / 530,
+   the counts the unmodified reference produced on these files."""
+import os
+
 import numpy as np
 import pytest
 
@@ -18,23 +39,80 @@ def rows_as_dict(rows):
     return {(S.NAMES[r.vartype], "BEST" if r.best else "NONE"): r for r in rows}
 
 
-def test_oracle_chain_reproduces_published_demo_rows():
-    rows, det = D.run(product=False)
+def quad(r):
+    return (r.truth_tp, r.query_tp, r.truth_fn, r.query_fp)
+
+
+def test_parsed_totals_equal_published_fasta_independent_totals():
+    """items 1 and 2 of the module docstring, at the parse stage alone (no alignment involved)"""
+    ka = D.known_answer()
+    bed = D.Bed(os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.bed"))
+
+    def totals(name, policy):
+        haps, st = D.parse_vcf(os.path.join(D.DEMO, name), bed, bed_policy=policy)
+        typ = np.concatenate([np.asarray(h["type"]) for h in haps])
+        big = max(max((len(x) for h in haps for x in h["ref"]), default=0), max((len(x) for h in haps for x in h["alt"]), default=0))
+        assert big < D.G["sv_threshold"]                       # no SV-sized record in the demo: INDEL = every INS / DEL
+        return int((typ == D.TYPE_SUB).sum()), int((typ != D.TYPE_SUB).sum()), st
+    pub_truth = tuple(ka[(t, "NONE")][0] + ka[(t, "NONE")][2] for t in ("SNP", "INDEL"))        # TRUTH_TP + TRUTH_FN
+    pub_query = tuple(ka[(t, "NONE")][1] + ka[(t, "NONE")][3] for t in ("SNP", "INDEL"))        # QUERY_TP + QUERY_FP
+    assert pub_truth == (8223, 927) and pub_query == (8224, 888)
+    assert ka[("ALL", "NONE")][0] + ka[("ALL", "NONE")][2] == sum(pub_truth) and ka[("ALL", "NONE")][1] + ka[("ALL", "NONE")][3] == sum(pub_query)
+    # the rule the published file was produced under: every total exact
+    ts, ti, st_t = totals("nist-v4.2.1_chr1_5Mb.vcf.gz", "v2.3")
+    qs, qi, st_q = totals("query.vcf", "v2.3")
+    assert (ts, ti) == pub_truth and (qs, qi) == pub_query
+    assert st_t["border_kept"] == 2 and st_q["border_kept"] == 2
+    # v2.6.4's rule: the same minus the two hap-variants of chr1:1722626 per callset (3 border hap-variants dropped, one of
+    # which the old rule called OUTSIDE)
+    ts, ti, st_t = totals("nist-v4.2.1_chr1_5Mb.vcf.gz", "v2.6.4")
+    qs, qi, st_q = totals("query.vcf", "v2.6.4")
+    assert (ts, ti) == (pub_truth[0], pub_truth[1] - 2) and (qs, qi) == (pub_query[0], pub_query[1] - 2)
+    assert st_t["border"] == 3 and st_q["border"] == 3
+    for name in ("nist-v4.2.1_chr1_5Mb.vcf.gz", "query.vcf"):
+        new = D.parse_vcf(os.path.join(D.DEMO, name), bed, bed_policy="v2.6.4")[0]
+        old = D.parse_vcf(os.path.join(D.DEMO, name), bed, bed_policy="v2.3")[0]
+        for h in range(2):
+            extra = sorted(set(zip(old[h]["pos"], old[h]["ref"], old[h]["alt"])) - set(zip(new[h]["pos"], new[h]["ref"], new[h]["alt"])))
+            assert extra == [(1722626, "GCG", "")], (name, h, extra)           # 0-based position of the trimmed deletion
+
+
+@pytest.mark.parametrize("gap,n_ref", [(50, 4624), (200, 2484), (1000, 530)])
+def test_gap_clusterings_give_the_reference_supercluster_counts(gap, n_ref):
+    """item 5: `-c gap N` + superclustering on the demo callsets (FASTA-independent); counts measured on the unmodified
+    reference.  reach_min_gap = 10 as in simple_cluster's two merge passes (cluster.cpp:895, 918)."""
+    import oracle_lib as O
+    from vcfdist_amd import cluster as K
+    bed = D.Bed(os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.bed"))
+    q, _ = D.parse_vcf(os.path.join(D.DEMO, "query.vcf"), bed)
+    t, _ = D.parse_vcf(os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.vcf.gz"), bed)
+    haps = [K.HapSeq(s["pos"], s["type"], s["ref"], s["alt"]) for s in (q[0], q[1], t[0], t[1])]
+    for lib, pre in ((O.lib(), "vco"), (None, "vcl")):          # the oracle's and the product's host clustering
+        cl = [K.simple_cluster(h, 0, gap, D.G["reach_min_gap"], L=lib, prefix=pre) for h in haps]
+        assert K.supercluster(haps, cl, D.G["max_supercluster_size"], L=lib, prefix=pre).n == n_ref
+
+
+@pytest.mark.parametrize("policy", ["v2.3", "v2.6.4"])
+def test_oracle_chain_reproduces_published_demo_rows(policy):
+    rows, det = D.run(product=False, bed_policy=policy)
     ka = D.known_answer()
     got = rows_as_dict(rows)
     assert det["n_sc"] > 6000 and det["query_stats"]["n"] == 10430 and det["truth_stats"]["n"] == 6676
     for th in ("NONE", "BEST"):
         r = got[("SNP", th)]
-        assert (r.truth_tp, r.query_tp, r.truth_fn, r.query_fp) == ka[("SNP", th)] == (8222, 8222, 1, 2)
+        assert quad(r) == ka[("SNP", th)] == (8222, 8222, 1, 2)
         # the printed floats of demo/output.txt: 0.999757 0.999878 0.999818 37.388565
         assert "%f %f %f %f" % (r.precision, r.recall, r.f1_score, r.f1_qscore) == "0.999757 0.999878 0.999818 37.388565"
-        r = got[("SV", th)]
-        assert (r.truth_tp, r.query_tp, r.truth_fn, r.query_fp) == ka[("SV", th)] == (0, 0, 0, 0)
-        # INDEL / ALL: one count below the published row in every column, as the real reference does on a surrogate FASTA
+        assert quad(got[("SV", th)]) == ka[("SV", th)] == (0, 0, 0, 0)
         for typ in ("INDEL", "ALL"):
-            r = got[(typ, th)]
-            want = tuple(x - 1 for x in ka[(typ, th)])
-            assert (r.truth_tp, r.query_tp, r.truth_fn, r.query_fp) == want, (typ, th)
+            p, r = ka[(typ, th)], got[(typ, th)]
+            if policy == "v2.3":
+                # totals exact; one truth and one query hap-variant TP here, FN / FP in the published (real-FASTA) run
+                assert r.truth_tp + r.truth_fn == p[0] + p[2] and r.query_tp + r.query_fp == p[1] + p[3], (typ, th)
+                assert quad(r) == (p[0] + 1, p[1] + 1, p[2] - 1, p[3] - 1), (typ, th)
+            else:
+                # v2.6.4 drops chr1:1722626 (a TP pair under the old rule): two TPs fewer per side than the row above
+                assert quad(r) == (p[0] - 1, p[1] - 1, p[2] - 1, p[3] - 1), (typ, th)
 
 
 @pytest.mark.gpu

@@ -27,7 +27,7 @@ for name in (sys.argv[1:] or ["biwfa", "gap50", "gap200"]):
         cl = [K.wfa_cluster(h, bytes(fasta), sub=D.G["sub"], open=D.G["open"], extend=D.G["extend"], max_cluster_itrs=D.G["max_cluster_itrs"],
                             reach_min_gap=D.G["reach_min_gap"], L=lib, prefix="vco")[0] for h in haps]
     else:
-        cl = [K.simple_cluster(h, 0, cluster[1], 0, L=lib, prefix="vco") for h in haps]
+        cl = [K.simple_cluster(h, 0, cluster[1], D.G["reach_min_gap"], L=lib, prefix="vco") for h in haps]
     sc = K.supercluster(haps, cl, D.G["max_supercluster_size"], L=lib, prefix="vco")
     pool, roff, aoff = [h.pool for h in haps], [h.ref_off for h in haps], [h.alt_off for h in haps]
     v = A.Variants(np.array([0, 5_100_000], np.int64), fasta, np.zeros(sc.n, np.int32), sc.beg, sc.end,

@@ -278,28 +278,27 @@ int vio_read_vcf(const char *path, const vio_bed *bed, const vio_params *prm, co
             std::string alt = alts[size_t(alt_idx) - 1];
             if (ngt == 2 && !same && !phased) { S.n_unphased++; continue; }
             if (alt == "*") { S.n_spanning_del++; continue; }
-            int pos = rpos, type, lm = 0, rm = -1;
+            // Allele normalisation (same outcome as variant.cpp:769-806).  A length-changing record loses its longest
+            // common prefix, then the longest common suffix of what is left of the SHORTER allele; it is a plain INS / DEL
+            // when that uses the shorter allele up, otherwise a complex record (kept trimmed, split below).  An
+            // equal-length record is a SUB when only its first base differs, complex (untrimmed) otherwise.
             const int reflen = int(ref.size()), altlen = int(alt.size());
-            if (altlen - reflen > 0) {
-                while (lm < reflen && ref[size_t(lm)] == alt[size_t(lm)]) lm++;
-                while (reflen + rm >= lm && ref[size_t(reflen + rm)] == alt[size_t(altlen + rm)]) rm--;
-                type = lm > reflen + rm ? T_INS : T_CPX;
-                pos += lm;
-                alt = alt.substr(size_t(lm), size_t(altlen + rm - lm + 1));
-                ref = ref.substr(size_t(lm), size_t(reflen + rm - lm + 1));
-            } else if (altlen - reflen < 0) {
-                while (lm < altlen && ref[size_t(lm)] == alt[size_t(lm)]) lm++;
-                while (altlen + rm >= lm && ref[size_t(reflen + rm)] == alt[size_t(altlen + rm)]) rm--;
-                type = lm > altlen + rm ? T_DEL : T_CPX;
-                pos += lm;
-                alt = alt.substr(size_t(lm), size_t(altlen + rm - lm + 1));
-                ref = ref.substr(size_t(lm), size_t(reflen + rm - lm + 1));
-            } else if (ref.size() == 1) {
+            int pos = rpos, type;
+            if (reflen != altlen) {
+                const int shorter = std::min(reflen, altlen);
+                int pre = 0, suf = 0;
+                while (pre < shorter && ref[size_t(pre)] == alt[size_t(pre)]) pre++;
+                while (suf < shorter - pre && ref[size_t(reflen - 1 - suf)] == alt[size_t(altlen - 1 - suf)]) suf++;
+                type = pre + suf < shorter ? T_CPX : (altlen > reflen ? T_INS : T_DEL);
+                ref = ref.substr(size_t(pre), size_t(reflen - pre - suf));
+                alt = alt.substr(size_t(pre), size_t(altlen - pre - suf));
+                pos += pre;
+            } else if (reflen == 1) {
                 if (ref[0] == alt[0]) { S.n_ref_call++; continue; }
                 type = T_SUB;
-            } else if (ref.substr(1) == alt.substr(1)) {
+            } else if (ref.compare(1, std::string::npos, alt, 1, std::string::npos) == 0) {
                 type = T_SUB;
-                ref = ref.substr(0, 1); alt = alt.substr(0, 1);
+                ref.resize(1); alt.resize(1);
             } else type = T_CPX;
             const int rlen = type == T_INS ? 0 : (type == T_SUB ? 1 : int(ref.size()));
             const int loc = vio_bed_contains(bed, ctg.c_str(), rpos, rpos + reflen, type);
