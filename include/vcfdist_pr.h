@@ -130,7 +130,7 @@ typedef struct vpr_variants {
     const uint8_t *ctg_seq;             /* concatenated upper-case contigs */
     const int32_t *sc_ctg;              /* [n_sc] contig of each supercluster */
     const int32_t *sc_beg;              /* [n_sc] begs[sc] (inclusive) */
-    const int32_t *sc_end;              /* [n_sc] ends[sc] (inclusive, dist.cpp:163); must be < contig length, see
+    const int32_t *sc_end;              /* [n_sc] ends[sc] (inclusive, dist.cpp:163); cut at the contig's last base, see
                                            vpr_batch_from_variants */
     const int64_t *var_off[VPR_HAPS];   /* [n_sc+1] */
     const int32_t *var_pos[VPR_HAPS];   /* absolute 0-based contig position */
@@ -305,11 +305,15 @@ int64_t vpr_download_path(const vpr_handle *h, int32_t sc, int32_t aln, int64_t 
 typedef struct vpr_owned_batch vpr_owned_batch;
 /* Returns VPR_ERR_ARG for input generate_ptrs_strs cannot process: a variant type other than SUB/INS/DEL
    (its ERROR, dist.cpp:199), unsorted or overlapping variants on a haplotype, a SUB whose alleles are not one base,
-   and a supercluster region that leaves the contig (sc_beg < 0 or sc_end >= contig length).  The last case is what
-   get_supercluster_range (cluster.cpp:563-596: end = pos + rlen + 1) yields for a variant that ends on the last base
-   of a contig; the reference has no defined result there -- its substr (dist.cpp:232) returns one base less than
-   the pointers it has just appended, and calc_prec_recall_path starts from the pointer arrays' size
-   (dist.cpp:539-540), one past its matrices -- so the library refuses the supercluster instead of guessing one. */
+   a variant that reaches behind its contig or its supercluster's region, and a region that starts in front of the
+   contig (sc_beg < 0: a variant at position 0; the reference's substr(-1) throws there and it exits, dist.cpp:232-238).
+   Contig end: get_supercluster_range (cluster.cpp:563-596) sets end = pos + rlen + 1 of the last variant, which is
+   >= the contig length when that variant ends on one of the contig's last two bases.  The reference has no defined
+   result there -- its substr (dist.cpp:232) silently returns fewer bases than the pointers it has just appended, and
+   calc_prec_recall_path starts from the pointer arrays' size (dist.cpp:539-546), outside its matrices.  The library
+   evaluates the region that exists: sc_end is cut at the contig's last base, strings and pointer arrays consistent
+   (so such a supercluster has one or no base behind its last variant instead of two); the tables keep the caller's
+   sc_end. */
 int  vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out);
 const vpr_batch *vpr_owned_batch_view(const vpr_owned_batch *b);
 void vpr_owned_batch_free(vpr_owned_batch *b);

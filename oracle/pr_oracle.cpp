@@ -566,10 +566,15 @@ int gen_hap(const vpr_variants *v, int slot, int sc, GenOut &o) {
     const int ctg = v->sc_ctg[sc];
     const uint8_t *fa = v->ctg_seq + v->ctg_off[ctg];
     const int64_t ctg_len = v->ctg_off[ctg + 1] - v->ctg_off[ctg];
-    const int beg_pos = v->sc_beg[sc], end_pos = v->sc_end[sc];
+    // (end_pos cut at the contig's last base: where cluster.cpp:591-595's pos + rlen + 1 leaves the contig the reference has
+    // no defined result -- dist.cpp:232 substr comes back short of the pointer arrays, dist.cpp:539 indexes by their size --
+    // and product and oracle both evaluate the region that exists; include/vcfdist_pr.h)
+    const int beg_pos = v->sc_beg[sc], end_pos = int(std::min<int64_t>(v->sc_end[sc], ctg_len - 1));
     int64_t var = v->var_off[slot][sc];
     const int64_t var_end = v->var_off[slot][sc + 1];
-    for (int ref_pos = beg_pos; ref_pos <= end_pos;) {
+    if (beg_pos < 0 || beg_pos > end_pos) return -2;
+    int ref_pos = beg_pos;
+    for (; ref_pos <= end_pos;) {
         if (var < var_end && ref_pos == v->var_pos[slot][var]) {
             const uint8_t *pool = v->allele_pool[slot];
             const int64_t r0 = v->var_ref_off[slot][var], r1 = r0 + v->var_ref_len[slot][var];
@@ -623,6 +628,7 @@ int gen_hap(const vpr_variants *v, int slot, int sc, GenOut &o) {
             ref_pos = ref_end;
         }
     }
+    if (ref_pos != end_pos + 1 || var != var_end) return -2;   // a variant that leaves the region / the contig
     return 0;
 }
 

@@ -85,6 +85,27 @@ def test_minimum_sizes_and_empty_haps():
     compare(batch)
 
 
+def test_superclusters_at_the_contig_end():
+    """a variant on one of the contig's last two bases: the region (end = pos + rlen + 1, cluster.cpp:595) is cut at the
+    last base (include/vcfdist_pr.h, vpr_batch_from_variants); with no base left behind the variant the alignment cannot
+    finish (the reference's ERROR at dist.cpp:440): a status bit, identical in library and oracle"""
+    ref = "ACGTTGCAACGTACGGTCAT"        # 20 bases
+    S, I, D = A.TYPE_SUB, A.TYPE_INS, A.TYPE_DEL
+    scs = [
+        dict(ctg=0, beg=16, end=20, vars=[[(17, D, "C", "", 9.0)], [], [(17, D, "C", "", 9.0)], []]),     # end = contig length
+        dict(ctg=0, beg=17, end=21, vars=[[(18, S, "A", "G", 9.0)], [], [(18, S, "A", "G", 9.0)], [(18, S, "A", "C", 5.0)]]),
+        dict(ctg=0, beg=15, end=20, vars=[[(16, D, "TC", "", 9.0)], [(17, I, "", "GG", 4.0)], [(16, D, "TC", "", 9.0)], []]),
+        dict(ctg=0, beg=18, end=21, vars=[[(19, D, "T", "", 9.0)], [], [(19, D, "T", "", 9.0)], []]),     # nothing behind the variant
+        dict(ctg=0, beg=18, end=21, vars=[[(19, S, "T", "A", 9.0)], [], [], [(19, S, "T", "A", 9.0)]]),
+        dict(ctg=0, beg=18, end=20, vars=[[(19, I, "", "AC", 9.0)], [(19, I, "", "AC", 9.0)], [(19, I, "", "AC", 9.0)], []]),
+    ]
+    v = A.Variants.from_sites([ref], scs)
+    batch = api.batch_from_variants(v)
+    assert batch.lens(0)[4] == 4 and batch.lens(3)[4] == 2
+    got, want, _, _ = compare(batch)
+    assert (want.aln_status & A.ST_ERR_UNFINISHED).any() and want.aln_dist[0] == 0
+
+
 def test_sv_sized_sections_use_deferred_edit_distance():
     """Large indels make sync sections whose ref/truth segments both exceed the inline limit,
     so K4 (k_ed) computes wf_ed for them."""
@@ -290,10 +311,19 @@ def _adjacent_deletions(k):
 
 def test_adjacent_deletion_records_up_to_the_swap_source_limit():
     """Directly adjacent deletion records all point at the hap base in front of the first one; each contributes one
-    allowed swap source to the position behind them.  The library keeps four sources per position (int4 lists, 2-bit
-    rank in the flag byte): three adjacent records match the oracle, four are refused by vpr_upload with a message --
-    a documented limit, not a wrong result."""
-    batch = api.batch_from_variants(_adjacent_deletions(3))
-    compare(batch)
+    allowed swap source to the position behind them.  The library keeps eight sources per position (two int4 lists, a
+    3-bit rank in the flag byte): up to seven adjacent records match the oracle, eight are refused by vpr_upload with a
+    message -- a documented limit, not a wrong result."""
+    for k in (3, 4, 5, 7):
+        compare(api.batch_from_variants(_adjacent_deletions(k)))
     with pytest.raises(api.VprError, match="swap sources"):
-        api.PrecisionRecall().run(api.batch_from_variants(_adjacent_deletions(4)))
+        api.PrecisionRecall().run(api.batch_from_variants(_adjacent_deletions(8)))
+
+
+@pytest.mark.parametrize("band_mode", [1, 3, 2, 0])
+def test_runs_of_adjacent_deletion_records(band_mode):
+    """five to eight swap sources on one position (second candidate list, third rank bit in F_SUB's place), with and
+    without the same records on the truth side, at every window mode"""
+    import indel_runs
+    for seed in (11, 12):
+        compare(api.batch_from_variants(indel_runs.indel_run_superclusters(seed)), A.default_config(band_mode=band_mode))

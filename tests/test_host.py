@@ -99,32 +99,51 @@ def test_batch_subset_roundtrip():
     assert r_sub.aln_dist.tolist() == np.concatenate([r_all.aln_dist[4 * i:4 * i + 4] for i in (3, 7, 7, 29)]).tolist()
 
 
-def test_region_past_the_contig_end_is_refused_by_product_and_oracle():
-    """A variant ending on the last base of a contig makes get_supercluster_range (cluster.cpp:595: pos + rlen + 1)
-    return end == contig length.  The reference has no defined result there (dist.cpp:232 substr one base short of its
-    pointer arrays, dist.cpp:539 start cell taken from the pointer arrays' size), so both the product marshalling and
-    the oracle restatement refuse it; the same variant one base further left is fine.  Found by tests/fuzz_chain.py."""
+def test_region_past_the_contig_end_is_cut_at_the_last_base():
+    """A variant ending on one of the last two bases of a contig makes get_supercluster_range (cluster.cpp:595:
+    pos + rlen + 1) return end >= contig length.  The reference has no defined result there (dist.cpp:232 substr comes
+    back short of its pointer arrays, dist.cpp:539 takes the start cell from the pointer arrays' size: outside its
+    matrices), so product marshalling and oracle both evaluate the region that exists -- cut at the contig's last base,
+    strings and pointers consistent -- instead of aborting a whole-genome run.  A variant that itself reaches behind the
+    contig, and a region that starts in front of it (the reference exits there too), stay errors.  Found by
+    tests/fuzz_chain.py."""
     import numpy as np
     import oracle_lib as O
     from vcfdist_amd import _abi as A
     ctg = np.frombuffer(b"ACGTACGTACGTACGTACGT", np.uint8)          # 20 bases
-    def variants(pos):
-        # one deletion of one base at `pos` on Q1 only; region = [pos - 1, pos + 1 + 1] as the reference computes it
-        n = [1, 0, 0, 0]
+
+    def variants(pos, rlen=1, beg=None):
+        # one deletion of `rlen` bases at `pos` on Q1 and T1; region = [pos - 1, pos + rlen + 1] as the reference computes it
+        n = [1, 0, 1, 0]
         z32, z64 = np.zeros(0, np.int32), np.zeros(0, np.int64)
-        return A.Variants(np.array([0, 20], np.int64), ctg, np.zeros(1, np.int32), np.array([pos - 1], np.int32),
-                          np.array([pos + 2], np.int32), [np.array([0, k], np.int64) for k in n],
-                          [np.array([pos], np.int32), z32, z32, z32], [np.array([3], np.uint8)] + [np.zeros(0, np.uint8)] * 3,
-                          [np.array([30.0], np.float32)] + [np.zeros(0, np.float32)] * 3, [np.array([0], np.int64), z64, z64, z64],
-                          [np.array([1], np.int32), z32, z32, z32], [np.array([1], np.int64), z64, z64, z64],
-                          [np.array([0], np.int32), z32, z32, z32], [ctg[pos:pos + 1].copy()] + [np.zeros(1, np.uint8)] * 3)
-    ok = variants(17)                       # end = 19 = last base: fine
-    assert api.batch_from_variants(ok).lens(0)[4] == 4 and O.generate(ok).lens(0)[4] == 4
-    bad = variants(18)                      # deletes base 18, the variant ends on base 19, end = 20 = contig length
-    with pytest.raises(api.VprError):
-        api.batch_from_variants(bad)
-    with pytest.raises(ValueError):
-        O.generate(bad)
+        one = lambda x, dt: [np.array([x], dt) if k else np.zeros(0, dt) for k in n]
+        return A.Variants(np.array([0, 20], np.int64), ctg, np.zeros(1, np.int32), np.array([pos - 1 if beg is None else beg], np.int32),
+                          np.array([pos + rlen + 1], np.int32), [np.array([0, k], np.int64) for k in n],
+                          one(pos, np.int32), one(3, np.uint8), one(30.0, np.float32), one(0, np.int64), one(rlen, np.int32),
+                          one(rlen, np.int64), one(0, np.int32), [ctg[pos:pos + rlen].copy() if k else np.zeros(1, np.uint8) for k in n])
+    for pos, rlen, want_ref, want_hap in ((17, 1, 4, 3),     # end = 19 = last base: the whole region
+                                          (18, 1, 3, 2),     # end = 20: cut to [17, 19], one base behind the deletion
+                                          (19, 1, 2, 1),     # end = 21: cut to [18, 19], the deletion ends the strings
+                                          (17, 3, 4, 1)):    # a three-base deletion of the contig's last bases
+        v = variants(pos, rlen)
+        for b in (api.batch_from_variants(v), O.generate(v)):
+            assert b.lens(0)[4] == want_ref and b.lens(0)[0] == want_hap and b.lens(0)[1] == want_ref, (pos, rlen, b.lens(0))
+        p, o = api.batch_from_variants(v), O.generate(v)
+        for f in ("hap_seq", "hap_ptr", "hap_flag"):
+            assert all(np.array_equal(getattr(p, f)[h], getattr(o, f)[h]) for h in range(4)), f
+        res = O.run(o)
+        res = res[0] if isinstance(res, tuple) else res
+        assert res.aln_dist[[1, 2, 3]].tolist() == [0, rlen, 0]        # Q1 reaches T2 over the REF plane; T1 carries the deletion, Q2 does not
+        if pos + rlen < 20:      # a base behind the variant: an ordinary supercluster, TP / TP under the original phasing
+            assert res.aln_dist[0] == 0 and res.errtype[0][0].tolist() == [0] and res.errtype[2][0].tolist() == [0]
+        else:                    # the variant ends the strings: the reference's "Alignment not finished" (dist.cpp:440, where it
+            # exits) is a status bit here and the variants stay ERRTYPE_UN -- write_precision_recall warns and skips them
+            assert res.aln_status[0] & A.ST_ERR_UNFINISHED and res.errtype[0][0].tolist() == [A.ERRTYPE_UN]
+    for bad in (variants(18, 3), variants(0, 1)):                     # variant leaves the contig / region starts at -1
+        with pytest.raises(api.VprError):
+            api.batch_from_variants(bad)
+        with pytest.raises(ValueError):
+            O.generate(bad)
 
 
 def test_transfer_phase_sets_matches_the_reference_walk():

@@ -130,7 +130,7 @@ def _forward_of(one, aln):
 
 def test_dense_model_equals_sparse_oracle_with_many_swap_sources():
     """runs of up to seven directly adjacent deletion records: up to eight allowed swap sources on the position behind
-    the run (the library's candidate lists hold four today); the dense formulation still gives the
+    the run (what the library's two candidate lists hold); the dense formulation still gives the
     oracle's distance, end plane and flag bytes"""
     from vcfdist_amd import api
     import indel_runs

@@ -97,12 +97,20 @@ Lens walk(const vpr_variants *v, int slot, int sc,
     const int ctg = v->sc_ctg[sc];
     const uint8_t *fa = v->ctg_seq + v->ctg_off[ctg];
     const int64_t ctg_len = v->ctg_off[ctg + 1] - v->ctg_off[ctg];
-    const int32_t beg = v->sc_beg[sc], end = v->sc_end[sc];
+    // Region end: get_supercluster_range (cluster.cpp:591-595) yields pos + rlen + 1 of the last variant, which lies
+    // behind the contig when that variant ends on one of its last two bases.  The reference has no defined result there
+    // (its substr, dist.cpp:232, silently returns fewer bases than the pointers appended beside it, and
+    // calc_prec_recall_path, dist.cpp:539-546, then indexes its matrices by the pointer arrays' size); here the region is
+    // cut at the contig's last base, strings and pointer arrays consistent -- see include/vcfdist_pr.h.  A region that
+    // starts in front of the contig (a variant at position 0: beg = -1) is an error in the reference as well
+    // (substr(-1) throws, dist.cpp:236-238).
+    const int32_t beg = v->sc_beg[sc];
+    const int32_t end = int32_t(std::min<int64_t>(v->sc_end[sc], ctg_len - 1));
     int64_t var = v->var_off[slot][sc];
     const int64_t var_end = v->var_off[slot][sc + 1];
     int64_t nh = 0, nr = 0;
     int32_t pos = beg;
-    if (beg < 0 || end >= ctg_len) return {0, 0, VPR_ERR_ARG};
+    if (beg < 0 || beg > end) return {0, 0, VPR_ERR_ARG};
     while (pos <= end) {
         if (var < var_end && v->var_pos[slot][var] == pos) {
             const uint8_t *pool = v->allele_pool[slot];
@@ -181,6 +189,7 @@ Lens walk(const vpr_variants *v, int slot, int sc,
             pos = stop;
         }
     }
+    if (pos != end + 1 || var != var_end) return {0, 0, VPR_ERR_ARG};   // a variant that leaves the region / the contig
     return {nh, nr, 0};
 }
 

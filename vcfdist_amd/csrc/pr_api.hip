@@ -829,6 +829,8 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if ((rc = dev_upload(h, &D.ref_flag[q], b->ref_flag[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.cand_q[q], hap_len[q]))) return rc;
         if ((rc = dev_alloc(h, &D.cand_r[q], ref_len))) return rc;
+        if ((rc = dev_alloc(h, &D.cand2_q[q], hap_len[q]))) return rc;
+        if ((rc = dev_alloc(h, &D.cand2_r[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.fk_q[q], hap_len[q]))) return rc;
         if ((rc = dev_alloc(h, &D.fk_r[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.bk_q[q], hap_len[q]))) return rc;
@@ -846,6 +848,8 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if ((rc = dev_alloc(h, &D.xb_r[q], ref_len))) return rc;
         HIPCHK(h, hipMemsetAsync(D.cand_q[q], 0xff, std::max<int64_t>(hap_len[q], 1) * sizeof(int4), h->stream));
         HIPCHK(h, hipMemsetAsync(D.cand_r[q], 0xff, std::max<int64_t>(ref_len, 1) * sizeof(int4), h->stream));
+        HIPCHK(h, hipMemsetAsync(D.cand2_q[q], 0xff, std::max<int64_t>(hap_len[q], 1) * sizeof(int4), h->stream));
+        HIPCHK(h, hipMemsetAsync(D.cand2_r[q], 0xff, std::max<int64_t>(ref_len, 1) * sizeof(int4), h->stream));
     }
     if ((rc = dev_alloc(h, &h->d_err, 1))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_err, 0, 4, h->stream));
@@ -1109,7 +1113,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     lap("plan + upload");
     uint32_t err = 0;
     HIPCHK(h, hipMemcpy(&err, h->d_err, 4, hipMemcpyDeviceToHost));
-    if (err) return fail(h, VPR_ERR_ARG, "more than 4 swap sources map to one position (unsupported variant layout)");
+    if (err) return fail(h, VPR_ERR_ARG, "more than 8 swap sources map to one position (unsupported variant layout)");
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     h->timing.ms_prep = ms;

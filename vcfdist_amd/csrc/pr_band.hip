@@ -65,9 +65,13 @@ __global__ void k_prep_pack(DevBatch B, int h, int dir, int64_t n_pos) {
             const int4 oc = ocand[ooff[sc] + zz];
             int rank = -1;
             if (oc.x == x) rank = 0; else if (oc.y == x) rank = 1; else if (oc.z == x) rank = 2; else if (oc.w == x) rank = 3;
+            else if (oc.w >= 0) {
+                const int4 o2 = (dir == 0 ? B.cand2_r[h] : B.cand2_q[h])[ooff[sc] + zz];
+                if (o2.x == x) rank = 4; else if (o2.y == x) rank = 5; else if (o2.z == x) rank = 6; else if (o2.w == x) rank = 7;
+            }
             if (rank >= 0) {
                 z = uint32_t(zz);
-                bits |= uint32_t(rank) << 1;
+                bits |= rank_bits(rank);
                 if (dir == 1) bits |= tp_of(B.hap_ptr[h], B.hap_flag[h], ooff[sc], int32_t(zz)) << 3;  // tp(z), z on QUERY
             }
         }
@@ -347,6 +351,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
     const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
     const int2 *fk[2] = {B.fk_q[d.qs] + d.q_off, B.fk_r[d.qs] + d.r_off};
     const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
+    const int4 *cand2[2] = {B.cand2_q[d.qs] + d.q_off, B.cand2_r[d.qs] + d.r_off};
     const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
     const int2 *xbp[2] = {B.xb_q[d.qs] + d.q_off, B.xb_r[d.qs] + d.r_off};   // free-shift budgets of the exit test (pr_device.h)
     const int32_t *vst = B.vs_hap[d.ts] + d.t_off;                             // W_t(i): truth steps >= i
@@ -517,7 +522,17 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
                         const int val = (need && srcs[k] >= 0) ? val0 : D_INF;
                         if (need && srcs[k] >= 0 && val <= sw[p]) { tie = (val == sw[p]); sw[p] = val; choice = k + 1; }
                     }
-                    swbits[p] = (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
+                    if (__builtin_expect(__any(need && cc.w >= 0), 0)) {      // sources five to eight
+                        int4 c2 = make_int4(-1, -1, -1, -1);
+                        if (need && cc.w >= 0) c2 = cand2[p][lo[p] + lane];
+                        const int more[4] = {c2.x, c2.y, c2.z, c2.w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int val = lane_get(more[k] - olo, Dp[o], D_INF);
+                            if (more[k] >= 0 && val <= sw[p]) { tie = (val == sw[p]); sw[p] = val; choice = k + 4; }
+                        }
+                    }
+                    swbits[p] = f_choice_bits(choice) | (tie ? F_TIE : 0);
                     if (tie && sw[p] < D_INF) min_tie = min(min_tie, sw[p]);
                 }
             }
@@ -671,12 +686,14 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
         // ---- per-lane constants of this stripe
         bool valid[2];
         int tp_own[2], tp_right[2], zl[2];
+        uint32_t zkey[2];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             valid[p] = lo[p] + col <= hi[p];
             tp_own[p] = (bkc[p] >> 24) & 1;
             tp_right[p] = wave_shr1(tp_own[p], 0);
             zl[p] = bkc[p] & 0xffffff;   // swap target (absolute index in the other plane) or FK_NONE24
+            zkey[p] = f_swp_key(rank_of(uint32_t(bkc[p]) >> 24));
         }
         const int sh[2] = {plo[0] - lo[0], plo[1] - lo[1]};   // origin shift against the stripe above (first row)
         stage_load(s - 1);                                     // prefetch the stripe below into registers
@@ -706,7 +723,7 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
                 }
                 int b = S_NEG;
                 uint32_t m = 0;
-                if (up_f & (F_MAT | F_SUB)) { b = up_s + tp_right[p]; m = up_f & (F_MAT | F_SUB); }
+                if (f_diag(up_f)) { b = up_s + tp_right[p]; m = f_diag(up_f); }
                 if (dn_f & F_DEL) {
                     if (dn_s > b) { b = dn_s; m = F_DEL; } else if (dn_s == b) m |= F_DEL;
                 }
@@ -715,7 +732,7 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
                 const int zlane = 63 - (zl[p] - olo);
                 const int zf = lane_get(zl[p] == int(FK_NONE24) ? -1 : zlane, f1[o], 0);
                 const int zs = lane_get(zl[p] == int(FK_NONE24) ? -1 : zlane, sc1[o], S_NEG);
-                if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((bkc[p] >> 25) & 3)) {
+                if ((uint32_t(zf) & F_SWP_KEY_MASK) == zkey[p]) {
                     const int v = zs + ((bkc[p] >> 27) & 1);
                     if (v >= 0 && (zf & F_TIE)) tie_used++;
                     if (v > b) { b = v; m = F_SWP; } else if (v == b) m |= F_SWP;

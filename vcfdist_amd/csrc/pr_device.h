@@ -10,8 +10,24 @@
 #define F_MAT 4
 #define F_SUB 8
 #define F_SWP 16
-#define F_CHOICE_SHIFT 5      // bits 5-6: rank of the chosen swap source within the cell's candidate list
+#define F_CHOICE_SHIFT 5      // bits 5-6: rank of the chosen swap source within the cell's candidate list (low two bits)
 #define F_TIE 128             // bit 7: more than one optimal swap source (order-defined in the reference)
+// A position keeps up to eight allowed swap sources (cand_* + cand2_*), so the rank has three bits.  Its third bit sits in
+// F_SUB's place: a swap needs equal bases at its target cell (dist.cpp:335-350), and where the bases are equal the
+// diagonal move is a match, never a substitution (D(cell) <= D(diagonal predecessor) < D(diagonal predecessor) + 1), so
+// F_SUB and F_SWP never meet in one byte.  Readers of the diagonal bits therefore go through f_diag().
+#define F_CHOICE_MASK (0x60u | F_SUB)
+__host__ __device__ __forceinline__ uint32_t f_choice_bits(int rank) { return (uint32_t(rank & 3) << F_CHOICE_SHIFT) | (uint32_t(rank >> 2) << 3); }
+__host__ __device__ __forceinline__ int f_choice_of(uint32_t f) { return int(((f >> F_CHOICE_SHIFT) & 3u) | ((f >> 1) & 4u)); }   // of a byte with F_SWP
+__host__ __device__ __forceinline__ uint32_t f_diag(uint32_t f) { return f & (F_MAT | (F_SUB & ~(f >> 1))); }    // F_MAT / F_SUB of a forward flag byte
+// a source's rank in its swap target's list, in the constant bytes of the backward sweeps (bk_* >> 24, the dense kc):
+// bits 1-2 and bit 4
+__host__ __device__ __forceinline__ uint32_t rank_bits(int rank) { return (uint32_t(rank & 3) << 1) | (uint32_t(rank >> 2) << 4); }
+__host__ __device__ __forceinline__ int rank_of(uint32_t bits) { return int(((bits >> 1) & 3u) | ((bits >> 2) & 4u)); }
+// "z's forward flags say: entered by a swap from the source of this rank" as one masked compare
+#define F_SWP_KEY_MASK (F_SWP | F_CHOICE_MASK)
+__host__ __device__ __forceinline__ uint32_t f_swp_key(int rank) { return F_SWP | f_choice_bits(rank); }
+#define SWAP_SOURCES_MAX 8
 // The backward sweeps replace a cell's forward flags with its path_ptr byte (low 5 bits; 0 = not on an optimal path) and
 // keep bits 5-7 of the forward flags for cells that are on one: a "used" tied cell is then (byte & F_TIE) != 0 with
 // bwd_allow(the cell's pointer flag), which is what the container-order replay looks for (pr_tie.hip); their number is
@@ -49,12 +65,14 @@ struct DevBatch {
     // derived by k_prep_*:
     int4 *cand_q[2];      // [hap positions of query hap h] allowed swap sources in the REF plane (ascending, -1 pad)
     int4 *cand_r[2];      // [ref positions]               allowed swap sources in QUERY hap h
+    int4 *cand2_q[2];     // sources five to eight of a position (read only where cand_*.w >= 0: directly adjacent separate
+    int4 *cand2_r[2];     //   indel records on one haplotype, each of which ends at the position)
     uint8_t *has_ins[4];  // [ref positions] an insertion of hap slot s sits at this ref index (dist.cpp:886-894)
     // packed per-position constants for the banded kernels (k_prep_pack):
     //   fk_*: .x = first swap source (cand.x) | FK_MULTI if there are more, -1 if none
     //         .y = swap target of this position as a *source* (ptr+1 if fwd_allow, else 0xffffff) | base << 24
     //   bk_*: swap target z (24 bits, 0xffffff none; includes fwd_allow(src), bwd_allow(z), membership in z's
-    //         candidate list) | tp(this cell, QUERY plane only) << 24 | rank in z's list << 25 | tp(z) << 27
+    //         candidate list) | tp(this cell, QUERY plane only) << 24 | rank_bits(rank in z's list) << 24 | tp(z) << 27
     int2 *fk_q[2];        // [hap positions of query hap h]
     int2 *fk_r[2];        // [ref positions]
     int32_t *bk_q[2];

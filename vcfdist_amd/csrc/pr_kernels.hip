@@ -46,6 +46,7 @@ __global__ void k_prep_cand(DevBatch B, int h, int dir, int64_t n_src, uint32_t 
     const int32_t *ptr = dir == 0 ? B.hap_ptr[h] : B.ref_ptr[h];
     const uint8_t *flg = dir == 0 ? B.hap_flag[h] : B.ref_flag[h];
     int4 *cand = dir == 0 ? B.cand_r[h] : B.cand_q[h];
+    int4 *cand2 = dir == 0 ? B.cand2_r[h] : B.cand2_q[h];
     if (!fwd_allow(flg[g])) return;
     const int sc = find_sc(src_off, B.n_sc, g);
     const int64_t s0 = src_off[sc];
@@ -57,9 +58,9 @@ __global__ void k_prep_cand(DevBatch B, int h, int dir, int64_t n_src, uint32_t 
     int rank = 0;
     for (int64_t y = g - 1; y >= s0 && ptr[y] == p; y--)
         if (fwd_allow(flg[y])) rank++;
-    if (rank >= 4) { atomicOr(err, VPR_ST_ERR_LIMIT); return; }
-    int32_t *slot = reinterpret_cast<int32_t *>(cand + dst_off[sc] + d);
-    slot[rank] = x;
+    if (rank >= SWAP_SOURCES_MAX) { atomicOr(err, VPR_ST_ERR_LIMIT); return; }
+    int32_t *slot = reinterpret_cast<int32_t *>((rank < 4 ? cand : cand2) + dst_off[sc] + d);
+    slot[rank & 3] = x;
 }
 
 __global__ void k_prep_ins(DevBatch B, int slot, int64_t n_src) {
@@ -153,6 +154,7 @@ __global__ void __launch_bounds__(NT) k_fwd(DevBatch B, const AlnDesc *__restric
     const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off;
     const uint8_t *Tf = B.hap_flag[d.ts] + d.t_off;
     const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
+    const int4 *cand2[2] = {B.cand2_q[d.qs] + d.q_off, B.cand2_r[d.qs] + d.r_off};
     const int Lp[2] = {Lq, Lr};
     const int Pp[2] = {PQ, PR};
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
@@ -254,6 +256,12 @@ __global__ void __launch_bounds__(NT) k_fwd(DevBatch B, const AlnDesc *__restric
                             if (cc.w >= 0) {
                                 const int v3 = other[cc.w];
                                 if (v3 <= sw) { tie = (v3 == sw); sw = v3; choice = 3; }
+                                const int4 c2 = cand2[p][q];
+                                const int more[4] = {c2.x, c2.y, c2.z, c2.w};
+                                for (int k = 0; k < 4 && more[k] >= 0; k++) {
+                                    const int v = other[more[k]];
+                                    if (v <= sw) { tie = (v == sw); sw = v; choice = 4 + k; }
+                                }
                             }
                         }
                     }
@@ -263,7 +271,7 @@ __global__ void __launch_bounds__(NT) k_fwd(DevBatch B, const AlnDesc *__restric
                 if (match && diag == b) m |= F_MAT;
                 if (diag + 1 == b) m |= F_SUB;
                 if (up + 1 == b) m |= F_DEL;
-                if (sw == b) m |= F_SWP | (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
+                if (sw == b) m |= F_SWP | f_choice_bits(choice) | (tie ? F_TIE : 0);
                 mk[p][c] = m;
                 bv[p][c] = b - q;
                 run = min(run, b - q);
@@ -406,14 +414,15 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
     const int32_t *ptr[2] = {B.hap_ptr[d.qs] + d.q_off, B.ref_ptr[d.qs] + d.r_off};
     const uint8_t *pfl[2] = {B.hap_flag[d.qs] + d.q_off, B.ref_flag[d.qs] + d.r_off};
     const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
+    const int4 *cand2[2] = {B.cand2_q[d.qs] + d.q_off, B.cand2_r[d.qs] + d.r_off};
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     const int q0 = tid * C;
     const int end_plane = outs[a].end_plane;
 
     // per-cell constants
     int32_t zq[2][C];       // swap target in the other plane (or -1 if this cell can never be a swap source)
-    uint8_t kc[2][C];       // bit0: tp of this cell (QUERY plane only); bits1-2: my rank in z's candidate list;
-                            // bit3: tp of z (only when z is on the QUERY plane)
+    uint8_t kc[2][C];       // bit0: tp of this cell (QUERY plane only); bits 1-2 and 4: my rank in z's candidate list
+                            // (rank_bits); bit3: tp of z (only when z is on the QUERY plane)
 #pragma unroll
     for (int p = 0; p < 2; p++) {
 #pragma unroll
@@ -430,9 +439,13 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
                     const int4 cc = cand[1 - p][z];
                     int rank = -1;
                     if (cc.x == q) rank = 0; else if (cc.y == q) rank = 1; else if (cc.z == q) rank = 2; else if (cc.w == q) rank = 3;
+                    else if (cc.w >= 0) {
+                        const int4 c2 = cand2[1 - p][z];
+                        if (c2.x == q) rank = 4; else if (c2.y == q) rank = 5; else if (c2.z == q) rank = 6; else if (c2.w == q) rank = 7;
+                    }
                     if (rank >= 0) {
                         zq[p][c] = z;
-                        kc[p][c] |= rank << 1;
+                        kc[p][c] |= uint8_t(rank_bits(rank));
                         if (p == 1) {  // z on the QUERY plane: leaving it scores tp(z), dist.cpp:656-658
                             const int pz = ptr[0][z];
                             if ((pz != ptr[0][z - 1] + 1) || (pfl[0][z] & PB)) kc[p][c] |= 8;
@@ -519,9 +532,9 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
                 const int xf = (c == C - 1) ? xf_r : f1[p][c + 1];
                 const int xtp = (c == C - 1) ? xtp_r : (kc[p][c + 1] & 1);
                 int best = S_NEG; uint8_t m = 0;
-                if (xf & (F_MAT | F_SUB)) {
+                if (f_diag(xf)) {
                     const int v = xs + xtp;
-                    best = v; m = xf & (F_MAT | F_SUB);
+                    best = v; m = uint8_t(f_diag(xf));
                 }
                 // successor (q, t+1): DEL
                 if (f1[p][c] & F_DEL) {
@@ -531,7 +544,7 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
                 // swap successor z = (other plane, zq, t+1)
                 if (zq[p][c] >= 0) {
                     const int zf = FROW(nxt, o, zq[p][c]);
-                    if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((kc[p][c] >> 1) & 3)) {
+                    if ((zf & F_SWP) && f_choice_of(zf) == rank_of(kc[p][c])) {
                         const int v = s_ld(o, zq[p][c]) + ((kc[p][c] >> 3) & 1);
                         if (v >= 0 && (zf & F_TIE)) tie_used++;
                         if (v > best) { best = v; m = F_SWP; } else if (v == best) m |= F_SWP;

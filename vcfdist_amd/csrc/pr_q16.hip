@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
     const int4 *fk[2] = {(qs == 0 ? B.fk4_q[0] : B.fk4_q[1]) + q_off, (qs == 0 ? B.fk4_r[0] : B.fk4_r[1]) + r_off};
     auto load_k = [&](int p, int idx) -> int4 { return fk[p][idx]; };
     const int4 *cand[2] = {(qs == 0 ? B.cand_q[0] : B.cand_q[1]) + q_off, (qs == 0 ? B.cand_r[0] : B.cand_r[1]) + r_off};
+    const int4 *cand2[2] = {(qs == 0 ? B.cand2_q[0] : B.cand2_q[1]) + q_off, (qs == 0 ? B.cand2_r[0] : B.cand2_r[1]) + r_off};
     uint32_t *mat = reinterpret_cast<uint32_t *>(ws + dp->mat_off[0]);
     int2 *blo2 = reinterpret_cast<int2 *>(blo_all + dp->blo_off);
     const int nstr = (Lt + Q_K - 1) / Q_K;
@@ -301,7 +302,17 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
                         const int val = (need && srcs[k] >= 0) ? val0 : D_INF;
                         if (need && srcs[k] >= 0 && val <= sw[p]) { tie = (val == sw[p]); sw[p] = val; choice = k + 1; }
                     }
-                    swbits[p] = (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
+                    if (__builtin_expect(__any(need && cc.w >= 0), 0)) {      // sources five to eight
+                        int4 c2 = make_int4(-1, -1, -1, -1);
+                        if (need && cc.w >= 0) c2 = cand2[p][lo[p] + gl];
+                        const int more[4] = {c2.x, c2.y, c2.z, c2.w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int val = grp_get(gbase, more[k] - olo, Dp[o], D_INF);
+                            if (more[k] >= 0 && val <= sw[p]) { tie = (val == sw[p]); sw[p] = val; choice = k + 4; }
+                        }
+                    }
+                    swbits[p] = f_choice_bits(choice) | (tie ? F_TIE : 0);
                 }
             }
 #pragma unroll
@@ -523,8 +534,19 @@ __global__ void __launch_bounds__(64) k_fwd_z16(DevBatch B, const AlnDesc *__res
                         const int val = (need && srcs[k] >= 0 && bit) ? 0 : D_INF;
                         if (need && srcs[k] >= 0 && val <= sw) { tie = (val == sw); sw = val; choice = k + 1; }
                     }
+                    if (__builtin_expect(__any(need && cc.w >= 0), 0)) {      // sources five to eight (one at a time: no
+                        const int32_t *c2 = reinterpret_cast<const int32_t *>(                  // registers for this path)
+                            (p == 0 ? (qs == 0 ? B.cand2_q[0] : B.cand2_q[1]) + q_off : (qs == 0 ? B.cand2_r[0] : B.cand2_r[1]) + r_off) + (lo[p] + gl));
+#pragma unroll 1
+                        for (int k = 0; k < 4; k++) {
+                            const int src = (need && cc.w >= 0) ? c2[k] : -1;
+                            const uint32_t bit = (G[o] >> min(unsigned(src - dlo[o]), 31u)) & 1u;
+                            const int val = (src >= 0 && bit) ? 0 : D_INF;
+                            if (src >= 0 && val <= sw) { tie = (val == sw); sw = val; choice = k + 4; }
+                        }
+                    }
                     sz[p] = (sw == 0);
-                    swbits[p] = (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
+                    swbits[p] = f_choice_bits(choice) | (tie ? F_TIE : 0);
                 }
             }
             uint32_t nb[2];
@@ -652,6 +674,7 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
         // ---- per-lane constants of this stripe
         bool valid[2];
         int tp_own[2], tp_right[2], zl[2], sh[2];
+        uint32_t zkey[2];
         uint32_t fwr[2], oacc[2] = {0, 0};
 #pragma unroll
         for (int p = 0; p < 2; p++) {
@@ -659,6 +682,7 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
             tp_own[p] = (bkc[p] >> 24) & 1;
             tp_right[p] = row_shr1(tp_own[p], 0);
             zl[p] = bkc[p] & 0xffffff;   // swap target (absolute index in the other plane) or FK_NONE24
+            zkey[p] = f_swp_key(rank_of(uint32_t(bkc[p]) >> 24));
             fw[p] = valid[p] ? fw[p] : 0;
             fwr[p] = uint32_t(row_shr1(int(fw[p]), 0));          // forward flags of column x+1
             sh[p] = (s == nstr - 1) ? 0 : plo[p] - lo[p];        // origin shift against the stripe above
@@ -697,7 +721,8 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
                 }
                 int b = S_NEG;
                 uint32_t m = 0;
-                if (up_f & (F_MAT | F_SUB)) { b = up_s + tp_right[p]; m = up_f & (F_MAT | F_SUB); }
+                const uint32_t dgm = ZERO ? (uint32_t(up_f) & F_MAT) : f_diag(up_f);      // (no substitutions at distance 0)
+                if (dgm) { b = up_s + tp_right[p]; m = dgm; }
                 if (dn_f & F_DEL) {
                     if (dn_s > b) { b = dn_s; m = F_DEL; } else if (dn_s == b) m |= F_DEL;
                 }
@@ -713,7 +738,7 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
                     zf = grp_get(gbase, zsrc, f1[o], 0);
                     zs = grp_get(gbase, zsrc, sc1[o], S_NEG);
                 }
-                if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((bkc[p] >> 25) & 3)) {
+                if ((uint32_t(zf) & F_SWP_KEY_MASK) == zkey[p]) {
                     const int v = zs + ((bkc[p] >> 27) & 1);
                     if (v >= 0 && (zf & F_TIE)) tie_used++;
                     if (v > b) { b = v; m = F_SWP; } else if (v == b) m |= F_SWP;

@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
     const uint8_t *flg0 = B.hap_flag[d.qs] + d.q_off, *flg1 = B.ref_flag[d.qs] + d.r_off;
     const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off, *Tf = B.hap_flag[d.ts] + d.t_off;
     const int4 *cand0 = B.cand_q[d.qs] + d.q_off, *cand1 = B.cand_r[d.qs] + d.r_off;
+    const int4 *cand20 = B.cand2_q[d.qs] + d.q_off, *cand21 = B.cand2_r[d.qs] + d.r_off;
 
     uint32_t *stamp = scratch + J.stamp_off;
     uint32_t *buf = scratch + J.buf_off;
@@ -452,11 +453,13 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
                     } else if ((f & (F_SWP | F_TIE)) != (F_SWP | F_TIE)) continue;
                 }
                 const int4 cc = (p ? cand1 : cand0)[xq];
-                const int srcs[4] = {cc.x, cc.y, cc.z, cc.w};
+                int4 c2 = make_int4(-1, -1, -1, -1);
+                if (cc.w >= 0) c2 = (p ? cand21 : cand20)[xq];
+                const int srcs[SWAP_SOURCES_MAX] = {cc.x, cc.y, cc.z, cc.w, c2.x, c2.y, c2.z, c2.w};
                 int best = -1, nsrc = 0;
                 uint32_t best_st = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < SWAP_SOURCES_MAX; k++) {
                     if (srcs[k] < 0) continue;
                     const uint32_t st = tie_ld(stamp + sidx(1 - p, srcs[k], t - 1));
                     if (st == TIE_NEVER || st < wave_lo) continue;       // not popped in z's wave
@@ -469,7 +472,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
                     if (k < dec_cap) dec[k] = make_int4(a, int(z.x), t, best);
                     atomicAdd(&lds_nres, 1);
                 } else {
-                    *fp = uint8_t((f & ~uint32_t((3u << F_CHOICE_SHIFT) | F_TIE)) | (uint32_t(best) << F_CHOICE_SHIFT));
+                    *fp = uint8_t((f & ~uint32_t(F_CHOICE_MASK | F_TIE)) | f_choice_bits(best));
                 }
             }
             if (wg_any(oob)) { fail = true; break; }
@@ -756,7 +759,8 @@ __global__ void k_tie_patch(const AlnDesc *__restrict__ descs, const int4 *__res
     uint8_t *fp = tie_flag_ptr(d, ws, reinterpret_cast<const int32_t *>(ws), int(uint32_t(e.y) >> 31), e.y & 0x7fffffff, e.z);
     if (!fp) return;
     const uint32_t f = *fp;
-    *fp = uint8_t((f & ~uint32_t((3u << F_CHOICE_SHIFT) | F_TIE)) | (uint32_t(e.w) << F_CHOICE_SHIFT));
+    if (!(f & F_SWP)) return;      // (the choice's third bit shares F_SUB's place: only a swap cell has a choice field)
+    *fp = uint8_t((f & ~uint32_t(F_CHOICE_MASK | F_TIE)) | f_choice_bits(e.w));
 }
 
 #endif

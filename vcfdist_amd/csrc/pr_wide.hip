@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
     const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
     const int2 *fk[2] = {B.fk_q[d.qs] + d.q_off, B.fk_r[d.qs] + d.r_off};
     const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
+    const int4 *cand2[2] = {B.cand2_q[d.qs] + d.q_off, B.cand2_r[d.qs] + d.r_off};
     const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
     const int2 *xbp[2] = {B.xb_q[d.qs] + d.q_off, B.xb_r[d.qs] + d.r_off};     // budgets of the exit test (pr_device.h)
     const int32_t *vst = B.vs_hap[d.ts] + d.t_off;
@@ -223,7 +224,18 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
                             const int val = (need && srcs[k] >= 0) ? val0 : D_INF;
                             if (need && srcs[k] >= 0 && val <= sw[p]) { tie = (val == sw[p]); sw[p] = val; choice = k + 1; }
                         }
-                        swbits[p] = (choice << F_CHOICE_SHIFT) | (tie ? F_TIE : 0);
+                        if (__builtin_expect(__any(need && cc.w >= 0), 0)) {      // sources five to eight
+                            int4 c2 = make_int4(-1, -1, -1, -1);
+                            if (need && cc.w >= 0) c2 = cand2[p][lo[p] + c];
+                            const int more[4] = {c2.x, c2.y, c2.z, c2.w};
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const int val0 = gather(pp, o, more[k] - olo);
+                                const int val = more[k] >= 0 ? val0 : D_INF;
+                                if (more[k] >= 0 && val <= sw[p]) { tie = (val == sw[p]); sw[p] = val; choice = k + 4; }
+                            }
+                        }
+                        swbits[p] = f_choice_bits(choice) | (tie ? F_TIE : 0);
                     }
                 }
 #pragma unroll
@@ -408,11 +420,13 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
         }
         bool valid[2];
         int tp_right[2], zl[2];
+        uint32_t zkey[2];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             valid[p] = lo[p] + col <= hi[p];
             tp_right[p] = (lo[p] + col + 1 <= hi[p]) ? ((bkrc[p] >> 24) & 1) : 0;
             zl[p] = bkc[p] & 0xffffff;   // swap target (absolute index in the other plane) or FK_NONE24
+            zkey[p] = f_swp_key(rank_of(uint32_t(bkc[p]) >> 24));
         }
         stage_load(s - 1);                                     // prefetch the stripe below into registers
         // forward flags of (plane p, absolute column x, row tt); tt == t+1 may lie in the stripe above
@@ -451,7 +465,7 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
                 const int dn_f = first ? fin_at(p, x, t + 1) : f1[p];
                 int b = S_NEG;
                 uint32_t m = 0;
-                if (up_f & (F_MAT | F_SUB)) { b = up_s + tp_right[p]; m = up_f & (F_MAT | F_SUB); }
+                if (f_diag(up_f)) { b = up_s + tp_right[p]; m = f_diag(up_f); }
                 if (dn_f & F_DEL) {
                     if (dn_s > b) { b = dn_s; m = F_DEL; } else if (dn_s == b) m |= F_DEL;
                 }
@@ -459,7 +473,7 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
                 const bool hasz = zl[p] != int(FK_NONE24);
                 const int zf = hasz ? fin_at(o, zl[p], t + 1) : 0;
                 const int zs = gather_s(pp, o, hasz ? zl[p] - (first ? plo[o] : lo[o]) : -1);
-                if ((zf & F_SWP) && ((zf >> F_CHOICE_SHIFT) & 3) == ((bkc[p] >> 25) & 3)) {
+                if ((uint32_t(zf) & F_SWP_KEY_MASK) == zkey[p]) {
                     const int v = zs + ((bkc[p] >> 27) & 1);
                     if (v >= 0 && (zf & F_TIE)) tie_used++;
                     if (v > b) { b = v; m = F_SWP; } else if (v == b) m |= F_SWP;
