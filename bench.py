@@ -98,6 +98,17 @@ def cpu_baseline(batch, target_s=15.0):
     }
 
 
+def launch_command(n_gpus, argv, port=None):
+    """the command that runs this script as `n_gpus` ranks, one per GPU, on this node (what the driver itself runs)"""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,15 +122,34 @@ def main():
                     help="weak: --n-sc superclusters per GPU (own seed, own contigs); strong: --n-sc-total superclusters of one "
                          "synthetic genome dealt over the ranks by estimated cells, phasing all-gathered every step")
     ap.add_argument("--n-sc-total", type=int, default=3000000)
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="launch path only (no GPU work): the ranks rendezvous over gloo, all-reduce their rank numbers and rank 0 "
+                         "prints {n_gpus, rank_sum}; tests/test_distributed.py runs `bench.py --gpus 2 --plumbing-check` on CPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU, RCCL); rank 0
+        # of the new job prints the line
+        os.execv(sys.executable, launch_command(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
+    if args.plumbing_check:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"plumbing_check": True, "n_gpus": world, "rank_sum": int(t.item())}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     dist = None
     if world > 1:
         import torch.distributed as dist

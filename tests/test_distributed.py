@@ -119,3 +119,25 @@ def test_deal_balances_estimated_cells():
         assert load.max() - load.min() <= cells.max()                             # as even as the largest item allows
         big = np.argsort(-cells)[:w * 10]
         assert all(abs(np.isin(big, p).sum() - 10) <= 4 for p in parts)           # the huge ones are spread over all ranks
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started the way the driver starts `--gpus 1` (plain python, no torchrun, WORLD_SIZE unset)
+    must become a two-rank job: bench.py re-executes itself under torch.distributed.run.  --plumbing-check stops behind the
+    rendezvous and one all-reduce (gloo), so this runs without a GPU; tests/test_gpu_configs.py runs the real thing on the
+    GPU box with both ranks on its one GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "3"], port=1234)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--plumbing-check"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"plumbing_check": True, "n_gpus": 2, "rank_sum": 3}

@@ -225,3 +225,22 @@ def test_stress_workload_full_size_properties():
             assert np.array_equal(r1.sync_group[h][w][idx], r2.sync_group[h][w])
     pr.execute()
     assert not r1.diff(pr.download())
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` as a plain process (no torchrun): it must re-launch itself as two ranks and print n_gpus 2.
+    VCFDIST_BENCH_ONE_GPU puts both ranks on the test box's one GPU with the counters' all-reduce over gloo (a plumbing
+    check: the numbers of such a run mean nothing); on an 8-GPU node the same command runs one rank per GPU over RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["VCFDIST_BENCH_ONE_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--n-sc", "20000", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
+    assert line["config"]["superclusters_per_gpu"] == 20000 and line["scaling"] == "weak"
