@@ -216,7 +216,7 @@ def main():
             pb = summary.phase(sc_phase, np.ones(whole.n_sc, np.int32))[0][my_idx]
         t = torch.from_numpy(summary.pr_counts(pr, None, pb)).to(dev)   # [2][4][3][61] int64, device histogram
         if dist is not None and dist.get_backend() == "gloo":
-            tc = t.cpu(); dist.all_reduce(tc); t = tc.to(dev)
+            th = t.cpu(); dist.all_reduce(th); t = th.to(dev)
         elif dist is not None:
             dist.all_reduce(t)          # the one collective of the path: the precision/recall counters (int64 sum)
         parts[2] += time.perf_counter() - tc

@@ -270,6 +270,10 @@ void backward_pass(const AlnIn &in, AlnState &A) {
     PS(start) = 0;
     fifo.push(start);
     CellSet curr_wave, prev_wave;
+    // A one-cell alignment (end cell == start cell; only where a region was cut at the contig end, include/vcfdist_pr.h):
+    // the reference's loop below never sets done(0,0) for it and spins for ever (dist.cpp:549-687).  Here the path is
+    // that one cell.
+    if (start.qri == 0 && start.ti == 0) { A.beg_plane = A.end_plane; if (A.end_plane == VPR_PLANE_QUERY) A.aln[0].at(0, 0) |= F_PATH; return; }
 
     // relax predecessor y of x with move type `mv` and bonus `tp`
     auto relax = [&](const Cell &x, const Cell &y, uint8_t mv, int tp) {

@@ -57,6 +57,18 @@ def test_many_ties_met_by_a_retry_round():
         assert t.n_tie_replays > 250 and t.n_band_retries > 1500
 
 
+def test_ties_in_every_chunk_of_a_many_chunk_plan():
+    """a tie-rich batch through an 8 MB workspace (the smallest the library takes): the round-0 plan is cut into dozens of chunks and each of them hands
+    alignments to early tie replays, every one of which takes a decision list -- the lists are recycled per chunk (they
+    used to be handed out once per vpr_execute: 64 of them, then VPR_ERR_STATE "out of decision lists")"""
+    batch = api.Synth(**dict(TIE_RICH, n_sc=18000, seed=43)).batch()
+    got, want, n_nonmax, pr = compare(batch, A.default_config(workspace_bytes=8 << 20))
+    n_main = sum(1 for s_ in pr.launch_stats() if s_.kernel.decode() == "k_zero_lane" and s_.n_units > 100)
+    n_tie = int(((want.aln_status & A.ST_SWAP_TIE) != 0).sum())
+    print(f"{n_main} chunks, {n_tie} tied alignments, {pr.timing().n_tie_replays} replays")
+    assert n_main > 20 and n_tie > 200
+
+
 def test_guarded_allocations_no_access_behind_an_array():
     """every device array in an allocation of its own (VPR_CFG_GUARD_ALLOC): a write or read far behind an array is a GPU
     fault here, not a silent hit on whatever the pooled allocator placed there.  Tie-rich retries, long alignments, a

@@ -87,8 +87,8 @@ def test_minimum_sizes_and_empty_haps():
 
 def test_superclusters_at_the_contig_end():
     """a variant on one of the contig's last two bases: the region (end = pos + rlen + 1, cluster.cpp:595) is cut at the
-    last base (include/vcfdist_pr.h, vpr_batch_from_variants); with no base left behind the variant the alignment cannot
-    finish (the reference's ERROR at dist.cpp:440): a status bit, identical in library and oracle"""
+    last base (include/vcfdist_pr.h, vpr_batch_from_variants); library and oracle agree on every array, also where no base
+    is left behind the variant (one-row alignments)"""
     ref = "ACGTTGCAACGTACGGTCAT"        # 20 bases
     S, I, D = A.TYPE_SUB, A.TYPE_INS, A.TYPE_DEL
     scs = [
@@ -103,7 +103,7 @@ def test_superclusters_at_the_contig_end():
     batch = api.batch_from_variants(v)
     assert batch.lens(0)[4] == 4 and batch.lens(3)[4] == 2
     got, want, _, _ = compare(batch)
-    assert (want.aln_status & A.ST_ERR_UNFINISHED).any() and want.aln_dist[0] == 0
+    assert want.aln_dist[0] == 0 and want.aln_dist[12] == 0 and batch.lens(3)[2] == 1
 
 
 def test_sv_sized_sections_use_deferred_edit_distance():

@@ -28,6 +28,7 @@
 #include "pr_kernels.hip"
 #include "pr_band.hip"
 #include "pr_q16.hip"
+#include "pr_zl.hip"
 #include "pr_wide.hip"
 #include "pr_tie.hip"
 
@@ -186,6 +187,10 @@ struct vpr_handle {
     int4 *d_tie_dec = nullptr; int64_t tie_dec_cap = 0;       // decision lists of the early replays (one region per launch)
     int32_t *d_tie_ndec = nullptr;                            // their lengths [TIE_DEC_SLOTS]
     std::vector<int32_t> plan0_pos;                           // position of every alignment in plan0's work list
+    // zero-distance lane kernel (pr_zl.hip): per-wave headers, the wave-interleaved position words (batch lifetime, written
+    // once by k_prep_zl) and the log blocks (shared by the chunks of plan 0, which run one after the other)
+    ZlWave *d_zl_hdr = nullptr; uint32_t *d_zl_in = nullptr; uint4 *d_zl_log = nullptr;
+    std::vector<int64_t> zl_wave0;                            // first wave of every chunk of plan 0
     // host-pinned, device-visible mirrors of d_fail / d_cnt: a publish kernel on the producing stream fills them, so the
     // host reads a fail list after an event wait and issues no copy that the bulk kernels of the round could starve
     int32_t *hp_fail = nullptr, *hp_cnt = nullptr;
@@ -290,6 +295,7 @@ void free_batch(vpr_handle *h) {
     h->d_tie_list = nullptr; h->hp_tie_list = nullptr; h->tie_list_cap = 0; h->d_tie_cnt = nullptr; h->hp_tie_cnt = nullptr;
     h->hp_tie_jobs = nullptr; h->tie_jobs_cap = 0;
     h->d_tie_dec = nullptr; h->tie_dec_cap = 0; h->d_tie_ndec = nullptr; h->plan0_pos.clear();
+    h->d_zl_hdr = nullptr; h->d_zl_in = nullptr; h->d_zl_log = nullptr; h->zl_wave0.clear();
     h->uploaded = h->executed = false;
 }
 
@@ -353,7 +359,7 @@ typedef void (*BandBwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, c
 // one-alignment-per-workgroup window kernels: 64 cells (one wave, striped), 256 and 1024 cells (4 / 16 waves)
 BandFwd band_fwd_kernel(int lv) { return lv == LV_C1 ? BandFwd(k_fwd_stripe) : lv == LV_C4 ? BandFwd(k_fwd_wide<4>) : BandFwd(k_fwd_wide<16>); }
 BandBwd band_bwd_kernel(int lv) { return lv == LV_C1 ? BandBwd(k_bwd_stripe) : lv == LV_C4 ? BandBwd(k_bwd_wide<4>) : BandBwd(k_bwd_wide<16>); }
-const char *band_fwd_name(int lv) { return lv == LV_Z ? "k_fwd_z16" : lv == LV_Q16 ? "k_fwd_q16" : lv == LV_C1 ? "k_fwd_stripe" : lv == LV_C4 ? "k_fwd_wide<4>" : "k_fwd_wide<16>"; }
+const char *band_fwd_name(int lv) { return lv == LV_Z ? "k_zero_lane" : lv == LV_Q16 ? "k_fwd_q16" : lv == LV_C1 ? "k_fwd_stripe" : lv == LV_C4 ? "k_fwd_wide<4>" : "k_fwd_wide<16>"; }
 const char *band_bwd_name(int lv) { return lv == LV_Z ? "k_bwd_q16<zero>" : lv == LV_Q16 ? "k_bwd_q16" : lv == LV_C1 ? "k_bwd_stripe" : lv == LV_C4 ? "k_bwd_wide<4>" : "k_bwd_wide<16>"; }
 
 int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -703,6 +709,55 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             }
         }
     }
+    return VPR_OK;
+}
+
+
+// Zero-distance lane kernel (pr_zl.hip): cut the short part of every chunk of plan 0 into waves of 64 alignments, size
+// each wave's interleaved input block and log blocks, and write the position words (k_prep_zl; behind K0 and the
+// descriptor scatter on the upload stream).
+int prep_zero_lane(vpr_handle *h) {
+    const Plan &P = h->plan0;
+    std::vector<ZlWave> hdr;
+    h->zl_wave0.assign(P.chunks.size(), 0);
+    int64_t in_words = 0, log_max = 0;
+    for (size_t ci = 0; ci < P.chunks.size(); ci++) {
+        const Chunk &ch = P.chunks[ci];
+        h->zl_wave0[ci] = int64_t(hdr.size());
+        const int64_t first = ch.work_off + ch.n_long, n_short = ch.count - ch.n_long;
+        int64_t log_cur = 0;
+        for (int64_t k = 0; k < n_short; k += 64) {
+            ZlWave W;
+            memset(&W, 0, sizeof(W));
+            for (int64_t j = k; j < std::min(n_short, k + 64); j++) {
+                const AlnDesc &d = P.descs[size_t(first + j)];
+                W.mq = std::max(W.mq, d.Lq); W.mr = std::max(W.mr, d.Lr); W.mt = std::max(W.mt, d.Lt);
+            }
+            W.in_off = in_words;
+            W.log_off = log_cur;
+            in_words += 64 * (int64_t(W.mq) + W.mr + W.mt);
+            log_cur += 2 * 64 * int64_t(W.mt);
+            hdr.push_back(W);
+        }
+        log_max = std::max(log_max, log_cur);
+    }
+    if (hdr.empty()) return VPR_OK;
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_zl_hdr, hdr.size()))) return rc;
+    if ((rc = dev_alloc(h, &h->d_zl_in, size_t(in_words)))) return rc;
+    if ((rc = dev_alloc(h, &h->d_zl_log, size_t(log_max)))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_zl_hdr, hdr.data(), hdr.size() * sizeof(ZlWave), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));         // (hdr is a local: the copy must have left it)
+    for (size_t ci = 0; ci < P.chunks.size(); ci++) {
+        const Chunk &ch = P.chunks[ci];
+        const int64_t n_short = ch.count - ch.n_long;
+        if (n_short <= 0) continue;
+        hipLaunchKernelGGL(k_prep_zl, dim3(unsigned((n_short + 63) / 64)), dim3(256), 0, h->stream, h->dB, h->d_descs,
+                           P.d_work + ch.work_off + ch.n_long, int(n_short), h->d_zl_hdr + h->zl_wave0[ci], h->d_zl_in);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (h->debug) fprintf(stderr, "[vpr] zero-distance lane level: %zu waves, %.2f GB position words, %.2f GB log\n", hdr.size(),
+                          double(in_words) * 4e-9, double(log_max) * 16e-9);
     return VPR_OK;
 }
 
@@ -1107,6 +1162,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         HIPCHK(h, hipMemcpyAsync(h->plan0.d_work, h->plan0.work.data(), na * 4, hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(na)), dim3(256), 0, h->stream, h->plan0.d_descs, int(na), h->d_descs);
     }
+    if (lv0 == LV_Z && (rc = prep_zero_lane(h))) return rc;
 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
@@ -1212,6 +1268,26 @@ struct Exec {
     void post_flag(int idx, hipStream_t ks) {     // "everything enqueued on ks so far is complete" -> hp_flag[idx]
         flag_exp[idx] = ++h->flag_seq;
         hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, ks, h->hp_flag + idx, flag_exp[idx]);
+        const hipError_t e = hipGetLastError();          // a failed launch (of this or an earlier kernel of the phase) would
+        if (e != hipSuccess && launch_err == hipSuccess) launch_err = e;   // leave the flag down for ever: see idle_check
+    }
+    hipError_t launch_err = hipSuccess;
+    int64_t zl_wave0 = 0;                          // first wave header of the chunk whose zero-distance part is being enqueued
+
+    // the host loop found nothing to serve `idle_polls` times in a row: make sure the device is still alive.  A stream in
+    // an error state (a failed launch, a fault in a kernel) never raises its flags; without this vpr_execute would hang.
+    int idle_check(int64_t idle_polls, std::chrono::steady_clock::time_point since) {
+        if (launch_err != hipSuccess) return fail(h, VPR_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(launch_err));
+        if (idle_polls % 2048) return VPR_OK;            // about every 40 ms without progress
+        hipStream_t ss[] = {h->stream, h->cls_stream[0], h->cls_stream[1], h->cls_stream[2], h->cls_stream[3],
+                            h->tie_stream[0], h->tie_stream[1], h->tie_stream[2], h->tie_stream[3]};
+        for (hipStream_t s_ : ss) {
+            const hipError_t e = hipStreamQuery(s_);
+            if (e != hipSuccess && e != hipErrorNotReady) return fail(h, VPR_ERR_DEVICE, "stream error while waiting for a round: %s", hipGetErrorString(e));
+        }
+        const double idle_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - since).count();
+        if (idle_s > 900.0) return fail(h, VPR_ERR_DEVICE, "no round completed for %.0f s", idle_s);
+        return VPR_OK;
     }
 
     bool flag_up(int idx) { return *static_cast<volatile int32_t *>(h->hp_flag + idx) == flag_exp[idx]; }
@@ -1490,9 +1566,9 @@ struct Exec {
         if (phases & 1) {
         cells_touched += ls.cells;
         rc = timed(1, ls, ks, band_fwd_name(lv), [&] {
-            if (zero)
-                hipLaunchKernelGGL(k_fwd_z16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                   P.arena, a_i32, h->d_outs, n_dev);
+            if (zero)        // forward + backward + walk of the zero-distance alignments, one lane each (pr_zl.hip)
+                hipLaunchKernelGGL(k_zero_lane, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->d_descs, list, cnt,
+                                   h->d_zl_hdr + zl_wave0, h->d_zl_in, h->d_zl_log, h->d_outs, a_path);
             else if (q16)
                 hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);
@@ -1513,13 +1589,10 @@ struct Exec {
         }
         HIPCHK(h, hipEventRecord(h->ev_slot[slot], ks));
         }
-        if (phases & 2) {
+        if ((phases & 2) && !zero) {
         ls.bytes_algorithmic = ls.cells;
         rc = timed(2, ls, ks, band_bwd_name(lv), [&] {
-            if (zero)
-                hipLaunchKernelGGL(k_bwd_q16<true>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                   P.arena, a_i32, h->d_outs, tag, dtag, n_dev);
-            else if (q16)
+            if (q16)
                 hipLaunchKernelGGL(k_bwd_q16<false>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, tag, dtag, n_dev);
             else
@@ -1537,8 +1610,8 @@ struct Exec {
         ws_.threads = q16 ? 16 : 64; ws_.n_units = cnt; ws_.cells_per_thread = 2;
         if (q16) {
             // 16-cell layout: row-sweep walk, four alignments per wave (phase A) + credit walk (phase B)
-            rc = timed(3, ws_, ks, "k_walk_q16", [&] {
-                hipLaunchKernelGGL(zero ? k_walk_q16<true> : k_walk_q16<false>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+            if (!zero) rc = timed(3, ws_, ks, "k_walk_q16", [&] {
+                hipLaunchKernelGGL(k_walk_q16<false>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, a_path, tag, dtag, n_dev);
             });
             if (rc) return rc;
@@ -1639,7 +1712,9 @@ struct Exec {
         if (!tie) n_retry += int64_t(fails.size());
         std::sort(fails.begin(), fails.end());   // deterministic planning
         std::vector<int32_t> by_lv[LV_DENSE + 1];
-        for (int32_t a : fails) by_lv[std::min<int>(h->level[size_t(a)] + (tie ? 0 : 1), LV_DENSE)].push_back(a);
+        // (a tie round repeats the alignment's level; the zero-distance lane kernel never marks one, so an alignment still
+        // listed at LV_Z was accepted by the in-place 16-cell round)
+        for (int32_t a : fails) by_lv[std::min<int>(tie ? std::max<int>(h->level[size_t(a)], LV_Q16) : h->level[size_t(a)] + 1, LV_DENSE)].push_back(a);
         if (h->debug)
             fprintf(stderr, "[vpr] retry round (ladder %d): %zu -> 16, %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n",
                     int(&c - h->lad), by_lv[1].size(), by_lv[2].size(), by_lv[3].size(), by_lv[4].size(), by_lv[5].size());
@@ -1665,7 +1740,7 @@ struct Exec {
         bool zero_slots = true;
         if (c.arena_cur == 0) drop_resident(c);
         if (!tie) hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, c.ls, h->d_tie_cnt + 5 + int(&c - h->lad), 0);   // the round's tie count
-        for (int lv = tie ? LV_Z : LV_Q16; lv <= LV_DENSE; lv++) {
+        for (int lv = LV_Q16; lv <= LV_DENSE; lv++) {
             if (by_lv[lv].empty()) continue;
             c.plans.emplace_back();
             Plan &P = c.plans.back();
@@ -1887,6 +1962,8 @@ struct Exec {
             HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
             HIPCHK(h, hipMemsetAsync(h->d_tie_cnt, 0, 32, st));
             HIPCHK(h, hipMemsetAsync(h->d_tie_ndec, 0, TIE_DEC_SLOTS * 4, st));
+            // the previous chunk has joined: its decision lists (slots of d_tie_ndec, regions of d_tie_dec) are free again
+            tie_dec_slot = 0; tie_dec_cur = 0; tie_patch_slot = -1; spec_slot = -1;
             HIPCHK(h, hipEventRecord(h->ev_fork, st));
             HIPCHK(h, hipStreamWaitEvent(s_long, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(s_short, h->ev_fork, 0));
@@ -1925,6 +2002,7 @@ struct Exec {
                 }
             }
             if (inplace) {
+                zl_wave0 = h->zl_wave0[ci];
                 const int32_t *n_dev = h->d_cnt + 1;
                 const int ztag = LV_TAG[LV_Z];
                 HIPCHK(h, hipMemsetAsync(h->d_cnt + SLOT_IP, 0, 4, s_short));
@@ -1963,10 +2041,13 @@ struct Exec {
             // ---- the host serves whatever is ready: a fail list of round 0 starts a ladder, a finished ladder round
             // starts the next, a published tie list starts a tie round; it never blocks on one while another is ready
             std::vector<int32_t> fails, carry[2];
+            int64_t idle_polls = 0;
+            auto idle_since = std::chrono::steady_clock::now();
             bool wait_fail[2] = {n_long > 0, n_short > 0}, wait_tie[2] = {n_long > 0, n_short > 0};
             while (wait_fail[0] || wait_fail[1] || wait_tie[0] || wait_tie[1] || wait_spec || lad_tie_wait[0] || lad_tie_wait[1] || !LL.pending.empty() || !LS.pending.empty() ||
                    !h->lad[2].pending.empty() || !h->lad[3].pending.empty()) {
                 bool progressed = false;
+                if (idle_polls == 0) idle_since = std::chrono::steady_clock::now();
                 if (wait_spec && flag_up(8)) {
                     const int32_t n = std::min(h->hp_tie_cnt[4], tie_cap[2]);
                     // (a speculative replay pays off as a head start for a few long chains; when thousands of alignments carry
@@ -2019,7 +2100,11 @@ struct Exec {
                         progressed = true;
                     }
                 // (no busy wait: a spinning host thread can exhaust the process's CPU quota, which stalls the runtime's threads)
-                if (!progressed) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                if (progressed) idle_polls = 0;
+                else {
+                    if ((rc = idle_check(++idle_polls, idle_since))) return rc;
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+                }
             }
             lapx("ladders and tie rounds drained");
             // join: the next chunk reuses the arena

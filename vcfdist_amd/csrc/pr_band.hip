@@ -339,6 +339,7 @@ __device__ __forceinline__ int exit_key(int ex, int p, int D, int rho, int2 bud,
 __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__restrict__ descs,
                                                    const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
                                                    int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
+    __builtin_amdgcn_s_setprio(2);      // a latency chain (rows are sequential): win issue arbitration against the bulk kernels
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     const int lane = threadIdx.x;
@@ -610,6 +611,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
 __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__restrict__ descs,
                                                    const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
                                                    const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs, int tag) {
+    __builtin_amdgcn_s_setprio(2);      // a latency chain (rows are sequential): win issue arbitration against the bulk kernels
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     if (outs[a].band_ok != tag || d.band_pad != tag) return;   // rejected by the exit test (re-run wider) or another round's
@@ -811,6 +813,7 @@ __global__ void __launch_bounds__(64) k_walk_rows(DevBatch B, const AlnDesc *__r
                                                   const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
                                                   AlnOut *__restrict__ outs, PathEnt *__restrict__ paths, int tag) {
     if (int(blockIdx.x) >= n_work) return;
+    __builtin_amdgcn_s_setprio(2);      // a latency chain (rows are sequential): win issue arbitration against the bulk kernels
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     AlnOut &O = outs[a];

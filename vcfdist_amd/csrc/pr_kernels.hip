@@ -841,6 +841,7 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
     __shared__ int32_t tblo[WAVE ? 2 * WALK_TR : 2];
     const int wi = WAVE ? int(blockIdx.x) : int(blockIdx.x * blockDim.x + threadIdx.x);
     if (wi >= n_work) return;
+    if (WAVE) __builtin_amdgcn_s_setprio(2);   // one wave per long alignment: a latency chain
     const int lane = threadIdx.x & 63;
     const bool lead = !WAVE || lane == 0;
     const int a = work[wi];
@@ -991,6 +992,7 @@ __global__ void __launch_bounds__(64) k_credit(DevBatch B, const AlnDesc *__rest
     if (n_dev) n_work = min(n_work, *n_dev);
     const int wi = WAVE ? int(blockIdx.x) : int(blockIdx.x * blockDim.x + threadIdx.x);
     if (wi >= n_work) return;
+    if (WAVE) __builtin_amdgcn_s_setprio(2);   // one wave per long alignment: a latency chain
     const int a = work[wi];
     if (a < 0) return;   // padding of a device-built work list
     const AlnDesc d = descs[a];

@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
                                                       const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
                                                       int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
     constexpr int W = NW * 64;
+    __builtin_amdgcn_s_setprio(2);      // a latency chain (rows are sequential): win issue arbitration against the bulk kernels
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     const int c = threadIdx.x;                     // window column of this thread
@@ -339,6 +340,7 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
                                                       const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
                                                       const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs, int tag) {
     constexpr int W = NW * 64;
+    __builtin_amdgcn_s_setprio(2);
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     if (outs[a].band_ok != tag || d.band_pad != tag) return;   // rejected by the exit test: re-run wider (uniform)

@@ -1,0 +1,404 @@
+// pr_zl.hip -- the zero-distance level of the short part: ONE LANE PER ALIGNMENT, forward expansion + backward max-TP
+// pass + walk in one kernel (k_zero_lane).
+//
+// On whole-genome input nine alignments in ten have distance 0, and for those the reference's own algorithm is tiny:
+// wave 0 of calc_prec_recall_aln (dist.cpp:312-381) is a breadth-first expansion over MAT and SWP edges only, every
+// edge advances the truth row by one, and a row holds the one or two cells (seldom more) whose diagonal still matches.
+// A window kernel spends a 16-lane row group on the 32 cells around them; here a lane owns an alignment and keeps the
+// reached cells of the current row in registers -- up to four diagonals per plane ("slots": a MAT edge keeps its slot,
+// a SWP edge lands in a slot of the other plane).  The 64 lanes of a wave walk 64 alignments of (nearly) equal length in
+// lockstep, row by row:
+//
+//   forward   row t -> t+1: MAT child of every live slot (next base of its plane == next truth base), SWP child
+//             (fwd_allow at the source and the truth row, dist.cpp:336-339, base at ptr + 1 of the other plane == next
+//             truth base).  The row's cells go to the log, 4 B each: position, "entered by MAT / by SWP from slot s",
+//             and the two bits of the cell's own position word the backward pass needs (is_tp, bwd_allow).
+//   backward  calc_prec_recall_path (dist.cpp:536-687, zero-cost moves only) over the log rows in reverse: score of a
+//             cell = max over its successors of (their score + is_tp), path_ptr bits = the moves that reach the max;
+//             the log entries get the bits and the slot of the SWP successor.
+//   walk      get_prec_recall_path_sync (dist.cpp:865-998): from the begin cell along the path_ptr bits by the
+//             reference's priorities (REF plane: SWP first; then MAT; QUERY plane: SWP last), sync flag per step;
+//             16-byte path entries in the layout k_credit reads.
+//
+// What it does not take: an alignment whose end cells are not reached at distance 0 (s > 0), a row with more than four
+// diagonals on a plane, lengths that do not fit the 16-bit position fields, and a cell that receives a SWP edge from two
+// different sources (the reference keeps the last writer, dist.cpp:347,376 -- at distance 0 that is plain FIFO order,
+// but such cells are rare and the general kernels + the container-order replay already decide them).  All of these are
+// *rejected* exactly like a failed window test: band_ok = 0, the alignment re-runs in place with the 16-cell kernels.
+//
+// Memory access is the point of the layout: a lane streams through its own alignment, so with the batch's CSR arrays
+// every load of a wave would touch 64 different cache lines.  k_prep_zl therefore writes, once per batch, a
+// WAVE-INTERLEAVED copy of what the kernel reads: for the 64 alignments of a wave, position x of alignment l is word
+// (x * 64 + l) of the wave's Q / R / T block -- the lanes are at (nearly) the same position at the same time, so a wave
+// load is a few consecutive 256-byte rows.  The log has the same shape: row t of lane l is 16 bytes at (t * 64 + l) * 16
+// (slots Q0 Q1 R0 R1; slots 2, 3 of both planes in a second block that is only touched when a row uses them).
+#ifndef PR_ZL_HIP_
+#define PR_ZL_HIP_
+
+// per wave of 64 alignments: offsets (in 32-bit words) of its interleaved input block and of its log blocks
+struct ZlWave {
+    int64_t in_off;       // Q block; R block at + 64 * mq, T block at + 64 * (mq + mr)
+    int64_t log_off;      // in uint4 units: rows of slots 0,1 at log_off + t * 64 + lane; slots 2,3 at + 64 * mt
+    int32_t mq, mr, mt;   // largest Lq / Lr / Lt of the wave's alignments
+    int32_t pad;
+};
+
+// position word
+#define ZW_PTR(w) (int((w) & 0xffffu) - 1)
+#define ZW_BASE(w) (((w) >> 16) & 0x7fu)
+#define ZW_PV (1u << 23)
+#define ZW_PB (1u << 24)
+#define ZW_PE (1u << 25)
+#define ZW_INS (1u << 26)
+#define ZW_TP (1u << 27)
+__device__ __forceinline__ bool zw_fwd_allow(uint32_t w) { return !(w & ZW_PV) || (w & ZW_PE); }
+__device__ __forceinline__ bool zw_bwd_allow(uint32_t w) { return !(w & ZW_PV) || (w & ZW_PB); }
+
+// log entry
+#define ZE_HASMAT (1u << 16)
+#define ZE_HASSWP (1u << 17)
+#define ZE_PSLOT_SHIFT 18      // 2 bits: slot of the SWP predecessor (other plane, previous row)
+#define ZE_PPMAT (1u << 20)
+#define ZE_PPSWP (1u << 21)
+#define ZE_SSLOT_SHIFT 22      // 2 bits: slot of the SWP successor (other plane, next row)
+#define ZE_TP (1u << 25)
+#define ZE_BWD (1u << 26)
+#define ZE_EXT (1u << 31)      // word 0 of a row only: the row also has cells in slots 2, 3
+
+#define ZL_MAXLEN 65000
+
+// K0z: wave-interleaved position words.  One thread per (wave, array, position, lane), lanes fastest.
+//   hdr[w], list: the waves of one chunk's short part (list[64 w + l] = alignment of lane l, -1 beyond the end)
+__global__ void __launch_bounds__(256) k_prep_zl(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list,
+                                                 int n_list, const ZlWave *__restrict__ hdr, uint32_t *__restrict__ zin) {
+    const int w = blockIdx.x;
+    const ZlWave H = hdr[w];
+    const int l = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int wi = w * 64 + l;
+    const int a = wi < n_list ? list[wi] : -1;
+    uint32_t *out = zin + H.in_off;
+    if (a < 0) {
+        const int tot = H.mq + H.mr + H.mt;
+        for (int x = sub; x < tot; x += 4) out[int64_t(x) * 64 + l] = 0x7f0000u;
+        return;
+    }
+    const AlnDesc d = descs[a];
+    const int qs = d.qs, ts = d.ts;
+    const uint8_t *insq = B.has_ins[qs] + d.r_off, *inst = B.has_ins[ts] + d.r_off;
+    auto ins_at = [&](int r) -> uint32_t { return (r >= 0 && r < d.Lr && (insq[r] | inst[r])) ? ZW_INS : 0u; };
+    auto flagbits = [](int f) -> uint32_t { return ((f & PV) ? ZW_PV : 0u) | ((f & PB) ? ZW_PB : 0u) | ((f & PE) ? ZW_PE : 0u); };
+    {   // Q
+        const uint8_t *seq = B.hap_seq[qs] + d.q_off, *flg = B.hap_flag[qs] + d.q_off;
+        const int32_t *ptr = B.hap_ptr[qs] + d.q_off;
+        for (int x = sub; x < H.mq; x += 4) {
+            uint32_t v = 0x7f0000u;
+            if (x < d.Lq) {
+                const int p = ptr[x], f = flg[x];
+                const bool tp = x > 0 && ((p != ptr[x - 1] + 1) || (f & PB));       // dist.cpp:572-574
+                v = uint32_t((p + 1) & 0xffff) | (uint32_t(seq[x] & 0x7f) << 16) | flagbits(f) | ins_at(p) | (tp ? ZW_TP : 0u);
+            }
+            out[int64_t(x) * 64 + l] = v;
+        }
+    }
+    out += int64_t(H.mq) * 64;
+    {   // R
+        const uint8_t *seq = B.ref_seq + d.r_off, *flg = B.ref_flag[qs] + d.r_off;
+        const int32_t *ptr = B.ref_ptr[qs] + d.r_off;
+        for (int x = sub; x < H.mr; x += 4) {
+            uint32_t v = 0x7f0000u;
+            if (x < d.Lr) v = uint32_t((ptr[x] + 1) & 0xffff) | (uint32_t(seq[x] & 0x7f) << 16) | flagbits(flg[x]) | ins_at(x);
+            out[int64_t(x) * 64 + l] = v;
+        }
+    }
+    out += int64_t(H.mr) * 64;
+    {   // T
+        const uint8_t *seq = B.hap_seq[ts] + d.t_off, *flg = B.hap_flag[ts] + d.t_off;
+        const int32_t *ptr = B.hap_ptr[ts] + d.t_off;
+        for (int x = sub; x < H.mt; x += 4) {
+            uint32_t v = 0x7f0000u;
+            if (x < d.Lt) v = uint32_t((ptr[x] + 1) & 0xffff) | (uint32_t(seq[x] & 0x7f) << 16) | flagbits(flg[x]) | ins_at(ptr[x]);
+            out[int64_t(x) * 64 + l] = v;
+        }
+    }
+}
+
+// ===========================================================================
+// KZ: forward + backward + walk of the zero-distance alignments, one lane per alignment
+// ===========================================================================
+__global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list, int n_list,
+                                                  const ZlWave *__restrict__ hdr, const uint32_t *__restrict__ zin,
+                                                  uint4 *__restrict__ zlog, AlnOut *__restrict__ outs, PathEnt *__restrict__ paths) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const ZlWave H = hdr[w];
+    const int wi = w * 64 + lane;
+    const int a_ = wi < n_list ? list[wi] : -1;
+    const bool live = a_ >= 0;
+    const int a = max(a_, 0);
+    const AlnDesc *dp = descs + a;
+    const int Lq = live ? dp->Lq : 1, Lr = live ? dp->Lr : 1, Lt = live ? dp->Lt : 0;
+    const int L[2] = {Lq, Lr};
+    const uint32_t *Z[2] = {zin + H.in_off + lane, zin + H.in_off + int64_t(H.mq) * 64 + lane};
+    const uint32_t *ZT = zin + H.in_off + int64_t(H.mq + H.mr) * 64 + lane;
+    uint4 *logA = zlog + H.log_off + lane, *logB = logA + int64_t(H.mt) * 64;
+    // (a one-row alignment only exists where a region was cut at the contig end, include/vcfdist_pr.h: the reference's
+    // backward pass never terminates on it -- left to the general kernels, which report it as unfinished)
+    bool ok = live && Lq < ZL_MAXLEN && Lr < ZL_MAXLEN && Lt < ZL_MAXLEN && Lt >= 2;
+    const int rows = ok ? Lt : 0;
+    int tmax = rows;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) tmax = max(tmax, __shfl_xor(tmax, o));
+    if (tmax == 0) {
+        if (live) { outs[a].dist_q = D_INF; outs[a].dist_r = D_INF; outs[a].exit_min = 0; }
+        return;
+    }
+
+    // ---------------- forward: the cells of wave 0, row by row (dist.cpp:317-381)
+    int qri[2][4];
+    uint32_t pw[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) { qri[p][s] = -1; pw[p][s] = 0; }
+    }
+    if (rows > 0) {     // the two start cells, dist.cpp:300-305
+        qri[0][0] = 0; pw[0][0] = Z[0][0];
+        qri[1][0] = 0; pw[1][0] = Z[1][0];
+        logA[0] = make_uint4(1u | ZE_HASMAT | (pw[0][0] & ZW_TP ? ZE_TP : 0u) | (zw_bwd_allow(pw[0][0]) ? ZE_BWD : 0u), 0u,
+                             1u | ZE_HASMAT | (zw_bwd_allow(pw[1][0]) ? ZE_BWD : 0u), 0u);
+    }
+    uint32_t tw0 = rows > 0 ? ZT[0] : 0u;
+    for (int t = 0; t + 1 < tmax; t++) {
+        const bool act = ok && t + 1 < rows;
+        const uint32_t tw1 = ZT[int64_t(min(t + 1, H.mt - 1)) * 64];
+        const uint32_t Tb = ZW_BASE(tw1);
+        const bool t_allow = zw_fwd_allow(tw0);
+        // children's position words: MAT child x + 1 of the own plane, SWP child ptr + 1 of the other plane
+        uint32_t mw[2][4], sw[2][4];
+        int sz[2][4];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const bool alive = act && qri[p][s] >= 0;
+                if (!__any(alive)) { mw[p][s] = 0x7f0000u; sw[p][s] = 0x7f0000u; sz[p][s] = -1; continue; }
+                const int c = qri[p][s] + 1;
+                mw[p][s] = (alive && c < L[p]) ? Z[p][int64_t(c) * 64] : 0x7f0000u;
+                const int z = ZW_PTR(pw[p][s]) + 1;
+                const bool sok = alive && t_allow && zw_fwd_allow(pw[p][s]) && z >= 0 && z < L[1 - p];
+                sz[p][s] = sok ? z : -1;
+                sw[p][s] = sok ? Z[1 - p][int64_t(z) * 64] : 0x7f0000u;
+            }
+        }
+        int nq[2][4];
+        uint32_t nw[2][4], ne[2][4];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const bool hit = act && qri[p][s] >= 0 && ZW_BASE(mw[p][s]) == Tb && qri[p][s] + 1 < L[p];
+                nq[p][s] = hit ? qri[p][s] + 1 : -1;
+                nw[p][s] = mw[p][s];
+                ne[p][s] = hit ? ZE_HASMAT : 0u;
+            }
+        }
+        bool bad = false;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int o = 1 - p;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const bool hit = sz[p][s] >= 0 && ZW_BASE(sw[p][s]) == Tb;
+                if (!__any(hit)) continue;
+                const int z = sz[p][s];
+                // the cell (o, z) of row t + 1: already there (by MAT, or by another source's SWP), else the first free slot
+                int at = -1;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) if (nq[o][k] < 0) at = k;
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (nq[o][k] == z) at = k;
+                if (hit && at < 0) bad = true;                    // a fifth diagonal on the plane
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (hit && at == k) {
+                        if (ne[o][k] & ZE_HASSWP) bad = true;     // a second SWP source of the cell: left to the general kernels
+                        nq[o][k] = z;
+                        nw[o][k] = sw[p][s];
+                        ne[o][k] |= ZE_HASSWP | (uint32_t(s) << ZE_PSLOT_SHIFT);
+                    }
+                }
+            }
+        }
+        if (bad) ok = false;
+        // the row's log entries
+        if (act && ok) {
+            uint32_t e[2][4];
+            bool ext = false;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    e[p][s] = nq[p][s] < 0 ? 0u
+                              : (uint32_t(nq[p][s] + 1) | ne[p][s] | ((nw[p][s] & ZW_TP) ? ZE_TP : 0u) | (zw_bwd_allow(nw[p][s]) ? ZE_BWD : 0u));
+                    if (s >= 2 && nq[p][s] >= 0) ext = true;
+                }
+            }
+            logA[int64_t(t + 1) * 64] = make_uint4(e[0][0] | (ext ? ZE_EXT : 0u), e[0][1], e[1][0], e[1][1]);
+            if (ext) logB[int64_t(t + 1) * 64] = make_uint4(e[0][2], e[0][3], e[1][2], e[1][3]);
+        }
+        if (act) {
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) { qri[p][s] = nq[p][s]; pw[p][s] = nw[p][s]; }
+            }
+            tw0 = tw1;
+        }
+    }
+    // end cells (dist.cpp:390-391, 436-439: the QUERY plane is preferred)
+    int endq = -1, endr = -1;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        if (qri[0][s] == Lq - 1) endq = s;
+        if (qri[1][s] == Lr - 1) endr = s;
+    }
+    ok = ok && (endq >= 0 || endr >= 0);
+    if (live) {
+        AlnOut &o = outs[a];
+        o.dist_q = (ok && endq >= 0) ? 0 : D_INF;
+        o.dist_r = (ok && endr >= 0) ? 0 : D_INF;
+        o.exit_min = ok ? D_INF : 0;          // k_fwd_band_finish: accepted iff s = 0 here
+    }
+    if (!__any(ok)) return;
+
+    // ---------------- backward: max-TP scores over the zero-cost moves (dist.cpp:550-681), rows Lt-1 .. 1
+    const int nrow = ok ? Lt : 0;
+    int sc[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) sc[p][s] = -1;
+    }
+    int bmax = nrow;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) bmax = max(bmax, __shfl_xor(bmax, o));
+    uint4 curA = make_uint4(0, 0, 0, 0), curB = curA;      // entries of row t
+    for (int t = bmax - 1; t >= 1; t--) {
+        const bool act = t < nrow;
+        if (t == nrow - 1) {      // this lane's last row: the end cell has score 0 (dist.cpp:538-546)
+            curA = logA[int64_t(t) * 64];
+            curB = (curA.x & ZE_EXT) ? logB[int64_t(t) * 64] : make_uint4(0, 0, 0, 0);
+            const int ep = endq >= 0 ? 0 : 1, es = endq >= 0 ? endq : endr;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) sc[p][s] = (p == ep && s == es) ? 0 : -1;
+            }
+        }
+        uint4 preA = make_uint4(0, 0, 0, 0), preB = preA;
+        if (act) {
+            preA = logA[int64_t(t - 1) * 64];
+            if (preA.x & ZE_EXT) preB = logB[int64_t(t - 1) * 64];
+        }
+        const uint32_t ce[2][4] = {{curA.x, curA.y, curB.x, curB.y}, {curA.z, curA.w, curB.z, curB.w}};
+        int best[2][4];
+        uint32_t pp[2][4];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) { best[p][s] = -1; pp[p][s] = 0; }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int o = 1 - p;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const bool on = act && sc[p][s] >= 0;
+                if (!__any(on)) continue;
+                const uint32_t e = ce[p][s];
+                const int tp = (e & ZE_TP) ? 1 : 0;
+                if (on && (e & ZE_HASMAT)) {      // MAT predecessor: same plane, same slot
+                    const int v = sc[p][s] + tp;
+                    if (v > best[p][s]) { best[p][s] = v; pp[p][s] = ZE_PPMAT; }
+                    else if (v == best[p][s]) pp[p][s] |= ZE_PPMAT;
+                }
+                if (on && (e & ZE_HASSWP) && (e & ZE_BWD)) {      // SWP predecessor (bwd_allow at this cell, dist.cpp:599-602)
+                    const int v = sc[p][s] + (p == 1 ? 0 : tp);  // leaving a REF cell scores 0 (dist.cpp:614)
+                    const int ps = int((e >> ZE_PSLOT_SHIFT) & 3u);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (ps == k) {
+                            if (v > best[o][k]) { best[o][k] = v; pp[o][k] = ZE_PPSWP | (uint32_t(s) << ZE_SSLOT_SHIFT); }
+                            else if (v == best[o][k]) pp[o][k] = (pp[o][k] & ~(3u << ZE_SSLOT_SHIFT)) | ZE_PPSWP | (uint32_t(s) << ZE_SSLOT_SHIFT);
+                        }
+                    }
+                }
+            }
+        }
+        if (act) {
+            // row t - 1 with its path_ptr bits (a cell has one SWP successor: the slot is unambiguous)
+            uint32_t pe[2][4] = {{preA.x, preA.y, preB.x, preB.y}, {preA.z, preA.w, preB.z, preB.w}};
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    if (best[p][s] >= 0) pe[p][s] |= pp[p][s];
+                    sc[p][s] = best[p][s];
+                }
+            }
+            curA = make_uint4(pe[0][0], pe[0][1], pe[1][0], pe[1][1]);
+            curB = make_uint4(pe[0][2], pe[0][3], pe[1][2], pe[1][3]);
+            logA[int64_t(t - 1) * 64] = curA;
+            if (preA.x & ZE_EXT) logB[int64_t(t - 1) * 64] = curB;
+        }
+    }
+    // (QUERY, 0, 0) on a path to the end?  dist.cpp:811-814
+    const int beg_plane = sc[0][0] >= 0 ? VPR_PLANE_QUERY : VPR_PLANE_REF;
+
+    // ---------------- walk (dist.cpp:905-982) + sync flags (dist.cpp:949-968)
+    PathEnt *path = paths + dp->path_off;
+    int hi = beg_plane, slot = 0, mv_in = 0;
+    uint32_t status = 0;
+    bool wok = ok;
+    for (int t = 0; t < bmax; t++) {
+        const bool act = wok && t < nrow;
+        const uint32_t *lw = reinterpret_cast<const uint32_t *>((slot < 2 ? logA : logB) + int64_t(t) * 64);
+        uint32_t e = 0, cw = 0, tw = 0;
+        if (act) {
+            e = lw[(hi << 1) | (slot & 1)];
+            tw = ZT[int64_t(t) * 64];
+        }
+        const int x = int(e & 0xffffu) - 1;
+        if (act) cw = Z[hi][int64_t(max(x, 0)) * 64];
+        if (act) {
+            const int trv = ZW_PTR(tw), qref = hi ? x : ZW_PTR(cw);
+            uint32_t sync = 1;
+            if (mv_in) {
+                const bool in_t = (tw & ZW_PV) && !(tw & ZW_PB);
+                const bool in_q = hi == 0 && (cw & ZW_PV) && !(cw & ZW_PB);
+                sync = (!in_t && !in_q && !((tw | cw) & ZW_INS) && trv == qref) ? 1u : 0u;
+            }
+            uint4 pe;
+            pe.x = uint32_t(x) | (uint32_t(hi) << 31);
+            pe.y = uint32_t(t) | (sync << 31);
+            pe.z = uint32_t(qref);
+            pe.w = uint32_t(trv);
+            *reinterpret_cast<uint4 *>(path + t) = pe;
+            if (t + 1 < nrow) {      // the move out of the cell, by priority
+                if (hi == 1 && (e & ZE_PPSWP)) { hi = 0; slot = int((e >> ZE_SSLOT_SHIFT) & 3u); }
+                else if (e & ZE_PPMAT) { }
+                else if (hi == 0 && (e & ZE_PPSWP)) { hi = 1; slot = int((e >> ZE_SSLOT_SHIFT) & 3u); }
+                else { status |= VPR_ST_ERR_NO_PTR; wok = false; }
+                mv_in = 1;
+            }
+        }
+    }
+    if (ok) {
+        AlnOut &o = outs[a];
+        o.beg_plane = beg_plane;
+        o.path_len = wok ? nrow : 0;
+        if (!wok) o.n_sec = 0;
+        if (status) atomicOr(&o.status, status);
+    }
+}
+
+#endif
