@@ -122,6 +122,9 @@ def main():
                     help="weak: --n-sc superclusters per GPU (own seed, own contigs); strong: --n-sc-total superclusters of one "
                          "synthetic genome dealt over the ranks by estimated cells, phasing all-gathered every step")
     ap.add_argument("--n-sc-total", type=int, default=3000000)
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches resident in HBM whose steps may overlap (each behind its own library handle and host thread): "
+                         "1 = strictly one step after the other")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launch path only (no GPU work): the ranks rendezvous over gloo, all-reduce their rank numbers and rank 0 "
                          "prints {n_gpus, rank_sum}; tests/test_distributed.py runs `bench.py --gpus 2 --plumbing-check` on CPU")
@@ -169,57 +172,81 @@ def main():
         api.build()                 # no-op when the in-tree library is current (the driver builds it beforehand)
     if dist is not None:
         dist.barrier()
-    t_a = time.perf_counter()
     strong = args.scaling == "strong"
-    if strong:      # every rank synthesises the same genome and keeps its share (dealt by estimated cells)
-        syn = make_workload(api, args.n_sc_total, args.seed, args.workload)
-        t_b = time.perf_counter()
-        whole = syn.batch(copy=False)
-        my_idx = shard.deal(shard.estimate_cells(whole), world)[rank]
-        batch = whole.subset(my_idx)
-        args.n_sc = batch.n_sc
-    else:
-        syn = make_workload(api, args.n_sc, shard.rank_seed(args.seed, rank), args.workload)
-        t_b = time.perf_counter()
-        batch = syn.batch(copy=False)       # host marshalling = the four generate_ptrs_strs calls per supercluster
-    t_c = time.perf_counter()
-    pr = api.PrecisionRecall(device=local_rank)
-    t_c1 = time.perf_counter()
-    pr.upload(batch)                    # inputs resident in HBM before the timed region (+ K0 prep kernels)
-    t_c2 = time.perf_counter()
-    cls = syn.var_class()               # SNP / INDEL / SV class of every variant (print.cpp:362-372), resident too
+    dev = torch.device("cuda", local_rank)
+    gloo = dist is not None and dist.get_backend() == "gloo"
+    n_fl = max(1, min(args.in_flight, args.steps))
+
+    class Slot:
+        """one batch resident in HBM behind its own library handle"""
+        pass
+
+    def make_slot(k):
+        S = Slot()
+        S.t_a = time.perf_counter()
+        if strong:      # every rank synthesises the same genome and keeps its share (SURVEY 8(e): dealt by estimated cells)
+            S.syn = make_workload(api, args.n_sc_total, args.seed + 104729 * k, args.workload)
+            S.t_b = time.perf_counter()
+            S.whole = S.syn.batch(copy=False)
+            S.my_idx = shard.deal(shard.estimate_cells(S.whole), world)[rank]
+            S.batch = S.whole.subset(S.my_idx)
+        else:
+            S.syn = make_workload(api, args.n_sc, shard.rank_seed(args.seed + 104729 * k, rank), args.workload)
+            S.t_b = time.perf_counter()
+            S.batch = S.syn.batch(copy=False)   # host marshalling = the four generate_ptrs_strs calls per supercluster
+        S.t_c = time.perf_counter()
+        S.pr = api.PrecisionRecall(device=local_rank)
+        S.t_c1 = time.perf_counter()
+        S.pr.upload(S.batch)                # inputs resident in HBM before the timed region (+ K0 prep kernels)
+        S.t_c2 = time.perf_counter()
+        cls = S.syn.var_class()             # SNP / INDEL / SV class of every variant (print.cpp:362-372), resident too
+        if strong:
+            cls = [shard.subset_per_variant(cls[s], S.whole.var_off[s], S.my_idx) for s in range(4)]
+        summary.upload_var_class(S.pr, cls)
+        S.t_d = time.perf_counter()
+        S.host_res = None
+        return S
+
+    slots = [make_slot(k) for k in range(n_fl)]
+    S0 = slots[0]
     if strong:
-        cls = [shard.subset_per_variant(cls[s], whole.var_off[s], my_idx) for s in range(4)]
-    summary.upload_var_class(pr, cls)
-    t_d = time.perf_counter()
+        args.n_sc = S0.batch.n_sc
+    batch, pr = S0.batch, S0.pr
+    t_a, t_b, t_c, t_c1, t_c2, t_d = S0.t_a, S0.t_b, S0.t_c, S0.t_c1, S0.t_c2, S0.t_d
     in_bytes = sum(a.nbytes for h in range(4) for a in (batch.hap_seq[h], batch.hap_ptr[h], batch.hap_flag[h],
                                                         batch.hap_off[h], batch.var_off[h], batch.var_pos[h],
                                                         batch.var_qual[h])) + batch.ref_seq.nbytes + \
         batch.ref_off.nbytes + sum(a.nbytes for h in range(2) for a in (batch.ref_ptr[h], batch.ref_flag[h]))
-    dev = torch.device("cuda", local_rank)
 
-    host_res = [None]
-    gloo = dist is not None and dist.get_backend() == "gloo"
-
+    import threading
     parts = [0.0, 0.0, 0.0]            # host-side seconds in execute / download / counters + collective, summed over the timed steps
+    lock = threading.Lock()
+    turn = threading.Condition()
+    next_coll = [0]                     # the collectives of step i are issued behind those of step i - 1 on every rank
 
-    def step():
+    def step(i, S):
         ta = time.perf_counter()
-        pr.execute()                    # K1..K5 on the device
+        S.pr.execute()                  # K1..K5 on the device
         tb = time.perf_counter()
-        host_res[0] = res = pr.download(host_res[0])   # final results to (reused) host buffers
+        S.host_res = res = S.pr.download(S.host_res)   # final results to (reused) host buffers
         tc = time.perf_counter()
-        parts[0] += tb - ta; parts[1] += tc - tb
+        with turn:
+            while next_coll[0] != i:
+                turn.wait()
         pb = None
         if strong:      # a contig's superclusters sit on all ranks: all-gather (sc_phase, orig, swap), phase redundantly
-            sc_phase, _, _ = shard.allgather_phase(res, my_idx, whole.n_sc, device=None if gloo else dev)
-            pb = summary.phase(sc_phase, np.ones(whole.n_sc, np.int32))[0][my_idx]
-        t = torch.from_numpy(summary.pr_counts(pr, None, pb)).to(dev)   # [2][4][3][61] int64, device histogram
-        if dist is not None and dist.get_backend() == "gloo":
+            sc_phase, _, _ = shard.allgather_phase(res, S.my_idx, S.whole.n_sc, device=None if gloo else dev)
+            pb = summary.phase(sc_phase, np.ones(S.whole.n_sc, np.int32))[0][S.my_idx]
+        t = torch.from_numpy(summary.pr_counts(S.pr, None, pb)).to(dev)   # [2][4][3][61] int64, device histogram
+        if gloo:
             th = t.cpu(); dist.all_reduce(th); t = th.to(dev)
         elif dist is not None:
             dist.all_reduce(t)          # the one collective of the path: the precision/recall counters (int64 sum)
-        parts[2] += time.perf_counter() - tc
+        with turn:
+            next_coll[0] = i + 1
+            turn.notify_all()
+        with lock:
+            parts[0] += tb - ta; parts[1] += tc - tb; parts[2] += time.perf_counter() - tc
         return res, t
 
     def sync():
@@ -227,20 +254,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    parts[:] = [0.0, 0.0, 0.0]
     kern_ms = []
     stats_acc = {}
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res, t = step()
-        tm = pr.timing()
+    last = {}
+
+    def account(S):
+        tm = S.pr.timing()
         kern_ms.append(tm.ms_total)
         # a kernel runs in several roles per step (round 0 over the whole part, retry and tie rounds over a few
         # alignments): the launch of a step with the most units is the kernel's main launch, the rest is "other"
-        ls = pr.launch_stats()
+        ls = S.pr.launch_stats()
         top = {}
         for s_ in ls:
             k = (s_.kind, s_.kernel.decode())
@@ -253,8 +276,38 @@ def main():
                 a[0] += 1; a[1] += s_.ms; a[2] += s_.bytes_algorithmic; a[3] += s_.cells; a[4] += s_.cells_dense
             else:
                 a[5] += 1; a[6] += s_.ms
+
+    def run_steps(first, n, timed):
+        """steps first .. first + n - 1; with more than one batch in flight, step i runs on slot i % n_fl from that slot's own
+        host thread (vpr_execute blocks its caller), so a batch's latency tail -- its few longest alignments are chains of
+        sequential rows -- overlaps the bulk of the next batch; every step is still one complete pass over one batch"""
+        def worker(j):
+            if dist is not None and not gloo:
+                torch.cuda.set_device(local_rank)
+            for i in range(first + j, first + n, n_fl):
+                r = step(i, slots[j])
+                if timed:
+                    with lock:
+                        account(slots[j])
+                        last[i] = (r, slots[j])
+        if n_fl == 1:
+            worker(0)
+            return
+        ths = [threading.Thread(target=worker, args=(j,)) for j in range(n_fl)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+
+    run_steps(0, max(args.warmup, 0), False)
+    parts[:] = [0.0, 0.0, 0.0]
+    sync()
+    t0 = time.perf_counter()
+    run_steps(args.warmup, args.steps, True)
     sync()
     elapsed = time.perf_counter() - t0
+    (res, t), S_last = last[args.warmup + args.steps - 1]
+    batch, pr = S_last.batch, S_last.pr
     if rank == 0:       # the device tally must equal the one recomputed from the downloaded results
         assert np.array_equal(shard.tally_from_results(res, batch.var_off), pr.tally()), "device tally != host tally"
         # after the timed region: per-contig phasing (host Viterbi) and the PRECISION-RECALL SUMMARY of this rank

@@ -7,6 +7,9 @@
  *   vrp_write_phase_blocks       write_results, phase-blocks.tsv                   src/print.cpp:585-609
  *   vrp_write_superclusters      write_results, superclusters.tsv                  src/print.cpp:611-671
  *   vrp_write_variants           write_results, query.tsv / truth.tsv              src/print.cpp:673-876
+ *   vrp_write_switchflips        phaseblockData::write_switchflips                 src/phase.cpp:406-509
+ *   vrp_write_phasing_summary    phaseblockData::write_phasing_summary             src/phase.cpp:515-528
+ *   vrp_ng50                     phaseblockData::calculate_ng50                    src/phase.cpp:534-626
  *   vrp_write_summary_vcf        phaseblockData::write_summary_vcf                 src/phase.cpp:8-222
  *                                ctgVariants::print_var_info / _empty / _sample    src/variant.cpp:229-286
  * Host code, like the reference's; the inputs are the columns of include/vcfdist_io.h, the tables of
@@ -76,6 +79,12 @@ int32_t vrp_phase_blocks(const int32_t *sc_phase_set, int32_t n_sc, int32_t *pha
 int vrp_write_precision_recall(const char *prefix, const int64_t *counts, int32_t min_qual, int32_t max_qual);
 
 int vrp_write_phase_blocks(const char *path, const vrp_contig *ctgs, int32_t n_ctg);
+/* switchflips.tsv: where every switch / flip error may have happened; phasing-summary.tsv: block and error totals with
+   the NG50 of the correctly phased stretches (genome size = sum of vrp_contig.length), broken at phase-block starts
+   only / also at switch errors / also around flipped superclusters (vrp_ng50; -1: inconsistent tables) */
+int vrp_write_switchflips(const char *path, const vrp_contig *ctgs, int32_t n_ctg);
+int vrp_write_phasing_summary(const char *path, const vrp_contig *ctgs, int32_t n_ctg);
+int32_t vrp_ng50(const vrp_contig *ctgs, int32_t n_ctg, int32_t break_on_switch, int32_t break_on_flip);
 int vrp_write_superclusters(const char *path, const vrp_contig *ctgs, int32_t n_ctg);
 /* callset 0: query.tsv, 1: truth.tsv */
 int vrp_write_variants(const char *path, const vrp_contig *ctgs, int32_t n_ctg, int32_t callset);

@@ -91,6 +91,106 @@ def phase_blocks_tsv(ctgs):
     return "".join(o)
 
 
+SW_FLIP, SW_SWITCH, SW_BOTH, SW_ERR, SW_NONE = 0, 1, 2, 3, 6     # defs.h:74-80
+
+
+def _breaks(c, on_switch, on_flip):
+    """the loop skeleton shared by write_switchflips (phase.cpp:424-505) and calculate_ng50 (phase.cpp:561-612):
+    yields (type, next_sc, pb_idx - 1); raises where the reference's ERROR() fires"""
+    n = len(c.sc_beg)
+    switch_idx = flip_idx = 0
+    pb_idx, sc = 1, 0
+    n_pb = len(c.pbs) - 1
+    while True:
+        next_sc, typ = n, SW_NONE
+        if pb_idx < n_pb and c.pbs[pb_idx] <= next_sc:
+            typ, next_sc = SW_SWITCH, c.pbs[pb_idx]
+        if on_switch and switch_idx < len(c.switches) and c.switches[switch_idx] <= next_sc:
+            typ, next_sc = SW_ERR, c.switches[switch_idx]
+        if on_flip and flip_idx < len(c.flips) and c.flips[flip_idx] <= next_sc:
+            typ = SW_BOTH if typ == SW_SWITCH else SW_FLIP
+            next_sc = c.flips[flip_idx]
+        if typ == SW_NONE:
+            return
+        if next_sc <= sc:
+            raise ValueError("Next supercluster is not after current supercluster")
+        yield typ, int(next_sc), pb_idx - 1
+        if typ in (SW_FLIP, SW_BOTH):
+            flip_idx += 1
+            if typ == SW_BOTH:
+                pb_idx += 1
+        elif typ == SW_SWITCH:
+            pb_idx += 1
+        else:
+            switch_idx += 1
+        sc = next_sc
+
+
+def switchflips_tsv(ctgs):
+    """phaseblockData::write_switchflips, phase.cpp:406-509"""
+    o = ["CONTIG\tSTART\tSTOP\tSWITCH_TYPE\tSUPERCLUSTER\tPHASE_BLOCK\n"]
+    for c in ctgs:
+        n = len(c.sc_beg)
+        if n == 0:
+            continue
+        for typ, next_sc, pb in _breaks(c, True, True):
+            if typ in (SW_FLIP, SW_BOTH):
+                left = next_sc - 1
+                while left > 0 and c.sc_phase[left] == 2:      # PHASE_NONE
+                    left -= 1
+                if left >= 0:
+                    o.append("%s\t%d\t%d\t%s\t%d\t%d\n" % (c.name, c.sc_end[left], c.sc_beg[next_sc], "FLIP_BEG", next_sc, pb))
+                right = next_sc + 1
+                while right < n - 1 and c.sc_phase[right] == 2:
+                    right += 1
+                if right < n:
+                    o.append("%s\t%d\t%d\t%s\t%d\t%d\n" % (c.name, c.sc_end[next_sc], c.sc_beg[right], "FLIP_END", next_sc, pb))
+            elif typ == SW_ERR:
+                left = next_sc - 1
+                while left > 0 and c.sc_phase[left] == 2:
+                    left -= 1
+                right = next_sc
+                while right < n - 1 and c.sc_phase[right] == 2:
+                    right += 1
+                if left >= 0 and right < n:
+                    o.append("%s\t%d\t%d\t%s\t%d\t%d\n" % (c.name, c.sc_end[left], c.sc_beg[right], "SWITCH_ERR", next_sc, pb))
+    return "".join(o)
+
+
+def ng50(ctgs, on_switch, on_flip):
+    """phaseblockData::calculate_ng50, phase.cpp:534-626 (a flip on a contig's last supercluster reads begs[n] there:
+    undefined; the library and this restatement start the following, empty stretch at the last supercluster's end)"""
+    total = sum(int(c.length) for c in ctgs)
+    blocks = []
+    for c in ctgs:
+        n = len(c.sc_beg)
+        if n == 0:
+            continue
+        beg = c.sc_beg[0]
+        nxt = lambda k: c.sc_beg[k] if k < n else c.sc_end[n - 1]
+        for typ, next_sc, _ in _breaks(c, on_switch, on_flip):
+            blocks.append(c.sc_end[next_sc - 1] - beg)
+            beg = nxt(next_sc)
+            if typ in (SW_FLIP, SW_BOTH):
+                blocks.append(c.sc_end[next_sc] - beg)
+                beg = nxt(next_sc + 1)
+        blocks.append(c.sc_end[n - 1] - beg)
+    acc = 0
+    for b in sorted(blocks, reverse=True):
+        acc += int(b)
+        if acc >= total // 2:
+            return int(b)
+    return 0
+
+
+def phasing_summary_tsv(ctgs):
+    """phaseblockData::write_phasing_summary, phase.cpp:515-528, with the totals of phase.cpp:363-386"""
+    nb = sum(len(c.pbs) - 1 for c in ctgs)
+    return ("PHASE_BLOCKS\tSWITCH_ERRORS\tFLIP_ERRORS\tNG_50\tSWITCH_NGC50\tSWITCHFLIP_NGC50\n%d\t%d\t%d\t%d\t%d\t%d" %
+            (nb, sum(len(c.switches) for c in ctgs), sum(len(c.flips) for c in ctgs), ng50(ctgs, False, False), ng50(ctgs, True, False),
+             ng50(ctgs, True, True)))
+
+
 def superclusters_tsv(ctgs):
     o = ["CONTIG\tSUPERCLUSTER\tSTART\tSTOP\tSIZE\tQUERY1_VARS\tQUERY2_VARS\tTRUTH1_VARS\tTRUTH2_VARS\tORIG_ED\tSWAP_ED"
          "\tPHASE_STATE\tSC_PHASE\tPHASE_SET\tPHASE_BLOCK\tFLIP_ERROR\n"]

@@ -174,6 +174,8 @@ def test_command_line_on_demo_files(tmp_path, capsys):
     assert rd("precision-recall-summary.tsv") == s
     octg = [D.report_view(det, length=248956422)]       # ##contig length of the demo VCF headers
     assert rd("phase-blocks.tsv") == RO.phase_blocks_tsv(octg)
+    assert rd("switchflips.tsv") == RO.switchflips_tsv(octg)
+    assert rd("phasing-summary.tsv") == RO.phasing_summary_tsv(octg)
     assert rd("superclusters.tsv") == RO.superclusters_tsv(octg)
     assert rd("query.tsv") == RO.variants_tsv(octg, 0)
     assert rd("truth.tsv") == RO.variants_tsv(octg, 1)
@@ -225,7 +227,8 @@ def test_command_line_two_ranks_deal_contigs(tmp_path):
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                     "--master-port", str(port), "-m", "vcfdist_amd"] + base + ["-p", str(tmp_path / "two") + "/"], check=True, env=env,
                    cwd=root, stdout=subprocess.DEVNULL, timeout=900)
-    for name in ("precision-recall.tsv", "precision-recall-summary.tsv", "phase-blocks.tsv", "superclusters.tsv", "query.tsv", "truth.tsv"):
+    for name in ("precision-recall.tsv", "precision-recall-summary.tsv", "phase-blocks.tsv", "superclusters.tsv", "query.tsv", "truth.tsv",
+                 "switchflips.tsv", "phasing-summary.tsv"):
         one, two = (tmp_path / "one" / name).read_bytes(), (tmp_path / "two" / name).read_bytes()
-        assert one == two and len(one) > 100, name
+        assert one == two and len(one) > 60, name
     assert b"chr2" in (tmp_path / "two" / "query.tsv").read_bytes()

@@ -64,8 +64,12 @@ def make_contig(rng, name, n_sc, ploidy=2, empty_slot=None):
     sc_phase = rng.integers(0, 3, size=n_sc).astype(np.int32)
     pb_phase = rng.integers(0, 2, size=n_sc).astype(np.int32)
     sc_phase_set = np.sort(rng.integers(0, 3, size=n_sc)).astype(np.int32) * 7
-    switches = np.sort(rng.choice(np.arange(max(n_sc, 1)), size=min(2, n_sc), replace=False)).astype(np.int32)
-    flips = np.sort(rng.choice(np.arange(max(n_sc, 1)), size=min(3, n_sc), replace=False)).astype(np.int32)
+    # phasing errors as phaseblockData::phase() produces them: behind the first supercluster, a supercluster is a switch or
+    # a flip but not both, and no switch error on the first supercluster of a phase block (phase.cpp:310)
+    starts = set(RO.phase_blocks(sc_phase_set))
+    ev = rng.permutation(np.arange(1, max(n_sc, 1)))[:min(5, max(n_sc - 1, 0))]
+    switches = np.sort([e for e in ev[:2] if int(e) not in starts]).astype(np.int32)
+    flips = np.sort(ev[2:]).astype(np.int32)
     res = types.SimpleNamespace(sc_phase=sc_phase, orig_phase_dist=rng.integers(0, 50, size=n_sc).astype(np.int32),
                                 swap_phase_dist=rng.integers(0, 50, size=n_sc).astype(np.int32))
     for nm, gen in (("errtype", lambda n: rng.choice([0, 1, 2, 5], size=n).astype(np.uint8)),
@@ -109,6 +113,9 @@ def test_result_tables_match_restatement(tmp_path, seed):
     R.write_results(prefix, [p for p, _ in pairs], cmd="vcfdist q.vcf t.vcf r.fa", file_date="20250919", credit_threshold=0.7)
     orc = [o for _, o in pairs]
     assert _read(prefix + "phase-blocks.tsv") == RO.phase_blocks_tsv(orc)
+    assert _read(prefix + "switchflips.tsv") == RO.switchflips_tsv(orc)
+    assert _read(prefix + "phasing-summary.tsv") == RO.phasing_summary_tsv(orc)
+    assert _read(prefix + "switchflips.tsv").count("\n") > 6
     assert _read(prefix + "superclusters.tsv") == RO.superclusters_tsv(orc)
     assert _read(prefix + "query.tsv") == RO.variants_tsv(orc, 0)
     assert _read(prefix + "truth.tsv") == RO.variants_tsv(orc, 1)
@@ -148,3 +155,43 @@ def test_phase_blocks():
 def test_unwritable_path_is_an_error(tmp_path):
     with pytest.raises(R.ReportError):
         R.write_precision_recall(str(tmp_path) + "/no/such/dir/", np.zeros((2, 4, 3, 61), np.int64), 0, 60)
+
+
+def test_file_headers_are_the_documented_columns():
+    """the column names and their order of every table, as the reference documents them
+    (docs/v2.6.0/09-Outputs.md; the one reference-held description of these files).  Three deliberate differences of the
+    reference's own writers from its documentation are kept, because the writers are what a user's scripts read:
+    query.tsv / truth.tsv say ERRTYPE where the page says ERR_TYPE (print.cpp:676, 778), and precision-recall-summary.tsv
+    has a THRESHOLD column (NONE / BEST) the page does not list (print.cpp:504)."""
+    documented = {
+        "query.tsv": "CONTIG POS HAP REF ALT QUAL TYPE ERR_TYPE CREDIT CLUSTER SUPERCLUSTER SYNC_GROUP REF_DIST QUERY_DIST LOCATION",
+        "truth.tsv": "CONTIG POS HAP REF ALT QUAL TYPE ERR_TYPE CREDIT CLUSTER SUPERCLUSTER SYNC_GROUP REF_DIST QUERY_DIST LOCATION",
+        "superclusters.tsv": "CONTIG SUPERCLUSTER START STOP SIZE QUERY1_VARS QUERY2_VARS TRUTH1_VARS TRUTH2_VARS ORIG_ED SWAP_ED "
+                             "PHASE_STATE SC_PHASE PHASE_SET PHASE_BLOCK FLIP_ERROR",
+        "precision-recall-summary.tsv": "VAR_TYPE MIN_QUAL TRUTH_TP QUERY_TP TRUTH_FN QUERY_FP PREC RECALL F1_SCORE F1_QSCORE",
+        "precision-recall.tsv": "VAR_TYPE MIN_QUAL PREC RECALL F1_SCORE F1_QSCORE TRUTH_TOTAL TRUTH_TP TRUTH_FN QUERY_TOTAL QUERY_TP QUERY_FP",
+        "phase-blocks.tsv": "CONTIG PHASE_BLOCK START STOP SIZE SUPERCLUSTERS FLIP_ERRORS SWITCH_ERRORS",
+        "phasing-summary.tsv": "PHASE_BLOCKS SWITCH_ERRORS FLIP_ERRORS NG_50 SWITCH_NGC50 SWITCHFLIP_NGC50",
+        "switchflips.tsv": "CONTIG START STOP SWITCH_TYPE SUPERCLUSTER PHASE_BLOCK",
+    }
+    import tempfile
+    rng = np.random.default_rng(5)
+    prod, _ = make_contig(rng, "chr1", 6)
+    with tempfile.TemporaryDirectory() as d:
+        prefix = d + "/"
+        R.write_results(prefix, [prod], cmd="vcfdist", file_date="20250919")
+        R.write_precision_recall(prefix, np.zeros((2, 4, 3, 61), np.int64), 0, 60)
+        for name, cols in documented.items():
+            got = _read(prefix + name).split("\n")[0].split("\t")
+            want = cols.split()
+            if name in ("query.tsv", "truth.tsv"):
+                want[want.index("ERR_TYPE")] = "ERRTYPE"
+            if name == "precision-recall-summary.tsv":
+                want.insert(1, "THRESHOLD")
+            assert got == want, name
+        # summary.vcf: the FORMAT keys of the documented table, in the documented order (phase.cpp:44-70)
+        vcf = _read(prefix + "summary.vcf")
+        keys = [l.split("ID=")[1].split(",")[0] for l in vcf.split("\n") if l.startswith("##FORMAT")]
+        assert keys == "GT BD BC RD QD BK QQ SC SG PS PB BS FE".split()
+        body = [l for l in vcf.split("\n") if l and not l.startswith("#")]
+        assert body and all(l.split("\t")[8] == "GT:BD:BC:RD:QD:BK:QQ:SC:SG:PS:PB:BS:FE" for l in body)

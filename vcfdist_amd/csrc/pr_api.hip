@@ -48,7 +48,11 @@ enum { LV_Z = 0, LV_Q16 = 1, LV_C1 = 2, LV_C4 = 3, LV_C16 = 4, LV_DENSE = 5 };
 const int LV_WINDOW[] = {16, 16, 64, 256, 1024, 0};   // window width = flag layout of the level
 const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnDesc::band_pad that marks the level
 // truth rows from which an alignment is a latency chain
-const int LONG_LT = 512;
+// Alignments with LONG_LT truth rows or more are latency chains (rows are sequential): a batch holds a handful of them and
+// the longest bounds the step, so they start at LONG_LV, four waves per alignment (k_fwd_wide<4>: 0.45 us per row against
+// 1 us for the one-wave 64-cell kernels).  Everything shorter is throughput work for the lane / 16-cell kernels.
+const int LONG_LT = 2048;
+const int LONG_LV = 2;    // LV_C1
 
 // std::vector whose resize() leaves trivially constructible elements uninitialised (the planner fills millions of
 // 96-byte descriptors from several threads; zero-filling them first costs as much as the fill)
@@ -85,7 +89,7 @@ struct Chunk {
     int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0};
 };
 // a set of alignments with workspace offsets assigned, all at window level `lv` (a 16-cell plan holds its
-// long alignments, which start at LV_C1, in front)
+// long alignments, which start at LONG_LV, in front)
 struct Plan {
     int lv = LV_DENSE;
     DescVec descs;                  // compact, in work-list order
@@ -511,7 +515,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
     P = Plan();
     P.lv = lv;
     P.arena = arena;
-    auto level_of = [&](const AlnDesc &d) { return (lv <= LV_Q16 && d.Lt >= LONG_LT) ? int(LV_C1) : lv; };
+    auto level_of = [&](const AlnDesc &d) { return (lv <= LV_Q16 && d.Lt >= LONG_LT) ? LONG_LV : lv; };
     auto mat_bytes = [&](int32_t a) -> int64_t {
         const AlnDesc &d = h->descs[a];
         const int W = LV_WINDOW[level_of(d)];
@@ -1112,8 +1116,9 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
                 const int64_t nstr = (int64_t(d.Lt) + 3) / 4;
                 flags = nstr * 128 + round_up(nstr * 8, 64);
             } else if (bm != 0) {
-                flags = round_up(round_up(std::min(64, d.Lq), 16) * int64_t(d.Lt), 64) +
-                        round_up(round_up(std::min(64, d.Lr), 16) * int64_t(d.Lt), 64) + round_up(8 * int64_t(d.Lt), 64);
+                const int W = (q16ok && bm != 2) ? LV_WINDOW[LONG_LV] : 64;
+                flags = round_up(round_up(std::min(W, d.Lq), 16) * int64_t(d.Lt), 64) +
+                        round_up(round_up(std::min(W, d.Lr), 16) * int64_t(d.Lt), 64) + round_up(8 * int64_t(d.Lt), 64);
             } else {
                 flags = round_up(round_up(d.Lq, 32) * int64_t(d.Lt), 64) + round_up(round_up(d.Lr, 32) * int64_t(d.Lt), 64);
             }
@@ -2017,7 +2022,7 @@ struct Exec {
                 }
             }
             if (n_long > 0) {
-                const int lv = P0.lv <= LV_Q16 ? int(LV_C1) : P0.lv;
+                const int lv = P0.lv <= LV_Q16 ? LONG_LV : P0.lv;
                 for (int ph = 1; ph <= 4; ph <<= 1) {
                     if ((rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0],
                                            ch.part_in[0], ch.part_dense[0], -1, ph))) return rc;

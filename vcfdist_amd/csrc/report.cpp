@@ -147,6 +147,126 @@ extern "C" int vrp_write_phase_blocks(const char *path, const vrp_contig *ctgs, 
     return VRP_OK;
 }
 
+// ---- phasing errors: switchflips.tsv (phaseblockData::write_switchflips, phase.cpp:406-509), phasing-summary.tsv
+// (write_phasing_summary, phase.cpp:515-528) and the three NG50 figures behind it (calculate_ng50, phase.cpp:534-626).
+// All of them sweep a contig's superclusters from break to break.  A break is the start of a phase block (a new phase
+// set: not an error), a switch error or a flip error; the next one is the pending event with the smallest supercluster,
+// where on equal superclusters a flip takes precedence over a switch error over a block start -- and a flip that is met
+// while a block start is the candidate is reported as "switch + flip" and uses up that block start, wherever the block
+// start lies (the reference's comparison order; the tables must come out the same).
+namespace {
+enum { BRK_FLIP = 0, BRK_BLOCK = 1, BRK_BLOCK_FLIP = 2, BRK_SWITCH_ERR = 3, BRK_NONE = 6 };
+
+// f(kind, supercluster, index of the phase block the break is counted in); false = events out of order
+template <class F>
+bool for_each_break(const vrp_contig &c, bool with_switches, bool with_flips, F f) {
+    int32_t i_pb = 1, i_sw = 0, i_fl = 0, at = 0;
+    for (;;) {
+        int kind = BRK_NONE;
+        int32_t nxt = c.n_sc;
+        if (i_pb < c.n_pb && c.phase_block[i_pb] <= nxt) { kind = BRK_BLOCK; nxt = c.phase_block[i_pb]; }
+        if (with_switches && i_sw < c.n_switches && c.switches[i_sw] <= nxt) { kind = BRK_SWITCH_ERR; nxt = c.switches[i_sw]; }
+        if (with_flips && i_fl < c.n_flips && c.flips[i_fl] <= nxt) { kind = kind == BRK_BLOCK ? BRK_BLOCK_FLIP : BRK_FLIP; nxt = c.flips[i_fl]; }
+        if (kind == BRK_NONE) return true;
+        if (nxt <= at) return false;        // the reference's ERROR("Next supercluster ... is not after current supercluster")
+        f(kind, nxt, i_pb - 1);
+        if (kind == BRK_FLIP || kind == BRK_BLOCK_FLIP) i_fl++;
+        if (kind == BRK_BLOCK || kind == BRK_BLOCK_FLIP) i_pb++;
+        if (kind == BRK_SWITCH_ERR) i_sw++;
+        at = nxt;
+    }
+}
+
+bool phasing_ok(const vrp_contig &c) {
+    if (!contig_ok(c) || c.n_pb < 0 || c.n_switches < 0 || c.n_flips < 0) return false;
+    if (c.n_sc > 0 && !c.phase_block) return false;
+    return (c.n_switches == 0 || c.switches) && (c.n_flips == 0 || c.flips);
+}
+}  // namespace
+
+extern "C" int vrp_write_switchflips(const char *path, const vrp_contig *ctgs, int32_t n_ctg) {
+    if (!path || n_ctg < 0 || (n_ctg && !ctgs)) return fail(VRP_ERR_ARG, "vrp_write_switchflips: bad argument");
+    File out(path);
+    if (!out) return fail(VRP_ERR_OPEN, std::string("cannot create ") + path);
+    fprintf(out, "CONTIG\tSTART\tSTOP\tSWITCH_TYPE\tSUPERCLUSTER\tPHASE_BLOCK\n");
+    for (int32_t ci = 0; ci < n_ctg; ci++) {
+        const vrp_contig &c = ctgs[ci];
+        if (!phasing_ok(c)) return fail(VRP_ERR_ARG, "vrp_write_switchflips: incomplete contig");
+        if (c.n_sc == 0) continue;
+        // nearest supercluster with a phase of its own at or left of `k` (stops at 0) / at or right of `k` (stops at the last)
+        auto phased_left = [&](int32_t k) { while (k > 0 && c.sc_phase[k] == VPR_PHASE_NONE) k--; return k; };
+        auto phased_right = [&](int32_t k) { while (k < c.n_sc - 1 && c.sc_phase[k] == VPR_PHASE_NONE) k++; return k; };
+        auto row = [&](int32_t from_sc, int32_t to_sc, const char *what, int32_t sc, int32_t pb) {
+            fprintf(out, "%s\t%d\t%d\t%s\t%d\t%d\n", c.name, c.sc_end[from_sc], c.sc_beg[to_sc], what, sc, pb);
+        };
+        const bool ordered = for_each_break(c, true, true, [&](int kind, int32_t sc, int32_t pb) {
+            if (kind == BRK_FLIP || kind == BRK_BLOCK_FLIP) {
+                // the phasing may have changed anywhere between the last phased supercluster in front of the flipped one and
+                // the flipped one, and back anywhere between it and the next phased one
+                const int32_t l = phased_left(sc - 1), r = phased_right(sc + 1);
+                if (l >= 0) row(l, sc, "FLIP_BEG", sc, pb);
+                if (r < c.n_sc) row(sc, r, "FLIP_END", sc, pb);
+            } else if (kind == BRK_SWITCH_ERR) {
+                const int32_t l = phased_left(sc - 1), r = phased_right(sc);
+                if (l >= 0 && r < c.n_sc) row(l, r, "SWITCH_ERR", sc, pb);
+            }       // (the start of a phase block is not an error: no row)
+        });
+        if (!ordered) return fail(VRP_ERR_ARG, "vrp_write_switchflips: phase blocks / switches / flips are not ascending");
+    }
+    if (!out.finish()) return fail(VRP_ERR_OPEN, std::string("write error on ") + path);
+    return VRP_OK;
+}
+
+// NG50 of the correctly phased stretches: break at phase-block starts, optionally at switch errors and around flipped
+// superclusters; the genome size is the sum of the contigs' header lengths.  Returns -1 for inconsistent tables.
+extern "C" int32_t vrp_ng50(const vrp_contig *ctgs, int32_t n_ctg, int32_t break_on_switch, int32_t break_on_flip) {
+    if (n_ctg < 0 || (n_ctg && !ctgs)) return -1;
+    uint64_t genome = 0;
+    std::vector<int32_t> stretch;
+    for (int32_t ci = 0; ci < n_ctg; ci++) {
+        const vrp_contig &c = ctgs[ci];
+        if (!phasing_ok(c)) return -1;
+        genome += uint64_t(uint32_t(c.length));
+        if (c.n_sc == 0) continue;
+        int32_t from = c.sc_beg[0];
+        auto cut = [&](int32_t last_sc, int32_t next_sc) {      // a stretch ends with last_sc, the next one starts at next_sc
+            stretch.push_back(c.sc_end[last_sc] - from);
+            // (a flip on the contig's last supercluster makes the reference read begs[n]: the stretch behind it is empty here)
+            from = next_sc < c.n_sc ? c.sc_beg[next_sc] : c.sc_end[c.n_sc - 1];
+        };
+        const bool ordered = for_each_break(c, break_on_switch != 0, break_on_flip != 0, [&](int kind, int32_t sc, int32_t) {
+            cut(sc - 1, sc);
+            if (kind == BRK_FLIP || kind == BRK_BLOCK_FLIP) cut(sc, sc + 1);     // the flipped supercluster is a stretch of its own
+        });
+        if (!ordered) return -1;
+        stretch.push_back(c.sc_end[c.n_sc - 1] - from);
+    }
+    std::sort(stretch.begin(), stretch.end(), std::greater<int32_t>());
+    uint64_t covered = 0;
+    for (int32_t len : stretch) {
+        covered += uint64_t(int64_t(len));      // (size_t arithmetic, as in the reference)
+        if (covered >= genome / 2) return len;
+    }
+    return 0;
+}
+
+extern "C" int vrp_write_phasing_summary(const char *path, const vrp_contig *ctgs, int32_t n_ctg) {
+    if (!path || n_ctg < 0 || (n_ctg && !ctgs)) return fail(VRP_ERR_ARG, "vrp_write_phasing_summary: bad argument");
+    int blocks = 0, switches = 0, flips = 0;
+    for (int32_t ci = 0; ci < n_ctg; ci++) {
+        if (!phasing_ok(ctgs[ci])) return fail(VRP_ERR_ARG, "vrp_write_phasing_summary: incomplete contig");
+        blocks += ctgs[ci].n_pb; switches += ctgs[ci].n_switches; flips += ctgs[ci].n_flips;
+    }
+    const int32_t ng50 = vrp_ng50(ctgs, n_ctg, 0, 0), sw50 = vrp_ng50(ctgs, n_ctg, 1, 0), sf50 = vrp_ng50(ctgs, n_ctg, 1, 1);
+    if (ng50 < 0 || sw50 < 0 || sf50 < 0) return fail(VRP_ERR_ARG, "vrp_write_phasing_summary: phase blocks / switches / flips are not ascending");
+    File out(path);
+    if (!out) return fail(VRP_ERR_OPEN, std::string("cannot create ") + path);
+    fprintf(out, "PHASE_BLOCKS\tSWITCH_ERRORS\tFLIP_ERRORS\tNG_50\tSWITCH_NGC50\tSWITCHFLIP_NGC50\n");
+    fprintf(out, "%d\t%d\t%d\t%d\t%d\t%d", blocks, switches, flips, ng50, sw50, sf50);      // (no newline behind the row, phase.cpp:526)
+    if (!out.finish()) return fail(VRP_ERR_OPEN, std::string("write error on ") + path);
+    return VRP_OK;
+}
+
 extern "C" int vrp_write_superclusters(const char *path, const vrp_contig *ctgs, int32_t n_ctg) {
     if (!path || n_ctg < 0 || (n_ctg && !ctgs)) return fail(VRP_ERR_ARG, "vrp_write_superclusters: bad argument");
     File out(path);

@@ -26,6 +26,7 @@ class VrpContig(C.Structure):
 
 
 EXPORTED = ["vrp_phase_blocks", "vrp_write_precision_recall", "vrp_write_phase_blocks", "vrp_write_superclusters",
+            "vrp_write_switchflips", "vrp_write_phasing_summary", "vrp_ng50",
             "vrp_write_variants", "vrp_write_summary_vcf", "vrp_last_error"]
 
 
@@ -128,7 +129,8 @@ def write_precision_recall(prefix, counts, min_qual, max_qual):
 
 
 def write_results(prefix, contigs, cmd="", file_date=None, credit_threshold=0.7):
-    """phase-blocks.tsv, superclusters.tsv, query.tsv, truth.tsv (write_results, print.cpp:575-878) and summary.vcf"""
+    """phase-blocks.tsv, superclusters.tsv, query.tsv, truth.tsv (write_results, print.cpp:575-878), switchflips.tsv and
+    phasing-summary.tsv (phase.cpp:406-528) and summary.vcf"""
     L = api.lib()
     arr, n = _array(contigs), len(contigs)
     P = C.POINTER(VrpContig)
@@ -136,7 +138,11 @@ def write_results(prefix, contigs, cmd="", file_date=None, credit_threshold=0.7)
     L.vrp_write_superclusters.argtypes = [C.c_char_p, P, C.c_int32]
     L.vrp_write_variants.argtypes = [C.c_char_p, P, C.c_int32, C.c_int32]
     L.vrp_write_summary_vcf.argtypes = [C.c_char_p, P, C.c_int32, C.c_char_p, C.c_char_p, C.c_float]
+    L.vrp_write_switchflips.argtypes = [C.c_char_p, P, C.c_int32]
+    L.vrp_write_phasing_summary.argtypes = [C.c_char_p, P, C.c_int32]
     _check(L.vrp_write_phase_blocks((prefix + "phase-blocks.tsv").encode(), arr, n), "vrp_write_phase_blocks")
+    _check(L.vrp_write_switchflips((prefix + "switchflips.tsv").encode(), arr, n), "vrp_write_switchflips")
+    _check(L.vrp_write_phasing_summary((prefix + "phasing-summary.tsv").encode(), arr, n), "vrp_write_phasing_summary")
     _check(L.vrp_write_superclusters((prefix + "superclusters.tsv").encode(), arr, n), "vrp_write_superclusters")
     _check(L.vrp_write_variants((prefix + "query.tsv").encode(), arr, n, 0), "vrp_write_variants")
     _check(L.vrp_write_variants((prefix + "truth.tsv").encode(), arr, n, 1), "vrp_write_variants")
