@@ -161,6 +161,9 @@ typedef struct vpr_config {
                                    and the second attempt (worst-case logs) has to decide the ties */
 #define VPR_CFG_GUARD_ALLOC 4   /* test aid: every device array gets an allocation of its own instead of a slice of a pooled
                                    block, so that an access far behind an array faults instead of reading its neighbour */
+#define VPR_CFG_KEEP_PATHS 8    /* the zero-distance lane kernel (most alignments of whole-genome input end there) keeps its walk in a
+                                   compact form only its own credit kernel reads; with this flag it also writes the 16-byte path
+                                   entries vpr_download_path returns (tests, callers who want the alignment path itself) */
 
 /* Results: the fields precision_recall_wrapper writes in place
    (ctgVariants::{errtypes,sync_group,credit,ref_ed,query_ed,callq}, src/variant.h:49-60;

@@ -97,6 +97,7 @@ def test_ties_in_long_alignments_and_retried_ones():
 # the walk at every window level
 # ----------------------------------------------------------------------------------------------------------------------
 def _check_paths(batch, cfg, pairs):
+    cfg.flags |= A.CFG_KEEP_PATHS       # (the zero-distance lane kernel writes 16-byte path entries on request only)
     pr = api.PrecisionRecall(cfg)
     pr.run(batch)
     n_checked = 0

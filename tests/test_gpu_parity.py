@@ -155,7 +155,7 @@ def test_repeat_execute_is_idempotent():
 
 def test_walk_matches_oracle_path():
     batch = api.Synth(n_sc=1, len_mode=2, len_a=120.0, len_min=120, len_max=120, seed=21, var_per_base=0.05).batch()
-    pr = api.PrecisionRecall()
+    pr = api.PrecisionRecall(A.default_config(flags=A.CFG_KEEP_PATHS))    # (the zero-distance lane kernel keeps 16-byte path entries on request)
     pr.run(batch)
     for aln in range(4):
         ex = O.Extra(batch, want=(0, aln))

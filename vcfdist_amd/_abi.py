@@ -75,6 +75,7 @@ class VprResults(C.Structure):
 CFG_DENSE_S16 = 1   # VPR_CFG_DENSE_S16
 CFG_TIE_SMALL_LOGS = 2   # VPR_CFG_TIE_SMALL_LOGS
 CFG_GUARD_ALLOC = 4      # VPR_CFG_GUARD_ALLOC
+CFG_KEEP_PATHS = 8       # VPR_CFG_KEEP_PATHS
 
 
 class VprTiming(C.Structure):

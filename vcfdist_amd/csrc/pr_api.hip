@@ -1573,7 +1573,8 @@ struct Exec {
         rc = timed(1, ls, ks, band_fwd_name(lv), [&] {
             if (zero)        // forward + backward + walk of the zero-distance alignments, one lane each (pr_zl.hip)
                 hipLaunchKernelGGL(k_zero_lane, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->d_descs, list, cnt,
-                                   h->d_zl_hdr + zl_wave0, h->d_zl_in, h->d_zl_log, h->d_outs, a_path);
+                                   h->d_zl_hdr + zl_wave0, h->d_zl_in, h->d_zl_log, h->d_outs, a_path,
+                                   (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0);
             else if (q16)
                 hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);
@@ -1621,7 +1622,12 @@ struct Exec {
             });
             if (rc) return rc;
             ws_.cells_per_thread = 3;
-            rc = timed(3, ws_, ks, "k_credit<lane>", [&] {
+            if (zero) rc = timed(3, ws_, ks, "k_zero_credit", [&] {
+                hipLaunchKernelGGL(k_zero_credit, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                   h->d_zl_hdr + zl_wave0, h->d_zl_log, h->d_outs, h->d_secs, h->d_fp_table, h->d_jobs,
+                                   h->d_njobs, h->jobs_cap, tag);
+            });
+            else rc = timed(3, ws_, ks, "k_credit<lane>", [&] {
                 hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
                                    list, cnt, h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs,
                                    h->d_njobs, h->jobs_cap, dtag, tag, n_dev);

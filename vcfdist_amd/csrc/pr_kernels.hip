@@ -637,12 +637,15 @@ __device__ int small_ed(const uint8_t *a, int m, const uint8_t *b, int n) {
 
 // Phase B of K3: the backward credit walk of calc_prec_recall (dist.cpp:1035-1400) over a stored path.
 // WAVE: every lane runs the same walk (one wavefront per alignment), lane 0 stores.
-template <bool WAVE>
+struct NoFetch { __device__ PathEnt operator()(int64_t) const { return PathEnt{0, 0, 0, 0}; } };
+// XF: where the path entries come from when they are not 16-byte records at `path` (k_zero_credit, pr_zl.hip: the
+// wave-interleaved walk log of the zero-distance lane kernel); XF()(i) returns entry i
+template <bool WAVE, class XF = NoFetch, bool EXT = false>
 __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d, AlnOut &O, const int a,
                                             const PathEnt *__restrict__ path, const int64_t n, uint32_t status,
                                             Section *__restrict__ secs, int32_t *const *__restrict__ fp_group,
                                             EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap,
-                                            const bool lead) {
+                                            const bool lead, XF xf = XF()) {
     const int qi = 0, ri = 1;
     const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
     const int32_t *t2r = B.hap_ptr[d.ts] + d.t_off;
@@ -693,7 +696,9 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
     PathEnt q0 = ccur, q1 = ccur, q2 = ccur, q3 = ccur, q4 = ccur, q5 = ccur, q6 = ccur, q7 = ccur;
     int64_t qbase = int64_t(1) << 60;
     auto fetch = [&](int64_t i) -> PathEnt {
-        if (WAVE) {
+        if constexpr (EXT) {
+            return xf(i);
+        } else if (WAVE) {
             if (i < cbase) {   // uniform
                 cbase -= 64;
                 ccur = cpre;

@@ -127,7 +127,8 @@ __global__ void __launch_bounds__(256) k_prep_zl(DevBatch B, const AlnDesc *__re
 // ===========================================================================
 __global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list, int n_list,
                                                   const ZlWave *__restrict__ hdr, const uint32_t *__restrict__ zin,
-                                                  uint4 *__restrict__ zlog, AlnOut *__restrict__ outs, PathEnt *__restrict__ paths) {
+                                                  uint4 *__restrict__ zlog, AlnOut *__restrict__ outs, PathEnt *__restrict__ paths,
+                                                  int keep_paths) {
     const int w = blockIdx.x, lane = threadIdx.x;
     const ZlWave H = hdr[w];
     const int wi = w * 64 + lane;
@@ -377,12 +378,17 @@ __global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ de
                 const bool in_q = hi == 0 && (cw & ZW_PV) && !(cw & ZW_PB);
                 sync = (!in_t && !in_q && !((tw | cw) & ZW_INS) && trv == qref) ? 1u : 0u;
             }
-            uint4 pe;
-            pe.x = uint32_t(x) | (uint32_t(hi) << 31);
-            pe.y = uint32_t(t) | (sync << 31);
-            pe.z = uint32_t(qref);
-            pe.w = uint32_t(trv);
-            *reinterpret_cast<uint4 *>(path + t) = pe;
+            // the step as k_zero_credit reads it, in place of the row's log entries (the walk is done with them)
+            *reinterpret_cast<uint2 *>(logA + int64_t(t) * 64) =
+                make_uint2(uint32_t(x) | (uint32_t(hi) << 16) | (sync << 17), uint32_t(qref + 1) | (uint32_t(trv + 1) << 16));
+            if (keep_paths) {       // VPR_CFG_KEEP_PATHS: also as a 16-byte path entry (vpr_download_path)
+                uint4 pe;
+                pe.x = uint32_t(x) | (uint32_t(hi) << 31);
+                pe.y = uint32_t(t) | (sync << 31);
+                pe.z = uint32_t(qref);
+                pe.w = uint32_t(trv);
+                *reinterpret_cast<uint4 *>(path + t) = pe;
+            }
             if (t + 1 < nrow) {      // the move out of the cell, by priority
                 if (hi == 1 && (e & ZE_PPSWP)) { hi = 0; slot = int((e >> ZE_SSLOT_SHIFT) & 3u); }
                 else if (e & ZE_PPMAT) { }
@@ -399,6 +405,47 @@ __global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ de
         if (!wok) o.n_sec = 0;
         if (status) atomicOr(&o.status, status);
     }
+}
+
+// ===========================================================================
+// KZc: the credit sections of the alignments k_zero_lane finished (integer part of calc_prec_recall, dist.cpp:1035-1400:
+// credit_walk), one lane per alignment.  The path comes from the walk log: row t of lane l is 8 bytes at
+// (t * 64 + l) * 16 of the wave's log block, so a wave's load of a step is one 1 KB stretch instead of 64 lines of 64
+// different path blocks.
+// ===========================================================================
+struct ZlFetch {
+    const uint4 *log;       // this lane's column of the wave's log block
+    int64_t pre_i;
+    uint2 pre;
+    __device__ PathEnt operator()(int64_t i) {
+        const uint2 v = (i == pre_i) ? pre : *reinterpret_cast<const uint2 *>(log + i * 64);
+        if (i > 0) { pre_i = i - 1; pre = *reinterpret_cast<const uint2 *>(log + (i - 1) * 64); }    // entries are read in descending order
+        PathEnt e;
+        e.a = (v.x & 0xffffu) | (((v.x >> 16) & 1u) << 31);
+        e.b = uint32_t(i) | (((v.x >> 17) & 1u) << 31);
+        e.qref = int(v.y & 0xffffu) - 1;
+        e.tref = int(v.y >> 16) - 1;
+        return e;
+    }
+};
+
+__global__ void __launch_bounds__(64) k_zero_credit(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list,
+                                                    int n_list, const ZlWave *__restrict__ hdr, const uint4 *__restrict__ zlog,
+                                                    AlnOut *__restrict__ outs, Section *__restrict__ secs,
+                                                    int32_t *const *__restrict__ fp_group, EdJob *__restrict__ jobs,
+                                                    int32_t *__restrict__ n_jobs, int32_t jobs_cap, int tag) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const int wi = w * 64 + lane;
+    if (wi >= n_list) return;
+    const int a = list[wi];
+    if (a < 0) return;
+    const AlnDesc d = descs[a];
+    AlnOut &O = outs[a];
+    if (d.band_pad != tag || O.band_ok != tag) return;       // not finished by k_zero_lane: the in-place 16-cell round has it
+    if (O.status & (VPR_ST_ERR_NO_PTR | VPR_ST_ERR_LIMIT)) return;
+    const ZlWave H = hdr[w];
+    ZlFetch f{zlog + H.log_off + lane, -1, make_uint2(0, 0)};
+    credit_walk<false, ZlFetch, true>(B, d, O, a, nullptr, int64_t(O.path_len), 0u, secs, fp_group, jobs, n_jobs, jobs_cap, true, f);
 }
 
 #endif
