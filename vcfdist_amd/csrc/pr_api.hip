@@ -740,7 +740,7 @@ int prep_zero_lane(vpr_handle *h) {
             W.in_off = in_words;
             W.log_off = log_cur;
             in_words += 64 * (int64_t(W.mq) + W.mr + W.mt);
-            log_cur += 2 * 64 * int64_t(W.mt);
+            log_cur += 80 * int64_t(W.mt);         // per row and lane: 8 flag bytes, a path_ptr word, an 8-byte step
             hdr.push_back(W);
         }
         log_max = std::max(log_max, log_cur);
@@ -1574,7 +1574,7 @@ struct Exec {
             if (zero)        // forward + backward + walk of the zero-distance alignments, one lane each (pr_zl.hip)
                 hipLaunchKernelGGL(k_zero_lane, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->d_descs, list, cnt,
                                    h->d_zl_hdr + zl_wave0, h->d_zl_in, h->d_zl_log, h->d_outs, a_path,
-                                   (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0);
+                                   ((h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0) | (getenv("ZL_EXP") ? atoi(getenv("ZL_EXP")) : 0));
             else if (q16)
                 hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);

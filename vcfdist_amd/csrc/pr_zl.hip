@@ -11,14 +11,14 @@
 //
 //   forward   row t -> t+1: MAT child of every live slot (next base of its plane == next truth base), SWP child
 //             (fwd_allow at the source and the truth row, dist.cpp:336-339, base at ptr + 1 of the other plane == next
-//             truth base).  The row's cells go to the log, 4 B each: position, "entered by MAT / by SWP from slot s",
-//             and the two bits of the cell's own position word the backward pass needs (is_tp, bwd_allow).
+//             truth base).  The row's cells go to the log, one byte each: "entered by MAT / by SWP from slot s" and the
+//             two bits of the cell's own position word the backward pass needs (is_tp, bwd_allow).
 //   backward  calc_prec_recall_path (dist.cpp:536-687, zero-cost moves only) over the log rows in reverse: score of a
 //             cell = max over its successors of (their score + is_tp), path_ptr bits = the moves that reach the max;
-//             the log entries get the bits and the slot of the SWP successor.
+//             they and the slot of the SWP successor are a second, 4-byte record per row.
 //   walk      get_prec_recall_path_sync (dist.cpp:865-998): from the begin cell along the path_ptr bits by the
-//             reference's priorities (REF plane: SWP first; then MAT; QUERY plane: SWP last), sync flag per step;
-//             16-byte path entries in the layout k_credit reads.
+//             reference's priorities (REF plane: SWP first; then MAT; QUERY plane: SWP last), sync flag per step; the
+//             steps are 8-byte records for k_zero_credit (16-byte path entries on request, VPR_CFG_KEEP_PATHS).
 //
 // What it does not take: an alignment whose end cells are not reached at distance 0 (s > 0), a row with more than four
 // diagonals on a plane, lengths that do not fit the 16-bit position fields, and a cell that receives a SWP edge from two
@@ -30,15 +30,17 @@
 // every load of a wave would touch 64 different cache lines.  k_prep_zl therefore writes, once per batch, a
 // WAVE-INTERLEAVED copy of what the kernel reads: for the 64 alignments of a wave, position x of alignment l is word
 // (x * 64 + l) of the wave's Q / R / T block -- the lanes are at (nearly) the same position at the same time, so a wave
-// load is a few consecutive 256-byte rows.  The log has the same shape: row t of lane l is 16 bytes at (t * 64 + l) * 16
-// (slots Q0 Q1 R0 R1; slots 2, 3 of both planes in a second block that is only touched when a row uses them).
+// load is a few consecutive 256-byte rows.  The logs have the same shape (row t of lane l at (t * 64 + l) * record size),
+// and their records are as small as they can be -- 8 + 4 + 8 bytes per row -- because the kernel is bound by the bytes it
+// moves: every byte is written once and read once, by a later pass, when it has long left the caches.
 #ifndef PR_ZL_HIP_
 #define PR_ZL_HIP_
 
 // per wave of 64 alignments: offsets (in 32-bit words) of its interleaved input block and of its log blocks
 struct ZlWave {
     int64_t in_off;       // Q block; R block at + 64 * mq, T block at + 64 * (mq + mr)
-    int64_t log_off;      // in uint4 units: rows of slots 0,1 at log_off + t * 64 + lane; slots 2,3 at + 64 * mt
+    int64_t log_off;      // in uint4 units; 80 * mt of them: the cells' flag bytes (8 B per row and lane), one path_ptr word per
+                          // row and lane, the walk's steps (8 B per row and lane)
     int32_t mq, mr, mt;   // largest Lq / Lr / Lt of the wave's alignments
     int32_t pad;
 };
@@ -54,16 +56,13 @@ struct ZlWave {
 __device__ __forceinline__ bool zw_fwd_allow(uint32_t w) { return !(w & ZW_PV) || (w & ZW_PE); }
 __device__ __forceinline__ bool zw_bwd_allow(uint32_t w) { return !(w & ZW_PV) || (w & ZW_PB); }
 
-// log entry
-#define ZE_HASMAT (1u << 16)
-#define ZE_HASSWP (1u << 17)
-#define ZE_PSLOT_SHIFT 18      // 2 bits: slot of the SWP predecessor (other plane, previous row)
-#define ZE_PPMAT (1u << 20)
-#define ZE_PPSWP (1u << 21)
-#define ZE_SSLOT_SHIFT 22      // 2 bits: slot of the SWP successor (other plane, next row)
-#define ZE_TP (1u << 25)
-#define ZE_BWD (1u << 26)
-#define ZE_EXT (1u << 31)      // word 0 of a row only: the row also has cells in slots 2, 3
+// log entry of a cell: one byte (a row's eight slots are one 8-byte record, byte p * 4 + s)
+#define ZE_ALIVE 1u
+#define ZE_HASMAT 2u
+#define ZE_HASSWP 4u
+#define ZE_PSLOT_SHIFT 3       // 2 bits: slot of the SWP predecessor (other plane, previous row)
+#define ZE_TP 32u
+#define ZE_BWD 64u
 
 #define ZL_MAXLEN 65000
 
@@ -123,8 +122,15 @@ __global__ void __launch_bounds__(256) k_prep_zl(DevBatch B, const AlnDesc *__re
 }
 
 // ===========================================================================
-// KZ: forward + backward + walk of the zero-distance alignments, one lane per alignment
+// KZ: forward + backward + walk of the zero-distance alignments, one lane per alignment.
+// All memory traffic goes through two buffer descriptors built from wave-uniform values (the wave's input block and its
+// log block): a lane's address is a 32-bit byte offset, and an offset behind the block -- what a lane without work for
+// the access gets -- is answered with zeros by the bounds check instead of costing a branch or a cache line.
 // ===========================================================================
+typedef __attribute__((ext_vector_type(4))) unsigned int zl_u4;
+typedef __attribute__((ext_vector_type(2))) unsigned int zl_u2;
+#define ZL_OOB 0xfffffff0u
+
 __global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list, int n_list,
                                                   const ZlWave *__restrict__ hdr, const uint32_t *__restrict__ zin,
                                                   uint4 *__restrict__ zlog, AlnOut *__restrict__ outs, PathEnt *__restrict__ paths,
@@ -138,11 +144,16 @@ __global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ de
     const AlnDesc *dp = descs + a;
     const int Lq = live ? dp->Lq : 1, Lr = live ? dp->Lr : 1, Lt = live ? dp->Lt : 0;
     const int L[2] = {Lq, Lr};
-    const uint32_t *Z[2] = {zin + H.in_off + lane, zin + H.in_off + int64_t(H.mq) * 64 + lane};
-    const uint32_t *ZT = zin + H.in_off + int64_t(H.mq + H.mr) * 64 + lane;
-    uint4 *logA = zlog + H.log_off + lane, *logB = logA + int64_t(H.mt) * 64;
+    // input block: position x of plane p at ((pos0[p] + x) * 64 + lane) * 4, truth row t at ((post + t) * 64 + lane) * 4
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(zin + H.in_off), 0, 256 * (H.mq + H.mr + H.mt), 0x00020000);
+    // log block: the cells' flag bytes (8 B per row and lane), the path_ptr words (4 B), the walk's steps (8 B)
+    const auto rlog = __builtin_amdgcn_make_buffer_rsrc(zlog + H.log_off, 0, 1280 * H.mt, 0x00020000);
+    const uint32_t lane4 = uint32_t(lane) << 2, lane8 = uint32_t(lane) << 3;
+    const uint32_t pos0[2] = {0u, uint32_t(H.mq) << 8}, post = uint32_t(H.mq + H.mr) << 8;
+    const uint32_t logP0 = uint32_t(H.mt) << 9, logS0 = logP0 + (uint32_t(H.mt) << 8);
+    auto in_at = [&](uint32_t off) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b32(rin, off, 0, 0); };
     // (a one-row alignment only exists where a region was cut at the contig end, include/vcfdist_pr.h: the reference's
-    // backward pass never terminates on it -- left to the general kernels, which report it as unfinished)
+    // backward pass never terminates on it -- left to the general kernels)
     bool ok = live && Lq < ZL_MAXLEN && Lr < ZL_MAXLEN && Lt < ZL_MAXLEN && Lt >= 2;
     const int rows = ok ? Lt : 0;
     int tmax = rows;
@@ -161,42 +172,48 @@ __global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ de
 #pragma unroll
         for (int s = 0; s < 4; s++) { qri[p][s] = -1; pw[p][s] = 0; }
     }
-    if (rows > 0) {     // the two start cells, dist.cpp:300-305
-        qri[0][0] = 0; pw[0][0] = Z[0][0];
-        qri[1][0] = 0; pw[1][0] = Z[1][0];
-        logA[0] = make_uint4(1u | ZE_HASMAT | (pw[0][0] & ZW_TP ? ZE_TP : 0u) | (zw_bwd_allow(pw[0][0]) ? ZE_BWD : 0u), 0u,
-                             1u | ZE_HASMAT | (zw_bwd_allow(pw[1][0]) ? ZE_BWD : 0u), 0u);
+    uint32_t tw0 = in_at(ok ? post + lane4 : ZL_OOB);
+    if (ok) {     // the two start cells, dist.cpp:300-305
+        qri[0][0] = 0; pw[0][0] = in_at(pos0[0] + lane4);
+        qri[1][0] = 0; pw[1][0] = in_at(pos0[1] + lane4);
+        zl_u2 e0;
+        e0.x = ZE_ALIVE | ZE_HASMAT | ((pw[0][0] & ZW_TP) ? ZE_TP : 0u) | (zw_bwd_allow(pw[0][0]) ? ZE_BWD : 0u);
+        e0.y = ZE_ALIVE | ZE_HASMAT | (zw_bwd_allow(pw[1][0]) ? ZE_BWD : 0u);
+        __builtin_amdgcn_raw_buffer_store_b64(e0, rlog, lane8, 0, 0);
     }
-    uint32_t tw0 = rows > 0 ? ZT[0] : 0u;
     for (int t = 0; t + 1 < tmax; t++) {
         const bool act = ok && t + 1 < rows;
-        const uint32_t tw1 = ZT[int64_t(min(t + 1, H.mt - 1)) * 64];
-        const uint32_t Tb = ZW_BASE(tw1);
+        const uint32_t tw1 = in_at(act ? post + (uint32_t(t + 1) << 8) + lane4 : ZL_OOB);
         const bool t_allow = zw_fwd_allow(tw0);
         // children's position words: MAT child x + 1 of the own plane, SWP child ptr + 1 of the other plane
         uint32_t mw[2][4], sw[2][4];
         int sz[2][4];
+        bool upper = false;
+#pragma unroll
+        for (int p = 0; p < 2; p++) upper = upper || (act && (qri[p][2] >= 0 || qri[p][3] >= 0));
+        const bool any_upper = __any(upper);
 #pragma unroll
         for (int p = 0; p < 2; p++) {
 #pragma unroll
             for (int s = 0; s < 4; s++) {
+                if (s >= 2 && !any_upper) { mw[p][s] = 0; sw[p][s] = 0; sz[p][s] = -1; continue; }
                 const bool alive = act && qri[p][s] >= 0;
-                if (!__any(alive)) { mw[p][s] = 0x7f0000u; sw[p][s] = 0x7f0000u; sz[p][s] = -1; continue; }
                 const int c = qri[p][s] + 1;
-                mw[p][s] = (alive && c < L[p]) ? Z[p][int64_t(c) * 64] : 0x7f0000u;
                 const int z = ZW_PTR(pw[p][s]) + 1;
-                const bool sok = alive && t_allow && zw_fwd_allow(pw[p][s]) && z >= 0 && z < L[1 - p];
+                const bool sok = alive && t_allow && zw_fwd_allow(pw[p][s]) && z < L[1 - p];
                 sz[p][s] = sok ? z : -1;
-                sw[p][s] = sok ? Z[1 - p][int64_t(z) * 64] : 0x7f0000u;
+                mw[p][s] = in_at((alive && c < L[p]) ? pos0[p] + (uint32_t(c) << 8) + lane4 : ZL_OOB);
+                sw[p][s] = in_at(sok ? pos0[1 - p] + (uint32_t(z) << 8) + lane4 : ZL_OOB);
             }
         }
+        const uint32_t Tb = ZW_BASE(tw1);
         int nq[2][4];
         uint32_t nw[2][4], ne[2][4];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const bool hit = act && qri[p][s] >= 0 && ZW_BASE(mw[p][s]) == Tb && qri[p][s] + 1 < L[p];
+                const bool hit = act && qri[p][s] >= 0 && ZW_BASE(mw[p][s]) == Tb;      // (a word from behind the block has base 0)
                 nq[p][s] = hit ? qri[p][s] + 1 : -1;
                 nw[p][s] = mw[p][s];
                 ne[p][s] = hit ? ZE_HASMAT : 0u;
@@ -208,52 +225,46 @@ __global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ de
             const int o = 1 - p;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
+                if (s >= 2 && !any_upper) continue;
                 const bool hit = sz[p][s] >= 0 && ZW_BASE(sw[p][s]) == Tb;
                 if (!__any(hit)) continue;
                 const int z = sz[p][s];
                 // the cell (o, z) of row t + 1: already there (by MAT, or by another source's SWP), else the first free slot
                 int at = -1;
 #pragma unroll
-                for (int k = 3; k >= 0; k--) if (nq[o][k] < 0) at = k;
+                for (int k = 3; k >= 0; k--) at = (nq[o][k] < 0) ? k : at;
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (nq[o][k] == z) at = k;
-                if (hit && at < 0) bad = true;                    // a fifth diagonal on the plane
+                for (int k = 0; k < 4; k++) at = (nq[o][k] == z) ? k : at;
+                bad = bad || (hit && at < 0);                     // a fifth diagonal on the plane
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (hit && at == k) {
-                        if (ne[o][k] & ZE_HASSWP) bad = true;     // a second SWP source of the cell: left to the general kernels
-                        nq[o][k] = z;
-                        nw[o][k] = sw[p][s];
-                        ne[o][k] |= ZE_HASSWP | (uint32_t(s) << ZE_PSLOT_SHIFT);
-                    }
+                    const bool here = hit && at == k;
+                    bad = bad || (here && (ne[o][k] & ZE_HASSWP));   // a second SWP source of the cell: left to the general kernels
+                    nq[o][k] = here ? z : nq[o][k];
+                    nw[o][k] = here ? sw[p][s] : nw[o][k];
+                    ne[o][k] = here ? (ne[o][k] | ZE_HASSWP | (uint32_t(s) << ZE_PSLOT_SHIFT)) : ne[o][k];
                 }
             }
         }
-        if (bad) ok = false;
+        ok = ok && !bad;
         // the row's log entries
-        if (act && ok) {
-            uint32_t e[2][4];
-            bool ext = false;
+        {
+            zl_u2 ev;
+            uint32_t wq = 0, wr_ = 0;
 #pragma unroll
-            for (int p = 0; p < 2; p++) {
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    e[p][s] = nq[p][s] < 0 ? 0u
-                              : (uint32_t(nq[p][s] + 1) | ne[p][s] | ((nw[p][s] & ZW_TP) ? ZE_TP : 0u) | (zw_bwd_allow(nw[p][s]) ? ZE_BWD : 0u));
-                    if (s >= 2 && nq[p][s] >= 0) ext = true;
-                }
+            for (int sl = 0; sl < 4; sl++) {
+                wq |= (nq[0][sl] < 0 ? 0u : (ZE_ALIVE | ne[0][sl] | ((nw[0][sl] & ZW_TP) ? ZE_TP : 0u) | (zw_bwd_allow(nw[0][sl]) ? ZE_BWD : 0u))) << (8 * sl);
+                wr_ |= (nq[1][sl] < 0 ? 0u : (ZE_ALIVE | ne[1][sl] | (zw_bwd_allow(nw[1][sl]) ? ZE_BWD : 0u))) << (8 * sl);
             }
-            logA[int64_t(t + 1) * 64] = make_uint4(e[0][0] | (ext ? ZE_EXT : 0u), e[0][1], e[1][0], e[1][1]);
-            if (ext) logB[int64_t(t + 1) * 64] = make_uint4(e[0][2], e[0][3], e[1][2], e[1][3]);
+            ev.x = wq; ev.y = wr_;
+            __builtin_amdgcn_raw_buffer_store_b64(ev, rlog, (act && ok) ? (uint32_t(t + 1) << 9) + lane8 : ZL_OOB, 0, 0);
         }
-        if (act) {
 #pragma unroll
-            for (int p = 0; p < 2; p++) {
+        for (int p = 0; p < 2; p++) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) { qri[p][s] = nq[p][s]; pw[p][s] = nw[p][s]; }
-            }
-            tw0 = tw1;
+            for (int s = 0; s < 4; s++) { qri[p][s] = act ? nq[p][s] : qri[p][s]; pw[p][s] = act ? nw[p][s] : pw[p][s]; }
         }
+        tw0 = act ? tw1 : tw0;
     }
     // end cells (dist.cpp:390-391, 436-439: the QUERY plane is preferred)
     int endq = -1, endr = -1;
@@ -270,8 +281,10 @@ __global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ de
         o.exit_min = ok ? D_INF : 0;          // k_fwd_band_finish: accepted iff s = 0 here
     }
     if (!__any(ok)) return;
+    if (keep_paths & 2) return;     // (experiment)
 
-    // ---------------- backward: max-TP scores over the zero-cost moves (dist.cpp:550-681), rows Lt-1 .. 1
+    // ---------------- backward: max-TP scores over the zero-cost moves (dist.cpp:550-681), rows Lt-1 .. 1.  The path_ptr
+    // bits of a row's cells are one word: four bits per slot (MAT, SWP, slot of the SWP successor)
     const int nrow = ok ? Lt : 0;
     int sc[2][4];
 #pragma unroll
@@ -282,27 +295,28 @@ __global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ de
     int bmax = nrow;
 #pragma unroll
     for (int o = 32; o; o >>= 1) bmax = max(bmax, __shfl_xor(bmax, o));
-    uint4 curA = make_uint4(0, 0, 0, 0), curB = curA;      // entries of row t
+    auto log_row = [&](int t, bool on) -> zl_u2 {
+        return __builtin_amdgcn_raw_buffer_load_b64(rlog, on ? (uint32_t(t) << 9) + lane8 : ZL_OOB, 0, 0);
+    };
+    zl_u2 cur = zl_u2{0, 0};      // entries of row t
     for (int t = bmax - 1; t >= 1; t--) {
         const bool act = t < nrow;
-        if (t == nrow - 1) {      // this lane's last row: the end cell has score 0 (dist.cpp:538-546)
-            curA = logA[int64_t(t) * 64];
-            curB = (curA.x & ZE_EXT) ? logB[int64_t(t) * 64] : make_uint4(0, 0, 0, 0);
+        const bool first = t == nrow - 1;     // this lane's last row: the end cell has score 0 (dist.cpp:538-546)
+        if (__any(first)) {
+            const zl_u2 fr = log_row(t, first);
             const int ep = endq >= 0 ? 0 : 1, es = endq >= 0 ? endq : endr;
+            if (first) {
+                cur = fr;
 #pragma unroll
-            for (int p = 0; p < 2; p++) {
+                for (int p = 0; p < 2; p++) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) sc[p][s] = (p == ep && s == es) ? 0 : -1;
+                    for (int s = 0; s < 4; s++) sc[p][s] = (p == ep && s == es) ? 0 : -1;
+                }
             }
         }
-        uint4 preA = make_uint4(0, 0, 0, 0), preB = preA;
-        if (act) {
-            preA = logA[int64_t(t - 1) * 64];
-            if (preA.x & ZE_EXT) preB = logB[int64_t(t - 1) * 64];
-        }
-        const uint32_t ce[2][4] = {{curA.x, curA.y, curB.x, curB.y}, {curA.z, curA.w, curB.z, curB.w}};
+        const zl_u2 pre = log_row(t - 1, act);
         int best[2][4];
-        uint32_t pp[2][4];
+        uint32_t pp[2][4];      // path_ptr nibble of the row t - 1 cells: 1 MAT, 2 SWP, bits 2-3 slot of the SWP successor
 #pragma unroll
         for (int p = 0; p < 2; p++) {
 #pragma unroll
@@ -314,88 +328,83 @@ __global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ de
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const bool on = act && sc[p][s] >= 0;
-                if (!__any(on)) continue;
-                const uint32_t e = ce[p][s];
+                if (s >= 2 && !__any(on)) continue;
+                const uint32_t e = ((p ? cur.y : cur.x) >> (8 * s)) & 0xffu;
                 const int tp = (e & ZE_TP) ? 1 : 0;
-                if (on && (e & ZE_HASMAT)) {      // MAT predecessor: same plane, same slot
+                {      // MAT predecessor: same plane, same slot
+                    const bool m = on && (e & ZE_HASMAT);
                     const int v = sc[p][s] + tp;
-                    if (v > best[p][s]) { best[p][s] = v; pp[p][s] = ZE_PPMAT; }
-                    else if (v == best[p][s]) pp[p][s] |= ZE_PPMAT;
+                    const bool gt = m && v > best[p][s], eq = m && v == best[p][s];
+                    best[p][s] = gt ? v : best[p][s];
+                    pp[p][s] = gt ? 1u : (eq ? (pp[p][s] | 1u) : pp[p][s]);
                 }
-                if (on && (e & ZE_HASSWP) && (e & ZE_BWD)) {      // SWP predecessor (bwd_allow at this cell, dist.cpp:599-602)
-                    const int v = sc[p][s] + (p == 1 ? 0 : tp);  // leaving a REF cell scores 0 (dist.cpp:614)
+                {      // SWP predecessor (bwd_allow at this cell, dist.cpp:599-602); leaving a REF cell scores 0 (dist.cpp:614)
+                    const bool m = on && (e & ZE_HASSWP) && (e & ZE_BWD);
+                    const int v = sc[p][s] + (p == 1 ? 0 : tp);
                     const int ps = int((e >> ZE_PSLOT_SHIFT) & 3u);
+                    const uint32_t mine = 2u | (uint32_t(s) << 2);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        if (ps == k) {
-                            if (v > best[o][k]) { best[o][k] = v; pp[o][k] = ZE_PPSWP | (uint32_t(s) << ZE_SSLOT_SHIFT); }
-                            else if (v == best[o][k]) pp[o][k] = (pp[o][k] & ~(3u << ZE_SSLOT_SHIFT)) | ZE_PPSWP | (uint32_t(s) << ZE_SSLOT_SHIFT);
-                        }
+                        const bool h_ = m && ps == k;
+                        const bool gt = h_ && v > best[o][k], eq = h_ && v == best[o][k];
+                        best[o][k] = gt ? v : best[o][k];
+                        pp[o][k] = gt ? mine : (eq ? ((pp[o][k] & 1u) | mine) : pp[o][k]);
                     }
                 }
             }
         }
-        if (act) {
-            // row t - 1 with its path_ptr bits (a cell has one SWP successor: the slot is unambiguous)
-            uint32_t pe[2][4] = {{preA.x, preA.y, preB.x, preB.y}, {preA.z, preA.w, preB.z, preB.w}};
+        uint32_t ppw = 0;
 #pragma unroll
-            for (int p = 0; p < 2; p++) {
+        for (int p = 0; p < 2; p++) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    if (best[p][s] >= 0) pe[p][s] |= pp[p][s];
-                    sc[p][s] = best[p][s];
-                }
+            for (int s = 0; s < 4; s++) {
+                ppw |= (best[p][s] >= 0 ? pp[p][s] : 0u) << (4 * (p * 4 + s));
+                sc[p][s] = act ? best[p][s] : sc[p][s];
             }
-            curA = make_uint4(pe[0][0], pe[0][1], pe[1][0], pe[1][1]);
-            curB = make_uint4(pe[0][2], pe[0][3], pe[1][2], pe[1][3]);
-            logA[int64_t(t - 1) * 64] = curA;
-            if (preA.x & ZE_EXT) logB[int64_t(t - 1) * 64] = curB;
         }
+        __builtin_amdgcn_raw_buffer_store_b32(ppw, rlog, act ? logP0 + (uint32_t(t - 1) << 8) + lane4 : ZL_OOB, 0, 0);
+        if (act) cur = pre;
     }
     // (QUERY, 0, 0) on a path to the end?  dist.cpp:811-814
     const int beg_plane = sc[0][0] >= 0 ? VPR_PLANE_QUERY : VPR_PLANE_REF;
+    if (keep_paths & 4) return;     // (experiment)
 
     // ---------------- walk (dist.cpp:905-982) + sync flags (dist.cpp:949-968)
     PathEnt *path = paths + dp->path_off;
-    int hi = beg_plane, slot = 0, mv_in = 0;
+    int hi = beg_plane, slot = 0, mv_in = 0, x = 0;
     uint32_t status = 0;
     bool wok = ok;
     for (int t = 0; t < bmax; t++) {
         const bool act = wok && t < nrow;
-        const uint32_t *lw = reinterpret_cast<const uint32_t *>((slot < 2 ? logA : logB) + int64_t(t) * 64);
-        uint32_t e = 0, cw = 0, tw = 0;
-        if (act) {
-            e = lw[(hi << 1) | (slot & 1)];
-            tw = ZT[int64_t(t) * 64];
+        const uint32_t ppw = __builtin_amdgcn_raw_buffer_load_b32(rlog, (act && t + 1 < nrow) ? logP0 + (uint32_t(t) << 8) + lane4 : ZL_OOB, 0, 0);
+        const uint32_t tw = in_at(act ? post + (uint32_t(t) << 8) + lane4 : ZL_OOB);
+        const uint32_t cw = in_at(act ? pos0[hi] + (uint32_t(x) << 8) + lane4 : ZL_OOB);
+        const int trv = ZW_PTR(tw), qref = hi ? x : ZW_PTR(cw);
+        uint32_t sync = 1;
+        if (mv_in) {
+            const bool in_t = (tw & ZW_PV) && !(tw & ZW_PB);
+            const bool in_q = hi == 0 && (cw & ZW_PV) && !(cw & ZW_PB);
+            sync = (!in_t && !in_q && !((tw | cw) & ZW_INS) && trv == qref) ? 1u : 0u;
         }
-        const int x = int(e & 0xffffu) - 1;
-        if (act) cw = Z[hi][int64_t(max(x, 0)) * 64];
-        if (act) {
-            const int trv = ZW_PTR(tw), qref = hi ? x : ZW_PTR(cw);
-            uint32_t sync = 1;
-            if (mv_in) {
-                const bool in_t = (tw & ZW_PV) && !(tw & ZW_PB);
-                const bool in_q = hi == 0 && (cw & ZW_PV) && !(cw & ZW_PB);
-                sync = (!in_t && !in_q && !((tw | cw) & ZW_INS) && trv == qref) ? 1u : 0u;
-            }
-            // the step as k_zero_credit reads it, in place of the row's log entries (the walk is done with them)
-            *reinterpret_cast<uint2 *>(logA + int64_t(t) * 64) =
-                make_uint2(uint32_t(x) | (uint32_t(hi) << 16) | (sync << 17), uint32_t(qref + 1) | (uint32_t(trv + 1) << 16));
-            if (keep_paths) {       // VPR_CFG_KEEP_PATHS: also as a 16-byte path entry (vpr_download_path)
-                uint4 pe;
-                pe.x = uint32_t(x) | (uint32_t(hi) << 31);
-                pe.y = uint32_t(t) | (sync << 31);
-                pe.z = uint32_t(qref);
-                pe.w = uint32_t(trv);
-                *reinterpret_cast<uint4 *>(path + t) = pe;
-            }
-            if (t + 1 < nrow) {      // the move out of the cell, by priority
-                if (hi == 1 && (e & ZE_PPSWP)) { hi = 0; slot = int((e >> ZE_SSLOT_SHIFT) & 3u); }
-                else if (e & ZE_PPMAT) { }
-                else if (hi == 0 && (e & ZE_PPSWP)) { hi = 1; slot = int((e >> ZE_SSLOT_SHIFT) & 3u); }
-                else { status |= VPR_ST_ERR_NO_PTR; wok = false; }
-                mv_in = 1;
-            }
+        zl_u2 st;           // the step as k_zero_credit reads it
+        st.x = uint32_t(x) | (uint32_t(hi) << 16) | (sync << 17);
+        st.y = uint32_t(qref + 1) | (uint32_t(trv + 1) << 16);
+        __builtin_amdgcn_raw_buffer_store_b64(st, rlog, act ? logS0 + (uint32_t(t) << 9) + lane8 : ZL_OOB, 0, 0);
+        if ((keep_paths & 1) && act) {       // VPR_CFG_KEEP_PATHS: also as a 16-byte path entry (vpr_download_path)
+            uint4 pe;
+            pe.x = uint32_t(x) | (uint32_t(hi) << 31);
+            pe.y = uint32_t(t) | (sync << 31);
+            pe.z = uint32_t(qref);
+            pe.w = uint32_t(trv);
+            *reinterpret_cast<uint4 *>(path + t) = pe;
+        }
+        if (act && t + 1 < nrow) {      // the move out of the cell, by priority; a SWP edge lands behind the cell's pointer
+            const uint32_t nb = (ppw >> (4 * ((hi << 2) | slot))) & 15u;
+            if (hi == 1 && (nb & 2u)) { hi = 0; slot = int(nb >> 2); x = ZW_PTR(cw) + 1; }
+            else if (nb & 1u) { x = x + 1; }
+            else if (hi == 0 && (nb & 2u)) { hi = 1; slot = int(nb >> 2); x = ZW_PTR(cw) + 1; }
+            else { status |= VPR_ST_ERR_NO_PTR; wok = false; }
+            mv_in = 1;
         }
     }
     if (ok) {
@@ -409,17 +418,17 @@ __global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ de
 
 // ===========================================================================
 // KZc: the credit sections of the alignments k_zero_lane finished (integer part of calc_prec_recall, dist.cpp:1035-1400:
-// credit_walk), one lane per alignment.  The path comes from the walk log: row t of lane l is 8 bytes at
-// (t * 64 + l) * 16 of the wave's log block, so a wave's load of a step is one 1 KB stretch instead of 64 lines of 64
-// different path blocks.
+// credit_walk), one lane per alignment.  The path comes from the walk's step records: row t of lane l is 8 bytes at
+// (t * 64 + l) * 8 of the wave's third log region, so a wave's load of a step is one 512-byte stretch instead of 64 lines
+// of 64 different path blocks.
 // ===========================================================================
 struct ZlFetch {
-    const uint4 *log;       // this lane's column of the wave's log block
+    const uint2 *log;       // this lane's column of the wave's step records
     int64_t pre_i;
     uint2 pre;
     __device__ PathEnt operator()(int64_t i) {
-        const uint2 v = (i == pre_i) ? pre : *reinterpret_cast<const uint2 *>(log + i * 64);
-        if (i > 0) { pre_i = i - 1; pre = *reinterpret_cast<const uint2 *>(log + (i - 1) * 64); }    // entries are read in descending order
+        const uint2 v = (i == pre_i) ? pre : log[i * 64];
+        if (i > 0) { pre_i = i - 1; pre = log[(i - 1) * 64]; }    // entries are read in descending order
         PathEnt e;
         e.a = (v.x & 0xffffu) | (((v.x >> 16) & 1u) << 31);
         e.b = uint32_t(i) | (((v.x >> 17) & 1u) << 31);
@@ -444,7 +453,7 @@ __global__ void __launch_bounds__(64) k_zero_credit(DevBatch B, const AlnDesc *_
     if (d.band_pad != tag || O.band_ok != tag) return;       // not finished by k_zero_lane: the in-place 16-cell round has it
     if (O.status & (VPR_ST_ERR_NO_PTR | VPR_ST_ERR_LIMIT)) return;
     const ZlWave H = hdr[w];
-    ZlFetch f{zlog + H.log_off + lane, -1, make_uint2(0, 0)};
+    ZlFetch f{reinterpret_cast<const uint2 *>(zlog + H.log_off + 48 * int64_t(H.mt)) + lane, -1, make_uint2(0, 0)};     // behind 512 + 256 bytes per row
     credit_walk<false, ZlFetch, true>(B, d, O, a, nullptr, int64_t(O.path_len), 0u, secs, fp_group, jobs, n_jobs, jobs_cap, true, f);
 }
 
