@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_SIMD, SCLK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; shader clock of the committed SQ_BUSY_CYCLES counters
-PROFILE_TAG = "r02"    # profiles/<tag>_counters_<workload>.json: tools/make_profiles.sh
+PROFILE_TAG = "r03"    # profiles/<tag>_counters_<workload>.json: tools/make_profiles.sh
 
 
 def make_workload(api, n_sc, seed, workload):
@@ -122,9 +122,11 @@ def main():
                     help="weak: --n-sc superclusters per GPU (own seed, own contigs); strong: --n-sc-total superclusters of one "
                          "synthetic genome dealt over the ranks by estimated cells, phasing all-gathered every step")
     ap.add_argument("--n-sc-total", type=int, default=3000000)
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="batches resident in HBM whose steps may overlap (each behind its own library handle and host thread): "
                          "1 = strictly one step after the other")
+    ap.add_argument("--one-pass-batches", type=int, default=9,
+                    help="batches of the one-pass leg (upload from the variant tables + execute + download each; 0 = skip)")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launch path only (no GPU work): the ranks rendezvous over gloo, all-reduce their rank numbers and rank 0 "
                          "prints {n_gpus, rank_sum}; tests/test_distributed.py runs `bench.py --gpus 2 --plumbing-check` on CPU")
@@ -320,8 +322,59 @@ def main():
 
     total_aln = 4 * (args.n_sc_total if strong else args.n_sc * world) * args.steps
     value = total_aln / elapsed
+
+    # ---- one pass per batch (N = 1, weak): what a run over fresh superclusters costs.  Every step starts from the variant
+    # tables in host memory: sizing + checks on the host, variant tables and contig over the link, generate_ptrs_strs on the
+    # device (pr_gen.hip), position constants, planning, then the same execute + download + counters as above; batches in
+    # flight overlap one batch's upload and planning with another's kernels.
+    one_pass = None
+    tm_main = pr.timing()
+    if world == 1 and not strong and args.one_pass_batches > 0:
+        nb = args.one_pass_batches
+        op_parts = [0.0, 0.0, 0.0]
+
+        for S in slots:                     # (the SNP / INDEL / SV class is a column of the variant tables: print.cpp:362-372)
+            S.cls = S.syn.var_class()
+
+        def op_step(S):
+            ta = time.perf_counter()
+            S.pr.upload_variants(S.syn.struct, S.batch)
+            summary.upload_var_class(S.pr, S.cls)
+            tb = time.perf_counter()
+            S.pr.execute()
+            tc = time.perf_counter()
+            S.host_res = S.pr.download(None)        # (the result block of the previous upload went with it)
+            summary.pr_counts(S.pr, None, None)
+            with lock:
+                op_parts[0] += tb - ta; op_parts[1] += tc - tb; op_parts[2] += time.perf_counter() - tc
+
+        def op_run(n):
+            def worker(j):
+                for i in range(j, n, n_fl):
+                    op_step(slots[j])
+            ths = [threading.Thread(target=worker, args=(j,)) for j in range(n_fl)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+        op_run(n_fl)                        # warm-up: one batch per slot
+        op_parts[:] = [0.0, 0.0, 0.0]
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        op_run(nb)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t1
+        one_pass = {"value": round(4 * args.n_sc * nb / dt, 1), "unit": "supercluster-alignments/s", "batches": nb, "in_flight": n_fl,
+                    "ms_per_batch": round(dt / nb * 1e3, 2),
+                    "host_thread_ms_per_batch": {"upload_variants": round(op_parts[0] / nb * 1e3, 2), "vpr_execute": round(op_parts[1] / nb * 1e3, 2),
+                                                 "download_and_counters": round(op_parts[2] / nb * 1e3, 2)},
+                    "note": "every batch from its variant tables in host memory: host sizing pass, upload, generate_ptrs_strs on the "
+                            "device, position constants, planning, execute, download, counters"}
+        for S in slots:                     # (the timed batches replaced the resident ones; what follows reads the last step's results)
+            S.host_res = None
+
     if rank == 0:
-        tm = pr.timing()
+        tm = tm_main
         # dominant K1/K2 kernel (the DP sweeps the byte model of SURVEY 8(d) is about): algorithmic bytes per launch
         # / average launch duration (HIP events on the stream the kernel is launched on)
         sweeps = {k: v for k, v in stats_acc.items() if k[0] in (1, 2) and v[0] > 0}
@@ -394,6 +447,7 @@ def main():
                                 # one batch through upload + one step (vpr_create, a per-process cost, left out)
                                 "pcie_inclusive_value": round(4 * args.n_sc / ((t_d - t_c1) + elapsed / args.steps), 1)},
             "kernel_only_value": round(4 * args.n_sc / (float(np.mean(kern_ms)) * 1e-3), 1),
+            "one_pass": one_pass,
             "kernels": per_kernel,
             "counts_at_min_qual_TP_FP_FN": t.cpu().numpy()[:, 3, :, 0].tolist(),   # [callset][TP,FP,FN], type ALL, all ranks
             "pr_summary_rank0": [{"type": summary.NAMES[r.vartype], "threshold": "BEST" if r.best else "NONE", "qual": r.qual,

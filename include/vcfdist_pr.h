@@ -318,6 +318,10 @@ typedef struct vpr_owned_batch vpr_owned_batch;
    (so such a supercluster has one or no base behind its last variant instead of two); the tables keep the caller's
    sc_end. */
 int  vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out);
+/* (vpr_upload_variants runs the same sizing and checking pass on the host and has the DEVICE write the arrays, from the
+   variant tables and the contig: the equivalent of generate_ptrs_strs inside the timed stage, dist.cpp:1786-1822.)
+   Test aid: the resident Level A arrays copied back; dst's arrays must hold what the uploaded batch's offsets say. */
+int  vpr_download_level_a(vpr_handle *h, vpr_batch *dst);
 const vpr_batch *vpr_owned_batch_view(const vpr_owned_batch *b);
 void vpr_owned_batch_free(vpr_owned_batch *b);
 

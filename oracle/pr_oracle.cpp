@@ -32,6 +32,8 @@
 // (tests/dense_model.py) for distances, flags, backward scores and path pointers, (4) hand-derived credit cases.
 // See DESIGN.md section 5.
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -83,19 +85,28 @@ struct Hap {
     std::vector<int> flag;
 };
 
-// a dense byte matrix [rows=q][cols=t]
-struct Mat8 {
+// Dense matrices [rows=q][cols=t], held as the reference holds them: one heap vector per row
+// (std::vector<std::vector<T>>, dist.cpp:1828-1844, 523-534; the `done` matrices are std::vector<std::vector<bool>>,
+// dist.cpp:293-296).  That is part of the algorithm's cost and belongs in a baseline that is timed: rows of a few KB
+// come from the allocator's heap and are reused from one supercluster to the next, whereas one flat block per matrix
+// is mapped and unmapped every time and spends its life in page faults (a 10 kb supercluster took 8 s that way, 5x
+// the reference's own time; profiles/r03_cpu_calibration.json).
+template <class T>
+struct MatRows {
     int rows = 0, cols = 0;
-    std::vector<uint8_t> d;
-    void init(int r, int c, uint8_t v) { rows = r; cols = c; d.assign(size_t(r) * size_t(c), v); }
-    uint8_t &at(int q, int t) { return d[size_t(q) * cols + t]; }
-    uint8_t at(int q, int t) const { return d[size_t(q) * cols + t]; }
+    std::vector<std::vector<T>> m;
+    void init(int r, int c, T v) { rows = r; cols = c; m.assign(size_t(r), std::vector<T>(size_t(c), v)); }
+    T &at(int q, int t) { return m[size_t(q)][size_t(t)]; }
+    T at(int q, int t) const { return m[size_t(q)][size_t(t)]; }
+    size_t size() const { return size_t(rows) * size_t(cols); }
+    T flat(size_t k) const { return m[k / size_t(cols)][k % size_t(cols)]; }
 };
-struct Mat16 {
-    int rows = 0, cols = 0;
-    std::vector<int16_t> d;
-    void init(int r, int c, int16_t v) { rows = r; cols = c; d.assign(size_t(r) * size_t(c), v); }
-    int16_t &at(int q, int t) { return d[size_t(q) * cols + t]; }
+typedef MatRows<uint8_t> Mat8;
+typedef MatRows<int16_t> Mat16;
+struct MatBit {
+    std::vector<std::vector<bool>> m;
+    void init(int r, int c, bool v) { m.assign(size_t(r), std::vector<bool>(size_t(c), v)); }
+    std::vector<bool>::reference at(int q, int t) { return m[size_t(q)][size_t(t)]; }
 };
 
 inline bool fwd_allow(int f) { return !(f & VPR_PTR_VARIANT) || (f & VPR_PTR_VAR_END); }  // dist.cpp:336-339
@@ -132,15 +143,20 @@ struct AlnState {
 // ---------------------------------------------------------------------------
 void forward_pass(const AlnIn &in, AlnState &A, bool track_writers) {
     const int qi = 2 * in.i, ri = 2 * in.i + 1;
-    const std::string &Q = in.q->seq, &T = in.t->seq, &R = *in.ref;
+    // (the reference works on its own copies of the strings and pointer arrays, one set per alignment: dist.cpp:270-281.  The
+    // copies are part of its per-supercluster cost, so the timed restatement makes them too.)
+    const std::string Q = in.q->seq, T = in.t->seq, R = *in.ref;
+    const std::vector<int> q_ptr_copy = in.q->ptr, q_flag_copy = in.q->flag, t_ptr_copy = in.t->ptr, t_flag_copy = in.t->flag,
+                           r_ptr_copy = *in.r2q_ptr, r_flag_copy = *in.r2q_flag;
+    (void)q_ptr_copy; (void)q_flag_copy; (void)t_ptr_copy; (void)t_flag_copy; (void)r_ptr_copy; (void)r_flag_copy;
     const int Lq = Q.size(), Lt = T.size(), Lr = R.size();
     A.aln[0].init(Lq, Lt, 0);
     A.aln[1].init(Lr, Lt, 0);
-    Mat8 done[2];
-    done[0].init(Lq, Lt, 0);
-    done[1].init(Lr, Lt, 0);
+    MatBit done[2];
+    done[0].init(Lq, Lt, false);
+    done[1].init(Lr, Lt, false);
     auto P = [&](const Cell &c) -> uint8_t & { return A.aln[c.hi == ri].at(c.qri, c.ti); };
-    auto D = [&](const Cell &c) -> uint8_t & { return done[c.hi == ri].at(c.qri, c.ti); };
+    auto D = [&](const Cell &c) -> std::vector<bool>::reference { return done[c.hi == ri].at(c.qri, c.ti); };
 
     std::queue<Cell> fifo;
     fifo.push(Cell(qi, 0, 0));
@@ -252,15 +268,19 @@ void backward_pass(const AlnIn &in, AlnState &A) {
     A.pptr[1].init(Lr, Lt, 0);
     A.pscore[0].init(Lq, Lt, -1);
     A.pscore[1].init(Lr, Lt, -1);
-    Mat8 done[2];
-    done[0].init(Lq, Lt, 0);
-    done[1].init(Lr, Lt, 0);
+    MatBit done[2];
+    done[0].init(Lq, Lt, false);
+    done[1].init(Lr, Lt, false);
     auto AP = [&](const Cell &c) -> uint8_t & { return A.aln[c.hi == ri].at(c.qri, c.ti); };
     auto PP = [&](const Cell &c) -> uint8_t & { return A.pptr[c.hi == ri].at(c.qri, c.ti); };
     auto PS = [&](const Cell &c) -> int16_t & { return A.pscore[c.hi == ri].at(c.qri, c.ti); };
-    auto D = [&](const Cell &c) -> uint8_t & { return done[c.hi == ri].at(c.qri, c.ti); };
-    const std::vector<int> &q2r = in.q->ptr, &qfl = in.q->flag;
-    const std::vector<int> &rfl = *in.r2q_flag;
+    auto D = [&](const Cell &c) -> std::vector<bool>::reference { return done[c.hi == ri].at(c.qri, c.ti); };
+    // (own copies, as in the reference: dist.cpp:506-514)
+    const std::vector<int> q2r = in.q->ptr, qfl = in.q->flag;
+    const std::vector<int> rfl = *in.r2q_flag;
+    const std::vector<int> t_ptr_copy = in.t->ptr, t_flag_copy = in.t->flag, r_ptr_copy = *in.r2q_ptr;
+    const std::string q_copy = in.q->seq, t_copy = in.t->seq;
+    (void)t_ptr_copy; (void)t_flag_copy; (void)r_ptr_copy; (void)q_copy; (void)t_copy;
 
     std::queue<Cell> fifo;
     Cell start(A.end_plane == VPR_PLANE_QUERY ? qi : ri,
@@ -672,6 +692,9 @@ int32_t vpo_store_phase(const int32_t s[4], double phase_threshold, int32_t *ori
 // Run the whole path over a Level A batch.  `res` arrays must be pre-initialised
 // by the caller to the reference's initial values (errtype = UN, rest 0).
 int vpo_run(const vpr_batch *b, const vpr_config *cfg, vpr_results *res, vpo_extra *ex) {
+    const bool timing = getenv("VPO_TIMING") != nullptr;
+    double tm[5] = {0, 0, 0, 0, 0};
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int sc = 0; sc < b->n_sc; sc++) {
         Hap hap[VPR_HAPS];
         for (int h = 0; h < VPR_HAPS; h++) load_hap(b, h, sc, hap[h]);
@@ -688,7 +711,9 @@ int vpo_run(const vpr_batch *b, const vpr_config *cfg, vpr_results *res, vpo_ext
             AlnIn in{i, &hap[i >> 1], &hap[2 + (i & 1)], &ref, &r2q_ptr[i >> 1], &r2q_flag[i >> 1]};
             st[i].reset(new AlnState());
             AlnState &A = *st[i];
+            const double t0_ = timing ? now() : 0;
             forward_pass(in, A, ex != nullptr);
+            if (timing) tm[0] += now() - t0_;
             s[i] = A.s;
             res->aln_dist[sc * 4 + i] = A.s;
             res->aln_end_plane[sc * 4 + i] = A.end_plane;
@@ -698,8 +723,11 @@ int vpo_run(const vpr_batch *b, const vpr_config *cfg, vpr_results *res, vpo_ext
         for (int i = 0; i < 4; i++) {
             AlnIn in{i, &hap[i >> 1], &hap[2 + (i & 1)], &ref, &r2q_ptr[i >> 1], &r2q_flag[i >> 1]};
             AlnState &A = *st[i];
+            double t1_ = timing ? now() : 0;
             if (!(A.status & VPR_ST_ERR_UNFINISHED)) backward_pass(in, A);
+            if (timing) { tm[1] += now() - t1_; t1_ = now(); }
             if (!(A.status & (VPR_ST_ERR_UNFINISHED | VPR_ST_ERR_NO_PTR))) walk_path(in, A);
+            if (timing) { tm[2] += now() - t1_; t1_ = now(); }
             res->aln_beg_plane[sc * 4 + i] = A.beg_plane;
             if (!(A.status & (VPR_ST_ERR_UNFINISHED | VPR_ST_ERR_NO_PTR))) {
                 const int swap = (i == 1 || i == 2);
@@ -738,17 +766,18 @@ int vpo_run(const vpr_batch *b, const vpr_config *cfg, vpr_results *res, vpo_ext
                 if (ex->want_sc == sc && ex->want_aln == i && ex->dump_flags[0]) {
                     // forward flags (masked to the 5 edge bits) and path_ptrs, [plane][q][t]
                     for (int p = 0; p < 2; p++) {
-                        const size_t n = A.aln[p].d.size();
+                        const size_t n = A.aln[p].size();
                         for (size_t k = 0; k < n; k++) {
-                            ex->dump_flags[p][k] = A.aln[p].d[k] & 31;
-                            ex->dump_pptr[p][k] = A.pptr[p].d[k] & 31;
-                            ex->dump_pscore[p][k] = A.pscore[p].d[k];
+                            ex->dump_flags[p][k] = A.aln[p].flat(k) & 31;
+                            ex->dump_pptr[p][k] = A.pptr[p].flat(k) & 31;
+                            ex->dump_pscore[p][k] = A.pscore[p].flat(k);
                         }
                     }
                 }
             }
         }
     }
+    if (timing) fprintf(stderr, "[vpo] forward %.3f s, backward %.3f s, walk %.3f s\n", tm[0], tm[1], tm[2]);
     return 0;
 }
 

@@ -327,3 +327,54 @@ def test_runs_of_adjacent_deletion_records(band_mode):
     import indel_runs
     for seed in (11, 12):
         compare(api.batch_from_variants(indel_runs.indel_run_superclusters(seed)), A.default_config(band_mode=band_mode))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_sc=500, len_a=6, len_b=120, len_min=5, len_max=120, seed=71, var_per_base=0.08, p_snp=0.4, p_repeat=0.5),
+    dict(n_sc=40, len_a=300, len_b=3000, len_min=300, len_max=3000, seed=72, var_per_base=0.02, p_snp=0.5, indel_mean=20.0),
+    dict(n_sc=3000, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=3000, seed=73),
+])
+def test_device_generate_ptrs_strs_equals_host_marshalling(kw):
+    """vpr_upload_variants: the device writes the haplotype strings, the reference string and the pointer / flag arrays
+    (generate_ptrs_strs, dist.cpp:145-242; pr_gen.hip) from the variant tables.  Every array must equal the host
+    marshalling's (itself compared with the oracle's restatement in tests/test_host.py), and the path's results the
+    oracle's."""
+    syn = api.Synth(**kw)
+    host = syn.batch()
+    pr = api.PrecisionRecall()
+    pr.upload_variants(syn.struct, host)
+    dev = pr.download_level_a(host)
+    for f in ("hap_off", "hap_seq", "hap_ptr", "hap_flag"):
+        for h in range(4):
+            assert np.array_equal(getattr(dev, f)[h], getattr(host, f)[h]), (f, h)
+    assert np.array_equal(dev.ref_off, host.ref_off) and np.array_equal(dev.ref_seq, host.ref_seq)
+    for q in range(2):
+        assert np.array_equal(dev.ref_ptr[q], host.ref_ptr[q]) and np.array_equal(dev.ref_flag[q], host.ref_flag[q])
+    pr.execute()
+    got = pr.download()
+    want = O.run(host)
+    want = want[0] if isinstance(want, tuple) else want
+    assert not got.diff(want)
+
+
+def test_device_generate_contig_end_and_bad_input():
+    """the regions at a contig's end (cut at the last base) through the device generator, and input the sizing pass refuses"""
+    ref = "ACGTTGCAACGTACGGTCAT"
+    S, I, D = A.TYPE_SUB, A.TYPE_INS, A.TYPE_DEL
+    scs = [dict(ctg=0, beg=16, end=20, vars=[[(17, D, "C", "", 9.0)], [], [(17, D, "C", "", 9.0)], []]),
+           dict(ctg=0, beg=15, end=20, vars=[[(16, D, "TC", "", 9.0)], [(17, I, "", "GG", 4.0)], [(16, D, "TC", "", 9.0)], []]),
+           dict(ctg=0, beg=18, end=20, vars=[[(19, I, "", "AC", 9.0)], [(19, I, "", "AC", 9.0)], [(19, I, "", "AC", 9.0)], []])]
+    v = A.Variants.from_sites([ref], scs)
+    host = api.batch_from_variants(v)
+    pr = api.PrecisionRecall()
+    pr.upload_variants(v.as_struct(), v)
+    dev = pr.download_level_a(host)
+    for h in range(4):
+        assert np.array_equal(dev.hap_seq[h], host.hap_seq[h]) and np.array_equal(dev.hap_ptr[h], host.hap_ptr[h]) and np.array_equal(dev.hap_flag[h], host.hap_flag[h])
+    pr.execute()
+    want = O.run(host)
+    want = want[0] if isinstance(want, tuple) else want
+    assert not pr.download().diff(want)
+    bad = A.Variants.from_sites([ref], [dict(ctg=0, beg=4, end=9, vars=[[(6, D, "CA", "", 5.0), (7, S, "A", "T", 5.0)], [], [], []])])
+    with pytest.raises(api.VprError):
+        api.PrecisionRecall().upload_variants(bad.as_struct(), bad)

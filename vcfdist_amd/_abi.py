@@ -309,6 +309,9 @@ class Variants:
                    [s["end"] for s in superclusters], var_off, pos, typ, qual, roff, rlen, aoff, alen,
                    [np.frombuffer(bytes(p), dtype=np.uint8) for p in pool])
 
+    def n_vars(self, h):
+        return int(self.var_off[h][-1])
+
     def as_struct(self):
         s = VprVariants()
         s.n_sc = self.n_sc

@@ -82,7 +82,7 @@ def lib():
 
 EXPORTED = [
     "vpr_create", "vpr_destroy", "vpr_last_error", "vpr_version", "vpr_run", "vpr_upload",
-    "vpr_upload_variants", "vpr_execute", "vpr_download", "vpr_host_alloc", "vpr_host_free", "vpr_get_timing", "vpr_get_launch_stats",
+    "vpr_upload_variants", "vpr_download_level_a", "vpr_execute", "vpr_download", "vpr_host_alloc", "vpr_host_free", "vpr_get_timing", "vpr_get_launch_stats",
     "vpr_get_tally",
     "vpr_download_path", "vpr_phase", "vpr_var_class", "vpr_upload_var_class", "vpr_results_alloc", "vpr_pr_counts", "vpr_pr_summary",
     "vpr_store_phase", "vpr_batch_from_variants", "vpr_owned_batch_view", "vpr_owned_batch_free",
@@ -267,9 +267,24 @@ class PrecisionRecall:
         return [arr[i] for i in range(n)]
 
     def upload_variants(self, variants_struct, batch_for_results):
-        """Upload a vpr_variants struct (e.g. Synth.struct); `batch_for_results` only sizes the result buffers."""
+        """Upload a vpr_variants struct (e.g. Synth.struct): the host sizes and checks the regions, the device writes the
+        haplotype strings and pointer arrays (generate_ptrs_strs, pr_gen.hip).  `batch_for_results` only sizes the result
+        buffers: anything with n_sc and n_vars(h) (a Batch, a Variants)."""
         self._batch = batch_for_results
         self._chk(lib().vpr_upload_variants(self._h, C.byref(variants_struct)), "vpr_upload_variants")
+
+    def download_level_a(self, like: A.Batch) -> A.Batch:
+        """test aid: the resident Level A arrays (written by the host marshalling or by the device generator) as a Batch
+        shaped like `like` (same offsets)"""
+        z = lambda a: np.zeros_like(a)
+        out = A.Batch(like.n_sc, [z(a) for a in like.hap_off], [z(a) for a in like.hap_seq], [z(a) for a in like.hap_ptr],
+                      [z(a) for a in like.hap_flag], z(like.ref_off), z(like.ref_seq), [z(a) for a in like.ref_ptr],
+                      [z(a) for a in like.ref_flag], like.var_off, like.var_pos, like.var_qual)
+        s = out.as_struct()
+        L = lib()
+        L.vpr_download_level_a.argtypes = [C.c_void_p, C.POINTER(A.VprBatch)]
+        self._chk(L.vpr_download_level_a(self._h, C.byref(s)), "vpr_download_level_a")
+        return out
 
     def path(self, sc, aln):
         """(plane, qri, ti, sync, edit) arrays of one alignment's walk (last workspace chunk only)."""

@@ -197,7 +197,9 @@ Lens walk(const vpr_variants *v, int slot, int sc,
 
 extern "C" {
 
-int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
+// fill = false: offsets, lengths and the variant tables only (every check of the full pass included); the strings, pointer
+// and flag arrays stay null -- vpr_upload_variants has the device write them (k_generate, pr_gen.hip)
+static int batch_from_variants_impl(const vpr_variants *v, vpr_owned_batch **out, bool fill) {
     if (!v || !out || v->n_sc < 0) return VPR_ERR_ARG;
     vpr_owned_batch *B = new (std::nothrow) vpr_owned_batch();
     if (!B) return VPR_ERR_NOMEM;
@@ -261,13 +263,16 @@ int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
             B->ref_flag[h] = c.take<uint8_t>(size_t(B->ref_off[n]));
         }
     };
-    {
+    if (fill) {
         Carver measure{nullptr};
         carve_big(measure);
         B->big = block_get(measure.off);
         if (!B->big.p) { vpr_owned_batch_free(B); return VPR_ERR_NOMEM; }
         Carver c{static_cast<uint8_t *>(B->big.p)};
         carve_big(c);
+    } else {
+        Carver none{nullptr};
+        carve_big(none);        // (null pointers)
     }
 
     // pass 2: fill
@@ -281,20 +286,29 @@ int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
             }
         }
     };
-    {
+    if (fill) {
         std::vector<std::thread> th;
         for (int t = 0; t < nthreads; t++) th.emplace_back(fill_job, t);
         for (auto &x : th) x.join();
     }
 
     // variants: positions relative to the supercluster start (dist.cpp:1075-1080)
-    for (int h = 0; h < VPR_HAPS; h++) {
-        std::copy(v->var_off[h], v->var_off[h] + n + 1, B->var_off[h]);
-        const int64_t nv = v->var_off[h][n];
-        std::copy(v->var_qual[h], v->var_qual[h] + nv, B->var_qual[h]);
-        for (int sc = 0; sc < n; sc++)
-            for (int64_t k = v->var_off[h][sc]; k < v->var_off[h][sc + 1]; k++)
-                B->var_pos[h][k] = v->var_pos[h][k] - v->sc_beg[sc];
+    auto var_job = [&](int t) {
+        const int sc0 = int(int64_t(n) * t / nthreads), sc1 = int(int64_t(n) * (t + 1) / nthreads);
+        for (int h = 0; h < VPR_HAPS; h++) {
+            std::copy(v->var_off[h] + sc0, v->var_off[h] + sc1 + (t == nthreads - 1 ? 1 : 0), B->var_off[h] + sc0);
+            const int64_t k0 = v->var_off[h][sc0], k1 = v->var_off[h][sc1];
+            std::copy(v->var_qual[h] + k0, v->var_qual[h] + k1, B->var_qual[h] + k0);
+            for (int sc = sc0; sc < sc1; sc++)
+                for (int64_t k = v->var_off[h][sc]; k < v->var_off[h][sc + 1]; k++)
+                    B->var_pos[h][k] = v->var_pos[h][k] - v->sc_beg[sc];
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back(var_job, t);
+        for (auto &x : th) x.join();
+        for (int h = 0; h < VPR_HAPS; h++) B->var_off[h][n] = v->var_off[h][n];
     }
 
     vpr_batch &b = B->view;
@@ -318,6 +332,10 @@ int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) {
     *out = B;
     return VPR_OK;
 }
+
+int vpr_batch_from_variants(const vpr_variants *v, vpr_owned_batch **out) { return batch_from_variants_impl(v, out, true); }
+// (library-internal: the skeleton vpr_upload_variants hands to the device generator)
+int vpr_batch_skeleton_from_variants(const vpr_variants *v, vpr_owned_batch **out) { return batch_from_variants_impl(v, out, false); }
 
 const vpr_batch *vpr_owned_batch_view(const vpr_owned_batch *b) { return b ? &b->view : nullptr; }
 void vpr_owned_batch_free(vpr_owned_batch *b) {

@@ -25,10 +25,12 @@
 
 #include "../../include/vcfdist_pr.h"
 #include "pr_device.h"
+extern "C" int vpr_batch_skeleton_from_variants(const vpr_variants *v, vpr_owned_batch **out);   // generate.cpp
 #include "pr_kernels.hip"
 #include "pr_band.hip"
 #include "pr_q16.hip"
 #include "pr_zl.hip"
+#include "pr_gen.hip"
 #include "pr_wide.hip"
 #include "pr_tie.hip"
 
@@ -135,7 +137,13 @@ struct vpr_handle {
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    std::vector<void *> allocs;          // batch-lifetime device allocations: pool blocks, carved by dev_alloc
+    // batch-lifetime device allocations: pool blocks, carved by dev_alloc.  Released blocks are KEPT (dev_cache / pin_cache)
+    // and handed out again by the next upload: hipFree of a used multi-GB block takes seconds and page-locking host memory
+    // runs at ~6 GB/s, which is most of what a re-upload into a used handle cost
+    struct Blk { void *p; size_t bytes; };
+    std::vector<Blk> dev_cache, pin_cache, pinned_blk;
+    std::vector<size_t> alloc_bytes;     // sizes of `allocs`
+    std::vector<void *> allocs;
     uint8_t *pool_cur = nullptr;         // bump pointer into the newest block
     size_t pool_left = 0, pool_next = size_t(16) << 20;   // block sizes double up to 2 GiB (a batch needs ~150 arrays)
     DevBatch dB;
@@ -195,6 +203,12 @@ struct vpr_handle {
     // once by k_prep_zl) and the log blocks (shared by the chunks of plan 0, which run one after the other)
     ZlWave *d_zl_hdr = nullptr; uint32_t *d_zl_in = nullptr; uint4 *d_zl_log = nullptr;
     std::vector<int64_t> zl_wave0;                            // first wave of every chunk of plan 0
+    std::vector<ZlWave> zl_hdr_host;
+    // vpr_upload_variants: the variant tables of the batch being uploaded (the device generates the Level A arrays from
+    // them, pr_gen.hip), and the contig sequence of the previous upload, which stays resident as long as the caller keeps
+    // passing the same one (a whole-genome run uploads a contig once, not once per batch)
+    const vpr_variants *gen_src = nullptr;
+    uint8_t *d_ctg_seq = nullptr; const uint8_t *ctg_src = nullptr; int64_t ctg_bytes = 0; uint64_t ctg_probe = 0;
     // host-pinned, device-visible mirrors of d_fail / d_cnt: a publish kernel on the producing stream fills them, so the
     // host reads a fail list after an event wait and issues no copy that the bulk kernels of the round could starve
     int32_t *hp_fail = nullptr, *hp_cnt = nullptr;
@@ -228,6 +242,56 @@ int fail(vpr_handle *h, int code, const char *fmt, ...) {
             return fail(h, VPR_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// a device block of at least `bytes` bytes: a kept one that is not wastefully larger, else a new allocation
+void *dev_block(vpr_handle *h, size_t bytes, hipError_t *err) {
+    *err = hipSuccess;
+    int best = -1;
+    for (size_t k = 0; k < h->dev_cache.size(); k++) {
+        const size_t b = h->dev_cache[k].bytes;
+        if (b >= bytes && b <= bytes + bytes / 2 + (size_t(64) << 20) && (best < 0 || b < h->dev_cache[size_t(best)].bytes)) best = int(k);
+    }
+    void *q = nullptr;
+    size_t got = bytes;
+    if (best >= 0) {
+        q = h->dev_cache[size_t(best)].p; got = h->dev_cache[size_t(best)].bytes;
+        h->dev_cache.erase(h->dev_cache.begin() + best);
+    } else {
+        *err = hipMalloc(&q, bytes);
+        if (*err != hipSuccess) {        // out of memory with blocks kept aside: release them and try once more
+            for (auto &c : h->dev_cache) (void)hipFree(c.p);
+            h->dev_cache.clear();
+            (void)hipGetLastError();
+            *err = hipMalloc(&q, bytes);
+            if (*err != hipSuccess) return nullptr;
+        }
+    }
+    h->allocs.push_back(q);
+    h->alloc_bytes.push_back(got);
+    return q;
+}
+
+// page-locked host memory of the batch's lifetime (h->pinned_blk), from the kept blocks when one fits
+int pin_alloc(vpr_handle *h, void **out, size_t bytes) {
+    bytes = bytes ? bytes : 1;
+    int best = -1;
+    for (size_t k = 0; k < h->pin_cache.size(); k++) {
+        const size_t b = h->pin_cache[k].bytes;
+        if (b >= bytes && b <= 2 * bytes + (size_t(1) << 20) && (best < 0 || b < h->pin_cache[size_t(best)].bytes)) best = int(k);
+    }
+    if (best >= 0) {
+        *out = h->pin_cache[size_t(best)].p;
+        h->pinned_blk.push_back(h->pin_cache[size_t(best)]);
+        h->pin_cache.erase(h->pin_cache.begin() + best);
+        return VPR_OK;
+    }
+    void *q = nullptr;
+    const hipError_t e = hipHostMalloc(&q, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(h, VPR_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    h->pinned_blk.push_back(vpr_handle::Blk{q, bytes});
+    *out = q;
+    return VPR_OK;
+}
+
 template <typename T>
 int dev_alloc(vpr_handle *h, T **p, size_t n) {
     *p = nullptr;
@@ -238,6 +302,7 @@ int dev_alloc(vpr_handle *h, T **p, size_t n) {
         hipError_t e = hipMalloc(&q, bytes);
         if (e != hipSuccess) return fail(h, VPR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
         h->allocs.push_back(q);
+        h->alloc_bytes.push_back(0);     // (0: not kept for reuse)
         *p = static_cast<T *>(q);
         return VPR_OK;
     }
@@ -245,10 +310,9 @@ int dev_alloc(vpr_handle *h, T **p, size_t n) {
         // a new block: the request alone when it is large (the remainder of the old block stays usable for nothing: blocks
         // double, so at most half of what was allocated is ever lost), else the next pool size
         const size_t blk = std::max(bytes, h->pool_next);
-        void *q = nullptr;
-        hipError_t e = hipMalloc(&q, blk);
-        if (e != hipSuccess) return fail(h, VPR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", blk, hipGetErrorString(e));
-        h->allocs.push_back(q);
+        hipError_t e;
+        void *q = dev_block(h, blk, &e);
+        if (!q) return fail(h, VPR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", blk, hipGetErrorString(e));
         if (bytes >= h->pool_next) {        // dedicated block; keep carving the previous one
             *p = static_cast<T *>(q);
             return VPR_OK;
@@ -268,17 +332,29 @@ int dev_upload(vpr_handle *h, const T **dst, const T *src, size_t n) {
     T *p;
     int rc = dev_alloc(h, &p, n);
     if (rc) return rc;
-    if (n) HIPCHK(h, hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    if (n && src) HIPCHK(h, hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));   // (null: filled on the device)
     *dst = p;
     return VPR_OK;
 }
 
 void free_batch(vpr_handle *h) {
-    for (void *p : h->allocs) (void)hipFree(p);
-    h->allocs.clear();
+    for (size_t k = 0; k < h->allocs.size(); k++) {
+        if (h->alloc_bytes[k]) h->dev_cache.push_back(vpr_handle::Blk{h->allocs[k], h->alloc_bytes[k]});
+        else (void)hipFree(h->allocs[k]);
+    }
+    h->allocs.clear(); h->alloc_bytes.clear();
+    while (h->dev_cache.size() > 96) {      // (a long run over batches of very different sizes: drop the smallest blocks)
+        size_t m = 0;
+        for (size_t k = 1; k < h->dev_cache.size(); k++) if (h->dev_cache[k].bytes < h->dev_cache[m].bytes) m = k;
+        (void)hipFree(h->dev_cache[m].p);
+        h->dev_cache.erase(h->dev_cache.begin() + long(m));
+    }
     h->pool_cur = nullptr; h->pool_left = 0; h->pool_next = size_t(16) << 20;
     for (void *p : h->pinned) (void)hipHostFree(p);
     h->pinned.clear();
+    for (auto &b : h->pinned_blk) h->pin_cache.push_back(b);
+    h->pinned_blk.clear();
+    while (h->pin_cache.size() > 48) { (void)hipHostFree(h->pin_cache.front().p); h->pin_cache.erase(h->pin_cache.begin()); }
     h->hp_fail = nullptr; h->hp_cnt = nullptr; h->hp_flag = nullptr;
     for (int s = 0; s < 4; s++) h->hp_dspan[s] = nullptr;
     h->res_dev = nullptr; h->res_bytes = 0; h->res_mirror = nullptr;     // (a mirror block belongs to the caller: it just stops matching)
@@ -722,26 +798,34 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
 // descriptor scatter on the upload stream).
 int prep_zero_lane(vpr_handle *h) {
     const Plan &P = h->plan0;
-    std::vector<ZlWave> hdr;
+    std::vector<ZlWave> &hdr = h->zl_hdr_host;      // (kept in the handle: the upload below reads it asynchronously)
+    hdr.clear();
     h->zl_wave0.assign(P.chunks.size(), 0);
     int64_t in_words = 0, log_max = 0;
     for (size_t ci = 0; ci < P.chunks.size(); ci++) {
         const Chunk &ch = P.chunks[ci];
         h->zl_wave0[ci] = int64_t(hdr.size());
         const int64_t first = ch.work_off + ch.n_long, n_short = ch.count - ch.n_long;
-        int64_t log_cur = 0;
-        for (int64_t k = 0; k < n_short; k += 64) {
-            ZlWave W;
-            memset(&W, 0, sizeof(W));
-            for (int64_t j = k; j < std::min(n_short, k + 64); j++) {
-                const AlnDesc &d = P.descs[size_t(first + j)];
-                W.mq = std::max(W.mq, d.Lq); W.mr = std::max(W.mr, d.Lr); W.mt = std::max(W.mt, d.Lt);
+        const size_t w0 = hdr.size(), nw = size_t((n_short + 63) / 64);
+        hdr.resize(w0 + nw);
+        par_for(nw * 64, [&](size_t b0, size_t e0, int) {           // the largest lengths of every wave's 64 alignments
+            for (size_t wv = (b0 + 63) / 64; wv * 64 < e0; wv++) {
+                ZlWave W;
+                memset(&W, 0, sizeof(W));
+                for (int64_t j = int64_t(wv) * 64; j < std::min<int64_t>(n_short, int64_t(wv) * 64 + 64); j++) {
+                    const AlnDesc &d = P.descs[size_t(first + j)];
+                    W.mq = std::max(W.mq, d.Lq); W.mr = std::max(W.mr, d.Lr); W.mt = std::max(W.mt, d.Lt);
+                }
+                hdr[w0 + wv] = W;
             }
+        });
+        int64_t log_cur = 0;
+        for (size_t wv = 0; wv < nw; wv++) {
+            ZlWave &W = hdr[w0 + wv];
             W.in_off = in_words;
             W.log_off = log_cur;
             in_words += 64 * (int64_t(W.mq) + W.mr + W.mt);
             log_cur += 80 * int64_t(W.mt);         // per row and lane: 8 flag bytes, a path_ptr word, an 8-byte step
-            hdr.push_back(W);
         }
         log_max = std::max(log_max, log_cur);
     }
@@ -751,7 +835,6 @@ int prep_zero_lane(vpr_handle *h) {
     if ((rc = dev_alloc(h, &h->d_zl_in, size_t(in_words)))) return rc;
     if ((rc = dev_alloc(h, &h->d_zl_log, size_t(log_max)))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_zl_hdr, hdr.data(), hdr.size() * sizeof(ZlWave), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));         // (hdr is a local: the copy must have left it)
     for (size_t ci = 0; ci < P.chunks.size(); ci++) {
         const Chunk &ch = P.chunks[ci];
         const int64_t n_short = ch.count - ch.n_long;
@@ -831,6 +914,9 @@ void vpr_destroy(vpr_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     free_batch(h);
+    for (auto &b : h->dev_cache) (void)hipFree(b.p);
+    for (auto &b : h->pin_cache) (void)hipHostFree(b.p);
+    if (h->d_ctg_seq) (void)hipFree(h->d_ctg_seq);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int k = 0; k < 8; k++) {
         if (h->cls_stream[k]) (void)hipStreamDestroy(h->cls_stream[k]);
@@ -859,7 +945,11 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     const bool dbg = h->debug;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double T0 = now();
-    auto lap = [&](const char *what) { if (dbg) { (void)hipDeviceSynchronize(); fprintf(stderr, "[vpr] upload %-28s %.3f s\n", what, now() - T0); } };
+    const bool tim = getenv("VPR_TIMING") != nullptr;       // host-side laps without device synchronisation
+    auto lap = [&](const char *what) {
+        if (dbg) { (void)hipDeviceSynchronize(); fprintf(stderr, "[vpr] upload %-28s %.3f s\n", what, now() - T0); }
+        else if (tim) fprintf(stderr, "[vpr] upload (host) %-28s %.3f s\n", what, now() - T0);
+    };
     DevBatch &D = h->dB;
     memset(&D, 0, sizeof(D));
     D.n_sc = n;
@@ -912,6 +1002,52 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     }
     if ((rc = dev_alloc(h, &h->d_err, 1))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_err, 0, 4, h->stream));
+    if (h->gen_src) {       // the strings, pointers and flags are written on the device from the variant tables (pr_gen.hip)
+        const vpr_variants *v = h->gen_src;
+        GenTables G;
+        GenOut O;
+        memset(&G, 0, sizeof(G));
+        const int64_t ctg_total = v->ctg_off[v->n_ctg];
+        if (ctg_total > h->ctg_bytes) {
+            if (h->d_ctg_seq) (void)hipFree(h->d_ctg_seq);
+            h->d_ctg_seq = nullptr; h->ctg_bytes = 0;
+            void *q = nullptr;
+            if (hipMalloc(&q, size_t(ctg_total) + 256) != hipSuccess) return fail(h, VPR_ERR_NOMEM, "contig sequence (%lld bytes)", (long long)ctg_total);
+            h->d_ctg_seq = static_cast<uint8_t *>(q);
+            h->ctg_bytes = ctg_total;
+        }
+        if (ctg_total) HIPCHK(h, hipMemcpyAsync(h->d_ctg_seq, v->ctg_seq, size_t(ctg_total), hipMemcpyHostToDevice, h->stream));
+        G.ctg_seq = h->d_ctg_seq;
+        if ((rc = dev_upload(h, &G.ctg_off, v->ctg_off, size_t(v->n_ctg) + 1))) return rc;
+        if ((rc = dev_upload(h, &G.sc_ctg, v->sc_ctg, size_t(n)))) return rc;
+        if ((rc = dev_upload(h, &G.sc_beg, v->sc_beg, size_t(n)))) return rc;
+        if ((rc = dev_upload(h, &G.sc_end, v->sc_end, size_t(n)))) return rc;
+        for (int s = 0; s < 4; s++) {
+            const size_t nv = size_t(h->n_var[s]);
+            std::vector<int64_t> pl(PAR_MAX, 1);
+            par_for(nv, [&](size_t b0, size_t e0, int tid) {
+                int64_t m = 1;
+                for (size_t k = b0; k < e0; k++)
+                    m = std::max(m, std::max(v->var_ref_off[s][k] + v->var_ref_len[s][k], v->var_alt_off[s][k] + v->var_alt_len[s][k]));
+                pl[size_t(tid)] = m;
+            });
+            int64_t pool_len = 1;
+            for (int64_t m : pl) pool_len = std::max(pool_len, m);
+            G.var_pos_rel[s] = D.var_pos[s];
+            if ((rc = dev_upload(h, &G.var_type[s], v->var_type[s], nv))) return rc;
+            if ((rc = dev_upload(h, &G.ref_off[s], v->var_ref_off[s], nv))) return rc;
+            if ((rc = dev_upload(h, &G.alt_off[s], v->var_alt_off[s], nv))) return rc;
+            if ((rc = dev_upload(h, &G.ref_len[s], v->var_ref_len[s], nv))) return rc;
+            if ((rc = dev_upload(h, &G.alt_len[s], v->var_alt_len[s], nv))) return rc;
+            if ((rc = dev_upload(h, &G.pool[s], v->allele_pool[s], size_t(pool_len)))) return rc;
+            O.hap_seq[s] = const_cast<uint8_t *>(D.hap_seq[s]); O.hap_ptr[s] = const_cast<int32_t *>(D.hap_ptr[s]);
+            O.hap_flag[s] = const_cast<uint8_t *>(D.hap_flag[s]);
+        }
+        O.ref_seq = const_cast<uint8_t *>(D.ref_seq);
+        for (int q = 0; q < 2; q++) { O.ref_ptr[q] = const_cast<int32_t *>(D.ref_ptr[q]); O.ref_flag[q] = const_cast<uint8_t *>(D.ref_flag[q]); }
+        if (n > 0) hipLaunchKernelGGL(k_generate, dim3(unsigned((n + 255) / 256), 4), dim3(256), 0, h->stream, D, G, O);
+        HIPCHK(h, hipGetLastError());
+    }
     lap("inputs copied");
 
     // ---- K0: position attributes
@@ -933,13 +1069,10 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     for (int s = 0; s < 4; s++)
         if (hap_len[s] > 0)
             hipLaunchKernelGGL(k_prep_ins, blocks(hap_len[s]), dim3(256), 0, h->stream, D, s, hap_len[s]);
-    if (n > 0)
-        for (int w = 0; w < 6; w++)
-            hipLaunchKernelGGL(k_prep_suffix, dim3((n + 63) / 64), dim3(64), 0, h->stream, D, w);
+    if (n > 0) hipLaunchKernelGGL(k_prep_suffix, dim3((n + 63) / 64, 6), dim3(64), 0, h->stream, D);
     {
         void *pd = nullptr;
-        HIPCHK(h, hipHostMalloc(&pd, size_t(std::max(n, 1)) * 4 * sizeof(int2), hipHostMallocDefault));
-        h->pinned.push_back(pd);
+        { int rc_pin = pin_alloc(h, &pd, size_t(std::max(n, 1)) * 4 * sizeof(int2)); if (rc_pin) return rc_pin; }
         for (int s = 0; s < 4; s++) {
             h->hp_dspan[s] = static_cast<int2 *>(pd) + size_t(s) * size_t(n);
             if (n > 0) HIPCHK(h, hipMemcpyAsync(h->hp_dspan[s], D.dspan[s], size_t(n) * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
@@ -1078,14 +1211,10 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     if ((rc = dev_alloc(h, &h->d_cnt, n_slots))) return rc;
     {
         void *pf = nullptr, *pc = nullptr, *pl = nullptr, *pt = nullptr;
-        HIPCHK(h, hipHostMalloc(&pf, n_fail * sizeof(int32_t), hipHostMallocDefault));
-        h->pinned.push_back(pf);
-        HIPCHK(h, hipHostMalloc(&pc, n_slots * sizeof(int32_t), hipHostMallocDefault));
-        h->pinned.push_back(pc);
-        HIPCHK(h, hipHostMalloc(&pl, size_t(h->tie_list_cap) * sizeof(int4), hipHostMallocDefault));
-        h->pinned.push_back(pl);
-        HIPCHK(h, hipHostMalloc(&pt, 32 * sizeof(int32_t), hipHostMallocDefault));
-        h->pinned.push_back(pt);
+        { int rc_pin = pin_alloc(h, &pf, n_fail * sizeof(int32_t)); if (rc_pin) return rc_pin; }
+        { int rc_pin = pin_alloc(h, &pc, n_slots * sizeof(int32_t)); if (rc_pin) return rc_pin; }
+        { int rc_pin = pin_alloc(h, &pl, size_t(h->tie_list_cap) * sizeof(int4)); if (rc_pin) return rc_pin; }
+        { int rc_pin = pin_alloc(h, &pt, 32 * sizeof(int32_t)); if (rc_pin) return rc_pin; }
         h->hp_fail = static_cast<int32_t *>(pf);
         h->hp_cnt = static_cast<int32_t *>(pc);
         h->hp_tie_list = static_cast<int4 *>(pl);
@@ -1186,12 +1315,47 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
 
 int vpr_upload_variants(vpr_handle *h, const vpr_variants *v) {
     if (!h || !v) return VPR_ERR_ARG;
+    // the host sizes and checks every region (the planner needs the lengths), the device writes the arrays: what crosses
+    // the link is the variant tables, the region bounds and the contig
     vpr_owned_batch *ob = nullptr;
-    int rc = vpr_batch_from_variants(v, &ob);
-    if (rc) return fail(h, rc, "vpr_batch_from_variants failed (%d): unsorted/overlapping variants or bad coordinates", rc);
+    const auto t0_ = std::chrono::steady_clock::now();
+    int rc = vpr_batch_skeleton_from_variants(v, &ob);
+    if (getenv("VPR_TIMING")) fprintf(stderr, "[vpr] upload (host) sizing pass %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count());
+    if (rc) return fail(h, rc, "vpr_upload_variants: unsorted / overlapping variants or bad coordinates (%d)", rc);
+    h->gen_src = v;
     rc = vpr_upload(h, vpr_owned_batch_view(ob));
+    h->gen_src = nullptr;
     vpr_owned_batch_free(ob);
     return rc;
+}
+
+/* test aid: the resident Level A arrays back to the host (dst's arrays sized by the offsets of the uploaded batch) */
+int vpr_download_level_a(vpr_handle *h, vpr_batch *dst) {
+    if (!h || !dst || !h->uploaded) return VPR_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const DevBatch &D = h->dB;
+    const int n = h->n_sc;
+    std::vector<int64_t> off(size_t(n) + 1);
+    auto copy = [&](void *d, const void *s, size_t bytes) { return !bytes || !d || hipMemcpy(d, s, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
+    bool ok = true;
+    int64_t ref_len = 0;
+    ok = ok && copy(off.data(), D.ref_off, (size_t(n) + 1) * 8);
+    ref_len = off[size_t(n)];
+    ok = ok && copy(const_cast<int64_t *>(dst->ref_off), D.ref_off, (size_t(n) + 1) * 8);
+    ok = ok && copy(const_cast<uint8_t *>(dst->ref_seq), D.ref_seq, size_t(ref_len));
+    for (int q = 0; q < 2; q++) {
+        ok = ok && copy(const_cast<int32_t *>(dst->ref_ptr[q]), D.ref_ptr[q], size_t(ref_len) * 4);
+        ok = ok && copy(const_cast<uint8_t *>(dst->ref_flag[q]), D.ref_flag[q], size_t(ref_len));
+    }
+    for (int s = 0; s < 4; s++) {
+        ok = ok && copy(off.data(), D.hap_off[s], (size_t(n) + 1) * 8);
+        const int64_t hl = off[size_t(n)];
+        ok = ok && copy(const_cast<int64_t *>(dst->hap_off[s]), D.hap_off[s], (size_t(n) + 1) * 8);
+        ok = ok && copy(const_cast<uint8_t *>(dst->hap_seq[s]), D.hap_seq[s], size_t(hl));
+        ok = ok && copy(const_cast<int32_t *>(dst->hap_ptr[s]), D.hap_ptr[s], size_t(hl) * 4);
+        ok = ok && copy(const_cast<uint8_t *>(dst->hap_flag[s]), D.hap_flag[s], size_t(hl));
+    }
+    return ok ? VPR_OK : fail(h, VPR_ERR_DEVICE, "vpr_download_level_a: copy failed");
 }
 
 }  // extern "C"
@@ -1742,10 +1906,8 @@ struct Exec {
         if (c.hp_cap < nf) {
             void *pd = nullptr, *pw = nullptr;
             HIPCHK(h, hipStreamSynchronize(c.ls));           // (nothing may still read the old staging block)
-            HIPCHK(h, hipHostMalloc(&pd, nf * 2 * sizeof(AlnDesc), hipHostMallocDefault));
-            h->pinned.push_back(pd);
-            HIPCHK(h, hipHostMalloc(&pw, nf * 2 * sizeof(int32_t), hipHostMallocDefault));
-            h->pinned.push_back(pw);
+            { int rc_pin = pin_alloc(h, &pd, nf * 2 * sizeof(AlnDesc)); if (rc_pin) return rc_pin; }
+            { int rc_pin = pin_alloc(h, &pw, nf * 2 * sizeof(int32_t)); if (rc_pin) return rc_pin; }
             c.hp_descs = static_cast<AlnDesc *>(pd); c.hp_work = static_cast<int32_t *>(pw); c.hp_cap = nf * 2;
         }
         bool zero_slots = true;
@@ -1883,8 +2045,7 @@ struct Exec {
         }
         if (h->tie_jobs_cap < tie_job_cur + size_t(n)) {
             void *pj = nullptr;
-            HIPCHK(h, hipHostMalloc(&pj, size_t(n) * 4 * sizeof(TieJob), hipHostMallocDefault));
-            h->pinned.push_back(pj);    // (an outgrown block stays until the batch is released: a launch may still read it)
+            { int rc_pin = pin_alloc(h, &pj, size_t(n) * 4 * sizeof(TieJob)); if (rc_pin) return rc_pin; }    // (an outgrown block stays until the batch is released: a launch may still read it)
             h->hp_tie_jobs = static_cast<TieJob *>(pj);
             h->tie_jobs_cap = size_t(n) * 4;
             tie_job_cur = 0;
@@ -1923,8 +2084,7 @@ struct Exec {
         }
         if (h->tie_jobs_cap < tie_job_cur + size_t(n)) {
             void *pj = nullptr;
-            HIPCHK(h, hipHostMalloc(&pj, size_t(n) * 4 * sizeof(TieJob), hipHostMallocDefault));
-            h->pinned.push_back(pj);
+            { int rc_pin = pin_alloc(h, &pj, size_t(n) * 4 * sizeof(TieJob)); if (rc_pin) return rc_pin; }
             h->hp_tie_jobs = static_cast<TieJob *>(pj);
             h->tie_jobs_cap = size_t(n) * 4;
             tie_job_cur = 0;

@@ -112,7 +112,8 @@ __device__ __forceinline__ int query_center(const int32_t *__restrict__ t2r, con
 
 // suffix sums of |pointer step - 1| (an inserted base contributes 1, a crossed deletion its length):
 // which = 0..3: hap slot (hap -> ref pointers), 4..5: ref -> query hap (which - 4)
-__global__ void k_prep_suffix(DevBatch B, int which) {
+__global__ void k_prep_suffix(DevBatch B) {      // blockIdx.y: the array (a supercluster is a serial chain: the six arrays side by side)
+    const int which = blockIdx.y;
     const int sc = blockIdx.x * blockDim.x + threadIdx.x;
     if (sc >= B.n_sc) return;
     const int64_t *off = which < 4 ? B.hap_off[which] : B.ref_off;
