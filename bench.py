@@ -57,44 +57,58 @@ def make_workload(api, n_sc, seed, workload):
 
 
 def cpu_baseline(batch, target_s=15.0):
-    """Time the CPU oracle (a port of the reference's algorithm) on a bounded sample of the same workload:
-    single-threaded, and with one thread per host core the way the reference's own driver spreads superclusters
-    over threads (precision_recall_threads_wrapper, dist.cpp:1656).  Checker code used as a *reported baseline*
-    only; `value` is the all-cores rate, `cores` the threads actually used."""
+    """Time the CPU oracle (a port of the reference's algorithm, matrices held as the reference holds them) on a bounded
+    sample of the same workload, STRATIFIED by octave of the supercluster length: the cost per supercluster grows with L^2,
+    so a uniform sample of a long-tailed workload is decided by whether it happens to draw one of the few huge
+    superclusters.  Every octave [2^k, 2^(k+1)) is sampled on its own (all host threads, one slice per thread, the way the
+    reference's driver spreads superclusters over threads: precision_recall_threads_wrapper, dist.cpp:1656) and timed;
+    the whole batch's CPU time is estimated as sum over octaves of (superclusters in the octave / measured rate), and
+    `value` = alignments of the batch / that time.  Checker code used as a *reported baseline* only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from concurrent.futures import ThreadPoolExecutor
     import oracle_lib
     rng = np.random.RandomState(1234)
     n = batch.n_sc
-    # probe on random superclusters (1 thread; grown until it takes a second or reaches 2000, so that a workload of huge
-    # superclusters does not spend minutes here), then size the threaded sample for ~target_s of wall time
-    m0 = min(n, 16)
-    while True:
-        probe = np.sort(rng.choice(n, size=m0, replace=False))
-        sub = batch.subset(probe)
-        t0 = time.perf_counter()
-        oracle_lib.run(sub)
-        dt1 = time.perf_counter() - t0
-        if dt1 >= 1.0 or m0 >= min(n, 2000):
-            break
-        m0 = min(n, 2000, max(2 * m0, int(m0 * 1.5 / max(dt1, 1e-3))))
-    per = dt1 / len(probe)
+    L = np.maximum(np.diff(batch.ref_off), 1)
+    octv = np.floor(np.log2(L)).astype(np.int64)
     threads = max(1, min(os.cpu_count() or 1, 64))
-    m = int(min(n, max(len(probe), threads * target_s / max(per, 1e-9))))
-    samp = np.sort(rng.choice(n, size=m, replace=False))
-    parts = [batch.subset(c) for c in np.array_split(samp, threads) if len(c)]
+    strata = []
+    octaves = [int(k) for k in np.unique(octv)]
+    # per-supercluster single-thread cost model for sizing the samples only: 40 us + 15 ns x L^2 (BASELINE.md section 2)
+    est = lambda k: 40e-6 + 15e-9 * (1.5 * 2.0 ** k) ** 2
+    budget = target_s / max(len(octaves), 1)
+    t_all = time.perf_counter()
+    est_total = 0.0
+    n_samp = 0
+    for k in octaves:
+        idx = np.flatnonzero(octv == k)
+        m = int(min(len(idx), max(threads if len(idx) >= threads else 1, budget * threads / est(k))))
+        samp = np.sort(rng.choice(idx, size=m, replace=False))
+        parts = [batch.subset(c) for c in np.array_split(samp, min(threads, m)) if len(c)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=len(parts)) as ex:     # ctypes releases the GIL inside vpo_run
+            list(ex.map(oracle_lib.run, parts))
+        dt = time.perf_counter() - t0
+        est_total += len(idx) * dt / m
+        n_samp += m
+        strata.append({"octave": f"[{2 ** k}, {2 ** (k + 1)})", "superclusters": int(len(idx)), "sampled": m, "threads": len(parts),
+                       "seconds": round(dt, 3), "est_batch_seconds": round(len(idx) * dt / m, 3)})
+    wall = time.perf_counter() - t_all
+    # single-thread probe on the most populated octave (for the per-core rate)
+    k_top = max(octaves, key=lambda k: int((octv == k).sum()))
+    idx = np.flatnonzero(octv == k_top)
+    probe = np.sort(rng.choice(idx, size=min(len(idx), 2000), replace=False))
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=len(parts)) as ex:     # ctypes releases the GIL inside vpo_run
-        list(ex.map(oracle_lib.run, parts))
-    dt = time.perf_counter() - t0
-    cells = sum(p.dense_cells() for p in parts)
+    oracle_lib.run(batch.subset(probe))
+    dt1 = time.perf_counter() - t0
     return {
-        "value": round(4 * len(samp) / dt, 1), "unit": "supercluster-alignments/s", "cores": len(parts), "kind": "port",
-        "sample": f"{len(samp)} superclusters drawn uniformly from the bench batch ({cells:.3e} dense cells), "
-                  f"{dt:.1f} s wall on {len(parts)} threads (oracle/pr_oracle.cpp, one slice per thread)",
-        "cells_per_s": round(cells / dt, 1),
+        "value": round(4 * n / est_total, 1), "unit": "supercluster-alignments/s", "cores": threads, "kind": "port",
+        "sample": f"{n_samp} superclusters in {len(octaves)} strata by octave of length, {wall:.1f} s wall on {threads} threads "
+                  f"(oracle/pr_oracle.cpp, one slice per thread); value = batch alignments / sum over strata of (stratum size / measured rate)",
+        "est_batch_seconds_all_threads": round(est_total, 2),
+        "strata": strata,
         "single_thread_value": round(4 * len(probe) / dt1, 1),
-        "single_thread_sample": f"{len(probe)} superclusters, {dt1:.2f} s",
+        "single_thread_sample": f"{len(probe)} superclusters of the most populated octave [{2 ** k_top}, {2 ** (k_top + 1)}), {dt1:.2f} s",
     }
 
 

@@ -246,6 +246,11 @@ int vpr_download(vpr_handle *h, vpr_results *res);              /* HBM -> host (
 int vpr_results_alloc(vpr_handle *h, vpr_results *res, void **block);
 void *vpr_host_alloc(size_t bytes);
 void  vpr_host_free(void *p);
+/* Multi-GPU processes: make `device` the calling thread's HIP device before anything that allocates without a handle
+   (vpr_host_alloc, vpr_batch_from_variants' staging blocks), so that a rank does not create a context on device 0.
+   Also note for C callers: the library keeps up to eight HIP streams busy; export GPU_MAX_HW_QUEUES=8 before the
+   process initialises HIP (the Python binding and bench.py do), or pairs of them share a hardware queue. */
+int   vpr_select_device(int32_t device);
 int vpr_get_timing(const vpr_handle *h, vpr_timing *t);
 int vpr_get_launch_stats(const vpr_handle *h, vpr_launch_stat *out, int32_t cap);  /* returns #launches */
 /* TP/FP/FN counts [callset QUERY,TRUTH][TP,FP,FN] of the phasing each supercluster's distances select

@@ -188,6 +188,10 @@ def main(argv=None):
     one_gpu = bool(os.environ.get("VCFDIST_ONE_GPU"))      # plumbing check on a one-GPU box: every rank uses device 0, gloo
     if one_gpu and args.device is None:
         device = 0
+    try:      # this process's GPU, before anything allocates page-locked staging memory (it would otherwise initialise device 0)
+        api.lib().vpr_select_device(int(device))
+    except api.VprError:
+        pass
     dist = None
     if world > 1:
         import torch

@@ -82,7 +82,7 @@ def lib():
 
 EXPORTED = [
     "vpr_create", "vpr_destroy", "vpr_last_error", "vpr_version", "vpr_run", "vpr_upload",
-    "vpr_upload_variants", "vpr_download_level_a", "vpr_execute", "vpr_download", "vpr_host_alloc", "vpr_host_free", "vpr_get_timing", "vpr_get_launch_stats",
+    "vpr_upload_variants", "vpr_download_level_a", "vpr_select_device", "vpr_execute", "vpr_download", "vpr_host_alloc", "vpr_host_free", "vpr_get_timing", "vpr_get_launch_stats",
     "vpr_get_tally",
     "vpr_download_path", "vpr_phase", "vpr_var_class", "vpr_upload_var_class", "vpr_results_alloc", "vpr_pr_counts", "vpr_pr_summary",
     "vpr_store_phase", "vpr_batch_from_variants", "vpr_owned_batch_view", "vpr_owned_batch_free",

@@ -53,6 +53,10 @@ const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnD
 // Alignments with LONG_LT truth rows or more are latency chains (rows are sequential): a batch holds a handful of them and
 // the longest bounds the step, so they start at LONG_LV, four waves per alignment (k_fwd_wide<4>: 0.45 us per row against
 // 1 us for the one-wave 64-cell kernels).  Everything shorter is throughput work for the lane / 16-cell kernels.
+// A batch in which such alignments are NOT a handful (SV evaluation, the stress workload) has no long part at all
+// (vpr_handle::long_lt): every alignment first goes through the zero-distance lane kernel, which follows a shared SV-sized
+// indel along its diagonals where a window would have to be as wide as the indel, and only what that and the 16-cell round
+// reject climbs the ladder.
 const int LONG_LT = 2048;
 const int LONG_LV = 2;    // LV_C1
 
@@ -88,7 +92,7 @@ struct Chunk {
     int64_t cells = 0, in_bytes = 0;           // touched cells / input bytes of the chunk
     // windowed plans: the leading n_long long alignments get their own launch sequence (part 0)
     int32_t n_long = 0;
-    int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0};
+    int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}, part_rows[2] = {0, 0};
 };
 // a set of alignments with workspace offsets assigned, all at window level `lv` (a 16-cell plan holds its
 // long alignments, which start at LONG_LV, in front)
@@ -204,6 +208,7 @@ struct vpr_handle {
     ZlWave *d_zl_hdr = nullptr; uint32_t *d_zl_in = nullptr; uint4 *d_zl_log = nullptr;
     std::vector<int64_t> zl_wave0;                            // first wave of every chunk of plan 0
     std::vector<ZlWave> zl_hdr_host;
+    int32_t long_lt = LONG_LT;                                // rows from which an alignment belongs to the long part of plan 0
     // vpr_upload_variants: the variant tables of the batch being uploaded (the device generates the Level A arrays from
     // them, pr_gen.hip), and the contig sequence of the previous upload, which stays resident as long as the caller keeps
     // passing the same one (a whole-genome run uploads a contig once, not once per batch)
@@ -440,7 +445,7 @@ typedef void (*BandBwd)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, c
 BandFwd band_fwd_kernel(int lv) { return lv == LV_C1 ? BandFwd(k_fwd_stripe) : lv == LV_C4 ? BandFwd(k_fwd_wide<4>) : BandFwd(k_fwd_wide<16>); }
 BandBwd band_bwd_kernel(int lv) { return lv == LV_C1 ? BandBwd(k_bwd_stripe) : lv == LV_C4 ? BandBwd(k_bwd_wide<4>) : BandBwd(k_bwd_wide<16>); }
 const char *band_fwd_name(int lv) { return lv == LV_Z ? "k_zero_lane" : lv == LV_Q16 ? "k_fwd_q16" : lv == LV_C1 ? "k_fwd_stripe" : lv == LV_C4 ? "k_fwd_wide<4>" : "k_fwd_wide<16>"; }
-const char *band_bwd_name(int lv) { return lv == LV_Z ? "k_bwd_q16<zero>" : lv == LV_Q16 ? "k_bwd_q16" : lv == LV_C1 ? "k_bwd_stripe" : lv == LV_C4 ? "k_bwd_wide<4>" : "k_bwd_wide<16>"; }
+const char *band_bwd_name(int lv) { return lv <= LV_Q16 ? "k_bwd_q16" : lv == LV_C1 ? "k_bwd_stripe" : lv == LV_C4 ? "k_bwd_wide<4>" : "k_bwd_wide<16>"; }
 
 int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -591,7 +596,8 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
     P = Plan();
     P.lv = lv;
     P.arena = arena;
-    auto level_of = [&](const AlnDesc &d) { return (lv <= LV_Q16 && d.Lt >= LONG_LT) ? LONG_LV : lv; };
+    const int LLT = h->long_lt;
+    auto level_of = [&](const AlnDesc &d) { return (lv <= LV_Q16 && d.Lt >= LLT) ? LONG_LV : lv; };
     auto mat_bytes = [&](int32_t a) -> int64_t {
         const AlnDesc &d = h->descs[a];
         const int W = LV_WINDOW[level_of(d)];
@@ -613,22 +619,25 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
         par_for(n_al, [&](size_t b, size_t e, int) { for (size_t i = b; i < e; i++) lt[i] = h->descs[size_t(alns[i])].Lt; });
         std::vector<std::pair<int64_t, int32_t>> big;
         for (size_t i = 0; i < n_al; i++)
-            if (lv == LV_DENSE || lt[i] >= LONG_LT) big.emplace_back(-mat_bytes(alns[i]), alns[i]);
+            if (lv == LV_DENSE || lt[i] >= LLT) big.emplace_back(-mat_bytes(alns[i]), alns[i]);
         std::sort(big.begin(), big.end());
         order.reserve(n_al);
         for (auto &b : big) order.push_back(b.second);
         n_big = big.size();
         if (lv <= LV_Q16) {
-            std::vector<int64_t> cnt(LONG_LT + 1, 0);
-            for (size_t i = 0; i < n_al; i++) if (lt[i] < LONG_LT) cnt[LONG_LT - 1 - lt[i] + 1]++;
-            for (int k = 0; k < LONG_LT; k++) cnt[k + 1] += cnt[k];
+            int32_t top = 0;                 // counting sort by rows, longest first: as many bins as the longest short alignment has rows
+            for (size_t i = 0; i < n_al; i++) if (lt[i] < LLT) top = std::max(top, lt[i]);
+            const int NB = top + 1;
+            std::vector<int64_t> cnt(size_t(NB) + 1, 0);
+            for (size_t i = 0; i < n_al; i++) if (lt[i] < LLT) cnt[size_t(NB - 1 - lt[i] + 1)]++;
+            for (int k = 0; k < NB; k++) cnt[size_t(k) + 1] += cnt[size_t(k)];
             const size_t base = order.size();
-            order.resize(base + size_t(cnt[LONG_LT]));
+            order.resize(base + size_t(cnt[size_t(NB)]));
             for (size_t i = 0; i < n_al; i++)
-                if (lt[i] < LONG_LT) order[base + size_t(cnt[LONG_LT - 1 - lt[i]]++)] = alns[i];
+                if (lt[i] < LLT) order[base + size_t(cnt[size_t(NB - 1 - lt[i])]++)] = alns[i];
         } else if (lv != LV_DENSE) {
             for (size_t i = 0; i < n_al; i++)
-                if (lt[i] < LONG_LT) order.push_back(alns[i]);
+                if (lt[i] < LLT) order.push_back(alns[i]);
         }
     }
     lap("order");
@@ -728,7 +737,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             // a LV_Q16 plan's long alignments use the 64-cell layout and cannot share a launch with the rest
             if (lv > LV_Q16 && (ch.n_long == ch.count || ch.count < 4096)) ch.n_long = 0;     // nothing to overlap with
         }
-    struct Sums { int64_t cells = 0, in_bytes = 0, part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}; };
+    struct Sums { int64_t cells = 0, in_bytes = 0, part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}, part_rows[2] = {0, 0}; };
     std::vector<Sums> sums(size_t(PAR_MAX) * n_ch);
     par_for(n, [&](size_t b, size_t e, int tid) {
         size_t ci = 0;
@@ -753,6 +762,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
                 S.part_cells[part] += int64_t(std::min(L.band_w, d.Lq) + std::min(L.band_w, d.Lr)) * d.Lt;
                 S.part_in[part] += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
                 S.part_dense[part] += int64_t(d.Lq + d.Lr) * d.Lt;
+                S.part_rows[part] += d.Lt;
             }
             h->level[size_t(order[k])] = uint8_t(L.dl);
             P.descs[k] = d;
@@ -765,7 +775,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             Chunk &ch = P.chunks[ci];
             ch.cells += S.cells;
             ch.in_bytes += S.in_bytes;
-            for (int q = 0; q < 2; q++) { ch.part_cells[q] += S.part_cells[q]; ch.part_in[q] += S.part_in[q]; ch.part_dense[q] += S.part_dense[q]; }
+            for (int q = 0; q < 2; q++) { ch.part_cells[q] += S.part_cells[q]; ch.part_in[q] += S.part_in[q]; ch.part_dense[q] += S.part_dense[q]; ch.part_rows[q] += S.part_rows[q]; }
         }
     for (Chunk &ch : P.chunks) {
         if (lv == LV_DENSE) {
@@ -988,7 +998,6 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if ((rc = dev_alloc(h, &D.fk4_q[q], hap_len[q]))) return rc;
         if ((rc = dev_alloc(h, &D.fk4_r[q], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.tk[q], hap_len[2 + q]))) return rc;
-        if ((rc = dev_alloc(h, &D.tz[q], hap_len[2 + q] + 8))) return rc;
         if ((rc = dev_alloc(h, &D.tj[q], hap_len[2 + q] + 8))) return rc;
         if ((rc = dev_alloc(h, &D.wk_q[q], hap_len[q]))) return rc;
         if ((rc = dev_alloc(h, &D.wk_r[q], ref_len))) return rc;
@@ -1225,6 +1234,20 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     }
 
     lap("result/aux allocations");
+    // ---- does the batch have a long part?  (see LONG_LT)
+    {
+        std::vector<int64_t> nl(PAR_MAX, 0);
+        par_for(h->descs.size(), [&](size_t b0, size_t e0, int tid) {
+            int64_t c = 0;
+            for (size_t k = b0; k < e0; k++) c += h->descs[k].Lt >= LONG_LT;
+            nl[size_t(tid)] = c;
+        });
+        int64_t n_long_all = 0;
+        for (int64_t c : nl) n_long_all += c;
+        h->long_lt = (n_long_all * 100 > int64_t(h->descs.size())) ? INT32_MAX : LONG_LT;
+        if (h->debug) fprintf(stderr, "[vpr] %lld of %zu alignments have %d+ rows: %s\n", (long long)n_long_all, h->descs.size(), LONG_LT,
+                              h->long_lt == LONG_LT ? "they are the long part of plan 0" : "no long part");
+    }
     // ---- arena for flag matrices, band origins and walks
     size_t free_b = 0, total_b = 0;
     HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
@@ -1241,7 +1264,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
           for (size_t k = b0; k < e0; k++) {
             const AlnDesc &d = h->descs[k];
             int64_t flags;
-            if (bm != 0 && q16ok && d.Lt < LONG_LT) {
+            if (bm != 0 && q16ok && d.Lt < h->long_lt) {
                 const int64_t nstr = (int64_t(d.Lt) + 3) / 4;
                 flags = nstr * 128 + round_up(nstr * 8, 64);
             } else if (bm != 0) {
@@ -1441,7 +1464,7 @@ struct Exec {
         if (e != hipSuccess && launch_err == hipSuccess) launch_err = e;   // leave the flag down for ever: see idle_check
     }
     hipError_t launch_err = hipSuccess;
-    int64_t zl_wave0 = 0;                          // first wave header of the chunk whose zero-distance part is being enqueued
+    int64_t zl_wave0 = 0, zl_rows = 0;             // first wave header / truth rows of the chunk whose zero-distance part is being enqueued
 
     // the host loop found nothing to serve `idle_polls` times in a row: make sure the device is still alive.  A stream in
     // an error state (a failed launch, a fault in a kernel) never raises its flags; without this vpr_execute would hang.
@@ -1733,6 +1756,11 @@ struct Exec {
         ls.bytes_algorithmic = ls.cells + part_in;
         int rc = VPR_OK;
         if (phases & 1) {
+        if (zero) {     // the lane kernel moves bytes per truth ROW, not per window cell: position words 24 B, cell records 8 B written
+            // + 8 B read, path_ptr words 4 + 4 B, walk steps 8 B (pr_zl.hip); part_in = 6 * (Lq + Lt + Lr) summed over the part
+            ls.bytes_algorithmic = 56 * zl_rows;
+            ls.cells = 8 * zl_rows;                               // cell slots per row
+        }
         cells_touched += ls.cells;
         rc = timed(1, ls, ks, band_fwd_name(lv), [&] {
             if (zero)        // forward + backward + walk of the zero-distance alignments, one lane each (pr_zl.hip)
@@ -1763,7 +1791,7 @@ struct Exec {
         ls.bytes_algorithmic = ls.cells;
         rc = timed(2, ls, ks, band_bwd_name(lv), [&] {
             if (q16)
-                hipLaunchKernelGGL(k_bwd_q16<false>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                hipLaunchKernelGGL(k_bwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, tag, dtag, n_dev);
             else
                 hipLaunchKernelGGL(band_bwd_kernel(lv), dim3(cnt), dim3(lv >= LV_C4 ? W : 64), 0,
@@ -1781,7 +1809,7 @@ struct Exec {
         if (q16) {
             // 16-cell layout: row-sweep walk, four alignments per wave (phase A) + credit walk (phase B)
             if (!zero) rc = timed(3, ws_, ks, "k_walk_q16", [&] {
-                hipLaunchKernelGGL(k_walk_q16<false>, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                hipLaunchKernelGGL(k_walk_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, a_path, tag, dtag, n_dev);
             });
             if (rc) return rc;
@@ -2174,6 +2202,7 @@ struct Exec {
             }
             if (inplace) {
                 zl_wave0 = h->zl_wave0[ci];
+                zl_rows = ch.part_rows[1];
                 const int32_t *n_dev = h->d_cnt + 1;
                 const int ztag = LV_TAG[LV_Z];
                 HIPCHK(h, hipMemsetAsync(h->d_cnt + SLOT_IP, 0, 4, s_short));
@@ -2581,9 +2610,11 @@ int vpr_download(vpr_handle *h, vpr_results *res) {
                    at(res->swap_phase_dist, R.swap_phase_dist);
         for (int s = 0; s < 4 && all; s++)
             for (int w = 0; w < 2; w++)
-                all = all && at(res->errtype[s][w], R.v[s][w].errtype) && at(res->sync_group[s][w], R.v[s][w].sync_group) &&
+                // (a hap slot without variants has columns of length 0: whatever address the caller's views carry matches)
+                all = all && (h->n_var[s] == 0 ||
+                      (at(res->errtype[s][w], R.v[s][w].errtype) && at(res->sync_group[s][w], R.v[s][w].sync_group) &&
                       at(res->credit[s][w], R.v[s][w].credit) && at(res->ref_ed[s][w], R.v[s][w].ref_ed) &&
-                      at(res->query_ed[s][w], R.v[s][w].query_ed) && at(res->callq[s][w], R.v[s][w].callq);
+                      at(res->query_ed[s][w], R.v[s][w].query_ed) && at(res->callq[s][w], R.v[s][w].callq)));
         if (all) {
             HIPCHK(h, get(h->res_mirror, h->res_dev, h->res_bytes));
             HIPCHK(h, hipStreamSynchronize(st));
@@ -2646,9 +2677,15 @@ int vpr_results_alloc(vpr_handle *h, vpr_results *res, void **block) {
     return VPR_OK;
 }
 
+int vpr_select_device(int32_t device) {
+    return hipSetDevice(device) == hipSuccess ? VPR_OK : VPR_ERR_DEVICE;
+}
+
 void *vpr_host_alloc(size_t bytes) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    // (portable: usable by every device of the process; the allocation still initialises the calling thread's current
+    // device, which a multi-GPU process selects first with vpr_select_device)
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
 

@@ -101,7 +101,6 @@ struct DevBatch {
     int4 *fk4_q[2];
     int4 *fk4_r[2];
     int2 *tk[2];
-    uint8_t *tz[2];       // truth slot 2+s: base | fwd_allow(flag[t-1]) << 7 per position, padded by 8 bytes (k_fwd_z16)
     // truth slot 2+s: how many positions in front of t share t's reference pointer, i.e. t's offset inside an insertion
     // (0 outside; saturates at 65535).  The window origins follow it: where the query hap carries an insertion at the same
     // reference position the optimal path runs along both, not past the query's (k_prep_tj, q16_center)

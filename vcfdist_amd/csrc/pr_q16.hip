@@ -25,7 +25,6 @@
 //   which 0,1: fk4_q[which] (positions of query hap `which`)   {fk.x, fk.y, q2r[x], vs_hap[x-1]}
 //   which 2,3: fk4_r[which-2] (ref positions, query hap h)     {fk.x, fk.y, x,      vs_ref[x-1]}
 //   which 4,5: tk[which-4]    (positions of truth slot which-2) {t2r[t], base | fwd_allow(flag[t-1]) << 8 | vs[t-1] << 9}
-//              tz[which-4]    one byte per truth position: base | fwd_allow(flag[t-1]) << 7 (k_fwd_z16)
 __global__ void k_prep_q16(DevBatch B, int which, int64_t n_pos) {
     const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= n_pos) return;
@@ -47,7 +46,6 @@ __global__ void k_prep_q16(DevBatch B, int which, int64_t n_pos) {
         const int at = (!(f & PV) || (f & PE)) ? 1 : 0;
         B.tk[which - 4][g] = make_int2(B.hap_ptr[slot][g],
                                        int32_t(uint32_t(B.hap_seq[slot][g]) | (uint32_t(at) << 8) | (uint32_t(B.vs_hap[slot][gm1]) << 9)));
-        B.tz[which - 4][g] = uint8_t((B.hap_seq[slot][g] & 0x7f) | (at << 7));
     }
 }
 
@@ -375,228 +373,12 @@ __global__ void __launch_bounds__(64) k_fwd_q16(DevBatch B, const AlnDesc *__res
 }
 
 // ===========================================================================
-// K1z: the zero-distance forward sweep, ballot formulation.  With D in {0, unreachable} a row of an alignment is 16 bits
-// per plane, so the reach state of the wave's four alignments is two wave-wide ballots held in scalar registers: a
-// lane reads its diagonal predecessor and its swap source as single bits of those masks (a shift by a per-lane
-// amount), and the new row is the next ballot.  No LDS permutes, no DPP, no loads inside the row loop: the truth row
-// constants of a stripe are one dword of tz (base | fwd_allow << 7 per row).  Same window, same exit test, same flag
-// bytes and the same outputs as k_fwd_q16<true>.
-// ===========================================================================
-__global__ void __launch_bounds__(64) k_fwd_z16(DevBatch B, const AlnDesc *__restrict__ descs,
-                                                const int32_t *__restrict__ work, int n_work,
-                                                uint8_t *__restrict__ ws, int32_t *__restrict__ blo_all,
-                                                AlnOut *__restrict__ outs, const int32_t *__restrict__ n_dev) {
-    if (n_dev) n_work = min(n_work, *n_dev);
-    if (int(blockIdx.x) * 4 >= n_work) return;
-    const int lane = threadIdx.x, gl = lane & 15, gbase = lane & 48;
-    const int wi = int(blockIdx.x) * 4 + (lane >> 4);
-    const int a_ = work[min(wi, n_work - 1)];
-    const bool live = wi < n_work && a_ >= 0;      // (-1: padding of a device-built work list)
-    const int a = max(a_, 0);
-    const AlnDesc *dp = descs + a;
-    const int Lq = dp->Lq, Lr = dp->Lr, Lt = live ? dp->Lt : 0;
-    const int qs = dp->qs, ts = dp->ts;
-    const int64_t q_off = dp->q_off, r_off = dp->r_off;
-    const int Lp[2] = {Lq, Lr};
-    const uint8_t *tz = (ts == 2 ? B.tz[0] : B.tz[1]) + dp->t_off;
-    const int2 *fk2[2] = {(qs == 0 ? B.fk_q[0] : B.fk_q[1]) + q_off, (qs == 0 ? B.fk_r[0] : B.fk_r[1]) + r_off};
-    uint32_t *mat = reinterpret_cast<uint32_t *>(ws + dp->mat_off[0]);
-    const int nstr = (Lt + Q_K - 1) / Q_K;
-    const int smax = wave_max4(nstr);
-
-    auto origin = [&](int s, int &oq, int &orr) {     // as in k_fwd_q16
-        const int2 *tk = (ts == 2 ? B.tk[0] : B.tk[1]) + dp->t_off;
-        const uint16_t *tjp = (ts == 2 ? B.tj[0] : B.tj[1]) + dp->t_off;
-        const int32_t *r2q = (qs == 0 ? B.ref_ptr[0] : B.ref_ptr[1]) + r_off;
-        int2 *blo2 = reinterpret_cast<int2 *>(blo_all + dp->blo_off);
-        oq = 0; orr = 0;
-        if (s > 0 && s < nstr) {
-            const int ta = s * Q_K, tb = min(ta + Q_K - 1, Lt - 1);
-            const int ra = tk[ta].x, rb = tk[tb].x;
-            // (query_center, pr_band.hip: follow the query hap's insertion while the truth rows are inside one)
-            const int ja = tjp[ta], jb = tjp[tb];
-            const int rac = min(max(ra, 0), Lr - 1), rbc = min(max(rb, 0), Lr - 1);
-            int qa = r2q[rac], qb = r2q[rbc];
-            if (ja | jb) {      // rare
-                if (ja) qa += min(ja, max((rac + 1 < Lr ? r2q[rac + 1] - qa - 1 : 0), 0));
-                if (jb) qb += min(jb, max((rbc + 1 < Lr ? r2q[rbc + 1] - qb - 1 : 0), 0));
-            }
-            orr = max(0, min((ra + rb) / 2 - Q_W / 2, Lr - min(Q_W, Lr)));
-            oq = max(0, min((qa + qb) / 2 - Q_W / 2, Lq - min(Q_W, Lq)));
-        }
-        if (s < nstr) blo2[s] = make_int2(oq, orr);    // read by K2 / K3
-    };
-    int cbQ, cbR, nbQ, nbR;
-    origin(gl, cbQ, cbR);
-    origin(16 + gl, nbQ, nbR);
-    // truth rows of a stripe: four bytes (unaligned dword; rows past the end are masked, the array is padded)
-    auto load_tz = [&](int s) -> uint32_t {
-        uint32_t w;
-        __builtin_memcpy(&w, tz + min(s, max(nstr - 1, 0)) * Q_K, 4);
-        return w;
-    };
-    uint32_t tzc = load_tz(0), tzn = 0;
-
-    // reach state: bit (gbase + j) = column j (relative to the origin the state is aligned to) of the group's alignment
-    unsigned long long RQ = __ballot(gl == 0), RR = RQ;     // row 0: the two start cells
-    uint32_t exitf = 0;
-    int lo[2] = {0, 0}, hi[2] = {min(Lq, Q_W) - 1, min(Lr, Q_W) - 1};
-    int dlo[2] = {0, 0};                    // origins the reach state is aligned to
-    int nlo[2] = {0, 0}, nhi[2] = {0, 0};
-    int2 kc[2], kn[2];
-#pragma unroll
-    for (int p = 0; p < 2; p++) kc[p] = fk2[p][min(gl, Lp[p] - 1)];
-
-    for (int s = 0; s < smax; s++) {
-        const bool act = s < nstr;
-        const bool has_next = s + 1 < nstr;
-        if (((s + 1) & 15) == 0) { nlo[0] = grp_get(gbase, 0, nbQ, 0); nlo[1] = grp_get(gbase, 0, nbR, 0); }
-        else { nlo[0] = grp_get(gbase, (s + 1) & 15, cbQ, 0); nlo[1] = grp_get(gbase, (s + 1) & 15, cbR, 0); }
-        if (!has_next) { nlo[0] = lo[0]; nlo[1] = lo[1]; }
-        nhi[0] = min(Lq - 1, nlo[0] + Q_W - 1);
-        nhi[1] = min(Lr - 1, nlo[1] + Q_W - 1);
-#pragma unroll
-        for (int p = 0; p < 2; p++) kn[p] = fk2[p][min(nlo[p] + gl, Lp[p] - 1)];
-        tzn = load_tz(s + 1);
-        // ---- per-lane constants of this stripe
-        int s0[2];
-        uint32_t base[2], vmask[2], swok[2], multi[2], ex_in[2], ex_last[2];
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int o = 1 - p;
-            const int x = lo[p] + gl;
-            const bool valid = act & (x <= hi[p]);
-            s0[p] = (kc[p].x < 0) ? -1 : (kc[p].x & (FK_MULTI - 1));
-            swok[p] = kc[p].x >= 0;
-            multi[p] = (kc[p].x >= 0) & ((kc[p].x & FK_MULTI) != 0);
-            base[p] = valid ? (uint32_t(kc[p].y) >> 24) : 0xffu;
-            vmask[p] = valid;
-            const int z = kc[p].y & 0xffffff;                       // FK_NONE24 >= any string length
-            const bool zok = valid & (z < Lp[o]);
-            const bool ins_out = valid & (x == hi[p]) & (hi[p] < Lp[p] - 1);
-            const bool z_out = unsigned(z - lo[o]) > unsigned(hi[o] - lo[o]);
-            const bool z_out_n = unsigned(z - nlo[o]) > unsigned(nhi[o] - nlo[o]);
-            const bool x_out_n = (x < nlo[p]) | ((x + 1 < Lp[p]) & (x + 1 > nhi[p]));
-            ex_in[p] = ins_out | (zok & z_out);
-            ex_last[p] = ins_out | (has_next & ((valid & x_out_n) | (zok & z_out_n)));
-        }
-        uint32_t facc[2] = {0, 0};
-
-#pragma unroll
-        for (int r = 0; r < Q_K; r++) {
-            const int t = s * Q_K + r;
-            const uint32_t ract = t < Lt;
-            const bool last = (r == Q_K - 1) || (t == Lt - 1);
-            if (r == 0 && s == 0) {   // row 0, dist.cpp:300-305,397-405: the start cells, state unchanged
-#pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    const uint32_t ex = last ? ex_last[p] : ex_in[p];
-                    facc[p] = (vmask[p] & uint32_t(gl == 0)) ? F_MAT : 0;
-                    exitf |= ex & ract & uint32_t(gl == 0);
-                }
-                continue;
-            }
-            const uint32_t tzb = (tzc >> (8 * r)) & 0xff;
-            const uint32_t Tt = tzb & 0x7f, at = tzb >> 7;
-            const uint32_t G[2] = {uint32_t(RQ >> gbase) & 0xffffu, uint32_t(RR >> gbase) & 0xffffu};
-            uint32_t dz[2], sz[2], match[2], on[2], need_multi = 0;
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                const int o = 1 - p;
-                // (the state is aligned to dlo: equal to lo except in the first row of a stripe)
-                const uint32_t dgbit = (G[p] >> min(unsigned(gl + lo[p] - dlo[p] - 1), 31u)) & 1u;
-                const uint32_t swbit = (G[o] >> min(unsigned(s0[p] - dlo[o]), 31u)) & 1u;
-                match[p] = base[p] == Tt;
-                on[p] = match[p] & at & swok[p];
-                dz[p] = match[p] & dgbit;
-                sz[p] = on[p] & swbit;
-                need_multi |= on[p] & multi[p];
-            }
-            uint32_t swbits[2] = {0, 0};
-            if (__builtin_expect(__any(need_multi), 0)) {
-                // rare: several allowed swap sources; the highest reachable index wins, ties are remembered
-#pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    const int o = 1 - p;
-                    const bool need = on[p] & multi[p];
-                    int4 cc = make_int4(-1, -1, -1, -1);
-                    if (need) {
-                        const int4 *cand = p == 0 ? (qs == 0 ? B.cand_q[0] : B.cand_q[1]) + q_off
-                                                  : (qs == 0 ? B.cand_r[0] : B.cand_r[1]) + r_off;
-                        cc = cand[lo[p] + gl];
-                    }
-                    const int srcs[3] = {cc.y, cc.z, cc.w};
-                    int sw = sz[p] ? 0 : D_INF, choice = 0;
-                    bool tie = false;
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        const uint32_t bit = (G[o] >> min(unsigned(srcs[k] - dlo[o]), 31u)) & 1u;
-                        const int val = (need && srcs[k] >= 0 && bit) ? 0 : D_INF;
-                        if (need && srcs[k] >= 0 && val <= sw) { tie = (val == sw); sw = val; choice = k + 1; }
-                    }
-                    if (__builtin_expect(__any(need && cc.w >= 0), 0)) {      // sources five to eight (one at a time: no
-                        const int32_t *c2 = reinterpret_cast<const int32_t *>(                  // registers for this path)
-                            (p == 0 ? (qs == 0 ? B.cand2_q[0] : B.cand2_q[1]) + q_off : (qs == 0 ? B.cand2_r[0] : B.cand2_r[1]) + r_off) + (lo[p] + gl));
-#pragma unroll 1
-                        for (int k = 0; k < 4; k++) {
-                            const int src = (need && cc.w >= 0) ? c2[k] : -1;
-                            const uint32_t bit = (G[o] >> min(unsigned(src - dlo[o]), 31u)) & 1u;
-                            const int val = (src >= 0 && bit) ? 0 : D_INF;
-                            if (src >= 0 && val <= sw) { tie = (val == sw); sw = val; choice = k + 4; }
-                        }
-                    }
-                    sz[p] = (sw == 0);
-                    swbits[p] = f_choice_bits(choice) | (tie ? F_TIE : 0);
-                }
-            }
-            uint32_t nb[2];
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                const uint32_t reach = (dz[p] | sz[p]) & vmask[p];
-                const uint32_t f = (dz[p] ? F_MAT : 0) | (sz[p] ? (F_SWP | swbits[p]) : 0);
-                facc[p] |= (ract & reach) ? (f << (8 * r)) : 0;
-                const uint32_t ex = last ? ex_last[p] : ex_in[p];
-                exitf |= ex & ract & reach;
-                nb[p] = ract ? reach : ((G[p] >> gl) & 1u);
-            }
-            RQ = __ballot(nb[0] != 0);
-            RR = __ballot(nb[1] != 0);
-            if (r == 0) { dlo[0] = act ? lo[0] : dlo[0]; dlo[1] = act ? lo[1] : dlo[1]; }
-        }
-        if (act) {
-            mat[s * 32 + gl] = facc[0];
-            mat[s * 32 + 16 + gl] = facc[1];
-        }
-        if (has_next) {
-            lo[0] = nlo[0]; lo[1] = nlo[1]; hi[0] = nhi[0]; hi[1] = nhi[1];
-            kc[0] = kn[0]; kc[1] = kn[1];
-        }
-        tzc = tzn;
-        if (((s + 1) & 15) == 0) {
-            cbQ = nbQ; cbR = nbR;
-            origin(s + 1 + 16 + gl, nbQ, nbR);
-        }
-    }
-    const uint32_t gq = uint32_t(RQ >> gbase) & 0xffffu, gr = uint32_t(RR >> gbase) & 0xffffu;
-    const int dq = ((gq >> min(unsigned(Lq - 1 - dlo[0]), 31u)) & 1u) ? 0 : D_INF;
-    const int dr = ((gr >> min(unsigned(Lr - 1 - dlo[1]), 31u)) & 1u) ? 0 : D_INF;
-    const uint32_t eg = uint32_t(__ballot(exitf != 0) >> gbase) & 0xffffu;
-    if (live && gl == 15) {
-        outs[a].dist_q = dq;
-        outs[a].dist_r = dr;
-        outs[a].exit_min = eg ? 0 : D_INF;
-    }
-}
-
-// ===========================================================================
 // K2q: backward max-TP sweep over the 16-cell layout, four alignments per wave (calc_prec_recall_path,
 // dist.cpp:486-823).  Lanes are mirrored inside the row (lane gl owns column 15 - gl) so "x+1" is lane gl-1
 // and the suffix composition of the max-plus maps is a prefix scan in lane order.  The forward flags of a
 // stripe are one dword per lane and plane, replaced in place by the path_ptr bytes.
 // ===========================================================================
-// ZERO: the flags come from the zero-distance forward sweep (MAT / SWP only), so there is no in-row INS chain and
-// the max-plus scan is skipped.  tag: the level tag the accept test stored in band_ok (see k_fwd_band_finish).
-template <bool ZERO>
+// tag: the level tag the accept test stored in band_ok (see k_fwd_band_finish).
 __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__restrict__ descs,
                                                 const int32_t *__restrict__ work, int n_work,
                                                 uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
@@ -696,19 +478,11 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
             int best[2], lk[2], f0[2];
             uint32_t bm[2];
             MP g[2];
-            // ZERO: score and forward flags of row t+1 cross lanes as one dword (score << 8 | flags, score -1 =
-            // not on a path to the end); there are no DEL edges at distance 0
-            const int pkv[2] = {((sc1[0] < 0 ? -1 : sc1[0]) << 8) | f1[0], ((sc1[1] < 0 ? -1 : sc1[1]) << 8) | f1[1]};
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 const int o = 1 - p;
                 int up_s, up_f, dn_s, dn_f;
-                if (ZERO) {
-                    const int u = first ? grp_get(gbase, gl + sh[p] - 1, pkv[p], -256) : row_shr1(pkv[p], -256);
-                    up_s = (u < 0) ? S_NEG : (u >> 8);
-                    up_f = u & 0xff;
-                    dn_s = S_NEG; dn_f = 0;
-                } else if (first) {
+                if (first) {
                     up_s = grp_get(gbase, gl + sh[p] - 1, sc1[p], S_NEG);
                     up_f = grp_get(gbase, gl + sh[p] - 1, f1[p], 0);
                     dn_s = grp_get(gbase, gl + sh[p], sc1[p], S_NEG);
@@ -721,7 +495,7 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
                 }
                 int b = S_NEG;
                 uint32_t m = 0;
-                const uint32_t dgm = ZERO ? (uint32_t(up_f) & F_MAT) : f_diag(up_f);      // (no substitutions at distance 0)
+                const uint32_t dgm = f_diag(up_f);
                 if (dgm) { b = up_s + tp_right[p]; m = dgm; }
                 if (dn_f & F_DEL) {
                     if (dn_s > b) { b = dn_s; m = F_DEL; } else if (dn_s == b) m |= F_DEL;
@@ -729,15 +503,8 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
                 // swap successor z = (other plane, zl, t+1): its lane in the alignment of row t+1
                 const int olo = (first && s != nstr - 1) ? plo[o] : lo[o];
                 const int zsrc = (zl[p] == int(FK_NONE24)) ? -1 : 15 - (zl[p] - olo);
-                int zf, zs;
-                if (ZERO) {
-                    const int zz = grp_get(gbase, zsrc, pkv[o], -256);
-                    zf = zz & 0xff;
-                    zs = (zz < 0) ? S_NEG : (zz >> 8);
-                } else {
-                    zf = grp_get(gbase, zsrc, f1[o], 0);
-                    zs = grp_get(gbase, zsrc, sc1[o], S_NEG);
-                }
+                const int zf = grp_get(gbase, zsrc, f1[o], 0);
+                const int zs = grp_get(gbase, zsrc, sc1[o], S_NEG);
                 if ((uint32_t(zf) & F_SWP_KEY_MASK) == zkey[p]) {
                     const int v = zs + ((bkc[p] >> 27) & 1);
                     if (v >= 0 && (zf & F_TIE)) tie_used++;
@@ -749,12 +516,12 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
                 bm[p] = m;
                 f0[p] = int((fw[p] >> (8 * r)) & 0xff);           // forward flags of (x, t)
                 const int f0r = int((fwr[p] >> (8 * r)) & 0xff);  // forward flags of (x+1, t)
-                lk[p] = (!ZERO && (f0r & F_INS)) ? tp_right[p] : -1;
+                lk[p] = (f0r & F_INS) ? tp_right[p] : -1;
                 g[p].A = b; g[p].B = lk[p];
             }
             MP hq = g[0], hr = g[1];
-            if (!ZERO) row_prefix_mp2(hq, hr);
-            const int inc[2] = {ZERO ? S_NEG : row_shr1(hq.A, S_NEG), ZERO ? S_NEG : row_shr1(hr.A, S_NEG)};
+            row_prefix_mp2(hq, hr);
+            const int inc[2] = {row_shr1(hq.A, S_NEG), row_shr1(hr.A, S_NEG)};
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 int v = best[p];
@@ -799,7 +566,6 @@ __global__ void __launch_bounds__(64) k_bwd_q16(DevBatch B, const AlnDesc *__res
 // it - a ballot over the row, a count-trailing-ones, the lanes of the run store their path entries side by
 // side, and one cross-lane read of the run's last cell decides the move into row t+1.
 // ===========================================================================
-template <bool ZERO>
 __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__restrict__ descs,
                                                  const int32_t *__restrict__ work, int n_work,
                                                  const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
@@ -835,23 +601,17 @@ __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__re
     int cbQ, cbR, nbQ, nbR;
     load_chunk(0, cbQ, cbR);
     load_chunk(16, nbQ, nbR);
-    // ZERO (the walk behind the zero-distance sweeps: path_ptr bytes hold MAT / SWP only, so a row is its entry cell
-    // and nothing else): pointer and flags of a row / column travel as one dword (pointer in the low 24 bits, PTR_* flags
-    // in bits 24-27, the ins4 bits in 28-31) and a row costs three cross-lane reads instead of eight and a ballot
-    auto pack = [](int2 v) -> int2 { return ZERO ? make_int2((v.x & 0xffffff) | ((v.y & 15) << 24) | (((v.y >> 8) & 15) << 28), 0) : v; };
-    auto unpack_x = [](int v) -> int { return (v << 8) >> 8; };
-    auto unpack_y = [](int v) -> int { return ((v >> 24) & 15) | (((v >> 28) & 15) << 8); };
     int2 wtc = make_int2(0, 0), wtn = make_int2(0, 0);   // truth-row constants of rows (t & ~15) + gl / the next 16
-    if (gl < Lt) wtc = pack(wt[gl]);
-    if (16 + gl < Lt) wtn = pack(wt[16 + gl]);
+    if (gl < Lt) wtc = wt[gl];
+    if (16 + gl < Lt) wtn = wt[16 + gl];
     // per-stripe data of this lane's column (prefetched one stripe ahead): path_ptr dwords and column constants
     int lo[2] = {0, 0};
     uint32_t pp[2] = {0, 0}, ppn[2] = {0, 0};
     int2 cq = make_int2(0, 0), cr = make_int2(0, 0), cqn, crn;
     if (nstr > 0) {
         pp[0] = mat[gl]; pp[1] = mat[16 + gl];
-        if (gl < Lq) cq = pack(wq[gl]);
-        if (gl < Lr) cr = pack(wr[gl]);
+        if (gl < Lq) cq = wq[gl];
+        if (gl < Lr) cr = wr[gl];
     }
 
     int hi = outs[a].beg_plane, e = 0, n = 0, mv_in = 0;   // plane / column of the entry cell of the current row
@@ -866,14 +626,14 @@ __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__re
         ppn[0] = 0; ppn[1] = 0; cqn = make_int2(0, 0); crn = make_int2(0, 0);
         if (s + 1 < nstr) {
             ppn[0] = mat[(s + 1) * 32 + gl]; ppn[1] = mat[(s + 1) * 32 + 16 + gl];
-            if (nlo[0] + gl < Lq) cqn = pack(wq[nlo[0] + gl]);
-            if (nlo[1] + gl < Lr) crn = pack(wr[nlo[1] + gl]);
+            if (nlo[0] + gl < Lq) cqn = wq[nlo[0] + gl];
+            if (nlo[1] + gl < Lr) crn = wr[nlo[1] + gl];
         }
         if ((s & 3) == 0 && s > 0) {
             wtc = wtn;
             wtn = make_int2(0, 0);
             const int tt = s * Q_K + 16 + gl;
-            if (tt < Lt) wtn = pack(wt[tt]);
+            if (tt < Lt) wtn = wt[tt];
         }
         const int trow = (gbase | ((s & 3) * Q_K)) << 2;
 
@@ -887,12 +647,7 @@ __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__re
             const int el = e - lo_h;
             if (ract && (el < 0 || el > 15 || e >= Lh)) { status |= VPR_ST_ERR_NO_PTR; ok = false; ract = false; }
             const int colx = hi ? cr.x : cq.x;          // r2q / q2r of this lane's column in the walk's plane
-            if (ZERO) {
-                const int tp_ = __builtin_amdgcn_ds_bpermute(trow + 4 * r, wtc.x);
-                const int cp_ = grp_get(gbase, el, colx, 0);
-                trv = unpack_x(tp_); twy = unpack_y(tp_);
-                ex = unpack_x(cp_); ey = unpack_y(cp_);
-            } else {
+            {
                 trv = __builtin_amdgcn_ds_bpermute(trow + 4 * r, wtc.x);
                 twy = __builtin_amdgcn_ds_bpermute(trow + 4 * r, wtc.y);
                 const int coly = hi ? cr.y : cq.y;          // flags | ins4 << 8 (REF plane: no flags)
@@ -910,28 +665,28 @@ __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__re
             // the run of INS-only cells that starts at the entry cell
             const int pc = int(((hi ? pp[1] : pp[0]) >> (8 * r)) & 0xff);
             int k = 0;
-            if (!ZERO) {
+            {
                 const bool ins_only = (pc & F_INS) && !(pc & (F_MAT | F_SUB)) && !(hi == 1 && (pc & F_SWP));
                 const unsigned long long bal = __ballot(ins_only);
                 const uint32_t m16 = (uint32_t(bal >> gbase) & 0xffffu) >> (el & 15);
                 k = __builtin_ctz(~m16);                         // bits 16.. of ~m16 are ones: k <= 16
             }
             const int c = e + k;                                 // last cell visited in this row
-            if (!ZERO && ract && (c - lo_h > 15 || c >= Lh)) { status |= VPR_ST_ERR_NO_PTR; ok = false; ract = false; }
+            if (ract && (c - lo_h > 15 || c >= Lh)) { status |= VPR_ST_ERR_NO_PTR; ok = false; ract = false; }
             if (ract && n + k + 1 > path_cap) { status |= VPR_ST_ERR_LIMIT; ok = false; ract = false; }
             if (ract && gl >= el && gl <= el + k) {
                 const int x = lo_h + gl;
                 PathEnt pe;
                 pe.a = uint32_t(x) | (uint32_t(hi) << 31);
                 pe.b = uint32_t(t) | ((gl == el) ? ((sync_in << 31) | (edit_in << 30)) : (1u << 30));
-                pe.qref = hi ? x : (ZERO ? ex : colx);
+                pe.qref = hi ? x : colx;
                 pe.tref = trv;
                 path[n + (gl - el)] = pe;
             }
             // move out of the row from cell c, by priority
             const int cl = c - lo_h;
             const int p = grp_get(gbase, cl, pc, 0) & 31;
-            const int cxv = ZERO ? ex : grp_get(gbase, cl, colx, 0);
+            const int cxv = grp_get(gbase, cl, colx, 0);
             if (ract) {
                 n += k + 1;
                 if (t == Lt - 1) {                               // the walk ends at the end cell of its plane
