@@ -475,7 +475,7 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only: the other ranks would wait for it)
-            out["cpu_baseline"] = cpu_baseline(batch)
+            out["cpu_baseline"] = cpu_baseline(batch, target_s=8.0)
             out["cpu_baseline"]["host"] = f"{os.cpu_count()} logical cores visible"
             try:    # how the port compares with the reference binary: its time on the reference's own demo workloads over the
                 # times BASELINE.md publishes for them (tools/calibrate_cpu.py, measured in the build container)

@@ -131,7 +131,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int zl_u4;
 typedef __attribute__((ext_vector_type(2))) unsigned int zl_u2;
 #define ZL_OOB 0xfffffff0u
 
-__global__ void __launch_bounds__(64) k_zero_lane(const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list, int n_list,
+__global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list, int n_list,
                                                   const ZlWave *__restrict__ hdr, const uint32_t *__restrict__ zin,
                                                   uint4 *__restrict__ zlog, AlnOut *__restrict__ outs, PathEnt *__restrict__ paths,
                                                   int keep_paths) {
