@@ -53,10 +53,9 @@ const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnD
 // Alignments with LONG_LT truth rows or more are latency chains (rows are sequential): a batch holds a handful of them and
 // the longest bounds the step, so they start at LONG_LV, four waves per alignment (k_fwd_wide<4>: 0.45 us per row against
 // 1 us for the one-wave 64-cell kernels).  Everything shorter is throughput work for the lane / 16-cell kernels.
-// A batch in which such alignments are NOT a handful (SV evaluation, the stress workload) has no long part at all
-// (vpr_handle::long_lt): every alignment first goes through the zero-distance lane kernel, which follows a shared SV-sized
-// indel along its diagonals where a window would have to be as wide as the indel, and only what that and the 16-cell round
-// reject climbs the ladder.
+// (Sending long alignments through the lane kernel and the 16-cell round first was measured on the SV and stress
+// workloads: no gain on the first -- what reaches the dense level there has s > 0 -- and 8x slower on the second, whose
+// rejects then climb the ladder in dozens of workspace-sized rounds.)
 const int LONG_LT = 2048;
 const int LONG_LV = 2;    // LV_C1
 
@@ -1234,20 +1233,6 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     }
 
     lap("result/aux allocations");
-    // ---- does the batch have a long part?  (see LONG_LT)
-    {
-        std::vector<int64_t> nl(PAR_MAX, 0);
-        par_for(h->descs.size(), [&](size_t b0, size_t e0, int tid) {
-            int64_t c = 0;
-            for (size_t k = b0; k < e0; k++) c += h->descs[k].Lt >= LONG_LT;
-            nl[size_t(tid)] = c;
-        });
-        int64_t n_long_all = 0;
-        for (int64_t c : nl) n_long_all += c;
-        h->long_lt = (n_long_all * 100 > int64_t(h->descs.size())) ? INT32_MAX : LONG_LT;
-        if (h->debug) fprintf(stderr, "[vpr] %lld of %zu alignments have %d+ rows: %s\n", (long long)n_long_all, h->descs.size(), LONG_LT,
-                              h->long_lt == LONG_LT ? "they are the long part of plan 0" : "no long part");
-    }
     // ---- arena for flag matrices, band origins and walks
     size_t free_b = 0, total_b = 0;
     HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
