@@ -136,11 +136,13 @@ def main():
                     help="weak: --n-sc superclusters per GPU (own seed, own contigs); strong: --n-sc-total superclusters of one "
                          "synthetic genome dealt over the ranks by estimated cells, phasing all-gathered every step")
     ap.add_argument("--n-sc-total", type=int, default=3000000)
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=None,
                     help="batches resident in HBM whose steps may overlap (each behind its own library handle and host thread): "
-                         "1 = strictly one step after the other")
-    ap.add_argument("--one-pass-batches", type=int, default=9,
-                    help="batches of the one-pass leg (upload from the variant tables + execute + download each; 0 = skip)")
+                         "1 = strictly one step after the other.  Default: 3 for wgs_synth, 1 for the workloads of long alignments "
+                         "(their replay scratches and ladder workspaces each want a large share of the free memory)")
+    ap.add_argument("--one-pass-batches", type=int, default=None,
+                    help="batches of the one-pass leg (upload from the variant tables + execute + download each; 0 = skip; "
+                         "default 9 for wgs_synth, 0 for the other workloads)")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launch path only (no GPU work): the ranks rendezvous over gloo, all-reduce their rank numbers and rank 0 "
                          "prints {n_gpus, rank_sum}; tests/test_distributed.py runs `bench.py --gpus 2 --plumbing-check` on CPU")
@@ -191,6 +193,10 @@ def main():
     strong = args.scaling == "strong"
     dev = torch.device("cuda", local_rank)
     gloo = dist is not None and dist.get_backend() == "gloo"
+    if args.in_flight is None:
+        args.in_flight = 3 if args.workload == "wgs_synth" else 1
+    if args.one_pass_batches is None:
+        args.one_pass_batches = 9 if args.workload == "wgs_synth" else 0
     n_fl = max(1, min(args.in_flight, args.steps))
 
     class Slot:
@@ -239,6 +245,7 @@ def main():
     lock = threading.Lock()
     turn = threading.Condition()
     next_coll = [0]                     # the collectives of step i are issued behind those of step i - 1 on every rank
+    failed = []                         # exceptions of the step threads: the others stop waiting for their turn
 
     def step(i, S):
         ta = time.perf_counter()
@@ -247,8 +254,10 @@ def main():
         S.host_res = res = S.pr.download(S.host_res)   # final results to (reused) host buffers
         tc = time.perf_counter()
         with turn:
-            while next_coll[0] != i:
-                turn.wait()
+            while next_coll[0] != i and not failed:
+                turn.wait(timeout=1.0)
+        if failed:
+            raise RuntimeError("another step failed")
         pb = None
         if strong:      # a contig's superclusters sit on all ranks: all-gather (sc_phase, orig, swap), phase redundantly
             sc_phase, _, _ = shard.allgather_phase(res, S.my_idx, S.whole.n_sc, device=None if gloo else dev)
@@ -274,7 +283,7 @@ def main():
     stats_acc = {}
     last = {}
 
-    def account(S):
+    def account(S, stats_acc=stats_acc, kern_ms=kern_ms):
         tm = S.pr.timing()
         kern_ms.append(tm.ms_total)
         # a kernel runs in several roles per step (round 0 over the whole part, retry and tie rounds over a few
@@ -298,22 +307,31 @@ def main():
         host thread (vpr_execute blocks its caller), so a batch's latency tail -- its few longest alignments are chains of
         sequential rows -- overlaps the bulk of the next batch; every step is still one complete pass over one batch"""
         def worker(j):
-            if dist is not None and not gloo:
-                torch.cuda.set_device(local_rank)
-            for i in range(first + j, first + n, n_fl):
-                r = step(i, slots[j])
-                if timed:
-                    with lock:
-                        account(slots[j])
-                        last[i] = (r, slots[j])
+            try:
+                if dist is not None and not gloo:
+                    torch.cuda.set_device(local_rank)
+                for i in range(first + j, first + n, n_fl):
+                    r = step(i, slots[j])
+                    if timed:
+                        with lock:
+                            account(slots[j])
+                            last[i] = (r, slots[j])
+            except BaseException as e:      # (a failed step must not leave the other threads waiting for its turn)
+                with turn:
+                    failed.append(e)
+                    turn.notify_all()
         if n_fl == 1:
             worker(0)
-            return
-        ths = [threading.Thread(target=worker, args=(j,)) for j in range(n_fl)]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
+        else:
+            ths = [threading.Thread(target=worker, args=(j,)) for j in range(n_fl)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+        if failed:      # (no interpreter teardown: after a device error the runtime's own cleanup can block for ever)
+            sys.stderr.write(f"bench step failed: {failed[0]!r}\n")
+            sys.stderr.flush()
+            os._exit(1)
 
     run_steps(0, max(args.warmup, 0), False)
     parts[:] = [0.0, 0.0, 0.0]
@@ -324,6 +342,14 @@ def main():
     elapsed = time.perf_counter() - t0
     (res, t), S_last = last[args.warmup + args.steps - 1]
     batch, pr = S_last.batch, S_last.pr
+    # two more steps of one batch ALONE (not timed, not in `value`): a kernel's launch duration without the neighbours that
+    # stretch it while batches are in flight -- the figure a rocprofv3 trace of `--in-flight 1` shows
+    alone_acc, alone_ms = {}, []
+    if n_fl > 1:
+        for k in range(2):
+            step(args.warmup + args.steps + k, S_last)
+            account(S_last, alone_acc, alone_ms)
+        sync()
     if rank == 0:       # the device tally must equal the one recomputed from the downloaded results
         assert np.array_equal(shard.tally_from_results(res, batch.var_off), pr.tally()), "device tally != host tally"
         # after the timed region: per-contig phasing (host Viterbi) and the PRECISION-RECALL SUMMARY of this rank
@@ -364,18 +390,29 @@ def main():
 
         def op_run(n):
             def worker(j):
-                for i in range(j, n, n_fl):
-                    op_step(slots[j])
+                try:
+                    for i in range(j, n, n_fl):
+                        op_step(slots[j])
+                except BaseException as e:
+                    failed.append(e)
             ths = [threading.Thread(target=worker, args=(j,)) for j in range(n_fl)]
             for th in ths:
                 th.start()
             for th in ths:
                 th.join()
         op_run(n_fl)                        # warm-up: one batch per slot
+        if failed:
+            sys.stderr.write(f"one-pass leg failed: {failed[0]!r}\n")
+            sys.stderr.flush()
+            os._exit(1)
         op_parts[:] = [0.0, 0.0, 0.0]
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         op_run(nb)
+        if failed:
+            sys.stderr.write(f"one-pass leg failed: {failed[0]!r}\n")
+            sys.stderr.flush()
+            os._exit(1)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t1
         one_pass = {"value": round(4 * args.n_sc * nb / dt, 1), "unit": "supercluster-alignments/s", "batches": nb, "in_flight": n_fl,
@@ -432,11 +469,19 @@ def main():
             "dense_equivalent": {"bytes_per_launch": int(dense_bytes), "cells_per_launch": int(dense / nl),
                                  "GB/s": round(dense_gbs, 2), "frac": round(dense_gbs / HBM_PEAK_GBS, 5)},
             "counters_source": prof_src,
+            "alone": None,
             "note": "frac = HBM traffic of the dominant sweep kernel (PMC counters) / its launch duration (HIP events, this run) / "
                     "8 TB/s; the kernel is an integer scan that is issue- and latency-bound, not HBM-bound: see valu_issue_frac "
                     "and DESIGN.md section 6" if traffic else
                     "no committed counters for this workload / size: frac falls back to the bytes of the swept cells",
         }
+        if (kind, kname) in alone_acc and alone_acc[(kind, kname)][0] > 0:
+            a_ = alone_acc[(kind, kname)]
+            a_s = a_[1] / a_[0] * 1e-3
+            a_bytes = (traffic if traffic else a_[2] / a_[0])
+            roof["alone"] = {"avg_launch_ms": round(a_[1] / a_[0], 4), "achieved": round(a_bytes / a_s / 1e9, 2),
+                             "frac": round(a_bytes / a_s / 1e9 / HBM_PEAK_GBS, 5), "step_ms": round(float(np.mean(alone_ms)), 3),
+                             "note": "the same kernel in two extra steps of one batch with nothing else in flight (kernel time of the step: step_ms)"}
         per_kernel = {k[1]: {"launches": v[0], "ms": round(v[1], 3), "other_launches": v[5], "other_ms": round(v[6], 3)}
                       for k, v in sorted(stats_acc.items())}
         out = {

@@ -1463,7 +1463,7 @@ struct Exec {
             if (e != hipSuccess && e != hipErrorNotReady) return fail(h, VPR_ERR_DEVICE, "stream error while waiting for a round: %s", hipGetErrorString(e));
         }
         const double idle_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - since).count();
-        if (idle_s > 900.0) return fail(h, VPR_ERR_DEVICE, "no round completed for %.0f s", idle_s);
+        if (idle_s > 300.0) return fail(h, VPR_ERR_DEVICE, "no round completed for %.0f s", idle_s);
         return VPR_OK;
     }
 
@@ -1531,7 +1531,8 @@ struct Exec {
             if (N.cells >= (int64_t(1) << 32) - 2)
                 return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d: (Lq + Lr + 2 Lt) * Lt = %lld stamps exceed the tie replay's 32-bit cell index",
                             d.sc, d.aln, (long long)N.cells);
-            N.cap = tie_full ? N.cells : std::min<int64_t>(N.cells, 16 * int64_t(d.Lq + d.Lr + d.Lt) + 4096);
+            static const int64_t cap_mult = getenv("VPR_TIE_CAP_MULT") ? atoll(getenv("VPR_TIE_CAP_MULT")) : 16;
+            N.cap = tie_full ? N.cells : std::min<int64_t>(N.cells, cap_mult * int64_t(d.Lq + d.Lr + d.Lt) + 4096);
             if (!tie_full && (h->cfg.flags & VPR_CFG_TIE_SMALL_LOGS)) N.cap = 32;
             N.cap = (std::max<int64_t>(2, std::min<int64_t>(N.cap, int64_t(1) << 26)) + 1) & ~int64_t(1);   // even: 8-byte entries follow
             int bi = 0;

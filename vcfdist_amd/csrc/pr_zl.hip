@@ -35,6 +35,7 @@
 // moves: every byte is written once and read once, by a later pass, when it has long left the caches.
 #ifndef PR_ZL_HIP_
 #define PR_ZL_HIP_
+#include <type_traits>
 
 // per wave of 64 alignments: offsets (in 32-bit words) of its interleaved input block and of its log blocks
 struct ZlWave {
@@ -181,22 +182,19 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
         e0.y = ZE_ALIVE | ZE_HASMAT | (zw_bwd_allow(pw[1][0]) ? ZE_BWD : 0u);
         __builtin_amdgcn_raw_buffer_store_b64(e0, rlog, lane8, 0, 0);
     }
-    for (int t = 0; t + 1 < tmax; t++) {
-        const bool act = ok && t + 1 < rows;
-        const uint32_t tw1 = in_at(act ? post + (uint32_t(t + 1) << 8) + lane4 : ZL_OOB);
+    // One row step over the first S slots of each plane (S = 2: no lane of the wave has a third diagonal -- nearly every
+    // row; S = 4 otherwise).  Returns false when S = 2 was not enough (a SWP child found both slots of its plane taken):
+    // nothing has been committed then and the caller repeats the row with S = 4.
+    auto fwd_row = [&](auto Sc, int t, bool act, uint32_t tw1) -> bool {
+        constexpr int S = decltype(Sc)::value;
         const bool t_allow = zw_fwd_allow(tw0);
         // children's position words: MAT child x + 1 of the own plane, SWP child ptr + 1 of the other plane
-        uint32_t mw[2][4], sw[2][4];
-        int sz[2][4];
-        bool upper = false;
-#pragma unroll
-        for (int p = 0; p < 2; p++) upper = upper || (act && (qri[p][2] >= 0 || qri[p][3] >= 0));
-        const bool any_upper = __any(upper);
+        uint32_t mw[2][S], sw[2][S];
+        int sz[2][S];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                if (s >= 2 && !any_upper) { mw[p][s] = 0; sw[p][s] = 0; sz[p][s] = -1; continue; }
+            for (int s = 0; s < S; s++) {
                 const bool alive = act && qri[p][s] >= 0;
                 const int c = qri[p][s] + 1;
                 const int z = ZW_PTR(pw[p][s]) + 1;
@@ -207,37 +205,36 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
             }
         }
         const uint32_t Tb = ZW_BASE(tw1);
-        int nq[2][4];
-        uint32_t nw[2][4], ne[2][4];
+        int nq[2][S];
+        uint32_t nw[2][S], ne[2][S];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
+            for (int s = 0; s < S; s++) {
                 const bool hit = act && qri[p][s] >= 0 && ZW_BASE(mw[p][s]) == Tb;      // (a word from behind the block has base 0)
                 nq[p][s] = hit ? qri[p][s] + 1 : -1;
                 nw[p][s] = mw[p][s];
                 ne[p][s] = hit ? ZE_HASMAT : 0u;
             }
         }
-        bool bad = false;
+        bool bad = false, full = false;
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int o = 1 - p;
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                if (s >= 2 && !any_upper) continue;
+            for (int s = 0; s < S; s++) {
                 const bool hit = sz[p][s] >= 0 && ZW_BASE(sw[p][s]) == Tb;
                 if (!__any(hit)) continue;
                 const int z = sz[p][s];
                 // the cell (o, z) of row t + 1: already there (by MAT, or by another source's SWP), else the first free slot
                 int at = -1;
 #pragma unroll
-                for (int k = 3; k >= 0; k--) at = (nq[o][k] < 0) ? k : at;
+                for (int k = S - 1; k >= 0; k--) at = (nq[o][k] < 0) ? k : at;
 #pragma unroll
-                for (int k = 0; k < 4; k++) at = (nq[o][k] == z) ? k : at;
-                bad = bad || (hit && at < 0);                     // a fifth diagonal on the plane
+                for (int k = 0; k < S; k++) at = (nq[o][k] == z) ? k : at;
+                full = full || (hit && at < 0);                   // S = 4: a fifth diagonal on the plane
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < S; k++) {
                     const bool here = hit && at == k;
                     bad = bad || (here && (ne[o][k] & ZE_HASSWP));   // a second SWP source of the cell: left to the general kernels
                     nq[o][k] = here ? z : nq[o][k];
@@ -246,13 +243,14 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
                 }
             }
         }
-        ok = ok && !bad;
+        if (S < 4 && __any(full)) return false;
+        ok = ok && !bad && !full;
         // the row's log entries
         {
             zl_u2 ev;
             uint32_t wq = 0, wr_ = 0;
 #pragma unroll
-            for (int sl = 0; sl < 4; sl++) {
+            for (int sl = 0; sl < S; sl++) {
                 wq |= (nq[0][sl] < 0 ? 0u : (ZE_ALIVE | ne[0][sl] | ((nw[0][sl] & ZW_TP) ? ZE_TP : 0u) | (zw_bwd_allow(nw[0][sl]) ? ZE_BWD : 0u))) << (8 * sl);
                 wr_ |= (nq[1][sl] < 0 ? 0u : (ZE_ALIVE | ne[1][sl] | (zw_bwd_allow(nw[1][sl]) ? ZE_BWD : 0u))) << (8 * sl);
             }
@@ -262,9 +260,19 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
 #pragma unroll
         for (int p = 0; p < 2; p++) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) { qri[p][s] = act ? nq[p][s] : qri[p][s]; pw[p][s] = act ? nw[p][s] : pw[p][s]; }
+            for (int s = 0; s < S; s++) { qri[p][s] = act ? nq[p][s] : qri[p][s]; pw[p][s] = act ? nw[p][s] : pw[p][s]; }
         }
         tw0 = act ? tw1 : tw0;
+        return true;
+    };
+    for (int t = 0; t + 1 < tmax; t++) {
+        const bool act = ok && t + 1 < rows;
+        const uint32_t tw1 = in_at(act ? post + (uint32_t(t + 1) << 8) + lane4 : ZL_OOB);
+        bool upper = false;
+#pragma unroll
+        for (int p = 0; p < 2; p++) upper = upper || (act && (qri[p][2] >= 0 || qri[p][3] >= 0));
+        if (__any(upper) || !fwd_row(std::integral_constant<int, 2>{}, t, act, tw1))
+            (void)fwd_row(std::integral_constant<int, 4>{}, t, act, tw1);
     }
     // end cells (dist.cpp:390-391, 436-439: the QUERY plane is preferred)
     int endq = -1, endr = -1;
@@ -299,6 +307,61 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
         return __builtin_amdgcn_raw_buffer_load_b64(rlog, on ? (uint32_t(t) << 9) + lane8 : ZL_OOB, 0, 0);
     };
     zl_u2 cur = zl_u2{0, 0};      // entries of row t
+    auto bwd_row = [&](auto Sc, int t, bool act, zl_u2 pre) {
+        constexpr int S = decltype(Sc)::value;
+        int best[2][S];
+        uint32_t pp[2][S];      // path_ptr nibble of the row t - 1 cells: 1 MAT, 2 SWP, bits 2-3 slot of the SWP successor
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+#pragma unroll
+            for (int s = 0; s < S; s++) { best[p][s] = -1; pp[p][s] = 0; }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int o = 1 - p;
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                const bool on = act && sc[p][s] >= 0;
+                const uint32_t e = ((p ? cur.y : cur.x) >> (8 * s)) & 0xffu;
+                const int tp = (e & ZE_TP) ? 1 : 0;
+                {      // MAT predecessor: same plane, same slot
+                    const bool m = on && (e & ZE_HASMAT);
+                    const int v = sc[p][s] + tp;
+                    const bool gt = m && v > best[p][s], eq = m && v == best[p][s];
+                    best[p][s] = gt ? v : best[p][s];
+                    pp[p][s] = gt ? 1u : (eq ? (pp[p][s] | 1u) : pp[p][s]);
+                }
+                {      // SWP predecessor (bwd_allow at this cell, dist.cpp:599-602); leaving a REF cell scores 0 (dist.cpp:614)
+                    const bool m = on && (e & ZE_HASSWP) && (e & ZE_BWD);
+                    const int v = sc[p][s] + (p == 1 ? 0 : tp);
+                    const int ps = int((e >> ZE_PSLOT_SHIFT) & 3u);
+                    const uint32_t mine = 2u | (uint32_t(s) << 2);
+#pragma unroll
+                    for (int k = 0; k < S; k++) {
+                        const bool h_ = m && ps == k;
+                        const bool gt = h_ && v > best[o][k], eq = h_ && v == best[o][k];
+                        best[o][k] = gt ? v : best[o][k];
+                        pp[o][k] = gt ? mine : (eq ? ((pp[o][k] & 1u) | mine) : pp[o][k]);
+                    }
+                }
+            }
+        }
+        uint32_t ppw = 0;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                if (s < S) {
+                    ppw |= (best[p][s] >= 0 ? pp[p][s] : 0u) << (4 * (p * 4 + s));
+                    sc[p][s] = act ? best[p][s] : sc[p][s];
+                } else {
+                    sc[p][s] = act ? -1 : sc[p][s];       // (no cell in the upper slots of either row)
+                }
+            }
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(ppw, rlog, act ? logP0 + (uint32_t(t - 1) << 8) + lane4 : ZL_OOB, 0, 0);
+        if (act) cur = pre;
+    };
     for (int t = bmax - 1; t >= 1; t--) {
         const bool act = t < nrow;
         const bool first = t == nrow - 1;     // this lane's last row: the end cell has score 0 (dist.cpp:538-546)
@@ -315,55 +378,10 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
             }
         }
         const zl_u2 pre = log_row(t - 1, act);
-        int best[2][4];
-        uint32_t pp[2][4];      // path_ptr nibble of the row t - 1 cells: 1 MAT, 2 SWP, bits 2-3 slot of the SWP successor
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) { best[p][s] = -1; pp[p][s] = 0; }
-        }
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int o = 1 - p;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const bool on = act && sc[p][s] >= 0;
-                if (s >= 2 && !__any(on)) continue;
-                const uint32_t e = ((p ? cur.y : cur.x) >> (8 * s)) & 0xffu;
-                const int tp = (e & ZE_TP) ? 1 : 0;
-                {      // MAT predecessor: same plane, same slot
-                    const bool m = on && (e & ZE_HASMAT);
-                    const int v = sc[p][s] + tp;
-                    const bool gt = m && v > best[p][s], eq = m && v == best[p][s];
-                    best[p][s] = gt ? v : best[p][s];
-                    pp[p][s] = gt ? 1u : (eq ? (pp[p][s] | 1u) : pp[p][s]);
-                }
-                {      // SWP predecessor (bwd_allow at this cell, dist.cpp:599-602); leaving a REF cell scores 0 (dist.cpp:614)
-                    const bool m = on && (e & ZE_HASSWP) && (e & ZE_BWD);
-                    const int v = sc[p][s] + (p == 1 ? 0 : tp);
-                    const int ps = int((e >> ZE_PSLOT_SHIFT) & 3u);
-                    const uint32_t mine = 2u | (uint32_t(s) << 2);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const bool h_ = m && ps == k;
-                        const bool gt = h_ && v > best[o][k], eq = h_ && v == best[o][k];
-                        best[o][k] = gt ? v : best[o][k];
-                        pp[o][k] = gt ? mine : (eq ? ((pp[o][k] & 1u) | mine) : pp[o][k]);
-                    }
-                }
-            }
-        }
-        uint32_t ppw = 0;
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                ppw |= (best[p][s] >= 0 ? pp[p][s] : 0u) << (4 * (p * 4 + s));
-                sc[p][s] = act ? best[p][s] : sc[p][s];
-            }
-        }
-        __builtin_amdgcn_raw_buffer_store_b32(ppw, rlog, act ? logP0 + (uint32_t(t - 1) << 8) + lane4 : ZL_OOB, 0, 0);
-        if (act) cur = pre;
+        // upper slots in use in either row (by any lane)?
+        const bool upper = act && (((cur.x | cur.y | pre.x | pre.y) & 0xffff0000u) != 0u);
+        if (__any(upper)) bwd_row(std::integral_constant<int, 4>{}, t, act, pre);
+        else bwd_row(std::integral_constant<int, 2>{}, t, act, pre);
     }
     // (QUERY, 0, 0) on a path to the end?  dist.cpp:811-814
     const int beg_plane = sc[0][0] >= 0 ? VPR_PLANE_QUERY : VPR_PLANE_REF;
