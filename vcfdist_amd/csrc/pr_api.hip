@@ -1531,8 +1531,10 @@ struct Exec {
             if (N.cells >= (int64_t(1) << 32) - 2)
                 return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d: (Lq + Lr + 2 Lt) * Lt = %lld stamps exceed the tie replay's 32-bit cell index",
                             d.sc, d.aln, (long long)N.cells);
-            static const int64_t cap_mult = getenv("VPR_TIE_CAP_MULT") ? atoll(getenv("VPR_TIE_CAP_MULT")) : 16;
-            N.cap = tie_full ? N.cells : std::min<int64_t>(N.cells, cap_mult * int64_t(d.Lq + d.Lr + d.Lt) + 4096);
+            // (first attempt: logs of 3 x the alignment's three lengths.  With 16 x, the logs and bucket words of a 16 k-row job
+            // were 90 MB against 26 MB of stamps and cut the stress workload's 7 000 replays into 70 serial launches: 2.97 s per
+            // step, 2.04 s with 3 x, no job overflowing; 1 x overflows and sends ~900 jobs to the full-log second attempt)
+            N.cap = tie_full ? N.cells : std::min<int64_t>(N.cells, 3 * int64_t(d.Lq + d.Lr + d.Lt) + 4096);
             if (!tie_full && (h->cfg.flags & VPR_CFG_TIE_SMALL_LOGS)) N.cap = 32;
             N.cap = (std::max<int64_t>(2, std::min<int64_t>(N.cap, int64_t(1) << 26)) + 1) & ~int64_t(1);   // even: 8-byte entries follow
             int bi = 0;
