@@ -1754,7 +1754,7 @@ struct Exec {
             if (zero)        // forward + backward + walk of the zero-distance alignments, one lane each (pr_zl.hip)
                 hipLaunchKernelGGL(k_zero_lane, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->d_descs, list, cnt,
                                    h->d_zl_hdr + zl_wave0, h->d_zl_in, h->d_zl_log, h->d_outs, a_path,
-                                   ((h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0) | (getenv("ZL_EXP") ? atoi(getenv("ZL_EXP")) : 0));
+                                   (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0);
             else if (q16)
                 hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);

@@ -289,7 +289,6 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
         o.exit_min = ok ? D_INF : 0;          // k_fwd_band_finish: accepted iff s = 0 here
     }
     if (!__any(ok)) return;
-    if (keep_paths & 2) return;     // (experiment)
 
     // ---------------- backward: max-TP scores over the zero-cost moves (dist.cpp:550-681), rows Lt-1 .. 1.  The path_ptr
     // bits of a row's cells are one word: four bits per slot (MAT, SWP, slot of the SWP successor)
@@ -385,7 +384,6 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
     }
     // (QUERY, 0, 0) on a path to the end?  dist.cpp:811-814
     const int beg_plane = sc[0][0] >= 0 ? VPR_PLANE_QUERY : VPR_PLANE_REF;
-    if (keep_paths & 4) return;     // (experiment)
 
     // ---------------- walk (dist.cpp:905-982) + sync flags (dist.cpp:949-968)
     PathEnt *path = paths + dp->path_off;
