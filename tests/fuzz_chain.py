@@ -50,17 +50,21 @@ def one(seed):
         return 0, 0, 0
     v2 = A.Variants(v.ctg_off, v.ctg_seq, np.zeros(s.n, np.int32), s.beg, s.end, [s.var_off(i) for i in range(4)],
                     v.var_pos, v.var_type, v.var_qual, v.var_ref_off, v.var_ref_len, v.var_alt_off, v.var_alt_len, v.allele_pool)
-    if int(s.end.max()) >= len(ctg) or int(s.beg.min()) < 0:
-        # a variant on the first / last base of the contig: the reference has no defined result (include/vcfdist_pr.h,
-        # vpr_batch_from_variants); product and oracle must both refuse the batch
+    if int(s.beg.min()) < 0:
+        # a variant on the first base of the contig: the region starts at -1, where the reference exits (its substr throws,
+        # dist.cpp:232-238); product and oracle must both refuse the batch.  (A region that reaches behind the contig's END is
+        # cut at the last base by both and evaluated: include/vcfdist_pr.h, vpr_batch_from_variants.)
         for f, exc in ((api.batch_from_variants, api.VprError), (O.generate, ValueError)):
             try:
                 f(v2)
             except exc:
                 continue
-            raise AssertionError(f"{f.__name__} accepted a region that leaves the contig")
+            raise AssertionError(f"{f.__name__} accepted a region that starts in front of the contig")
         return sum(c.n for c in cl), 0, -1
     batch = api.batch_from_variants(v2)
+    gen = O.generate(v2)
+    for f in ("hap_seq", "hap_ptr", "hap_flag"):
+        assert all(np.array_equal(getattr(batch, f)[h], getattr(gen, f)[h]) for h in range(4)), ("marshalling", f)
     _, _, ntie, _ = T.compare(batch, A.default_config(flags=int(os.environ.get("VCFDIST_FUZZ_FLAGS", "0"))))
     return sum(c.n for c in cl), s.n, s.n_oversize
 

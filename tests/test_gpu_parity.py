@@ -13,13 +13,19 @@ from vcfdist_amd import api
 pytestmark = pytest.mark.gpu
 
 
-def compare(batch, cfg=None):
+def compare(batch, cfg=None, variants_struct=None):
     """every result array of the library against the oracle, bit for bit; returns the number of alignments in which
-    the oracle's containers kept a swap predecessor other than the highest index (the ones only the replay gets right)"""
+    the oracle's containers kept a swap predecessor other than the highest index (the ones only the replay gets right).
+    variants_struct: upload the batch's variant tables instead (generate_ptrs_strs on the device, vpr_upload_variants)."""
     ex = O.Extra(batch)
     want = O.run(batch, extra=ex)
     pr = api.PrecisionRecall(cfg) if cfg is not None else api.PrecisionRecall()
-    got = pr.run(batch)
+    if variants_struct is None:
+        got = pr.run(batch)
+    else:
+        pr.upload_variants(variants_struct, batch)
+        pr.execute()
+        got = pr.download()
     for f in ("aln_dist", "aln_end_plane", "aln_beg_plane", "aln_status", "sc_phase", "orig_phase_dist", "swap_phase_dist"):
         a, b = getattr(got, f), getattr(want, f)
         assert np.array_equal(a, b), (f, np.flatnonzero(a != b)[:8])
