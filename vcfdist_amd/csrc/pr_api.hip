@@ -18,6 +18,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -46,7 +50,7 @@ const size_t LDS_MAX = 160 * 1024;
 // window levels an alignment climbs until its exit test passes: 16 cells (four alignments per wave, only
 // for alignments shorter than LONG_LT rows), 64, 256, 1024 cells (one wave per alignment), dense
 // LV_Z: 16 cells, zero-distance variant (accepts only alignments with s = 0); LV_Q16: 16 cells, general.
-enum { LV_Z = 0, LV_Q16 = 1, LV_C1 = 2, LV_C4 = 3, LV_C16 = 4, LV_DENSE = 5 };
+// (enum LV_*: pr_device.h)
 const int LV_WINDOW[] = {16, 16, 64, 256, 1024, 0};   // window width = flag layout of the level
 const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnDesc::band_pad that marks the level
 // truth rows from which an alignment is a latency chain
@@ -74,15 +78,90 @@ using DescVec = std::vector<AlnDesc, NoInitAlloc<AlnDesc>>;
 // fn(begin, end, thread) over [0, n) on up to PAR_MAX host threads (planning a batch of a million superclusters is a few
 // passes over 4 M descriptors: memory-latency bound on one core)
 const int PAR_MAX = 32;
+// (a pool that lives as long as the library: starting 32 threads per pass costs more than most passes, and with several
+// batches in flight on several handles the thread stacks' mmap / munmap calls serialise on the address space)
+class ParPool {
+  public:
+    static ParPool &get() { static ParPool *p = new ParPool(); return *p; }      // (never destroyed: no join at exit)
+    // run task(t) for t in [0, nt) on the workers and the calling thread
+    void run(size_t nt, const std::function<void(size_t)> &task) {
+        Job job;
+        job.task = &task; job.nt = nt;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            jobs_.push_back(&job);
+        }
+        cv_.notify_all();
+        work_on(job);
+        std::unique_lock<std::mutex> g(m_);
+        job.done_cv.wait(g, [&] { return job.done == job.nt; });
+    }
+  private:
+    struct Job { const std::function<void(size_t)> *task; size_t nt = 0, next = 0, done = 0; std::condition_variable done_cv; };
+    ParPool() {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned n = std::min<unsigned>(hw, PAR_MAX) - 1;
+        for (unsigned t = 0; t < n; t++) std::thread([this] { worker(); }).detach();
+    }
+    void work_on(Job &job) {
+        for (;;) {
+            size_t t;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (job.next >= job.nt) return;
+                t = job.next++;
+                if (job.next >= job.nt) jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job));
+            }
+            (*job.task)(t);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (++job.done == job.nt) job.done_cv.notify_all();
+            }
+        }
+    }
+    void worker() {
+        for (;;) {
+            Job *job;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return !jobs_.empty(); });
+                job = jobs_.front();
+            }
+            work_on(*job);
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Job *> jobs_;
+};
 template <typename F>
 void par_for(size_t n, F fn) {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const size_t nt = std::min<size_t>(std::min<unsigned>(hw, PAR_MAX), n / 32768);
     if (nt <= 1) { fn(size_t(0), n, 0); return; }
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; t++) th.emplace_back([=, &fn] { fn(n * t / nt, n * (t + 1) / nt, int(t)); });
-    for (auto &x : th) x.join();
+    const std::function<void(size_t)> task = [&](size_t t) { fn(n * t / nt, n * (t + 1) / nt, int(t)); };
+    ParPool::get().run(nt, task);
 }
+
+// base descriptors (no workspace layout) of the uploaded batch: computed on demand from host copies of its offsets
+struct BaseDescs {
+    std::vector<int64_t> hap_off[4], ref_off;
+    BatchOffsets O;
+    size_t n = 0;
+    void set(const vpr_batch *b, const std::vector<int64_t> *var_off) {      // var_off: the handle's copies
+        const size_t m = size_t(b->n_sc) + 1;
+        for (int s = 0; s < 4; s++) {
+            hap_off[s].assign(b->hap_off[s], b->hap_off[s] + m); O.hap_off[s] = hap_off[s].data();
+            O.var_off[s] = var_off[s].data();
+        }
+        ref_off.assign(b->ref_off, b->ref_off + m); O.ref_off = ref_off.data();
+        n = size_t(b->n_sc) * 4;
+    }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void clear() { n = 0; }
+    AlnDesc operator[](size_t a) const { return base_desc(O, int64_t(a)); }
+};
 
 struct Launch { int cls; int64_t work_off; int32_t count; };   // dense: one k_fwd/k_bwd launch of a class
 struct Chunk {
@@ -97,7 +176,13 @@ struct Chunk {
 // long alignments, which start at LONG_LV, in front)
 struct Plan {
     int lv = LV_DENSE;
-    DescVec descs;                  // compact, in work-list order
+    DescVec descs;                  // compact, in work-list order (empty when `lazy`)
+    // lazy plan (round 0 of a windowed batch): the descriptors are a function of the batch offsets, the alignment and its
+    // workspace offset (pr_device.h: base_desc + window_layout); the host keeps 4 bytes per alignment, the device builds
+    // its copy from the same 4 bytes (k_build_plan), and plan_desc() below recomputes the few the host ever looks at
+    bool lazy = false;
+    std::vector<uint32_t> off128;   // workspace offset of every entry in 128-byte units (lazy plans)
+    int tag_or = 0, long_lt = 0;
     std::vector<int32_t> work;      // alignment ids
     std::vector<Chunk> chunks;
     AlnDesc *d_descs = nullptr;     // device copy of `descs` (plan 0 only, cached)
@@ -155,7 +240,9 @@ struct vpr_handle {
     std::vector<int64_t> var_off[4];
     std::vector<float> var_qual[4];
     int64_t n_var[4] = {0, 0, 0, 0};
-    DescVec descs;                       // base descriptors (no workspace offsets)
+    BaseDescs descs;                     // base descriptors (no workspace offsets)
+    std::vector<int32_t> scratch_i32[4]; // planner scratch that keeps its pages across uploads
+    std::vector<uint32_t> scratch_u32[2];
     Plan plan0;                          // first round over all alignments, cached at upload
     std::vector<uint8_t> level, level0;  // current / round-0 window level of every alignment
     int64_t last_need = 0;               // workspace bytes of the alignment make_plan could not place
@@ -228,6 +315,30 @@ struct vpr_handle {
 namespace {
 
 std::string g_create_err;
+
+// window level an alignment has in a plan of level lv (a 16-cell plan holds its long alignments at LONG_LV)
+inline int plan_level_of(int lv, int long_lt, int Lt) { return (lv <= LV_Q16 && Lt >= long_lt) ? LONG_LV : lv; }
+
+// descriptor k of a plan
+AlnDesc plan_desc(const vpr_handle *h, const Plan &P, size_t k) {
+    if (!P.lazy) return P.descs[k];
+    AlnDesc d = h->descs[size_t(P.work[k])];
+    (void)window_layout(d, plan_level_of(P.lv, P.long_lt, d.Lt), int64_t(P.off128[k]) * 128, P.tag_or);
+    return d;
+}
+
+// the device's copy of a lazy plan: descriptors in plan order (plan_descs) and by alignment (descs)
+__global__ void k_build_plan(BatchOffsets O, const int32_t *__restrict__ work, const uint32_t *__restrict__ off128, int n, int lv,
+                             int long_lt, int tag_or, AlnDesc *__restrict__ plan_descs, AlnDesc *__restrict__ descs) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int a = work[k];
+    AlnDesc d = base_desc(O, a);
+    const int dl = (lv <= LV_Q16 && d.Lt >= long_lt) ? 2 /* LONG_LV */ : lv;
+    (void)window_layout(d, dl, int64_t(off128[k]) * 128, tag_or);
+    plan_descs[k] = d;
+    descs[a] = d;
+}
 
 int fail(vpr_handle *h, int code, const char *fmt, ...) {
     char buf[512];
@@ -364,7 +475,13 @@ void free_batch(vpr_handle *h) {
     h->res_dev = nullptr; h->res_bytes = 0; h->res_mirror = nullptr;     // (a mirror block belongs to the caller: it just stops matching)
     h->events.clear();
     h->descs.clear();
-    h->plan0 = Plan();
+    {
+        std::vector<int32_t> kw; std::vector<uint32_t> ko;
+        kw.swap(h->plan0.work); ko.swap(h->plan0.off128);
+        h->plan0 = Plan();
+        kw.clear(); ko.clear();
+        h->plan0.work.swap(kw); h->plan0.off128.swap(ko);
+    }
     h->dirty.clear();
     h->d_arena = nullptr; h->d_secs = nullptr;
     for (int k = 0; k < 4; k++) h->d_cls[k] = nullptr;
@@ -591,144 +708,175 @@ __global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc 
 // Assign arena offsets (flag matrices, band origins, walk scratch) to `alns` and cut them into chunks
 // that fit the arena.  lv: window level of the plan (LV_DENSE: dense layout + kernel classes).
 // tag_or: TIE_TAG_BIT for the plan of a tie round (see pr_device.h), else 0
-int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, uint8_t *arena, int64_t arena_bytes, int tag_or = 0) {
-    P = Plan();
+int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, uint8_t *arena, int64_t arena_bytes, int tag_or = 0,
+              bool lazy = false) {
+    {   // (the work list and the offsets keep their pages: plan 0 of every upload is as large as the last one)
+        std::vector<int32_t> kw; std::vector<uint32_t> ko;
+        kw.swap(P.work); ko.swap(P.off128);
+        P = Plan();
+        kw.clear(); ko.clear();
+        P.work.swap(kw); P.off128.swap(ko);
+    }
     P.lv = lv;
     P.arena = arena;
+    P.tag_or = tag_or;
     const int LLT = h->long_lt;
-    auto level_of = [&](const AlnDesc &d) { return (lv <= LV_Q16 && d.Lt >= LLT) ? LONG_LV : lv; };
-    auto mat_bytes = [&](int32_t a) -> int64_t {
-        const AlnDesc &d = h->descs[a];
-        const int W = LV_WINDOW[level_of(d)];
-        if (W) return int64_t(round_up(std::min(W, d.Lq), 16) + round_up(std::min(W, d.Lr), 16)) * d.Lt;
-        return int64_t(round_up(d.Lq, 32) + round_up(d.Lr, 32)) * d.Lt;
-    };
+    P.long_lt = LLT;
+    P.lazy = lazy && lv != LV_DENSE;
+    auto level_of = [&](const AlnDesc &d) { return plan_level_of(lv, LLT, d.Lt); };
     // Order: the long alignments first, longest first (they are latency chains and must start early).  The
     // rest keeps its input order, except at LV_Q16 where four alignments share a wave in lockstep and are
     // therefore grouped by their number of truth rows (counting sort, longest first, stable).
     const size_t n_al = alns.size();
-    const bool dbg = h->debug && n_al >= 1000000;
+    const bool dbg = (h->debug || getenv("VPR_TIMING")) && n_al >= 1000000;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double T0 = now();
     auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[vpr]   make_plan %-24s %.3f s\n", what, now() - T0); };
-    std::vector<int32_t> order;
+    // compact per-alignment figures (the descriptors are computed on demand: h->descs): truth rows, and the workspace
+    // bytes at the alignment's level in 128-byte units (0 with `bad` set: cannot be placed)
+    std::vector<int32_t> &lt = h->scratch_i32[0], &lq = h->scratch_i32[2], &lr = h->scratch_i32[3];
+    std::vector<uint32_t> &need128 = h->scratch_u32[0];
+    lt.resize(n_al); lq.resize(n_al); lr.resize(n_al); need128.resize(n_al);
+    std::atomic<size_t> bad{n_al};          // first alignment (in input order) that cannot be placed
+    par_for(n_al, [&](size_t b, size_t e, int) {
+        for (size_t i = b; i < e; i++) {
+            AlnDesc d = h->descs[size_t(alns[i])];
+            lt[i] = d.Lt; lq[i] = d.Lq; lr[i] = d.Lr;
+            const int dl = level_of(d);
+            int64_t need;
+            bool too_long = false;
+            if (dl != LV_DENSE) {
+                need = window_layout(d, dl, 0, 0);
+            } else {
+                const int cls = class_of(std::max(d.Lq, d.Lr));
+                // (the backward kernel's int32 score rows may not fit: it then runs with int16 rows, 4 B per cell)
+                too_long = cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX ||
+                           (bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX && (!s16_ok(d) || bwd_lds_bytes(cls, d.Lq, d.Lr, true) > LDS_MAX));
+                const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)) + 128, 128);
+                need = round_up(int64_t(round_up(d.Lq, 32)) * d.Lt, 128) + round_up(int64_t(round_up(d.Lr, 32)) * d.Lt, 128) + pb + 128;
+            }
+            need128[i] = uint32_t(std::min<int64_t>(need / 128, 0xffffffffll));
+            if (too_long || need > arena_bytes) {
+                size_t cur = bad.load();
+                while (i < cur && !bad.compare_exchange_weak(cur, i)) {}
+            }
+        }
+    });
+    lap("pass 1 (rows, need)");
+    if (bad.load() < n_al) {
+        const AlnDesc d = h->descs[size_t(alns[bad.load()])];
+        bool too_long = false;
+        if (level_of(d) == LV_DENSE) {
+            const int cls = class_of(std::max(d.Lq, d.Lr));
+            too_long = cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX ||
+                       (bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX && (!s16_ok(d) || bwd_lds_bytes(cls, d.Lq, d.Lr, true) > LDS_MAX));
+        }
+        if (too_long)
+            return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d too long for the dense kernels (Lq=%d Lr=%d)", d.sc, d.aln, d.Lq, d.Lr);
+        h->last_need = int64_t(need128[bad.load()]) * 128;
+        return fail(h, VPR_ERR_NOMEM, "workspace (%lld bytes) too small for supercluster %d alignment %d (%lld bytes)",
+                    (long long)arena_bytes, d.sc, d.aln, (long long)h->last_need);
+    }
+    std::vector<int32_t> &order = P.work;   // plan order: positions in `alns` first, alignment ids in the end
+    std::vector<uint32_t> &off = P.off128;  // need, then offset inside the chunk (128-byte units)
     size_t n_big = 0;                       // long alignments, in front of the plan
     {
-        std::vector<int32_t> lt(n_al);      // (compact copy: the descriptors are 96 bytes apart)
-        par_for(n_al, [&](size_t b, size_t e, int) { for (size_t i = b; i < e; i++) lt[i] = h->descs[size_t(alns[i])].Lt; });
         std::vector<std::pair<int64_t, int32_t>> big;
         for (size_t i = 0; i < n_al; i++)
-            if (lv == LV_DENSE || lt[i] >= LLT) big.emplace_back(-mat_bytes(alns[i]), alns[i]);
+            if (lv == LV_DENSE || lt[i] >= LLT) {
+                const AlnDesc d = h->descs[size_t(alns[i])];
+                const int W = LV_WINDOW[level_of(d)];
+                const int64_t mat = W ? int64_t(round_up(std::min(W, d.Lq), 16) + round_up(std::min(W, d.Lr), 16)) * d.Lt
+                                      : int64_t(round_up(d.Lq, 32) + round_up(d.Lr, 32)) * d.Lt;
+                big.emplace_back(-mat, int32_t(i));
+            }
         std::sort(big.begin(), big.end());
         order.reserve(n_al);
         for (auto &b : big) order.push_back(b.second);
         n_big = big.size();
         if (lv <= LV_Q16) {
-            int32_t top = 0;                 // counting sort by rows, longest first: as many bins as the longest short alignment has rows
-            for (size_t i = 0; i < n_al; i++) if (lt[i] < LLT) top = std::max(top, lt[i]);
-            const int NB = top + 1;
-            std::vector<int64_t> cnt(size_t(NB) + 1, 0);
-            for (size_t i = 0; i < n_al; i++) if (lt[i] < LLT) cnt[size_t(NB - 1 - lt[i] + 1)]++;
-            for (int k = 0; k < NB; k++) cnt[size_t(k) + 1] += cnt[size_t(k)];
+            // counting sort by rows, longest first, stable: as many bins as the longest short alignment has rows; every
+            // thread counts its slice, then scatters it behind the slices in front of it
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(hw, PAR_MAX), n_al / 32768));
+            std::vector<int32_t> tops(nt, 0);
+            par_for(n_al, [&](size_t b, size_t e, int tid) {
+                int32_t top = 0;
+                for (size_t i = b; i < e; i++) if (lt[i] < LLT) top = std::max(top, lt[i]);
+                tops[size_t(tid)] = top;
+            });
+            int32_t top = 0;
+            for (int32_t t : tops) top = std::max(top, t);
+            const size_t NB = size_t(top) + 1;
+            std::vector<int64_t> cnt(NB * nt, 0);       // [bin][thread]
+            par_for(n_al, [&](size_t b, size_t e, int tid) {
+                for (size_t i = b; i < e; i++) if (lt[i] < LLT) cnt[size_t(top - lt[i]) * nt + size_t(tid)]++;
+            });
+            int64_t run = 0;
+            for (size_t k = 0; k < NB * nt; k++) { const int64_t c = cnt[k]; cnt[k] = run; run += c; }
             const size_t base = order.size();
-            order.resize(base + size_t(cnt[size_t(NB)]));
-            for (size_t i = 0; i < n_al; i++)
-                if (lt[i] < LLT) order[base + size_t(cnt[size_t(NB - 1 - lt[i])]++)] = alns[i];
+            order.resize(base + size_t(run));
+            par_for(n_al, [&](size_t b, size_t e, int tid) {
+                for (size_t i = b; i < e; i++)
+                    if (lt[i] < LLT) order[base + size_t(cnt[size_t(top - lt[i]) * nt + size_t(tid)]++)] = int32_t(i);
+            });
         } else if (lv != LV_DENSE) {
             for (size_t i = 0; i < n_al; i++)
-                if (lt[i] < LLT) order.push_back(alns[i]);
+                if (lt[i] < LLT) order.push_back(int32_t(i));
         }
     }
     lap("order");
-    // layout of one alignment at its level: flag matrices, window origins, walk scratch
-    struct Layout { int dl, band_w, pitch0, pitch1; int64_t m0, m1, bl, need; bool too_long; };
-    auto layout = [&](const AlnDesc &d) -> Layout {
-        Layout L;
-        L.dl = level_of(d);
-        L.too_long = false;
-        const int W = LV_WINDOW[L.dl];
-        if (L.dl <= LV_Q16) {
-            // stripe-transposed records of 128 B per 4 truth rows (both planes) + int2 origins per stripe
-            const int64_t nstr = (int64_t(d.Lt) + 3) / 4;
-            L.band_w = 16;
-            L.pitch0 = L.pitch1 = 16;
-            L.m0 = nstr * 128; L.m1 = 0;
-            L.bl = round_up(nstr * 8, 128);
-        } else if (W) {
-            L.band_w = W;
-            L.pitch0 = int32_t(round_up(std::min(W, d.Lq), 16));
-            L.pitch1 = int32_t(round_up(std::min(W, d.Lr), 16));
-            L.m0 = round_up(int64_t(L.pitch0) * d.Lt, 128); L.m1 = round_up(int64_t(L.pitch1) * d.Lt, 128);
-            L.bl = round_up(int64_t(2) * d.Lt * 4, 128);
-        } else {
-            L.band_w = 0;
-            L.pitch0 = int32_t(round_up(d.Lq, 32));
-            L.pitch1 = int32_t(round_up(d.Lr, 32));
-            const int cls = class_of(std::max(d.Lq, d.Lr));
-            // (the backward kernel's int32 score rows may not fit: it then runs with int16 rows, 4 B per cell)
-            L.too_long = cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX ||
-                         (bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX && (!s16_ok(d) || bwd_lds_bytes(cls, d.Lq, d.Lr, true) > LDS_MAX));
-            L.m0 = round_up(int64_t(L.pitch0) * d.Lt, 128); L.m1 = round_up(int64_t(L.pitch1) * d.Lt, 128);
-            L.bl = 0;
-        }
-        // (every piece a multiple of 128 bytes: the path block of an alignment starts on a 128-byte line, which the credit
-        // walk's refills rely on -- the path reads past path_cap inside the block's padding)
-        const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)) + 128, 128);   // 16 B per step
-        L.need = L.m0 + L.m1 + L.bl + pb + 128;
-        return L;
-    };
-    // pass 1 (parallel): workspace bytes of every alignment; pass 2 (one thread, 8 bytes per alignment): offsets and the cut
-    // into chunks that fit the workspace; pass 3 (parallel): the descriptors
+    // pass 2 (one thread, 4 bytes per alignment): offsets and the cut into chunks that fit the workspace
     const size_t n = order.size();
-    std::vector<int64_t> off(n);            // pass 1: need, pass 2: offset inside the chunk
-    std::atomic<size_t> bad{n};             // first alignment (in plan order) that cannot be placed
-    par_for(n, [&](size_t b, size_t e, int) {
-        for (size_t k = b; k < e; k++) {
-            const Layout L = layout(h->descs[size_t(order[k])]);
-            off[k] = L.need;
-            if (L.too_long || L.need > arena_bytes) {
-                size_t cur = bad.load();
-                while (k < cur && !bad.compare_exchange_weak(cur, k)) {}
-            }
-        }
-    });
-    lap("pass 1 (need)");
-    if (bad.load() < n) {
-        const AlnDesc &d = h->descs[size_t(order[bad.load()])];
-        const Layout L = layout(d);
-        if (L.too_long)
-            return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d too long for the dense kernels (Lq=%d Lr=%d)", d.sc, d.aln, d.Lq, d.Lr);
-        h->last_need = L.need;
-        return fail(h, VPR_ERR_NOMEM, "workspace (%lld bytes) too small for supercluster %d alignment %d (%lld bytes)",
-                    (long long)arena_bytes, d.sc, d.aln, (long long)L.need);
-    }
-    std::vector<int32_t> chunk_of;          // only for multi-chunk plans
+    off.resize(n);
     {
-        int64_t used = 0;
-        size_t k0 = 0;
-        for (size_t k = 0; k < n; k++) {
-            const int64_t need = off[k];
-            P.total_need += need;
-            if (k > k0 && used + need > arena_bytes) {
+        // the needs in plan order; when everything fits one chunk (the usual case) the offsets are a parallel prefix sum
+        const int64_t cap128 = arena_bytes / 128;
+        std::vector<int64_t> part(PAR_MAX + 1, 0);
+        par_for(n, [&](size_t b, size_t e, int tid) {
+            int64_t sum = 0;
+            for (size_t k = b; k < e; k++) { const uint32_t v = need128[size_t(order[k])]; off[k] = v; sum += v; }
+            part[size_t(tid) + 1] = sum;
+        });
+        for (int t = 0; t < PAR_MAX; t++) part[size_t(t) + 1] += part[size_t(t)];
+        const int64_t total = part[PAR_MAX];
+        P.total_need = total * 128;
+        if (total <= cap128) {
+            par_for(n, [&](size_t b, size_t e, int tid) {
+                int64_t used = part[size_t(tid)];
+                for (size_t k = b; k < e; k++) { const uint32_t v = off[k]; off[k] = uint32_t(used); used += v; }
+            });
+            if (n) {
                 Chunk ch;
-                ch.work_off = int64_t(k0); ch.count = int32_t(k - k0);
+                ch.work_off = 0; ch.count = int32_t(n);
                 P.chunks.push_back(std::move(ch));
-                P.arena_used = std::max(P.arena_used, used);
-                k0 = k; used = 0;
+                P.arena_used = total * 128;
             }
-            off[k] = used;
-            used += need;
-        }
-        if (n > k0) {
-            Chunk ch;
-            ch.work_off = int64_t(k0); ch.count = int32_t(n - k0);
-            P.chunks.push_back(std::move(ch));
-            P.arena_used = std::max(P.arena_used, used);
+        } else {
+            int64_t used = 0;
+            size_t k0 = 0;
+            for (size_t k = 0; k < n; k++) {
+                const int64_t need = off[k];
+                if (k > k0 && used + need > cap128) {
+                    Chunk ch;
+                    ch.work_off = int64_t(k0); ch.count = int32_t(k - k0);
+                    P.chunks.push_back(std::move(ch));
+                    P.arena_used = std::max(P.arena_used, used * 128);
+                    k0 = k; used = 0;
+                }
+                off[k] = uint32_t(used);
+                used += need;
+            }
+            if (n > k0) {
+                Chunk ch;
+                ch.work_off = int64_t(k0); ch.count = int32_t(n - k0);
+                P.chunks.push_back(std::move(ch));
+                P.arena_used = std::max(P.arena_used, used * 128);
+            }
         }
     }
     lap("pass 2 (offsets)");
-    P.work = order;
-    P.descs.resize(n);
+    if (!P.lazy) P.descs.resize(n);
     const size_t n_ch = P.chunks.size();
     if (lv != LV_DENSE)
         for (Chunk &ch : P.chunks) {
@@ -738,33 +886,44 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
         }
     struct Sums { int64_t cells = 0, in_bytes = 0, part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}, part_rows[2] = {0, 0}; };
     std::vector<Sums> sums(size_t(PAR_MAX) * n_ch);
+    // pass 3 (parallel): positions -> alignment ids, levels, the chunks' sums, and (unless lazy) the descriptors
     par_for(n, [&](size_t b, size_t e, int tid) {
         size_t ci = 0;
         while (ci + 1 < n_ch && size_t(P.chunks[ci + 1].work_off) <= b) ci++;       // (chunks are few)
         for (size_t k = b; k < e; k++) {
             while (ci + 1 < n_ch && size_t(P.chunks[ci + 1].work_off) <= k) ci++;
-            AlnDesc d = h->descs[size_t(order[k])];
-            const Layout L = layout(d);
-            const int64_t used = off[k];
-            d.band_w = L.band_w; d.pitch[0] = L.pitch0; d.pitch[1] = L.pitch1;
-            d.band_pad = LV_TAG[L.dl] | tag_or;
-            d.mat_off[0] = used;
-            d.mat_off[1] = used + L.m0;
-            d.blo_off = (used + L.m0 + L.m1) / 4;            // int index into the arena
-            d.path_off = (used + L.m0 + L.m1 + L.bl) / int64_t(sizeof(PathEnt));
-            const int W = LV_WINDOW[L.dl];
+            const size_t pos = size_t(order[k]);
+            const int32_t a = alns[pos];
+            order[k] = a;
+            AlnDesc d;
+            if (P.lazy) { d.Lq = lq[pos]; d.Lr = lr[pos]; d.Lt = lt[pos]; d.path_cap = d.Lq + d.Lr + d.Lt + 4; }   // (all the sums look at)
+            else d = h->descs[size_t(a)];
+            const int dl = level_of(d);
+            const int64_t used = int64_t(off[k]) * 128;
+            if (dl != LV_DENSE) {
+                (void)window_layout(d, dl, used, tag_or);
+            } else {
+                d.band_w = 0;
+                d.pitch[0] = int32_t(round_up(d.Lq, 32)); d.pitch[1] = int32_t(round_up(d.Lr, 32));
+                const int64_t m0 = round_up(int64_t(d.pitch[0]) * d.Lt, 128), m1 = round_up(int64_t(d.pitch[1]) * d.Lt, 128);
+                d.band_pad = LV_TAG[dl] | tag_or;
+                d.mat_off[0] = used; d.mat_off[1] = used + m0;
+                d.blo_off = (used + m0 + m1) / 4;
+                d.path_off = (used + m0 + m1) / int64_t(sizeof(PathEnt));
+            }
+            const int W = LV_WINDOW[dl];
             Sums &S = sums[size_t(tid) * n_ch + ci];
             S.cells += W ? int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt : int64_t(d.Lq + d.Lr) * d.Lt;
             S.in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
             if (lv != LV_DENSE) {
                 const int part = int64_t(k) - P.chunks[ci].work_off < P.chunks[ci].n_long ? 0 : 1;
-                S.part_cells[part] += int64_t(std::min(L.band_w, d.Lq) + std::min(L.band_w, d.Lr)) * d.Lt;
+                S.part_cells[part] += int64_t(std::min(d.band_w, d.Lq) + std::min(d.band_w, d.Lr)) * d.Lt;
                 S.part_in[part] += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
                 S.part_dense[part] += int64_t(d.Lq + d.Lr) * d.Lt;
                 S.part_rows[part] += d.Lt;
             }
-            h->level[size_t(order[k])] = uint8_t(L.dl);
-            P.descs[k] = d;
+            h->level[size_t(a)] = uint8_t(dl);
+            if (!P.lazy) P.descs[k] = d;
         }
     });
     lap("pass 3 (descriptors)");
@@ -822,7 +981,7 @@ int prep_zero_lane(vpr_handle *h) {
                 ZlWave W;
                 memset(&W, 0, sizeof(W));
                 for (int64_t j = int64_t(wv) * 64; j < std::min<int64_t>(n_short, int64_t(wv) * 64 + 64); j++) {
-                    const AlnDesc &d = P.descs[size_t(first + j)];
+                    const AlnDesc d = h->descs[size_t(P.work[size_t(first + j)])];
                     W.mq = std::max(W.mq, d.Lq); W.mr = std::max(W.mr, d.Lr); W.mt = std::max(W.mt, d.Lt);
                 }
                 hdr[w0 + wv] = W;
@@ -948,9 +1107,6 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     if (!h || !b) return VPR_ERR_ARG;
     if (b->n_sc < 0) return fail(h, VPR_ERR_ARG, "negative n_sc");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    free_batch(h);
-    const int n = b->n_sc;
-    h->n_sc = n;
     const bool dbg = h->debug;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double T0 = now();
@@ -959,6 +1115,10 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if (dbg) { (void)hipDeviceSynchronize(); fprintf(stderr, "[vpr] upload %-28s %.3f s\n", what, now() - T0); }
         else if (tim) fprintf(stderr, "[vpr] upload (host) %-28s %.3f s\n", what, now() - T0);
     };
+    free_batch(h);
+    lap("previous batch released");
+    const int n = b->n_sc;
+    h->n_sc = n;
     DevBatch &D = h->dB;
     memset(&D, 0, sizeof(D));
     D.n_sc = n;
@@ -978,10 +1138,12 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if ((rc = dev_alloc(h, &D.has_ins[s], ref_len))) return rc;
         if ((rc = dev_alloc(h, &D.vs_hap[s], hap_len[s]))) return rc;
         if ((rc = dev_alloc(h, &D.dspan[s], size_t(n)))) return rc;
+        if ((rc = dev_alloc(h, &D.sc_hap[s], hap_len[s]))) return rc;
         HIPCHK(h, hipMemsetAsync(D.has_ins[s], 0, std::max<int64_t>(ref_len, 1), h->stream));
     }
     if ((rc = dev_upload(h, &D.ref_off, b->ref_off, n + 1))) return rc;
     if ((rc = dev_upload(h, &D.ref_seq, b->ref_seq, ref_len))) return rc;
+    if ((rc = dev_alloc(h, &D.sc_ref, ref_len))) return rc;
     for (int q = 0; q < 2; q++) {
         if ((rc = dev_upload(h, &D.ref_ptr[q], b->ref_ptr[q], ref_len))) return rc;
         if ((rc = dev_upload(h, &D.ref_flag[q], b->ref_flag[q], ref_len))) return rc;
@@ -1064,6 +1226,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, h->stream));
     auto blocks = [](int64_t n_) { return dim3(unsigned((n_ + 255) / 256)); };
+    if (n > 0) hipLaunchKernelGGL(k_prep_scof, dim3(unsigned((n + 255) / 256), 5), dim3(256), 0, h->stream, D);
     for (int q = 0; q < 2; q++) {
         if (hap_len[q] > 0)
             hipLaunchKernelGGL(k_prep_cand, blocks(hap_len[q]), dim3(256), 0, h->stream, D, q, 0, hap_len[q], h->d_err);
@@ -1100,20 +1263,13 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     HIPCHK(h, hipEventRecord(e1, h->stream));
 
     lap("prep kernels");
-    // ---- base descriptors
-    h->descs.resize(size_t(n) * 4);
+    // ---- base descriptors: a function of the offsets (BaseDescs); here only the sums and the checks
+    h->descs.set(b, h->var_off);
     int64_t sec_total = 0, jobs_total = 0;
     int64_t cells = 0, bytes_alg = 0;
     {
-        // section-table offsets: every supercluster's four alignments take 2 * (its variants) + 16 entries
-        std::vector<int64_t> sec_base(size_t(n) + 1);
-        sec_base[0] = 0;
-        for (int sc = 0; sc < n; sc++) {
-            int64_t nv = 0;
-            for (int s = 0; s < 4; s++) nv += b->var_off[s][sc + 1] - b->var_off[s][sc];
-            sec_base[size_t(sc) + 1] = sec_base[size_t(sc)] + 2 * nv + 16;
-        }
-        sec_total = sec_base[size_t(n)];
+        for (int s = 0; s < 4; s++) sec_total += 2 * b->var_off[s][n];
+        sec_total += 16 * int64_t(n);
         struct Acc { int64_t jobs = 0, cells = 0, bytes = 0; int bad = -1; };
         std::vector<Acc> acc(PAR_MAX);
         par_for(size_t(n), [&](size_t b0, size_t e0, int tid) {
@@ -1126,23 +1282,11 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
                 int64_t nv = 0;
                 for (int s = 0; s < 4; s++) nv += b->var_off[s][sc + 1] - b->var_off[s][sc];
                 A.bytes += 6 * (Lh[0] + Lh[1] + Lh[2] + Lh[3]) + 11 * Lr + 26 * nv;
-                int64_t sec = sec_base[scu];
+                if ((Lh[0] < 1 || Lh[1] < 1 || Lh[2] < 1 || Lh[3] < 1 || Lr < 1) && A.bad < 0) A.bad = sc;
                 for (int i = 0; i < 4; i++) {
-                    AlnDesc &d = h->descs[scu * 4 + i];
-                    memset(&d, 0, sizeof(d));
-                    d.qs = i >> 1; d.ts = 2 + (i & 1);
-                    d.sc = sc; d.aln = i;
-                    d.q_off = b->hap_off[d.qs][sc]; d.t_off = b->hap_off[d.ts][sc]; d.r_off = b->ref_off[sc];
-                    d.Lq = int32_t(Lh[d.qs]); d.Lt = int32_t(Lh[d.ts]); d.Lr = int32_t(Lr);
-                    if ((d.Lq < 1 || d.Lt < 1 || d.Lr < 1) && A.bad < 0) A.bad = sc;
-                    d.qv_beg = b->var_off[d.qs][sc]; d.qv_end = b->var_off[d.qs][sc + 1];
-                    d.tv_beg = b->var_off[d.ts][sc]; d.tv_end = b->var_off[d.ts][sc + 1];
-                    d.sec_cap = int32_t((d.qv_end - d.qv_beg) + (d.tv_end - d.tv_beg) + 4);
-                    d.sec_off = sec;
-                    sec += d.sec_cap;
-                    A.jobs += std::min(d.Lr, d.Lt) / 33;
-                    d.path_cap = d.Lq + d.Lr + d.Lt + 4;
-                    A.cells += int64_t(d.Lq + d.Lr) * d.Lt;
+                    const int64_t Lq = Lh[i >> 1], Lt = Lh[2 + (i & 1)];
+                    A.jobs += std::min(Lr, Lt) / 33;
+                    A.cells += (Lq + Lr) * Lt;
                 }
             }
         });
@@ -1285,21 +1429,42 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
 
     lap("arena allocation");
     // ---- round-0 plan over all alignments, cached (descriptors + work list live on the device)
-    std::vector<int32_t> all(na);
+    std::vector<int32_t> &all = h->scratch_i32[1];
+    all.resize(na);
     par_for(na, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) all[k] = int32_t(k); });
     h->level.assign(na, uint8_t(LV_DENSE));
     const int lv0 = h->cfg.band_mode == 0 ? LV_DENSE
                     : h->cfg.band_mode == 2 ? LV_C1
                     : h->cfg.band_mode == 3 ? LV_Q16 : LV_Z;
-    if ((rc = make_plan(h, all, lv0, h->plan0, h->d_arena, h->arena_bytes))) return rc;
+    if ((rc = make_plan(h, all, lv0, h->plan0, h->d_arena, h->arena_bytes, 0, true))) return rc;
     lap("make_plan");
     h->level0 = h->level;
-    h->plan0_pos.assign(na, 0);
+    h->plan0_pos.resize(na);
     par_for(na, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) h->plan0_pos[size_t(h->plan0.work[k])] = int32_t(k); });
     if ((rc = dev_alloc(h, &h->plan0.d_descs, na))) return rc;
     if ((rc = dev_alloc(h, &h->plan0.d_work, na))) return rc;
     lap("plan0_pos");
-    if (na) {
+    if (na && h->plan0.lazy) {
+        // the plan crosses the link as (alignment, workspace offset) pairs; the device builds both descriptor tables
+        void *pw = nullptr;
+        { int rc_pin = pin_alloc(h, &pw, na * 8); if (rc_pin) return rc_pin; }
+        int32_t *hw = static_cast<int32_t *>(pw);
+        uint32_t *ho = reinterpret_cast<uint32_t *>(hw + na);
+        const Plan &P0 = h->plan0;
+        par_for(na, [&](size_t b0, size_t e0, int) {
+            memcpy(hw + b0, P0.work.data() + b0, (e0 - b0) * 4);
+            memcpy(ho + b0, P0.off128.data() + b0, (e0 - b0) * 4);
+        });
+        uint32_t *d_off = nullptr;
+        if ((rc = dev_alloc(h, &d_off, na))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->plan0.d_work, hw, na * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_off, ho, na * 4, hipMemcpyHostToDevice, h->stream));
+        BatchOffsets DO;
+        for (int s = 0; s < 4; s++) { DO.hap_off[s] = D.hap_off[s]; DO.var_off[s] = D.var_off[s]; }
+        DO.ref_off = D.ref_off;
+        hipLaunchKernelGGL(k_build_plan, blocks(int64_t(na)), dim3(256), 0, h->stream, DO, h->plan0.d_work, d_off, int(na), P0.lv,
+                           P0.long_lt, P0.tag_or, h->plan0.d_descs, h->d_descs);
+    } else if (na) {
         HIPCHK(h, hipMemcpyAsync(h->plan0.d_descs, h->plan0.descs.data(), na * sizeof(AlnDesc), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->plan0.d_work, h->plan0.work.data(), na * 4, hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(na)), dim3(256), 0, h->stream, h->plan0.d_descs, int(na), h->d_descs);
@@ -1334,6 +1499,7 @@ int vpr_upload_variants(vpr_handle *h, const vpr_variants *v) {
     rc = vpr_upload(h, vpr_owned_batch_view(ob));
     h->gen_src = nullptr;
     vpr_owned_batch_free(ob);
+    if (getenv("VPR_TIMING")) fprintf(stderr, "[vpr] upload (host) vpr_upload_variants %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count());
     return rc;
 }
 
@@ -1501,7 +1667,7 @@ struct Exec {
         needs.reserve(size_t(cnt));
         int64_t total = 0, largest = 0, dec_need = 0;
         for (int32_t k = 0; k < cnt; k++) {
-            const AlnDesc &d = P.descs[size_t(off) + k];
+            const AlnDesc d = plan_desc(h, P, size_t(off) + k);
             const auto it = tie_early.find(P.work[size_t(off) + k]);
             if ((it != tie_early.end()) != early) continue;
             if (early && it->second.mode == 3) { tie_patch_spec = true; continue; }
@@ -1607,7 +1773,7 @@ struct Exec {
                 J.bkt_off = (words + N.w_st + N.w_buf) / 2;   // (all three terms are multiples of four words)
                 if (early) {
                     const TieEarly &E = tie_early[J.a];
-                    const AlnDesc &o = E.plan->descs[size_t(E.pos)];
+                    const AlnDesc o = plan_desc(h, *E.plan, size_t(E.pos));
                     J.mode = E.mode; J.n_used = E.n_used;
                     J.old_band_w = o.band_w; J.old_pitch[0] = o.pitch[0]; J.old_pitch[1] = o.pitch[1];
                     J.old_mat_off[0] = o.mat_off[0]; J.old_mat_off[1] = o.mat_off[1]; J.old_blo_off = o.blo_off;
@@ -2053,7 +2219,7 @@ struct Exec {
             marked.push_back(e.x);
             if (resident && !full && e.z > 0) {
                 const int32_t pos = h->plan0_pos[size_t(e.x)];
-                const int dtag = h->plan0.descs[size_t(pos)].band_pad;
+                const int dtag = plan_desc(h, h->plan0, size_t(pos)).band_pad;
                 if (pos >= resident->work_off && pos < resident->work_off + resident->count &&
                     (dtag == e.y || (dtag == LV_TAG[LV_Z] && e.y == LV_TAG[LV_Q16])))
                     tie_early[e.x] = TieEarly{e.z, pos, &h->plan0, spec_set.count(e.x) ? 3 : 1};

@@ -38,9 +38,7 @@ __global__ void k_prep_pack(DevBatch B, int h, int dir, int64_t n_pos) {
     int2 *fk = dir == 0 ? B.fk_q[h] : B.fk_r[h];
     int32_t *bk = dir == 0 ? B.bk_q[h] : B.bk_r[h];
 
-    int lo = 0, hi = B.n_sc;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
-    const int sc = lo;
+    const int sc = (dir == 0 ? B.sc_hap[h] : B.sc_ref)[g];
     const int32_t x = int32_t(g - off[sc]);
     const int64_t olen = ooff[sc + 1] - ooff[sc];
     const int f = flg[g];
@@ -87,10 +85,7 @@ __global__ void k_prep_tj(DevBatch B, int s, int64_t n_pos) {
     const int32_t *ptr = B.hap_ptr[2 + s];
     uint16_t j = 0;
     if ((B.hap_flag[2 + s][g] & PV) && g > 0 && ptr[g - 1] == ptr[g]) {
-        const int64_t *off = B.hap_off[2 + s];
-        int lo = 0, hi = B.n_sc;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
-        int64_t a = off[lo], b = g;      // first position in [a, b] whose pointer equals ptr[g]
+        int64_t a = B.hap_off[2 + s][B.sc_hap[2 + s][g]], b = g;      // first position in [a, b] whose pointer equals ptr[g]
         const int32_t p = ptr[g];
         while (a < b) { const int64_t m = (a + b) >> 1; if (ptr[m] < p) a = m + 1; else b = m; }
         j = uint16_t(min<int64_t>(g - a, 65535));
@@ -137,9 +132,7 @@ __global__ void k_prep_xb(DevBatch B, int h, int dir, int64_t n_pos) {
     const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= n_pos) return;
     const int64_t *off = dir == 0 ? B.hap_off[h] : B.ref_off;
-    int lo = 0, hi = B.n_sc;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
-    const int sc = lo;
+    const int sc = (dir == 0 ? B.sc_hap[h] : B.sc_ref)[g];
     const int64_t qo = B.hap_off[h][sc], ro = B.ref_off[sc];
     const int Lq = int(B.hap_off[h][sc + 1] - qo), Lr = int(B.ref_off[sc + 1] - ro);
     const int32_t *W = B.vs_hap[h] + qo, *q2r = B.hap_ptr[h] + qo, *r2q = B.ref_ptr[h] + ro;

@@ -63,6 +63,8 @@ struct DevBatch {
     const int64_t *var_off[4];
     const int32_t *var_pos[4];
     // derived by k_prep_*:
+    int32_t *sc_hap[4];   // supercluster of every hap position / ref position (k_prep_scof): the other K0 kernels are
+    int32_t *sc_ref;      //   one thread per position and need its supercluster's offsets
     int4 *cand_q[2];      // [hap positions of query hap h] allowed swap sources in the REF plane (ascending, -1 pad)
     int4 *cand_r[2];      // [ref positions]               allowed swap sources in QUERY hap h
     int4 *cand2_q[2];     // sources five to eight of a position (read only where cand_*.w >= 0: directly adjacent separate
@@ -193,5 +195,75 @@ struct DevResults {
 // the cell (qref = qri on the REF plane, q2r[qri] on the QUERY plane; tref = t2r[ti]) so the backward credit
 // walk needs no pointer-array loads
 struct PathEnt { uint32_t a, b; int32_t qref, tref; };
+
+// ---------------------------------------------------------------------------
+// Descriptors as a function of the batch offsets and a plan's (alignment, workspace offset) pair.  The host planner and
+// the device builder (k_build_plan, pr_api.hip) share these, so a round-0 plan crosses the link as 12 bytes per
+// alignment (its place in the work list and its workspace offset) instead of a 96-byte descriptor.
+// ---------------------------------------------------------------------------
+enum { LV_Z = 0, LV_Q16 = 1, LV_C1 = 2, LV_C4 = 3, LV_C16 = 4, LV_DENSE = 5 };
+__host__ __device__ inline int lv_window(int lv) { return lv <= LV_Q16 ? 16 : lv == LV_C1 ? 64 : lv == LV_C4 ? 256 : lv == LV_C16 ? 1024 : 0; }
+__host__ __device__ inline int lv_tag(int lv) { return lv == LV_Z ? 8 : lv_window(lv); }
+__host__ __device__ inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct BatchOffsets {       // CSR offsets of a batch (host copies or the resident ones)
+    const int64_t *hap_off[4];
+    const int64_t *ref_off;
+    const int64_t *var_off[4];
+};
+
+// the descriptor of alignment a = 4 * supercluster + i without a workspace layout (query hap i >> 1 against truth hap i & 1)
+__host__ __device__ inline AlnDesc base_desc(const BatchOffsets &O, int64_t a) {
+    AlnDesc d{};
+    const int sc = int(a >> 2), i = int(a & 3);
+    d.qs = i >> 1; d.ts = 2 + (i & 1);
+    d.sc = sc; d.aln = i;
+    d.q_off = O.hap_off[d.qs][sc]; d.t_off = O.hap_off[d.ts][sc]; d.r_off = O.ref_off[sc];
+    d.Lq = int32_t(O.hap_off[d.qs][sc + 1] - d.q_off);
+    d.Lt = int32_t(O.hap_off[d.ts][sc + 1] - d.t_off);
+    d.Lr = int32_t(O.ref_off[sc + 1] - d.r_off);
+    int64_t nv[4], v0 = 0;
+    for (int s = 0; s < 4; s++) { nv[s] = O.var_off[s][sc + 1] - O.var_off[s][sc]; v0 += O.var_off[s][sc]; }
+    d.qv_beg = O.var_off[d.qs][sc]; d.qv_end = O.var_off[d.qs][sc + 1];
+    d.tv_beg = O.var_off[d.ts][sc]; d.tv_end = O.var_off[d.ts][sc + 1];
+    // section table: alignment (q, t) holds (its query's + its truth's variants + 4) entries, a supercluster's four
+    // alignments therefore 2 * (its variants) + 16, one after the other
+    d.sec_cap = int32_t(nv[d.qs] + nv[d.ts] + 4);
+    int64_t sec = 2 * v0 + 16 * int64_t(sc);
+    for (int j = 0; j < i; j++) sec += nv[j >> 1] + nv[2 + (j & 1)] + 4;
+    d.sec_off = sec;
+    d.path_cap = d.Lq + d.Lr + d.Lt + 4;
+    return d;
+}
+
+// Workspace layout of an alignment at window level dl (not LV_DENSE): flag matrices, window origins, walk scratch.
+// Fills the layout fields of d for workspace offset `used` and returns the bytes the alignment occupies.
+__host__ __device__ inline int64_t window_layout(AlnDesc &d, int dl, int64_t used, int tag_or) {
+    const int W = lv_window(dl);
+    int64_t m0, m1, bl;
+    if (dl <= LV_Q16) {
+        // stripe-transposed records of 128 B per 4 truth rows (both planes) + int2 origins per stripe
+        const int64_t nstr = (int64_t(d.Lt) + 3) / 4;
+        d.band_w = 16;
+        d.pitch[0] = d.pitch[1] = 16;
+        m0 = nstr * 128; m1 = 0;
+        bl = round_up64(nstr * 8, 128);
+    } else {
+        d.band_w = W;
+        d.pitch[0] = int32_t(round_up64(W < d.Lq ? W : d.Lq, 16));
+        d.pitch[1] = int32_t(round_up64(W < d.Lr ? W : d.Lr, 16));
+        m0 = round_up64(int64_t(d.pitch[0]) * d.Lt, 128); m1 = round_up64(int64_t(d.pitch[1]) * d.Lt, 128);
+        bl = round_up64(int64_t(2) * d.Lt * 4, 128);
+    }
+    // (every piece a multiple of 128 bytes: the path block of an alignment starts on a 128-byte line, which the credit
+    // walk's refills rely on -- the path reads past path_cap inside the block's padding)
+    const int64_t pb = round_up64(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)) + 128, 128);   // 16 B per step
+    d.band_pad = lv_tag(dl) | tag_or;
+    d.mat_off[0] = used;
+    d.mat_off[1] = used + m0;
+    d.blo_off = (used + m0 + m1) / 4;            // int index into the arena
+    d.path_off = (used + m0 + m1 + bl) / int64_t(sizeof(PathEnt));
+    return m0 + m1 + bl + pb + 128;
+}
 
 #endif

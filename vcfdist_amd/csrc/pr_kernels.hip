@@ -27,13 +27,25 @@ __device__ __forceinline__ bool bwd_allow(int f) { return !(f & PV) || (f & PB);
 // ---------------------------------------------------------------------------
 // K0: position attributes
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int find_sc(const int64_t *off, int n, int64_t g) {
-    int lo = 0, hi = n;  // largest sc with off[sc] <= g
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (off[mid] <= g) lo = mid; else hi = mid;
+// supercluster of every position: a workgroup takes 256 superclusters, whose positions are one contiguous range of the
+// array, and searches their 257 offsets in LDS.  blockIdx.y: hap slot 0..3, 4 = ref
+__global__ void __launch_bounds__(256) k_prep_scof(DevBatch B) {
+    __shared__ int64_t s_off[257];
+    const int which = blockIdx.y;
+    const int64_t *off = which < 4 ? B.hap_off[which] : B.ref_off;
+    int32_t *out = which < 4 ? B.sc_hap[which] : B.sc_ref;
+    const int sc0 = blockIdx.x * 256, m = min(256, B.n_sc - sc0);
+    for (int i = threadIdx.x; i <= m; i += 256) s_off[i] = off[sc0 + i];
+    __syncthreads();
+    const int64_t beg = s_off[0], end = s_off[m];
+    for (int64_t g = beg + threadIdx.x; g < end; g += 256) {
+        int lo = 0, hi = m;  // largest sc with off[sc] <= g
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_off[mid] <= g) lo = mid; else hi = mid;
+        }
+        out[g] = sc0 + lo;
     }
-    return lo;
 }
 
 // dir 0: sources = positions of query hap h, destinations in the REF plane   -> cand_r[h]
@@ -48,7 +60,7 @@ __global__ void k_prep_cand(DevBatch B, int h, int dir, int64_t n_src, uint32_t 
     int4 *cand = dir == 0 ? B.cand_r[h] : B.cand_q[h];
     int4 *cand2 = dir == 0 ? B.cand2_r[h] : B.cand2_q[h];
     if (!fwd_allow(flg[g])) return;
-    const int sc = find_sc(src_off, B.n_sc, g);
+    const int sc = (dir == 0 ? B.sc_hap[h] : B.sc_ref)[g];
     const int64_t s0 = src_off[sc];
     const int32_t x = int32_t(g - s0);
     const int32_t p = ptr[g];
@@ -67,7 +79,7 @@ __global__ void k_prep_ins(DevBatch B, int slot, int64_t n_src) {
     const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= n_src) return;
     if (!(B.hap_flag[slot][g] & PI)) return;
-    const int sc = find_sc(B.hap_off[slot], B.n_sc, g);
+    const int sc = B.sc_hap[slot][g];
     const int32_t p = B.hap_ptr[slot][g];
     if (p >= 0) B.has_ins[slot][B.ref_off[sc] + p] = 1;
 }

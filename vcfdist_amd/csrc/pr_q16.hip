@@ -30,8 +30,7 @@ __global__ void k_prep_q16(DevBatch B, int which, int64_t n_pos) {
     if (g >= n_pos) return;
     const int slot = which < 2 ? which : (which < 4 ? -1 : which - 2);
     const int64_t *off = slot >= 0 ? B.hap_off[slot] : B.ref_off;
-    int lo = 0, hi = B.n_sc;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
+    const int lo = (slot >= 0 ? B.sc_hap[slot] : B.sc_ref)[g];
     const int64_t beg = off[lo];
     const int64_t gm1 = g > beg ? g - 1 : beg;
     if (which < 2) {
@@ -54,9 +53,7 @@ __global__ void k_prep_wk(DevBatch B, int which, int64_t n_pos) {
     const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= n_pos) return;
     const int slot = which < 2 ? which : (which < 4 ? -1 : which - 2);
-    const int64_t *off = slot >= 0 ? B.hap_off[slot] : B.ref_off;
-    int lo = 0, hi = B.n_sc;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
+    const int lo = (slot >= 0 ? B.sc_hap[slot] : B.sc_ref)[g];
     const int64_t rbeg = B.ref_off[lo], rlen = B.ref_off[lo + 1] - rbeg;
     auto ins4 = [&](int32_t r) -> int {
         if (r < 0 || r >= rlen) return 0;

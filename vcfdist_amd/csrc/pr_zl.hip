@@ -67,58 +67,68 @@ __device__ __forceinline__ bool zw_bwd_allow(uint32_t w) { return !(w & ZW_PV) |
 
 #define ZL_MAXLEN 65000
 
-// K0z: wave-interleaved position words.  One thread per (wave, array, position, lane), lanes fastest.
+// K0z: wave-interleaved position words.  One workgroup per wave of 64 alignments.  The arrays are read the way they lie
+// (64 consecutive positions of ONE alignment per wave load), turned in LDS, and written the way the lane kernel reads them
+// (position x of the 64 alignments = one 256-byte row): both sides of the transpose are whole cache lines.
 //   hdr[w], list: the waves of one chunk's short part (list[64 w + l] = alignment of lane l, -1 beyond the end)
 __global__ void __launch_bounds__(256) k_prep_zl(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list,
                                                  int n_list, const ZlWave *__restrict__ hdr, uint32_t *__restrict__ zin) {
+    __shared__ uint32_t tile[64][65];       // [position in the tile][alignment]
+    __shared__ int64_t s_qo[64], s_ro[64], s_to[64];
+    __shared__ int32_t s_lq[64], s_lr[64], s_lt[64];
+    __shared__ uint8_t s_qs[64], s_ts[64];
     const int w = blockIdx.x;
     const ZlWave H = hdr[w];
-    const int l = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int wi = w * 64 + l;
-    const int a = wi < n_list ? list[wi] : -1;
-    uint32_t *out = zin + H.in_off;
-    if (a < 0) {
-        const int tot = H.mq + H.mr + H.mt;
-        for (int x = sub; x < tot; x += 4) out[int64_t(x) * 64 + l] = 0x7f0000u;
-        return;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    if (threadIdx.x < 64) {
+        const int wi = w * 64 + lane;
+        const int a = wi < n_list ? list[wi] : -1;
+        if (a >= 0) {
+            const AlnDesc *d = descs + a;
+            s_qo[lane] = d->q_off; s_ro[lane] = d->r_off; s_to[lane] = d->t_off;
+            s_lq[lane] = d->Lq; s_lr[lane] = d->Lr; s_lt[lane] = d->Lt;
+            s_qs[lane] = uint8_t(d->qs); s_ts[lane] = uint8_t(d->ts);
+        } else {
+            s_qo[lane] = s_ro[lane] = s_to[lane] = 0;
+            s_lq[lane] = s_lr[lane] = s_lt[lane] = 0;
+            s_qs[lane] = 0; s_ts[lane] = 2;
+        }
     }
-    const AlnDesc d = descs[a];
-    const int qs = d.qs, ts = d.ts;
-    const uint8_t *insq = B.has_ins[qs] + d.r_off, *inst = B.has_ins[ts] + d.r_off;
-    auto ins_at = [&](int r) -> uint32_t { return (r >= 0 && r < d.Lr && (insq[r] | inst[r])) ? ZW_INS : 0u; };
+    __syncthreads();
     auto flagbits = [](int f) -> uint32_t { return ((f & PV) ? ZW_PV : 0u) | ((f & PB) ? ZW_PB : 0u) | ((f & PE) ? ZW_PE : 0u); };
-    {   // Q
-        const uint8_t *seq = B.hap_seq[qs] + d.q_off, *flg = B.hap_flag[qs] + d.q_off;
-        const int32_t *ptr = B.hap_ptr[qs] + d.q_off;
-        for (int x = sub; x < H.mq; x += 4) {
-            uint32_t v = 0x7f0000u;
-            if (x < d.Lq) {
-                const int p = ptr[x], f = flg[x];
-                const bool tp = x > 0 && ((p != ptr[x - 1] + 1) || (f & PB));       // dist.cpp:572-574
-                v = uint32_t((p + 1) & 0xffff) | (uint32_t(seq[x] & 0x7f) << 16) | flagbits(f) | ins_at(p) | (tp ? ZW_TP : 0u);
+    uint32_t *out = zin + H.in_off;
+    for (int arr = 0; arr < 3; arr++) {                 // Q, R, T blocks
+        const int mlen = arr == 0 ? H.mq : (arr == 1 ? H.mr : H.mt);
+        for (int x0 = 0; x0 < mlen; x0 += 64) {
+            const int x = x0 + lane;
+#pragma unroll 4
+            for (int k = 0; k < 16; k++) {              // this wave's 16 alignments, 64 positions each
+                const int l = sub * 16 + k;
+                const int qs = s_qs[l], ts = s_ts[l];
+                const int Lr = s_lr[l];
+                const int len = arr == 0 ? s_lq[l] : (arr == 1 ? Lr : s_lt[l]);
+                uint32_t v = 0x7f0000u;
+                if (x < len) {
+                    const int64_t ro = s_ro[l];
+                    const int slot = arr == 2 ? ts : qs;
+                    const int64_t o = (arr == 0 ? s_qo[l] : (arr == 1 ? ro : s_to[l])) + x;
+                    const uint8_t *seq = arr == 1 ? B.ref_seq : B.hap_seq[slot];
+                    const uint8_t *flg = arr == 1 ? B.ref_flag[qs] : B.hap_flag[slot];
+                    const int32_t *ptr = arr == 1 ? B.ref_ptr[qs] : B.hap_ptr[slot];
+                    const int p = ptr[o], f = flg[o];
+                    const int r = arr == 1 ? x : p;     // the reference base whose insertions count
+                    const uint32_t ins = (r >= 0 && r < Lr && (B.has_ins[qs][ro + r] | B.has_ins[ts][ro + r])) ? ZW_INS : 0u;
+                    v = uint32_t((p + 1) & 0xffff) | (uint32_t(seq[o] & 0x7f) << 16) | flagbits(f) | ins;
+                    if (arr == 0 && x > 0 && ((p != ptr[o - 1] + 1) || (f & PB))) v |= ZW_TP;       // dist.cpp:572-574
+                }
+                tile[lane][l] = v;
             }
-            out[int64_t(x) * 64 + l] = v;
+            __syncthreads();
+            const int rows = min(64, mlen - x0);
+            for (int r = sub; r < rows; r += 4) out[int64_t(x0 + r) * 64 + lane] = tile[r][lane];
+            __syncthreads();
         }
-    }
-    out += int64_t(H.mq) * 64;
-    {   // R
-        const uint8_t *seq = B.ref_seq + d.r_off, *flg = B.ref_flag[qs] + d.r_off;
-        const int32_t *ptr = B.ref_ptr[qs] + d.r_off;
-        for (int x = sub; x < H.mr; x += 4) {
-            uint32_t v = 0x7f0000u;
-            if (x < d.Lr) v = uint32_t((ptr[x] + 1) & 0xffff) | (uint32_t(seq[x] & 0x7f) << 16) | flagbits(flg[x]) | ins_at(x);
-            out[int64_t(x) * 64 + l] = v;
-        }
-    }
-    out += int64_t(H.mr) * 64;
-    {   // T
-        const uint8_t *seq = B.hap_seq[ts] + d.t_off, *flg = B.hap_flag[ts] + d.t_off;
-        const int32_t *ptr = B.hap_ptr[ts] + d.t_off;
-        for (int x = sub; x < H.mt; x += 4) {
-            uint32_t v = 0x7f0000u;
-            if (x < d.Lt) v = uint32_t((ptr[x] + 1) & 0xffff) | (uint32_t(seq[x] & 0x7f) << 16) | flagbits(flg[x]) | ins_at(ptr[x]);
-            out[int64_t(x) * 64 + l] = v;
-        }
+        out += int64_t(mlen) * 64;
     }
 }
 
