@@ -36,6 +36,7 @@ extern "C" int vpr_batch_skeleton_from_variants(const vpr_variants *v, vpr_owned
 #include "pr_zl.hip"
 #include "pr_gen.hip"
 #include "pr_wide.hip"
+#include "pr_strip.hip"
 #include "pr_tie.hip"
 
 namespace {
@@ -242,6 +243,11 @@ struct vpr_handle {
     int64_t n_var[4] = {0, 0, 0, 0};
     BaseDescs descs;                     // base descriptors (no workspace offsets)
     std::vector<int32_t> scratch_i32[4]; // planner scratch that keeps its pages across uploads
+    // device blocks with the lifetime of one execute (the strip tables and boundary columns of the wide dense sweeps,
+    // pr_strip.hip): taken from the batch's allocations, handed out again by the next execute
+    struct ExecBlk { uint8_t *p; size_t bytes; bool used; };
+    std::vector<ExecBlk> exec_blks;
+    bool no_strips = false;              // VPR_NO_STRIPS in the environment: wide alignments stay in one workgroup
     std::vector<uint32_t> scratch_u32[2];
     Plan plan0;                          // first round over all alignments, cached at upload
     std::vector<uint8_t> level, level0;  // current / round-0 window level of every alignment
@@ -452,6 +458,25 @@ int dev_upload(vpr_handle *h, const T **dst, const T *src, size_t n) {
     return VPR_OK;
 }
 
+int exec_alloc(vpr_handle *h, void **out, size_t bytes) {
+    bytes = std::max<size_t>((bytes + 255) & ~size_t(255), 256);
+    int best = -1;
+    for (size_t k = 0; k < h->exec_blks.size(); k++) {
+        const auto &b = h->exec_blks[k];
+        if (!b.used && b.bytes >= bytes && (best < 0 || b.bytes < h->exec_blks[size_t(best)].bytes)) best = int(k);
+    }
+    if (best < 0) {
+        uint8_t *q = nullptr;
+        const int rc = dev_alloc(h, &q, bytes);
+        if (rc) return rc;
+        h->exec_blks.push_back(vpr_handle::ExecBlk{q, bytes, false});
+        best = int(h->exec_blks.size()) - 1;
+    }
+    h->exec_blks[size_t(best)].used = true;
+    *out = h->exec_blks[size_t(best)].p;
+    return VPR_OK;
+}
+
 void free_batch(vpr_handle *h) {
     for (size_t k = 0; k < h->allocs.size(); k++) {
         if (h->alloc_bytes[k]) h->dev_cache.push_back(vpr_handle::Blk{h->allocs[k], h->alloc_bytes[k]});
@@ -465,6 +490,7 @@ void free_batch(vpr_handle *h) {
         h->dev_cache.erase(h->dev_cache.begin() + long(m));
     }
     h->pool_cur = nullptr; h->pool_left = 0; h->pool_next = size_t(16) << 20;
+    h->exec_blks.clear();
     for (void *p : h->pinned) (void)hipHostFree(p);
     h->pinned.clear();
     for (auto &b : h->pinned_blk) h->pin_cache.push_back(b);
@@ -521,7 +547,7 @@ size_t bwd_lds_bytes(int cls, int Lq, int Lr, bool s16 = false) {
 // largest score the int16 rows must hold: query-variant entries on a path <= query variants of the alignment
 bool s16_ok(const AlnDesc &d) { return d.qv_end - d.qv_beg < 32000; }
 
-typedef void (*AlnKernel)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, AlnOut *);
+typedef void (*AlnKernel)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, AlnOut *, const int32_t *);
 AlnKernel fwd_kernel(int cls) {
     switch (cls) {
         case 0: return k_fwd<64, 1>;
@@ -1035,6 +1061,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     vpr_handle *h = new vpr_handle();
     h->cfg = *cfg;
     h->debug = getenv("VPR_DEBUG") != nullptr;
+    h->no_strips = getenv("VPR_NO_STRIPS") != nullptr;
     memset(&h->dB, 0, sizeof(h->dB));
     memset(&h->timing, 0, sizeof(h->timing));
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
@@ -1824,13 +1851,94 @@ struct Exec {
     // ---- dense plan: per chunk, each kernel class runs K1 -> K2 -> K3 on its own stream (forked from and
     // joined into `base`); one_stream: everything on `base` (retry rounds that run beside other work)
     // tag_or: TIE_TAG_BIT when the plan belongs to a tie round (forward sweep, container-order replay, then the rest)
+    // Strip tables of the wide alignments [off, off + cnt) of a dense plan (pr_strip.hip), planned on the device on stream ks.
+    struct StripGroup {
+        int64_t off = 0; int32_t cnt = 0, grid = 0;
+        int32_t *d_base = nullptr, *d_n = nullptr, *d_ok = nullptr, *d_prog = nullptr;     // d_prog: [2][grid] forward / backward
+        int64_t *d_boff = nullptr;
+        StripTab *d_tab = nullptr;
+        int2 *d_bnd = nullptr; int4 *d_bbnd = nullptr;
+    };
+    int strip_plan(const Plan &P, const int32_t *d_work, int64_t off, int32_t cnt, hipStream_t ks, StripGroup &G) {
+        G.off = off; G.cnt = cnt;
+        // slots per alignment: twice what the longer plane needs (a cut may have to move far back to a clean column)
+        void *pb = nullptr;
+        { int rc_pin = pin_alloc(h, &pb, size_t(cnt + 1) * 4 + size_t(cnt) * 8 + 16); if (rc_pin) return rc_pin; }
+        int64_t *h_boff = static_cast<int64_t *>(pb);
+        int32_t *h_base = reinterpret_cast<int32_t *>(h_boff + cnt);
+        int64_t slots = 0, rows = 0;
+        for (int32_t k = 0; k < cnt; k++) {
+            const AlnDesc &d = P.descs[size_t(off) + k];
+            const int ns = 2 * ((std::max(d.Lq, d.Lr) + ST_CAP - 1) / ST_CAP) + 2;
+            h_base[k] = int32_t(slots);
+            h_boff[k] = rows;
+            slots += ns;
+            rows += int64_t(ns) * d.Lt;
+        }
+        h_base[cnt] = int32_t(slots);
+        G.grid = int32_t(slots);
+        void *q = nullptr;
+        int rc;
+        const size_t b_small = size_t(cnt + 1) * 4 + size_t(cnt) * 8 + size_t(slots) * (sizeof(StripTab) + 8) + 4096;
+        if ((rc = exec_alloc(h, &q, b_small))) return rc;
+        uint8_t *u = static_cast<uint8_t *>(q);
+        G.d_boff = reinterpret_cast<int64_t *>(u); u += size_t(cnt) * 8;
+        G.d_tab = reinterpret_cast<StripTab *>(u); u += size_t(slots) * sizeof(StripTab);
+        G.d_base = reinterpret_cast<int32_t *>(u); u += size_t(cnt + 1) * 4;
+        G.d_n = reinterpret_cast<int32_t *>(u); u += size_t(cnt) * 4;
+        G.d_ok = reinterpret_cast<int32_t *>(u); u += size_t(cnt) * 4;
+        if ((rc = exec_alloc(h, &q, size_t(slots) * 8))) return rc;
+        G.d_prog = static_cast<int32_t *>(q);
+        if ((rc = exec_alloc(h, &q, size_t(rows) * sizeof(int4)))) return rc;      // (the forward columns first, then reused by the backward sweep)
+        G.d_bnd = static_cast<int2 *>(q);
+        G.d_bbnd = static_cast<int4 *>(q);
+        HIPCHK(h, hipMemcpyAsync(G.d_boff, h_boff, size_t(cnt) * 8, hipMemcpyHostToDevice, ks));
+        HIPCHK(h, hipMemcpyAsync(G.d_base, h_base, size_t(cnt + 1) * 4, hipMemcpyHostToDevice, ks));
+        HIPCHK(h, hipMemsetAsync(G.d_prog, 0, size_t(slots) * 8, ks));
+        hipLaunchKernelGGL(k_strip_plan, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, d_work + off, cnt, G.d_base, G.d_tab,
+                           G.d_n, G.d_ok);
+        return VPR_OK;
+    }
+
     int run_dense(const Plan &P, const int32_t *d_work, hipStream_t base, bool one_stream, int tag_or = 0) {
+        const int STRIP_CLS = 4;      // kernel classes from 1024 threads x 8 cells on: alignments wider than 2048 columns
         for (const Chunk &ch : P.chunks) {
             if (!one_stream) HIPCHK(h, hipEventRecord(h->ev_fork, base));
+            // the wide alignments of the chunk (its last launches: the classes are in ascending order), spread over several
+            // workgroups each; what the strip planner cannot cut is left to the one-workgroup kernels (skip lists)
+            StripGroup G;
+            bool strips = false;
+            if (!h->no_strips && !tag_or) {
+                int64_t g_off = -1; int32_t g_cnt = 0;
+                for (const Launch &L : ch.launches)
+                    if (L.cls >= STRIP_CLS) { if (g_off < 0) g_off = L.work_off; g_cnt += L.count; }
+                if (g_cnt > 0) {
+                    hipStream_t ks = one_stream ? base : h->cls_stream[STRIP_CLS];
+                    if (!one_stream) HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
+                    int rc = strip_plan(P, d_work, g_off, g_cnt, ks, G);
+                    if (rc) return rc;
+                    strips = true;
+                    vpr_launch_stat ls;
+                    memset(&ls, 0, sizeof(ls));
+                    ls.threads = ST_NT; ls.cells_per_thread = ST_C; ls.n_units = g_cnt;
+                    for (int32_t w = 0; w < g_cnt; w++) {
+                        const AlnDesc &d = P.descs[size_t(g_off) + w];
+                        ls.cells += int64_t(d.Lq + d.Lr) * d.Lt;
+                    }
+                    ls.cells_dense = ls.cells; ls.bytes_algorithmic = ls.cells;
+                    rc = timed(1, ls, ks, "k_fwd_strip", [&] {
+                        hipLaunchKernelGGL(k_fwd_strip, dim3(G.grid), dim3(ST_NT), 0, ks, h->dB, h->d_descs, d_work + g_off, g_cnt, G.d_base,
+                                           G.d_tab, G.d_n, G.d_boff, G.d_bnd, G.d_prog, P.arena, h->d_outs);
+                    });
+                    if (rc) return rc;
+                }
+            }
             for (const Launch &L : ch.launches) {
                 const KernelClass &K = CLASSES[L.cls];
-                hipStream_t ks = one_stream ? base : h->cls_stream[L.cls];
-                if (!one_stream) HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
+                const bool in_group = strips && L.cls >= STRIP_CLS;
+                hipStream_t ks = one_stream ? base : h->cls_stream[in_group ? STRIP_CLS : L.cls];
+                if (!one_stream && !in_group) HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
+                const int32_t *skip = in_group ? G.d_ok + (L.work_off - G.off) : nullptr;
                 size_t lds_f = 0, lds_b = 0;
                 vpr_launch_stat ls;
                 memset(&ls, 0, sizeof(ls));
@@ -1854,6 +1962,7 @@ struct Exec {
                     ls.cells += int64_t(d.Lq + d.Lr) * d.Lt;
                     in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
                 }
+                if (in_group) { ls.cells = 0; in_bytes = 0; }      // (counted with the strip launch; this one only takes what that left)
                 cells_touched += ls.cells;
                 ls.cells_dense = ls.cells;
                 ls.bytes_algorithmic = ls.cells + in_bytes;
@@ -1861,23 +1970,68 @@ struct Exec {
                 if (tag_or && (rc = tie_replay(P, L.work_off, L.count, ks, true))) return rc;
                 rc = timed(1, ls, ks, (std::string("k_fwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + ">").c_str(), [&] {
                     hipLaunchKernelGGL(fwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_f, ks, h->dB, h->d_descs,
-                                       d_work + L.work_off, P.arena, h->d_outs);
+                                       d_work + L.work_off, P.arena, h->d_outs, skip);
                     hipLaunchKernelGGL(k_fwd_finish, dim3((L.count + 255) / 256), dim3(256), 0, ks,
                                        d_work + L.work_off, L.count, h->d_outs, tag_or);
                 });
                 if (rc) return rc;
                 n_fwd++;
                 if (tag_or && ((rc = tie_replay(P, L.work_off, L.count, ks, false)) || (rc = tie_patch(P, ks, tag_or)))) return rc;
+                if (in_group) continue;     // (backward sweeps and walks of the group: below, behind all its forward sweeps)
                 ls.bytes_algorithmic = ls.cells;
                 rc = timed(2, ls, ks, (std::string("k_bwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + (s16 ? ",s16>" : ">")).c_str(), [&] {
                     hipLaunchKernelGGL(bwd_kernel(L.cls, s16), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
-                                       d_work + L.work_off, P.arena, h->d_outs);
+                                       d_work + L.work_off, P.arena, h->d_outs, skip);
                 });
                 if (rc) return rc;
                 if ((rc = walk_launch(P, d_work + L.work_off, L.count, ks, false, tag_or))) return rc;
                 if (!one_stream) {
                     HIPCHK(h, hipEventRecord(h->ev_join[L.cls], ks));
                     HIPCHK(h, hipStreamWaitEvent(base, h->ev_join[L.cls], 0));
+                }
+            }
+            if (strips) {
+                hipStream_t ks = one_stream ? base : h->cls_stream[STRIP_CLS];
+                vpr_launch_stat ls;
+                memset(&ls, 0, sizeof(ls));
+                ls.threads = ST_NT; ls.cells_per_thread = ST_C; ls.n_units = G.cnt;
+                for (int32_t w = 0; w < G.cnt; w++) {
+                    const AlnDesc &d = P.descs[size_t(G.off) + w];
+                    ls.cells += int64_t(d.Lq + d.Lr) * d.Lt;
+                }
+                ls.cells_dense = ls.cells; ls.bytes_algorithmic = ls.cells;
+                int rc = timed(2, ls, ks, "k_bwd_strip", [&] {
+                    hipLaunchKernelGGL(k_bwd_strip, dim3(G.cnt), dim3(ST_NT), 0, ks, h->dB, h->d_descs, d_work + G.off, G.cnt, G.d_base,
+                                       G.d_tab, G.d_n, G.d_boff, G.d_bbnd, G.d_prog + G.grid, P.arena, h->d_outs);
+                });
+                if (rc) return rc;
+                for (const Launch &L : ch.launches) {      // what the planner could not cut
+                    if (L.cls < STRIP_CLS) continue;
+                    const KernelClass &K = CLASSES[L.cls];
+                    bool s16 = (h->cfg.flags & VPR_CFG_DENSE_S16) != 0;
+                    size_t lds_b = 0;
+                    for (int32_t w = 0; w < L.count; w++) {
+                        const AlnDesc &d = P.descs[L.work_off + w];
+                        if (bwd_lds_bytes(L.cls, d.Lq, d.Lr) > LDS_MAX) s16 = true;
+                    }
+                    for (int32_t w = 0; w < L.count; w++) if (s16 && !s16_ok(P.descs[L.work_off + w])) s16 = false;
+                    for (int32_t w = 0; w < L.count; w++) {
+                        const AlnDesc &d = P.descs[L.work_off + w];
+                        lds_b = std::max(lds_b, bwd_lds_bytes(L.cls, d.Lq, d.Lr, s16));
+                    }
+                    vpr_launch_stat l2;
+                    memset(&l2, 0, sizeof(l2));
+                    l2.threads = K.nt; l2.cells_per_thread = K.c; l2.n_units = L.count;
+                    rc = timed(2, l2, ks, (std::string("k_bwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + (s16 ? ",s16>" : ">")).c_str(), [&] {
+                        hipLaunchKernelGGL(bwd_kernel(L.cls, s16), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
+                                           d_work + L.work_off, P.arena, h->d_outs, G.d_ok + (L.work_off - G.off));
+                    });
+                    if (rc) return rc;
+                }
+                if ((rc = walk_launch(P, d_work + G.off, G.cnt, ks, false, tag_or))) return rc;
+                if (!one_stream) {
+                    HIPCHK(h, hipEventRecord(h->ev_join[STRIP_CLS], ks));
+                    HIPCHK(h, hipStreamWaitEvent(base, h->ev_join[STRIP_CLS], 0));
                 }
             }
         }
@@ -2151,7 +2305,11 @@ struct Exec {
             zero_slots = false;
             h->dirty.insert(h->dirty.end(), P.work.begin(), P.work.end());
             if (lv == LV_DENSE) {
-                if ((rc = run_dense(P, dw, c.ls, true, tag_or))) return rc;
+                // (several kernel classes: side by side on the class streams -- the largest alignment of the largest class is
+                // the critical path of a batch of long alignments, it should not wait for the smaller classes)
+                bool many = false;
+                for (const Chunk &ch : P.chunks) many = many || ch.launches.size() > 1;
+                if ((rc = run_dense(P, dw, c.ls, !many || tag_or != 0, tag_or))) return rc;     // (a tie round's replays share one scratch)
             } else {
                 for (const Chunk &ch : P.chunks) {
                     if (c.slot_cur + 2 > LadderCtx::N_SLOTS) {   // out of fail slots: drain what is in flight
@@ -2722,6 +2880,7 @@ extern "C" {
 int vpr_execute(vpr_handle *h) {
     if (!h) return VPR_ERR_ARG;
     if (!h->uploaded) return fail(h, VPR_ERR_STATE, "vpr_execute before vpr_upload");
+    for (auto &b : h->exec_blks) b.used = false;
     Exec x(h);
     const int rc = x.run();
     if (x.t0) (void)hipEventDestroy(x.t0);

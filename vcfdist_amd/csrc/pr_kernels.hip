@@ -152,7 +152,8 @@ template <int C> __device__ __forceinline__ void unpack_flags(const FlagReg<C> &
 template <int NT, int C>
 __global__ void __launch_bounds__(NT) k_fwd(DevBatch B, const AlnDesc *__restrict__ descs,
                                             const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
-                                            AlnOut *__restrict__ outs) {
+                                            AlnOut *__restrict__ outs, const int32_t *__restrict__ skip) {
+    if (skip && skip[blockIdx.x]) return;      // (done by the strip kernels, pr_strip.hip)
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -395,7 +396,8 @@ __device__ __forceinline__ void block_suffix_mp2(MP gq, MP gr, int &inq, int &in
 template <int NT, int C, bool S16>
 __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restrict__ descs,
                                             const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
-                                            AlnOut *__restrict__ outs) {
+                                            AlnOut *__restrict__ outs, const int32_t *__restrict__ skip) {
+    if (skip && skip[blockIdx.x]) return;
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     const int tid = threadIdx.x;

@@ -1,0 +1,648 @@
+// pr_strip.hip -- the dense level for WIDE alignments: one alignment spread over several workgroups (compute units).
+//
+// A dense sweep is sequential over the truth rows and, inside a workgroup, bound by one compute unit's issue rate: a
+// 12 000 x 24 000 alignment with a one-sided SV (distance in the thousands, so no window level accepts it) took 0.2 s
+// forward and 0.7 s backward in one 1024-thread workgroup whose per-thread state no longer fits the register file.  Here
+// the columns are cut into STRIPS of at most ST_NT * C cells per plane, one workgroup each, and the strips of an
+// alignment run as a pipeline over the rows:
+//   * every edge of the two-plane graph leads to the same or a larger column (MAT / SUB / INS: +1, DEL: same, swap:
+//     pointer + 1 in the other plane, and the pointers are monotone), so strip j only needs values from strip j - 1
+//     (forward sweep) or strip j + 1 (backward sweep: the edges reversed);
+//   * the cuts are placed where the planes map 1:1 onto each other (k_strip_plan), so exactly ONE cell per plane and row
+//     crosses a cut: the neighbour's last (first) column.  It is handled as a GHOST cell of the consuming strip -- a cell
+//     whose value is given -- and everything else (diagonal move, INS chain, swap sources, the backward max-plus chain)
+//     is the single-workgroup code unchanged;
+//   * a strip publishes its boundary column in blocks of 64 rows (values staged in LDS, one coalesced store, a release
+//     of its progress counter); the consumer acquires the counter once per 64 rows.  Workgroups are dispatched in
+//     blockIdx order and a strip only ever waits for a strip with a smaller blockIdx, so the wait cannot deadlock.
+// Flag matrices, results and everything downstream (walk, credit) are those of k_fwd / k_bwd (pr_kernels.hip): dist.cpp
+// :251-443 (forward), :486-823 (backward).
+#ifndef PR_STRIP_HIP_
+#define PR_STRIP_HIP_
+
+#define ST_NT 1024
+#define ST_C 4
+#define ST_CAP (ST_NT * ST_C - 8)     // columns of one plane a strip may hold (ghost + alignment slack taken off)
+
+struct StripTab { int32_t lo[2], hi[2]; };      // columns [lo[p], hi[p]) of plane p (0 QUERY, 1 REF)
+
+// Cuts of every alignment of a launch.  One thread per alignment: from the last cut, the furthest column of the REF plane
+// (and the QUERY column it maps to) within ST_CAP of the cut in both planes where both planes map 1:1 onto each other
+// and the two cells behind the cut have the cells in front of it as their only swap source.
+//   tab_base[i]..tab_base[i+1]: the slots of alignment i (an alignment that needs more, or has no such column, gets
+//   ok[i] = 0 and n_strips[i] = 0: it is left to the single-workgroup kernels)
+__global__ void k_strip_plan(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ work, int n,
+                             const int32_t *__restrict__ tab_base, StripTab *__restrict__ tab, int32_t *__restrict__ n_strips,
+                             int32_t *__restrict__ ok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AlnDesc d = descs[work[i]];
+    const int Lq = d.Lq, Lr = d.Lr;
+    const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off, *r2q = B.ref_ptr[d.qs] + d.r_off;
+    const int4 *cq = B.cand_q[d.qs] + d.q_off, *cr = B.cand_r[d.qs] + d.r_off;
+    const int max_n = tab_base[i + 1] - tab_base[i];
+    StripTab *T = tab + tab_base[i];
+    int r_lo = 0, q_lo = 0, j = 0;
+    bool good = true;
+    for (;;) {
+        if (j >= max_n) { good = false; break; }
+        if (Lr - r_lo <= ST_CAP && Lq - q_lo <= ST_CAP) {
+            T[j].lo[0] = q_lo; T[j].lo[1] = r_lo; T[j].hi[0] = Lq; T[j].hi[1] = Lr;
+            j++;
+            break;
+        }
+        int fr = -1, fq = -1;
+        for (int r = min(r_lo + ST_CAP, Lr - 1); r > r_lo; r--) {
+            const int q = r2q[r];
+            if (q <= q_lo) break;                       // (monotone: nothing further left qualifies)
+            if (q - q_lo > ST_CAP || q >= Lq) continue;
+            if (r2q[r - 1] != q - 1 || q2r[q] != r || q2r[q - 1] != r - 1) continue;
+            const int4 a = cr[r], b = cq[q];
+            if (!(a.x < 0 || (a.x == q - 1 && a.y < 0))) continue;
+            if (!(b.x < 0 || (b.x == r - 1 && b.y < 0))) continue;
+            fr = r; fq = q;
+            break;
+        }
+        if (fr < 0) { good = false; break; }
+        T[j].lo[0] = q_lo; T[j].lo[1] = r_lo; T[j].hi[0] = fq; T[j].hi[1] = fr;
+        j++;
+        r_lo = fr; q_lo = fq;
+    }
+    n_strips[i] = good ? j : 0;
+    ok[i] = good ? 1 : 0;
+}
+
+// cell roles of a thread's chunk
+#define ST_REAL 1
+#define ST_GHOST 2
+
+// ---------------------------------------------------------------------------
+// K1 over strips.  prog[slot]: rows a strip has published; bnd[bnd_off[i] + j * Lt + t] = {D(QUERY, last column of strip j,
+// row t), D(REF, ...)}.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ work,
+                                                     int n, const int32_t *__restrict__ tab_base, const StripTab *__restrict__ tab,
+                                                     const int32_t *__restrict__ n_strips, const int64_t *__restrict__ bnd_off,
+                                                     int2 *__restrict__ bnd, int32_t *__restrict__ prog, uint8_t *__restrict__ ws,
+                                                     AlnOut *__restrict__ outs) {
+    constexpr int NT = ST_NT, C = ST_C, NC = NT * C;
+    int i;
+    {
+        int lo = 0, hi = n;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tab_base[mid] <= int(blockIdx.x)) lo = mid; else hi = mid; }
+        i = lo;
+    }
+    const int j = int(blockIdx.x) - tab_base[i], ns = n_strips[i];
+    if (j >= ns) return;
+    const int a = work[i];
+    const AlnDesc d = descs[a];
+    const StripTab S = tab[tab_base[i] + j];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
+    const int Lp[2] = {Lq, Lr};
+    const bool has_left = j > 0, has_right = j + 1 < ns;
+    const int bal[2] = {max(S.lo[0] - 1, 0) & ~(C - 1), max(S.lo[1] - 1, 0) & ~(C - 1)};    // column of thread 0's first cell
+    __shared__ int32_t rowD[2][NC + 4];
+    __shared__ int32_t wsc[2 * (NT / 64)];
+    __shared__ int2 bin[64], bout[64];
+
+    const uint8_t *seq[2] = {B.hap_seq[d.qs] + d.q_off, B.ref_seq + d.r_off};
+    const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off;
+    const uint8_t *Tf = B.hap_flag[d.ts] + d.t_off;
+    const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
+    const int4 *cand2[2] = {B.cand2_q[d.qs] + d.q_off, B.cand2_r[d.qs] + d.r_off};
+    uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
+    const int rel0 = tid * C;
+    int2 *my_bnd = bnd + bnd_off[i] + int64_t(j) * Lt;                   // the column this strip publishes
+    const int2 *left_bnd = bnd + bnd_off[i] + int64_t(j - 1) * Lt;       // the column it consumes
+    int32_t *my_prog = prog + tab_base[i] + j;
+
+    // per-cell constants and roles
+    uint8_t sb[2][C];
+    int32_t c0[2][C];
+    uint32_t multi[2] = {0, 0}, real[2] = {0, 0}, ghost[2] = {0, 0};
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int q = bal[p] + rel0 + c;
+            sb[p][c] = 0xff;
+            c0[p][c] = -1;
+            if (q >= S.lo[p] && q < S.hi[p]) {
+                real[p] |= 1u << c;
+                sb[p][c] = seq[p][q];
+                const int4 cc = cand[p][q];
+                c0[p][c] = cc.x;
+                if (cc.y >= 0) multi[p] |= 1u << c;
+            } else if (has_left && q == S.lo[p] - 1) {
+                ghost[p] |= 1u << c;
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int c = 0; c < C; c++) asm volatile("" ::"v"(uint32_t(sb[p][c])), "v"(c0[p][c]));
+
+    // row 0: D = q (INS chain from the origin), dist.cpp:300-305,397-405; cells left of the ghost do not exist
+    int32_t dp[2][C];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int q = bal[p] + rel0 + c;
+            const bool left_ph = has_left && q < S.lo[p] - 1;
+            dp[p][c] = left_ph ? D_INF : q;
+            rowD[p][rel0 + c] = dp[p][c];
+            if (real[p] & (1u << c)) mat[p][q] = (q == 0) ? F_MAT : F_INS;
+        }
+    }
+    if (tid == 0) bout[0] = make_int2(S.hi[0] - 1, S.hi[1] - 1);
+    __syncthreads();
+
+    auto publish = [&](int t0, int t_last) {       // rows [t0, t_last] of this strip's last column
+        if (has_right) {
+            if (tid < 64 && t0 + tid <= t_last) my_bnd[t0 + tid] = bout[tid];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(my_prog, t_last + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (Lt == 1) publish(0, 0);
+
+    uint32_t tchunk = 0;
+    if (lane < Lt) tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
+    uint32_t tlast = 0;
+    for (int t = 1; t < Lt; t++) {
+        const int t0 = t & ~63;
+        if ((t & 63) == 0 || t == 1) {
+            if (has_left) {     // the left strip's column for the rows of this block
+                const int need = min(t0 + 64, Lt);
+                if (tid == 0)
+                    while (__hip_atomic_load(my_prog - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(4);
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (tid < 64 && t0 + tid < Lt) bin[tid] = left_bnd[t0 + tid];
+                __syncthreads();
+            }
+        }
+        if ((t & 63) == 0) {
+            tlast = __builtin_amdgcn_readlane(tchunk, 63);
+            const int tt = t + lane;
+            tchunk = 0;
+            if (tt < Lt) tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
+        }
+        const uint32_t cur = __builtin_amdgcn_readlane(tchunk, t & 63);
+        const uint32_t prv = ((t & 63) == 0) ? tlast : uint32_t(__builtin_amdgcn_readlane(tchunk, (t - 1) & 63));
+        const uint8_t Tt = cur & 0xff;
+        const bool at = fwd_allow(int((prv >> 8) & 0xff));   // truth flag of row t-1, dist.cpp:338-339
+        int2 gin = make_int2(0, 0);
+        if (has_left) gin = bin[t - t0];
+
+        int32_t bv[2][C];     // base - q
+        uint8_t mk[2][C];     // flags achieving base
+        int cmin[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int32_t *other = rowD[1 - p];
+            const int ob = bal[1 - p];
+            int diag = (rel0 > 0) ? rowD[p][rel0 - 1] : D_INF;
+            int run = D_INF;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int q = bal[p] + rel0 + c;
+                const int up = dp[p][c];
+                uint8_t m = 0;
+                int nb;
+                if (ghost[p] & (1u << c)) {
+                    nb = (p == 0 ? gin.x : gin.y) - q;
+                } else if (has_left && q < S.lo[p]) {
+                    nb = D_INF;
+                } else {
+                    const bool match = sb[p][c] == Tt;
+                    const int cm = match ? diag : diag + 1;
+                    int b = min(cm, up + 1);
+                    int sw = D_INF;
+                    int choice = 0;
+                    bool tie = false;
+                    if (match && at && c0[p][c] >= 0) {
+                        sw = other[c0[p][c] - ob];
+                        if (multi[p] & (1u << c)) {
+                            const int4 cc = cand[p][q];
+                            const int v1 = other[cc.y - ob];
+                            if (v1 <= sw) { tie = (v1 == sw); sw = v1; choice = 1; }
+                            if (cc.z >= 0) {
+                                const int v2 = other[cc.z - ob];
+                                if (v2 <= sw) { tie = (v2 == sw); sw = v2; choice = 2; }
+                                if (cc.w >= 0) {
+                                    const int v3 = other[cc.w - ob];
+                                    if (v3 <= sw) { tie = (v3 == sw); sw = v3; choice = 3; }
+                                    const int4 c2 = cand2[p][q];
+                                    const int more[4] = {c2.x, c2.y, c2.z, c2.w};
+                                    for (int k = 0; k < 4 && more[k] >= 0; k++) {
+                                        const int v = other[more[k] - ob];
+                                        if (v <= sw) { tie = (v == sw); sw = v; choice = 4 + k; }
+                                    }
+                                }
+                            }
+                        }
+                        b = min(b, sw);
+                    }
+                    if (match && diag == b) m |= F_MAT;
+                    if (diag + 1 == b) m |= F_SUB;
+                    if (up + 1 == b) m |= F_DEL;
+                    if (sw == b) m |= F_SWP | f_choice_bits(choice) | (tie ? F_TIE : 0);
+                    nb = b - q;
+                }
+                mk[p][c] = m;
+                bv[p][c] = nb;
+                run = min(run, nb);
+                diag = up;
+            }
+            cmin[p] = run;
+        }
+        int carryQ = cmin[0], carryR = cmin[1];
+        block_excl_prefix_min2<NT>(carryQ, carryR, wsc);   // barrier inside: all reads of rowD are done
+        const int carry[2] = {carryQ, carryR};
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            uint8_t fl[C];
+            int run = carry[p];
+            int left = carry[p] + bal[p] + rel0 - 1;   // D of the cell in front of the chunk in this row
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int q = bal[p] + rel0 + c;
+                const int nb = bv[p][c];
+                uint8_t f = 0;
+                if (nb <= run) { run = nb; f = mk[p][c]; }
+                const int Dn = min(run + q, D_INF);
+                if (left + 1 == Dn && q > 0) f |= F_INS;
+                fl[c] = f;
+                dp[p][c] = Dn;
+                left = Dn;
+                rowD[p][rel0 + c] = Dn;
+                if ((real[p] & (1u << c)) && q == S.hi[p] - 1) {
+                    if (p == 0) bout[t - t0].x = Dn; else bout[t - t0].y = Dn;
+                }
+            }
+            uint8_t *row = mat[p] + size_t(t) * d.pitch[p] + bal[p] + rel0;
+            if (real[p] == (1u << C) - 1) {
+                typename FlagVec<C>::T v;
+                __builtin_memcpy(&v, fl, C);
+                *reinterpret_cast<typename FlagVec<C>::T *>(row) = v;
+            } else if (real[p]) {
+#pragma unroll
+                for (int c = 0; c < C; c++) if (real[p] & (1u << c)) row[c] = fl[c];
+            }
+        }
+        lds_barrier<NT>();
+        if ((t & 63) == 63 || t == Lt - 1) publish(t0, t);
+    }
+    // end cells
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        if ((real[0] & (1u << c)) && bal[0] + rel0 + c == Lq - 1) outs[a].dist_q = dp[0][c];
+        if ((real[1] & (1u << c)) && bal[1] + rel0 + c == Lr - 1) outs[a].dist_r = dp[1][c];
+    }
+    (void)Lp;
+}
+
+// ---------------------------------------------------------------------------
+// K2 over strips, right to left.  A strip publishes, per row and plane, {score of its first column, that
+// cell's FORWARD flag byte} (the consumer's successor cell, whose flags the producer has overwritten by then);
+// bbnd[bnd_off[i] + j * Lt + t] is the record of strip j + 1's first column.  prog counts rows from the last one.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ work,
+                                                     int n, const int32_t *__restrict__ tab_base, const StripTab *__restrict__ tab,
+                                                     const int32_t *__restrict__ n_strips, const int64_t *__restrict__ bnd_off,
+                                                     int4 *__restrict__ bbnd, int32_t *__restrict__ prog, uint8_t *__restrict__ ws,
+                                                     AlnOut *__restrict__ outs) {
+    constexpr int NT = ST_NT, C = ST_C, NC = NT * C;
+    // One workgroup per alignment, its strips one after the other from the right: the optimal paths cross the strips one
+    // after the other, so strips side by side would mostly wait for each other (and hold a compute unit while they do);
+    // here a strip's rows off the paths are skipped in blocks, and the sweep costs what the paths' rows cost.
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int ns = n_strips[i];
+    for (int j = ns - 1; j >= 0; j--) {
+    const int a = work[i];
+    const AlnDesc d = descs[a];
+    const StripTab S = tab[tab_base[i] + j];
+    const int tid = threadIdx.x;
+    const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
+    const int Lp[2] = {Lq, Lr};
+    const bool has_left = j > 0, has_right = j + 1 < ns;
+    const int bal[2] = {max(S.lo[0] - 1, 0) & ~(C - 1), max(S.lo[1] - 1, 0) & ~(C - 1)};
+    __shared__ int32_t srow[2][NC + 4];                  // scores of row t+1
+    __shared__ uint8_t frow[2][2][NC + 16];              // [buffer][plane]: forward flags of rows t+1 / t
+    __shared__ int32_t wsc[4 * (NT / 64)];
+    __shared__ int4 rin[66], rout[64];                   // rin[x]: record of row (t0 - 1) + x
+    __shared__ int32_t actf[2];                          // [row parity]: a cell of the row has a score
+    __shared__ int32_t blk_or;
+    const int32_t *ptr[2] = {B.hap_ptr[d.qs] + d.q_off, B.ref_ptr[d.qs] + d.r_off};
+    const uint8_t *pfl[2] = {B.hap_flag[d.qs] + d.q_off, B.ref_flag[d.qs] + d.r_off};
+    const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
+    const int4 *cand2[2] = {B.cand2_q[d.qs] + d.q_off, B.cand2_r[d.qs] + d.r_off};
+    uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
+    const int rel0 = tid * C;
+    const int end_plane = outs[a].end_plane;
+    const bool inb[2] = {bal[0] + rel0 < d.pitch[0], bal[1] + rel0 < d.pitch[1]};     // the chunk starts inside the flag row
+    int4 *my_bnd = bbnd + bnd_off[i] + int64_t(j - 1) * Lt;              // what this strip publishes (boundary j-1 | j)
+    const int4 *right_bnd = bbnd + bnd_off[i] + int64_t(j) * Lt;         // what it consumes (boundary j | j+1)
+    int32_t *my_prog = prog + tab_base[i] + j;
+
+    // per-cell constants (pr_kernels.hip: k_bwd) and roles
+    int32_t zq[2][C];
+    uint8_t kc[2][C];
+    uint32_t real[2] = {0, 0}, ghost[2] = {0, 0};
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int q = bal[p] + rel0 + c;
+            zq[p][c] = -1;
+            kc[p][c] = 0;
+            const bool is_real = q >= S.lo[p] && q < S.hi[p];
+            const bool is_ghost = has_right && q == S.hi[p];
+            if (is_real) real[p] |= 1u << c;
+            if (is_ghost) ghost[p] |= 1u << c;
+            if ((is_real || is_ghost) && q < Lp[p]) {
+                const int pq = ptr[p][q];
+                const int fq = pfl[p][q];
+                if (p == 0 && q > 0 && ((pq != ptr[0][q - 1] + 1) || (fq & PB))) kc[p][c] |= 1;  // dist.cpp:572-574
+                const int z = pq + 1;
+                if (is_real && fwd_allow(fq) && z > 0 && z < Lp[1 - p] && bwd_allow(pfl[1 - p][z])) {
+                    const int4 cc = cand[1 - p][z];
+                    int rank = -1;
+                    if (cc.x == q) rank = 0; else if (cc.y == q) rank = 1; else if (cc.z == q) rank = 2; else if (cc.w == q) rank = 3;
+                    else if (cc.w >= 0) {
+                        const int4 c2 = cand2[1 - p][z];
+                        if (c2.x == q) rank = 4; else if (c2.y == q) rank = 5; else if (c2.z == q) rank = 6; else if (c2.w == q) rank = 7;
+                    }
+                    if (rank >= 0) {
+                        zq[p][c] = z - bal[1 - p];      // (index into the other plane's LDS rows)
+                        kc[p][c] |= uint8_t(rank_bits(rank));
+                        if (p == 1) {  // z on the QUERY plane: leaving it scores tp(z), dist.cpp:656-658
+                            const int pz = ptr[0][z];
+                            if ((pz != ptr[0][z - 1] + 1) || (pfl[0][z] & PB)) kc[p][c] |= 8;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // tp of the QUERY-plane cell right of this chunk (constant over rows)
+    int xtp_right = 0;
+    {
+        const int qn = bal[0] + rel0 + C;
+        if (qn < Lq && qn <= S.hi[0]) xtp_right = ((ptr[0][qn] != ptr[0][qn - 1] + 1) || (pfl[0][qn] & PB)) ? 1 : 0;
+    }
+
+    // the right strip's records for the rows of a block: rows [t0 - 1, t0 + 64] as far as they exist
+    auto acquire_block = [&](int t0) {
+        if (has_right) {
+            const int lowest = max(t0 - 1, 0);                 // lowest row needed
+            if (tid == 0)
+                while (__hip_atomic_load(my_prog + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < Lt - lowest) __builtin_amdgcn_s_sleep(4);
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (tid < 66) {
+                const int t = t0 - 1 + tid;
+                if (t >= 0 && t < Lt) rin[tid] = right_bnd[t];
+            }
+            __syncthreads();
+        }
+    };
+    auto publish = [&](int t0, int t_hi) {       // rows [t0, t_hi] of this strip's first column
+        if (has_left) {
+            if (tid < 64 && t0 + tid <= t_hi) my_bnd[t0 + tid] = rout[tid];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(my_prog, Lt - t0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
+    int32_t sc[2][C];   // scores of row t+1 (S_NEG = unreachable)
+    uint8_t f1[2][C];   // forward flags of row t+1
+    uint8_t f0[2][C];   // forward flags of row t
+    acquire_block((Lt - 1) & ~63);
+    {
+        const int t0 = (Lt - 1) & ~63;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            FlagReg<C> v = FlagReg<C>();
+            if (inb[p]) v = load_flags<C>(mat[p] + size_t(Lt - 1) * d.pitch[p] + bal[p] + rel0);
+            unpack_flags<C>(v, f0[p]);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                sc[p][c] = S_NEG; f1[p][c] = 0;
+                if (!(real[p] & (1u << c))) f0[p][c] = 0;
+                if (ghost[p] & (1u << c)) { const int4 R = rin[Lt - 1 - (t0 - 1)]; f0[p][c] = uint8_t(p == 0 ? R.y : R.w); }
+                srow[p][rel0 + c] = S_NEG;
+                frow[0][p][rel0 + c] = 0;
+                frow[1][p][rel0 + c] = f0[p][c];
+            }
+        }
+        if (tid == 0) {
+            for (int p = 0; p < 2; p++) { srow[p][NC] = S_NEG; frow[0][p][NC] = 0; frow[1][p][NC] = 0; }
+            actf[0] = actf[1] = 0;
+        }
+    }
+    lds_barrier<NT>();
+    uint32_t tie_used = 0;
+    FlagReg<C> pf[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        pf[p] = FlagReg<C>();
+        if (Lt >= 2 && inb[p]) pf[p] = load_flags<C>(mat[p] + size_t(Lt - 2) * d.pitch[p] + bal[p] + rel0);
+    }
+
+    for (int t = Lt - 1; t >= 0; t--) {
+        const int t0 = t & ~63;
+        if ((t & 63) == 63 && t != Lt - 1) {
+            acquire_block(t0);
+            // A whole block of 64 rows off the optimal paths -- nothing in the row above it, nothing coming in from the right
+            // in any of its rows -- is cleared without sweeping it: the flags of its rows become 0, the records for the left
+            // neighbour say "no score", and the sweep resumes below it.
+            blk_or = 0;
+            __syncthreads();
+            if (tid < 64 && has_right) { const int4 Rr = rin[tid + 1]; if (Rr.x >= 0 || Rr.z >= 0) blk_or = 1; }
+            if (tid == 0 && actf[(t + 1) & 1]) blk_or = 1;
+            __syncthreads();
+            if (!blk_or) {
+                if (tid < 64 && has_left)      // the forward flags of this strip's first column, before they are cleared
+                    rout[tid] = make_int4(S_NEG, mat[0][size_t(t0 + tid) * d.pitch[0] + S.lo[0]], S_NEG, mat[1][size_t(t0 + tid) * d.pitch[1] + S.lo[1]]);
+                __syncthreads();
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    if (!real[p]) continue;
+                    for (int r = t; r >= t0; r--) {
+                        uint8_t *row = mat[p] + size_t(r) * d.pitch[p] + bal[p] + rel0;
+                        if (real[p] == (1u << C) - 1) {
+                            *reinterpret_cast<typename FlagVec<C>::T *>(row) = typename FlagVec<C>::T();
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < C; c++) if (real[p] & (1u << c)) row[c] = 0;
+                        }
+                    }
+                }
+                publish(t0, t);
+                if (t0 > 0) {       // state for row t0 - 1: its forward flags (the ghost's from the record), nothing scored above
+                    const int curm = (Lt - 1 - (t0 - 1) + 1) & 1;
+                    const int4 Rg = has_right ? rin[0] : make_int4(S_NEG, 0, S_NEG, 0);
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        FlagReg<C> v = FlagReg<C>();
+                        if (inb[p]) v = load_flags<C>(mat[p] + size_t(t0 - 1) * d.pitch[p] + bal[p] + rel0);
+                        unpack_flags<C>(v, f0[p]);
+                        pf[p] = FlagReg<C>();
+                        if (t0 > 1 && inb[p]) pf[p] = load_flags<C>(mat[p] + size_t(t0 - 2) * d.pitch[p] + bal[p] + rel0);
+#pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            sc[p][c] = S_NEG; f1[p][c] = 0;
+                            if (!(real[p] & (1u << c))) f0[p][c] = 0;
+                            if (ghost[p] & (1u << c)) f0[p][c] = uint8_t(p == 0 ? Rg.y : Rg.w);
+                            frow[curm][p][rel0 + c] = f0[p][c];
+                        }
+                    }
+                    if (tid == 0) actf[0] = actf[1] = 0;
+                    lds_barrier<NT>();
+                }
+                t = t0;
+                continue;
+            }
+        }
+        const int cur = (Lt - 1 - t + 1) & 1;      // buffer holding row t's forward flags
+        const int nxt = cur ^ 1;                   // buffer holding row t+1's forward flags
+        int4 R = make_int4(S_NEG, 0, S_NEG, 0), Rm = make_int4(S_NEG, 0, S_NEG, 0);      // records of rows t and t-1
+        if (has_right) { R = rin[t - (t0 - 1)]; if (t > 0) Rm = rin[t - 1 - (t0 - 1)]; }
+
+        // A row in which no cell of the strip can be on an optimal path -- none was in the row below, and nothing comes in
+        // from the strip to the right -- only clears its flags: the optimal paths of an alignment are a thin bundle, most
+        // strips are off it in most rows.
+        const bool act = t == Lt - 1 || actf[(t + 1) & 1] != 0 || R.x >= 0 || R.z >= 0;
+        if (tid == 0) actf[t & 1] = 0;
+        int32_t base[2][C];
+        uint8_t bm[2][C];
+        int8_t lk[2][C];      // INS link from cell c+1 into c: tp value (0/1) or -1 broken
+        int inq = S_NEG, inr = S_NEG;
+        if (!act) {
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int c = 0; c < C; c++) { base[p][c] = S_NEG; bm[p][c] = 0; lk[p][c] = -1; }
+        } else {
+        MP g[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int o = 1 - p;
+            int xs_r = srow[p][rel0 + C];
+            int xf_r = frow[nxt][p][rel0 + C], xf0_r = frow[cur][p][rel0 + C];
+            int xtp_r = (p == 0) ? xtp_right : 0;
+            MP G; G.A = S_NEG; G.B = 0;
+            bool first = true;
+#pragma unroll
+            for (int c = C - 1; c >= 0; c--) {
+                const int q = bal[p] + rel0 + c;
+                const int xs = (c == C - 1) ? xs_r : sc[p][c + 1];
+                const int xf = (c == C - 1) ? xf_r : f1[p][c + 1];
+                const int xtp = (c == C - 1) ? xtp_r : (kc[p][c + 1] & 1);
+                int best = S_NEG; uint8_t m = 0;
+                int l = -1;
+                if (real[p] & (1u << c)) {
+                    if (f_diag(xf)) {
+                        best = xs + xtp; m = uint8_t(f_diag(xf));
+                    }
+                    if (f1[p][c] & F_DEL) {
+                        const int v = sc[p][c];
+                        if (v > best) { best = v; m = F_DEL; } else if (v == best) m |= F_DEL;
+                    }
+                    if (zq[p][c] >= 0) {
+                        const int zf = frow[nxt][o][zq[p][c]];
+                        if ((zf & F_SWP) && f_choice_of(zf) == rank_of(kc[p][c])) {
+                            const int v = srow[o][zq[p][c]] + ((kc[p][c] >> 3) & 1);
+                            if (v >= 0 && (zf & F_TIE)) tie_used++;
+                            if (v > best) { best = v; m = F_SWP; } else if (v == best) m |= F_SWP;
+                        }
+                    }
+                    if (t == Lt - 1 && p == end_plane && q == Lp[p] - 1) { best = 0; m = F_MAT; }  // dist.cpp:538-546
+                    const int xf0 = (c == C - 1) ? xf0_r : f0[p][c + 1];
+                    l = (xf0 & F_INS) ? xtp : -1;
+                } else if (ghost[p] & (1u << c)) {
+                    best = (p == 0) ? R.x : R.z;       // its score in this row is final: nothing flows in
+                }
+                base[p][c] = best;
+                bm[p][c] = m;
+                lk[p][c] = int8_t(l);
+                MP F; F.A = best; F.B = l;
+                if (first) { G = F; first = false; } else G = mp_compose(F, G);
+            }
+            g[p] = G;
+        }
+        block_suffix_mp2<NT>(g[0], g[1], inq, inr, wsc);   // barrier: all reads of the score rows / flag buffer nxt done
+        }
+        const int inc[2] = {inq, inr};
+        uint8_t out[2][C];
+        bool anyp = false;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            int prev = inc[p];
+            uint8_t fnew[C];
+            if (t > 0) unpack_flags<C>(pf[p], fnew);   // row t-1 flags (requested one row ago)
+#pragma unroll
+            for (int c = C - 1; c >= 0; c--) {
+                int v = base[p][c];
+                uint8_t m = bm[p][c];
+                if (lk[p][c] >= 0) {
+                    const int w = prev + lk[p][c];
+                    if (w > v) { v = w; m = F_INS; } else if (w == v) m |= F_INS;
+                }
+                if (v < 0) { v = S_NEG; m = 0; }
+                sc[p][c] = v;
+                anyp = anyp || v >= 0;
+                out[p][c] = m ? uint8_t(m | (f0[p][c] & F_KEEP)) : uint8_t(0);
+                prev = v;
+                f1[p][c] = f0[p][c];
+                if (act) srow[p][rel0 + c] = v;
+                if ((real[p] & (1u << c)) && bal[p] + rel0 + c == S.lo[p]) {       // this strip's first column: published
+                    if (p == 0) { rout[t - t0].x = v; rout[t - t0].y = f1[p][c]; } else { rout[t - t0].z = v; rout[t - t0].w = f1[p][c]; }
+                }
+                if (t > 0) {
+                    uint8_t nf = (real[p] & (1u << c)) ? fnew[c] : uint8_t(0);
+                    if (ghost[p] & (1u << c)) nf = uint8_t(p == 0 ? Rm.y : Rm.w);
+                    f0[p][c] = nf;
+                    frow[nxt][p][rel0 + c] = nf;   // nxt becomes "cur" of row t-1
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            if (t > 1 && inb[p]) pf[p] = load_flags<C>(mat[p] + size_t(t - 2) * d.pitch[p] + bal[p] + rel0);
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            uint8_t *row = mat[p] + size_t(t) * d.pitch[p] + bal[p] + rel0;
+            if (real[p] == (1u << C) - 1) {
+                typename FlagVec<C>::T v;
+                __builtin_memcpy(&v, out[p], C);
+                *reinterpret_cast<typename FlagVec<C>::T *>(row) = v;
+            } else if (real[p]) {
+#pragma unroll
+                for (int c = 0; c < C; c++) if (real[p] & (1u << c)) row[c] = out[p][c];
+            }
+        }
+        if (anyp) actf[t & 1] = 1;
+        lds_barrier<NT>();
+        if ((t & 63) == 0) publish(t0, min(t0 + 63, Lt - 1));
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            if (bal[0] + rel0 + c == 0) outs[a].beg_plane = (sc[0][c] >= 0) ? VPR_PLANE_QUERY : VPR_PLANE_REF;   // dist.cpp:811-814
+    }
+    if (tie_used) { atomicOr(&outs[a].status, VPR_ST_SWAP_TIE); outs[a].band_ok = TIE_MARK(0); atomicAdd(&outs[a].n_sec, int(tie_used)); }
+    __threadfence();
+    __syncthreads();
+    }
+}
+
+#endif
