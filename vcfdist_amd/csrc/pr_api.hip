@@ -123,12 +123,19 @@ class ParPool {
     void worker() {
         for (;;) {
             Job *job;
-            {
+            size_t t;
+            {   // (a task is claimed under the lock that found the job: a job with an unfinished task cannot go away)
                 std::unique_lock<std::mutex> g(m_);
                 cv_.wait(g, [&] { return !jobs_.empty(); });
                 job = jobs_.front();
+                t = job->next++;
+                if (job->next >= job->nt) jobs_.pop_front();
             }
-            work_on(*job);
+            (*job->task)(t);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (++job->done == job->nt) job->done_cv.notify_all();
+            }
         }
     }
     std::mutex m_;
@@ -1984,7 +1991,7 @@ struct Exec {
                                        d_work + L.work_off, P.arena, h->d_outs, skip);
                 });
                 if (rc) return rc;
-                if ((rc = walk_launch(P, d_work + L.work_off, L.count, ks, false, tag_or))) return rc;
+                if ((rc = walk_launch(P, d_work + L.work_off, L.count, ks, L.count < 2048, tag_or))) return rc;
                 if (!one_stream) {
                     HIPCHK(h, hipEventRecord(h->ev_join[L.cls], ks));
                     HIPCHK(h, hipStreamWaitEvent(base, h->ev_join[L.cls], 0));
@@ -2028,7 +2035,7 @@ struct Exec {
                     });
                     if (rc) return rc;
                 }
-                if ((rc = walk_launch(P, d_work + G.off, G.cnt, ks, false, tag_or))) return rc;
+                if ((rc = walk_launch(P, d_work + G.off, G.cnt, ks, G.cnt < 2048, tag_or))) return rc;
                 if (!one_stream) {
                     HIPCHK(h, hipEventRecord(h->ev_join[STRIP_CLS], ks));
                     HIPCHK(h, hipStreamWaitEvent(base, h->ev_join[STRIP_CLS], 0));
@@ -2109,7 +2116,7 @@ struct Exec {
         }
         if (!(phases & 4)) return rc;
         // long part (or a small launch of long retries): wave-per-alignment walk; windows up to 256
-        const bool wave_walk = !q16 && C <= 4 && (long_part || cnt < 2048);
+        const bool wave_walk = !q16 && (long_part || cnt < 2048);      // (k_walk<wave> stages tiles around the walk for the wider windows)
         const bool row_walk = lv == LV_C1 && wave_walk;
         vpr_launch_stat ws_;
         memset(&ws_, 0, sizeof(ws_));

@@ -880,6 +880,7 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
     const uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     const int q_size = d.Lq, r_size = d.Lr, t_size = d.Lt;
     const bool banded = d.band_w > 0;   // rows hold cells [blo[t], blo[t]+band_w) of each plane
+    const bool wide = WAVE && (!banded || d.band_w > WALK_TW);
     const int32_t *blo = blo_all + d.blo_off;
     PathEnt *path = paths + d.path_off;
     uint32_t status = 0;
@@ -927,7 +928,38 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
     bool ok = true;
     while ((hi == ri && qri < r_size - 1) || (hi == qi && qri < q_size - 1) || ti < t_size - 1) {
         int p;
-        if (WAVE) {
+        if (WAVE && wide) {
+            // dense rows / windows wider than the tile: the tile holds WALK_TW columns of each plane around the walk's
+            // position (the other plane's around the position it maps to) and is staged again when the walk leaves it
+            const int r0 = ti - tile_t0;
+            int colw = (r0 >= 0 && r0 < WALK_TR) ? qri - tblo[hi * WALK_TR] : -1;
+            if (colw < 0 || colw >= WALK_TW) {
+                tile_t0 = ti;
+                const int rows = min(WALK_TR, t_size - ti);
+                const int other = col_get(hi, qri).x;       // q2r / r2q of the position
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                    const int pos = (pl == hi) ? qri : other;
+                    const int c0 = max(0, min(pos - 64, (pl == 0 ? q_size : r_size) - WALK_TW));
+                    for (int r = 0; r < rows; r++) {
+                        const int org = banded ? blo[pl * t_size + ti + r] : 0;
+                        const int wdt = banded ? d.band_w : (pl == 0 ? q_size : r_size);
+                        const uint8_t *src = mat[pl] + size_t(ti + r) * d.pitch[pl];
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int x = c0 + lane * 4 + k - org;
+                            if (x >= 0 && x < wdt) v |= uint32_t(src[x]) << (8 * k);
+                        }
+                        *reinterpret_cast<uint32_t *>(tile + (pl * WALK_TR + r) * WALK_TW + lane * 4) = v;
+                    }
+                    if (lane == 0) tblo[pl * WALK_TR] = c0;
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                colw = qri - tblo[hi * WALK_TR];
+            }
+            p = tile[(hi * WALK_TR + (ti - tile_t0)) * WALK_TW + colw] & 31;
+        } else if (WAVE) {
             if (ti >= tile_t0 + WALK_TR) {   // stage the next WALK_TR rows of both planes (uniform branch)
                 tile_t0 = ti;
                 const int rows = min(WALK_TR, t_size - ti);
