@@ -172,8 +172,32 @@ def test_sv_sized_indels_long_alignments_against_the_oracle(seed):
           f"{t.n_band_retries} retries, wf_ed {t.ms_ed:.2f} ms, largest ref_ed {int(max(got.ref_ed[2][0].max(), got.ref_ed[3][0].max()))}")
     names = {s.kernel.decode() for s in pr.launch_stats()}
     assert t.ms_ed > 0 and t.n_band_retries > 0 and any(n.startswith("k_fwd<") for n in names)
+    assert "k_fwd_strip" in names and "k_bwd_strip" in names        # the wide alignments of the dense level: over column strips
     if seed == 64017:
         assert any("s16" in n for n in names)
+
+
+def test_dense_strips_and_what_the_strip_planner_cannot_cut():
+    """dense plan over 9 000-base haplotypes: the alignments of the query haplotype without the SV run as column strips
+    (three workgroups each, pr_strip.hip); the other query haplotype carries a 5 000-base insertion, more columns than one
+    strip holds and no column inside it where the planes map 1:1, so the planner leaves its two alignments to the
+    one-workgroup kernels (skip lists).  Both against the oracle."""
+    rng = np.random.RandomState(17)
+    L = 9000
+    ref = "".join(rng.choice(list("ACGT"), L))
+    ins = "".join(rng.choice(list("ACGT"), 5000))
+    S, I, D = A.TYPE_SUB, A.TYPE_INS, A.TYPE_DEL
+    other = lambda c: "ACGT"[("ACGT".index(c) + 1) % 4]
+    q1 = [(3000, I, "", ins, 30.0), (6000, S, ref[6000], other(ref[6000]), 30.0)]
+    q2 = [(2000, D, ref[2000:2040], "", 20.0), (6000, S, ref[6000], other(ref[6000]), 30.0)]
+    t1 = [(6000, S, ref[6000], other(ref[6000]), 40.0), (7000, S, ref[7000], other(ref[7000]), 40.0)]
+    t2 = [(2000, D, ref[2000:2040], "", 40.0), (4500, I, "", ins[:90], 40.0)]
+    v = A.Variants.from_sites([ref], [dict(ctg=0, beg=100, end=8900, vars=[q1, q2, t1, t2])])
+    batch = api.batch_from_variants(v)
+    got, want, _, pr = compare(batch, A.default_config(band_mode=0))
+    names = {s.kernel.decode() for s in pr.launch_stats()}
+    assert "k_fwd_strip" in names and "k_bwd_strip" in names and any(n.startswith("k_fwd<1024") for n in names)
+    assert want.aln_dist[0] <= 2 and want.aln_dist[3] >= 90
 
 
 def test_dense_backward_int16_rows_forced():
