@@ -443,6 +443,10 @@ def main():
         swept_gbs = (byt / nl) / avg_s / 1e9
         traffic = valu_frac = None
         prof_src = None
+        # SIMDs and shader clock of the device this run is on (the fallbacks are MI355X's: 256 CUs x 4 SIMDs, 2.4 GHz)
+        props = torch.cuda.get_device_properties(dev)
+        n_simd = 4 * int(getattr(props, "multi_processor_count", 0) or N_SIMD // 4)
+        sclk_hz = float(getattr(props, "clock_rate", 0) or 0) * 1e3 or SCLK_HZ
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_counters_{args.workload}.json")))
             if prof["workload"] == args.workload and prof["superclusters_per_gpu"] == args.n_sc and kname in prof["kernels"]:
@@ -452,7 +456,7 @@ def main():
                 # VALU issue: quad-cycles a wave spends issuing VALU instructions x waves, over the SIMD-quad-cycles of the
                 # launch (1024 SIMDs x its duration at the 2.4 GHz the counters' SQ_BUSY_CYCLES imply)
                 if k.get("valu_active_per_wave") and k.get("waves"):
-                    valu_frac = k["valu_active_per_wave"] * 4 * k["waves"] / (N_SIMD * avg_s * SCLK_HZ)
+                    valu_frac = k["valu_active_per_wave"] * 4 * k["waves"] / (n_simd * avg_s * sclk_hz)
                 prof_src = f"profiles/{PROFILE_TAG}_counters_{args.workload}.json"
         except (OSError, KeyError, ValueError):
             pass
@@ -469,6 +473,7 @@ def main():
             "dense_equivalent": {"bytes_per_launch": int(dense_bytes), "cells_per_launch": int(dense / nl),
                                  "GB/s": round(dense_gbs, 2), "frac": round(dense_gbs / HBM_PEAK_GBS, 5)},
             "counters_source": prof_src,
+            "device": {"name": props.name, "simds": n_simd, "sclk_hz": sclk_hz},
             "alone": None,
             "note": "frac = HBM traffic of the dominant sweep kernel (PMC counters) / its launch duration (HIP events, this run) / "
                     "8 TB/s; the kernel is an integer scan that is issue- and latency-bound, not HBM-bound: see valu_issue_frac "

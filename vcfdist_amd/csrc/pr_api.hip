@@ -1907,7 +1907,8 @@ struct Exec {
         return VPR_OK;
     }
 
-    int run_dense(const Plan &P, const int32_t *d_work, hipStream_t base, bool one_stream, int tag_or = 0) {
+    // from_window: the plan's alignments failed the exit test of a window level (their AlnOut::s is that level's distance)
+    int run_dense(const Plan &P, const int32_t *d_work, hipStream_t base, bool one_stream, int tag_or = 0, bool from_window = false) {
         const int STRIP_CLS = 4;      // kernel classes from 1024 threads x 8 cells on: alignments wider than 2048 columns
         for (const Chunk &ch : P.chunks) {
             if (!one_stream) HIPCHK(h, hipEventRecord(h->ev_fork, base));
@@ -1935,7 +1936,7 @@ struct Exec {
                     ls.cells_dense = ls.cells; ls.bytes_algorithmic = ls.cells;
                     rc = timed(1, ls, ks, "k_fwd_strip", [&] {
                         hipLaunchKernelGGL(k_fwd_strip, dim3(G.grid), dim3(ST_NT), 0, ks, h->dB, h->d_descs, d_work + g_off, g_cnt, G.d_base,
-                                           G.d_tab, G.d_n, G.d_boff, G.d_bnd, G.d_prog, P.arena, h->d_outs);
+                                           G.d_tab, G.d_n, G.d_boff, G.d_bnd, G.d_prog, P.arena, h->d_outs, from_window ? 1 : 0);
                     });
                     if (rc) return rc;
                 }
@@ -2316,7 +2317,7 @@ struct Exec {
                 // the critical path of a batch of long alignments, it should not wait for the smaller classes)
                 bool many = false;
                 for (const Chunk &ch : P.chunks) many = many || ch.launches.size() > 1;
-                if ((rc = run_dense(P, dw, c.ls, !many || tag_or != 0, tag_or))) return rc;     // (a tie round's replays share one scratch)
+                if ((rc = run_dense(P, dw, c.ls, !many || tag_or != 0, tag_or, !tie))) return rc;     // (a tie round's replays share one scratch)
             } else {
                 for (const Chunk &ch : P.chunks) {
                     if (c.slot_cur + 2 > LadderCtx::N_SLOTS) {   // out of fail slots: drain what is in flight

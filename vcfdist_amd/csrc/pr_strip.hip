@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *
                                                      int n, const int32_t *__restrict__ tab_base, const StripTab *__restrict__ tab,
                                                      const int32_t *__restrict__ n_strips, const int64_t *__restrict__ bnd_off,
                                                      int2 *__restrict__ bnd, int32_t *__restrict__ prog, uint8_t *__restrict__ ws,
-                                                     AlnOut *__restrict__ outs) {
+                                                     AlnOut *__restrict__ outs, int use_ub) {
     constexpr int NT = ST_NT, C = ST_C, NC = NT * C;
     int i;
     {
@@ -105,6 +105,14 @@ __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *
     __shared__ int32_t rowD[2][NC + 4];
     __shared__ int32_t wsc[2 * (NT / 64)];
     __shared__ int2 bin[64], bout[64];
+    __shared__ int32_t blk_min;
+    // use_ub: the alignment comes from a window level whose exit test failed; the distance that level found (paths inside
+    // its window only) bounds the true one from above.  A cell beyond the bound is on no optimal path, and neither is
+    // anything reached through it: a block of 64 rows in which every cell of the strip (and what comes in from the left)
+    // is beyond it is not swept -- its cells count as unreachable, its flags are never read (the backward sweep only
+    // follows flags of cells on optimal paths, and clears the rest).
+    int s_ub = D_INF;
+    if (use_ub) { const int sv = outs[a].s; if (sv >= 0 && sv < D_INF / 2) s_ub = sv; }
 
     const uint8_t *seq[2] = {B.hap_seq[d.qs] + d.q_off, B.ref_seq + d.r_off};
     const uint8_t *Ts = B.hap_seq[d.ts] + d.t_off;
@@ -185,9 +193,35 @@ __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *
                 if (tid < 64 && t0 + tid < Lt) bin[tid] = left_bnd[t0 + tid];
                 __syncthreads();
             }
+            if (s_ub < D_INF) {
+                if (tid == 0) blk_min = D_INF;
+                __syncthreads();
+                int m = D_INF;
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+#pragma unroll
+                    for (int c = 0; c < C; c++) if (real[p] & (1u << c)) m = min(m, dp[p][c]);
+                if (has_left && tid < 64 && t0 + tid < Lt) m = min(m, min(bin[tid].x, bin[tid].y));
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) m = min(m, __shfl_xor(m, o));
+                if (lane == 0) atomicMin(&blk_min, m);
+                __syncthreads();
+                if (blk_min > s_ub) {
+                    const int t_end = min(t0 + 63, Lt - 1);
+#pragma unroll
+                    for (int p = 0; p < 2; p++)
+#pragma unroll
+                        for (int c = 0; c < C; c++) { dp[p][c] = D_INF; rowD[p][rel0 + c] = D_INF; }
+                    if (tid < 64) bout[tid] = make_int2(D_INF, D_INF);
+                    __syncthreads();
+                    publish(t0, t_end);
+                    t = t_end;
+                    continue;
+                }
+            }
         }
         if ((t & 63) == 0) {
-            tlast = __builtin_amdgcn_readlane(tchunk, 63);
+            tlast = uint32_t(Ts[t - 1]) | (uint32_t(Tf[t - 1]) << 8);
             const int tt = t + lane;
             tchunk = 0;
             if (tt < Lt) tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
