@@ -83,10 +83,11 @@ extern "C" {
 
 /* return codes */
 #define VPR_OK            0
-#define VPR_ERR_ARG      -1   /* also: an alignment that needs the dense kernels with Lq + Lr above ~40 000 (their LDS rows),
-                                 vpr_last_error names the supercluster; see DESIGN.md section 4 */
+#define VPR_ERR_ARG      -1   /* also (vpr_execute): an alignment of the dense level wider than one workgroup holds (Lq + Lr above
+                                 ~40 000) that cannot be cut into column strips either -- an insertion of more than 4 088
+                                 bases; see DESIGN.md section 4 */
 #define VPR_ERR_DEVICE   -2   /* no HIP device / HIP runtime error: there is NO CPU fallback */
-/* vpr_upload also returns VPR_ERR_ARG when more than four allowed swap sources map onto one position (four or more
+/* vpr_upload also returns VPR_ERR_ARG when more than eight allowed swap sources map onto one position (nine or more
    directly adjacent separate indel records on one haplotype): an implementation limit, see DESIGN.md section 4 */
 #define VPR_ERR_NOMEM    -3
 #define VPR_ERR_STATE    -4

@@ -209,7 +209,7 @@ def test_sv_property_identical_callsets():
     """SV-sized variants carried by truth and query alike (the true positives of an SV evaluation), beyond what the oracle
     does in seconds: truth == query and all homozygous, so every distance is 0 and every variant a TP with credit 1.
     (A shared indel longer than the widest window still sends the alignment to the dense level -- the exit test is
-    evaluated at the cell a swap edge leaves from, where the bound is 0 -- so Lq + Lr has to stay below its 40 k.)"""
+    evaluated at the cell a swap edge leaves from, where the bound is 0.)"""
     syn = api.Synth(n_sc=24, len_mode=0, len_a=4000.0, len_b=13000.0, len_min=4000, len_max=13000, seed=62, var_per_base=0.0005,
                     p_snp=0.3, indel_mean=1500.0, p_keep=1.0, p_drop=0.0, p_hom=1.0)
     batch = syn.batch()
@@ -224,6 +224,25 @@ def test_sv_property_identical_callsets():
         for w in range(2):
             assert (r.errtype[h][w] == A.ERRTYPE_TP).all() and (r.credit[h][w] == 1.0).all() and (r.query_ed[h][w] == 0).all()
             assert (r.ref_ed[h][w] >= 1).all()
+
+
+def test_dense_level_beyond_one_workgroup():
+    """haplotypes of 22-30 k bases at the dense level (band_mode 0): Lq + Lr is above what one workgroup's LDS rows hold
+    (~40 k; an explicit error until round 3), the column strips take them.  The oracle needs minutes and 10 GB per such
+    supercluster, so this is the identical-callsets property (every distance 0, every variant a TP with credit 1); the
+    strips' parity with the oracle is tested at 9-16 k bases above."""
+    syn = api.Synth(n_sc=2, len_mode=0, len_a=22000.0, len_b=30000.0, len_min=22000, len_max=30000, seed=63, var_per_base=0.0005,
+                    p_snp=0.3, indel_mean=300.0, p_keep=1.0, p_drop=0.0, p_hom=1.0)
+    batch = syn.batch()
+    assert max(batch.lens(k)[0] + batch.lens(k)[4] for k in range(batch.n_sc)) > 44000
+    pr = api.PrecisionRecall(A.default_config(band_mode=0))
+    r = pr.run(batch)
+    names = {s.kernel.decode() for s in pr.launch_stats()}
+    assert "k_fwd_strip" in names and "k_bwd_strip" in names
+    assert (r.aln_dist == 0).all() and (r.sc_phase == A.PHASE_NONE).all() and not (r.aln_status & np.uint32(0xffffffff ^ A.ST_SWAP_TIE)).any()
+    for h in range(4):
+        for w in range(2):
+            assert (r.errtype[h][w] == A.ERRTYPE_TP).all() and (r.credit[h][w] == 1.0).all() and (r.query_ed[h][w] == 0).all()
 
 
 # ----------------------------------------------------------------------------------------------------------------------

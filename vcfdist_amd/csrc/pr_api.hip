@@ -45,7 +45,10 @@ struct KernelClass { int nt, c, max_len; };
 // dense thread-chunk configurations: a plane of up to nt*c cells per row
 const KernelClass CLASSES[] = {
     {64, 1, 64}, {64, 4, 256}, {256, 4, 1024}, {256, 8, 2048}, {1024, 8, 8192}, {1024, 16, 16384}, {1024, 32, 32768},
+    {1024, 32, 0x7fffffff},     // no one-workgroup kernel: column strips only (pr_strip.hip)
 };
+const int STRIP_CLS = 4;        // kernel classes from 1024 threads x 8 cells on (more than 2048 columns): column strips
+const int STRIP_ONLY_CLS = 7;
 const int N_CLASSES = sizeof(CLASSES) / sizeof(CLASSES[0]);
 const size_t LDS_MAX = 160 * 1024;
 // window levels an alignment climbs until its exit test passes: 16 cells (four alignments per wave, only
@@ -554,6 +557,14 @@ size_t bwd_lds_bytes(int cls, int Lq, int Lr, bool s16 = false) {
 // largest score the int16 rows must hold: query-variant entries on a path <= query variants of the alignment
 bool s16_ok(const AlnDesc &d) { return d.qv_end - d.qv_beg < 32000; }
 
+// the one-workgroup dense kernels can hold the alignment's rows in LDS (the backward one maybe only as int16)
+bool dense_fits(const AlnDesc &d) {
+    const int cls = class_of(std::max(d.Lq, d.Lr));
+    if (cls < 0 || cls >= STRIP_ONLY_CLS) return false;
+    return fwd_lds_bytes(cls, d.Lq, d.Lr) <= LDS_MAX &&
+           (bwd_lds_bytes(cls, d.Lq, d.Lr) <= LDS_MAX || (s16_ok(d) && bwd_lds_bytes(cls, d.Lq, d.Lr, true) <= LDS_MAX));
+}
+
 typedef void (*AlnKernel)(DevBatch, const AlnDesc *, const int32_t *, uint8_t *, AlnOut *, const int32_t *);
 AlnKernel fwd_kernel(int cls) {
     switch (cls) {
@@ -781,10 +792,9 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             if (dl != LV_DENSE) {
                 need = window_layout(d, dl, 0, 0);
             } else {
-                const int cls = class_of(std::max(d.Lq, d.Lr));
-                // (the backward kernel's int32 score rows may not fit: it then runs with int16 rows, 4 B per cell)
-                too_long = cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX ||
-                           (bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX && (!s16_ok(d) || bwd_lds_bytes(cls, d.Lq, d.Lr, true) > LDS_MAX));
+                // (the backward kernel's int32 score rows may not fit: it then runs with int16 rows, 4 B per cell; what fits
+                // neither is left to the column strips, which have no size limit -- unless they are switched off)
+                too_long = !dense_fits(d) && h->no_strips;
                 const int64_t pb = round_up(int64_t(d.path_cap) * int64_t(sizeof(PathEnt)) + 128, 128);
                 need = round_up(int64_t(round_up(d.Lq, 32)) * d.Lt, 128) + round_up(int64_t(round_up(d.Lr, 32)) * d.Lt, 128) + pb + 128;
             }
@@ -799,11 +809,7 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
     if (bad.load() < n_al) {
         const AlnDesc d = h->descs[size_t(alns[bad.load()])];
         bool too_long = false;
-        if (level_of(d) == LV_DENSE) {
-            const int cls = class_of(std::max(d.Lq, d.Lr));
-            too_long = cls < 0 || fwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX ||
-                       (bwd_lds_bytes(cls, d.Lq, d.Lr) > LDS_MAX && (!s16_ok(d) || bwd_lds_bytes(cls, d.Lq, d.Lr, true) > LDS_MAX));
-        }
+        if (level_of(d) == LV_DENSE) too_long = !dense_fits(d) && h->no_strips;
         if (too_long)
             return fail(h, VPR_ERR_ARG, "supercluster %d alignment %d too long for the dense kernels (Lq=%d Lr=%d)", d.sc, d.aln, d.Lq, d.Lr);
         h->last_need = int64_t(need128[bad.load()]) * 128;
@@ -1619,6 +1625,7 @@ struct Exec {
     static dim3 blocks(int64_t n_) { return dim3(unsigned((n_ + 255) / 256)); }
 
     // HIP events bracket each launch on the stream the kernel is launched on
+    bool need_err_check = false;    // a dense round holds an alignment only the strips can take: did the planner cut it?
     template <typename F>
     int timed(int kind, const vpr_launch_stat &ls, hipStream_t ks, const char *name, F &&launch) {
         EvPair ev; ev.kind = kind; ev.st = ls; ev.st.kind = kind;
@@ -1870,15 +1877,18 @@ struct Exec {
         G.off = off; G.cnt = cnt;
         // slots per alignment: twice what the longer plane needs (a cut may have to move far back to a clean column)
         void *pb = nullptr;
-        { int rc_pin = pin_alloc(h, &pb, size_t(cnt + 1) * 4 + size_t(cnt) * 8 + 16); if (rc_pin) return rc_pin; }
+        { int rc_pin = pin_alloc(h, &pb, size_t(cnt + 1) * 4 + size_t(cnt) * 9 + 16); if (rc_pin) return rc_pin; }
         int64_t *h_boff = static_cast<int64_t *>(pb);
         int32_t *h_base = reinterpret_cast<int32_t *>(h_boff + cnt);
+        uint8_t *h_fits = reinterpret_cast<uint8_t *>(h_base + cnt + 1);
         int64_t slots = 0, rows = 0;
         for (int32_t k = 0; k < cnt; k++) {
             const AlnDesc &d = P.descs[size_t(off) + k];
             const int ns = 2 * ((std::max(d.Lq, d.Lr) + ST_CAP - 1) / ST_CAP) + 2;
             h_base[k] = int32_t(slots);
             h_boff[k] = rows;
+            h_fits[k] = dense_fits(d) ? 1 : 0;
+            if (!h_fits[k]) need_err_check = true;
             slots += ns;
             rows += int64_t(ns) * d.Lt;
         }
@@ -1886,7 +1896,7 @@ struct Exec {
         G.grid = int32_t(slots);
         void *q = nullptr;
         int rc;
-        const size_t b_small = size_t(cnt + 1) * 4 + size_t(cnt) * 8 + size_t(slots) * (sizeof(StripTab) + 8) + 4096;
+        const size_t b_small = size_t(cnt + 1) * 4 + size_t(cnt) * 17 + size_t(slots) * sizeof(StripTab) + 4096;
         if ((rc = exec_alloc(h, &q, b_small))) return rc;
         uint8_t *u = static_cast<uint8_t *>(q);
         G.d_boff = reinterpret_cast<int64_t *>(u); u += size_t(cnt) * 8;
@@ -1894,6 +1904,7 @@ struct Exec {
         G.d_base = reinterpret_cast<int32_t *>(u); u += size_t(cnt + 1) * 4;
         G.d_n = reinterpret_cast<int32_t *>(u); u += size_t(cnt) * 4;
         G.d_ok = reinterpret_cast<int32_t *>(u); u += size_t(cnt) * 4;
+        uint8_t *d_fits = u;
         if ((rc = exec_alloc(h, &q, size_t(slots) * 8))) return rc;
         G.d_prog = static_cast<int32_t *>(q);
         if ((rc = exec_alloc(h, &q, size_t(rows) * sizeof(int4)))) return rc;      // (the forward columns first, then reused by the backward sweep)
@@ -1901,95 +1912,88 @@ struct Exec {
         G.d_bbnd = static_cast<int4 *>(q);
         HIPCHK(h, hipMemcpyAsync(G.d_boff, h_boff, size_t(cnt) * 8, hipMemcpyHostToDevice, ks));
         HIPCHK(h, hipMemcpyAsync(G.d_base, h_base, size_t(cnt + 1) * 4, hipMemcpyHostToDevice, ks));
+        HIPCHK(h, hipMemcpyAsync(d_fits, h_fits, size_t(cnt), hipMemcpyHostToDevice, ks));
         HIPCHK(h, hipMemsetAsync(G.d_prog, 0, size_t(slots) * 8, ks));
         hipLaunchKernelGGL(k_strip_plan, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, d_work + off, cnt, G.d_base, G.d_tab,
-                           G.d_n, G.d_ok);
+                           G.d_n, G.d_ok, d_fits, h->d_err);
         return VPR_OK;
     }
 
     // from_window: the plan's alignments failed the exit test of a window level (their AlnOut::s is that level's distance)
     int run_dense(const Plan &P, const int32_t *d_work, hipStream_t base, bool one_stream, int tag_or = 0, bool from_window = false) {
-        const int STRIP_CLS = 4;      // kernel classes from 1024 threads x 8 cells on: alignments wider than 2048 columns
         for (const Chunk &ch : P.chunks) {
             if (!one_stream) HIPCHK(h, hipEventRecord(h->ev_fork, base));
-            // the wide alignments of the chunk (its last launches: the classes are in ascending order), spread over several
-            // workgroups each; what the strip planner cannot cut is left to the one-workgroup kernels (skip lists)
             StripGroup G;
             bool strips = false;
-            if (!h->no_strips && !tag_or) {
-                int64_t g_off = -1; int32_t g_cnt = 0;
+            int64_t g_off = -1; int32_t g_cnt = 0;
+            if (!h->no_strips)
                 for (const Launch &L : ch.launches)
                     if (L.cls >= STRIP_CLS) { if (g_off < 0) g_off = L.work_off; g_cnt += L.count; }
-                if (g_cnt > 0) {
-                    hipStream_t ks = one_stream ? base : h->cls_stream[STRIP_CLS];
-                    if (!one_stream) HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
-                    int rc = strip_plan(P, d_work, g_off, g_cnt, ks, G);
-                    if (rc) return rc;
-                    strips = true;
-                    vpr_launch_stat ls;
-                    memset(&ls, 0, sizeof(ls));
-                    ls.threads = ST_NT; ls.cells_per_thread = ST_C; ls.n_units = g_cnt;
-                    for (int32_t w = 0; w < g_cnt; w++) {
-                        const AlnDesc &d = P.descs[size_t(g_off) + w];
-                        ls.cells += int64_t(d.Lq + d.Lr) * d.Lt;
-                    }
-                    ls.cells_dense = ls.cells; ls.bytes_algorithmic = ls.cells;
-                    rc = timed(1, ls, ks, "k_fwd_strip", [&] {
-                        hipLaunchKernelGGL(k_fwd_strip, dim3(G.grid), dim3(ST_NT), 0, ks, h->dB, h->d_descs, d_work + g_off, g_cnt, G.d_base,
-                                           G.d_tab, G.d_n, G.d_boff, G.d_bnd, G.d_prog, P.arena, h->d_outs, from_window ? 1 : 0);
-                    });
-                    if (rc) return rc;
+            strips = g_cnt > 0;
+            // per launch of a class: LDS of its largest member the one-workgroup kernels can hold, int16 rows or not
+            struct ClsLds { size_t f = 0, b = 0; bool s16 = false, any = false; };
+            auto cls_lds = [&](const Launch &L) {
+                ClsLds R;
+                // the backward launch uses int16 score rows when a member's int32 rows do not fit LDS (make_plan
+                // has checked that the int16 rows do and that the scores are in range); vpr_config.flags bit 0 forces it.
+                // Members the one-workgroup kernels cannot hold at all belong to the strips (the skip list has them).
+                R.s16 = (h->cfg.flags & VPR_CFG_DENSE_S16) != 0;
+                for (int32_t w = 0; w < L.count; w++) {
+                    const AlnDesc &d = P.descs[L.work_off + w];
+                    if (!dense_fits(d)) continue;
+                    R.any = true;
+                    if (bwd_lds_bytes(L.cls, d.Lq, d.Lr) > LDS_MAX) R.s16 = true;
                 }
-            }
+                for (int32_t w = 0; w < L.count; w++) {
+                    const AlnDesc &d = P.descs[L.work_off + w];
+                    if (dense_fits(d) && R.s16 && !s16_ok(d)) R.s16 = false;    // (only reachable when forced: keep the int32 rows)
+                }
+                for (int32_t w = 0; w < L.count; w++) {
+                    const AlnDesc &d = P.descs[L.work_off + w];
+                    if (!dense_fits(d)) continue;
+                    R.f = std::max(R.f, fwd_lds_bytes(L.cls, d.Lq, d.Lr));
+                    R.b = std::max(R.b, bwd_lds_bytes(L.cls, d.Lq, d.Lr, R.s16));
+                }
+                return R;
+            };
+            auto fwd_name = [&](const KernelClass &K) { return std::string("k_fwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + ">"; };
+            auto bwd_name = [&](const KernelClass &K, bool s16) {
+                return std::string("k_bwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + (s16 ? ",s16>" : ">");
+            };
+            // ---- classes of up to 2048 columns: one workgroup per alignment
             for (const Launch &L : ch.launches) {
+                if (strips && L.cls >= STRIP_CLS) continue;
                 const KernelClass &K = CLASSES[L.cls];
-                const bool in_group = strips && L.cls >= STRIP_CLS;
-                hipStream_t ks = one_stream ? base : h->cls_stream[in_group ? STRIP_CLS : L.cls];
-                if (!one_stream && !in_group) HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
-                const int32_t *skip = in_group ? G.d_ok + (L.work_off - G.off) : nullptr;
-                size_t lds_f = 0, lds_b = 0;
+                hipStream_t ks = one_stream ? base : h->cls_stream[L.cls];
+                if (!one_stream) HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
+                const ClsLds Z = cls_lds(L);
                 vpr_launch_stat ls;
                 memset(&ls, 0, sizeof(ls));
                 ls.threads = K.nt; ls.cells_per_thread = K.c; ls.n_units = L.count;
                 int64_t in_bytes = 0;
-                // the backward launch uses int16 score rows when a member's int32 rows do not fit LDS (make_plan
-                // has checked that the int16 rows do and that the scores are in range); vpr_config.flags bit 0 forces it
-                bool s16 = (h->cfg.flags & VPR_CFG_DENSE_S16) != 0;
                 for (int32_t w = 0; w < L.count; w++) {
                     const AlnDesc &d = P.descs[L.work_off + w];
-                    if (bwd_lds_bytes(L.cls, d.Lq, d.Lr) > LDS_MAX) s16 = true;
-                }
-                for (int32_t w = 0; w < L.count; w++) {   // the launch's dynamic LDS = its largest member
-                    const AlnDesc &d = P.descs[L.work_off + w];
-                    if (s16 && !s16_ok(d)) s16 = false;    // (only reachable when forced: keep the int32 rows)
-                    lds_f = std::max(lds_f, fwd_lds_bytes(L.cls, d.Lq, d.Lr));
-                }
-                for (int32_t w = 0; w < L.count; w++) {
-                    const AlnDesc &d = P.descs[L.work_off + w];
-                    lds_b = std::max(lds_b, bwd_lds_bytes(L.cls, d.Lq, d.Lr, s16));
                     ls.cells += int64_t(d.Lq + d.Lr) * d.Lt;
                     in_bytes += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
                 }
-                if (in_group) { ls.cells = 0; in_bytes = 0; }      // (counted with the strip launch; this one only takes what that left)
                 cells_touched += ls.cells;
                 ls.cells_dense = ls.cells;
                 ls.bytes_algorithmic = ls.cells + in_bytes;
                 int rc = VPR_OK;
                 if (tag_or && (rc = tie_replay(P, L.work_off, L.count, ks, true))) return rc;
-                rc = timed(1, ls, ks, (std::string("k_fwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + ">").c_str(), [&] {
-                    hipLaunchKernelGGL(fwd_kernel(L.cls), dim3(L.count), dim3(K.nt), lds_f, ks, h->dB, h->d_descs,
-                                       d_work + L.work_off, P.arena, h->d_outs, skip);
+                rc = timed(1, ls, ks, fwd_name(K).c_str(), [&] {
+                    hipLaunchKernelGGL(fwd_kernel(L.cls), dim3(L.count), dim3(K.nt), Z.f, ks, h->dB, h->d_descs,
+                                       d_work + L.work_off, P.arena, h->d_outs, static_cast<const int32_t *>(nullptr));
                     hipLaunchKernelGGL(k_fwd_finish, dim3((L.count + 255) / 256), dim3(256), 0, ks,
                                        d_work + L.work_off, L.count, h->d_outs, tag_or);
                 });
                 if (rc) return rc;
                 n_fwd++;
                 if (tag_or && ((rc = tie_replay(P, L.work_off, L.count, ks, false)) || (rc = tie_patch(P, ks, tag_or)))) return rc;
-                if (in_group) continue;     // (backward sweeps and walks of the group: below, behind all its forward sweeps)
                 ls.bytes_algorithmic = ls.cells;
-                rc = timed(2, ls, ks, (std::string("k_bwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + (s16 ? ",s16>" : ">")).c_str(), [&] {
-                    hipLaunchKernelGGL(bwd_kernel(L.cls, s16), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
-                                       d_work + L.work_off, P.arena, h->d_outs, skip);
+                rc = timed(2, ls, ks, bwd_name(K, Z.s16).c_str(), [&] {
+                    hipLaunchKernelGGL(bwd_kernel(L.cls, Z.s16), dim3(L.count), dim3(K.nt), Z.b, ks, h->dB, h->d_descs,
+                                       d_work + L.work_off, P.arena, h->d_outs, static_cast<const int32_t *>(nullptr));
                 });
                 if (rc) return rc;
                 if ((rc = walk_launch(P, d_work + L.work_off, L.count, ks, L.count < 2048, tag_or))) return rc;
@@ -1998,8 +2002,15 @@ struct Exec {
                     HIPCHK(h, hipStreamWaitEvent(base, h->ev_join[L.cls], 0));
                 }
             }
+            // ---- the wide alignments of the chunk (its last launches: the classes are in ascending order), spread over
+            // several workgroups each; what the strip planner cannot cut is left to the one-workgroup kernels (skip lists).
+            // A tie round treats the group as one launch: early replays, forward sweeps, late replays + patch, backward sweeps.
             if (strips) {
                 hipStream_t ks = one_stream ? base : h->cls_stream[STRIP_CLS];
+                if (!one_stream) HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
+                int rc = strip_plan(P, d_work, g_off, g_cnt, ks, G);
+                if (rc) return rc;
+                if (tag_or && (rc = tie_replay(P, G.off, G.cnt, ks, true))) return rc;
                 vpr_launch_stat ls;
                 memset(&ls, 0, sizeof(ls));
                 ls.threads = ST_NT; ls.cells_per_thread = ST_C; ls.n_units = G.cnt;
@@ -2008,30 +2019,44 @@ struct Exec {
                     ls.cells += int64_t(d.Lq + d.Lr) * d.Lt;
                 }
                 ls.cells_dense = ls.cells; ls.bytes_algorithmic = ls.cells;
-                int rc = timed(2, ls, ks, "k_bwd_strip", [&] {
+                cells_touched += ls.cells;
+                rc = timed(1, ls, ks, "k_fwd_strip", [&] {
+                    hipLaunchKernelGGL(k_fwd_strip, dim3(G.grid), dim3(ST_NT), 0, ks, h->dB, h->d_descs, d_work + g_off, g_cnt, G.d_base,
+                                       G.d_tab, G.d_n, G.d_boff, G.d_bnd, G.d_prog, P.arena, h->d_outs, from_window ? 1 : 0);
+                });
+                if (rc) return rc;
+                n_fwd++;
+                vpr_launch_stat l2;
+                for (const Launch &L : ch.launches) {      // forward: what the planner could not cut; s / end plane of all
+                    if (L.cls < STRIP_CLS) continue;
+                    const KernelClass &K = CLASSES[L.cls];
+                    const ClsLds Z = cls_lds(L);
+                    memset(&l2, 0, sizeof(l2));
+                    l2.threads = K.nt; l2.cells_per_thread = K.c; l2.n_units = L.count;
+                    rc = timed(1, l2, ks, fwd_name(K).c_str(), [&] {
+                        if (Z.any)
+                            hipLaunchKernelGGL(fwd_kernel(L.cls), dim3(L.count), dim3(K.nt), Z.f, ks, h->dB, h->d_descs,
+                                               d_work + L.work_off, P.arena, h->d_outs, G.d_ok + (L.work_off - G.off));
+                        hipLaunchKernelGGL(k_fwd_finish, dim3((L.count + 255) / 256), dim3(256), 0, ks,
+                                           d_work + L.work_off, L.count, h->d_outs, tag_or);
+                    });
+                    if (rc) return rc;
+                }
+                if (tag_or && ((rc = tie_replay(P, G.off, G.cnt, ks, false)) || (rc = tie_patch(P, ks, tag_or)))) return rc;
+                rc = timed(2, ls, ks, "k_bwd_strip", [&] {
                     hipLaunchKernelGGL(k_bwd_strip, dim3(G.cnt), dim3(ST_NT), 0, ks, h->dB, h->d_descs, d_work + G.off, G.cnt, G.d_base,
                                        G.d_tab, G.d_n, G.d_boff, G.d_bbnd, G.d_prog + G.grid, P.arena, h->d_outs);
                 });
                 if (rc) return rc;
-                for (const Launch &L : ch.launches) {      // what the planner could not cut
+                for (const Launch &L : ch.launches) {      // backward: what the planner could not cut
                     if (L.cls < STRIP_CLS) continue;
                     const KernelClass &K = CLASSES[L.cls];
-                    bool s16 = (h->cfg.flags & VPR_CFG_DENSE_S16) != 0;
-                    size_t lds_b = 0;
-                    for (int32_t w = 0; w < L.count; w++) {
-                        const AlnDesc &d = P.descs[L.work_off + w];
-                        if (bwd_lds_bytes(L.cls, d.Lq, d.Lr) > LDS_MAX) s16 = true;
-                    }
-                    for (int32_t w = 0; w < L.count; w++) if (s16 && !s16_ok(P.descs[L.work_off + w])) s16 = false;
-                    for (int32_t w = 0; w < L.count; w++) {
-                        const AlnDesc &d = P.descs[L.work_off + w];
-                        lds_b = std::max(lds_b, bwd_lds_bytes(L.cls, d.Lq, d.Lr, s16));
-                    }
-                    vpr_launch_stat l2;
+                    const ClsLds Z = cls_lds(L);
+                    if (!Z.any) continue;
                     memset(&l2, 0, sizeof(l2));
                     l2.threads = K.nt; l2.cells_per_thread = K.c; l2.n_units = L.count;
-                    rc = timed(2, l2, ks, (std::string("k_bwd<") + std::to_string(K.nt) + "," + std::to_string(K.c) + (s16 ? ",s16>" : ">")).c_str(), [&] {
-                        hipLaunchKernelGGL(bwd_kernel(L.cls, s16), dim3(L.count), dim3(K.nt), lds_b, ks, h->dB, h->d_descs,
+                    rc = timed(2, l2, ks, bwd_name(K, Z.s16).c_str(), [&] {
+                        hipLaunchKernelGGL(bwd_kernel(L.cls, Z.s16), dim3(L.count), dim3(K.nt), Z.b, ks, h->dB, h->d_descs,
                                            d_work + L.work_off, P.arena, h->d_outs, G.d_ok + (L.work_off - G.off));
                     });
                     if (rc) return rc;
@@ -2803,6 +2828,13 @@ struct Exec {
         HIPCHK(h, hipStreamSynchronize(st));
         lapx("done");
         HIPCHK(h, hipGetLastError());
+        if (need_err_check) {
+            uint32_t err = 0;
+            HIPCHK(h, hipMemcpy(&err, h->d_err, 4, hipMemcpyDeviceToHost));
+            if (err & VPR_ST_ERR_LIMIT)
+                return fail(h, VPR_ERR_ARG, "an alignment of the dense level is too wide for one workgroup and has no column where it can be cut "
+                                            "into strips (an insertion of more than %d bases?)", ST_CAP);
+        }
         float ms = 0;
         (void)hipEventElapsedTime(&ms, t0, t1);
         h->timing.ms_total = ms;

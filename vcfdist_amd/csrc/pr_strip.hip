@@ -30,10 +30,10 @@ struct StripTab { int32_t lo[2], hi[2]; };      // columns [lo[p], hi[p]) of pla
 // (and the QUERY column it maps to) within ST_CAP of the cut in both planes where both planes map 1:1 onto each other
 // and the two cells behind the cut have the cells in front of it as their only swap source.
 //   tab_base[i]..tab_base[i+1]: the slots of alignment i (an alignment that needs more, or has no such column, gets
-//   ok[i] = 0 and n_strips[i] = 0: it is left to the single-workgroup kernels)
+//   n_strips[i] = 0: it is left to the one-workgroup kernels if they can hold it, fits[i])
 __global__ void k_strip_plan(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ work, int n,
                              const int32_t *__restrict__ tab_base, StripTab *__restrict__ tab, int32_t *__restrict__ n_strips,
-                             int32_t *__restrict__ ok) {
+                             int32_t *__restrict__ ok, const uint8_t *__restrict__ fits, uint32_t *__restrict__ err) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const AlnDesc d = descs[work[i]];
@@ -69,7 +69,9 @@ __global__ void k_strip_plan(DevBatch B, const AlnDesc *__restrict__ descs, cons
         r_lo = fr; q_lo = fq;
     }
     n_strips[i] = good ? j : 0;
-    ok[i] = good ? 1 : 0;
+    // ok: 1 = the strips take it; 0 = the one-workgroup kernels do; 2 = neither can (those kernels skip it, the execute fails)
+    ok[i] = good ? 1 : (fits[i] ? 0 : 2);
+    if (!good && !fits[i]) atomicOr(err, VPR_ST_ERR_LIMIT);
 }
 
 // cell roles of a thread's chunk
