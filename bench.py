@@ -56,6 +56,24 @@ def make_workload(api, n_sc, seed, workload):
     raise SystemExit(f"unknown workload {workload}")
 
 
+def cpu_limit():
+    """CPUs this process may use: the cgroup's quota where there is one (the GPU boxes show 256 logical cores and allow 16)"""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(batch, target_s=15.0):
     """Time the CPU oracle (a port of the reference's algorithm, matrices held as the reference holds them) on a bounded
     sample of the same workload, STRATIFIED by octave of the supercluster length: the cost per supercluster grows with L^2,
@@ -71,7 +89,7 @@ def cpu_baseline(batch, target_s=15.0):
     n = batch.n_sc
     L = np.maximum(np.diff(batch.ref_off), 1)
     octv = np.floor(np.log2(L)).astype(np.int64)
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    threads = max(1, min(cpu_limit(), 64))     # (more threads than the quota allows get the whole group suspended)
     strata = []
     octaves = [int(k) for k in np.unique(octv)]
     # per-supercluster single-thread cost model for sizing the samples only: 40 us + 15 ns x L^2
@@ -526,7 +544,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only: the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(batch, target_s=8.0)
-            out["cpu_baseline"]["host"] = f"{os.cpu_count()} logical cores visible"
+            out["cpu_baseline"]["host"] = f"{os.cpu_count()} logical cores visible, {cpu_limit()} allowed (cgroup quota)"
             try:    # how the port compares with the reference binary: its time on the reference's own demo workloads over the
                 # times BASELINE.md publishes for them (tools/calibrate_cpu.py, measured in the build container)
                 cal = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_cpu_calibration.json")))

@@ -27,6 +27,28 @@
 #include <thread>
 #include <vector>
 
+// host threads for the marshalling passes: three quarters of what the process may use -- the cgroup's CPU quota where
+// there is one (a container that sees 256 cores may be allowed 16; more runnable threads than that get the group suspended)
+static int host_threads() {
+    static const int n = [] {
+        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        long long quota = -1, period = 100000;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *p = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(p, "%lld", &period) != 1) period = 100000; fclose(p); }
+        }
+        if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, unsigned(std::max<long long>(1, quota / period)));
+        return int(std::min<unsigned>(std::max(1u, hw - std::max(1u, hw / 4)), 32));
+    }();
+    return n;
+}
+
+
 #include "../../include/vcfdist_pr.h"
 
 // The arrays of a marshalled batch live in two page-locked staging blocks (vpr_host_alloc: vpr_upload's copies then run
@@ -224,8 +246,7 @@ static int batch_from_variants_impl(const vpr_variants *v, vpr_owned_batch **out
     for (int h = 0; h < VPR_HAPS; h++) std::fill(B->hap_off[h], B->hap_off[h] + n + 1, int64_t(0));
     std::fill(B->ref_off, B->ref_off + n + 1, int64_t(0));
 
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int nthreads = int(std::min<unsigned>(hw, 32));
+    const int nthreads = host_threads();
     std::atomic<int> err{0};
 
     // pass 1: sizes

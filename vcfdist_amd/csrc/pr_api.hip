@@ -102,9 +102,28 @@ class ParPool {
     }
   private:
     struct Job { const std::function<void(size_t)> *task; size_t nt = 0, next = 0, done = 0; std::condition_variable done_cv; };
+    // CPUs the process may use: the cgroup's quota where there is one (a container that sees 256 cores may be allowed 16:
+    // more runnable threads than that and the scheduler suspends the whole group for the rest of the period -- including
+    // the threads that feed the GPU)
+    static unsigned cpu_limit() {
+        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        long long quota = -1, period = 100000;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *p = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(p, "%lld", &period) != 1) period = 100000; fclose(p); }
+        }
+        if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, unsigned(std::max<long long>(1, quota / period)));
+        return hw;
+    }
     ParPool() {
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned n = std::min<unsigned>(hw, PAR_MAX) - 1;
+        // (a quarter of the quota stays free for the callers themselves and the runtime's threads)
+        const unsigned lim = cpu_limit();
+        const unsigned n = std::min<unsigned>(std::max(1u, lim - std::max(2u, lim / 4)), PAR_MAX) - 1;
         for (unsigned t = 0; t < n; t++) std::thread([this] { worker(); }).detach();
     }
     void work_on(Job &job) {
