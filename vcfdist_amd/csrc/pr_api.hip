@@ -2041,7 +2041,7 @@ struct Exec {
                 cells_touched += ls.cells;
                 rc = timed(1, ls, ks, "k_fwd_strip", [&] {
                     hipLaunchKernelGGL(k_fwd_strip, dim3(G.grid), dim3(ST_NT), 0, ks, h->dB, h->d_descs, d_work + g_off, g_cnt, G.d_base,
-                                       G.d_tab, G.d_n, G.d_boff, G.d_bnd, G.d_prog, P.arena, h->d_outs, from_window ? 1 : 0);
+                                       G.d_tab, G.d_n, G.d_boff, G.d_bnd, G.d_prog, P.arena, h->d_outs, (from_window && !getenv("VPR_NO_UB")) ? 1 : 0);
                 });
                 if (rc) return rc;
                 n_fwd++;
@@ -2787,10 +2787,52 @@ struct Exec {
                 max_short = std::max<int64_t>(max_short, std::min(j.ref_len, j.tru_len));
                 max_sum = std::max<int64_t>(max_sum, int64_t(j.ref_len) + j.tru_len);
             }
-            // anti-diagonal kernel when the largest section fits LDS and 16-bit distances (VPR_ED_ROWS: the row-sweep one)
+            // wavefront kernel when the largest section's furthest-reaching rows fit LDS; else the anti-diagonal kernel when its
+            // diagonals do (16-bit distances); else the row sweep through global memory
+            const int64_t max_long = stride - 1;
+            const size_t lds_wf = size_t(2 * (2 * max_long + 3) * 2 + max_sum + 16);
             const int64_t pitch = (max_short + 2 + 7) & ~int64_t(7);
             const size_t lds_diag = size_t(3 * pitch * 2 + max_sum + 16);
-            if (lds_diag <= 150 * 1024 && max_sum < 65000) {
+            if (lds_wf <= 150 * 1024 && max_long < 29000 && !getenv("VPR_ED_DIAG")) {
+                // size classes by the longer string (x 4 from class to class), largest first
+                void *ps = nullptr, *qs = nullptr;
+                { int rc_pin = pin_alloc(h, &ps, size_t(n_jobs) * 4); if (rc_pin) return rc_pin; }
+                if ((rc = exec_alloc(h, &qs, size_t(n_jobs) * 4))) return rc;
+                int32_t *h_sel = static_cast<int32_t *>(ps), *d_sel = static_cast<int32_t *>(qs);
+                std::vector<int32_t> order(static_cast<size_t>(n_jobs));
+                for (int32_t k = 0; k < n_jobs; k++) order[size_t(k)] = k;
+                auto longer = [&](int32_t k) { return std::max(jobs[size_t(k)].ref_len, jobs[size_t(k)].tru_len); };
+                std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return longer(x) > longer(y); });
+                std::copy(order.begin(), order.end(), h_sel);
+                HIPCHK(h, hipMemcpyAsync(d_sel, h_sel, size_t(n_jobs) * 4, hipMemcpyHostToDevice, st));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ed_wf), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_wf));
+                HIPCHK(h, hipEventRecord(h->ev_fork, st));
+                int n_cls = 0;
+                for (int32_t k0 = 0; k0 < n_jobs;) {
+                    hipStream_t ks = h->cls_stream[n_cls % N_CLASSES];      // (the classes side by side)
+                    HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
+                    const int64_t top = longer(order[size_t(k0)]);
+                    int32_t k1 = k0;
+                    int64_t sum = 0;
+                    while (k1 < n_jobs && longer(order[size_t(k1)]) * 4 > top) {
+                        sum = std::max<int64_t>(sum, int64_t(jobs[size_t(order[size_t(k1)])].ref_len) + jobs[size_t(order[size_t(k1)])].tru_len);
+                        k1++;
+                    }
+                    const size_t lds = size_t(2 * (2 * top + 3) * 2 + sum + 16);
+                    vpr_launch_stat es_;
+                    memset(&es_, 0, sizeof(es_));
+                    es_.threads = EDW_NT; es_.n_units = k1 - k0;
+                    rc = timed(4, es_, ks, "k_ed_wf", [&] {
+                        hipLaunchKernelGGL(k_ed_wf, dim3(k1 - k0), dim3(EDW_NT), lds, ks, h->dB, h->d_descs, h->d_jobs, d_sel + k0, k1 - k0,
+                                           h->d_secs, int(top));
+                    });
+                    if (rc) return rc;
+                    HIPCHK(h, hipEventRecord(h->ev_join[n_cls % N_CLASSES], ks));
+                    HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[n_cls % N_CLASSES], 0));
+                    n_cls++;
+                    k0 = k1;
+                }
+            } else if (lds_diag <= 150 * 1024 && max_sum < 65000) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ed_diag), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_diag));
                 vpr_launch_stat es_;
                 memset(&es_, 0, sizeof(es_));

@@ -1209,6 +1209,75 @@ __global__ void __launch_bounds__(ED_NT) k_ed_diag(DevBatch B, const AlnDesc *__
     }
 }
 
+// K4w: the same edit distance by WAVEFRONTS (furthest-reaching points per diagonal, the formulation of the reference's own
+// wf_ed, dist.cpp:1406-1506): step d holds, for every diagonal k = x - y within d edits of the main one, the largest x
+// reachable with d edits; the answer is the first d at which diagonal nx - ny reaches x = nx.  O(d^2 + nx + ny) instead of
+// nx * ny: the deferred sections are the reference / truth segments around SV-sized indels -- thousands of bases that
+// differ by one block -- so d is the indel's size and most of the work is one long run of matches.
+// One workgroup per section; both strings and two rows of 16-bit furthest-reaching points in LDS
+// (2 * (2 * max_long + 3) * 2 + nx + ny bytes; the host picks the anti-diagonal kernel when that does not fit).
+#define EDW_NEG (-30000)
+#define EDW_NT 1024        // a step of a large section holds thousands of diagonals
+// sel: the jobs of this launch (the host launches size classes apart: the rows in LDS are as long as the class's largest
+// section, and a launch sized by a 12 000-base section would leave one workgroup per compute unit for hundreds of small ones)
+__global__ void __launch_bounds__(EDW_NT) k_ed_wf(DevBatch B, const AlnDesc *__restrict__ descs,
+                                                 const EdJob *__restrict__ jobs, const int32_t *__restrict__ sel, int n_jobs,
+                                                 Section *__restrict__ secs, int max_long) {
+    extern __shared__ __align__(16) uint8_t ed_lds[];
+    if (int(blockIdx.x) >= n_jobs) return;
+    const int j = sel[blockIdx.x];
+    const EdJob J = jobs[j];
+    const AlnDesc d = descs[J.aln];
+    const uint8_t *X = B.ref_seq + d.r_off + J.ref_beg;
+    const uint8_t *Y = B.hap_seq[d.ts] + d.t_off + J.tru_beg;
+    const int nx = J.ref_len, ny = J.tru_len;
+    const int W = 2 * max_long + 3, O = max_long + 1;             // row width, index of diagonal 0
+    int16_t *fr = reinterpret_cast<int16_t *>(ed_lds);            // [2][W]
+    uint8_t *sx = ed_lds + size_t(2) * W * 2;
+    uint8_t *sy = sx + nx;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nx; i += EDW_NT) sx[i] = X[i];
+    for (int i = tid; i < ny; i += EDW_NT) sy[i] = Y[i];
+    for (int i = tid; i < 2 * W; i += EDW_NT) fr[i] = EDW_NEG;
+    __syncthreads();
+    const int kt = nx - ny;
+    auto extend = [&](int x, int k) {
+        while (x < nx && x - k < ny && sx[x] == sy[x - k]) x++;
+        return x;
+    };
+    if (tid == 0) fr[O] = int16_t(extend(0, 0));
+    __syncthreads();
+    int dist = 0;
+    if (!(kt == 0 && fr[O] >= nx)) {
+        for (int e = 1; e <= nx + ny; e++) {
+            const int16_t *prev = fr + ((e + 1) & 1) * W;
+            int16_t *cur = fr + (e & 1) * W;
+            // diagonals that can still matter: a path through diagonal k at step e needs at least |kt - k| more edits, and the
+            // distance is at most max(nx, ny) (substitutions along the shorter string, the rest as one block).  For the
+            // typical deferred section -- one side thousands of bases longer than the other -- that leaves a band as wide as
+            // the shorter string instead of 2 e + 1 diagonals.  (Entries outside keep older, smaller values: still reachable.)
+            const int slack = max(nx, ny) - e;
+            const int klo = max(-min(e, ny), kt - slack), khi = min(min(e, nx), kt + slack);
+            for (int k = klo + tid; k <= khi; k += EDW_NT) {
+                int best = EDW_NEG;
+                const int a = prev[O + k - 1], b = prev[O + k], c = prev[O + k + 1];
+                if (a >= 0 && a + 1 <= nx) best = a + 1;                                     // a base of X alone
+                if (b >= 0) best = max(best, (b + 1 <= nx && b + 1 - k <= ny) ? b + 1 : b);   // a substitution (at the diagonal's end: nothing)
+                if (c >= 0 && c - k <= ny && c - k >= 0) best = max(best, c);                 // a base of Y alone
+                if (best >= 0) best = extend(best, k);
+                cur[O + k] = int16_t(best);
+            }
+            __syncthreads();
+            if (cur[O + kt] >= nx) { dist = e; break; }      // (one barrier per step: the next step writes the other row)
+        }
+    }
+    if (tid == 0) {
+        Section &S = secs[d.sec_off + J.sec];
+        S.ref_ed = dist;
+        S.flags &= ~SEC_DEFERRED;
+    }
+}
+
 __global__ void __launch_bounds__(64) k_ed(DevBatch B, const AlnDesc *__restrict__ descs,
                                            const EdJob *__restrict__ jobs, int n_jobs,
                                            Section *__restrict__ secs, int32_t *__restrict__ scratch,

@@ -202,7 +202,8 @@ __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *
 #pragma unroll
                 for (int p = 0; p < 2; p++)
 #pragma unroll
-                    for (int c = 0; c < C; c++) if (real[p] & (1u << c)) m = min(m, dp[p][c]);
+                    for (int c = 0; c < C; c++) if ((real[p] | ghost[p]) & (1u << c)) m = min(m, dp[p][c]);      // (the row above the block:
+                        // also the ghost's cell there, from which a diagonal move enters the block's first row)
                 if (has_left && tid < 64 && t0 + tid < Lt) m = min(m, min(bin[tid].x, bin[tid].y));
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) m = min(m, __shfl_xor(m, o));
