@@ -71,7 +71,8 @@ def cpu_limit():
                 n = min(n, max(1, q // p))
         except (OSError, ValueError):
             pass
-    return n
+    lw = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)     # (ranks of one node share the quota)
+    return max(1, n // max(lw, 1))
 
 
 def cpu_baseline(batch, target_s=15.0):

@@ -43,6 +43,7 @@ static int host_threads() {
             if (FILE *p = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(p, "%lld", &period) != 1) period = 100000; fclose(p); }
         }
         if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, unsigned(std::max<long long>(1, quota / period)));
+        if (const char *lw = getenv("LOCAL_WORLD_SIZE")) { const int n = atoi(lw); if (n > 1) hw = std::max(1u, hw / unsigned(n)); }   // (ranks of a node share it)
         return int(std::min<unsigned>(std::max(1u, hw - std::max(1u, hw / 4)), 32));
     }();
     return n;

@@ -118,6 +118,8 @@ class ParPool {
             if (FILE *p = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(p, "%lld", &period) != 1) period = 100000; fclose(p); }
         }
         if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, unsigned(std::max<long long>(1, quota / period)));
+        // one process per GPU on a node (torch.distributed.run exports the number of local ranks): they share the quota
+        if (const char *lw = getenv("LOCAL_WORLD_SIZE")) { const int n = atoi(lw); if (n > 1) hw = std::max(1u, hw / unsigned(n)); }
         return hw;
     }
     ParPool() {
