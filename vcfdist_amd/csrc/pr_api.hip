@@ -279,6 +279,7 @@ struct vpr_handle {
     struct ExecBlk { uint8_t *p; size_t bytes; bool used; };
     std::vector<ExecBlk> exec_blks;
     bool no_strips = false;              // VPR_NO_STRIPS in the environment: wide alignments stay in one workgroup
+    bool no_round_overlap = false;       // VPR_NO_ROUND_OVERLAP: a retry round is complete before the host looks at its fail lists
     std::vector<uint32_t> scratch_u32[2];
     Plan plan0;                          // first round over all alignments, cached at upload
     std::vector<uint8_t> level, level0;  // current / round-0 window level of every alignment
@@ -300,6 +301,7 @@ struct vpr_handle {
     hipEvent_t ev_slot[2 + 4 * LadderCtx::N_SLOTS] = {};      // "fail list of slot k is complete"
     hipStream_t tie_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // tie ladder k: [2k] main, [2k+1] early replays (high priority)
     hipEvent_t ev_tie2[2] = {nullptr, nullptr};
+    hipEvent_t ev_side[2] = {nullptr, nullptr};               // retry ladder k: "the forward sweeps of the round are enqueued"
     hipEvent_t ev_tie[2] = {nullptr, nullptr};                // "the tie list of the long / short part of round 0 is published"
     // plans of the last execute in launch order (the last one that holds an alignment has its final walk); second = the
     // plan's workspace, nullptr once that workspace has been reused
@@ -1096,6 +1098,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->cfg = *cfg;
     h->debug = getenv("VPR_DEBUG") != nullptr;
     h->no_strips = getenv("VPR_NO_STRIPS") != nullptr;
+    h->no_round_overlap = getenv("VPR_NO_ROUND_OVERLAP") != nullptr;
     memset(&h->dB, 0, sizeof(h->dB));
     memset(&h->timing, 0, sizeof(h->timing));
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
@@ -1121,7 +1124,8 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
             return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
     for (int k = 0; k < 2; k++)
         if (hipEventCreateWithFlags(&h->ev_tie[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_tie2[k], hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&h->ev_tie2[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_side[k], hipEventDisableTiming) != hipSuccess)
             return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     if (hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming) != hipSuccess) return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess)
@@ -1159,6 +1163,7 @@ void vpr_destroy(vpr_handle *h) {
     for (int k = 0; k < 2; k++) {
         if (h->ev_tie[k]) (void)hipEventDestroy(h->ev_tie[k]);
         if (h->ev_tie2[k]) (void)hipEventDestroy(h->ev_tie2[k]);
+        if (h->ev_side[k]) (void)hipEventDestroy(h->ev_side[k]);
     }
     if (h->ev_spec) (void)hipEventDestroy(h->ev_spec);
     delete h;
@@ -2237,6 +2242,12 @@ struct Exec {
     // until its exit test passes.  Two independent ladders (one fed by the long part of round 0, one by the
     // short part) each own a stream, a workspace, staging buffers and fail slots, so their rounds run beside
     // each other and beside the rest of round 0; the host only ever waits for a fail list it needs next.
+    bool overlap(const LadderCtx &c) const { return !h->no_round_overlap && !h->no_strips && c.ls2 != nullptr && (&c - h->lad) < 2; }
+    int lad_sync(LadderCtx &c) {        // everything the context has in flight (its side stream: the back halves of retry rounds)
+        HIPCHK(h, hipStreamSynchronize(c.ls));
+        if (overlap(c)) HIPCHK(h, hipStreamSynchronize(c.ls2));
+        return VPR_OK;
+    }
     int lad_flush(LadderCtx &c, std::vector<int32_t> &out) {
         for (const auto &pd : c.pending) {
             int rc = read_fails(pd.first, pd.second, c.ls, out);
@@ -2244,7 +2255,10 @@ struct Exec {
         }
         c.pending.clear();
         c.plans.clear();
-        c.slot_cur = 0; c.fail_cur = 0; c.stage_cur = 0; c.arena_cur = 0;
+        c.slot_cur = 0; c.fail_cur = 0;
+        // (a retry ladder whose rounds overlap keeps handing out fresh workspace and staging: what the last rounds' backward
+        // sweeps and walks still use stays untouched; lad_start waits for them when it runs out)
+        if (!overlap(c)) { c.stage_cur = 0; c.arena_cur = 0; }
         return VPR_OK;
     }
 
@@ -2285,7 +2299,7 @@ struct Exec {
                     int(&c - h->lad), by_lv[1].size(), by_lv[2].size(), by_lv[3].size(), by_lv[4].size(), by_lv[5].size());
         const size_t nf = fails.size();
         if (c.work_cap < c.stage_cur + nf || c.hp_cap < c.stage_cur + nf) {   // (rounds still in flight hold the front)
-            HIPCHK(h, hipStreamSynchronize(c.ls));
+            { const int rs = lad_sync(c); if (rs) return rs; }
             c.stage_cur = 0;
         }
         if (c.work_cap < nf) {
@@ -2295,12 +2309,14 @@ struct Exec {
         }
         if (c.hp_cap < nf) {
             void *pd = nullptr, *pw = nullptr;
-            HIPCHK(h, hipStreamSynchronize(c.ls));           // (nothing may still read the old staging block)
+            { const int rs = lad_sync(c); if (rs) return rs; }           // (nothing may still read the old staging block)
             { int rc_pin = pin_alloc(h, &pd, nf * 2 * sizeof(AlnDesc)); if (rc_pin) return rc_pin; }
             { int rc_pin = pin_alloc(h, &pw, nf * 2 * sizeof(int32_t)); if (rc_pin) return rc_pin; }
             c.hp_descs = static_cast<AlnDesc *>(pd); c.hp_work = static_cast<int32_t *>(pw); c.hp_cap = nf * 2;
         }
         bool zero_slots = true;
+        std::vector<std::function<int()>> later;      // what a retry round enqueues behind its flag (below)
+        c.plans.reserve(c.plans.size() + LV_DENSE + 1);    // (the closures index c.plans; no reallocation while they are pending)
         if (c.arena_cur == 0) drop_resident(c);
         if (!tie) hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, c.ls, h->d_tie_cnt + 5 + int(&c - h->lad), 0);   // the round's tie count
         for (int lv = LV_Q16; lv <= LV_DENSE; lv++) {
@@ -2311,7 +2327,7 @@ struct Exec {
             int rc = make_plan(h, by_lv[lv], lv, P, c.arena + c.arena_cur, c.arena_bytes - c.arena_cur, tag_or);
             if (rc == VPR_OK && P.chunks.size() > 1 && c.arena_cur > 0) rc = VPR_ERR_NOMEM;   // retry with the whole workspace
             if (rc == VPR_ERR_NOMEM && c.arena_cur > 0) {
-                HIPCHK(h, hipStreamSynchronize(c.ls));
+                { const int rs = lad_sync(c); if (rs) return rs; }
                 c.arena_cur = 0;
                 drop_resident(c);
                 rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes, tag_or);
@@ -2324,7 +2340,7 @@ struct Exec {
                 HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
                 const int64_t nb = std::min<int64_t>(P.total_need + (1 << 20), int64_t(free_b / 2));
                 if (nb > c.arena_bytes + c.arena_bytes / 2) {
-                    HIPCHK(h, hipStreamSynchronize(c.ls));
+                    { const int rs = lad_sync(c); if (rs) return rs; }
                     uint8_t *na2 = nullptr;
                     if (dev_alloc(h, &na2, size_t(nb) + 256) == VPR_OK) {   // (the old block is released with the batch)
                         c.arena = na2; c.arena_bytes = nb; c.arena_cur = 0;
@@ -2336,7 +2352,7 @@ struct Exec {
             }
             if (rc == VPR_ERR_NOMEM && h->cfg.workspace_bytes <= 0) {
                 // one alignment does not fit the ladder's workspace: grow it to twice that need
-                HIPCHK(h, hipStreamSynchronize(c.ls));
+                { const int rs = lad_sync(c); if (rs) return rs; }
                 const int64_t nb = std::max<int64_t>(2 * h->last_need, 2 * c.arena_bytes);
                 uint8_t *na2 = nullptr;
                 if (dev_alloc(h, &na2, size_t(nb) + 256) == VPR_OK) {   // (the old block is released with the batch)
@@ -2358,12 +2374,44 @@ struct Exec {
                                h->d_cnt + c.slot0, zero_slots ? LadderCtx::N_SLOTS : 0);
             zero_slots = false;
             h->dirty.insert(h->dirty.end(), P.work.begin(), P.work.end());
+            // A retry round whose plan is one workspace chunk: the forward sweeps (and fail lists) of all its plans first, then
+            // the flag the host waits for, then the backward sweeps, tie lists and walks of what was accepted -- the host starts
+            // the next round while those still run (on the ladder's other context when that is idle: the main loop).
+            const bool defer = !tie && lv != LV_DENSE && P.chunks.size() == 1 && c.slot_cur + 2 <= LadderCtx::N_SLOTS && !h->no_round_overlap;
+            const size_t pi_ = c.plans.size() - 1;
             if (lv == LV_DENSE) {
                 // (several kernel classes: side by side on the class streams -- the largest alignment of the largest class is
                 // the critical path of a batch of long alignments, it should not wait for the smaller classes)
                 bool many = false;
                 for (const Chunk &ch : P.chunks) many = many || ch.launches.size() > 1;
-                if ((rc = run_dense(P, dw, c.ls, !many || tag_or != 0, tag_or, !tie))) return rc;     // (a tie round's replays share one scratch)
+                if (!tie && !h->no_round_overlap) {
+                    later.push_back([this, &c, pi_, dw, many, tag_or]() { return run_dense(c.plans[pi_], dw, c.ls, !many, tag_or, true); });
+                } else {
+                    if ((rc = run_dense(P, dw, c.ls, !many || tag_or != 0, tag_or, !tie))) return rc;     // (a tie round's replays share one scratch)
+                }
+            } else if (defer) {
+                const Chunk &ch = P.chunks[0];
+                const int ci_k = int(&c - h->lad);
+                for (int part = 0; part < 2; part++) {
+                    const int32_t n_long = ch.n_long;
+                    const int64_t off = part == 0 ? ch.work_off : ch.work_off + n_long;
+                    const int32_t cnt = part == 0 ? n_long : ch.count - n_long;
+                    if (cnt <= 0) continue;
+                    const int slot = c.slot0 + c.slot_cur++;
+                    const int64_t foff = c.fail_base + c.fail_cur;
+                    const int64_t pc = ch.part_cells[part], pin = ch.part_in[part], pd = ch.part_dense[part];
+                    if ((rc = enqueue_part(P, dw, off, cnt, lv, c.ls, slot, foff, part == 0, pc, pin, pd, -1, 1, nullptr, 0, tag_or))) return rc;
+                    later.push_back([this, &c, pi_, dw, off, cnt, lv, slot, foff, part, pc, pin, pd, tag_or, ci_k]() {
+                        const Plan &Pl = c.plans[pi_];
+                        hipStream_t ks = overlap(c) ? c.ls2 : c.ls;
+                        int r = enqueue_part(Pl, dw, off, cnt, lv, ks, slot, foff, part == 0, pc, pin, pd, -1, 2, nullptr, 0, tag_or);
+                        if (r) return r;
+                        ladder_collect(ci_k, dw + off, cnt, ks);
+                        return enqueue_part(Pl, dw, off, cnt, lv, ks, slot, foff, part == 0, pc, pin, pd, -1, 4, nullptr, 0, tag_or);
+                    });
+                    c.pending.emplace_back(slot, foff);
+                    c.fail_cur += cnt;
+                }
             } else {
                 for (const Chunk &ch : P.chunks) {
                     if (c.slot_cur + 2 > LadderCtx::N_SLOTS) {   // out of fail slots: drain what is in flight
@@ -2411,6 +2459,12 @@ struct Exec {
         }
         post_flag(4 + int(&c - h->lad), c.ls);
         (void)hipStreamQuery(c.ls);     // flush
+        if (!later.empty() && overlap(c)) {     // the back halves: on the side stream, behind the forward sweeps
+            HIPCHK(h, hipEventRecord(c.ev2, c.ls));
+            HIPCHK(h, hipStreamWaitEvent(c.ls2, c.ev2, 0));
+        }
+        for (auto &fn : later) { const int rc = fn(); if (rc) return rc; }
+        if (!later.empty()) { (void)hipStreamQuery(c.ls); if (overlap(c)) (void)hipStreamQuery(c.ls2); }
         return VPR_OK;
     }
 
@@ -2518,10 +2572,15 @@ struct Exec {
         // backward sweep met a tied swap cell are known right after that sweep, and their tie rounds run beside it too.
         // HIP maps streams onto 4 hardware queues: round 0 uses two, the ladders and the tie rounds share the others
         LL.ls = h->cls_stream[2]; LS.ls = h->cls_stream[3];
+        // (side streams for the back halves of the retry rounds: the class streams of the widest dense classes, which the
+        // column strips leave unused)
+        LL.ls2 = h->cls_stream[5]; LS.ls2 = h->cls_stream[6]; LL.ev2 = h->ev_side[0]; LS.ev2 = h->ev_side[1];
         LL.slot0 = 2; LS.slot0 = 2 + LadderCtx::N_SLOTS;
         for (size_t ci = 0; ci < P0.chunks.size(); ci++) {
             const Chunk &ch = P0.chunks[ci];
             const int32_t n_long = ch.n_long;
+            // (nothing of an earlier chunk or execute is in flight: the retry ladders hand out their workspaces from the front)
+            LL.arena_cur = LS.arena_cur = 0; LL.stage_cur = LS.stage_cur = 0;
             const int64_t rbase = na_ + na_ / 16 + 256;                    // start of the retry rounds' fail region
             LL.fail_base = rbase; LS.fail_base = rbase + n_long;
             HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
@@ -2646,11 +2705,21 @@ struct Exec {
                         wait_fail[k] = false;
                         progressed = true;
                     } else if (!wait_fail[k] && !c.pending.empty() && flag_up(4 + k)) {
-                        fails.clear();
-                        fails.swap(carry[k]);
-                        if ((rc = lad_flush(c, fails))) return rc;
-                        if ((rc = lad_start(c, fails, carry[k]))) return rc;
-                        progressed = true;
+                        // The round's fail lists are complete (its backward sweeps and walks may still be running: lad_start).
+                        // The next round goes to the other retry ladder's context when that is idle -- own stream, own
+                        // workspace: it then runs beside the rest of this round instead of behind it -- else to this one.
+                        // A context whose last tie list the host has not taken yet is not reused (the list would be overwritten).
+                        const int o = 1 - k;
+                        int tk = -1;
+                        if (!h->no_round_overlap && h->lad[o].pending.empty() && !wait_fail[o] && !lad_tie_wait[o] && carry[o].empty()) tk = o;
+                        else if (!lad_tie_wait[k]) tk = k;
+                        if (tk >= 0) {
+                            fails.clear();
+                            fails.swap(carry[k]);
+                            if ((rc = lad_flush(c, fails))) return rc;
+                            if ((rc = lad_start(h->lad[tk], fails, carry[tk]))) return rc;
+                            progressed = true;
+                        }
                     }
                     if (wait_tie[k] && flag_up(2 + k)) {
                         const int32_t n = std::min(h->hp_tie_cnt[2 + k], tie_cap[k]);
@@ -2680,7 +2749,9 @@ struct Exec {
             HIPCHK(h, hipEventRecord(h->ev_join[3], LS.ls));
             HIPCHK(h, hipEventRecord(h->ev_join[4], h->lad[2].ls));
             HIPCHK(h, hipEventRecord(h->ev_join[5], h->lad[3].ls));
-            for (int k = 0; k < 6; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
+            HIPCHK(h, hipEventRecord(h->ev_join[6], LL.ls2));
+            HIPCHK(h, hipEventRecord(h->ev_join[7], LS.ls2));
+            for (int k = 0; k < 8; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
             if (ci + 1 < P0.chunks.size()) HIPCHK(h, hipStreamSynchronize(st));
             if (ci + 1 == P0.chunks.size()) { h->res0_off = ch.work_off; h->res0_cnt = ch.count; }
         }
