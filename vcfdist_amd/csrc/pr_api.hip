@@ -805,11 +805,26 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
     std::vector<uint32_t> &need128 = h->scratch_u32[0];
     lt.resize(n_al); lq.resize(n_al); lr.resize(n_al); need128.resize(n_al);
     std::atomic<size_t> bad{n_al};          // first alignment (in input order) that cannot be placed
-    par_for(n_al, [&](size_t b, size_t e, int) {
+    // (lazy plans: what pass 3 would gather in plan order -- the parts' sums, the levels -- is taken here, in input order)
+    struct Sums { int64_t cells = 0, in_bytes = 0, part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}, part_rows[2] = {0, 0}; };
+    std::vector<Sums> sums1(PAR_MAX);
+    std::vector<std::vector<int32_t>> big_of(PAR_MAX);      // per slice: positions of the long alignments
+    par_for(n_al, [&](size_t b, size_t e, int tid) {
+        Sums &S1 = sums1[size_t(tid)];
+        std::vector<int32_t> &bigs = big_of[size_t(tid)];
         for (size_t i = b; i < e; i++) {
             AlnDesc d = h->descs[size_t(alns[i])];
             lt[i] = d.Lt; lq[i] = d.Lq; lr[i] = d.Lr;
             const int dl = level_of(d);
+            if (lv == LV_DENSE || d.Lt >= LLT) bigs.push_back(int32_t(i));
+            if (P.lazy) {
+                const int W = LV_WINDOW[dl], part = d.Lt >= LLT ? 0 : 1;
+                S1.part_cells[part] += int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt;
+                S1.part_in[part] += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
+                S1.part_dense[part] += int64_t(d.Lq + d.Lr) * d.Lt;
+                S1.part_rows[part] += d.Lt;
+                h->level[size_t(alns[i])] = uint8_t(dl);
+            }
             int64_t need;
             bool too_long = false;
             if (dl != LV_DENSE) {
@@ -844,8 +859,9 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
     size_t n_big = 0;                       // long alignments, in front of the plan
     {
         std::vector<std::pair<int64_t, int32_t>> big;
-        for (size_t i = 0; i < n_al; i++)
-            if (lv == LV_DENSE || lt[i] >= LLT) {
+        for (const auto &bl : big_of)
+            for (const int32_t i32 : bl) {
+                const size_t i = size_t(i32);
                 const AlnDesc d = h->descs[size_t(alns[i])];
                 const int W = LV_WINDOW[level_of(d)];
                 const int64_t mat = W ? int64_t(round_up(std::min(W, d.Lq), 16) + round_up(std::min(W, d.Lr), 16)) * d.Lt
@@ -946,8 +962,21 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
             // a LV_Q16 plan's long alignments use the 64-cell layout and cannot share a launch with the rest
             if (lv > LV_Q16 && (ch.n_long == ch.count || ch.count < 4096)) ch.n_long = 0;     // nothing to overlap with
         }
-    struct Sums { int64_t cells = 0, in_bytes = 0, part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}, part_rows[2] = {0, 0}; };
     std::vector<Sums> sums(size_t(PAR_MAX) * n_ch);
+    if (P.lazy && n_ch == 1) {
+        // one chunk, descriptors on demand: the sums are pass 1's (an alignment is in part 0 iff it is long, unless the chunk
+        // has no long part), the levels are set; what is left is positions -> alignment ids
+        par_for(n, [&](size_t b, size_t e, int) { for (size_t k = b; k < e; k++) order[k] = alns[size_t(order[k])]; });
+        Sums &S = sums[0];
+        const bool no_long = P.chunks[0].n_long == 0;
+        for (const Sums &T : sums1)
+            for (int q = 0; q < 2; q++) {
+                const int part = no_long ? 1 : q;
+                S.part_cells[part] += T.part_cells[q]; S.part_in[part] += T.part_in[q];
+                S.part_dense[part] += T.part_dense[q]; S.part_rows[part] += T.part_rows[q];
+                S.cells += T.part_cells[q]; S.in_bytes += T.part_in[q];
+            }
+    } else
     // pass 3 (parallel): positions -> alignment ids, levels, the chunks' sums, and (unless lazy) the descriptors
     par_for(n, [&](size_t b, size_t e, int tid) {
         size_t ci = 0;
