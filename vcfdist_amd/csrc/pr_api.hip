@@ -2414,7 +2414,7 @@ struct Exec {
                 bool many = false;
                 for (const Chunk &ch : P.chunks) many = many || ch.launches.size() > 1;
                 if (!tie && !h->no_round_overlap) {
-                    later.push_back([this, &c, pi_, dw, many, tag_or]() { return run_dense(c.plans[pi_], dw, c.ls, !many, tag_or, true); });
+                    later.push_back([this, &c, pi_, dw, many, tag_or]() { return run_dense(c.plans[pi_], dw, overlap(c) ? c.ls2 : c.ls, !many, tag_or, true); });
                 } else {
                     if ((rc = run_dense(P, dw, c.ls, !many || tag_or != 0, tag_or, !tie))) return rc;     // (a tie round's replays share one scratch)
                 }
