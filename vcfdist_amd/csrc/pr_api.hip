@@ -2019,7 +2019,8 @@ struct Exec {
             for (const Launch &L : ch.launches) {
                 if (strips && L.cls >= STRIP_CLS) continue;
                 const KernelClass &K = CLASSES[L.cls];
-                hipStream_t ks = one_stream ? base : h->cls_stream[L.cls];
+                // (streams 2 and 3 are the retry ladders' own: a dense class there would hold up the ladder's next round)
+                hipStream_t ks = one_stream ? base : h->cls_stream[(L.cls == 2 || L.cls == 3) ? 7 : L.cls];
                 if (!one_stream) HIPCHK(h, hipStreamWaitEvent(ks, h->ev_fork, 0));
                 const ClsLds Z = cls_lds(L);
                 vpr_launch_stat ls;
@@ -2367,7 +2368,9 @@ struct Exec {
                 // 256-CU device.  Grow the workspace to hold the plan, as far as half of the free memory allows.
                 size_t free_b = 0, total_b = 0;
                 HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
-                const int64_t nb = std::min<int64_t>(P.total_need + (1 << 20), int64_t(free_b / 2));
+                // (a ladder whose rounds overlap hands its workspace out once: twice the plan leaves room for the next round
+                // without waiting for this one)
+                const int64_t nb = std::min<int64_t>((overlap(c) ? 2 : 1) * P.total_need + (1 << 20), int64_t(free_b / 2));
                 if (nb > c.arena_bytes + c.arena_bytes / 2) {
                     { const int rs = lad_sync(c); if (rs) return rs; }
                     uint8_t *na2 = nullptr;
