@@ -200,6 +200,23 @@ def test_dense_strips_and_what_the_strip_planner_cannot_cut():
     assert want.aln_dist[0] <= 2 and want.aln_dist[3] >= 90
 
 
+def test_diagnostic_switches_leave_the_results_unchanged(monkeypatch):
+    """the dense level in one workgroup instead of column strips, forward strips without the skipped blocks, one complete
+    retry round at a time, edit distances by anti-diagonals: every array equal to the default run's (and that one to the
+    oracle's)"""
+    import fuzz_parity
+    shape, kw, band_mode = fuzz_parity.random_workload(64006, 6)        # (one of the SV cases above: it reaches the strips)
+    batch = api.Synth(**kw).batch()
+    got, want, _, pr = compare(batch, A.default_config(band_mode=1))
+    names = {s.kernel.decode() for s in pr.launch_stats()}
+    assert "k_fwd_strip" in names
+    for var in ("VPR_NO_STRIPS", "VPR_NO_UB", "VPR_NO_ROUND_OVERLAP", "VPR_ED_DIAG"):
+        monkeypatch.setenv(var, "1")
+        other = api.PrecisionRecall(A.default_config(band_mode=1)).run(batch)
+        monkeypatch.delenv(var)
+        assert not got.diff(other), var
+
+
 def test_dense_backward_int16_rows_forced():
     batch = api.Synth(n_sc=30, len_a=30, len_b=900, len_min=30, len_max=900, seed=61, var_per_base=0.03).batch()
     compare(batch, A.default_config(band_mode=0, flags=A.CFG_DENSE_S16))
