@@ -213,10 +213,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     gloo = dist is not None and dist.get_backend() == "gloo"
     if args.in_flight is None:
-        args.in_flight = 3 if args.workload == "wgs_synth" else 1
+        # One batch at a time.  (Round 3 kept three batches resident behind three handles so that one batch's latency tail ran
+        # beside the next batch's bulk: 25 ms per step on a good run, but a handle's first launches then waited up to seconds
+        # behind another handle's streams -- 39 streams on 8 hardware queues -- and the driver's run measured 133 ms.)
+        args.in_flight = 1
     if args.one_pass_batches is None:
         args.one_pass_batches = 9 if args.workload == "wgs_synth" else 0
-    n_fl = max(1, min(args.in_flight, args.steps))
+    # (every resident batch goes through at least one untimed step: a handle's workspaces settle in its first execute)
+    n_fl = max(1, min(args.in_flight, args.steps, max(args.warmup, 1)))
 
     class Slot:
         """one batch resident in HBM behind its own library handle"""
@@ -266,6 +270,8 @@ def main():
     next_coll = [0]                     # the collectives of step i are issued behind those of step i - 1 on every rank
     failed = []                         # exceptions of the step threads: the others stop waiting for their turn
 
+    step_log = []                       # (step, start, end) of every timed step, seconds on this rank's clock
+
     def step(i, S):
         ta = time.perf_counter()
         S.pr.execute()                  # K1..K5 on the device
@@ -289,8 +295,10 @@ def main():
         with turn:
             next_coll[0] = i + 1
             turn.notify_all()
+        te = time.perf_counter()
         with lock:
-            parts[0] += tb - ta; parts[1] += tc - tb; parts[2] += time.perf_counter() - tc
+            parts[0] += tb - ta; parts[1] += tc - tb; parts[2] += te - tc
+            step_log.append((i, ta, te))
         return res, t
 
     def sync():
@@ -302,9 +310,16 @@ def main():
     stats_acc = {}
     last = {}
 
-    def account(S, stats_acc=stats_acc, kern_ms=kern_ms):
+    host_acc = {"n_device_allocs": 0, "n_device_frees": 0, "n_host_allocs": 0, "ms_host_alloc": 0.0, "ms_host_blocked": 0.0,
+                "execute_wall_ms": []}
+
+    def account(S, stats_acc=stats_acc, kern_ms=kern_ms, host_acc=host_acc):
         tm = S.pr.timing()
         kern_ms.append(tm.ms_total)
+        if host_acc is not None:
+            for k in ("n_device_allocs", "n_device_frees", "n_host_allocs", "ms_host_alloc", "ms_host_blocked"):
+                host_acc[k] += getattr(tm, k)
+            host_acc["execute_wall_ms"].append(tm.ms_wall)
         # a kernel runs in several roles per step (round 0 over the whole part, retry and tie rounds over a few
         # alignments): the launch of a step with the most units is the kernel's main launch, the rest is "other"
         ls = S.pr.launch_stats()
@@ -354,11 +369,13 @@ def main():
 
     run_steps(0, max(args.warmup, 0), False)
     parts[:] = [0.0, 0.0, 0.0]
+    step_log.clear()
     sync()
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps, True)
     sync()
     elapsed = time.perf_counter() - t0
+    timed_log = sorted(step_log)
     (res, t), S_last = last[args.warmup + args.steps - 1]
     batch, pr = S_last.batch, S_last.pr
     # two more steps of one batch ALONE (not timed, not in `value`): a kernel's launch duration without the neighbours that
@@ -367,7 +384,7 @@ def main():
     if n_fl > 1:
         for k in range(2):
             step(args.warmup + args.steps + k, S_last)
-            account(S_last, alone_acc, alone_ms)
+            account(S_last, alone_acc, alone_ms, None)
         sync()
     if rank == 0:       # the device tally must equal the one recomputed from the downloaded results
         assert np.array_equal(shard.tally_from_results(res, batch.var_off), pr.tally()), "device tally != host tally"
@@ -520,6 +537,21 @@ def main():
                                     if strong else f"{world} ranks x independent superclusters")},
             "dense_cells_per_s": round(tm.cells_dense * world * args.steps / elapsed, 1),
             "kernel_ms_per_step": round(float(np.mean(kern_ms)), 3),
+            # every timed step on this rank: its own duration (start of vpr_execute -> counters reduced; with batches in flight
+            # the steps overlap, so this is a step's latency, not the time per step) and the spacing of the completions
+            "step_ms": (lambda d: {"p50": round(float(np.percentile(d, 50)), 3), "p95": round(float(np.percentile(d, 95)), 3),
+                                   "max": round(float(d.max()), 3), "min": round(float(d.min()), 3)})(
+                np.array([(e - a) * 1e3 for _, a, e in timed_log])),
+            "step_completion_interval_ms": (lambda d: {"p50": round(float(np.percentile(d, 50)), 3), "p95": round(float(np.percentile(d, 95)), 3),
+                                                       "max": round(float(d.max()), 3)})(
+                np.diff(np.sort(np.array([t0] + [e for _, _, e in timed_log]))) * 1e3),
+            "in_flight": n_fl,
+            "host": {"n_device_allocs": int(host_acc["n_device_allocs"]), "n_device_frees": int(host_acc["n_device_frees"]),
+                     "n_host_allocs": int(host_acc["n_host_allocs"]), "ms_host_alloc": round(host_acc["ms_host_alloc"], 3),
+                     "ms_host_blocked": round(host_acc["ms_host_blocked"], 3),
+                     "execute_wall_ms_max": round(max(host_acc["execute_wall_ms"]), 3),
+                     "note": "allocator calls and blocking waits inside the timed vpr_execute calls of rank 0 (vpr_timing): 0 once a "
+                             "handle's workspaces have settled"},
             "step_parts_ms": {"vpr_execute": round(parts[0] / args.steps * 1e3, 3), "vpr_download": round(parts[1] / args.steps * 1e3, 3),
                               "counters_and_collective": round(parts[2] / args.steps * 1e3, 3)},
             "setup_not_timed": {"generate_s": round(t_b - t_a, 2), "host_marshalling_s": round(t_c - t_b, 2),

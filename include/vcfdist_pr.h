@@ -205,6 +205,15 @@ typedef struct vpr_timing {
     int64_t n_tie_replays; /* alignments whose tied swap predecessors were resolved by replaying the reference's
                               container order (VPR_ST_SWAP_TIE), counting second attempts */
     double  ms_tie;        /* the replay kernel */
+    /* host side of the last vpr_execute */
+    double  ms_wall;       /* wall-clock time of the call */
+    double  ms_wall_phase[6]; /* wall-clock time from the start of the call until: [0] inputs reset, first launches possible,
+                              [1] round 0 enqueued, [2] retry ladders and tie rounds drained, [3] final tie pass done,
+                              [4] deferred edit distances + finalisation enqueued, [5] last kernel complete */
+    double  ms_host_alloc; /* time inside hipMalloc / hipFree / hipHostMalloc */
+    double  ms_host_blocked; /* time inside blocking waits other than the final one ([4] -> [5]) */
+    int64_t n_device_allocs, n_device_frees, n_host_allocs;   /* hipMalloc / hipFree / hipHostMalloc calls of the execute: all 0
+                              once the handle's workspaces have settled (normally after the first execute of a batch) */
 } vpr_timing;
 
 /* one kernel launch of the last vpr_execute (HIP events around the launch) */
@@ -253,6 +262,9 @@ void  vpr_host_free(void *p);
    process initialises HIP (the Python binding and bench.py do), or pairs of them share a hardware queue. */
 int   vpr_select_device(int32_t device);
 int vpr_get_timing(const vpr_handle *h, vpr_timing *t);
+/* test aid (no device): worker threads the library's planning pool starts beside the calling thread when the process may
+   use `cpu_quota` CPUs (cgroup quota / local ranks): 0 for a quota of 1 - 3, never more than the quota */
+int32_t vpr_test_pool_workers(int32_t cpu_quota);
 int vpr_get_launch_stats(const vpr_handle *h, vpr_launch_stat *out, int32_t cap);  /* returns #launches */
 /* TP/FP/FN counts [callset QUERY,TRUTH][TP,FP,FN] of the phasing each supercluster's distances select
    (sc_phase SWAP -> swap slot 1, else slot 0), accumulated on the device by the last vpr_execute: the

@@ -43,6 +43,26 @@ def test_struct_sizes_match_header():
     assert p.n_sc == 3 and p.seed == 9 and abs(p.var_per_base - 1 / 200) < 1e-12 and p.max_qual == 60
 
 
+def test_planning_pool_never_outnumbers_a_small_cpu_quota():
+    """round 3's unsigned `lim - max(2, lim / 4)` wrapped around for a quota of 1 CPU (quota 8 shared by 8 local ranks) and
+    started 31 detached workers"""
+    L = api.lib()
+    L.vpr_test_pool_workers.restype = C.c_int32
+    L.vpr_test_pool_workers.argtypes = [C.c_int32]
+    got = {q: L.vpr_test_pool_workers(q) for q in (1, 2, 3, 4, 8, 16, 64, 256)}
+    assert got[1] == got[2] == got[3] == 0
+    assert got[4] == 1 and got[8] == 5 and got[16] == 11
+    assert all(0 <= w < max(q, 2) for q, w in got.items()) and got[256] <= 32
+
+
+def test_timing_struct_matches_the_header_field_for_field():
+    hdr = open(os.path.join(ROOT, "include", "vcfdist_pr.h")).read()
+    body = hdr[hdr.index("typedef struct vpr_timing {"):hdr.index("} vpr_timing;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n for decl in re.findall(r"(?:double|int64_t)\s+([^;]+);", body) for n in re.findall(r"([a-z_0-9]+)(?:\[\d+\])?", decl)]
+    assert names == [f[0] for f in A.VprTiming._fields_]
+
+
 def test_no_gpu_is_a_hard_error():
     import torch
     if torch.cuda.is_available():

@@ -85,6 +85,9 @@ class VprTiming(C.Structure):
         ("n_fwd_launches", C.c_int64), ("cells_dense", C.c_int64), ("cells_touched", C.c_int64),
         ("bytes_algorithmic", C.c_int64), ("n_band_retries", C.c_int64),
         ("n_tie_replays", C.c_int64), ("ms_tie", C.c_double),
+        ("ms_wall", C.c_double), ("ms_wall_phase", C.c_double * 6), ("ms_host_alloc", C.c_double),
+        ("ms_host_blocked", C.c_double), ("n_device_allocs", C.c_int64), ("n_device_frees", C.c_int64),
+        ("n_host_allocs", C.c_int64),
     ]
 
 

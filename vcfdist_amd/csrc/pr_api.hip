@@ -24,6 +24,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -122,10 +123,17 @@ class ParPool {
         if (const char *lw = getenv("LOCAL_WORLD_SIZE")) { const int n = atoi(lw); if (n > 1) hw = std::max(1u, hw / unsigned(n)); }
         return hw;
     }
+  public:
+    // detached workers beside the calling thread for a quota of `lim` CPUs: none when the quota is 1 - 3 (the unsigned
+    // `lim - max(2, lim / 4)` of round 3 wrapped around for lim = 1 and started 31)
+    static unsigned pool_workers(unsigned lim) {
+        const unsigned keep = std::max(2u, lim / 4);
+        return (lim > keep ? std::min<unsigned>(lim - keep, PAR_MAX) : 1u) - 1;
+    }
+  private:
     ParPool() {
         // (a quarter of the quota stays free for the callers themselves and the runtime's threads)
-        const unsigned lim = cpu_limit();
-        const unsigned n = std::min<unsigned>(std::max(1u, lim - std::max(2u, lim / 4)), PAR_MAX) - 1;
+        const unsigned n = pool_workers(cpu_limit());
         for (unsigned t = 0; t < n; t++) std::thread([this] { worker(); }).detach();
     }
     void work_on(Job &job) {
@@ -254,6 +262,13 @@ struct vpr_handle {
     vpr_config cfg;
     std::string err;
     bool debug = false;                  // VPR_DEBUG in the environment at vpr_create: progress lines on stderr
+    // host-side cost of the current / last vpr_execute: allocator calls and blocking waits (vpr_timing reports them; with
+    // VPR_STALL_LOG in the environment every such call that takes more than 5 ms is printed with its site)
+    struct HostStat {
+        int64_t n_dev_alloc = 0, n_dev_free = 0, n_pin_alloc = 0;
+        double ms_alloc = 0, ms_sync = 0, ms_idle_max = 0;
+    } hs;
+    bool stall_log = false;
     hipStream_t stream = nullptr;
     hipStream_t cls_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -262,6 +277,9 @@ struct vpr_handle {
     // runs at ~6 GB/s, which is most of what a re-upload into a used handle cost
     struct Blk { void *p; size_t bytes; };
     std::vector<Blk> dev_cache, pin_cache, pinned_blk;
+    std::vector<Blk> parked;             // device blocks outgrown during an execute: to dev_cache when the batch is released
+    int64_t dev_total = 0;               // the device's memory (vpr_create)
+    int64_t tie_scratch_max = 0, lad_arena_max = 0;   // bounds of the replay scratches / ladder workspaces that grow on demand
     std::vector<size_t> alloc_bytes;     // sizes of `allocs`
     std::vector<void *> allocs;
     uint8_t *pool_cur = nullptr;         // bump pointer into the newest block
@@ -277,7 +295,7 @@ struct vpr_handle {
     // device blocks with the lifetime of one execute (the strip tables and boundary columns of the wide dense sweeps,
     // pr_strip.hip): taken from the batch's allocations, handed out again by the next execute
     struct ExecBlk { uint8_t *p; size_t bytes; bool used; };
-    std::vector<ExecBlk> exec_blks;
+    std::vector<ExecBlk> exec_blks, exec_pins;
     bool no_strips = false;              // VPR_NO_STRIPS in the environment: wide alignments stay in one workgroup
     bool no_round_overlap = false;       // VPR_NO_ROUND_OVERLAP: a retry round is complete before the host looks at its fail lists
     std::vector<uint32_t> scratch_u32[2];
@@ -396,6 +414,55 @@ int fail(vpr_handle *h, int code, const char *fmt, ...) {
             return fail(h, VPR_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+inline double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline void slow_call(vpr_handle *h, const char *what, const char *site, size_t bytes, double dt) {
+    if (h && h->stall_log && dt > 5.0) fprintf(stderr, "[vpr] slow host call: %s (%zu bytes) at %s: %.1f ms\n", what, bytes, site, dt);
+}
+// every allocator call and blocking wait of the library goes through these: counted and timed per execute
+hipError_t x_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
+    const double t = wall_ms();
+    const hipError_t e = hipMalloc(q, bytes);
+    const double dt = wall_ms() - t;
+    if (h) { h->hs.n_dev_alloc++; h->hs.ms_alloc += dt; }
+    slow_call(h, "hipMalloc", site, bytes, dt);
+    return e;
+}
+hipError_t x_free(vpr_handle *h, void *q, const char *site) {
+    const double t = wall_ms();
+    const hipError_t e = hipFree(q);
+    const double dt = wall_ms() - t;
+    if (h) { h->hs.n_dev_free++; h->hs.ms_alloc += dt; }
+    slow_call(h, "hipFree", site, 0, dt);
+    return e;
+}
+hipError_t x_host_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
+    const double t = wall_ms();
+    const hipError_t e = hipHostMalloc(q, bytes, hipHostMallocDefault);
+    const double dt = wall_ms() - t;
+    if (h) { h->hs.n_pin_alloc++; h->hs.ms_alloc += dt; }
+    slow_call(h, "hipHostMalloc", site, bytes, dt);
+    return e;
+}
+hipError_t x_sync(vpr_handle *h, hipStream_t s_, const char *site) {
+    const double t = wall_ms();
+    const hipError_t e = hipStreamSynchronize(s_);
+    const double dt = wall_ms() - t;
+    if (h) h->hs.ms_sync += dt;
+    slow_call(h, "hipStreamSynchronize", site, 0, dt);
+    return e;
+}
+hipError_t x_event_sync(vpr_handle *h, hipEvent_t ev, const char *site) {
+    const double t = wall_ms();
+    const hipError_t e = hipEventSynchronize(ev);
+    const double dt = wall_ms() - t;
+    if (h) h->hs.ms_sync += dt;
+    slow_call(h, "hipEventSynchronize", site, 0, dt);
+    return e;
+}
+#define SITE_STR2(x) #x
+#define SITE_STR(x) SITE_STR2(x)
+#define SITE __FILE__ ":" SITE_STR(__LINE__)
+
 // a device block of at least `bytes` bytes: a kept one that is not wastefully larger, else a new allocation
 void *dev_block(vpr_handle *h, size_t bytes, hipError_t *err) {
     *err = hipSuccess;
@@ -410,12 +477,12 @@ void *dev_block(vpr_handle *h, size_t bytes, hipError_t *err) {
         q = h->dev_cache[size_t(best)].p; got = h->dev_cache[size_t(best)].bytes;
         h->dev_cache.erase(h->dev_cache.begin() + best);
     } else {
-        *err = hipMalloc(&q, bytes);
+        *err = x_malloc(h, &q, bytes, SITE);
         if (*err != hipSuccess) {        // out of memory with blocks kept aside: release them and try once more
-            for (auto &c : h->dev_cache) (void)hipFree(c.p);
+            for (auto &c : h->dev_cache) (void)x_free(h, c.p, SITE);
             h->dev_cache.clear();
             (void)hipGetLastError();
-            *err = hipMalloc(&q, bytes);
+            *err = x_malloc(h, &q, bytes, SITE);
             if (*err != hipSuccess) return nullptr;
         }
     }
@@ -439,7 +506,7 @@ int pin_alloc(vpr_handle *h, void **out, size_t bytes) {
         return VPR_OK;
     }
     void *q = nullptr;
-    const hipError_t e = hipHostMalloc(&q, bytes, hipHostMallocDefault);
+    const hipError_t e = x_host_malloc(h, &q, bytes, SITE);
     if (e != hipSuccess) return fail(h, VPR_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
     h->pinned_blk.push_back(vpr_handle::Blk{q, bytes});
     *out = q;
@@ -453,7 +520,7 @@ int dev_alloc(vpr_handle *h, T **p, size_t n) {
     const size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
     if (h->cfg.flags & VPR_CFG_GUARD_ALLOC) {      // debugging aid: every array its own allocation (an access far behind one faults)
         void *q = nullptr;
-        hipError_t e = hipMalloc(&q, bytes);
+        hipError_t e = x_malloc(h, &q, bytes, SITE);
         if (e != hipSuccess) return fail(h, VPR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
         h->allocs.push_back(q);
         h->alloc_bytes.push_back(0);     // (0: not kept for reuse)
@@ -510,20 +577,42 @@ int exec_alloc(vpr_handle *h, void **out, size_t bytes) {
     return VPR_OK;
 }
 
+// page-locked host memory with the lifetime of one execute (strip planning tables, the selection list of the deferred edit
+// distances): blocks of the batch's, handed out again by the next execute
+int exec_pin(vpr_handle *h, void **out, size_t bytes) {
+    bytes = std::max<size_t>((bytes + 255) & ~size_t(255), 256);
+    int best = -1;
+    for (size_t k = 0; k < h->exec_pins.size(); k++) {
+        const auto &b = h->exec_pins[k];
+        if (!b.used && b.bytes >= bytes && (best < 0 || b.bytes < h->exec_pins[size_t(best)].bytes)) best = int(k);
+    }
+    if (best < 0) {
+        void *q = nullptr;
+        const int rc = pin_alloc(h, &q, bytes + bytes / 2);
+        if (rc) return rc;
+        h->exec_pins.push_back(vpr_handle::ExecBlk{static_cast<uint8_t *>(q), bytes + bytes / 2, false});
+        best = int(h->exec_pins.size()) - 1;
+    }
+    h->exec_pins[size_t(best)].used = true;
+    *out = h->exec_pins[size_t(best)].p;
+    return VPR_OK;
+}
+
 void free_batch(vpr_handle *h) {
     for (size_t k = 0; k < h->allocs.size(); k++) {
         if (h->alloc_bytes[k]) h->dev_cache.push_back(vpr_handle::Blk{h->allocs[k], h->alloc_bytes[k]});
-        else (void)hipFree(h->allocs[k]);
+        else (void)x_free(h, h->allocs[k], SITE);
     }
     h->allocs.clear(); h->alloc_bytes.clear();
     while (h->dev_cache.size() > 96) {      // (a long run over batches of very different sizes: drop the smallest blocks)
         size_t m = 0;
         for (size_t k = 1; k < h->dev_cache.size(); k++) if (h->dev_cache[k].bytes < h->dev_cache[m].bytes) m = k;
-        (void)hipFree(h->dev_cache[m].p);
+        (void)x_free(h, h->dev_cache[m].p, SITE);
         h->dev_cache.erase(h->dev_cache.begin() + long(m));
     }
     h->pool_cur = nullptr; h->pool_left = 0; h->pool_next = size_t(16) << 20;
     h->exec_blks.clear();
+    h->exec_pins.clear();
     for (void *p : h->pinned) (void)hipHostFree(p);
     h->pinned.clear();
     for (auto &b : h->pinned_blk) h->pin_cache.push_back(b);
@@ -545,10 +634,16 @@ void free_batch(vpr_handle *h) {
     h->d_arena = nullptr; h->d_secs = nullptr;
     for (int k = 0; k < 4; k++) h->d_cls[k] = nullptr;
     h->d_hist = nullptr; h->hist_cap = 0; h->d_pb = nullptr;
-    for (int k = 0; k < 4; k++) {
-        for (int e = 0; e < 2; e++) if (h->lad[k].tie_scratch[e]) (void)hipFree(h->lad[k].tie_scratch[e]);
-        h->lad[k] = LadderCtx();
+    for (int k = 0; k < 4; k++) {      // (the replay scratches are the handle's, not the batch's: they survive)
+        LadderCtx keep;
+        for (int e = 0; e < 2; e++) {
+            keep.tie_scratch[e] = h->lad[k].tie_scratch[e]; keep.tie_scratch_bytes[e] = h->lad[k].tie_scratch_bytes[e];
+            keep.tie_first[e] = h->lad[k].tie_first[e];
+        }
+        h->lad[k] = keep;
     }
+    for (auto &b : h->parked) h->dev_cache.push_back(b);     // (nothing is in flight when a batch is released)
+    h->parked.clear();
     h->resident.clear();
     h->res0_cnt = 0;
     h->d_ed_scratch = nullptr; h->ed_scratch_ints = 0;
@@ -1128,11 +1223,19 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->debug = getenv("VPR_DEBUG") != nullptr;
     h->no_strips = getenv("VPR_NO_STRIPS") != nullptr;
     h->no_round_overlap = getenv("VPR_NO_ROUND_OVERLAP") != nullptr;
+    h->stall_log = getenv("VPR_STALL_LOG") != nullptr;
     memset(&h->dB, 0, sizeof(h->dB));
     memset(&h->timing, 0, sizeof(h->timing));
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
         delete h;
         return fail(nullptr, VPR_ERR_DEVICE, "hipSetDevice/hipStreamCreate failed");
+    }
+    {   // bounds of what grows on demand during an execute: fractions of the DEVICE's memory, fixed here
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { delete h; return fail(nullptr, VPR_ERR_DEVICE, "hipMemGetInfo failed"); }
+        h->dev_total = int64_t(total_b);
+        h->tie_scratch_max = std::max<int64_t>(h->dev_total / 16, int64_t(64) << 20);
+        h->lad_arena_max = std::max<int64_t>(h->dev_total / 8, int64_t(64) << 20);
     }
     // Streams 0, 2, 3 carry latency chains (long alignments, retry ladders) and get the highest priority, so their
     // few workgroups are dispatched ahead of the millions of the bulk stream (1) instead of behind them.
@@ -1176,9 +1279,11 @@ void vpr_destroy(vpr_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     free_batch(h);
-    for (auto &b : h->dev_cache) (void)hipFree(b.p);
+    for (auto &b : h->dev_cache) (void)x_free(h, b.p, SITE);
+    for (int k = 0; k < 4; k++)
+        for (int e = 0; e < 2; e++) if (h->lad[k].tie_scratch[e]) (void)x_free(h, h->lad[k].tie_scratch[e], SITE);
     for (auto &b : h->pin_cache) (void)hipHostFree(b.p);
-    if (h->d_ctg_seq) (void)hipFree(h->d_ctg_seq);
+    if (h->d_ctg_seq) (void)x_free(h, h->d_ctg_seq, SITE);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int k = 0; k < 8; k++) {
         if (h->cls_stream[k]) (void)hipStreamDestroy(h->cls_stream[k]);
@@ -1274,10 +1379,10 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         memset(&G, 0, sizeof(G));
         const int64_t ctg_total = v->ctg_off[v->n_ctg];
         if (ctg_total > h->ctg_bytes) {
-            if (h->d_ctg_seq) (void)hipFree(h->d_ctg_seq);
+            if (h->d_ctg_seq) (void)x_free(h, h->d_ctg_seq, SITE);
             h->d_ctg_seq = nullptr; h->ctg_bytes = 0;
             void *q = nullptr;
-            if (hipMalloc(&q, size_t(ctg_total) + 256) != hipSuccess) return fail(h, VPR_ERR_NOMEM, "contig sequence (%lld bytes)", (long long)ctg_total);
+            if (x_malloc(h, &q, size_t(ctg_total) + 256, SITE) != hipSuccess) return fail(h, VPR_ERR_NOMEM, "contig sequence (%lld bytes)", (long long)ctg_total);
             h->d_ctg_seq = static_cast<uint8_t *>(q);
             h->ctg_bytes = ctg_total;
         }
@@ -1566,7 +1671,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     }
     if (lv0 == LV_Z && (rc = prep_zero_lane(h))) return rc;
 
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, x_sync(h, h->stream, SITE));
     HIPCHK(h, hipGetLastError());
     lap("plan + upload");
     uint32_t err = 0;
@@ -1637,7 +1742,7 @@ namespace {
 struct Exec {
     vpr_handle *h;
     hipStream_t st;
-    std::chrono::steady_clock::time_point wall0;
+    std::chrono::steady_clock::time_point wall0, call0 = std::chrono::steady_clock::now();
     hipEvent_t t0 = nullptr, t1 = nullptr;      // bracket the whole call on the main stream
     int32_t flag_exp[16] = {};                  // value post_flag asked the device to write into hp_flag[idx]
     int64_t n_fwd = 0, cells_touched = 0, n_retry = 0;
@@ -1699,6 +1804,19 @@ struct Exec {
         return VPR_OK;
     }
 
+    std::vector<std::pair<double, std::string>> trace_;      // (VPR_STALL_LOG) host actions with their wall-clock offsets
+    double stall_dump_ms = 200.0;
+    void trace(const char *fmt, ...) {
+        if (!h->stall_log) return;
+        char buf[160];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        trace_.emplace_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - call0).count(), buf);
+    }
+    double phase_ms[6] = {0, 0, 0, 0, 0, 0};
+    void phase(int k) { phase_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - call0).count(); }
     void lapx(const char *what) {
         if (h->debug) fprintf(stderr, "[vpr] execute %-34s %8.3f ms\n", what,
                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
@@ -1718,14 +1836,25 @@ struct Exec {
     int idle_check(int64_t idle_polls, std::chrono::steady_clock::time_point since) {
         if (launch_err != hipSuccess) return fail(h, VPR_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(launch_err));
         if (idle_polls % 2048) return VPR_OK;            // about every 40 ms without progress
-        hipStream_t ss[] = {h->stream, h->cls_stream[0], h->cls_stream[1], h->cls_stream[2], h->cls_stream[3],
+        hipStream_t ss[] = {h->stream, h->cls_stream[0], h->cls_stream[1], h->cls_stream[2], h->cls_stream[3], h->cls_stream[4],
+                            h->cls_stream[5], h->cls_stream[6], h->cls_stream[7],
                             h->tie_stream[0], h->tie_stream[1], h->tie_stream[2], h->tie_stream[3]};
+        bool busy = false;
         for (hipStream_t s_ : ss) {
             const hipError_t e = hipStreamQuery(s_);
             if (e != hipSuccess && e != hipErrorNotReady) return fail(h, VPR_ERR_DEVICE, "stream error while waiting for a round: %s", hipGetErrorString(e));
+            busy = busy || e == hipErrorNotReady;
         }
+        // every stream idle and still no flag: the work the flag stands behind is lost.  Streams busy: a round may take long
+        // (one dense alignment of an SV-sized supercluster is a chain of tens of thousands of rows), so the bound is generous
+        // -- VPR_IDLE_TIMEOUT_S in the environment, 1800 s -- and on giving up the device is drained first, so that the
+        // caller can release or re-upload the handle without kernels still at work in its memory.
         const double idle_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - since).count();
-        if (idle_s > 300.0) return fail(h, VPR_ERR_DEVICE, "no round completed for %.0f s", idle_s);
+        static const double limit_s = [] { const char *e = getenv("VPR_IDLE_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 1800.0; }();
+        if ((!busy && idle_s > 10.0) || idle_s > limit_s) {
+            (void)hipDeviceSynchronize();
+            return fail(h, VPR_ERR_DEVICE, "no round completed for %.0f s (%s)", idle_s, busy ? "streams still busy" : "every stream idle: a flag was lost");
+        }
         return VPR_OK;
     }
 
@@ -1814,21 +1943,24 @@ struct Exec {
         // should share theirs with each other, not spread over all of them
         std::stable_sort(needs.begin(), needs.end(), [](const Need &x, const Need &y) { return x.cells > y.cells; });
         if (tie_job_cur + needs.size() > h->tie_jobs_cap) return fail(h, VPR_ERR_STATE, "tie round: job buffer overflow");
-        size_t free_b = 0, total_b = 0;
-        if (total * 4 + 256 > scratch_bytes) HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
-        // (the block a launch outgrew is released first, so what it holds counts as free; a block already at the bound stays)
-        const int64_t nb_want = std::max<int64_t>(std::min<int64_t>(total * 4, int64_t((free_b + size_t(scratch_bytes)) / 3)), largest * 4) + 256;
-        if (largest * 4 + 256 > scratch_bytes || (total * 4 > scratch_bytes && nb_want > scratch_bytes + scratch_bytes / 8)) {
-            HIPCHK(h, hipStreamSynchronize(ks));
-            if (scratch) (void)hipFree(scratch);
-            scratch = nullptr; scratch_bytes = 0;
-            const int64_t nb = nb_want;
+        // The scratch grows to hold the whole launch, at least doubling, up to a bound fixed at vpr_create (a sixteenth of the
+        // device's memory; never from hipMemGetInfo: with other handles at work on the device that figure depends on the
+        // moment).  The outgrown block is PARKED, not freed (kernels of this stream may still use it, and hipFree both waits
+        // for the whole device and takes seconds for a block of gigabytes): free_batch moves it to the kept blocks.  The
+        // scratches themselves have the handle's lifetime.
+        if (largest * 4 + 256 > scratch_bytes || (total * 4 + 256 > scratch_bytes && scratch_bytes < h->tie_scratch_max)) {
+            const int64_t nb = std::max<int64_t>(std::max<int64_t>(std::min<int64_t>(total * 4, h->tie_scratch_max), 2 * scratch_bytes), largest * 4) + 256;
             void *q = nullptr;
-            if (hipMalloc(&q, size_t(nb)) != hipSuccess)
-                return fail(h, VPR_ERR_NOMEM, "tie replay scratch (%lld bytes)", (long long)nb);
-            scratch = static_cast<uint32_t *>(q);
-            scratch_bytes = nb;
-            tc.tie_clean[early ? 1 : 0] = 0;
+            if (x_malloc(h, &q, size_t(nb), SITE) != hipSuccess) {
+                (void)hipGetLastError();
+                if (largest * 4 + 256 > scratch_bytes) return fail(h, VPR_ERR_NOMEM, "tie replay scratch (%lld bytes)", (long long)nb);
+                // (the launch still fits in sub-batches: keep the block)
+            } else {
+                if (scratch) h->parked.push_back(vpr_handle::Blk{scratch, size_t(scratch_bytes)});
+                scratch = static_cast<uint32_t *>(q);
+                scratch_bytes = nb;
+                tc.tie_clean[early ? 1 : 0] = 0;
+            }
         }
         // decision list of an early launch: one region of the decision buffer, its length in a counter of its own
         int4 *dec = nullptr;
@@ -1932,7 +2064,7 @@ struct Exec {
         G.off = off; G.cnt = cnt;
         // slots per alignment: twice what the longer plane needs (a cut may have to move far back to a clean column)
         void *pb = nullptr;
-        { int rc_pin = pin_alloc(h, &pb, size_t(cnt + 1) * 4 + size_t(cnt) * 9 + 16); if (rc_pin) return rc_pin; }
+        { int rc_pin = exec_pin(h, &pb, size_t(cnt + 1) * 4 + size_t(cnt) * 9 + 16); if (rc_pin) return rc_pin; }
         int64_t *h_boff = static_cast<int64_t *>(pb);
         int32_t *h_base = reinterpret_cast<int32_t *>(h_boff + cnt);
         uint8_t *h_fits = reinterpret_cast<uint8_t *>(h_base + cnt + 1);
@@ -2248,7 +2380,7 @@ struct Exec {
 
     // read a fail slot once its list is complete (copies ride on stream `ls`, never the null stream)
     int read_fails(int slot, int64_t fail_off, hipStream_t ls, std::vector<int32_t> &fails) {
-        HIPCHK(h, hipEventSynchronize(h->ev_slot[slot]));      // the list and its length are in pinned host memory by then
+        HIPCHK(h, x_event_sync(h, h->ev_slot[slot], SITE));      // the list and its length are in pinned host memory by then
         const int32_t nf = h->hp_cnt[slot];
         if (nf > 0) {
             const size_t f0 = fails.size();
@@ -2258,7 +2390,7 @@ struct Exec {
                     const int32_t a = fails[k];
                     AlnOut o;
                     (void)hipMemcpyAsync(&o, h->d_outs + a, sizeof(o), hipMemcpyDeviceToHost, ls);
-                    (void)hipStreamSynchronize(ls);
+                    (void)x_sync(h, ls, SITE);
                     const AlnDesc &d = h->descs[a];
                     fprintf(stderr, "[vpr] level %d rejected sc %d aln %d: Lq %d Lr %d Lt %d  s %d exit_min %d dq %d dr %d\n",
                             int(h->level[a]), d.sc, d.aln, d.Lq, d.Lr, d.Lt, o.s, o.exit_min, o.dist_q, o.dist_r);
@@ -2274,8 +2406,8 @@ struct Exec {
     // each other and beside the rest of round 0; the host only ever waits for a fail list it needs next.
     bool overlap(const LadderCtx &c) const { return !h->no_round_overlap && !h->no_strips && c.ls2 != nullptr && (&c - h->lad) < 2; }
     int lad_sync(LadderCtx &c) {        // everything the context has in flight (its side stream: the back halves of retry rounds)
-        HIPCHK(h, hipStreamSynchronize(c.ls));
-        if (overlap(c)) HIPCHK(h, hipStreamSynchronize(c.ls2));
+        HIPCHK(h, x_sync(h, c.ls, SITE));
+        if (overlap(c)) HIPCHK(h, x_sync(h, c.ls2, SITE));
         return VPR_OK;
     }
     int lad_flush(LadderCtx &c, std::vector<int32_t> &out) {
@@ -2315,6 +2447,28 @@ struct Exec {
             if (r.second >= c.arena && r.second < c.arena + c.arena_bytes) r.second = nullptr;
     }
 
+    // A larger workspace for ladder context c -- and for its sibling retry ladder: which of the two contexts a round runs
+    // on depends on which is idle at that moment, so they grow together and one execute settles the sizes of both.  The
+    // old blocks stay allocated until the batch is released (dev_alloc: the plans in flight point into them), so nothing
+    // has to be waited for.
+    bool lad_grow(LadderCtx &c, int64_t nb) {
+        const int k = int(&c - h->lad);
+        for (int j = 0; j < 4; j++) {
+            LadderCtx &g = h->lad[j];
+            if (&g != &c && !(k < 2 && j == 1 - k)) continue;
+            if (g.arena_bytes >= nb) continue;
+            uint8_t *na2 = nullptr;
+            if (dev_alloc(h, &na2, size_t(nb) + 256) != VPR_OK) {
+                h->err.clear();
+                (void)hipGetLastError();
+                if (&g == &c) return false;
+                continue;
+            }
+            g.arena = na2; g.arena_bytes = nb; g.arena_cur = 0;
+        }
+        return true;
+    }
+
     // tie: the tie pass -- same level again, with the container-order replay between the forward and the backward sweep
     int lad_start(LadderCtx &c, std::vector<int32_t> &fails, std::vector<int32_t> &carry, bool tie = false) {
         if (fails.empty()) return VPR_OK;
@@ -2328,21 +2482,26 @@ struct Exec {
             fprintf(stderr, "[vpr] retry round (ladder %d): %zu -> 16, %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n",
                     int(&c - h->lad), by_lv[1].size(), by_lv[2].size(), by_lv[3].size(), by_lv[4].size(), by_lv[5].size());
         const size_t nf = fails.size();
-        if (c.work_cap < c.stage_cur + nf || c.hp_cap < c.stage_cur + nf) {   // (rounds still in flight hold the front)
-            { const int rs = lad_sync(c); if (rs) return rs; }
-            c.stage_cur = 0;
-        }
-        if (c.work_cap < nf) {
-            int rc = dev_alloc(h, &c.d_work, nf * 2);
-            if (rc) return rc;
-            c.work_cap = nf * 2;
-        }
-        if (c.hp_cap < nf) {
-            void *pd = nullptr, *pw = nullptr;
-            { const int rs = lad_sync(c); if (rs) return rs; }           // (nothing may still read the old staging block)
-            { int rc_pin = pin_alloc(h, &pd, nf * 2 * sizeof(AlnDesc)); if (rc_pin) return rc_pin; }
-            { int rc_pin = pin_alloc(h, &pw, nf * 2 * sizeof(int32_t)); if (rc_pin) return rc_pin; }
-            c.hp_descs = static_cast<AlnDesc *>(pd); c.hp_work = static_cast<int32_t *>(pw); c.hp_cap = nf * 2;
+        if (c.work_cap < c.stage_cur + nf || c.hp_cap < c.stage_cur + nf) {
+            // The staging of this context (device work lists, page-locked descriptor source of k_stage) has run out: rounds
+            // still in flight hold its front.  New, larger blocks -- for the sibling retry ladder too, see lad_grow -- instead
+            // of waiting for those rounds; the old blocks are released with the batch.
+            const int k = int(&c - h->lad);
+            for (int j = 0; j < 4; j++) {
+                LadderCtx &g = h->lad[j];
+                if (&g != &c && !(k < 2 && j == 1 - k)) continue;
+                const size_t cap = std::max<size_t>(2 * (c.stage_cur + nf), 1 << 14);
+                if (g.work_cap >= cap && g.hp_cap >= cap && &g != &c) continue;
+                void *pd = nullptr, *pw = nullptr;
+                int32_t *dw_ = nullptr;
+                int rc = dev_alloc(h, &dw_, cap);
+                if (rc) return rc;
+                { int rc_pin = pin_alloc(h, &pd, cap * sizeof(AlnDesc)); if (rc_pin) return rc_pin; }
+                { int rc_pin = pin_alloc(h, &pw, cap * sizeof(int32_t)); if (rc_pin) return rc_pin; }
+                g.d_work = dw_; g.work_cap = cap;
+                g.hp_descs = static_cast<AlnDesc *>(pd); g.hp_work = static_cast<int32_t *>(pw); g.hp_cap = cap;
+                g.stage_cur = 0;
+            }
         }
         bool zero_slots = true;
         std::vector<std::function<int()>> later;      // what a retry round enqueues behind its flag (below)
@@ -2365,32 +2524,17 @@ struct Exec {
             if (rc == VPR_OK && P.chunks.size() > 1 && h->cfg.workspace_bytes <= 0) {
                 // the plan needs several passes through the ladder's workspace (it starts small), i.e. its launches run one
                 // after the other with a few alignments each -- at the dense level that is one workgroup per alignment on a
-                // 256-CU device.  Grow the workspace to hold the plan, as far as half of the free memory allows.
-                size_t free_b = 0, total_b = 0;
-                HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
-                // (a ladder whose rounds overlap hands its workspace out once: twice the plan leaves room for the next round
-                // without waiting for this one)
-                const int64_t nb = std::min<int64_t>((overlap(c) ? 2 : 1) * P.total_need + (1 << 20), int64_t(free_b / 2));
-                if (nb > c.arena_bytes + c.arena_bytes / 2) {
-                    { const int rs = lad_sync(c); if (rs) return rs; }
-                    uint8_t *na2 = nullptr;
-                    if (dev_alloc(h, &na2, size_t(nb) + 256) == VPR_OK) {   // (the old block is released with the batch)
-                        c.arena = na2; c.arena_bytes = nb; c.arena_cur = 0;
-                        rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes, tag_or);
-                    } else {
-                        h->err.clear();
-                    }
-                }
+                // 256-CU device.  Grow the workspace to hold the plan (a ladder whose rounds overlap hands its workspace out
+                // once: twice the plan leaves room for the next round without waiting for this one), up to the bound fixed at
+                // vpr_create.
+                const int64_t nb = std::min<int64_t>((overlap(c) ? 2 : 1) * P.total_need + (1 << 20), h->lad_arena_max);
+                if (nb > c.arena_bytes + c.arena_bytes / 2 && lad_grow(c, nb))
+                    rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes, tag_or);
             }
             if (rc == VPR_ERR_NOMEM && h->cfg.workspace_bytes <= 0) {
                 // one alignment does not fit the ladder's workspace: grow it to twice that need
-                { const int rs = lad_sync(c); if (rs) return rs; }
-                const int64_t nb = std::max<int64_t>(2 * h->last_need, 2 * c.arena_bytes);
-                uint8_t *na2 = nullptr;
-                if (dev_alloc(h, &na2, size_t(nb) + 256) == VPR_OK) {   // (the old block is released with the batch)
-                    c.arena = na2; c.arena_bytes = nb; c.arena_cur = 0;
+                if (lad_grow(c, std::max<int64_t>(2 * h->last_need, 2 * c.arena_bytes)))
                     rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes, tag_or);
-                }
             }
             if (rc) return rc;
             if (P.chunks.size() == 1) c.arena_cur += round_up(P.arena_used, 256);
@@ -2695,6 +2839,7 @@ struct Exec {
             // (the runtime submits a stream's trailing marker lazily: without these flushes the fork event on the main
             // stream, on which everything above waits, is only submitted when the host next blocks on something)
             lapx("round 0 enqueued");
+            if (ci == 0) phase(1);
             // ---- the host serves whatever is ready: a fail list of round 0 starts a ladder, a finished ladder round
             // starts the next, a published tie list starts a tie round; it never blocks on one while another is ready
             std::vector<int32_t> fails, carry[2];
@@ -2706,6 +2851,7 @@ struct Exec {
                 bool progressed = false;
                 if (idle_polls == 0) idle_since = std::chrono::steady_clock::now();
                 if (wait_spec && flag_up(8)) {
+                    trace("flag 8 (speculative list), %d candidates", h->hp_tie_cnt[4]);
                     const int32_t n = std::min(h->hp_tie_cnt[4], tie_cap[2]);
                     // (a speculative replay pays off as a head start for a few long chains; when thousands of alignments carry
                     // tied cells most of them are never consulted, and the round waits for the backward sweep's marks instead)
@@ -2717,12 +2863,14 @@ struct Exec {
                 for (int k = 0; k < 2; k++) {
                     LadderCtx &c = h->lad[k];
                     if (lad_tie_wait[k] && flag_up(9 + k)) {       // (before the ladder's next round reuses the region)
+                        trace("flag %d (ladder %d tie list), %d marked", 9 + k, k, h->hp_tie_cnt[5 + k]);
                         const int32_t n = std::min(h->hp_tie_cnt[5 + k], lad_tie_cap(k));
                         if (n > 0 && (rc = tie_round(h->lad[2 + k], h->hp_tie_list + lad_tie_off(k), n, false, nullptr))) return rc;
                         lad_tie_wait[k] = false;
                         progressed = true;
                     }
                     if (wait_fail[k] && flag_up(k)) {
+                        trace("flag %d (round 0 fail list, part %d)", k, k);
                         fails.clear();
                         if (k == 1 && inplace) {
                             if ((rc = read_fails(SLOT_IP, foff_ip, c.ls, fails))) return rc;
@@ -2732,7 +2880,9 @@ struct Exec {
                         } else {
                             if ((rc = read_fails(k, k == 0 ? 0 : n_long, c.ls, fails))) return rc;
                         }
+                        trace("  %zu rejected -> ladder %d", fails.size(), k);
                         if ((rc = lad_start(c, fails, carry[k]))) return rc;
+                        trace("  ladder %d round enqueued", k);
                         lapx(k ? "short fail list -> ladder" : "long fail list -> ladder");
                         wait_fail[k] = false;
                         progressed = true;
@@ -2746,15 +2896,19 @@ struct Exec {
                         if (!h->no_round_overlap && h->lad[o].pending.empty() && !wait_fail[o] && !lad_tie_wait[o] && carry[o].empty()) tk = o;
                         else if (!lad_tie_wait[k]) tk = k;
                         if (tk >= 0) {
+                            trace("flag %d (ladder %d round done)", 4 + k, k);
                             fails.clear();
                             fails.swap(carry[k]);
                             if ((rc = lad_flush(c, fails))) return rc;
+                            trace("  %zu rejected -> ladder %d", fails.size(), tk);
                             if ((rc = lad_start(h->lad[tk], fails, carry[tk]))) return rc;
+                            trace("  ladder %d round enqueued", tk);
                             progressed = true;
                         }
                     }
                     if (wait_tie[k] && flag_up(2 + k)) {
                         const int32_t n = std::min(h->hp_tie_cnt[2 + k], tie_cap[k]);
+                        trace("flag %d (round 0 tie list, part %d), %d marked", 2 + k, k, n);
                         if (n > 0 && (rc = tie_round(h->lad[2 + k], h->hp_tie_list + tie_off[k], n, false, &ch))) return rc;
                         lapx(k ? "short tie list -> tie round" : "long tie list -> tie round");
                         wait_tie[k] = false;
@@ -2763,6 +2917,7 @@ struct Exec {
                 }
                 for (int k = 0; k < 2; k++)
                     if (!wait_tie[k] && !lad_tie_wait[k] && !h->lad[2 + k].pending.empty() && flag_up(6 + k)) {
+                        trace("flag %d (tie ladder %d round done)", 6 + k, k);
                         if ((rc = tie_flush(h->lad[2 + k]))) return rc;
                         progressed = true;
                     }
@@ -2774,6 +2929,7 @@ struct Exec {
                 }
             }
             lapx("ladders and tie rounds drained");
+            phase(2);
             // join: the next chunk reuses the arena
             HIPCHK(h, hipEventRecord(h->ev_join[0], s_long));
             HIPCHK(h, hipEventRecord(h->ev_join[1], s_short));
@@ -2784,7 +2940,7 @@ struct Exec {
             HIPCHK(h, hipEventRecord(h->ev_join[6], LL.ls2));
             HIPCHK(h, hipEventRecord(h->ev_join[7], LS.ls2));
             for (int k = 0; k < 8; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
-            if (ci + 1 < P0.chunks.size()) HIPCHK(h, hipStreamSynchronize(st));
+            if (ci + 1 < P0.chunks.size()) HIPCHK(h, x_sync(h, st, SITE));
             if (ci + 1 == P0.chunks.size()) { h->res0_off = ch.work_off; h->res0_cnt = ch.count; }
         }
         return VPR_OK;
@@ -2803,7 +2959,7 @@ struct Exec {
                 HIPCHK(h, hipMemcpyAsync(&n_mark, h->d_tie_cnt, 4, hipMemcpyDeviceToHost, st));
                 // (the number of deferred edit distances rides along: when nothing is marked it is final, and K4 needs no wait of its own)
                 HIPCHK(h, hipMemcpyAsync(&n_jobs_pre, h->d_njobs, 4, hipMemcpyDeviceToHost, st));
-                HIPCHK(h, hipStreamSynchronize(st));
+                HIPCHK(h, x_sync(h, st, SITE));
                 n_jobs_final = (n_mark == 0);
                 if (n_mark == 0) break;
                 if (iter >= 3) return fail(h, VPR_ERR_STATE, "tie pass: %d alignments still marked after %d attempts", n_mark, iter);
@@ -2814,7 +2970,7 @@ struct Exec {
                 if (h->debug) fprintf(stderr, "[vpr] final tie pass %d: %d alignments marked\n", iter, n_mark);
                 if ((rc = tie_round(h->lad[2], lst.data(), n, iter > 0, nullptr))) return rc;
                 if ((rc = tie_flush(h->lad[2]))) return rc;
-                HIPCHK(h, hipStreamSynchronize(h->lad[2].ls));
+                HIPCHK(h, x_sync(h, h->lad[2].ls, SITE));
             }
         }
         return rc;
@@ -2880,7 +3036,7 @@ struct Exec {
         int32_t n_jobs = n_jobs_pre;
         if (!n_jobs_final) {
             HIPCHK(h, hipMemcpyAsync(&n_jobs, h->d_njobs, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(h, hipStreamSynchronize(st));
+            HIPCHK(h, x_sync(h, st, SITE));
         }
         n_jobs = std::min(n_jobs, h->jobs_cap);
         if (n_jobs > 0) {
@@ -2901,7 +3057,7 @@ struct Exec {
             if (lds_wf <= 150 * 1024 && max_long < 29000 && !getenv("VPR_ED_DIAG")) {
                 // size classes by the longer string (x 4 from class to class), largest first
                 void *ps = nullptr, *qs = nullptr;
-                { int rc_pin = pin_alloc(h, &ps, size_t(n_jobs) * 4); if (rc_pin) return rc_pin; }
+                { int rc_pin = exec_pin(h, &ps, size_t(n_jobs) * 4); if (rc_pin) return rc_pin; }
                 if ((rc = exec_alloc(h, &qs, size_t(n_jobs) * 4))) return rc;
                 int32_t *h_sel = static_cast<int32_t *>(ps), *d_sel = static_cast<int32_t *>(qs);
                 std::vector<int32_t> order(static_cast<size_t>(n_jobs));
@@ -2991,7 +3147,9 @@ struct Exec {
             if (rc) return rc;
         }
         HIPCHK(h, hipEventRecord(t1, st));
-        HIPCHK(h, hipStreamSynchronize(st));
+        phase(4);
+        HIPCHK(h, hipStreamSynchronize(st));       // (the one wait every execute has: not counted as "blocked")
+        phase(5);
         lapx("done");
         HIPCHK(h, hipGetLastError());
         if (need_err_check) {
@@ -3019,6 +3177,30 @@ struct Exec {
         h->timing.cells_touched = cells_touched;
         h->timing.n_band_retries = n_retry;
         h->timing.n_tie_replays = n_tie_jobs;
+        h->timing.ms_wall = phase_ms[5];
+        for (int k = 0; k < 6; k++) h->timing.ms_wall_phase[k] = phase_ms[k];
+        h->timing.ms_host_alloc = h->hs.ms_alloc;
+        h->timing.ms_host_blocked = h->hs.ms_sync;
+        h->timing.n_device_allocs = h->hs.n_dev_alloc;
+        h->timing.n_device_frees = h->hs.n_dev_free;
+        h->timing.n_host_allocs = h->hs.n_pin_alloc;
+        if (h->stall_log && phase_ms[5] > stall_dump_ms) {      // the device's timeline of a slow execute, and what the host did when
+            std::vector<std::tuple<float, float, const char *, int>> tl;
+            for (auto &e : h->events) {
+                float a = 0, d = 0;
+                (void)hipEventElapsedTime(&a, t0, e.a);
+                (void)hipEventElapsedTime(&d, e.a, e.b);
+                tl.emplace_back(a, d, e.st.kernel, e.st.n_units);
+            }
+            std::sort(tl.begin(), tl.end());
+            for (auto &x : tl) fprintf(stderr, "[vpr]   %p dev %9.2f ms +%8.2f  %-24s %d\n", (void *)h, std::get<0>(x), std::get<1>(x), std::get<2>(x), std::get<3>(x));
+            for (auto &x : trace_) fprintf(stderr, "[vpr]   %p host %9.2f ms  %s\n", (void *)h, x.first, x.second.c_str());
+        }
+        if (h->stall_log)
+            fprintf(stderr, "[vpr] execute %p: wall %.1f ms (reset %.1f, round 0 enqueued %.1f, drained %.1f, ties %.1f, K4/K5 enqueued %.1f), kernels %.1f ms, "
+                            "allocator %.1f ms (%lld hipMalloc, %lld hipFree, %lld hipHostMalloc), blocked %.1f ms\n", (void *)h, phase_ms[5], phase_ms[0],
+                    phase_ms[1], phase_ms[2], phase_ms[3], phase_ms[4], ms, h->hs.ms_alloc, (long long)h->hs.n_dev_alloc, (long long)h->hs.n_dev_free,
+                    (long long)h->hs.n_pin_alloc, h->hs.ms_sync);
         return VPR_OK;
     }
 
@@ -3047,8 +3229,9 @@ struct Exec {
         }
         // (measured: without one blocking call here the runtime does not start this call's submissions for 0.1 - 2 s when the
         // host goes straight to polling memory below, e.g. right behind another library's work on the device)
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, x_sync(h, h->stream, SITE));
         wall0 = std::chrono::steady_clock::now();
+        phase(0);
         HIPCHK(h, hipEventCreate(&t0));
         HIPCHK(h, hipEventCreate(&t1));
         HIPCHK(h, hipEventRecord(t0, st));
@@ -3074,6 +3257,7 @@ struct Exec {
         debug_replays();
         debug_levels();
         lapx("final tie pass done");
+        phase(3);
         if ((rc = deferred_edit_distances())) return rc;
         return finish();
     }
@@ -3087,6 +3271,8 @@ int vpr_execute(vpr_handle *h) {
     if (!h) return VPR_ERR_ARG;
     if (!h->uploaded) return fail(h, VPR_ERR_STATE, "vpr_execute before vpr_upload");
     for (auto &b : h->exec_blks) b.used = false;
+    for (auto &b : h->exec_pins) b.used = false;
+    h->hs = vpr_handle::HostStat();
     Exec x(h);
     const int rc = x.run();
     if (x.t0) (void)hipEventDestroy(x.t0);
@@ -3094,6 +3280,8 @@ int vpr_execute(vpr_handle *h) {
     if (rc == VPR_OK) h->executed = true;
     return rc;
 }
+
+int32_t vpr_test_pool_workers(int32_t cpu_quota) { return int32_t(ParPool::pool_workers(unsigned(std::max(cpu_quota, 1)))); }
 
 int vpr_get_launch_stats(const vpr_handle *h, vpr_launch_stat *out, int32_t cap) {
     if (!h) return VPR_ERR_ARG;
@@ -3136,7 +3324,7 @@ int vpr_download(vpr_handle *h, vpr_results *res) {
                       at(res->query_ed[s][w], R.v[s][w].query_ed) && at(res->callq[s][w], R.v[s][w].callq)));
         if (all) {
             HIPCHK(h, get(h->res_mirror, h->res_dev, h->res_bytes));
-            HIPCHK(h, hipStreamSynchronize(st));
+            HIPCHK(h, x_sync(h, st, SITE));
             return VPR_OK;
         }
     }
@@ -3160,7 +3348,7 @@ int vpr_download(vpr_handle *h, vpr_results *res) {
             HIPCHK(h, get(res->callq[s][w], R.v[s][w].callq, nv * 4));
         }
     }
-    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, x_sync(h, st, SITE));
     return VPR_OK;
 }
 
@@ -3263,7 +3451,7 @@ int vpr_upload_var_class(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS]
         }
         if (h->n_var[s]) HIPCHK(h, hipMemcpyAsync(h->d_cls[s], var_class[s], size_t(h->n_var[s]), hipMemcpyHostToDevice, h->stream));
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, x_sync(h, h->stream, SITE));
     return VPR_OK;
 }
 
@@ -3298,7 +3486,7 @@ int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const
     }
     std::vector<unsigned long long> hist(nh);
     HIPCHK(h, hipMemcpyAsync(hist.data(), d_hist, nh * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, x_sync(h, h->stream, SITE));
     // counts at threshold k: variants whose last threshold index is >= k (print.cpp:378-381, 425-428); a truth variant
     // additionally counts as FN at every threshold above its own (print.cpp:429-432)
     std::fill(counts, counts + size_t(2) * VPR_VARTYPES * 3 * size_t(nq), 0);
