@@ -33,6 +33,7 @@
 extern "C" int vpr_batch_skeleton_from_variants(const vpr_variants *v, vpr_owned_batch **out);   // generate.cpp
 #include "pr_kernels.hip"
 #include "pr_band.hip"
+#include "pr_walkseg.hip"
 #include "pr_q16.hip"
 #include "pr_zl.hip"
 #include "pr_gen.hip"
@@ -297,6 +298,7 @@ struct vpr_handle {
     struct ExecBlk { uint8_t *p; size_t bytes; bool used; };
     std::vector<ExecBlk> exec_blks, exec_pins;
     bool no_strips = false;              // VPR_NO_STRIPS in the environment: wide alignments stay in one workgroup
+    bool seq_walk = false;               // VPR_SEQ_WALK: the sequential row-sweep walk instead of the segment-parallel one
     bool no_round_overlap = false;       // VPR_NO_ROUND_OVERLAP: a retry round is complete before the host looks at its fail lists
     std::vector<uint32_t> scratch_u32[2];
     Plan plan0;                          // first round over all alignments, cached at upload
@@ -1224,6 +1226,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->no_strips = getenv("VPR_NO_STRIPS") != nullptr;
     h->no_round_overlap = getenv("VPR_NO_ROUND_OVERLAP") != nullptr;
     h->stall_log = getenv("VPR_STALL_LOG") != nullptr;
+    h->seq_walk = getenv("VPR_SEQ_WALK") != nullptr;
     memset(&h->dB, 0, sizeof(h->dB));
     memset(&h->timing, 0, sizeof(h->timing));
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
@@ -1805,7 +1808,7 @@ struct Exec {
     }
 
     std::vector<std::pair<double, std::string>> trace_;      // (VPR_STALL_LOG) host actions with their wall-clock offsets
-    double stall_dump_ms = 200.0;
+    double stall_dump_ms = getenv("VPR_STALL_DUMP_MS") ? atof(getenv("VPR_STALL_DUMP_MS")) : 200.0;     // executes slower than this are dumped
     void trace(const char *fmt, ...) {
         if (!h->stall_log) return;
         char buf[160];
@@ -2331,7 +2334,7 @@ struct Exec {
         if (!(phases & 4)) return rc;
         // long part (or a small launch of long retries): wave-per-alignment walk; windows up to 256
         const bool wave_walk = !q16 && (long_part || cnt < 2048);      // (k_walk<wave> stages tiles around the walk for the wider windows)
-        const bool row_walk = lv == LV_C1 && wave_walk;
+        const bool row_walk = lv == LV_C1 && (wave_walk || !h->seq_walk);      // (the segment walk serves launches of any size)
         vpr_launch_stat ws_;
         memset(&ws_, 0, sizeof(ws_));
         ws_.threads = q16 ? 16 : 64; ws_.n_units = cnt; ws_.cells_per_thread = 2;
@@ -2354,12 +2357,37 @@ struct Exec {
                                    h->d_njobs, h->jobs_cap, dtag, tag, n_dev);
             });
         } else if (row_walk) {
-            // striped 64-cell layout, long alignments: row-sweep walk (phase A) + credit walk (phase B); for the
-            // short ones the per-wave setup outweighs the pointer chase of the lane-per-alignment walk
-            rc = timed(3, ws_, ks, "k_walk_rows", [&] {
-                hipLaunchKernelGGL(k_walk_rows, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
-                                   P.arena, a_i32, h->d_outs, a_path, tag);
-            });
+            // striped 64-cell layout: the walk (phase A) in parallel over segments of 128 truth rows (pr_walkseg.hip; the
+            // sequential row sweep, k_walk_rows, with VPR_SEQ_WALK in the environment), then the credit walk (phase B)
+            if (h->seq_walk) {
+                rc = timed(3, ws_, ks, "k_walk_rows", [&] {
+                    hipLaunchKernelGGL(k_walk_rows, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                       P.arena, a_i32, h->d_outs, a_path, tag);
+                });
+            } else {
+                int64_t rows_sum = 0;
+                for (int32_t k = 0; k < cnt; k++) rows_sum += plan_desc(h, P, size_t(off) + size_t(k)).Lt;
+                WsegTables T;
+                T.cap = int32_t(std::min<int64_t>(rows_sum / WSEG_ROWS + cnt + 1, 0x7fffffff));
+                void *q = nullptr;
+                const size_t b_cnt = 256, b_base = round_up(int64_t(cnt) * 4, 256), b_own = round_up(int64_t(T.cap) * 8, 256),
+                             b_map = size_t(T.cap) * 128 * 8, b_ent = size_t(T.cap) * 16;
+                if ((rc = exec_alloc(h, &q, b_cnt + b_base + b_own + b_map + b_ent))) return rc;
+                uint8_t *u = static_cast<uint8_t *>(q);
+                T.counter = reinterpret_cast<int32_t *>(u); u += b_cnt;
+                T.seg_base = reinterpret_cast<int32_t *>(u); u += b_base;
+                T.owner = reinterpret_cast<int2 *>(u); u += b_own;
+                T.map = reinterpret_cast<uint2 *>(u); u += b_map;
+                T.entry = reinterpret_cast<int4 *>(u);
+                HIPCHK(h, hipMemsetAsync(T.counter, 0, 4, ks));
+                rc = timed(3, ws_, ks, "k_walk_seg", [&] {
+                    hipLaunchKernelGGL(k_wseg_plan, blocks(cnt), dim3(256), 0, ks, h->d_descs, list, cnt, h->d_outs, tag, T);
+                    hipLaunchKernelGGL(k_wseg_map, dim3(T.cap), dim3(128), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, T);
+                    hipLaunchKernelGGL(k_wseg_compose, dim3(cnt), dim3(64), 0, ks, h->d_descs, list, cnt, a_i32, h->d_outs, T);
+                    hipLaunchKernelGGL(k_wseg_emit, dim3(T.cap), dim3(64), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs,
+                                       a_path, T);
+                });
+            }
             if (rc) return rc;
             ws_.cells_per_thread = 3;
             rc = timed(3, ws_, ks, wave_walk ? "k_credit<wave>" : "k_credit<lane>", [&] {

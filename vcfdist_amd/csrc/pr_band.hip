@@ -330,6 +330,16 @@ __device__ __forceinline__ int exit_key(int ex, int p, int D, int rho, int2 bud,
     return ex ? D + k : D_INF;
 }
 
+// 16 bytes per lane from LDS to global memory, issued without the compiler's knowledge: it keeps no record of a store in
+// flight, so it places no s_waitcnt vmcnt(0) for it later on (a latency chain of one wave pays a full store round trip, ~0.5 us,
+// for each of those; gfx9 reads a store's data registers at issue, so reusing them at once is safe -- LLVM relies on the same).
+// The data becomes visible at the latest when the kernel ends.
+__device__ __forceinline__ void lds_to_global16(const void *lds_src, void *dst) {
+    uint4 tmp;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tglobal_store_dwordx4 %2, %0, off"
+                 : "=&v"(tmp) : "v"(uint32_t(uintptr_t(lds_src))), "v"(dst) : "memory");
+}
+
 __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__restrict__ descs,
                                                    const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
                                                    int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs) {
@@ -353,8 +363,16 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     int32_t *blo = blo_all + d.blo_off;
     const int n_stripes = (Lt + FS_K - 1) / FS_K;
-    // flag bytes of one stripe (FS_K rows x pitch <= 64 B per plane), flushed with one 16-byte store per lane
-    __shared__ __align__(16) uint8_t fbuf[2][FS_K * FS_W];
+    // flag bytes of a stripe (FS_K rows x pitch <= 64 B per plane), flushed with one 16-byte store per lane -- a stripe LATER
+    // (two buffers), so that the store is long complete when the wave next waits for a load: see lds_to_global16
+    __shared__ __align__(16) uint8_t fbuf2[2][2][FS_K * FS_W];
+    auto flush_stripe = [&](int s_) {
+        const int ta = s_ * FS_K, nr = min(FS_K, Lt - ta);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            if (lane * 16 < nr * d.pitch[p])
+                lds_to_global16(&fbuf2[s_ & 1][p][lane * 16], mat[p] + size_t(ta) * d.pitch[p] + lane * 16);
+    };
 
     // stripe origins, 64 stripes per register chunk (lane l <-> stripe c0 + l); next chunk prefetched
     int cbQ, cbR, nbQ, nbR;
@@ -393,6 +411,8 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
     for (int s = 0; s < n_stripes; s++) {
         const int t0 = s * FS_K;
         const int rows = min(FS_K, Lt - t0);
+        uint8_t (*fbuf)[FS_K * FS_W] = fbuf2[s & 1];
+        if (s > 0) flush_stripe(s - 1);
         // ---- next stripe's window, prefetch of its constants
         const bool has_next = s + 1 < n_stripes;
         if (has_next) {
@@ -558,16 +578,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
                 Dp[p] = Dn;
             }
         }
-        // ---- flush the stripe's flag rows: rows * pitch contiguous bytes per plane, 16 per lane
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int nbytes = rows * d.pitch[p];
-            if (lane * 16 < nbytes)
-                *reinterpret_cast<uint4 *>(mat[p] + size_t(t0) * d.pitch[p] + lane * 16) =
-                    *reinterpret_cast<const uint4 *>(&fbuf[p][lane * 16]);
-        }
-        asm volatile("" ::: "memory");
+        asm volatile("" ::: "memory");      // (the stripe's flag rows leave LDS at the start of the next stripe)
         // ---- advance to the next stripe
         plo[0] = lo[0]; plo[1] = lo[1];
         lo[0] = nlo[0]; lo[1] = nlo[1]; hi[0] = nhi[0]; hi[1] = nhi[1];
@@ -578,6 +589,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
             stripe_origin(t2r, tjp, r2q, s + 1 + 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
         }
     }
+    flush_stripe(n_stripes - 1);
     // end cells: row Lt-1 was computed with origins plo (the last stripe's)
     const int eq = Lq - 1 - plo[0], er = Lr - 1 - plo[1];
     const int dq = (eq >= 0 && eq < 64) ? __builtin_amdgcn_readlane(Dp[0], eq & 63) : D_INF;
@@ -802,26 +814,19 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
 // and one readlane of the run's last cell decides the move into row t+1.  Rows are read once, coalesced, from
 // the stripe's 16-byte LDS staging - no per-step pointer chase through HBM.
 // ===========================================================================
-__global__ void __launch_bounds__(64) k_walk_rows(DevBatch B, const AlnDesc *__restrict__ descs,
-                                                  const int32_t *__restrict__ work, int n_work,
-                                                  const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
-                                                  AlnOut *__restrict__ outs, PathEnt *__restrict__ paths, int tag) {
-    if (int(blockIdx.x) >= n_work) return;
-    __builtin_amdgcn_s_setprio(2);      // a latency chain (rows are sequential): win issue arbitration against the bulk kernels
-    const int a = work[blockIdx.x];
-    const AlnDesc d = descs[a];
-    AlnOut &O = outs[a];
-    if (O.band_ok != tag || d.band_pad != tag) return;
+// The walk over stripes [s_begin, s_end) of one alignment from a known entry state (plane hi, column e, the move mv_in that
+// entered the first row, path index n): the whole alignment (k_walk_rows) or one segment of it (k_wseg_emit, pr_walkseg.hip).
+// whole: this call covers the alignment: it also stores path_len.
+__device__ __forceinline__ void walk_rows_range(const DevBatch &B, const AlnDesc &d, AlnOut &O, const uint8_t *__restrict__ ws,
+                                                const int32_t *__restrict__ blo_all, PathEnt *__restrict__ paths,
+                                                int s_begin, int s_end, int hi, int e, int mv_in, int64_t n, bool whole) {
     const int lane = threadIdx.x;
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int Lp[2] = {Lq, Lr};
-    const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
-    const uint8_t *qfl = B.hap_flag[d.qs] + d.q_off;
-    const int32_t *t2r = B.hap_ptr[d.ts] + d.t_off;
-    const uint8_t *tfl = B.hap_flag[d.ts] + d.t_off;
-    const int32_t *r2q = B.ref_ptr[d.qs] + d.r_off;
-    const uint8_t *insQ = B.has_ins[d.qs] + d.r_off;
-    const uint8_t *insT = B.has_ins[d.ts] + d.r_off;
+    // packed walk constants (k_prep_wk): {pointer to the other coordinate system, flags | "an insertion at this reference
+    // position" per hap slot << 8}: one load per position instead of a pointer load and dependent has_ins loads
+    const int2 *wq_ = B.wk_q[d.qs] + d.q_off, *wr_ = B.wk_r[d.qs] + d.r_off, *wt_ = B.wk_t[d.ts - 2] + d.t_off;
+    const int insmask = ((1 << d.qs) | (1 << d.ts)) << 8;
     const uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     const int32_t *blo = blo_all + d.blo_off;
     PathEnt *path = paths + d.path_off;
@@ -843,69 +848,79 @@ __global__ void __launch_bounds__(64) k_walk_rows(DevBatch B, const AlnDesc *__r
         for (int p = 0; p < 2; p++)
             if (lane * 16 < FS_K * FS_W) *reinterpret_cast<uint4 *>(&pin[buf][p][lane * 16]) = pfv[p];
     };
-    // ---- per-row constants of 64 truth rows at a time (lane l <-> row (t & ~63) + l)
-    int tflc = 0, t2rc = 0, insc = 0;
-    auto load_rows = [&](int tb) {
-        tflc = 0; t2rc = 0; insc = 0;
-        const int tt = tb + lane;
-        if (tt < Lt) {
-            tflc = tfl[tt];
-            t2rc = t2r[tt];
-            insc = insQ[t2rc] | insT[t2rc];
-        }
+    // ---- per-row constants of 64 truth rows at a time (lane l <-> row (t & ~63) + l), the next 64 prefetched
+    const int t_first = s_begin * FS_K;
+    int2 rcur = make_int2(0, 0), rnxt = make_int2(0, 0);
+    {
+        const int rb = t_first & ~63;
+        if (rb + lane < Lt) rcur = wt_[rb + lane];
+        if (rb + 64 + lane < Lt) rnxt = wt_[rb + 64 + lane];
+    }
+    // ---- stripe origins, 64 stripes per register chunk (lane l <-> stripe c0 + l), the next chunk prefetched
+    int cbQ = 0, cbR = 0, nbQ = 0, nbR = 0;
+    auto load_org = [&](int c0, int &bq, int &br) {
+        bq = 0; br = 0;
+        const int s_ = c0 + lane;
+        if (s_ < n_stripes) { bq = blo[s_ * FS_K]; br = blo[Lt + s_ * FS_K]; }
     };
-    // ---- per-column constants of the current stripe (lane l <-> column lo_p + l)
-    int cq2r = 0, cqfl = 0, cinsq = 0, cr2q = 0, cinsr = 0;
-    auto load_cols = [&](int loQ, int loR) {
-        cq2r = 0; cqfl = 0; cinsq = 0; cr2q = 0; cinsr = 0;
+    load_org(s_begin & ~63, cbQ, cbR);
+    load_org((s_begin & ~63) + 64, nbQ, nbR);
+    // ---- per-column constants of the current stripe (lane l <-> column lo_p + l) and, requested a stripe ahead, of the next
+    int2 ccq = make_int2(0, 0), ccr = make_int2(0, 0), ncq = make_int2(0, 0), ncr = make_int2(0, 0);
+    auto load_cols = [&](int loQ, int loR, int2 &cq, int2 &cr) {
+        cq = make_int2(0, 0); cr = make_int2(0, 0);
         const int xq = loQ + lane, xr = loR + lane;
-        if (xq < Lq) { cq2r = q2r[xq]; cqfl = qfl[xq]; cinsq = insQ[cq2r] | insT[cq2r]; }
-        if (xr < Lr) { cr2q = r2q[xr]; cinsr = insQ[xr] | insT[xr]; }
+        if (xq < Lq) cq = wq_[xq];
+        if (xr < Lr) cr = wr_[xr];
     };
 
-    stage_load(0);
-    stage_commit(0);
-    load_rows(0);
-    int lo[2] = {blo[0], blo[Lt]};
-    load_cols(lo[0], lo[1]);
+    stage_load(s_begin);
+    stage_commit(s_begin & 1);
+    int lo[2] = {__builtin_amdgcn_readlane(cbQ, s_begin & 63), __builtin_amdgcn_readlane(cbR, s_begin & 63)};
+    load_cols(lo[0], lo[1], ccq, ccr);
 
-    int hi = O.beg_plane, e = 0;          // plane and column of the entry cell of the current row
-    int64_t n = 0;
     uint32_t status = 0;
-    int mv_in = 0;                         // move that entered the current row (0: the start cell)
-    uint32_t edit_in = 0;
+    uint32_t edit_in = (mv_in & (F_SUB | F_DEL)) ? 1u : 0u;
     bool ok = true;
 
-    for (int s = 0; s < n_stripes && ok; s++) {
+    for (int s = s_begin; s < s_end && ok; s++) {
         const int t0 = s * FS_K, rows = min(FS_K, Lt - t0);
         stage_load(s + 1);                 // next stripe's rows into registers
         int nlo[2] = {0, 0};
-        if (s + 1 < n_stripes) { nlo[0] = blo[(s + 1) * FS_K]; nlo[1] = blo[Lt + (s + 1) * FS_K]; }
+        if (s + 1 < n_stripes) {
+            if (((s + 1) & 63) == 0) { nlo[0] = __builtin_amdgcn_readlane(nbQ, 0); nlo[1] = __builtin_amdgcn_readlane(nbR, 0); }
+            else { nlo[0] = __builtin_amdgcn_readlane(cbQ, (s + 1) & 63); nlo[1] = __builtin_amdgcn_readlane(cbR, (s + 1) & 63); }
+            load_cols(nlo[0], nlo[1], ncq, ncr);      // (consumed when the stripe is done)
+        }
         asm volatile("" ::: "memory");
         const uint8_t *pcurQ = pin[s & 1][0], *pcurR = pin[s & 1][1];
         for (int r = 0; r < rows; r++) {
             const int t = t0 + r;
-            if ((t & 63) == 0 && t > 0) load_rows(t);
+            if ((t & 63) == 0 && t != t_first) {
+                rcur = rnxt;
+                rnxt = make_int2(0, 0);
+                if (t + 64 + lane < Lt) rnxt = wt_[t + 64 + lane];
+            }
             const int el = e - lo[hi];
             if (el < 0 || el > 63 || e >= Lp[hi]) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+            const int trv = __builtin_amdgcn_readlane(rcur.x, t & 63);
             // sync flag of the entry cell, dist.cpp:949-968 (only a diagonal move can make a sync point)
             uint32_t sync_in = 1;
             if (mv_in != 0) {
-                const int tflv = __builtin_amdgcn_readlane(tflc, t & 63);
-                const int trv = __builtin_amdgcn_readlane(t2rc, t & 63);
-                const int insrow = __builtin_amdgcn_readlane(insc, t & 63);
-                int qflv = 0, qr, inscell;
+                const int rwy = __builtin_amdgcn_readlane(rcur.y, t & 63);
+                const int tflv = rwy & 0xff;
+                int qflv = 0, qr, cwy;
                 if (hi == 0) {
-                    qflv = __builtin_amdgcn_readlane(cqfl, el);
-                    qr = __builtin_amdgcn_readlane(cq2r, el);
-                    inscell = __builtin_amdgcn_readlane(cinsq, el);
+                    cwy = __builtin_amdgcn_readlane(ccq.y, el);
+                    qflv = cwy & 0xff;
+                    qr = __builtin_amdgcn_readlane(ccq.x, el);
                 } else {
                     qr = e;
-                    inscell = __builtin_amdgcn_readlane(cinsr, el);
+                    cwy = __builtin_amdgcn_readlane(ccr.y, el);
                 }
                 const bool in_t = (tflv & PV) && !(tflv & PB);
                 const bool in_q = (qflv & PV) && !(qflv & PB);
-                sync_in = (!in_t && !in_q && !(insrow | inscell) && trv == qr && (mv_in & (F_MAT | F_SWP | F_SUB))) ? 1u : 0u;
+                sync_in = (!in_t && !in_q && !((rwy | cwy) & insmask) && trv == qr && (mv_in & (F_MAT | F_SWP | F_SUB))) ? 1u : 0u;
             }
             // the run of INS-only cells that starts at the entry cell
             const int pq = (lane < d.pitch[0]) ? int(pcurQ[r * d.pitch[0] + lane]) : 0;
@@ -922,8 +937,8 @@ __global__ void __launch_bounds__(64) k_walk_rows(DevBatch B, const AlnDesc *__r
                 PathEnt pe;
                 pe.a = uint32_t(x) | (uint32_t(hi) << 31);
                 pe.b = uint32_t(t) | ((lane == el) ? ((sync_in << 31) | (edit_in << 30)) : (1u << 30));
-                pe.qref = (hi == 0) ? cq2r : x;
-                pe.tref = __builtin_amdgcn_readlane(t2rc, t & 63);
+                pe.qref = (hi == 0) ? ccq.x : x;
+                pe.tref = trv;
                 path[n + (lane - el)] = pe;
             }
             n += k + 1;
@@ -934,21 +949,38 @@ __global__ void __launch_bounds__(64) k_walk_rows(DevBatch B, const AlnDesc *__r
             // move out of the row from cell c, by priority
             const int cl = c - lo[hi];
             const int p = __builtin_amdgcn_readlane(pc, cl) & 31;
-            if (hi == 1 && (p & F_SWP)) { mv_in = F_SWP; e = __builtin_amdgcn_readlane(cr2q, cl) + 1; hi = 0; edit_in = 0; }
+            if (hi == 1 && (p & F_SWP)) { mv_in = F_SWP; e = __builtin_amdgcn_readlane(ccr.x, cl) + 1; hi = 0; edit_in = 0; }
             else if (p & F_MAT) { mv_in = F_MAT; e = c + 1; edit_in = 0; }
             else if (p & F_SUB) { mv_in = F_SUB; e = c + 1; edit_in = 1; }
             else if (p & F_DEL) { mv_in = F_DEL; e = c; edit_in = 1; }
-            else if (hi == 0 && (p & F_SWP)) { mv_in = F_SWP; e = __builtin_amdgcn_readlane(cq2r, cl) + 1; hi = 1; edit_in = 0; }
+            else if (hi == 0 && (p & F_SWP)) { mv_in = F_SWP; e = __builtin_amdgcn_readlane(ccq.x, cl) + 1; hi = 1; edit_in = 0; }
             else { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
         }
-        // advance to the next stripe: commit its staged rows, reload the per-column constants
+        // advance to the next stripe: commit its staged rows, take over its per-column constants
         stage_commit((s + 1) & 1);
         asm volatile("" ::: "memory");
-        if (s + 1 < n_stripes && (nlo[0] != lo[0] || nlo[1] != lo[1])) { lo[0] = nlo[0]; lo[1] = nlo[1]; load_cols(lo[0], lo[1]); }
+        if (s + 1 < n_stripes) { lo[0] = nlo[0]; lo[1] = nlo[1]; ccq = ncq; ccr = ncr; }
+        if (((s + 1) & 63) == 0) {
+            cbQ = nbQ; cbR = nbR;
+            load_org(s + 1 + 64, nbQ, nbR);
+        }
     }
     if (lane == 0) {
-        O.path_len = int32_t(n);
+        if (whole) O.path_len = int32_t(n);
         if (!ok) { O.n_sec = 0; }
         if (status) atomicOr(&O.status, status);
     }
+}
+
+__global__ void __launch_bounds__(64) k_walk_rows(DevBatch B, const AlnDesc *__restrict__ descs,
+                                                  const int32_t *__restrict__ work, int n_work,
+                                                  const uint8_t *__restrict__ ws, const int32_t *__restrict__ blo_all,
+                                                  AlnOut *__restrict__ outs, PathEnt *__restrict__ paths, int tag) {
+    if (int(blockIdx.x) >= n_work) return;
+    __builtin_amdgcn_s_setprio(2);      // a latency chain (rows are sequential): win issue arbitration against the bulk kernels
+    const int a = work[blockIdx.x];
+    const AlnDesc d = descs[a];
+    AlnOut &O = outs[a];
+    if (O.band_ok != tag || d.band_pad != tag) return;
+    walk_rows_range(B, d, O, ws, blo_all, paths, 0, (d.Lt + FS_K - 1) / FS_K, O.beg_plane, 0, 0, 0, true);
 }

@@ -752,6 +752,35 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
         }
     };
     uint32_t cur_b = 0;     // .b of path[sync_idx]
+    // WAVE: the reference / truth bases the sections compare come from 64-base register chunks (lane l <-> base + l), refilled
+    // when the walk leaves them -- it moves towards the front, so a chunk ends at the base asked for.  Nearly every step of a
+    // long alignment is a sync point with a one-base section: two dependent global loads per step were most of this walk.
+    int rs_base = 1 << 30, ts_base = 1 << 30;
+    int rs_cur = 0, ts_cur = 0;
+    auto rs_at = [&](int i) -> int {
+        if constexpr (WAVE) {
+            if (i < rs_base || i >= rs_base + 64) {   // uniform
+                rs_base = max(0, i - 63);
+                const int x = rs_base + lane_;
+                rs_cur = x < r_size ? int(Rs[x]) : 0;
+            }
+            return __builtin_amdgcn_readlane(rs_cur, i - rs_base);
+        } else {
+            return int(Rs[i]);
+        }
+    };
+    auto ts_at = [&](int i) -> int {
+        if constexpr (WAVE) {
+            if (i < ts_base || i >= ts_base + 64) {   // uniform
+                ts_base = max(0, i - 63);
+                const int x = ts_base + lane_;
+                ts_cur = x < t_size ? int(Ts[x]) : 0;
+            }
+            return __builtin_amdgcn_readlane(ts_cur, i - ts_base);
+        } else {
+            return int(Ts[i]);
+        }
+    };
 
     while (sync_idx >= 0) {
         const int query_ref_pos = prev_qref;
@@ -782,10 +811,10 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
             bool deferred = false;
             if (rl == 0) ref_ed = tl;
             else if (tl == 0) ref_ed = rl;
-            else if (rl == 1 && tl == 1) ref_ed = (Rs[sync_ref_idx] != Ts[sync_truth_idx]);
+            else if (rl == 1 && tl == 1) ref_ed = (rs_at(sync_ref_idx) != ts_at(sync_truth_idx));
             else if (!has_q && !has_t && rl == tl) {
                 bool same = true;
-                for (int k = 0; k < rl && same; k++) same = (Rs[sync_ref_idx + k] == Ts[sync_truth_idx + k]);
+                for (int k = rl - 1; k >= 0 && same; k--) same = (rs_at(sync_ref_idx + k) == ts_at(sync_truth_idx + k));
                 if (same) ref_ed = 0;
             }
             if (ref_ed < 0) {
