@@ -217,6 +217,23 @@ def test_diagnostic_switches_leave_the_results_unchanged(monkeypatch):
         assert not got.diff(other), var
 
 
+def test_parallel_sweep_and_walk_switches_equal_the_oracle(monkeypatch):
+    """long alignments at the 64-cell level (a fifth of them inside tandem repeats, where the block-parallel forward sweep's runs
+    do not meet and it falls back): the segment-parallel walk (default), the sequential row-sweep walk (VPR_SEQ_WALK) and the
+    block-parallel forward sweep (VPR_PAR_FWD) all give the oracle's arrays"""
+    batch = api.Synth(n_sc=24, len_mode=0, len_a=700.0, len_b=3000.0, len_min=700, len_max=3000, seed=415, p_repeat=0.3).batch()
+    got, want, _, pr = compare(batch, A.default_config(band_mode=1))
+    names = {s.kernel.decode() for s in pr.launch_stats()}
+    assert "k_walk_seg" in names and "k_fwd_stripe" in names
+    for var, kernel in (("VPR_SEQ_WALK", "k_walk_rows"), ("VPR_PAR_FWD", "k_fwd_par")):
+        monkeypatch.setenv(var, "1")
+        pr2 = api.PrecisionRecall(A.default_config(band_mode=1))
+        other = pr2.run(batch)
+        monkeypatch.delenv(var)
+        assert kernel in {s.kernel.decode() for s in pr2.launch_stats()}, var
+        assert not got.diff(other), var
+
+
 def test_dense_backward_int16_rows_forced():
     batch = api.Synth(n_sc=30, len_a=30, len_b=900, len_min=30, len_max=900, seed=61, var_per_base=0.03).batch()
     compare(batch, A.default_config(band_mode=0, flags=A.CFG_DENSE_S16))

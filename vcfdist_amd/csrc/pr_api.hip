@@ -34,6 +34,7 @@ extern "C" int vpr_batch_skeleton_from_variants(const vpr_variants *v, vpr_owned
 #include "pr_kernels.hip"
 #include "pr_band.hip"
 #include "pr_walkseg.hip"
+#include "pr_fwdpar.hip"
 #include "pr_q16.hip"
 #include "pr_zl.hip"
 #include "pr_gen.hip"
@@ -298,6 +299,8 @@ struct vpr_handle {
     struct ExecBlk { uint8_t *p; size_t bytes; bool used; };
     std::vector<ExecBlk> exec_blks, exec_pins;
     bool no_strips = false;              // VPR_NO_STRIPS in the environment: wide alignments stay in one workgroup
+    bool seq_fwd = true;                 // unless VPR_PAR_FWD is in the environment: the sequential forward sweep of the 64-cell level; the
+                                         // block-parallel one (pr_fwdpar.hip) is exact but only pays where its runs meet: not inside long tandem repeats
     bool seq_walk = false;               // VPR_SEQ_WALK: the sequential row-sweep walk instead of the segment-parallel one
     bool no_round_overlap = false;       // VPR_NO_ROUND_OVERLAP: a retry round is complete before the host looks at its fail lists
     std::vector<uint32_t> scratch_u32[2];
@@ -1227,6 +1230,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->no_round_overlap = getenv("VPR_NO_ROUND_OVERLAP") != nullptr;
     h->stall_log = getenv("VPR_STALL_LOG") != nullptr;
     h->seq_walk = getenv("VPR_SEQ_WALK") != nullptr;
+    h->seq_fwd = getenv("VPR_PAR_FWD") == nullptr;
     memset(&h->dB, 0, sizeof(h->dB));
     memset(&h->timing, 0, sizeof(h->timing));
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
@@ -2294,7 +2298,40 @@ struct Exec {
             ls.cells = 8 * zl_rows;                               // cell slots per row
         }
         cells_touched += ls.cells;
-        rc = timed(1, ls, ks, band_fwd_name(lv), [&] {
+        // the 64-cell level: block-parallel sweep (pr_fwdpar.hip) with VPR_PAR_FWD in the environment
+        const bool fwdp = lv == LV_C1 && !h->seq_fwd;
+        FwdParTables FT;
+        memset(&FT, 0, sizeof(FT));
+        if (fwdp) {
+            int64_t rows_sum = 0;
+            for (int32_t k = 0; k < cnt; k++) rows_sum += plan_desc(h, P, size_t(off) + size_t(k)).Lt;
+            FT.cap_stripes = int32_t(std::min<int64_t>(rows_sum / FS_K + cnt + 1, 0x7fffffff));
+            FT.cap_blocks = int32_t(std::min<int64_t>(rows_sum / (FS_K * FP_S) + cnt + 1, 0x7fffffff));
+            const size_t b_cnt = 256, b_pos = round_up(int64_t(cnt) * 4, 256), b_own = round_up(int64_t(FT.cap_blocks) * 8, 256),
+                         b_snap = size_t(FT.cap_stripes) * 512, b_acc = round_up(int64_t(FT.cap_stripes) * 8, 256),
+                         b_blk = round_up(int64_t(FT.cap_blocks) * 16, 256), b_end = round_up(int64_t(cnt) * 16, 256);
+            void *q = nullptr;
+            if ((rc = exec_alloc(h, &q, b_cnt + 3 * b_pos + b_own + b_snap + b_acc + b_blk + b_end))) return rc;
+            uint8_t *u = static_cast<uint8_t *>(q);
+            FT.counter = reinterpret_cast<int32_t *>(u); u += b_cnt;
+            FT.st_base = reinterpret_cast<int32_t *>(u); u += b_pos;
+            FT.bl_base = reinterpret_cast<int32_t *>(u); u += b_pos;
+            FT.fallback = reinterpret_cast<int32_t *>(u); u += b_pos;
+            FT.owner = reinterpret_cast<int2 *>(u); u += b_own;
+            FT.snap = reinterpret_cast<int32_t *>(u); u += b_snap;
+            FT.acc = reinterpret_cast<int2 *>(u); u += b_acc;
+            FT.blk = reinterpret_cast<int4 *>(u); u += b_blk;
+            FT.endc = reinterpret_cast<int4 *>(u);
+            HIPCHK(h, hipMemsetAsync(FT.counter, 0, 32, ks));
+        }
+        rc = timed(1, ls, ks, fwdp ? "k_fwd_par" : band_fwd_name(lv), [&] {
+            if (fwdp) {
+                hipLaunchKernelGGL(k_fwdp_plan, blocks(cnt), dim3(256), 0, ks, h->d_descs, list, cnt, FT);
+                hipLaunchKernelGGL(k_fwdp_block<1>, dim3(FT.cap_blocks), dim3(64), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs, FT);
+                hipLaunchKernelGGL(k_fwdp_block<2>, dim3(FT.cap_blocks), dim3(64), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs, FT);
+                hipLaunchKernelGGL(k_fwdp_finish, dim3(cnt), dim3(64), 0, ks, h->d_descs, list, cnt, h->d_outs, FT);
+                hipLaunchKernelGGL(k_fwd_stripe_only, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs, FT.fallback);
+            } else
             if (zero)        // forward + backward + walk of the zero-distance alignments, one lane each (pr_zl.hip)
                 hipLaunchKernelGGL(k_zero_lane, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->d_descs, list, cnt,
                                    h->d_zl_hdr + zl_wave0, h->d_zl_in, h->d_zl_log, h->d_outs, a_path,
@@ -2308,6 +2345,13 @@ struct Exec {
             hipLaunchKernelGGL(k_fwd_band_finish, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs, tag, n_dev);
         });
         if (rc) return rc;
+        if (fwdp && getenv("VPR_FWDP_STATS")) {      // (diagnostic: waits for the sweep)
+            int32_t c[8] = {0};
+            (void)hipStreamSynchronize(ks);
+            (void)hipMemcpy(c, FT.counter, 32, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[vpr] block-parallel forward sweep: %d alignments, %d stripes, %d blocks; %d fix-up runs, %d met (mean stripe %.2f), %d did not meet, "
+                            "%d alignments to the sequential sweep\n", cnt, c[0], c[1], c[2], c[3], c[3] ? double(c[4]) / c[3] : 0.0, c[5], c[6]);
+        }
         n_fwd++;
         {
             const int32_t nc = n_dev ? n_all : cnt;
