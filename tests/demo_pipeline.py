@@ -183,13 +183,13 @@ def surrogate_fasta(length, seed=0x5eed):
     return seq
 
 
-def run(product, ctg_len=5_100_000, cluster="biwfa", bed_policy="v2.6.4"):
+def run(product, ctg_len=5_100_000, cluster="biwfa", bed_policy="v2.6.4", fasta_seed=0x5eed):
     """-> (summary rows, details).  product = False: oracle chain on the CPU; True: HIP library (needs a GPU).
     cluster: "biwfa" (the reference's default) or ("gap", N) for `-c gap N` (simple_cluster, cluster.cpp:826-945)."""
     bed = Bed(os.path.join(DEMO, "nist-v4.2.1_chr1_5Mb.bed"))
     q, qs = parse_vcf(os.path.join(DEMO, "query.vcf"), bed, bed_policy=bed_policy)
     t, ts = parse_vcf(os.path.join(DEMO, "nist-v4.2.1_chr1_5Mb.vcf.gz"), bed, bed_policy=bed_policy)
-    fasta = surrogate_fasta(ctg_len)
+    fasta = surrogate_fasta(ctg_len, fasta_seed)
     slots = [q[0], q[1], t[0], t[1]]
     haps = [K.HapSeq(s["pos"], s["type"], s["ref"], s["alt"]) for s in slots]
     lib = None if product else O.lib()

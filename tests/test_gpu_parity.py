@@ -384,3 +384,14 @@ def test_device_generate_contig_end_and_bad_input():
     bad = A.Variants.from_sites([ref], [dict(ctg=0, beg=4, end=9, vars=[[(6, D, "CA", "", 5.0), (7, S, "A", "T", 5.0)], [], [], []])])
     with pytest.raises(api.VprError):
         api.PrecisionRecall().upload_variants(bad.as_struct(), bad)
+
+
+@pytest.mark.gpu
+def test_hand_derived_credit_and_sync_rules_through_the_hip_path():
+    """the hand-derived cases of tests/test_oracle.py (partial credit, sync rules, cancelling truth variants) through the C ABI:
+    the HIP result equals the hand-derived answer directly, not only the oracle's"""
+    import test_oracle as TO
+    for case in TO.HAND_CASES:
+        batch = api.batch_from_variants(TO.hand_case_variants(case))
+        TO.check_hand_case(case, api.PrecisionRecall().run(batch))
+

@@ -202,6 +202,64 @@ def test_dropped_truth_variant_is_fp_and_missing_query_is_fn():
     assert r2.aln_dist.tolist() == [1, 1, 1, 1]
 
 
+HAND_REF = "GATTACAGCCTGCAAAAAAGTAGCATCGGATCTTGACCA"      # positions 13..18: AAAAAA
+# (name, supercluster [beg, end], query variants, truth variants, expectations derived BY HAND from the reference's rules):
+# per slot (query 0 / truth 2): errtype, credit, ref_ed, query_ed, sync_group, callq; the four distances; the status bits
+HAND_CASES = [
+    # dist.cpp:1293-1296: credit = 1 - query_ed / ref_ed.  The truth inserts GG, the query G: one edit is left of two ->
+    # credit 0.5 < credit_threshold 0.7 -> FP / FN; an FN's quality is max_qual (dist.cpp:1333-1346)
+    ("half of an insertion", 8, 30, [(22, I, "", "G", 40.0)], [(22, I, "", "GG", 50.0)],
+     dict(q=([A.ERRTYPE_FP], [0.5], [2], [1], [0], [40.0]), t=([A.ERRTYPE_FN], [0.5], [2], [1], [0], [60.0]), dist=[1] * 4, status=0)),
+    # three of four deleted bases: 1 - 1/4 = 0.75 >= 0.7 -> TP on both sides, with the query's quality
+    ("three quarters of a deletion", 8, 34, [(22, D, "GCA", "", 40.0)], [(22, D, "GCAT", "", 50.0)],
+     dict(q=([A.ERRTYPE_TP], [0.75], [4], [1], [0], [40.0]), t=([A.ERRTYPE_TP], [0.75], [4], [1], [0], [40.0]), dist=[1] * 4, status=0)),
+    # dist.cpp:949-968: no sync point at an insertion's location, so a SNP and the insertion right behind it share one sync
+    # section: ref_ed = 1 + 2, one sync group, the smaller of the two qualities for both (dist.cpp:1284-1288)
+    ("SNP and adjacent insertion: one section", 8, 34, [(21, S, "A", "C", 40.0), (22, I, "", "GG", 30.0)],
+     [(21, S, "A", "C", 50.0), (22, I, "", "GG", 50.0)],
+     dict(q=([A.ERRTYPE_TP] * 2, [1.0] * 2, [3] * 2, [0] * 2, [0, 0], [30.0] * 2), t=([A.ERRTYPE_TP] * 2, [1.0] * 2, [3] * 2, [0] * 2, [0, 0], [30.0] * 2),
+          dist=[0] * 4, status=0)),
+    # ... while two SNPs with matching bases between them are two sections (groups count from the end of the supercluster)
+    ("two SNPs: two sections", 8, 34, [(21, S, "A", "C", 40.0), (24, S, "A", "T", 30.0)], [(21, S, "A", "C", 50.0), (24, S, "A", "T", 50.0)],
+     dict(q=([A.ERRTYPE_TP] * 2, [1.0] * 2, [1] * 2, [0] * 2, [1, 0], [40.0, 30.0]), t=([A.ERRTYPE_TP] * 2, [1.0] * 2, [1] * 2, [0] * 2, [1, 0], [40.0, 30.0]),
+          dist=[0] * 4, status=0)),
+    # dist.cpp:1219-1223: truth variants that cancel (an inserted and a deleted A of one homopolymer: the haplotype IS the
+    # reference, and between them truth and reference are a base apart, so there is no sync point): ref_ed = 0 with truth
+    # variants -> the WARN, ref_ed = 1 "to prevent divide-by-zero", credit 1 - 0/1 -> TP; no query variant: quality max_qual
+    ("truth variants that cancel", 8, 26, [], [(13, I, "", "A", 50.0), (18, D, "A", "", 45.0)],
+     dict(q=([], [], [], [], [], []), t=([A.ERRTYPE_TP] * 2, [1.0] * 2, [1] * 2, [0] * 2, [0, 0], [60.0] * 2), dist=[0] * 4, status=A.ST_WARN_ZERO_ED)),
+    # the wrong allele: nothing of the one edit is explained -> credit 0
+    ("wrong SNP allele", 8, 30, [(21, S, "A", "C", 40.0)], [(21, S, "A", "G", 50.0)],
+     dict(q=([A.ERRTYPE_FP], [0.0], [1], [1], [0], [40.0]), t=([A.ERRTYPE_FN], [0.0], [1], [1], [0], [60.0]), dist=[1] * 4, status=0)),
+]
+
+
+def hand_case_variants(case):
+    name, beg, end, q, t, want = case
+    return A.Variants.from_sites([HAND_REF], [dict(ctg=0, beg=beg, end=end, vars=[q, q, t, t])])
+
+
+def check_hand_case(case, r):
+    name, want = case[0], case[5]
+    assert r.aln_dist.tolist() == want["dist"], name
+    assert [int(x) & A.ST_WARN_MASK for x in r.aln_status.tolist()] == [want["status"]] * 4, name
+    for slot, key in ((0, "q"), (1, "q"), (2, "t"), (3, "t")):
+        err, credit, ref_ed, query_ed, sg, callq = want[key]
+        for w in range(2):      # homozygous on both sides: ORIG and SWAP phasing agree
+            assert r.errtype[slot][w].tolist() == err, (name, slot, w)
+            assert r.credit[slot][w].tolist() == credit and r.callq[slot][w].tolist() == callq, (name, slot, w)
+            assert r.ref_ed[slot][w].tolist() == ref_ed and r.query_ed[slot][w].tolist() == query_ed, (name, slot, w)
+            assert r.sync_group[slot][w].tolist() == sg, (name, slot, w)
+
+
+@pytest.mark.parametrize("case", HAND_CASES, ids=[c[0] for c in HAND_CASES])
+def test_hand_derived_credit_and_sync_rules(case):
+    """rules of calc_prec_recall / get_prec_recall_path_sync the demo never reaches (partial credit on either side of the
+    threshold, the no-sync-at-an-insertion rule, cancelling truth variants), each with the answer worked out by hand from
+    dist.cpp:949-968, :1219-1223, :1284-1346"""
+    check_hand_case(case, O.run(O.generate(hand_case_variants(case))))
+
+
 def test_golden_toy_vector_file():
     """tests/golden/toy_a1.json (reference-produced) against the oracle."""
     import json
