@@ -131,6 +131,48 @@ def cpu_baseline(batch, target_s=15.0):
     }
 
 
+def secondary_leg(api, summary, workload, n_sc, seed, steps, device):
+    """one more workload after the headline (rank 0, N = 1): `steps` timed passes over one resident batch, one at a time, after
+    one untimed pass; the line of the dominant sweep kernel is priced by the bytes of the cells it sweeps (no committed
+    counters for these sizes)"""
+    t0 = time.perf_counter()
+    syn = make_workload(api, n_sc, seed, workload)
+    batch = syn.batch(copy=False)
+    pr = api.PrecisionRecall(device=device)
+    pr.upload(batch)
+    summary.upload_var_class(pr, syn.var_class())
+    setup_s = time.perf_counter() - t0
+    res = None
+    step_ms, acc = [], {}
+    for i in range(steps + 1):
+        ta = time.perf_counter()
+        pr.execute()
+        res = pr.download(res)
+        summary.pr_counts(pr, None, None)
+        dt = (time.perf_counter() - ta) * 1e3
+        if i == 0:
+            continue
+        step_ms.append(dt)
+        for s_ in pr.launch_stats():
+            a = acc.setdefault((s_.kind, s_.kernel.decode()), [0, 0.0, 0, 0])
+            a[0] += 1; a[1] += s_.ms; a[2] += s_.bytes_algorithmic; a[3] += s_.cells
+    tm = pr.timing()
+    ms = float(np.mean(step_ms))
+    sweeps = {k: v for k, v in acc.items() if k[0] in (1, 2) and v[1] > 0}
+    (kind, kname), (nl, kms, byt, cells) = max(sweeps.items(), key=lambda kv: kv[1][1])
+    gbs = (byt / nl) / (kms / nl * 1e-3) / 1e9 if kms > 0 else 0.0
+    out = {"workload": workload, "superclusters": n_sc, "steps": steps, "ms_per_step": round(ms, 3),
+           "value": round(4 * n_sc / (ms * 1e-3), 1), "unit": "supercluster-alignments/s", "in_flight": 1,
+           "dense_cells_per_s": round(tm.cells_dense / (ms * 1e-3), 1), "kernel_ms_per_step": round(tm.ms_total, 3),
+           "setup_s": round(setup_s, 2),
+           "roofline": {"bound": "hbm", "kernel": kname, "launches_per_step": round(nl / steps, 2), "avg_launch_ms": round(kms / nl, 4),
+                        "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                        "note": "bytes of the swept cells (1 B per cell + inputs) / launch duration (HIP events); latency-bound rows, not HBM"},
+           "top_kernels_ms_per_step": {k[1]: round(v[1] / steps, 3) for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:6]}}
+    del pr
+    return out
+
+
 def launch_command(n_gpus, argv, port=None):
     """the command that runs this script as `n_gpus` ranks, one per GPU, on this node (what the driver itself runs)"""
     if port is None:
@@ -162,6 +204,9 @@ def main():
     ap.add_argument("--one-pass-batches", type=int, default=None,
                     help="batches of the one-pass leg (upload from the variant tables + execute + download each; 0 = skip; "
                          "default 9 for wgs_synth, 0 for the other workloads)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the legs measured after the headline (N = 1, default workload only): two batches in flight, and the "
+                         "sv_synth / stress_synth workloads (BASELINE configs[2] / configs[4]) on small batches")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launch path only (no GPU work): the ranks rendezvous over gloo, all-reduce their rank numbers and rank 0 "
                          "prints {n_gpus, rank_sum}; tests/test_distributed.py runs `bench.py --gpus 2 --plumbing-check` on CPU")
@@ -313,7 +358,16 @@ def main():
     host_acc = {"n_device_allocs": 0, "n_device_frees": 0, "n_host_allocs": 0, "ms_host_alloc": 0.0, "ms_host_blocked": 0.0,
                 "execute_wall_ms": []}
 
+    acct_s = [0.0]
+
     def account(S, stats_acc=stats_acc, kern_ms=kern_ms, host_acc=host_acc):
+        t_acc = time.perf_counter()
+        try:
+            return account_(S, stats_acc, kern_ms, host_acc)
+        finally:
+            acct_s[0] += time.perf_counter() - t_acc
+
+    def account_(S, stats_acc, kern_ms, host_acc):
         tm = S.pr.timing()
         kern_ms.append(tm.ms_total)
         if host_acc is not None:
@@ -367,15 +421,25 @@ def main():
             sys.stderr.flush()
             os._exit(1)
 
+    import gc
     run_steps(0, max(args.warmup, 0), False)
     parts[:] = [0.0, 0.0, 0.0]
     step_log.clear()
+    # (the interpreter's cyclic collector otherwise runs a full collection inside one of the timed steps -- always the same one,
+    # +38 ms -- over the millions of objects the setup left behind: collected now, switched off while the steps are timed)
+    gc.collect()
+    gc.disable()
     sync()
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps, True)
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     timed_log = sorted(step_log)
+    if os.environ.get("BENCH_STEP_LOG") and rank == 0:
+        sys.stderr.write("step ms: " + " ".join(f"{(e - a) * 1e3:.1f}" for _, a, e in timed_log) + "\n")
+        sys.stderr.write("execute wall ms: " + " ".join(f"{x:.1f}" for x in host_acc["execute_wall_ms"]) + "\n")
+        sys.stderr.write("kernel ms: " + " ".join(f"{x:.1f}" for x in kern_ms) + "\n")
     (res, t), S_last = last[args.warmup + args.steps - 1]
     batch, pr = S_last.batch, S_last.pr
     # two more steps of one batch ALONE (not timed, not in `value`): a kernel's launch duration without the neighbours that
@@ -459,6 +523,54 @@ def main():
                             "device, position constants, planning, execute, download, counters"}
         for S in slots:                     # (the timed batches replaced the resident ones; what follows reads the last step's results)
             S.host_res = None
+
+    # ---- legs after the headline (rank 0 at N = 1 only; nothing here enters `value`)
+    two_fl = None
+    secondary = []
+    if world == 1 and not strong and not args.no_secondary and args.workload == "wgs_synth":
+        # (a) two batches in flight behind two handles: a batch's latency tail beside the other batch's bulk.  (Three handles --
+        # round 3's default -- stall: see --in-flight.)
+        try:
+            S2 = make_slot(1)
+            pair = [slots[0], S2]
+            lat = []
+
+            def tf_worker(j, first, n, timed):
+                for i in range(first + j, first + n, 2):
+                    ta = time.perf_counter()
+                    pair[j].pr.execute()
+                    pair[j].host_res = pair[j].pr.download(pair[j].host_res)
+                    summary.pr_counts(pair[j].pr, None, None)
+                    if timed:
+                        with lock:
+                            lat.append((time.perf_counter() - ta) * 1e3)
+
+            def tf_run(first, n, timed):
+                ths = [threading.Thread(target=tf_worker, args=(j, first, n, timed)) for j in range(2)]
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
+            n_tf = max(args.steps, 12)
+            tf_run(0, 4, False)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            tf_run(4, n_tf, True)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+            two_fl = {"value": round(4 * args.n_sc * n_tf / dt, 1), "unit": "supercluster-alignments/s", "in_flight": 2, "steps": n_tf,
+                      "ms_per_step": round(dt / n_tf * 1e3, 3),
+                      "step_latency_ms": {"p50": round(float(np.percentile(lat, 50)), 3), "max": round(float(np.max(lat)), 3)},
+                      "note": "every step still a complete pass over one batch; not the headline: `value` is measured one batch at a time"}
+            del S2
+        except Exception as e:      # (a leg must not cost the headline)
+            two_fl = {"error": repr(e)}
+        # (b) the other single-GPU configurations of BASELINE.json on small batches
+        for wl, n_sc_, st_ in (("sv_synth", 200, 2), ("stress_synth", 20000, 2)):
+            try:
+                secondary.append(secondary_leg(api, summary, wl, n_sc_, args.seed, st_, local_rank))
+            except Exception as e:
+                secondary.append({"workload": wl, "error": repr(e)})
 
     if rank == 0:
         tm = tm_main
@@ -546,6 +658,7 @@ def main():
                                                        "max": round(float(d.max()), 3)})(
                 np.diff(np.sort(np.array([t0] + [e for _, _, e in timed_log]))) * 1e3),
             "in_flight": n_fl,
+            "bookkeeping_ms_per_step": round(acct_s[0] / max(args.steps, 1) * 1e3, 3),   # (reading the launch statistics: inside the timed region)
             "host": {"n_device_allocs": int(host_acc["n_device_allocs"]), "n_device_frees": int(host_acc["n_device_frees"]),
                      "n_host_allocs": int(host_acc["n_host_allocs"]), "ms_host_alloc": round(host_acc["ms_host_alloc"], 3),
                      "ms_host_blocked": round(host_acc["ms_host_blocked"], 3),
@@ -563,6 +676,8 @@ def main():
                                 "pcie_inclusive_value": round(4 * args.n_sc / ((t_d - t_c1) + elapsed / args.steps), 1)},
             "kernel_only_value": round(4 * args.n_sc / (float(np.mean(kern_ms)) * 1e-3), 1),
             "one_pass": one_pass,
+            "two_in_flight": two_fl,
+            "secondary": secondary,
             "kernels": per_kernel,
             "counts_at_min_qual_TP_FP_FN": t.cpu().numpy()[:, 3, :, 0].tolist(),   # [callset][TP,FP,FN], type ALL, all ranks
             "pr_summary_rank0": [{"type": summary.NAMES[r.vartype], "threshold": "BEST" if r.best else "NONE", "qual": r.qual,

@@ -69,6 +69,7 @@ const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnD
 // rejects then climb the ladder in dozens of workspace-sized rounds.)
 const int LONG_LT = 2048;
 const int LONG_LV = 2;    // LV_C1
+const int64_t WSEG_MAX_ROWS = int64_t(4) << 20;      // truth rows of a launch up to which its walk runs over segments (pr_walkseg.hip)
 
 // std::vector whose resize() leaves trivially constructible elements uninitialised (the planner fills millions of
 // 96-byte descriptors from several threads; zero-filling them first costs as much as the fill)
@@ -253,6 +254,9 @@ struct LadderCtx {
     // bytes at the front of each scratch that are preset (filled at the start of vpr_execute, beside round 0, with as much
     // as the previous execute's first launch used) and the size of that first launch
     int64_t tie_clean[2] = {0, 0}, tie_first[2] = {0, 0}; bool tie_first_seen[2] = {false, false};
+    // tie ladders: the round being enqueued runs on the side stream (ls and ls2 are swapped meanwhile) because the main stream is
+    // still busy with an earlier round; its replays then use the side stream's scratch
+    bool alt = false;
 };
 
 struct EvPair { hipEvent_t a, b; int kind; vpr_launch_stat st; };
@@ -1890,8 +1894,9 @@ struct Exec {
         if (early) { tie_patch_slot = -1; tie_patch_spec = false; }
         LadderCtx &tc = *tie_ctx;
         hipStream_t ks = early ? tc.ls2 : ks_main;
-        uint32_t *&scratch = tc.tie_scratch[early ? 1 : 0];
-        int64_t &scratch_bytes = tc.tie_scratch_bytes[early ? 1 : 0];
+        const int se = (early || tc.alt) ? 1 : 0;      // the scratch of the stream the replays run on
+        uint32_t *&scratch = tc.tie_scratch[se];
+        int64_t &scratch_bytes = tc.tie_scratch_bytes[se];
         // scratch words of every job; the scratch grows to hold the whole launch (all replays concurrent: a long one is a
         // latency chain), bounded by half of the free memory -- beyond that the launch is cut into sub-batches
         struct Need { int32_t k; int64_t cells, cap, bcap, w_st, w_buf, w_bk; int32_t dlo[2], dn[2]; };
@@ -1966,7 +1971,7 @@ struct Exec {
                 if (scratch) h->parked.push_back(vpr_handle::Blk{scratch, size_t(scratch_bytes)});
                 scratch = static_cast<uint32_t *>(q);
                 scratch_bytes = nb;
-                tc.tie_clean[early ? 1 : 0] = 0;
+                tc.tie_clean[se] = 0;
             }
         }
         // decision list of an early launch: one region of the decision buffer, its length in a counter of its own
@@ -2020,7 +2025,6 @@ struct Exec {
             const int32_t nj = int32_t(k1 - k0);
             tie_job_cur += size_t(nj);
             n_tie_jobs += nj;
-            const int se = early ? 1 : 0;
             if (!tc.tie_first_seen[se]) { tc.tie_first_seen[se] = true; tc.tie_first[se] = words * 4; }
             if (words * 4 > tc.tie_clean[se]) HIPCHK(h, hipMemsetAsync(scratch, 0xff, size_t(words) * 4, ks));
             tc.tie_clean[se] = 0;
@@ -2378,7 +2382,14 @@ struct Exec {
         if (!(phases & 4)) return rc;
         // long part (or a small launch of long retries): wave-per-alignment walk; windows up to 256
         const bool wave_walk = !q16 && (long_part || cnt < 2048);      // (k_walk<wave> stages tiles around the walk for the wider windows)
-        const bool row_walk = lv == LV_C1 && (wave_walk || !h->seq_walk);      // (the segment walk serves launches of any size)
+        // The segment walk follows all 128 possible entry cells of every segment: right for launches that are latency chains (a
+        // few hundred long alignments, a retry round of some thousands), 128 times the work for a launch that fills the device
+        // by itself (the stress workload's 80 000 alignments of thousands of rows: 216 ms against the lane walk's 40)
+        int64_t walk_rows_sum = 0;
+        if (lv == LV_C1 && !h->seq_walk)
+            for (int32_t k = 0; k < cnt && walk_rows_sum <= WSEG_MAX_ROWS; k++) walk_rows_sum += plan_desc(h, P, size_t(off) + size_t(k)).Lt;
+        const bool seg_walk = lv == LV_C1 && !h->seq_walk && walk_rows_sum <= WSEG_MAX_ROWS;
+        const bool row_walk = lv == LV_C1 && (wave_walk || seg_walk);
         vpr_launch_stat ws_;
         memset(&ws_, 0, sizeof(ws_));
         ws_.threads = q16 ? 16 : 64; ws_.n_units = cnt; ws_.cells_per_thread = 2;
@@ -2403,14 +2414,13 @@ struct Exec {
         } else if (row_walk) {
             // striped 64-cell layout: the walk (phase A) in parallel over segments of 128 truth rows (pr_walkseg.hip; the
             // sequential row sweep, k_walk_rows, with VPR_SEQ_WALK in the environment), then the credit walk (phase B)
-            if (h->seq_walk) {
+            if (!seg_walk) {
                 rc = timed(3, ws_, ks, "k_walk_rows", [&] {
                     hipLaunchKernelGGL(k_walk_rows, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                        P.arena, a_i32, h->d_outs, a_path, tag);
                 });
             } else {
-                int64_t rows_sum = 0;
-                for (int32_t k = 0; k < cnt; k++) rows_sum += plan_desc(h, P, size_t(off) + size_t(k)).Lt;
+                const int64_t rows_sum = walk_rows_sum;
                 WsegTables T;
                 T.cap = int32_t(std::min<int64_t>(rows_sum / WSEG_ROWS + cnt + 1, 0x7fffffff));
                 void *q = nullptr;
@@ -2479,7 +2489,7 @@ struct Exec {
     bool overlap(const LadderCtx &c) const { return !h->no_round_overlap && !h->no_strips && c.ls2 != nullptr && (&c - h->lad) < 2; }
     int lad_sync(LadderCtx &c) {        // everything the context has in flight (its side stream: the back halves of retry rounds)
         HIPCHK(h, x_sync(h, c.ls, SITE));
-        if (overlap(c)) HIPCHK(h, x_sync(h, c.ls2, SITE));
+        if (overlap(c) || c.alt) HIPCHK(h, x_sync(h, c.ls2, SITE));      // (alt: the earlier round is on the other stream)
         return VPR_OK;
     }
     int lad_flush(LadderCtx &c, std::vector<int32_t> &out) {
@@ -2937,7 +2947,26 @@ struct Exec {
                     if (lad_tie_wait[k] && flag_up(9 + k)) {       // (before the ladder's next round reuses the region)
                         trace("flag %d (ladder %d tie list), %d marked", 9 + k, k, h->hp_tie_cnt[5 + k]);
                         const int32_t n = std::min(h->hp_tie_cnt[5 + k], lad_tie_cap(k));
-                        if (n > 0 && (rc = tie_round(h->lad[2 + k], h->hp_tie_list + lad_tie_off(k), n, false, nullptr))) return rc;
+                        if (n > 0) {
+                            // the tie ladder's main stream may still be busy with the round of the part's own tie list (some thousand
+                            // alignments, 6 - 8 ms): this round -- no early replays, its own workspace and fail slots -- then runs
+                            // on the side stream, and the ladder's "idle" flag is posted behind BOTH streams
+                            LadderCtx &T = h->lad[2 + k];
+                            const bool alt = !T.pending.empty() && T.ls2 != nullptr && !h->no_round_overlap;
+                            if (alt) { T.alt = true; std::swap(T.ls, T.ls2); }
+                            rc = tie_round(T, h->hp_tie_list + lad_tie_off(k), n, false, nullptr);
+                            if (alt) {
+                                if (rc == VPR_OK) {
+                                    HIPCHK(h, hipEventRecord(T.ev2, T.ls2));
+                                    HIPCHK(h, hipStreamWaitEvent(T.ls, T.ev2, 0));
+                                    post_flag(4 + 2 + k, T.ls);
+                                    (void)hipStreamQuery(T.ls);
+                                }
+                                std::swap(T.ls, T.ls2);
+                                T.alt = false;
+                            }
+                            if (rc) return rc;
+                        }
                         lad_tie_wait[k] = false;
                         progressed = true;
                     }
