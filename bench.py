@@ -173,6 +173,22 @@ def secondary_leg(api, summary, workload, n_sc, seed, steps, device):
     return out
 
 
+class stdout_to_stderr:
+    """file descriptor 1 -> 2 for the duration (RCCL prints a version banner to stdout when a communicator is created; the
+    driver reads ONE JSON line from this script's stdout)"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)       # (the banner sits in the C library's buffer: out with it while 1 is still 2)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def launch_command(n_gpus, argv, port=None):
     """the command that runs this script as `n_gpus` ranks, one per GPU, on this node (what the driver itself runs)"""
     if port is None:
@@ -247,13 +263,36 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            with stdout_to_stderr():
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()
 
     from vcfdist_amd import api, shard, summary, _abi as A
     if rank == 0:
         api.build()                 # no-op when the in-tree library is current (the driver builds it beforehand)
     if dist is not None:
         dist.barrier()
+    # The path's collectives through the C ABI (vpr_allreduce_counts / vpr_allgather_phase: RCCL on the library's own stream, on
+    # a communicator of this job's ranks; at N = 1 a communicator of one rank, so that the default run exercises the same entry
+    # point).  torch.distributed only carries the communicator's id to the ranks.  Any failure: torch.distributed's all_reduce.
+    native_comm, collective = None, "torch.distributed all_reduce (" + (dist.get_backend() if dist is not None else "single rank: none") + ")"
+    if not (dist is not None and dist.get_backend() == "gloo") and not os.environ.get("VCFDIST_BENCH_TORCH_COLLECTIVE"):
+        try:
+            from vcfdist_amd import rccl
+            if rccl.available():
+                torch.cuda.set_device(local_rank)
+                uid_t = torch.zeros(rccl.ID_BYTES, dtype=torch.uint8, device=torch.device("cuda", local_rank))
+                if rank == 0:
+                    uid_t.copy_(torch.frombuffer(bytearray(rccl.unique_id()), dtype=torch.uint8))
+                with stdout_to_stderr():
+                    if dist is not None:
+                        dist.broadcast(uid_t, 0)
+                    native_comm = rccl.Comm(world, rank, bytes(uid_t.cpu().numpy().tobytes()))
+                    torch.cuda.synchronize()
+                collective = "vpr_allreduce_counts (RCCL through the C ABI, library stream)"
+        except Exception as e:      # noqa: BLE001 -- the bench must not die of an optional path
+            sys.stderr.write(f"native RCCL communicator not available ({e!r}): torch.distributed collectives\n")
+            native_comm = None
     strong = args.scaling == "strong"
     dev = torch.device("cuda", local_rank)
     gloo = dist is not None and dist.get_backend() == "gloo"
@@ -330,13 +369,21 @@ def main():
             raise RuntimeError("another step failed")
         pb = None
         if strong:      # a contig's superclusters sit on all ranks: all-gather (sc_phase, orig, swap), phase redundantly
-            sc_phase, _, _ = shard.allgather_phase(res, S.my_idx, S.whole.n_sc, device=None if gloo else dev)
+            if native_comm is not None:
+                sc_phase, _, _ = rccl.allgather_phase(S.pr, native_comm, S.my_idx, S.whole.n_sc)
+            else:
+                sc_phase, _, _ = shard.allgather_phase(res, S.my_idx, S.whole.n_sc, device=None if gloo else dev)
             pb = summary.phase(sc_phase, np.ones(S.whole.n_sc, np.int32))[0][S.my_idx]
-        t = torch.from_numpy(summary.pr_counts(S.pr, None, pb)).to(dev)   # [2][4][3][61] int64, device histogram
-        if gloo:
-            th = t.cpu(); dist.all_reduce(th); t = th.to(dev)
-        elif dist is not None:
-            dist.all_reduce(t)          # the one collective of the path: the precision/recall counters (int64 sum)
+        if native_comm is not None:
+            # the one collective of the path: the precision/recall counters [2][4][3][61] (int64 sum), all-reduced on the device
+            # between the histogram kernel and the copy to the host
+            t = torch.from_numpy(rccl.allreduce_counts(S.pr, native_comm, None, pb))
+        else:
+            t = torch.from_numpy(summary.pr_counts(S.pr, None, pb)).to(dev)   # [2][4][3][61] int64, device histogram
+            if gloo:
+                th = t.cpu(); dist.all_reduce(th); t = th.to(dev)
+            elif dist is not None:
+                dist.all_reduce(t)
         with turn:
             next_coll[0] = i + 1
             turn.notify_all()
@@ -658,6 +705,7 @@ def main():
                                                        "max": round(float(d.max()), 3)})(
                 np.diff(np.sort(np.array([t0] + [e for _, _, e in timed_log]))) * 1e3),
             "in_flight": n_fl,
+            "collective": collective,
             "bookkeeping_ms_per_step": round(acct_s[0] / max(args.steps, 1) * 1e3, 3),   # (reading the launch statistics: inside the timed region)
             "host": {"n_device_allocs": int(host_acc["n_device_allocs"]), "n_device_frees": int(host_acc["n_device_frees"]),
                      "n_host_allocs": int(host_acc["n_host_allocs"]), "ms_host_alloc": round(host_acc["ms_host_alloc"], 3),

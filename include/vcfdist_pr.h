@@ -302,6 +302,23 @@ int vpr_upload_var_class(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS]
 int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
                   int32_t min_qual, int32_t max_qual, int64_t *counts);
 
+/* Multi-GPU, one process per GPU: superclusters are independent, so the ranks own disjoint sets and exchange
+   nothing on the data path.  What remains of the reference's serial tail:
+     - vpr_allreduce_counts: the counters of write_precision_recall (print.cpp:328-438, a serial loop over every variant in the
+       reference) summed over all ranks -- vpr_pr_counts with ONE all-reduce (RCCL over xGMI) of the device histogram in between;
+       every rank gets the global counts;
+     - vpr_allgather_phase: (sc_phase, orig_phase_dist, swap_phase_dist) of ALL superclusters on every rank, for the per-contig
+       phasing (phase.cpp:271-355), which needs every supercluster of a contig: sc_index[k] is the global index of this rank's
+       k-th supercluster, the three output arrays hold n_total entries (entries no rank owns are left untouched).
+   nccl_comm is the caller's ncclComm_t (rccl.h), created with the librccl of the process; the library resolves RCCL at run time
+   (no link-time dependency): vpr_rccl_available() says whether it found one.  Collective: every rank of the communicator
+   calls, in the same order. */
+int vpr_rccl_available(void);
+int vpr_allreduce_counts(vpr_handle *h, void *nccl_comm, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
+                         int32_t min_qual, int32_t max_qual, int64_t *counts);
+int vpr_allgather_phase(vpr_handle *h, void *nccl_comm, int32_t n_ranks, const int32_t *sc_index, int32_t n_total,
+                        int32_t *sc_phase, int32_t *orig_phase_dist, int32_t *swap_phase_dist);
+
 /* one line of the PRECISION-RECALL SUMMARY (src/print.cpp:497-566) */
 typedef struct vpr_pr_row {
     int32_t vartype;       /* VPR_VARTYPE_* */

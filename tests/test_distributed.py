@@ -7,6 +7,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -141,3 +142,28 @@ def test_bench_launches_its_own_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line == {"plumbing_check": True, "n_gpus": 2, "rank_sum": 3}
+
+
+@pytest.mark.gpu
+def test_native_collectives_on_a_one_rank_communicator():
+    """vpr_allreduce_counts / vpr_allgather_phase (the C ABI's RCCL entry points) on a communicator of one rank: the plumbing --
+    run-time resolution of librccl, data types, packing -- gives exactly vpr_pr_counts and the local phasing columns"""
+    import torch
+    from vcfdist_amd import api, rccl, summary
+    if not rccl.available():
+        pytest.skip("no RCCL library in this process")
+    torch.cuda.set_device(0)
+    syn = api.Synth(n_sc=500, len_a=10, len_b=300, len_max=300, seed=77, var_per_base=0.02)
+    pr = api.PrecisionRecall()
+    res = pr.run(syn.batch())
+    cls = syn.var_class()
+    comm = rccl.Comm(1, 0, rccl.unique_id())
+    try:
+        want = summary.pr_counts(pr, cls, None)
+        got = rccl.allreduce_counts(pr, comm, cls, None)
+        assert want.sum() > 0 and np.array_equal(got, want)
+        perm = np.random.RandomState(3).permutation(500).astype(np.int32)      # global indices of the local superclusters
+        ph, og, sw = rccl.allgather_phase(pr, comm, perm, 500)
+        assert np.array_equal(ph[perm], res.sc_phase) and np.array_equal(og[perm], res.orig_phase_dist) and np.array_equal(sw[perm], res.swap_phase_dist)
+    finally:
+        comm.destroy()

@@ -234,6 +234,23 @@ def test_parallel_sweep_and_walk_switches_equal_the_oracle(monkeypatch):
         assert not got.diff(other), var
 
 
+def test_repeated_executes_of_one_batch_are_identical():
+    """the planner's host loop serves fail lists and tie lists in the order the device raises them, so the launch order differs
+    from execute to execute: every result array has to come out the same each time (60 executes of a batch with every level,
+    retry rounds and a few thousand tie replays; a race between concurrent rounds showed up as 1 execute in 50 with
+    VPR_ST_ERR_NO_PTR on a handful of alignments)"""
+    syn = api.Synth(n_sc=120000, seed=0x5eed, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=10000)
+    pr = api.PrecisionRecall()
+    pr.upload(syn.batch(copy=False))
+    pr.execute()
+    first = pr.download()
+    assert not (first.aln_status & (A.ST_ERR_NO_PTR | A.ST_ERR_LIMIT | A.ST_ERR_UNFINISHED)).any()
+    for it in range(60):
+        pr.execute()
+        d = first.diff(pr.download())
+        assert not d, (it, d[:3])
+
+
 def test_dense_backward_int16_rows_forced():
     batch = api.Synth(n_sc=30, len_a=30, len_b=900, len_min=30, len_max=900, seed=61, var_per_base=0.03).batch()
     compare(batch, A.default_config(band_mode=0, flags=A.CFG_DENSE_S16))

@@ -10,6 +10,7 @@
 // There is no CPU fallback: without a HIP device every entry point that needs one
 // returns VPR_ERR_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -257,6 +258,7 @@ struct LadderCtx {
     // tie ladders: the round being enqueued runs on the side stream (ls and ls2 are swapped meanwhile) because the main stream is
     // still busy with an earlier round; its replays then use the side stream's scratch
     bool alt = false;
+    bool alt_used = false;      // a round of this context is (or was, since the last flush) on the side stream
 };
 
 struct EvPair { hipEvent_t a, b; int kind; vpr_launch_stat st; };
@@ -305,6 +307,7 @@ struct vpr_handle {
     bool no_strips = false;              // VPR_NO_STRIPS in the environment: wide alignments stay in one workgroup
     bool seq_fwd = true;                 // unless VPR_PAR_FWD is in the environment: the sequential forward sweep of the 64-cell level; the
                                          // block-parallel one (pr_fwdpar.hip) is exact but only pays where its runs meet: not inside long tandem repeats
+    bool alt_tie = false;                // VPR_ALT_TIE: ladder-born tie rounds on the tie ladder's side stream while its main stream is busy
     bool seq_walk = false;               // VPR_SEQ_WALK: the sequential row-sweep walk instead of the segment-parallel one
     bool no_round_overlap = false;       // VPR_NO_ROUND_OVERLAP: a retry round is complete before the host looks at its fail lists
     std::vector<uint32_t> scratch_u32[2];
@@ -1234,6 +1237,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->no_round_overlap = getenv("VPR_NO_ROUND_OVERLAP") != nullptr;
     h->stall_log = getenv("VPR_STALL_LOG") != nullptr;
     h->seq_walk = getenv("VPR_SEQ_WALK") != nullptr;
+    h->alt_tie = getenv("VPR_ALT_TIE") != nullptr;
     h->seq_fwd = getenv("VPR_PAR_FWD") == nullptr;
     memset(&h->dB, 0, sizeof(h->dB));
     memset(&h->timing, 0, sizeof(h->timing));
@@ -2769,6 +2773,7 @@ struct Exec {
 
     int tie_flush(LadderCtx &LT) {
         std::vector<int32_t> rejected;
+        LT.alt_used = false;
         int rc_ = lad_flush(LT, rejected);
         if (rc_) return rc_;
         if (!rejected.empty()) return fail(h, VPR_ERR_STATE, "tie round: the re-run forward sweep rejected alignment %d", rejected[0]);
@@ -2952,8 +2957,10 @@ struct Exec {
                             // alignments, 6 - 8 ms): this round -- no early replays, its own workspace and fail slots -- then runs
                             // on the side stream, and the ladder's "idle" flag is posted behind BOTH streams
                             LadderCtx &T = h->lad[2 + k];
-                            const bool alt = !T.pending.empty() && T.ls2 != nullptr && !h->no_round_overlap;
-                            if (alt) { T.alt = true; std::swap(T.ls, T.ls2); }
+                            // (opt-in, VPR_ALT_TIE: repeated executes of one batch showed a rare wrong walk -- VPR_ST_ERR_NO_PTR on a handful of
+                            // tied alignments, 2 - 9 executes in 400 -- with this on and none in 1 200 with it off; not found yet)
+                            const bool alt = h->alt_tie && !T.pending.empty() && T.ls2 != nullptr && !h->no_round_overlap;
+                            if (alt) { T.alt = true; T.alt_used = true; std::swap(T.ls, T.ls2); }
                             rc = tie_round(T, h->hp_tie_list + lad_tie_off(k), n, false, nullptr);
                             if (alt) {
                                 if (rc == VPR_OK) {
@@ -2966,6 +2973,12 @@ struct Exec {
                                 T.alt = false;
                             }
                             if (rc) return rc;
+                            if (!alt && T.alt_used) {       // (see the round-0 tie lists below)
+                                HIPCHK(h, hipEventRecord(T.ev2, T.ls2));
+                                HIPCHK(h, hipStreamWaitEvent(T.ls, T.ev2, 0));
+                                post_flag(4 + 2 + k, T.ls);
+                                (void)hipStreamQuery(T.ls);
+                            }
                         }
                         lad_tie_wait[k] = false;
                         progressed = true;
@@ -3011,6 +3024,16 @@ struct Exec {
                         const int32_t n = std::min(h->hp_tie_cnt[2 + k], tie_cap[k]);
                         trace("flag %d (round 0 tie list, part %d), %d marked", 2 + k, k, n);
                         if (n > 0 && (rc = tie_round(h->lad[2 + k], h->hp_tie_list + tie_off[k], n, false, &ch))) return rc;
+                        if (n > 0 && h->lad[2 + k].alt_used) {
+                            // an earlier round of this tie ladder runs on its side stream: the "idle" flag this round has just
+                            // posted on the main stream would be raised while that one is still at work, and the flush behind
+                            // the flag hands its workspace out again -- post the flag once more, behind both streams
+                            LadderCtx &T = h->lad[2 + k];
+                            HIPCHK(h, hipEventRecord(T.ev2, T.ls2));
+                            HIPCHK(h, hipStreamWaitEvent(T.ls, T.ev2, 0));
+                            post_flag(4 + 2 + k, T.ls);
+                            (void)hipStreamQuery(T.ls);
+                        }
                         lapx(k ? "short tie list -> tie round" : "long tie list -> tie round");
                         wait_tie[k] = false;
                         progressed = true;
@@ -3556,9 +3579,53 @@ int vpr_upload_var_class(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS]
     return VPR_OK;
 }
 
-int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
-                  int32_t min_qual, int32_t max_qual, int64_t *counts) {
+}   // extern "C"
+
+namespace {
+// RCCL, resolved at run time: the symbols the process already has (a host that links librccl, PyTorch's copy in a Python
+// process: the communicator the caller passes belongs to that one), else librccl.so.1.  The library itself has no link-time
+// dependency on RCCL: a single-GPU caller never needs it.
+struct Rccl {
+    typedef int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    typedef int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t);
+    typedef const char *(*ErrStr)(int);
+    AllReduce all_reduce = nullptr;
+    AllGather all_gather = nullptr;
+    ErrStr err_str = nullptr;
+    static const Rccl &get() {
+        static Rccl r = [] {
+            Rccl x;
+            void *hd = RTLD_DEFAULT;
+            if (!dlsym(hd, "ncclAllReduce")) hd = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!hd && !dlsym(RTLD_DEFAULT, "ncclAllReduce")) hd = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (hd || dlsym(RTLD_DEFAULT, "ncclAllReduce")) {
+                if (!hd) hd = RTLD_DEFAULT;
+                x.all_reduce = reinterpret_cast<AllReduce>(dlsym(hd, "ncclAllReduce"));
+                x.all_gather = reinterpret_cast<AllGather>(dlsym(hd, "ncclAllGather"));
+                x.err_str = reinterpret_cast<ErrStr>(dlsym(hd, "ncclGetErrorString"));
+            }
+            return x;
+        }();
+        return r;
+    }
+};
+const int RCCL_INT32 = 2, RCCL_UINT64 = 5, RCCL_SUM = 0;      // ncclDataType_t / ncclRedOp_t (rccl.h)
+
+__global__ void k_pack_phase(const int32_t *__restrict__ idx, const int32_t *__restrict__ sc_phase, const int32_t *__restrict__ orig,
+                             const int32_t *__restrict__ swap, int n, int4 *__restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = make_int4(idx[k], sc_phase[k], orig[k], swap[k]);
+}
+}  // namespace
+
+extern "C" {
+
+int vpr_rccl_available(void) { return Rccl::get().all_reduce && Rccl::get().all_gather ? 1 : 0; }
+
+static int pr_counts_impl(vpr_handle *h, void *comm, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
+                          int32_t min_qual, int32_t max_qual, int64_t *counts) {
     if (!h || !counts || max_qual < min_qual) return VPR_ERR_ARG;
+    if (comm && !Rccl::get().all_reduce) return fail(h, VPR_ERR_STATE, "no RCCL in this process (librccl.so.1 not found)");
     if (!h->executed) return fail(h, VPR_ERR_STATE, "vpr_pr_counts before vpr_execute");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int nq = max_qual - min_qual + 1;
@@ -3584,6 +3651,10 @@ int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const
         hipLaunchKernelGGL(k_pr_hist, dim3(unsigned((nv + 255) / 256)), dim3(256), size_t(9) * (nq + 1) * 4, h->stream,
                            h->dB.var_off[s], h->n_sc, nv, h->d_cls[s], h->dR.sc_phase, d_pb, h->dR.v[s][0], h->dR.v[s][1],
                            s >> 1, min_qual, max_qual, d_hist);
+    }
+    if (comm) {     // the one collective of the path: the histogram words summed over the ranks, in place on the device
+        const int e = Rccl::get().all_reduce(d_hist, d_hist, nh, RCCL_UINT64, RCCL_SUM, comm, h->stream);
+        if (e) return fail(h, VPR_ERR_DEVICE, "ncclAllReduce failed: %s", Rccl::get().err_str ? Rccl::get().err_str(e) : "?");
     }
     std::vector<unsigned long long> hist(nh);
     HIPCHK(h, hipMemcpyAsync(hist.data(), d_hist, nh * 8, hipMemcpyDeviceToHost, h->stream));
@@ -3611,6 +3682,68 @@ int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const
                     for (int e = 0; e < 3; e++) below += int64_t(hist[((size_t(cs) * 3 + t) * 3 + e) * (nq + 1) + k]);
                 }
             }
+        }
+    return VPR_OK;
+}
+
+int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
+                  int32_t min_qual, int32_t max_qual, int64_t *counts) {
+    return pr_counts_impl(h, nullptr, var_class, pb_phase, min_qual, max_qual, counts);
+}
+
+int vpr_allreduce_counts(vpr_handle *h, void *nccl_comm, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
+                         int32_t min_qual, int32_t max_qual, int64_t *counts) {
+    if (!nccl_comm) return VPR_ERR_ARG;
+    return pr_counts_impl(h, nccl_comm, var_class, pb_phase, min_qual, max_qual, counts);
+}
+
+int vpr_allgather_phase(vpr_handle *h, void *nccl_comm, int32_t n_ranks, const int32_t *sc_index, int32_t n_total,
+                        int32_t *sc_phase, int32_t *orig_phase_dist, int32_t *swap_phase_dist) {
+    if (!h || !nccl_comm || n_ranks < 1 || !sc_index || !sc_phase || !orig_phase_dist || !swap_phase_dist) return VPR_ERR_ARG;
+    if (!h->executed) return fail(h, VPR_ERR_STATE, "vpr_allgather_phase before vpr_execute");
+    const Rccl &R = Rccl::get();
+    if (!R.all_gather) return fail(h, VPR_ERR_STATE, "no RCCL in this process (librccl.so.1 not found)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int n = h->n_sc;
+    int rc;
+    // 1. how many superclusters every rank holds; 2. their {global index, sc_phase, orig, swap} records, padded to the largest share
+    int32_t *d_cnt = nullptr;
+    void *q = nullptr;
+    if ((rc = exec_alloc(h, &q, size_t(n_ranks + 1) * 4))) return rc;
+    d_cnt = static_cast<int32_t *>(q);
+    HIPCHK(h, hipMemcpyAsync(d_cnt + n_ranks, &n, 4, hipMemcpyHostToDevice, h->stream));
+    int e = R.all_gather(d_cnt + n_ranks, d_cnt, 1, RCCL_INT32, nccl_comm, h->stream);
+    if (e) return fail(h, VPR_ERR_DEVICE, "ncclAllGather failed: %s", R.err_str ? R.err_str(e) : "?");
+    std::vector<int32_t> cnt(size_t(n_ranks), 0);
+    HIPCHK(h, hipMemcpyAsync(cnt.data(), d_cnt, size_t(n_ranks) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, x_sync(h, h->stream, SITE));
+    int64_t m = 1, tot = 0;
+    for (int32_t c : cnt) { m = std::max<int64_t>(m, c); tot += c; }
+    if (tot > n_total) return fail(h, VPR_ERR_ARG, "vpr_allgather_phase: the ranks hold %lld superclusters, n_total is %d", (long long)tot, n_total);
+    int4 *d_send = nullptr, *d_recv = nullptr;
+    int32_t *d_idx = nullptr;
+    if ((rc = exec_alloc(h, &q, size_t(m) * 16))) return rc;
+    d_send = static_cast<int4 *>(q);
+    if ((rc = exec_alloc(h, &q, size_t(m) * 16 * size_t(n_ranks)))) return rc;
+    d_recv = static_cast<int4 *>(q);
+    if ((rc = exec_alloc(h, &q, size_t(std::max(n, 1)) * 4))) return rc;
+    d_idx = static_cast<int32_t *>(q);
+    HIPCHK(h, hipMemsetAsync(d_send, 0, size_t(m) * 16, h->stream));
+    if (n) {
+        HIPCHK(h, hipMemcpyAsync(d_idx, sc_index, size_t(n) * 4, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_pack_phase, dim3(unsigned((n + 255) / 256)), dim3(256), 0, h->stream, d_idx, h->dR.sc_phase,
+                           h->dR.orig_phase_dist, h->dR.swap_phase_dist, n, d_send);
+    }
+    e = R.all_gather(d_send, d_recv, size_t(m) * 4, RCCL_INT32, nccl_comm, h->stream);
+    if (e) return fail(h, VPR_ERR_DEVICE, "ncclAllGather failed: %s", R.err_str ? R.err_str(e) : "?");
+    std::vector<int4> recv(size_t(m) * size_t(n_ranks));
+    HIPCHK(h, hipMemcpyAsync(recv.data(), d_recv, recv.size() * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, x_sync(h, h->stream, SITE));
+    for (int r = 0; r < n_ranks; r++)
+        for (int32_t k = 0; k < cnt[size_t(r)]; k++) {
+            const int4 v = recv[size_t(r) * size_t(m) + size_t(k)];
+            if (v.x < 0 || v.x >= n_total) return fail(h, VPR_ERR_ARG, "vpr_allgather_phase: supercluster index %d of rank %d out of range", v.x, r);
+            sc_phase[v.x] = v.y; orig_phase_dist[v.x] = v.z; swap_phase_dist[v.x] = v.w;
         }
     return VPR_OK;
 }

@@ -1,0 +1,106 @@
+"""The native collectives of the C ABI (vpr_allreduce_counts, vpr_allgather_phase: include/vcfdist_pr.h) from Python, and the
+RCCL communicator they run on.  ctypes plumbing: the communicator is created with the process's own librccl (the one PyTorch
+ships, when PyTorch is loaded), which is also the one the library resolves at run time."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+from . import api
+from . import summary
+
+_RCCL = None
+ID_BYTES = 128          # ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
+
+
+def lib():
+    global _RCCL
+    if _RCCL is None:
+        err = None
+        for name in ("librccl.so.1", "librccl.so"):
+            try:
+                _RCCL = C.CDLL(name, mode=C.RTLD_GLOBAL)
+                break
+            except OSError as e:
+                err = e
+        if _RCCL is None:
+            raise OSError(f"no RCCL library: {err}")
+        _RCCL.ncclGetErrorString.restype = C.c_char_p
+    return _RCCL
+
+
+class UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * ID_BYTES)]
+
+
+def unique_id() -> bytes:
+    uid = UniqueId()
+    _chk(lib().ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+    return bytes(C.string_at(C.byref(uid), ID_BYTES))
+
+
+def _chk(rc, what):
+    if rc:
+        raise RuntimeError(f"{what} failed: {lib().ncclGetErrorString(rc).decode()}")
+
+
+class Comm:
+    """ncclComm_t of `world` ranks; `uid` = unique_id() of rank 0, handed to the other ranks by the caller (any channel: the
+    bench broadcasts it over torch.distributed).  The calling thread's HIP device must be the rank's GPU."""
+
+    def __init__(self, world: int, rank: int, uid: bytes):
+        self.world, self.rank = world, rank
+        u = UniqueId()
+        C.memmove(C.byref(u), uid, ID_BYTES)
+        self._c = C.c_void_p()
+        L = lib()
+        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        _chk(L.ncclCommInitRank(C.byref(self._c), world, u, rank), "ncclCommInitRank")
+
+    def destroy(self):
+        if self._c:
+            lib().ncclCommDestroy.argtypes = [C.c_void_p]
+            lib().ncclCommDestroy(self._c)
+            self._c = C.c_void_p()
+
+
+def available() -> bool:
+    L = api.lib()
+    L.vpr_rccl_available.restype = C.c_int
+    try:
+        lib()
+    except OSError:
+        return False
+    return bool(L.vpr_rccl_available())
+
+
+def allreduce_counts(pr, comm: Comm, var_class_per_slot=None, pb_phase=None, min_qual=0, max_qual=60):
+    """summary.pr_counts summed over the ranks of `comm`: one all-reduce of the device histogram -> int64 [2][4][3][nq]"""
+    L = api.lib()
+    nq = max_qual - min_qual + 1
+    out = np.zeros((2, summary.VARTYPES, 3, nq), np.int64)
+    pb = None if pb_phase is None else np.ascontiguousarray(pb_phase, dtype=np.int32)
+    L.vpr_allreduce_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, A.P_i32, C.c_int32, C.c_int32, A.P_i64]
+    arr = None
+    if var_class_per_slot is not None:
+        cls = [np.ascontiguousarray(c, dtype=np.uint8) for c in var_class_per_slot]
+        arr = (A.P_u8 * 4)(*[A._ptr(c, C.c_uint8) for c in cls])
+    rc = L.vpr_allreduce_counts(pr._h, comm._c, arr, None if pb is None else A._ptr(pb, C.c_int32), min_qual, max_qual,
+                                A._ptr(out, C.c_int64))
+    if rc:
+        raise RuntimeError(f"vpr_allreduce_counts failed: {rc} {L.vpr_last_error(pr._h)}")
+    return out
+
+
+def allgather_phase(pr, comm: Comm, idx_local, n_total: int):
+    """(sc_phase, orig_phase_dist, swap_phase_dist) of all n_total superclusters on every rank; idx_local[k] = global index of
+    this rank's k-th supercluster"""
+    L = api.lib()
+    idx = np.ascontiguousarray(idx_local, dtype=np.int32)
+    out = [np.zeros(n_total, np.int32) for _ in range(3)]
+    L.vpr_allgather_phase.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, A.P_i32, C.c_int32, A.P_i32, A.P_i32, A.P_i32]
+    rc = L.vpr_allgather_phase(pr._h, comm._c, comm.world, A._ptr(idx, C.c_int32), n_total, A._ptr(out[0], C.c_int32),
+                               A._ptr(out[1], C.c_int32), A._ptr(out[2], C.c_int32))
+    if rc:
+        raise RuntimeError(f"vpr_allgather_phase failed: {rc} {L.vpr_last_error(pr._h)}")
+    return out
