@@ -216,10 +216,12 @@ def test_command_line_on_demo_files(tmp_path, capsys):
 
 
 @pytest.mark.gpu
-def test_command_line_two_ranks_deal_contigs(tmp_path):
+@pytest.mark.parametrize("how", ["superclusters", "contigs"])
+def test_command_line_two_ranks(tmp_path, how):
     """two contigs (the demo callsets twice, as chr1 and chr2) through the command line as one process and as two ranks
-    under torch.distributed.run (both on the one GPU of the test box, gloo): contigs dealt over the ranks, counters
-    all-reduced, per-contig tables gathered on rank 0 -- the files must be the same"""
+    under torch.distributed.run (both on the one GPU of the test box, gloo): every contig's superclusters dealt over the ranks
+    (phasing all-gathered, records gathered) or whole contigs dealt; counters all-reduced, rank 0 writes -- the files must be
+    the same, byte for byte"""
     import gzip
     import os
     import socket
@@ -254,7 +256,7 @@ def test_command_line_two_ranks_deal_contigs(tmp_path):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                    "--master-port", str(port), "-m", "vcfdist_amd"] + base + ["-p", str(tmp_path / "two") + "/"], check=True, env=env,
+                    "--master-port", str(port), "-m", "vcfdist_amd"] + base + ["-p", str(tmp_path / "two") + "/", "--shard", how], check=True, env=env,
                    cwd=root, stdout=subprocess.DEVNULL, timeout=900)
     for name in ("precision-recall.tsv", "precision-recall-summary.tsv", "phase-blocks.tsv", "superclusters.tsv", "query.tsv", "truth.tsv",
                  "switchflips.tsv", "phasing-summary.tsv"):

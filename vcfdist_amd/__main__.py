@@ -93,9 +93,14 @@ def prepare_contig(name, seq, slots, args, device=0):
     return dict(name=name, haps=haps, cl=cl, sc=sc, batch=batch, slots=slots)
 
 
-def evaluate_contig(prep, args, device=0):
+def evaluate_contig(prep, args, device=0, part=None):
     """the precision/recall path on the GPU, phasing and counters for a prepared contig.  -> int64 counters [2][4][3][nq],
-    n_sc, and what the writers need: (clusters after splitting, superclusters, results, phase sets, pb_phase, switches, flips)"""
+    n_sc, and what the writers need: (clusters after splitting, superclusters, results, phase sets, pb_phase, switches, flips).
+    part = (rank, world, collective device): this rank evaluates its share of the contig's SUPERCLUSTERS -- dealt by the
+    reference's own size estimate (shard.deal: LPT + snake, as precision_recall_threads_wrapper spreads superclusters over its
+    threads, dist.cpp:1670-1726) -- the per-supercluster phasing is all-gathered (the contig's phasing needs all of it and
+    every rank then runs it), the counters returned are this rank's share (the caller all-reduces the sum over the contigs),
+    and the result records are gathered (every rank gets the contig's full tables; rank 0 writes them)."""
     name, haps, cl, sc, slots = prep["name"], prep["haps"], prep["cl"], prep["sc"], prep["slots"]
     nq = args.max_qual - args.min_qual + 1
     if sc.n == 0:
@@ -104,12 +109,30 @@ def evaluate_contig(prep, args, device=0):
     cfg = A.default_config(device=device)
     cfg.max_qual = float(args.max_qual); cfg.credit_threshold = args.credit_threshold; cfg.phase_threshold = args.phase_threshold
     pr = api.PrecisionRecall(cfg)
-    res = pr.run(prep["batch"])
-    print_warnings(name, res.aln_status)
     phase_sets = transfer_phase_sets(slots, cl, sc)
-    pb, sw, fl = S.phase(res.sc_phase, phase_sets)
     cls = [S.var_class(h.type, h.ref_len, h.alt_len, args.sv_threshold) for h in haps]
-    counts = S.pr_counts(pr, cls, pb, args.min_qual, args.max_qual)
+    if part is None:
+        res = pr.run(prep["batch"])
+        pb, sw, fl = S.phase(res.sc_phase, phase_sets)
+        counts = S.pr_counts(pr, cls, pb, args.min_qual, args.max_qual)
+    else:
+        from . import shard
+        rank, world, cdev = part
+        whole = prep["batch"]
+        idx = shard.deal(shard.estimate_cells(whole), world)[rank]
+        mine = whole.subset(idx)
+        local = pr.run(mine) if len(idx) else A.Results(0, [0, 0, 0, 0])
+        sc_phase, _, _ = shard.allgather_phase(local, idx, sc.n, device=cdev)
+        pb, sw, fl = S.phase(sc_phase, phase_sets)
+        if len(idx):
+            cls_mine = [shard.subset_per_variant(cls[s], whole.var_off[s], idx) for s in range(4)]
+            counts = S.pr_counts(pr, cls_mine, pb[idx], args.min_qual, args.max_qual)
+        else:
+            counts = np.zeros((2, 4, 3, nq), np.int64)
+        res = shard.gather_results(local, idx, whole.var_off, device=cdev)
+        if rank != 0:
+            return counts, sc.n, (sc.clusters, sc, res, phase_sets, pb, sw, fl)
+    print_warnings(name, res.aln_status)
     print(f"[vcfdist_amd] {name}: {sum(len(h.pos) for h in haps)} hap-variants, {sum(c.n for c in cl)} clusters, {sc.n} superclusters, "
           f"{len(sw)} switch / {len(fl)} flip errors", file=sys.stderr)
     return counts, sc.n, (sc.clusters, sc, res, phase_sets, pb, sw, fl)
@@ -172,6 +195,9 @@ def main(argv=None):
     ap.add_argument("-p", "--prefix", default="./", help="prefix of the output files")
     ap.add_argument("-n", "--no-output-files", action="store_true")
     ap.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK, else 0)")
+    ap.add_argument("--shard", default="superclusters", choices=["superclusters", "contigs"],
+                    help="several ranks (torch.distributed.run, one per GPU): deal every contig's superclusters over the ranks "
+                         "(default; balanced whatever the contigs' sizes) or whole contigs")
     args = ap.parse_args(argv)
     args.cluster_gap = 50
     if args.cluster[0] in ("gap", "size") and len(args.cluster) > 1:
@@ -179,9 +205,9 @@ def main(argv=None):
     args.cluster = args.cluster[0]
     if args.max_size + 2 > args.max_supercluster_size:          # globals.cpp:478-481
         raise SystemExit("ERROR: Max supercluster size (-s) must be at least two larger than max variant size (-l).")
-    # one process per GPU under torch.distributed.run: contigs are dealt over the ranks (a contig's phasing needs all of its
-    # superclusters, so a contig stays on one rank), the counters are summed with one all-reduce (RCCL), and the per-contig
-    # tables are gathered to rank 0, which writes the files
+    # one process per GPU under torch.distributed.run: every contig's superclusters are dealt over the ranks (--shard; the
+    # per-supercluster phasing is all-gathered, a contig's phasing needs all of it), the counters are summed with one all-reduce
+    # (RCCL), the result records are gathered, and rank 0 writes the files
     import os
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     device = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
@@ -221,7 +247,11 @@ def main(argv=None):
 
     from . import shard
     weights = [sum(len(s["pos"]) for s in slots_of(c)) + 1 for c in contigs]
-    mine = shard.deal_contigs(weights, world)[rank]
+    by_sc = dist is not None and args.shard == "superclusters"
+    # by superclusters: every rank clusters and marshals every contig (host work and the biWFA clustering, done redundantly)
+    # and evaluates its share of each; by contigs: a rank does everything for the contigs dealt to it
+    mine = list(range(len(contigs))) if by_sc else shard.deal_contigs(weights, world)[rank]
+    cdev = None if dist is None or dist.get_backend() == "gloo" else f"cuda:{device}"
     # everything in front of the path for all of this rank's contigs first: input the library refuses ends the run here,
     # like the reference's ERROR(), before anything has been evaluated or written
     prepared = {}
@@ -235,7 +265,7 @@ def main(argv=None):
     for k in mine:
         ctg = contigs[k]
         try:
-            counts, n_sc, tables = evaluate_contig(prepared.pop(k), args, device=device)
+            counts, n_sc, tables = evaluate_contig(prepared.pop(k), args, device=device, part=(rank, world, cdev) if by_sc else None)
         except api.VprError as e:     # the library's explicit refusals end the run like the reference's ERROR()
             raise SystemExit(f"ERROR: contig '{ctg}': {e}")
         total += counts
@@ -248,10 +278,11 @@ def main(argv=None):
                 length, ploidy = len(fasta[ctg]), 0
             reports[k] = (ctg, length, ploidy, slots_of(ctg), tables)
     if dist is not None:
-        total = shard.allreduce_tally(total, device=None if dist.get_backend() == "gloo" else f"cuda:{device}")
-        gathered = [None] * world
-        dist.all_gather_object(gathered, reports)
-        reports = {k: v for part in gathered for k, v in part.items()}
+        total = shard.allreduce_tally(total, device=cdev)       # the one all-reduce: counts[2][4][3][nq] summed over the ranks
+        if not by_sc:       # (by superclusters every rank already holds every contig's gathered tables)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, reports)
+            reports = {k: v for part in gathered for k, v in part.items()}
     rows = S.pr_summary(total, args.min_qual, args.max_qual)
     if rank == 0:
         if not args.no_output_files:
