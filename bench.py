@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_SIMD, SCLK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; shader clock of the committed SQ_BUSY_CYCLES counters
-PROFILE_TAG = "r03"    # profiles/<tag>_counters_<workload>.json: tools/make_profiles.sh
+PROFILE_TAG = "r04"    # profiles/<tag>_counters_<workload>.json: tools/make_profiles.sh
 
 
 def make_workload(api, n_sc, seed, workload):

@@ -79,16 +79,19 @@ extern "C" {
 #define VPR_ST_WARN_ZERO_ED  16u  /* "Zero edit distance with truth variants" (ref_ed forced to 1) dist.cpp:1219 */
 #define VPR_ST_ERR_NO_PTR    32u  /* "No valid pointer" during the walk               dist.cpp:937 */
 #define VPR_ST_ERR_UNFINISHED 64u /* "Alignment not finished"                         dist.cpp:440 */
-#define VPR_ST_ERR_LIMIT     128u /* problem exceeds an implementation limit of this library */
+#define VPR_ST_ERR_LIMIT     128u /* the alignment exceeds an implementation limit of this library (the reference has none of them); its
+                                     variants stay unevaluated (VPR_ERRTYPE_UN), the rest of the batch is evaluated as usual:
+                                     - more than eight allowed swap sources map onto one position of its supercluster (nine or more
+                                       directly adjacent separate indel records on one haplotype; dist.cpp:335-350 has no bound);
+                                     - it reached the dense level wider than one workgroup holds (Lq + Lr above ~40 000) and cannot
+                                       be cut into column strips either: an insertion OR a deletion of more than 4 088 bases inside
+                                       it (the planner cuts where both planes map 1:1);
+                                     - its walk is longer than the path entries reserved for it */
 
 /* return codes */
 #define VPR_OK            0
-#define VPR_ERR_ARG      -1   /* also (vpr_execute): an alignment of the dense level wider than one workgroup holds (Lq + Lr above
-                                 ~40 000) that cannot be cut into column strips either -- an insertion of more than 4 088
-                                 bases; see DESIGN.md section 4 */
+#define VPR_ERR_ARG      -1
 #define VPR_ERR_DEVICE   -2   /* no HIP device / HIP runtime error: there is NO CPU fallback */
-/* vpr_upload also returns VPR_ERR_ARG when more than eight allowed swap sources map onto one position (nine or more
-   directly adjacent separate indel records on one haplotype): an implementation limit, see DESIGN.md section 4 */
 #define VPR_ERR_NOMEM    -3
 #define VPR_ERR_STATE    -4
 

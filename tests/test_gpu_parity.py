@@ -322,8 +322,40 @@ def test_adjacent_deletion_records_up_to_the_swap_source_limit():
     message -- a documented limit, not a wrong result."""
     for k in (3, 4, 5, 7):
         compare(api.batch_from_variants(_adjacent_deletions(k)))
-    with pytest.raises(api.VprError, match="swap sources"):
-        api.PrecisionRecall().run(api.batch_from_variants(_adjacent_deletions(8)))
+    r = api.PrecisionRecall().run(api.batch_from_variants(_adjacent_deletions(8)))
+    assert ((r.aln_status & A.ST_ERR_LIMIT) != 0).all() and (r.errtype[0][0] == A.ERRTYPE_UN).all()
+
+
+def test_a_supercluster_beyond_the_swap_source_limit_does_not_touch_the_rest_of_the_batch():
+    """nine directly adjacent deletion records in ONE supercluster of a batch (the reference has no limit on swap sources per
+    position, dist.cpp:335-350; the library keeps eight): that supercluster's four alignments come back with VPR_ST_ERR_LIMIT
+    and unevaluated variants, every other supercluster equals the oracle -- vpr_upload used to refuse the whole batch"""
+    rng = np.random.RandomState(23)
+    ref = "".join(rng.choice(list("ACGT"), 400))
+    S, I, D = A.TYPE_SUB, A.TYPE_INS, A.TYPE_DEL
+    other = lambda c: "ACGT"[("ACGT".index(c) + 1) % 4]
+    run9 = [(200 + k, D, ref[200 + k], "", 30.0) for k in range(9)]
+    scs = [dict(ctg=0, beg=40, end=70, vars=[[(50, S, ref[50], other(ref[50]), 20.0)], [], [(50, S, ref[50], other(ref[50]), 40.0)], [(60, I, "", "GT", 9.0)]]),
+           dict(ctg=0, beg=190, end=220, vars=[run9, [], [(200, D, ref[200:209], "", 50.0)], []]),
+           dict(ctg=0, beg=300, end=340, vars=[[(310, D, ref[310:313], "", 20.0)], [(320, S, ref[320], other(ref[320]), 5.0)],
+                                               [(310, D, ref[310:313], "", 40.0)], [(320, S, ref[320], other(ref[320]), 7.0)]])]
+    v = A.Variants.from_sites([ref], scs)
+    batch = api.batch_from_variants(v)
+    got = api.PrecisionRecall().run(batch)
+    want = O.run(batch)
+    want = want[0] if isinstance(want, tuple) else want
+    st = got.aln_status.reshape(-1, 4)
+    assert ((st[1] & A.ST_ERR_LIMIT) != 0).all() and not (st[[0, 2]] & A.ST_ERR_LIMIT).any()
+    for name in ("aln_dist", "aln_end_plane", "aln_beg_plane", "aln_status"):
+        assert np.array_equal(getattr(got, name).reshape(-1, 4)[[0, 2]], getattr(want, name).reshape(-1, 4)[[0, 2]]), name
+    for h in range(4):
+        keep = np.ones(int(batch.var_off[h][-1]), bool)
+        keep[batch.var_off[h][1]:batch.var_off[h][2]] = False
+        for w in range(2):
+            assert (got.errtype[h][w][~keep] == A.ERRTYPE_UN).all()
+            for name, dt in A.Results.PER_VAR:
+                x, y = getattr(got, name)[h][w][keep], getattr(want, name)[h][w][keep]
+                assert np.array_equal(x.view(np.uint32) if dt == np.float32 else x, y.view(np.uint32) if dt == np.float32 else y), (name, h, w)
 
 
 @pytest.mark.parametrize("band_mode", [1, 3, 2, 0])

@@ -8,9 +8,9 @@ R=$(pwd)
 OUT=$R/gpurun_out/profiles_${TAG}_${WL}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$R"
-CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --workload $WL --n-sc $NSC"
+CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --workload $WL --n-sc $NSC"
 timeout ${PASS_TIMEOUT:-400} rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $CMD > "$OUT/stats.log" 2>&1
-CMD2="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --in-flight 1 --one-pass-batches 0 --workload $WL --n-sc $NSC"
+CMD2="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --in-flight 1 --one-pass-batches 0 --no-secondary --workload $WL --n-sc $NSC"
 timeout ${PASS_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $CMD2 > "$OUT/fetch.log" 2>&1
 timeout ${PASS_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" --output-format csv -- $CMD2 > "$OUT/write.log" 2>&1
 timeout ${PASS_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \

@@ -295,6 +295,7 @@ struct vpr_handle {
     DevBatch dB;
     // host mirrors needed for planning / finalisation
     int32_t n_sc = 0;
+    int32_t n_limit_sc = 0;              // nonzero: some supercluster of the batch is marked in DevBatch::sc_limit
     std::vector<int64_t> var_off[4];
     std::vector<float> var_qual[4];
     int64_t n_var[4] = {0, 0, 0, 0};
@@ -1355,6 +1356,10 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if ((rc = dev_alloc(h, &D.dspan[s], size_t(n)))) return rc;
         if ((rc = dev_alloc(h, &D.sc_hap[s], hap_len[s]))) return rc;
         HIPCHK(h, hipMemsetAsync(D.has_ins[s], 0, std::max<int64_t>(ref_len, 1), h->stream));
+        if (s == 0) {
+            if ((rc = dev_alloc(h, &D.sc_limit, size_t(std::max(b->n_sc, 1))))) return rc;
+            HIPCHK(h, hipMemsetAsync(D.sc_limit, 0, size_t(std::max(b->n_sc, 1)), h->stream));
+        }
     }
     if ((rc = dev_upload(h, &D.ref_off, b->ref_off, n + 1))) return rc;
     if ((rc = dev_upload(h, &D.ref_seq, b->ref_seq, ref_len))) return rc;
@@ -1691,7 +1696,9 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     lap("plan + upload");
     uint32_t err = 0;
     HIPCHK(h, hipMemcpy(&err, h->d_err, 4, hipMemcpyDeviceToHost));
-    if (err) return fail(h, VPR_ERR_ARG, "more than 8 swap sources map to one position (unsupported variant layout)");
+    // (err: some supercluster has more than eight swap sources on one position -- DevBatch::sc_limit says which; its four
+    // alignments come back with VPR_ST_ERR_LIMIT, everything else is evaluated)
+    h->n_limit_sc = err ? 1 : 0;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     h->timing.ms_prep = ms;
@@ -2117,7 +2124,7 @@ struct Exec {
         HIPCHK(h, hipMemcpyAsync(d_fits, h_fits, size_t(cnt), hipMemcpyHostToDevice, ks));
         HIPCHK(h, hipMemsetAsync(G.d_prog, 0, size_t(slots) * 8, ks));
         hipLaunchKernelGGL(k_strip_plan, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, d_work + off, cnt, G.d_base, G.d_tab,
-                           G.d_n, G.d_ok, d_fits, h->d_err);
+                           G.d_n, G.d_ok, d_fits, h->d_err, h->d_outs);
         return VPR_OK;
     }
 
@@ -3264,7 +3271,7 @@ struct Exec {
             fs_.threads = 128; fs_.n_units = na;
             rc = timed(5, fs_, st, "k_finalize+k_phase_tally", [&] {
                 if (na) hipLaunchKernelGGL(k_finalize, dim3((na + 127) / 128), dim3(128), 0, st, h->d_descs, na, h->d_outs,
-                                           h->d_secs, h->d_fp_table, h->dR);
+                                           h->d_secs, h->d_fp_table, h->dR, h->dB.sc_limit);
                 if (h->n_sc) hipLaunchKernelGGL(k_phase_tally, dim3((h->n_sc + 127) / 128), dim3(128), 0, st, h->d_descs,
                                                 h->n_sc, h->dR);
             });
@@ -3276,13 +3283,7 @@ struct Exec {
         phase(5);
         lapx("done");
         HIPCHK(h, hipGetLastError());
-        if (need_err_check) {
-            uint32_t err = 0;
-            HIPCHK(h, hipMemcpy(&err, h->d_err, 4, hipMemcpyDeviceToHost));
-            if (err & VPR_ST_ERR_LIMIT)
-                return fail(h, VPR_ERR_ARG, "an alignment of the dense level is too wide for one workgroup and has no column where it can be cut "
-                                            "into strips (an insertion of more than %d bases?)", ST_CAP);
-        }
+        (void)need_err_check;      // (an alignment neither the strips nor one workgroup can take carries VPR_ST_ERR_LIMIT: k_strip_plan)
         float ms = 0;
         (void)hipEventElapsedTime(&ms, t0, t1);
         h->timing.ms_total = ms;

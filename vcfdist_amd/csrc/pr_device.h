@@ -70,6 +70,8 @@ struct DevBatch {
     int4 *cand2_q[2];     // sources five to eight of a position (read only where cand_*.w >= 0: directly adjacent separate
     int4 *cand2_r[2];     //   indel records on one haplotype, each of which ends at the position)
     uint8_t *has_ins[4];  // [ref positions] an insertion of hap slot s sits at this ref index (dist.cpp:886-894)
+    uint8_t *sc_limit;    // [superclusters] nonzero: the supercluster exceeds an implementation limit (more than eight swap sources on
+                          //   one position): its alignments are reported with VPR_ST_ERR_LIMIT and no variant results
     // packed per-position constants for the banded kernels (k_prep_pack):
     //   fk_*: .x = first swap source (cand.x) | FK_MULTI if there are more, -1 if none
     //         .y = swap target of this position as a *source* (ptr+1 if fwd_allow, else 0xffffff) | base << 24

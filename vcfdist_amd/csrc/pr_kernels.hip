@@ -70,7 +70,7 @@ __global__ void k_prep_cand(DevBatch B, int h, int dir, int64_t n_src, uint32_t 
     int rank = 0;
     for (int64_t y = g - 1; y >= s0 && ptr[y] == p; y--)
         if (fwd_allow(flg[y])) rank++;
-    if (rank >= SWAP_SOURCES_MAX) { atomicOr(err, VPR_ST_ERR_LIMIT); return; }
+    if (rank >= SWAP_SOURCES_MAX) { atomicOr(err, VPR_ST_ERR_LIMIT); B.sc_limit[sc] = 1; return; }
     int32_t *slot = reinterpret_cast<int32_t *>((rank < 4 ? cand : cand2) + dst_off[sc] + d);
     slot[rank & 3] = x;
 }
@@ -1090,12 +1090,22 @@ __global__ void __launch_bounds__(64) k_credit(DevBatch B, const AlnDesc *__rest
 // the parity tests compare the bit patterns.
 // ---------------------------------------------------------------------------
 __global__ void k_finalize(const AlnDesc *__restrict__ descs, int n_aln, const AlnOut *__restrict__ outs,
-                           const Section *__restrict__ secs, int32_t *const *__restrict__ fp_group, DevResults R) {
+                           const Section *__restrict__ secs, int32_t *const *__restrict__ fp_group, DevResults R,
+                           const uint8_t *__restrict__ sc_limit) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_aln) return;
     const AlnDesc d = descs[a];
     const AlnOut O = outs[a];
     uint32_t status = O.status;
+    if (sc_limit[d.sc] || (status & VPR_ST_ERR_LIMIT)) {
+        // beyond an implementation limit (include/vcfdist_pr.h): the alignment is reported as such and its variants stay
+        // unevaluated (ERRTYPE_UN); the rest of the batch is not affected
+        R.aln_dist[a] = O.s;
+        R.aln_end_plane[a] = uint8_t(O.end_plane);
+        R.aln_beg_plane[a] = uint8_t(O.beg_plane);
+        R.aln_status[a] = (status & VPR_ST_SWAP_TIE) | VPR_ST_ERR_LIMIT;
+        return;
+    }
     const int swap = (d.aln == 1 || d.aln == 2);
     const VarCols Q = R.v[d.qs][swap], T = R.v[d.ts][swap];
     const float *qq = R.var_qual[d.qs];

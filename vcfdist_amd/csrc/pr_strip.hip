@@ -33,7 +33,8 @@ struct StripTab { int32_t lo[2], hi[2]; };      // columns [lo[p], hi[p]) of pla
 //   n_strips[i] = 0: it is left to the one-workgroup kernels if they can hold it, fits[i])
 __global__ void k_strip_plan(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ work, int n,
                              const int32_t *__restrict__ tab_base, StripTab *__restrict__ tab, int32_t *__restrict__ n_strips,
-                             int32_t *__restrict__ ok, const uint8_t *__restrict__ fits, uint32_t *__restrict__ err) {
+                             int32_t *__restrict__ ok, const uint8_t *__restrict__ fits, uint32_t *__restrict__ err,
+                             AlnOut *__restrict__ outs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const AlnDesc d = descs[work[i]];
@@ -69,9 +70,10 @@ __global__ void k_strip_plan(DevBatch B, const AlnDesc *__restrict__ descs, cons
         r_lo = fr; q_lo = fq;
     }
     n_strips[i] = good ? j : 0;
-    // ok: 1 = the strips take it; 0 = the one-workgroup kernels do; 2 = neither can (those kernels skip it, the execute fails)
+    // ok: 1 = the strips take it; 0 = the one-workgroup kernels do; 2 = neither can (those kernels skip it; the alignment is
+    // reported with VPR_ST_ERR_LIMIT)
     ok[i] = good ? 1 : (fits[i] ? 0 : 2);
-    if (!good && !fits[i]) atomicOr(err, VPR_ST_ERR_LIMIT);
+    if (!good && !fits[i]) { atomicOr(err, VPR_ST_ERR_LIMIT); atomicOr(&outs[work[i]].status, VPR_ST_ERR_LIMIT); }
 }
 
 // cell roles of a thread's chunk
