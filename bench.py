@@ -297,10 +297,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     gloo = dist is not None and dist.get_backend() == "gloo"
     if args.in_flight is None:
-        # One batch at a time.  (Round 3 kept three batches resident behind three handles so that one batch's latency tail ran
-        # beside the next batch's bulk: 25 ms per step on a good run, but a handle's first launches then waited up to seconds
-        # behind another handle's streams -- 39 streams on 8 hardware queues -- and the driver's run measured 133 ms.)
-        args.in_flight = 1
+        # Two batches resident behind two handles: one batch's latency tail -- a handful of alignments that are chains of
+        # thousands of sequential rows, then their tie rounds -- runs beside the other batch's bulk (22 ms per step against 33
+        # one at a time; every run of 12 on fresh boxes within 2 %).  Round 3 kept THREE: the third handle's first launches
+        # then waited up to seconds behind the other handles' streams (39 streams on 8 hardware queues) and the driver's run
+        # measured 133 ms per step; the first two handles never did, and the warm-up steps are watched for it below.
+        args.in_flight = 2 if args.workload == "wgs_synth" else 1
     if args.one_pass_batches is None:
         args.one_pass_batches = 9 if args.workload == "wgs_synth" else 0
     # (every resident batch goes through at least one untimed step: a handle's workspaces settle in its first execute)
@@ -351,7 +353,11 @@ def main():
     parts = [0.0, 0.0, 0.0]            # host-side seconds in execute / download / counters + collective, summed over the timed steps
     lock = threading.Lock()
     turn = threading.Condition()
-    next_coll = [0]                     # the collectives of step i are issued behind those of step i - 1 on every rank
+    # several ranks: the collectives of step i are issued behind those of step i - 1 on every rank (every rank must issue them in
+    # one order); one rank: the batches in flight only take turns at the communicator
+    ordered = world > 1 or bool(os.environ.get("BENCH_ORDERED"))
+    coll_lock = threading.Lock()
+    next_coll = [0]
     failed = []                         # exceptions of the step threads: the others stop waiting for their turn
 
     step_log = []                       # (step, start, end) of every timed step, seconds on this rank's clock
@@ -362,10 +368,15 @@ def main():
         tb = time.perf_counter()
         S.host_res = res = S.pr.download(S.host_res)   # final results to (reused) host buffers
         tc = time.perf_counter()
-        with turn:
-            while next_coll[0] != i and not failed:
-                turn.wait(timeout=1.0)
+        if ordered:
+            with turn:
+                while next_coll[0] != i and not failed:
+                    turn.wait(timeout=1.0)
+        else:
+            coll_lock.acquire()
         if failed:
+            if not ordered:
+                coll_lock.release()
             raise RuntimeError("another step failed")
         pb = None
         if strong:      # a contig's superclusters sit on all ranks: all-gather (sc_phase, orig, swap), phase redundantly
@@ -384,9 +395,12 @@ def main():
                 th = t.cpu(); dist.all_reduce(th); t = th.to(dev)
             elif dist is not None:
                 dist.all_reduce(t)
-        with turn:
-            next_coll[0] = i + 1
-            turn.notify_all()
+        if ordered:
+            with turn:
+                next_coll[0] = i + 1
+                turn.notify_all()
+        else:
+            coll_lock.release()
         te = time.perf_counter()
         with lock:
             parts[0] += tb - ta; parts[1] += tc - tb; parts[2] += te - tc
@@ -437,6 +451,11 @@ def main():
             else:
                 a[5] += 1; a[6] += s_.ms
 
+    # Batches in flight start half a step apart and the order of the collectives (step i behind step i - 1) keeps them there: one
+    # batch's bulk kernels then run beside the other's latency tail.  Started together they stay in lock step -- both bulks at
+    # once, both tails at once: 28 ms per step instead of 22.  The delay is inside the timed region.
+    stagger_s = [0.0]
+
     def run_steps(first, n, timed):
         """steps first .. first + n - 1; with more than one batch in flight, step i runs on slot i % n_fl from that slot's own
         host thread (vpr_execute blocks its caller), so a batch's latency tail -- its few longest alignments are chains of
@@ -445,6 +464,8 @@ def main():
             try:
                 if dist is not None and not gloo:
                     torch.cuda.set_device(local_rank)
+                if j and stagger_s[0] > 0:      # (see stagger_s)
+                    time.sleep(j * stagger_s[0])
                 for i in range(first + j, first + n, n_fl):
                     r = step(i, slots[j])
                     if timed:
@@ -470,6 +491,23 @@ def main():
 
     import gc
     run_steps(0, max(args.warmup, 0), False)
+    # the stall guard: a warm-up step (behind the handles' first ones, which allocate) that took several times the others means
+    # the handles are in each other's way on this box -- the timed steps then run one batch at a time
+    stall_guard = None
+    if n_fl > 1 and len(step_log) > n_fl + 1:
+        wl = np.array([(e - a) * 1e3 for _, a, e in sorted(step_log)][n_fl:])
+        if wl.max() > max(6.0 * float(np.median(wl)), 250.0):
+            stall_guard = {"warmup_step_ms": [round(float(x), 1) for x in wl], "action": "timed steps one batch at a time"}
+            n_fl = 1
+    if dist is not None and world > 1:      # (all ranks alike: the collectives are issued in step order)
+        tg = torch.tensor([1 if stall_guard else 0], device="cpu" if gloo else dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        if int(tg.item()):
+            n_fl = 1
+    if n_fl > 1 and len(step_log) > n_fl:
+        env_st = os.environ.get("BENCH_STAGGER_MS")
+        lat = np.array([(e - a) * 1e3 for _, a, e in sorted(step_log)][n_fl:])
+        stagger_s[0] = (float(env_st) if env_st else 0.5 * float(np.median(lat)) / n_fl) * 1e-3
     parts[:] = [0.0, 0.0, 0.0]
     step_log.clear()
     # (the interpreter's cyclic collector otherwise runs a full collection inside one of the timed steps -- always the same one,
@@ -492,11 +530,20 @@ def main():
     # two more steps of one batch ALONE (not timed, not in `value`): a kernel's launch duration without the neighbours that
     # stretch it while batches are in flight -- the figure a rocprofv3 trace of `--in-flight 1` shows
     alone_acc, alone_ms = {}, []
+    one_at_a_time = None
     if n_fl > 1:
-        for k in range(2):
+        n_al = 6
+        sync()
+        t_al = time.perf_counter()
+        for k in range(n_al):
             step(args.warmup + args.steps + k, S_last)
             account(S_last, alone_acc, alone_ms, None)
         sync()
+        dt_al = time.perf_counter() - t_al
+        one_at_a_time = {"value": round(4 * args.n_sc * world / (dt_al / n_al), 1), "unit": "supercluster-alignments/s", "steps": n_al,
+                         "ms_per_step": round(dt_al / n_al * 1e3, 3), "kernel_ms_per_step": round(float(np.mean(alone_ms)), 3),
+                         "note": "rank 0's figure x ranks; the same steps strictly one after the other on one batch (the latency of a "
+                                 "lone step: DESIGN.md section 6)"}
     if rank == 0:       # the device tally must equal the one recomputed from the downloaded results
         assert np.array_equal(shard.tally_from_results(res, batch.var_off), pr.tally()), "device tally != host tally"
         # after the timed region: per-contig phasing (host Viterbi) and the PRECISION-RECALL SUMMARY of this rank
@@ -575,9 +622,10 @@ def main():
     two_fl = None
     secondary = []
     if world == 1 and not strong and not args.no_secondary and args.workload == "wgs_synth":
-        # (a) two batches in flight behind two handles: a batch's latency tail beside the other batch's bulk.  (Three handles --
-        # round 3's default -- stall: see --in-flight.)
+        # (a) two batches in flight behind two handles, when the headline ran one at a time (--in-flight 1 or the stall guard)
         try:
+            if n_fl > 1:
+                raise StopIteration
             S2 = make_slot(1)
             pair = [slots[0], S2]
             lat = []
@@ -610,6 +658,8 @@ def main():
                       "step_latency_ms": {"p50": round(float(np.percentile(lat, 50)), 3), "max": round(float(np.max(lat)), 3)},
                       "note": "every step still a complete pass over one batch; not the headline: `value` is measured one batch at a time"}
             del S2
+        except StopIteration:
+            two_fl = None
         except Exception as e:      # (a leg must not cost the headline)
             two_fl = {"error": repr(e)}
         # (b) the other single-GPU configurations of BASELINE.json on small batches
@@ -725,6 +775,8 @@ def main():
             "kernel_only_value": round(4 * args.n_sc / (float(np.mean(kern_ms)) * 1e-3), 1),
             "one_pass": one_pass,
             "two_in_flight": two_fl,
+            "one_at_a_time": one_at_a_time,
+            "stall_guard": stall_guard,
             "secondary": secondary,
             "kernels": per_kernel,
             "counts_at_min_qual_TP_FP_FN": t.cpu().numpy()[:, 3, :, 0].tolist(),   # [callset][TP,FP,FN], type ALL, all ranks

@@ -70,6 +70,7 @@ const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnD
 // rejects then climb the ladder in dozens of workspace-sized rounds.)
 const int LONG_LT = 2048;
 const int LONG_LV = 2;    // LV_C1
+const int32_t CREDIT_WAVE_MAX = 16384;                // alignments of a launch up to which the credit walk takes a wavefront each
 const int64_t WSEG_MAX_ROWS = int64_t(4) << 20;      // truth rows of a launch up to which its walk runs over segments (pr_walkseg.hip)
 
 // std::vector whose resize() leaves trivially constructible elements uninitialised (the planner fills millions of
@@ -1258,6 +1259,8 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     for (int k = 0; k < N_CLASSES; k++) {
+        // (tried: the retry rounds' side streams 5, 6 at high priority -- their back halves then start 2 ms earlier and the step
+        // with two batches in flight gets 2 ms LONGER: they take the bulk kernels' slots)
         const int prio = (k == 0 || k == 2 || k == 3) ? prio_hi : prio_lo;
         if (hipStreamCreateWithPriority(&h->cls_stream[k], hipStreamNonBlocking, prio) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming) != hipSuccess) {
@@ -2417,6 +2420,13 @@ struct Exec {
                                    h->d_zl_hdr + zl_wave0, h->d_zl_log, h->d_outs, h->d_secs, h->d_fp_table, h->d_jobs,
                                    h->d_njobs, h->jobs_cap, tag);
             });
+            // (a launch of a few thousand alignments -- a tie round, a late retry round -- lasts as long as its longest member:
+            // a wavefront per alignment reads the path in coalesced chunks, 0.45 us per row against 1.3 for a lane)
+            else if (cnt <= CREDIT_WAVE_MAX && !n_dev) rc = timed(3, ws_, ks, "k_credit<wave>", [&] {
+                hipLaunchKernelGGL(k_credit<true>, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+                                   h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs, h->d_njobs,
+                                   h->jobs_cap, dtag, tag, n_dev);
+            });
             else rc = timed(3, ws_, ks, "k_credit<lane>", [&] {
                 hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
                                    list, cnt, h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs,
@@ -2455,8 +2465,9 @@ struct Exec {
             }
             if (rc) return rc;
             ws_.cells_per_thread = 3;
-            rc = timed(3, ws_, ks, wave_walk ? "k_credit<wave>" : "k_credit<lane>", [&] {
-                if (wave_walk)
+            const bool wave_credit = wave_walk || cnt <= CREDIT_WAVE_MAX;
+            rc = timed(3, ws_, ks, wave_credit ? "k_credit<wave>" : "k_credit<lane>", [&] {
+                if (wave_credit)
                     hipLaunchKernelGGL(k_credit<true>, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                        h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs, h->d_njobs,
                                        h->jobs_cap, dtag, tag, n_dev);
