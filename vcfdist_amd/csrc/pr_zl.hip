@@ -195,12 +195,20 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
     // One row step over the first S slots of each plane (S = 2: no lane of the wave has a third diagonal -- nearly every
     // row; S = 4 otherwise).  Returns false when S = 2 was not enough (a SWP child found both slots of its plane taken):
     // nothing has been committed then and the caller repeats the row with S = 4.
+    // Software pipeline of the two-slot path: the children's words of the cells of row t + 1 -- what the NEXT row step compares --
+    // are requested as soon as those cells are known, in the middle of this row step, and the rest of the step (the log entries,
+    // their store, the loop) runs while they are on their way.  pf_*: the words requested by the previous two-slot step for
+    // slots 0 and 1 (have_pf: there are such; a four-slot step leaves none).  The SWP child is requested wherever the cell
+    // allows a swap at all; whether the truth row does is only known in the next step, which then ignores the word.
+    uint32_t pf_mw[2][2] = {{0, 0}, {0, 0}}, pf_sw[2][2] = {{0, 0}, {0, 0}};
+    bool have_pf = false;
     auto fwd_row = [&](auto Sc, int t, bool act, uint32_t tw1) -> bool {
         constexpr int S = decltype(Sc)::value;
         const bool t_allow = zw_fwd_allow(tw0);
         // children's position words: MAT child x + 1 of the own plane, SWP child ptr + 1 of the other plane
         uint32_t mw[2][S], sw[2][S];
         int sz[2][S];
+        const bool use_pf = S == 2 && have_pf;
 #pragma unroll
         for (int p = 0; p < 2; p++) {
 #pragma unroll
@@ -210,8 +218,13 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
                 const int z = ZW_PTR(pw[p][s]) + 1;
                 const bool sok = alive && t_allow && zw_fwd_allow(pw[p][s]) && z < L[1 - p];
                 sz[p][s] = sok ? z : -1;
-                mw[p][s] = in_at((alive && c < L[p]) ? pos0[p] + (uint32_t(c) << 8) + lane4 : ZL_OOB);
-                sw[p][s] = in_at(sok ? pos0[1 - p] + (uint32_t(z) << 8) + lane4 : ZL_OOB);
+                if (use_pf) {
+                    mw[p][s] = (alive && c < L[p]) ? pf_mw[p][s & 1] : 0u;
+                    sw[p][s] = sok ? pf_sw[p][s & 1] : 0u;
+                } else {
+                    mw[p][s] = in_at((alive && c < L[p]) ? pos0[p] + (uint32_t(c) << 8) + lane4 : ZL_OOB);
+                    sw[p][s] = in_at(sok ? pos0[1 - p] + (uint32_t(z) << 8) + lane4 : ZL_OOB);
+                }
             }
         }
         const uint32_t Tb = ZW_BASE(tw1);
@@ -255,6 +268,20 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
         }
         if (S < 4 && __any(full)) return false;
         ok = ok && !bad && !full;
+        if (S == 2) {       // the next step's words (see pf_*)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    const bool alive = act && ok && nq[p][s] >= 0;
+                    const int c = nq[p][s] + 1;
+                    const int z = ZW_PTR(nw[p][s]) + 1;
+                    pf_mw[p][s] = in_at((alive && c < L[p]) ? pos0[p] + (uint32_t(c) << 8) + lane4 : ZL_OOB);
+                    pf_sw[p][s] = in_at((alive && zw_fwd_allow(nw[p][s]) && z < L[1 - p]) ? pos0[1 - p] + (uint32_t(z) << 8) + lane4 : ZL_OOB);
+                }
+            }
+        }
+        have_pf = S == 2;
         // the row's log entries
         {
             zl_u2 ev;
