@@ -326,6 +326,7 @@ def main():
             S.t_b = time.perf_counter()
             S.batch = S.syn.batch(copy=False)   # host marshalling = the four generate_ptrs_strs calls per supercluster
         S.t_c = time.perf_counter()
+        # (library defaults: all four alignments of every supercluster are computed)
         S.pr = api.PrecisionRecall(device=local_rank)
         S.t_c1 = time.perf_counter()
         S.pr.upload(S.batch)                # inputs resident in HBM before the timed region (+ K0 prep kernels)

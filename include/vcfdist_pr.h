@@ -165,6 +165,11 @@ typedef struct vpr_config {
                                    and the second attempt (worst-case logs) has to decide the ties */
 #define VPR_CFG_GUARD_ALLOC 4   /* test aid: every device array gets an allocation of its own instead of a slice of a pooled
                                    block, so that an access far behind an array faults instead of reading its neighbour */
+#define VPR_CFG_HAP_DEDUP 16     /* an alignment whose haplotypes are identical (strings, pointers, flags, variant positions) to those of
+                                   another alignment of its supercluster -- a callset that is homozygous there -- is not computed a
+                                   second time: it gets that alignment's results (bit for bit what computing it gives; never where
+                                   a swap tie can occur).  Off by default: on whole-genome-like input half of the alignments are
+                                   such copies, but they are the short ones -- a tenth of the rows (vpr_timing.n_alignments_computed) */
 #define VPR_CFG_KEEP_PATHS 8    /* the zero-distance lane kernel (most alignments of whole-genome input end there) keeps its walk in a
                                    compact form only its own credit kernel reads; with this flag it also writes the 16-byte path
                                    entries vpr_download_path returns (tests, callers who want the alignment path itself) */
@@ -215,6 +220,7 @@ typedef struct vpr_timing {
                               [4] deferred edit distances + finalisation enqueued, [5] last kernel complete */
     double  ms_host_alloc; /* time inside hipMalloc / hipFree / hipHostMalloc */
     double  ms_host_blocked; /* time inside blocking waits other than the final one ([4] -> [5]) */
+    int64_t n_alignments_computed; /* alignments the kernels ran (all of them without VPR_CFG_HAP_DEDUP) */
     int64_t n_device_allocs, n_device_frees, n_host_allocs;   /* hipMalloc / hipFree / hipHostMalloc calls of the execute: all 0
                               once the handle's workspaces have settled (normally after the first execute of a batch) */
 } vpr_timing;

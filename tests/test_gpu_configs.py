@@ -251,6 +251,20 @@ def test_repeated_executes_of_one_batch_are_identical():
         assert not d, (it, d[:3])
 
 
+def test_identical_alignments_computed_once_equal_all_four_computed():
+    """VPR_CFG_HAP_DEDUP: a callset that is homozygous over a supercluster has two identical haplotypes, and the alignments that
+    differ only in which of them they name are computed once (k_hap_alias; not where a swap tie can occur: the reference's
+    container order depends on the alignment's index there).  Same arrays as the default, which computes all four, and as the
+    oracle, which always does."""
+    syn = api.Synth(n_sc=4000, len_a=10, len_b=400, len_max=400, seed=314, var_per_base=0.02, p_hom=0.8, p_repeat=0.3)
+    batch = syn.batch()
+    got, want, _, pr = compare(batch, A.default_config(flags=A.CFG_HAP_DEDUP))
+    n_run = pr.timing().n_alignments_computed
+    assert 4000 < n_run < 4 * 4000 * 0.8, n_run          # a good part is aliased, not everything
+    pr2 = api.PrecisionRecall()
+    assert not got.diff(pr2.run(batch)) and pr2.timing().n_alignments_computed == 4 * 4000
+
+
 def test_dense_backward_int16_rows_forced():
     batch = api.Synth(n_sc=30, len_a=30, len_b=900, len_min=30, len_max=900, seed=61, var_per_base=0.03).batch()
     compare(batch, A.default_config(band_mode=0, flags=A.CFG_DENSE_S16))

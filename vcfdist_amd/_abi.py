@@ -76,6 +76,7 @@ CFG_DENSE_S16 = 1   # VPR_CFG_DENSE_S16
 CFG_TIE_SMALL_LOGS = 2   # VPR_CFG_TIE_SMALL_LOGS
 CFG_GUARD_ALLOC = 4      # VPR_CFG_GUARD_ALLOC
 CFG_KEEP_PATHS = 8       # VPR_CFG_KEEP_PATHS
+CFG_HAP_DEDUP = 16       # VPR_CFG_HAP_DEDUP
 
 
 class VprTiming(C.Structure):
@@ -86,7 +87,7 @@ class VprTiming(C.Structure):
         ("bytes_algorithmic", C.c_int64), ("n_band_retries", C.c_int64),
         ("n_tie_replays", C.c_int64), ("ms_tie", C.c_double),
         ("ms_wall", C.c_double), ("ms_wall_phase", C.c_double * 6), ("ms_host_alloc", C.c_double),
-        ("ms_host_blocked", C.c_double), ("n_device_allocs", C.c_int64), ("n_device_frees", C.c_int64),
+        ("ms_host_blocked", C.c_double), ("n_alignments_computed", C.c_int64), ("n_device_allocs", C.c_int64), ("n_device_frees", C.c_int64),
         ("n_host_allocs", C.c_int64),
     ]
 

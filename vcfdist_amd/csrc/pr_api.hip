@@ -296,6 +296,9 @@ struct vpr_handle {
     DevBatch dB;
     // host mirrors needed for planning / finalisation
     int32_t n_sc = 0;
+    uint8_t *d_alias = nullptr;          // [superclusters] alias bits (k_hap_alias), all 0 without VPR_CFG_HAP_DEDUP
+    std::vector<uint8_t> alias;          // host copy
+    int64_t n_aliased = 0;               // alignments of the batch that are copies of another one
     int32_t n_limit_sc = 0;              // nonzero: some supercluster of the batch is marked in DevBatch::sc_limit
     std::vector<int64_t> var_off[4];
     std::vector<float> var_qual[4];
@@ -872,6 +875,66 @@ __global__ void k_init_execute(InitArgs A) {
 __global__ void k_flag(int32_t *__restrict__ h_flag, int32_t v) {
     *h_flag = v;
     __threadfence_system();
+}
+
+// ---- identical alignments of a supercluster.  Its four alignments pair query hap 0 / 1 with truth hap 0 / 1; where a callset
+// is homozygous over the whole supercluster its two haps are the same strings with the same pointers and flags, and alignments
+// that differ only in which of them they name are the same computation with the same result -- unless a swap tie can occur,
+// see below.  k_hap_alias finds such
+// superclusters (bit 0: query hap 1 == query hap 0, bit 1: truth hap 1 == truth hap 0: every Level A array and the variant
+// positions compared); the planner leaves the aliases out, k_alias_outs gives them their source's alignment scalars and
+// k_finalize writes their variants' results from the source's sections (with their own qualities).
+__global__ void k_hap_alias(DevBatch B, uint8_t *__restrict__ bits) {
+    const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sc >= B.n_sc) return;
+    auto same = [&](int a, int b) -> bool {
+        const int64_t oa = B.hap_off[a][sc], ob = B.hap_off[b][sc];
+        const int64_t n = B.hap_off[a][sc + 1] - oa;
+        if (n != B.hap_off[b][sc + 1] - ob) return false;
+        const int64_t va = B.var_off[a][sc], vb = B.var_off[b][sc];
+        const int64_t nv = B.var_off[a][sc + 1] - va;
+        if (nv != B.var_off[b][sc + 1] - vb) return false;
+        for (int64_t k = 0; k < nv; k++) if (B.var_pos[a][va + k] != B.var_pos[b][vb + k]) return false;
+        for (int64_t k = 0; k < n; k++)
+            if (B.hap_seq[a][oa + k] != B.hap_seq[b][ob + k] || B.hap_ptr[a][oa + k] != B.hap_ptr[b][ob + k] ||
+                B.hap_flag[a][oa + k] != B.hap_flag[b][ob + k]) return false;
+        return true;
+    };
+    // Not where a cell can have two swap sources (a position with a second candidate, k_prep_cand): which of two optimal
+    // sources the reference keeps depends on the iteration order of its hash containers, and its cell keys carry the
+    // alignment's index (hi = 2 i + plane, dist.cpp:286-289) -- there the four alignments differ even on identical strings.
+    for (int q = 0; q < 2; q++) {
+        const int64_t qo = B.hap_off[q][sc], nq = B.hap_off[q][sc + 1] - qo, ro = B.ref_off[sc], nr = B.ref_off[sc + 1] - ro;
+        for (int64_t k = 0; k < nq; k++) if (B.cand_q[q][qo + k].y >= 0) { bits[sc] = 0; return; }
+        for (int64_t k = 0; k < nr; k++) if (B.cand_r[q][ro + k].y >= 0) { bits[sc] = 0; return; }
+    }
+    uint8_t r = 0;
+    if (same(0, 1)) {       // (the reference-side arrays of a query hap: pointers into it and the flags of its variants' positions)
+        const int64_t ro = B.ref_off[sc], nr = B.ref_off[sc + 1] - ro;
+        bool eq = true;
+        for (int64_t k = 0; k < nr && eq; k++) eq = B.ref_ptr[0][ro + k] == B.ref_ptr[1][ro + k] && B.ref_flag[0][ro + k] == B.ref_flag[1][ro + k];
+        if (eq) r |= 1;
+    }
+    if (same(2, 3)) r |= 2;
+    bits[sc] = r;
+}
+// source of alignment i (0..3) of a supercluster with alias bits b, -1: it is computed itself
+__host__ __device__ inline int alias_source(int b, int i) {
+    const int q = i >> 1, t = i & 1;
+    const int qs = (b & 1) ? 0 : q, ts = (b & 2) ? 0 : t;
+    const int src = qs * 2 + ts;
+    return src == i ? -1 : src;
+}
+__global__ void k_alias_descs(BatchOffsets O, const uint8_t *__restrict__ bits, int n_sc, AlnDesc *__restrict__ descs) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= 4 * n_sc) return;
+    if (alias_source(bits[a >> 2], a & 3) >= 0) descs[a] = base_desc(O, a);
+}
+__global__ void k_alias_outs(const uint8_t *__restrict__ bits, int n_sc, AlnOut *__restrict__ outs) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= 4 * n_sc) return;
+    const int src = alias_source(bits[a >> 2], a & 3);
+    if (src >= 0) outs[a] = outs[(a & ~3) | src];
 }
 
 __global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc *__restrict__ dst) {
@@ -1654,7 +1717,23 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     // ---- round-0 plan over all alignments, cached (descriptors + work list live on the device)
     std::vector<int32_t> &all = h->scratch_i32[1];
     all.resize(na);
-    par_for(na, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) all[k] = int32_t(k); });
+    h->alias.assign(size_t(b->n_sc), 0);
+    h->n_aliased = 0;
+    if ((rc = dev_alloc(h, &h->d_alias, size_t(std::max(b->n_sc, 1))))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_alias, 0, size_t(std::max(b->n_sc, 1)), h->stream));
+    if (b->n_sc && (h->cfg.flags & VPR_CFG_HAP_DEDUP)) {
+        hipLaunchKernelGGL(k_hap_alias, blocks(int64_t(b->n_sc)), dim3(256), 0, h->stream, D, h->d_alias);
+        HIPCHK(h, hipMemcpyAsync(h->alias.data(), h->d_alias, size_t(b->n_sc), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, x_sync(h, h->stream, SITE));
+        size_t np = 0;
+        for (size_t a = 0; a < na; a++)
+            if (alias_source(h->alias[a >> 2], int(a & 3)) < 0) all[np++] = int32_t(a);
+        h->n_aliased = int64_t(na - np);
+        all.resize(np);
+    } else {
+        par_for(na, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) all[k] = int32_t(k); });
+    }
+    const size_t np = all.size();      // alignments that are computed
     h->level.assign(na, uint8_t(LV_DENSE));
     const int lv0 = h->cfg.band_mode == 0 ? LV_DENSE
                     : h->cfg.band_mode == 2 ? LV_C1
@@ -1662,35 +1741,41 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     if ((rc = make_plan(h, all, lv0, h->plan0, h->d_arena, h->arena_bytes, 0, true))) return rc;
     lap("make_plan");
     h->level0 = h->level;
-    h->plan0_pos.resize(na);
-    par_for(na, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) h->plan0_pos[size_t(h->plan0.work[k])] = int32_t(k); });
-    if ((rc = dev_alloc(h, &h->plan0.d_descs, na))) return rc;
-    if ((rc = dev_alloc(h, &h->plan0.d_work, na))) return rc;
+    h->plan0_pos.assign(na, -1);
+    par_for(np, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) h->plan0_pos[size_t(h->plan0.work[k])] = int32_t(k); });
+    if ((rc = dev_alloc(h, &h->plan0.d_descs, np))) return rc;
+    if ((rc = dev_alloc(h, &h->plan0.d_work, np))) return rc;
     lap("plan0_pos");
-    if (na && h->plan0.lazy) {
+    if (h->n_aliased) {
+        BatchOffsets DO;
+        for (int s = 0; s < 4; s++) { DO.hap_off[s] = D.hap_off[s]; DO.var_off[s] = D.var_off[s]; }
+        DO.ref_off = D.ref_off;
+        hipLaunchKernelGGL(k_alias_descs, blocks(int64_t(na)), dim3(256), 0, h->stream, DO, h->d_alias, b->n_sc, h->d_descs);
+    }
+    if (np && h->plan0.lazy) {
         // the plan crosses the link as (alignment, workspace offset) pairs; the device builds both descriptor tables
         void *pw = nullptr;
-        { int rc_pin = pin_alloc(h, &pw, na * 8); if (rc_pin) return rc_pin; }
+        { int rc_pin = pin_alloc(h, &pw, np * 8); if (rc_pin) return rc_pin; }
         int32_t *hw = static_cast<int32_t *>(pw);
-        uint32_t *ho = reinterpret_cast<uint32_t *>(hw + na);
+        uint32_t *ho = reinterpret_cast<uint32_t *>(hw + np);
         const Plan &P0 = h->plan0;
-        par_for(na, [&](size_t b0, size_t e0, int) {
+        par_for(np, [&](size_t b0, size_t e0, int) {
             memcpy(hw + b0, P0.work.data() + b0, (e0 - b0) * 4);
             memcpy(ho + b0, P0.off128.data() + b0, (e0 - b0) * 4);
         });
         uint32_t *d_off = nullptr;
-        if ((rc = dev_alloc(h, &d_off, na))) return rc;
-        HIPCHK(h, hipMemcpyAsync(h->plan0.d_work, hw, na * 4, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(d_off, ho, na * 4, hipMemcpyHostToDevice, h->stream));
+        if ((rc = dev_alloc(h, &d_off, np))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->plan0.d_work, hw, np * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_off, ho, np * 4, hipMemcpyHostToDevice, h->stream));
         BatchOffsets DO;
         for (int s = 0; s < 4; s++) { DO.hap_off[s] = D.hap_off[s]; DO.var_off[s] = D.var_off[s]; }
         DO.ref_off = D.ref_off;
-        hipLaunchKernelGGL(k_build_plan, blocks(int64_t(na)), dim3(256), 0, h->stream, DO, h->plan0.d_work, d_off, int(na), P0.lv,
+        hipLaunchKernelGGL(k_build_plan, blocks(int64_t(np)), dim3(256), 0, h->stream, DO, h->plan0.d_work, d_off, int(np), P0.lv,
                            P0.long_lt, P0.tag_or, h->plan0.d_descs, h->d_descs);
-    } else if (na) {
-        HIPCHK(h, hipMemcpyAsync(h->plan0.d_descs, h->plan0.descs.data(), na * sizeof(AlnDesc), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->plan0.d_work, h->plan0.work.data(), na * 4, hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(na)), dim3(256), 0, h->stream, h->plan0.d_descs, int(na), h->d_descs);
+    } else if (np) {
+        HIPCHK(h, hipMemcpyAsync(h->plan0.d_descs, h->plan0.descs.data(), np * sizeof(AlnDesc), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->plan0.d_work, h->plan0.work.data(), np * 4, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(np)), dim3(256), 0, h->stream, h->plan0.d_descs, int(np), h->d_descs);
     }
     if (lv0 == LV_Z && (rc = prep_zero_lane(h))) return rc;
 
@@ -3281,8 +3366,9 @@ struct Exec {
             memset(&fs_, 0, sizeof(fs_));
             fs_.threads = 128; fs_.n_units = na;
             rc = timed(5, fs_, st, "k_finalize+k_phase_tally", [&] {
+                if (na && h->n_aliased) hipLaunchKernelGGL(k_alias_outs, blocks(int64_t(na)), dim3(256), 0, st, h->d_alias, h->n_sc, h->d_outs);
                 if (na) hipLaunchKernelGGL(k_finalize, dim3((na + 127) / 128), dim3(128), 0, st, h->d_descs, na, h->d_outs,
-                                           h->d_secs, h->d_fp_table, h->dR, h->dB.sc_limit);
+                                           h->d_secs, h->d_fp_table, h->dR, h->dB.sc_limit, h->d_alias);
                 if (h->n_sc) hipLaunchKernelGGL(k_phase_tally, dim3((h->n_sc + 127) / 128), dim3(128), 0, st, h->d_descs,
                                                 h->n_sc, h->dR);
             });
@@ -3313,6 +3399,7 @@ struct Exec {
         h->timing.cells_touched = cells_touched;
         h->timing.n_band_retries = n_retry;
         h->timing.n_tie_replays = n_tie_jobs;
+        h->timing.n_alignments_computed = int64_t(h->descs.size()) - h->n_aliased;
         h->timing.ms_wall = phase_ms[5];
         for (int k = 0; k < 6; k++) h->timing.ms_wall_phase[k] = phase_ms[k];
         h->timing.ms_host_alloc = h->hs.ms_alloc;
@@ -3358,8 +3445,8 @@ struct Exec {
             hipLaunchKernelGGL(k_init_execute, blocks(top), dim3(256), 0, st, IA);
         }
         if (!h->dirty.empty()) {   // restore the round-0 descriptors and levels a previous execute's retry rounds replaced
-            hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(h->descs.size())), dim3(256), 0, st, h->plan0.d_descs,
-                               int(h->descs.size()), h->d_descs);
+            hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(h->plan0.work.size())), dim3(256), 0, st, h->plan0.d_descs,
+                               int(h->plan0.work.size()), h->d_descs);
             for (int32_t a : h->dirty) h->level[size_t(a)] = h->level0[size_t(a)];     // (every level change goes through a plan)
             h->dirty.clear();
         }
@@ -3772,14 +3859,16 @@ int64_t vpr_download_path(const vpr_handle *h, int32_t sc, int32_t aln, int64_t 
     if (!h || !h->executed || sc < 0 || sc >= h->n_sc || aln < 0 || aln > 3) return VPR_ERR_ARG;
     // the walk scratch lives in a workspace that is reused per chunk: only the last chunk of round 0 and the
     // retry plans are still resident (the most recent plan of an alignment holds its final walk)
-    const int32_t a = sc * 4 + aln;
+    // (an alignment that is a copy of another one of its supercluster, k_hap_alias: that one's walk)
+    const int src_ = h->alias.empty() ? -1 : alias_source(h->alias[size_t(sc)], aln);
+    const int32_t a = sc * 4 + (src_ >= 0 ? src_ : aln);
     const uint8_t *arena = nullptr;
     bool found = false;
     for (auto it = h->resident.rbegin(); it != h->resident.rend() && !found; ++it)
         if (std::find(it->first.begin(), it->first.end(), a) != it->first.end()) { arena = it->second; found = true; }
     if (!found && h->res0_cnt > 0) {
         const int64_t pos = h->plan0_pos[size_t(a)];
-        if (pos >= h->res0_off && pos < h->res0_off + h->res0_cnt) arena = h->plan0.arena;
+        if (pos >= 0 && pos >= h->res0_off && pos < h->res0_off + h->res0_cnt) arena = h->plan0.arena;
     }
     if (!arena) return VPR_ERR_STATE;
     AlnOut O;

@@ -1091,12 +1091,22 @@ __global__ void __launch_bounds__(64) k_credit(DevBatch B, const AlnDesc *__rest
 // ---------------------------------------------------------------------------
 __global__ void k_finalize(const AlnDesc *__restrict__ descs, int n_aln, const AlnOut *__restrict__ outs,
                            const Section *__restrict__ secs, int32_t *const *__restrict__ fp_group, DevResults R,
-                           const uint8_t *__restrict__ sc_limit) {
+                           const uint8_t *__restrict__ sc_limit, const uint8_t *__restrict__ alias) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_aln) return;
     const AlnDesc d = descs[a];
-    const AlnOut O = outs[a];
+    const AlnOut O = outs[a];      // (an alias: its source's, k_alias_outs)
     uint32_t status = O.status;
+    // an alias (k_hap_alias, pr_api.hip) takes its sections and FP marks from the alignment it is a copy of: the same variants
+    // under the indices of that alignment's hap slots
+    int src_i = -1;
+    {
+        const int b = alias[d.sc], q = d.aln >> 1, t = d.aln & 1;
+        const int si = ((b & 1) ? 0 : q) * 2 + ((b & 2) ? 0 : t);
+        if (si != d.aln) src_i = si;
+    }
+    const AlnDesc ds = src_i >= 0 ? descs[d.sc * 4 + src_i] : d;
+    const int64_t dq = d.qv_beg - ds.qv_beg, dt = d.tv_beg - ds.tv_beg;      // variant index of the source -> this alignment's
     if (sc_limit[d.sc] || (status & VPR_ST_ERR_LIMIT)) {
         // beyond an implementation limit (include/vcfdist_pr.h): the alignment is reported as such and its variants stay
         // unevaluated (ERRTYPE_UN); the rest of the batch is not affected
@@ -1109,7 +1119,7 @@ __global__ void k_finalize(const AlnDesc *__restrict__ descs, int n_aln, const A
     const int swap = (d.aln == 1 || d.aln == 2);
     const VarCols Q = R.v[d.qs][swap], T = R.v[d.ts][swap];
     const float *qq = R.var_qual[d.qs];
-    const int32_t *fpg = fp_group[d.qs * 2 + swap];
+    const int32_t *fpg = fp_group[ds.qs * 2 + ((ds.aln == 1 || ds.aln == 2) ? 1 : 0)] - dq;      // indexed by this alignment's variants
     for (int64_t v = d.qv_beg; v < d.qv_end; v++) {   // passed on the REF plane: FP in a group of its own
         const int g = fpg[v];
         if (g >= 0) {
@@ -1119,7 +1129,8 @@ __global__ void k_finalize(const AlnDesc *__restrict__ descs, int n_aln, const A
     }
     if (!(status & (VPR_ST_ERR_NO_PTR | VPR_ST_ERR_UNFINISHED))) {
         for (int k = 0; k < O.n_sec; k++) {
-            const Section S = secs[d.sec_off + k];
+            Section S = secs[ds.sec_off + k];
+            S.q_lo += int32_t(dq); S.q_hi += int32_t(dq); S.t_lo += int32_t(dt); S.t_hi += int32_t(dt);
             int ref_ed = S.ref_ed;
             const int query_ed = S.query_ed;
             const bool has_q = S.q_hi != S.q_lo, has_t = S.t_hi != S.t_lo;
