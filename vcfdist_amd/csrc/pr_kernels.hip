@@ -752,6 +752,11 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
         }
     };
     uint32_t cur_b = 0;     // .b of path[sync_idx]
+    // PathEnt::b bits 28 / 29 (set by the zero-distance walk only, pr_zl.hip): "the reference base at the entry's reference
+    // coordinate equals its truth base" / "that bit is valid".  A one-base section below sync entry i is exactly entry i + 1's
+    // cell when every step is a diagonal one, so the comparison needs no loads.  eq_next: the bits of entry sync_idx + 1.
+    uint32_t eq_next = 0, eq_cur = 0;
+    int nx_qref = -2, nx_ti = -2;      // reference coordinate and truth row of entry sync_idx + 1
     // WAVE: the reference / truth bases the sections compare come from 64-base register chunks (lane l <-> base + l), refilled
     // when the walk leaves them -- it moves towards the front, so a chunk ends at the base asked for.  Nearly every step of a
     // long alignment is a sync point with a one-base section: two dependent global loads per step were most of this walk.
@@ -811,7 +816,9 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
             bool deferred = false;
             if (rl == 0) ref_ed = tl;
             else if (tl == 0) ref_ed = rl;
-            else if (rl == 1 && tl == 1) ref_ed = (rs_at(sync_ref_idx) != ts_at(sync_truth_idx));
+            else if (rl == 1 && tl == 1)
+                ref_ed = ((eq_next & 2u) && nx_qref == sync_ref_idx && nx_ti == sync_truth_idx) ? int(!(eq_next & 1u))
+                                                                                                : int(rs_at(sync_ref_idx) != ts_at(sync_truth_idx));
             else if (!has_q && !has_t && rl == tl) {
                 bool same = true;
                 for (int k = rl - 1; k >= 0 && same; k--) same = (rs_at(sync_ref_idx + k) == ts_at(sync_truth_idx + k));
@@ -856,9 +863,11 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
         cur_hi = prev_hi;
         const PathEnt e = fetch(sync_idx);
         cur_b = e.b;
+        eq_next = eq_cur; eq_cur = (e.b >> 28) & 3u;
+        nx_qref = prev_qref; nx_ti = prev_ti;
         prev_qri = int(e.a & 0x7fffffffu);
         prev_hi = int(e.a >> 31);
-        prev_ti = int(e.b & 0x3fffffffu);
+        prev_ti = int(e.b & 0x0fffffffu);
         prev_qref = e.qref;
         prev_tref = e.tref;
         // (dist.cpp re-reads the two variant positions here; they only change in the loops above)

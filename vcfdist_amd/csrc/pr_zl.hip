@@ -439,8 +439,14 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
             const bool in_q = hi == 0 && (cw & ZW_PV) && !(cw & ZW_PB);
             sync = (!in_t && !in_q && !((tw | cw) & ZW_INS) && trv == qref) ? 1u : 0u;
         }
+        // "the reference base at this step's reference coordinate equals its truth base": what the credit walk compares for the
+        // one-base sections between neighbouring sync points (nearly every step), from the words at hand instead of two scattered
+        // byte loads per lane and step in k_zero_credit.  On the REF plane the cell's base IS that reference base; on the QUERY
+        // plane it is wherever the hap position lies outside a variant (generate_ptrs_strs copies the reference there); inside
+        // one the bit is marked invalid and the credit walk loads the bases.
+        const uint32_t eqb = (ZW_BASE(cw) == ZW_BASE(tw) ? 1u : 0u) | ((hi || !(cw & ZW_PV)) ? 2u : 0u);
         zl_u2 st;           // the step as k_zero_credit reads it
-        st.x = uint32_t(x) | (uint32_t(hi) << 16) | (sync << 17);
+        st.x = uint32_t(x) | (uint32_t(hi) << 16) | (sync << 17) | (eqb << 18);
         st.y = uint32_t(qref + 1) | (uint32_t(trv + 1) << 16);
         __builtin_amdgcn_raw_buffer_store_b64(st, rlog, act ? logS0 + (uint32_t(t) << 9) + lane8 : ZL_OOB, 0, 0);
         if ((keep_paths & 1) && act) {       // VPR_CFG_KEEP_PATHS: also as a 16-byte path entry (vpr_download_path)
@@ -484,7 +490,7 @@ struct ZlFetch {
         if (i > 0) { pre_i = i - 1; pre = log[(i - 1) * 64]; }    // entries are read in descending order
         PathEnt e;
         e.a = (v.x & 0xffffu) | (((v.x >> 16) & 1u) << 31);
-        e.b = uint32_t(i) | (((v.x >> 17) & 1u) << 31);
+        e.b = uint32_t(i) | (((v.x >> 17) & 1u) << 31) | (((v.x >> 18) & 3u) << 28);      // bits 28, 29: see credit_walk
         e.qref = int(v.y & 0xffffu) - 1;
         e.tref = int(v.y >> 16) - 1;
         return e;
