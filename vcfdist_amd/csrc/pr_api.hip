@@ -3883,7 +3883,7 @@ int64_t vpr_download_path(const vpr_handle *h, int32_t sc, int32_t aln, int64_t 
     for (int64_t k = 0; k < n; k++) {
         plane[k] = uint8_t(p[k].a >> 31);
         qri[k] = int32_t(p[k].a & 0x7fffffffu);
-        ti[k] = int32_t(p[k].b & 0x3fffffffu);
+        ti[k] = int32_t(p[k].b & 0x0fffffffu);       // (bits 28, 29: credit_walk's base-equality bits)
         sync[k] = uint8_t(p[k].b >> 31);
         edit[k] = uint8_t((p[k].b >> 30) & 1);
     }

@@ -193,7 +193,7 @@ struct DevResults {
     double credit_threshold, phase_threshold;
 };
 
-// packed walk entry: a = qri | plane<<31,  b = ti | sync<<31 | edit<<30, plus the reference coordinates of
+// packed walk entry: a = qri | plane<<31,  b = ti (28 bits) | sync<<31 | edit<<30 | base-equality bits 28, 29 (credit_walk), plus the reference coordinates of
 // the cell (qref = qri on the REF plane, q2r[qri] on the QUERY plane; tref = t2r[ti]) so the backward credit
 // walk needs no pointer-array loads
 struct PathEnt { uint32_t a, b; int32_t qref, tref; };

@@ -675,7 +675,11 @@ __global__ void __launch_bounds__(64) k_walk_q16(DevBatch B, const AlnDesc *__re
                 const int x = lo_h + gl;
                 PathEnt pe;
                 pe.a = uint32_t(x) | (uint32_t(hi) << 31);
-                pe.b = uint32_t(t) | ((gl == el) ? ((sync_in << 31) | (edit_in << 30)) : (1u << 30));
+                // bits 28 / 29 (credit_walk, pr_kernels.hip): "the reference base here equals the truth base" / "that bit is valid" --
+                // a cell entered by MAT or SWP has the truth row's base, by SUB another one, and its base is the reference's on
+                // the REF plane and outside variants on the QUERY plane
+                const uint32_t eqb = ((mv_in & (F_MAT | F_SWP | F_SUB)) && (hi == 1 || !(ey & PV))) ? (2u | ((mv_in & F_SUB) ? 0u : 1u)) : 0u;
+                pe.b = uint32_t(t) | ((gl == el) ? ((sync_in << 31) | (edit_in << 30) | (eqb << 28)) : (1u << 30));
                 pe.qref = hi ? x : colx;
                 pe.tref = trv;
                 path[n + (gl - el)] = pe;
