@@ -126,7 +126,10 @@ def cpu_baseline(batch, target_s=15.0):
                   f"(oracle/pr_oracle.cpp, one slice per thread); value = batch alignments / sum over strata of (stratum size / measured rate)",
         "est_batch_seconds_all_threads": round(est_total, 2),
         "strata": strata,
-        "single_thread_value": round(4 * len(probe) / dt1, 1),
+        # one thread on the WHOLE mix: the strata's thread-seconds (the slices of a stratum run side by side on `threads` threads)
+        "single_thread_value": round(4 * n / (est_total * threads), 1),
+        "single_thread_note": "whole mix: batch alignments / (sum over strata of estimated seconds x threads used)",
+        "single_thread_value_most_populated_octave": round(4 * len(probe) / dt1, 1),
         "single_thread_sample": f"{len(probe)} superclusters of the most populated octave [{2 ** k_top}, {2 ** (k_top + 1)}), {dt1:.2f} s",
     }
 
@@ -287,9 +290,30 @@ def main():
                 with stdout_to_stderr():
                     if dist is not None:
                         dist.broadcast(uid_t, 0)
-                    native_comm = rccl.Comm(world, rank, bytes(uid_t.cpu().numpy().tobytes()))
-                    torch.cuda.synchronize()
-                collective = "vpr_allreduce_counts (RCCL through the C ABI, library stream)"
+                    uid_b = bytes(uid_t.cpu().numpy().tobytes())
+                    box = []
+
+                    def init_comm():        # (in a thread: a communicator that does not come up must not hang the bench)
+                        try:
+                            torch.cuda.set_device(local_rank)
+                            box.append(rccl.Comm(world, rank, uid_b))
+                        except Exception as e_:      # noqa: BLE001
+                            box.append(e_)
+                    import threading as _th
+                    th_ = _th.Thread(target=init_comm, daemon=True)
+                    th_.start()
+                    th_.join(timeout=120.0)
+                    mine_ok = bool(box) and not isinstance(box[0], Exception)
+                    if dist is not None:    # every rank or none
+                        okt = torch.tensor([1 if mine_ok else 0], device=torch.device("cuda", local_rank))
+                        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                        mine_ok = mine_ok and bool(int(okt.item()))
+                    if mine_ok:
+                        native_comm = box[0]
+                        torch.cuda.synchronize()
+                        collective = "vpr_allreduce_counts (RCCL through the C ABI, library stream)"
+                    else:
+                        sys.stderr.write(f"native RCCL communicator did not come up on every rank ({box[:1]!r}): torch.distributed collectives\n")
         except Exception as e:      # noqa: BLE001 -- the bench must not die of an optional path
             sys.stderr.write(f"native RCCL communicator not available ({e!r}): torch.distributed collectives\n")
             native_comm = None
@@ -689,6 +713,7 @@ def main():
         swept_gbs = (byt / nl) / avg_s / 1e9
         traffic = valu_frac = None
         prof_src = None
+        lds_info = None
         # SIMDs and shader clock of the device this run is on (the fallbacks are MI355X's: 256 CUs x 4 SIMDs, 2.4 GHz)
         props = torch.cuda.get_device_properties(dev)
         n_simd = 4 * int(getattr(props, "multi_processor_count", 0) or N_SIMD // 4)
@@ -704,6 +729,17 @@ def main():
                 if k.get("valu_active_per_wave") and k.get("waves"):
                     valu_frac = k["valu_active_per_wave"] * 4 * k["waves"] / (n_simd * avg_s * sclk_hz)
                 prof_src = f"profiles/{PROFILE_TAG}_counters_{args.workload}.json"
+                # LDS side: instructions per wave and the share of a wave's cycles in which it issues LDS instructions
+                lds_info = {"lds_insts_per_wave": k.get("lds_insts_per_wave"),
+                            "lds_active_frac_of_wave_cycles": (round(k["lds_active_per_wave"] / k["wave_cycles_per_wave"], 5)
+                                                               if k.get("lds_active_per_wave") is not None and k.get("wave_cycles_per_wave") else None),
+                            "other_kernels": {kn: {"lds_insts_per_wave": kv.get("lds_insts_per_wave"),
+                                                   "lds_active_frac_of_wave_cycles": round(kv["lds_active_per_wave"] / kv["wave_cycles_per_wave"], 5)}
+                                              for kn, kv in prof["kernels"].items()
+                                              if kv.get("lds_active_per_wave") and kv.get("wave_cycles_per_wave") and kv.get("lds_insts_per_wave", 0) > 100},
+                            "note": "the lane kernel keeps its state in registers and streams through HBM: LDS is not on its path; the window "
+                                    "kernels stage rows and constants in LDS and exchange cells through ds_bpermute / DPP: LDS instructions "
+                                    "issue in 1 - 3 % of a wave's cycles (SQ_ACTIVE_INST_LDS / SQ_WAVE_CYCLES), far from the LDS peak"}
         except (OSError, KeyError, ValueError):
             pass
         achieved = (traffic / avg_s / 1e9) if traffic else swept_gbs
@@ -719,6 +755,7 @@ def main():
             "dense_equivalent": {"bytes_per_launch": int(dense_bytes), "cells_per_launch": int(dense / nl),
                                  "GB/s": round(dense_gbs, 2), "frac": round(dense_gbs / HBM_PEAK_GBS, 5)},
             "counters_source": prof_src,
+            "lds": lds_info,
             "device": {"name": props.name, "simds": n_simd, "sclk_hz": sclk_hz},
             "alone": None,
             "note": "frac = HBM traffic of the dominant sweep kernel (PMC counters) / its launch duration (HIP events, this run) / "

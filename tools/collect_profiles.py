@@ -91,7 +91,9 @@ for k, c in kern.items():
                           ("SQ_INSTS_SALU", "salu_insts_per_wave"), ("SQ_INSTS_LDS", "lds_insts_per_wave"),
                           ("SQ_INSTS_VMEM_RD", "vmem_rd_per_wave"), ("SQ_INSTS_VMEM_WR", "vmem_wr_per_wave"),
                           ("SQ_ACTIVE_INST_VALU", "valu_active_per_wave"), ("SQ_ACTIVE_INST_ANY", "any_active_per_wave"),
-                          ("SQ_WAIT_INST_ANY", "wait_inst_per_wave"), ("SQ_WAIT_ANY", "wait_any_per_wave")):
+                          ("SQ_WAIT_INST_ANY", "wait_inst_per_wave"), ("SQ_WAIT_ANY", "wait_any_per_wave"),
+                          ("SQ_ACTIVE_INST_LDS", "lds_active_per_wave"), ("SQ_WAIT_INST_LDS", "lds_wait_per_wave"),
+                          ("SQ_ACTIVE_INST_SCA", "salu_active_per_wave")):
             if name in c:
                 e[key] = round(c[name] / waves, 1)
     kept[k] = e
