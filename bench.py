@@ -602,7 +602,7 @@ def main():
             tb = time.perf_counter()
             S.pr.execute()
             tc = time.perf_counter()
-            S.host_res = S.pr.download(None)        # (the result block of the previous upload went with it)
+            S.host_res = S.pr.download(S.host_res)  # (the page-locked block of the first batch: same shape, same column offsets)
             summary.pr_counts(S.pr, None, None)
             with lock:
                 op_parts[0] += tb - ta; op_parts[1] += tc - tb; op_parts[2] += time.perf_counter() - tc

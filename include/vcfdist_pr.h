@@ -260,8 +260,10 @@ int vpr_download(vpr_handle *h, vpr_results *res);              /* HBM -> host (
 /* Result buffers in ONE page-locked block laid out like the device's result columns of the uploaded batch: sets every
    pointer of *res into the block and returns the block (release it with vpr_host_free).  vpr_download into such a
    vpr_results is a single copy (178 MB per million superclusters: 3.4 ms instead of 3.9 ms for 55 copies).  The block
-   belongs to the caller and stays valid after the next vpr_upload; it then simply no longer matches, and vpr_download
-   copies column by column as for any other buffers. */
+   belongs to the caller and stays valid after the next vpr_upload: for a batch of the same shape (same numbers of superclusters
+   and of variants per hap slot -- the columns lie at the same offsets) vpr_download still takes the single copy; for any
+   other batch the pointers no longer match the layout and it copies column by column as for any other buffers (which then
+   have to be large enough for that batch). */
 int vpr_results_alloc(vpr_handle *h, vpr_results *res, void **block);
 void *vpr_host_alloc(size_t bytes);
 void  vpr_host_free(void *p);

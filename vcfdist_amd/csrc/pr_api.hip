@@ -3531,9 +3531,15 @@ int vpr_download(vpr_handle *h, vpr_results *res) {
     auto get = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
         return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
     };
-    if (h->res_mirror && h->res_bytes) {       // a block of vpr_results_alloc: one copy when every pointer is the mirror's
+    // A block of vpr_results_alloc -- of this upload, or of an earlier upload of a batch of the same shape (a caller that streams
+    // batches of one size keeps its block: the columns lie at the same offsets) -- takes ONE copy: every pointer of *res has to
+    // sit where the device's column sits in the result region.
+    uint8_t *mirror = h->res_mirror;
+    if (!mirror && h->res_bytes && na && res->aln_dist)
+        mirror = reinterpret_cast<uint8_t *>(res->aln_dist) - (reinterpret_cast<const uint8_t *>(R.aln_dist) - h->res_dev);
+    if (mirror && h->res_bytes) {
         auto at = [&](const void *dst, const void *src) {
-            return static_cast<const uint8_t *>(dst) - h->res_mirror == static_cast<const uint8_t *>(src) - h->res_dev;
+            return static_cast<const uint8_t *>(dst) - mirror == static_cast<const uint8_t *>(src) - h->res_dev;
         };
         bool all = at(res->aln_dist, R.aln_dist) && at(res->aln_end_plane, R.aln_end_plane) && at(res->aln_beg_plane, R.aln_beg_plane) &&
                    at(res->aln_status, R.aln_status) && at(res->sc_phase, R.sc_phase) && at(res->orig_phase_dist, R.orig_phase_dist) &&
@@ -3546,7 +3552,7 @@ int vpr_download(vpr_handle *h, vpr_results *res) {
                       at(res->credit[s][w], R.v[s][w].credit) && at(res->ref_ed[s][w], R.v[s][w].ref_ed) &&
                       at(res->query_ed[s][w], R.v[s][w].query_ed) && at(res->callq[s][w], R.v[s][w].callq)));
         if (all) {
-            HIPCHK(h, get(h->res_mirror, h->res_dev, h->res_bytes));
+            HIPCHK(h, get(mirror, h->res_dev, h->res_bytes));
             HIPCHK(h, x_sync(h, st, SITE));
             return VPR_OK;
         }
