@@ -192,9 +192,9 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
         e0.y = ZE_ALIVE | ZE_HASMAT | (zw_bwd_allow(pw[1][0]) ? ZE_BWD : 0u);
         __builtin_amdgcn_raw_buffer_store_b64(e0, rlog, lane8, 0, 0);
     }
-    // One row step over the first S slots of each plane (S = 1: every lane of the wave has one diagonal per plane -- most rows;
-    // S = 2: none has a third; S = 4 otherwise).  Returns false when S slots were not enough (a SWP child found the first S
-    // slots of its plane taken): nothing has been committed then and the caller repeats the row with the next size.
+    // One row step over the first S slots of each plane (S = 2: no lane of the wave has a third diagonal -- nearly every
+    // row; S = 4 otherwise).  Returns false when S = 2 was not enough (a SWP child found both slots of its plane taken):
+    // nothing has been committed then and the caller repeats the row with S = 4.
     // Software pipeline of the two-slot path: the children's words of the cells of row t + 1 -- what the NEXT row step compares --
     // are requested as soon as those cells are known, in the middle of this row step, and the rest of the step (the log entries,
     // their store, the loop) runs while they are on their way.  pf_*: the words requested by the previous two-slot step for
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
         // children's position words: MAT child x + 1 of the own plane, SWP child ptr + 1 of the other plane
         uint32_t mw[2][S], sw[2][S];
         int sz[2][S];
-        const bool use_pf = S <= 2 && have_pf;
+        const bool use_pf = S == 2 && have_pf;
 #pragma unroll
         for (int p = 0; p < 2; p++) {
 #pragma unroll
@@ -268,11 +268,11 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
         }
         if (S < 4 && __any(full)) return false;
         ok = ok && !bad && !full;
-        if (S <= 2) {       // the next step's words (see pf_*; after a one-slot step the second slots are empty: their words are not looked at)
+        if (S == 2) {       // the next step's words (see pf_*)
 #pragma unroll
             for (int p = 0; p < 2; p++) {
 #pragma unroll
-                for (int s = 0; s < S; s++) {
+                for (int s = 0; s < 2; s++) {
                     const bool alive = act && ok && nq[p][s] >= 0;
                     const int c = nq[p][s] + 1;
                     const int z = ZW_PTR(nw[p][s]) + 1;
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
                 }
             }
         }
-        have_pf = S <= 2;
+        have_pf = S == 2;
         // the row's log entries
         {
             zl_u2 ev;
@@ -305,16 +305,10 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
     for (int t = 0; t + 1 < tmax; t++) {
         const bool act = ok && t + 1 < rows;
         const uint32_t tw1 = in_at(act ? post + (uint32_t(t + 1) << 8) + lane4 : ZL_OOB);
-        bool upper = false, second = false;
+        bool upper = false;
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
-            upper = upper || (act && (qri[p][2] >= 0 || qri[p][3] >= 0));
-            second = second || (act && qri[p][1] >= 0);
-        }
-        // one diagonal per plane in every lane (outside repeats: nearly every row) -> the one-slot step, half the work
-        if (__any(upper)) (void)fwd_row(std::integral_constant<int, 4>{}, t, act, tw1);
-        else if ((__any(second) || !fwd_row(std::integral_constant<int, 1>{}, t, act, tw1)) &&
-                 !fwd_row(std::integral_constant<int, 2>{}, t, act, tw1))
+        for (int p = 0; p < 2; p++) upper = upper || (act && (qri[p][2] >= 0 || qri[p][3] >= 0));
+        if (__any(upper) || !fwd_row(std::integral_constant<int, 2>{}, t, act, tw1))
             (void)fwd_row(std::integral_constant<int, 4>{}, t, act, tw1);
     }
     // end cells (dist.cpp:390-391, 436-439: the QUERY plane is preferred)
@@ -421,10 +415,9 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
         }
         const zl_u2 pre = log_row(t - 1, act);
         // upper slots in use in either row (by any lane)?
-        const uint32_t used = act ? (cur.x | cur.y | pre.x | pre.y) : 0u;
-        if (__any((used & 0xffff0000u) != 0u)) bwd_row(std::integral_constant<int, 4>{}, t, act, pre);
-        else if (__any((used & 0x0000ff00u) != 0u)) bwd_row(std::integral_constant<int, 2>{}, t, act, pre);
-        else bwd_row(std::integral_constant<int, 1>{}, t, act, pre);
+        const bool upper = act && (((cur.x | cur.y | pre.x | pre.y) & 0xffff0000u) != 0u);
+        if (__any(upper)) bwd_row(std::integral_constant<int, 4>{}, t, act, pre);
+        else bwd_row(std::integral_constant<int, 2>{}, t, act, pre);
     }
     // (QUERY, 0, 0) on a path to the end?  dist.cpp:811-814
     const int beg_plane = sc[0][0] >= 0 ? VPR_PLANE_QUERY : VPR_PLANE_REF;
