@@ -312,6 +312,9 @@ struct vpr_handle {
     bool no_strips = false;              // VPR_NO_STRIPS in the environment: wide alignments stay in one workgroup
     bool seq_fwd = true;                 // unless VPR_PAR_FWD is in the environment: the sequential forward sweep of the 64-cell level; the
                                          // block-parallel one (pr_fwdpar.hip) is exact but only pays where its runs meet: not inside long tandem repeats
+    uint8_t *d_save = nullptr;           // second copy of the forward flags of round 0's long part (k_fwd_stripe_save), nullptr: none
+    int64_t save_bytes = 0;
+    bool no_flag_save = false;           // VPR_NO_FLAG_SAVE: tie rounds of the long part repeat the forward sweep
     bool alt_tie = false;                // VPR_ALT_TIE: ladder-born tie rounds on the tie ladder's side stream while its main stream is busy
     bool seq_walk = false;               // VPR_SEQ_WALK: the sequential row-sweep walk instead of the segment-parallel one
     bool no_round_overlap = false;       // VPR_NO_ROUND_OVERLAP: a retry round is complete before the host looks at its fail lists
@@ -436,12 +439,19 @@ inline void slow_call(vpr_handle *h, const char *what, const char *site, size_t 
     if (h && h->stall_log && dt > 5.0) fprintf(stderr, "[vpr] slow host call: %s (%zu bytes) at %s: %.1f ms\n", what, bytes, site, dt);
 }
 // every allocator call and blocking wait of the library goes through these: counted and timed per execute
+static int poison_byte() {
+    static const int v = [] { const char *e = getenv("VPR_POISON"); return e ? int(strtol(e, nullptr, 0)) & 0xff : -1; }();
+    return v;
+}
 hipError_t x_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
     const double t = wall_ms();
     const hipError_t e = hipMalloc(q, bytes);
     const double dt = wall_ms() - t;
     if (h) { h->hs.n_dev_alloc++; h->hs.ms_alloc += dt; }
     slow_call(h, "hipMalloc", site, bytes, dt);
+    // debugging aid (VPR_POISON=<byte>): new device memory holds that byte instead of whatever the driver left there, so that
+    // a read of something never written shows up the same way in every run
+    if (e == hipSuccess && poison_byte() >= 0) { (void)hipMemset(*q, poison_byte(), bytes); (void)hipDeviceSynchronize(); }
     return e;
 }
 hipError_t x_free(vpr_handle *h, void *q, const char *site) {
@@ -458,6 +468,7 @@ hipError_t x_host_malloc(vpr_handle *h, void **q, size_t bytes, const char *site
     const double dt = wall_ms() - t;
     if (h) { h->hs.n_pin_alloc++; h->hs.ms_alloc += dt; }
     slow_call(h, "hipHostMalloc", site, bytes, dt);
+    if (e == hipSuccess && poison_byte() >= 0) memset(*q, poison_byte(), bytes);
     return e;
 }
 hipError_t x_sync(vpr_handle *h, hipStream_t s_, const char *site) {
@@ -493,6 +504,7 @@ void *dev_block(vpr_handle *h, size_t bytes, hipError_t *err) {
     if (best >= 0) {
         q = h->dev_cache[size_t(best)].p; got = h->dev_cache[size_t(best)].bytes;
         h->dev_cache.erase(h->dev_cache.begin() + best);
+        if (poison_byte() >= 0) { (void)hipMemset(q, poison_byte(), got); (void)hipDeviceSynchronize(); }
     } else {
         *err = x_malloc(h, &q, bytes, SITE);
         if (*err != hipSuccess) {        // out of memory with blocks kept aside: release them and try once more
@@ -518,6 +530,7 @@ int pin_alloc(vpr_handle *h, void **out, size_t bytes) {
     }
     if (best >= 0) {
         *out = h->pin_cache[size_t(best)].p;
+        if (poison_byte() >= 0) memset(*out, poison_byte(), h->pin_cache[size_t(best)].bytes);
         h->pinned_blk.push_back(h->pin_cache[size_t(best)]);
         h->pin_cache.erase(h->pin_cache.begin() + best);
         return VPR_OK;
@@ -1303,6 +1316,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->stall_log = getenv("VPR_STALL_LOG") != nullptr;
     h->seq_walk = getenv("VPR_SEQ_WALK") != nullptr;
     h->alt_tie = getenv("VPR_ALT_TIE") != nullptr;
+    h->no_flag_save = getenv("VPR_NO_FLAG_SAVE") != nullptr;
     h->seq_fwd = getenv("VPR_PAR_FWD") == nullptr;
     memset(&h->dB, 0, sizeof(h->dB));
     memset(&h->timing, 0, sizeof(h->timing));
@@ -1740,6 +1754,21 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
                     : h->cfg.band_mode == 3 ? LV_Q16 : LV_Z;
     if ((rc = make_plan(h, all, lv0, h->plan0, h->d_arena, h->arena_bytes, 0, true))) return rc;
     lap("make_plan");
+    // the long part's forward flags are kept a second time (tie rounds copy them back instead of repeating the sweep:
+    // k_fwd_stripe_save / k_restore_stripe): a region as large as the part's share of the workspace -- the front of every
+    // chunk -- unless that is more than 1 GB (a batch of tens of thousands of long alignments is a throughput problem, not a
+    // latency chain)
+    h->d_save = nullptr; h->save_bytes = 0;
+    if (lv0 <= LV_Q16 && LONG_LV == LV_C1 && !h->no_flag_save && !h->plan0.off128.empty()) {
+        int64_t need = 0;
+        for (const Chunk &ch : h->plan0.chunks)
+            if (ch.n_long > 0)
+                need = std::max<int64_t>(need, ch.n_long < ch.count ? int64_t(h->plan0.off128[size_t(ch.work_off + ch.n_long)]) * 128 : h->plan0.arena_used);
+        if (need > 0 && need <= (int64_t(1) << 30)) {
+            if ((rc = dev_alloc(h, &h->d_save, size_t(need) + 256))) return rc;
+            h->save_bytes = need;
+        }
+    }
     h->level0 = h->level;
     h->plan0_pos.assign(na, -1);
     par_for(np, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) h->plan0_pos[size_t(h->plan0.work[k])] = int32_t(k); });
@@ -1865,6 +1894,8 @@ struct Exec {
     int64_t tie_dec_cur = 0;
     struct TieEarly { int32_t n_used; int32_t pos; const Plan *plan; int mode; };   // mode 1 / 2: TieJob::mode; 3: decided speculatively
     std::unordered_map<int32_t, TieEarly> tie_early;   // alignment -> where the bytes of its marking round are
+    const Chunk *tie_resident = nullptr;               // the chunk of plan 0 a tie round's early entries lie in (tie_round)
+    int64_t fwd_save_delta = 0;                        // != 0: the next 64-cell forward sweep also writes its flags that far behind (round 0's long part)
     std::unordered_map<int32_t, int32_t> tie_s;        // alignment -> its distance (from the tie lists): bounds the stamp grids
     int tie_patch_slot = -1; int64_t tie_patch_off = 0, tie_patch_cap = 0;   // decision list of the last early launch
     bool tie_patch_spec = false;                   // the part has alignments whose decisions are in the speculative list
@@ -2427,7 +2458,26 @@ struct Exec {
             FT.endc = reinterpret_cast<int4 *>(u);
             HIPCHK(h, hipMemsetAsync(FT.counter, 0, 32, ks));
         }
-        rc = timed(1, ls, ks, fwdp ? "k_fwd_par" : band_fwd_name(lv), [&] {
+        // round 0's long part: the flags a second time; a tie round whose alignments all have such a copy: the copy instead of the sweep
+        const bool save = lv == LV_C1 && !fwdp && !tag_or && fwd_save_delta != 0;
+        RestoreJob *rjobs = nullptr;
+        bool restore = false;
+        if (lv == LV_C1 && !fwdp && tag_or && h->d_save && tie_resident && !n_dev) {
+            void *pb = nullptr;
+            { int rc_pin = exec_pin(h, &pb, size_t(cnt) * sizeof(RestoreJob)); if (rc_pin) return rc_pin; }
+            rjobs = static_cast<RestoreJob *>(pb);
+            restore = true;
+            for (int32_t k = 0; k < cnt && restore; k++) {
+                const auto it = tie_early.find(P.work[size_t(off) + size_t(k)]);
+                if (it == tie_early.end() || it->second.plan != &h->plan0 || (it->second.mode != 1 && it->second.mode != 3) ||
+                    it->second.pos < tie_resident->work_off || it->second.pos >= tie_resident->work_off + tie_resident->n_long) { restore = false; break; }
+                const AlnDesc od = plan_desc(h, h->plan0, size_t(it->second.pos)), nd = plan_desc(h, P, size_t(off) + size_t(k));
+                if (od.band_pad != LV_TAG[LV_C1] || od.pitch[0] != nd.pitch[0] || od.pitch[1] != nd.pitch[1] ||
+                    od.mat_off[1] + int64_t(od.pitch[1]) * od.Lt > h->save_bytes) { restore = false; break; }
+                rjobs[k] = RestoreJob{{od.mat_off[0], od.mat_off[1]}, od.blo_off};
+            }
+        }
+        rc = timed(1, ls, ks, fwdp ? "k_fwd_par" : restore ? "k_restore_stripe" : band_fwd_name(lv), [&] {
             if (fwdp) {
                 hipLaunchKernelGGL(k_fwdp_plan, blocks(cnt), dim3(256), 0, ks, h->d_descs, list, cnt, FT);
                 hipLaunchKernelGGL(k_fwdp_block<1>, dim3(FT.cap_blocks), dim3(64), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs, FT);
@@ -2442,6 +2492,12 @@ struct Exec {
             else if (q16)
                 hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);
+            else if (restore)
+                hipLaunchKernelGGL(k_restore_stripe, dim3(cnt), dim3(256), 0, ks, h->d_descs, list, rjobs, h->plan0.arena,
+                                   int64_t(reinterpret_cast<intptr_t>(h->d_save) - reinterpret_cast<intptr_t>(h->plan0.arena)), P.arena, a_i32);
+            else if (save)
+                hipLaunchKernelGGL(k_fwd_stripe_save, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs,
+                                   fwd_save_delta);
             else
                 hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3(lv >= LV_C4 ? W : 64), 0,
                                    ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs);
@@ -2837,6 +2893,7 @@ struct Exec {
     // accepted where plan0 placed it (also by the in-place 16-cell round) is replayed early, from that workspace.
     int tie_round(LadderCtx &LT, const int4 *lst_in, int32_t n, bool full, const Chunk *resident) {
         tie_ctx = &LT;
+        tie_resident = full ? nullptr : resident;
         std::vector<int4> lst(lst_in, lst_in + n);
         std::sort(lst.begin(), lst.end(), [](const int4 &x, const int4 &y) { return x.x < y.x; });   // deterministic planning
         std::vector<int32_t> marked, carry;
@@ -3010,8 +3067,11 @@ struct Exec {
             if (n_long > 0) {
                 const int lv = P0.lv <= LV_Q16 ? LONG_LV : P0.lv;
                 for (int ph = 1; ph <= 4; ph <<= 1) {
-                    if ((rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0],
-                                           ch.part_in[0], ch.part_dense[0], -1, ph))) return rc;
+                    fwd_save_delta = (ph == 1 && lv == LV_C1 && h->d_save) ? int64_t(reinterpret_cast<intptr_t>(h->d_save) - reinterpret_cast<intptr_t>(P0.arena)) : 0;
+                    rc = enqueue_part(P0, P0.d_work, ch.work_off, n_long, lv, s_long, 0, 0, true, ch.part_cells[0],
+                                      ch.part_in[0], ch.part_dense[0], -1, ph);
+                    fwd_save_delta = 0;
+                    if (rc) return rc;
                     if (ph == 1) {
                         post_flag(0, s_long);
                         if (lv == LV_C1) {

@@ -357,7 +357,8 @@ struct FwdParOut {
 template <int MODE>
 __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDesc &d, const int a, uint8_t *__restrict__ ws,
                                                  int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs,
-                                                 const int s_begin, const int s_end, const FwdParOut FP) {
+                                                 const int s_begin, const int s_end, const FwdParOut FP,
+                                                 const int64_t save_delta = 0) {
     const int lane = threadIdx.x;
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int Lp[2] = {Lq, Lr};
@@ -382,8 +383,11 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
         const int ta = s_ * FS_K, nr = min(FS_K, Lt - ta);
 #pragma unroll
         for (int p = 0; p < 2; p++)
-            if (lane * 16 < nr * d.pitch[p])
+            if (lane * 16 < nr * d.pitch[p]) {
                 lds_to_global16(&fbuf2[s_ & 1][p][lane * 16], mat[p] + size_t(ta) * d.pitch[p] + lane * 16);
+                // (k_fwd_stripe_save: a second copy the backward sweep does not overwrite, for k_restore_stripe)
+                if (save_delta) lds_to_global16(&fbuf2[s_ & 1][p][lane * 16], mat[p] + save_delta + size_t(ta) * d.pitch[p] + lane * 16);
+            }
     };
 
     // stripe origins, 64 stripes per register chunk (lane l <-> stripe c0 + l); next chunk prefetched
@@ -670,6 +674,43 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
     fwd_stripe_range<0>(B, d, a, ws, blo_all, outs, 0, (d.Lt + FS_K - 1) / FS_K, FwdParOut{nullptr, nullptr, nullptr, nullptr});
+}
+// The forward sweep of round 0's long part: the flag bytes are also written save_delta bytes further on (a region as large as
+// the part's workspace).  The backward sweep replaces the flags by path_ptr bytes in place, and a tie round needs the flags again
+// (it patches the decided cells and repeats the backward sweep): instead of repeating this sweep -- a chain of up to 9 288
+// sequential rows, 3.3 ms on the lone step's critical path -- it copies them back (k_restore_stripe).
+__global__ void __launch_bounds__(64) k_fwd_stripe_save(DevBatch B, const AlnDesc *__restrict__ descs,
+                                                        const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
+                                                        int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs, int64_t save_delta) {
+    __builtin_amdgcn_s_setprio(2);
+    const int a = work[blockIdx.x];
+    const AlnDesc d = descs[a];
+    fwd_stripe_range<0>(B, d, a, ws, blo_all, outs, 0, (d.Lt + FS_K - 1) / FS_K, FwdParOut{nullptr, nullptr, nullptr, nullptr}, save_delta);
+}
+// where round 0 left an alignment's forward flags (the saved copy) and stripe origins, relative to its workspace
+struct RestoreJob {
+    int64_t old_mat[2];     // byte offsets of the two planes' flag rows in round 0's workspace
+    int64_t old_blo;        // int32 offset of the stripe origins there
+};
+// one workgroup per alignment of a tie round's list: the saved flags and the origins into the round's own workspace (the
+// descriptor the round staged); dist_q / dist_r / exit_min / path_len of AlnOut are still the forward sweep's
+__global__ void __launch_bounds__(256) k_restore_stripe(const AlnDesc *__restrict__ descs, const int32_t *__restrict__ work,
+                                                        const RestoreJob *__restrict__ jobs, const uint8_t *__restrict__ old_ws,
+                                                        int64_t save_delta, uint8_t *__restrict__ ws, int32_t *__restrict__ blo_all) {
+    const int a = work[blockIdx.x];
+    const AlnDesc d = descs[a];
+    const RestoreJob J = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int64_t n16 = int64_t(d.Lt) * d.pitch[p] / 16;        // (pitch: a multiple of 16; both layouts start 16-byte aligned)
+        const uint4 *src = reinterpret_cast<const uint4 *>(old_ws + save_delta + J.old_mat[p]);
+        uint4 *dst = reinterpret_cast<uint4 *>(ws + d.mat_off[p]);
+        for (int64_t k = tid; k < n16; k += 256) dst[k] = src[k];
+    }
+    const int32_t *bs = reinterpret_cast<const int32_t *>(old_ws) + J.old_blo;
+    int32_t *bd = blo_all + d.blo_off;
+    for (int k = tid; k < 2 * d.Lt; k += 256) bd[k] = bs[k];
 }
 // the fallback of the block-parallel sweep (k_fwdp_finish, pr_fwdpar.hip): only the launch positions whose flag is set
 __global__ void __launch_bounds__(64) k_fwd_stripe_only(DevBatch B, const AlnDesc *__restrict__ descs,

@@ -787,7 +787,62 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
         }
     };
 
+    // WAVE: runs of PLAIN entries are passed in one step.  An entry is plain when it is a sync point without an edit, lies one
+    // diagonal step below its upper neighbour, the reference base and the truth base of the one-base section between the two
+    // are equal, and neither variant pointer moves at it: its iteration then changes nothing but the last sync point (no
+    // section, no warning, query_ed stays 0) -- provided the entry above was itself a sync point without an edit (`clean`).
+    // Nearly every row of a long alignment is such an entry; the chain of dependent scalar steps per row was this walk.
+    // pl_static: per lane (entry cbase + lane of the register chunk), everything but the pointer tests; the top entry of a
+    // chunk and the path's last entry (their upper neighbour is not in the chunk) always take the scalar iteration.
+    bool clean = false;
+    int64_t pl_base = -1;
+    bool pl_static = false;
+    auto plain_static = [&]() {
+        const int qr = ccur.qref, ti = int(ccur.b & 0x0fffffffu);
+        const bool have = cbase + lane_ < n;
+        const bool eqb = have && qr >= 0 && qr < r_size && ti < t_size && Rs[qr] == Ts[ti];
+        const int qr_up = __shfl_down(qr, 1), ti_up = __shfl_down(ti, 1);
+        const bool eq_up = __shfl_down(int(eqb), 1) != 0;
+        pl_static = have && lane_ < 63 && cbase + lane_ + 1 < n && (ccur.b >> 31) && !((ccur.b >> 30) & 1u) &&
+                    qr_up == qr + 1 && ti_up == ti + 1 && eq_up;
+        pl_base = cbase;
+    };
     while (sync_idx >= 0) {
+        if constexpr (WAVE && !EXT) {
+            if (clean && sync_idx < n) {      // (uniform)
+                if (pl_base != cbase) plain_static();
+                const int l = int(sync_idx - cbase);
+                const bool plain = pl_static && ccur.qref >= query_var_pos && ccur.tref >= truth_var_pos;
+                // the run of plain entries from lane l downwards
+                const unsigned long long below = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
+                const unsigned long long stop = ~__ballot(plain) & below;
+                const int run = stop ? l - (63 - __builtin_clzll(stop)) : l + 1;
+                if (run > 0) {
+                    const int lj = l - run + 1;      // the run's last entry: afterwards as if it had just been processed
+                    prev_qref = __builtin_amdgcn_readlane(ccur.qref, lj);
+                    prev_tref = __builtin_amdgcn_readlane(ccur.tref, lj);
+                    cur_b = uint32_t(__builtin_amdgcn_readlane(int(ccur.b), lj));
+                    prev_hi = int(uint32_t(__builtin_amdgcn_readlane(int(ccur.a), lj)) >> 31);
+                    prev_ti = int(cur_b & 0x0fffffffu);
+                    prev_sync_ref_idx = prev_qref + 1;
+                    prev_sync_truth_idx = prev_ti + 1;
+                    eq_cur = (cur_b >> 28) & 3u;
+                    sync_idx -= run;
+                    if (sync_idx < 0) break;
+                    cur_hi = prev_hi;
+                    const PathEnt e = fetch(sync_idx);
+                    cur_b = e.b;
+                    eq_next = eq_cur; eq_cur = (e.b >> 28) & 3u;
+                    nx_qref = prev_qref; nx_ti = prev_ti;
+                    prev_qri = int(e.a & 0x7fffffffu);
+                    prev_hi = int(e.a >> 31);
+                    prev_ti = int(e.b & 0x0fffffffu);
+                    prev_qref = e.qref;
+                    prev_tref = e.tref;
+                    continue;
+                }
+            }
+        }
         const int query_ref_pos = prev_qref;
         while (query_ref_pos < query_var_pos && query_var_ptr >= d.qv_beg) {
             if (cur_hi == ri) {   // FP: passed on the REF plane, dist.cpp:1157-1168
@@ -858,6 +913,7 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
             query_ed = 0;
         }
         query_ed += is_edit;
+        clean = is_sync && !is_edit;
         sync_idx--;
         if (sync_idx < 0) break;
         cur_hi = prev_hi;
