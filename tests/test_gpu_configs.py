@@ -271,6 +271,25 @@ def test_parallel_sweep_and_walk_switches_equal_the_oracle(monkeypatch):
         assert not got.diff(other), var
 
 
+def test_long_part_threshold_leaves_the_results_unchanged(monkeypatch):
+    """alignments of LONG_LT (1 024) truth rows or more start at the 64-cell level with a wavefront each, the shorter ones at the
+    lane level; VPR_LONG_LT moves the border (diagnostic).  A batch with alignments on both sides of every border: the oracle's
+    arrays at the default, the same arrays at 256 and at 2 048 (round 3's border)."""
+    batch = api.Synth(n_sc=96, len_mode=0, len_a=150.0, len_b=2600.0, len_min=150, len_max=2600, seed=1024, p_repeat=0.2).batch()
+    got, want, _, pr = compare(batch, A.default_config(band_mode=1))
+    lt = np.diff(np.asarray(batch.hap_off[2][:97]))
+    assert (lt < 256).any() and ((lt >= 256) & (lt < 1024)).any() and ((lt >= 1024) & (lt < 2048)).any() and (lt >= 2048).any()
+    units = {}
+    for v in ("256", "2048"):
+        monkeypatch.setenv("VPR_LONG_LT", v)
+        pr2 = api.PrecisionRecall(A.default_config(band_mode=1))
+        other = pr2.run(batch)
+        monkeypatch.delenv("VPR_LONG_LT")
+        units[v] = max(s_.n_units for s_ in pr2.launch_stats() if s_.kernel.decode() == "k_zero_lane")
+        assert not got.diff(other), v
+    assert units["256"] < units["2048"]          # (the border really moved)
+
+
 def test_repeated_executes_of_one_batch_are_identical():
     """the planner's host loop serves fail lists and tie lists in the order the device raises them, so the launch order differs
     from execute to execute: every result array has to come out the same each time (60 executes of a batch with every level,

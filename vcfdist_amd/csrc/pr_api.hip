@@ -68,7 +68,7 @@ const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnD
 // (Sending long alignments through the lane kernel and the 16-cell round first was measured on the SV and stress
 // workloads: no gain on the first -- what reaches the dense level there has s > 0 -- and 8x slower on the second, whose
 // rejects then climb the ladder in dozens of workspace-sized rounds.)
-const int LONG_LT = 2048;
+const int LONG_LT = 1024;      // (2048 until round 4: the lane kernels' launches lasted as long as their longest waves, 2 047 rows of three dependent passes)
 const int LONG_LV = 2;    // LV_C1
 const int32_t CREDIT_WAVE_MAX = 16384;                // alignments of a launch up to which the credit walk takes a wavefront each
 const int64_t WSEG_MAX_ROWS = int64_t(4) << 20;      // truth rows of a launch up to which its walk runs over segments (pr_walkseg.hip)
@@ -1318,6 +1318,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->alt_tie = getenv("VPR_ALT_TIE") != nullptr;
     h->no_flag_save = getenv("VPR_NO_FLAG_SAVE") != nullptr;
     h->seq_fwd = getenv("VPR_PAR_FWD") == nullptr;
+    if (const char *e = getenv("VPR_LONG_LT")) { const int v = atoi(e); if (v >= 64 && v <= 2048) h->long_lt = v; }     // diagnostic
     memset(&h->dB, 0, sizeof(h->dB));
     memset(&h->timing, 0, sizeof(h->timing));
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
