@@ -2234,7 +2234,7 @@ struct Exec {
         G.d_n = reinterpret_cast<int32_t *>(u); u += size_t(cnt) * 4;
         G.d_ok = reinterpret_cast<int32_t *>(u); u += size_t(cnt) * 4;
         uint8_t *d_fits = u;
-        if ((rc = exec_alloc(h, &q, size_t(slots) * 8))) return rc;
+        if ((rc = exec_alloc(h, &q, size_t(slots) * 8 + 8))) return rc;       // (+ the forward sweep's ticket counter)
         G.d_prog = static_cast<int32_t *>(q);
         if ((rc = exec_alloc(h, &q, size_t(rows) * sizeof(int4)))) return rc;      // (the forward columns first, then reused by the backward sweep)
         G.d_bnd = static_cast<int2 *>(q);
@@ -2242,7 +2242,7 @@ struct Exec {
         HIPCHK(h, hipMemcpyAsync(G.d_boff, h_boff, size_t(cnt) * 8, hipMemcpyHostToDevice, ks));
         HIPCHK(h, hipMemcpyAsync(G.d_base, h_base, size_t(cnt + 1) * 4, hipMemcpyHostToDevice, ks));
         HIPCHK(h, hipMemcpyAsync(d_fits, h_fits, size_t(cnt), hipMemcpyHostToDevice, ks));
-        HIPCHK(h, hipMemsetAsync(G.d_prog, 0, size_t(slots) * 8, ks));
+        HIPCHK(h, hipMemsetAsync(G.d_prog, 0, size_t(slots) * 8 + 8, ks));
         hipLaunchKernelGGL(k_strip_plan, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, d_work + off, cnt, G.d_base, G.d_tab,
                            G.d_n, G.d_ok, d_fits, h->d_err, h->d_outs);
         return VPR_OK;

@@ -13,8 +13,8 @@
 //     whose value is given -- and everything else (diagonal move, INS chain, swap sources, the backward max-plus chain)
 //     is the single-workgroup code unchanged;
 //   * a strip publishes its boundary column in blocks of 64 rows (values staged in LDS, one coalesced store, a release
-//     of its progress counter); the consumer acquires the counter once per 64 rows.  Workgroups are dispatched in
-//     blockIdx order and a strip only ever waits for a strip with a smaller blockIdx, so the wait cannot deadlock.
+//     of its progress counter); the consumer acquires the counter once per 64 rows.  A workgroup's strip is a ticket
+//     drawn at entry and a strip only ever waits for the ticket before its own, so the wait cannot deadlock.
 // Flag matrices, results and everything downstream (walk, credit) are those of k_fwd / k_bwd (pr_kernels.hip): dist.cpp
 // :251-443 (forward), :486-823 (backward).
 #ifndef PR_STRIP_HIP_
@@ -90,13 +90,20 @@ __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *
                                                      int2 *__restrict__ bnd, int32_t *__restrict__ prog, uint8_t *__restrict__ ws,
                                                      AlnOut *__restrict__ outs, int use_ub) {
     constexpr int NT = ST_NT, C = ST_C, NC = NT * C;
+    // The strip slot is a TICKET drawn at entry (a counter behind the two progress arrays, zeroed with them), not blockIdx: a
+    // strip waits for the slot before its own, and that ticket has been drawn by a workgroup that is already running -- the
+    // wait cannot deadlock whatever order the workgroups are dispatched in and however many fit on the device at once.
+    __shared__ int s_slot;
+    if (threadIdx.x == 0) s_slot = atomicAdd(prog + 2 * int(gridDim.x), 1);
+    __syncthreads();
+    const int slot = s_slot;
     int i;
     {
         int lo = 0, hi = n;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tab_base[mid] <= int(blockIdx.x)) lo = mid; else hi = mid; }
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tab_base[mid] <= slot) lo = mid; else hi = mid; }
         i = lo;
     }
-    const int j = int(blockIdx.x) - tab_base[i], ns = n_strips[i];
+    const int j = slot - tab_base[i], ns = n_strips[i];
     if (j >= ns) return;
     const int a = work[i];
     const AlnDesc d = descs[a];
