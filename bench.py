@@ -446,6 +446,9 @@ def main():
 
     acct_s = [0.0]
 
+    units_acc = {}          # alignments in the main launches of a kernel over the timed steps, summed like stats_acc
+    stats_main = stats_acc
+
     def account(S, stats_acc=stats_acc, kern_ms=kern_ms, host_acc=host_acc):
         t_acc = time.perf_counter()
         try:
@@ -473,6 +476,8 @@ def main():
             a = stats_acc.setdefault(k, [0, 0.0, 0, 0, 0, 0, 0.0])
             if main:
                 a[0] += 1; a[1] += s_.ms; a[2] += s_.bytes_algorithmic; a[3] += s_.cells; a[4] += s_.cells_dense
+                if stats_acc is stats_main:
+                    units_acc[k] = units_acc.get(k, 0) + s_.n_units
             else:
                 a[5] += 1; a[6] += s_.ms
 
@@ -698,8 +703,14 @@ def main():
         tm = tm_main
         # dominant K1/K2 kernel (the DP sweeps the byte model of SURVEY 8(d) is about): algorithmic bytes per launch
         # / average launch duration (HIP events on the stream the kernel is launched on)
+        # Dominant = the largest accumulated launch time among the sweep kernels whose launches are THROUGHPUT work -- on average
+        # at least 1 % of the batch's alignments per launch.  (A launch over a handful of long alignments is a chain of dependent
+        # rows: its duration is a latency, and dividing its few bytes by it says nothing about the memory system; with the long
+        # part starting at 1 024 rows the accumulated time of such chains can exceed the bulk kernel's.)  No such kernel -- the
+        # workloads of long alignments -- : the largest accumulated time.
         sweeps = {k: v for k, v in stats_acc.items() if k[0] in (1, 2) and v[0] > 0}
-        (kind, kname), (nl, ms, byt, cells, dense, _, _) = max(sweeps.items(), key=lambda kv: kv[1][1])
+        bulk = {k: v for k, v in sweeps.items() if units_acc.get(k, 0) / v[0] >= 0.01 * 4 * args.n_sc}
+        (kind, kname), (nl, ms, byt, cells, dense, _, _) = max((bulk or sweeps).items(), key=lambda kv: kv[1][1])
         avg_s = ms / nl * 1e-3
         # Three byte counts for that launch: (1) what the PMC counters of the committed rocprofv3
         # passes of this very command saw (FETCH_SIZE x 2 + WRITE_SIZE): `traffic`, and `achieved` = traffic / the
