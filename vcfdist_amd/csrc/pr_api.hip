@@ -956,6 +956,13 @@ __global__ void k_scatter_descs(const AlnDesc *__restrict__ src, int n, AlnDesc 
     const AlnDesc d = src[i];
     dst[d.sc * 4 + d.aln] = d;
 }
+// the same for the plan positions in `pos` only (what a previous execute's retry rounds replaced)
+__global__ void k_scatter_some(const AlnDesc *__restrict__ src, const int32_t *__restrict__ pos, int n, AlnDesc *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AlnDesc d = src[pos[i]];
+    dst[d.sc * 4 + d.aln] = d;
+}
 
 // Assign arena offsets (flag matrices, band origins, walk scratch) to `alns` and cut them into chunks
 // that fit the arena.  lv: window level of the plan (LV_DENSE: dense layout + kernel classes).
@@ -3506,6 +3513,21 @@ struct Exec {
             hipLaunchKernelGGL(k_init_execute, blocks(top), dim3(256), 0, st, IA);
         }
         if (!h->dirty.empty()) {   // restore the round-0 descriptors and levels a previous execute's retry rounds replaced
+            // (only those: a few thousand of a whole-genome batch's millions -- rewriting all of them was 0.5 GB of traffic per
+            // execute, 0.4 ms alone and 1.5 ms beside another batch's kernels, on the host's way to the first launch)
+            const size_t nd = h->dirty.size();
+            bool some = nd * 8 < h->plan0.work.size() && h->plan0_pos.size() == h->descs.size();
+            for (size_t k = 0; k < nd && some; k++) some = h->plan0_pos[size_t(h->dirty[k])] >= 0;
+            if (some) {
+                void *hp = nullptr, *dp = nullptr;
+                { const int rc = exec_pin(h, &hp, nd * 4); if (rc) return rc; }
+                { const int rc = exec_alloc(h, &dp, nd * 4); if (rc) return rc; }
+                int32_t *hpos = static_cast<int32_t *>(hp);
+                for (size_t k = 0; k < nd; k++) hpos[k] = h->plan0_pos[size_t(h->dirty[k])];
+                HIPCHK(h, hipMemcpyAsync(dp, hp, nd * 4, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_scatter_some, blocks(int64_t(nd)), dim3(256), 0, st, h->plan0.d_descs, static_cast<const int32_t *>(dp),
+                                   int(nd), h->d_descs);
+            } else
             hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(h->plan0.work.size())), dim3(256), 0, st, h->plan0.d_descs,
                                int(h->plan0.work.size()), h->d_descs);
             for (int32_t a : h->dirty) h->level[size_t(a)] = h->level0[size_t(a)];     // (every level change goes through a plan)
