@@ -8,7 +8,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/profiles_${TAG}_${WL}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$R"
-CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --workload $WL --n-sc $NSC"
+CMD="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --workload $WL --n-sc $NSC"     # (warm-up >= 2: two batches in flight, as in the driver's command)
 timeout ${PASS_TIMEOUT:-400} rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $CMD > "$OUT/stats.log" 2>&1
 CMD2="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --in-flight 1 --one-pass-batches 0 --no-secondary --workload $WL --n-sc $NSC"
 timeout ${PASS_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $CMD2 > "$OUT/fetch.log" 2>&1
