@@ -10,6 +10,7 @@
 // There is no CPU fallback: without a HIP device every entry point that needs one
 // returns VPR_ERR_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -1935,8 +1936,13 @@ struct Exec {
 
     // HIP events bracket each launch on the stream the kernel is launched on
     bool need_err_check = false;    // a dense round holds an alignment only the strips can take: did the planner cut it?
-    template <typename F>
-    int timed(int kind, const vpr_launch_stat &ls, hipStream_t ks, const char *name, F &&launch) {
+    // own_events: the launch attaches the pair to ONE kernel itself (hipExtLaunchKernelGGL: start and stop of that kernel as the
+    // device saw them); recorded around the launch, the first event completes when the stream reaches it and the interval then also
+    // holds the time the kernel waits for the dispatcher behind other streams' work -- with two batches in flight 7 - 10 ms for a
+    // 6 ms kernel.  Used for the lane kernel, whose duration the bench line's roofline block divides by.
+    hipEvent_t own_a = nullptr, own_b = nullptr;
+    template <class F>
+    int timed(int kind, const vpr_launch_stat &ls, hipStream_t ks, const char *name, F &&launch, bool own_events = false) {
         EvPair ev; ev.kind = kind; ev.st = ls; ev.st.kind = kind;
         snprintf(ev.st.kernel, sizeof(ev.st.kernel), "%s", name);
         while (h->ev_pool.size() < h->ev_used + 2) {
@@ -1946,9 +1952,15 @@ struct Exec {
         }
         ev.a = h->ev_pool[h->ev_used++];
         ev.b = h->ev_pool[h->ev_used++];
-        HIPCHK(h, hipEventRecord(ev.a, ks));
-        launch();
-        HIPCHK(h, hipEventRecord(ev.b, ks));
+        if (own_events) {
+            own_a = ev.a; own_b = ev.b;
+            launch();
+            own_a = own_b = nullptr;
+        } else {
+            HIPCHK(h, hipEventRecord(ev.a, ks));
+            launch();
+            HIPCHK(h, hipEventRecord(ev.b, ks));
+        }
         h->events.push_back(ev);
         return VPR_OK;
     }
@@ -2494,9 +2506,9 @@ struct Exec {
                 hipLaunchKernelGGL(k_fwd_stripe_only, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs, FT.fallback);
             } else
             if (zero)        // forward + backward + walk of the zero-distance alignments, one lane each (pr_zl.hip)
-                hipLaunchKernelGGL(k_zero_lane, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->d_descs, list, cnt,
-                                   h->d_zl_hdr + zl_wave0, h->d_zl_in, h->d_zl_log, h->d_outs, a_path,
-                                   (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0);
+                hipExtLaunchKernelGGL(k_zero_lane, dim3((cnt + 63) / 64), dim3(64), 0, ks, own_a, own_b, 0, h->d_descs, list, cnt,
+                                      h->d_zl_hdr + zl_wave0, h->d_zl_in, h->d_zl_log, h->d_outs, a_path,
+                                      (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0);
             else if (q16)
                 hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);
@@ -2510,7 +2522,7 @@ struct Exec {
                 hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3(lv >= LV_C4 ? W : 64), 0,
                                    ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs);
             hipLaunchKernelGGL(k_fwd_band_finish, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs, tag, n_dev);
-        });
+        }, zero && !fwdp);
         if (rc) return rc;
         if (fwdp && getenv("VPR_FWDP_STATS")) {      // (diagnostic: waits for the sweep)
             int32_t c[8] = {0};
