@@ -770,23 +770,26 @@ __global__ void k_collect_fails(const int32_t *__restrict__ work, int n, const A
     const bool bad = live && a >= 0 && !outs[a].band_ok;
     const unsigned long long mbad = __ballot(bad);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // pad4: the list feeds a four-alignments-per-wave kernel directly.  A wave's rejected ids are consecutive in
-    // the (row-count sorted) work list, so they are kept together and padded with -1 to a multiple of four:
-    // groups of four then never mix alignments of very different lengths.
-    const int npop = __popcll(mbad), nres = pad4 ? ((npop + 3) & ~3) : npop;
+    // pad4: the list feeds a four-alignments-per-wave kernel directly.  A workgroup's rejected ids are consecutive in the
+    // (row-count sorted) work list, so they are kept together and padded with -1 to a multiple of four: groups of four then
+    // never mix alignments of very different lengths.  (Padded per workgroup of 256 list entries, not per wavefront of 64: at
+    // 9 % rejects a wavefront has five or six, and rounding each wavefront's up left a quarter of the 16-cell round's lanes idle.)
+    const int npop = __popcll(mbad);
     // one atomic per workgroup (a single contended counter serialises in L2: ~10 ns each)
-    __shared__ int wcnt[4], wbase;
-    if (lane == 0) wcnt[wave] = nres;
+    __shared__ int wcnt[4], wbase, wtot, wpad;
+    if (lane == 0) wcnt[wave] = npop;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        wbase = tot ? atomicAdd(cnt, tot) : 0;
+        const int totp = pad4 ? ((tot + 3) & ~3) : tot;
+        wbase = totp ? atomicAdd(cnt, totp) : 0;
+        wtot = tot; wpad = totp - tot;
     }
     __syncthreads();
     int base = wbase;
     for (int w = 0; w < wave; w++) base += wcnt[w];
     if (bad) fail_list[base + __popcll(mbad & ((1ull << lane) - 1ull))] = a;
-    if (lane < nres - npop) fail_list[base + npop + lane] = -1;
+    if (int(threadIdx.x) < wpad) fail_list[wbase + wtot + int(threadIdx.x)] = -1;
 }
 
 // Mirror a fail list and its length into host-pinned memory (launched on the stream that produced them, right behind
