@@ -444,8 +444,29 @@ static int poison_byte() {
     static const int v = [] { const char *e = getenv("VPR_POISON"); return e ? int(strtol(e, nullptr, 0)) & 0xff : -1; }();
     return v;
 }
+// Device memory the library leaves alone (VPR_DEV_RESERVE_MB, default 1 536): the runtime allocates on its own behind the
+// library's back -- private (scratch) memory of kernels per hardware queue, hundreds of MB each for the walk and replay kernels --
+// and a queue that cannot get it is ABORTED (HSA_STATUS_ERROR_OUT_OF_RESOURCES, the process dies: 125 000 stress superclusters
+// with the long part from 2 048 rows ended that way, 38 MB free).  An allocation that would go below the reserve fails like an
+// exhausted device instead, which every caller handles (smaller workspaces and more rounds, sub-batches of replays, VPR_ERR_NOMEM).
+// (The default keeps what fitted before fitting: a GPU's share of the stress workload, 125 000 superclusters, ends with 2.4 GB free.
+// Its upload takes 278 of 309 GB -- round 0's workspace 60 % of the free memory, four ladder workspaces an eighth of the rest each --
+// and a single tied 16 k x 16 k alignment then wants 6.9 GB of replay stamps: the shares want planning from the batch)
+static int64_t dev_reserve_bytes() {
+    static const int64_t v = [] { const char *e = getenv("VPR_DEV_RESERVE_MB"); return (e ? int64_t(atoll(e)) : int64_t(1536)) << 20; }();
+    return v;
+}
 hipError_t x_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
     const double t = wall_ms();
+    {
+        size_t fr = 0, tt = 0;
+        if (dev_reserve_bytes() > 0 && hipMemGetInfo(&fr, &tt) == hipSuccess && int64_t(fr) < int64_t(bytes) + dev_reserve_bytes() &&
+            int64_t(bytes) + dev_reserve_bytes() < int64_t(tt)) {       // (a device smaller than the reserve: no reserve)
+            if (h) h->hs.n_dev_alloc++;
+            *q = nullptr;
+            return hipErrorOutOfMemory;
+        }
+    }
     const hipError_t e = hipMalloc(q, bytes);
     const double dt = wall_ms() - t;
     if (h) { h->hs.n_dev_alloc++; h->hs.ms_alloc += dt; }
