@@ -274,6 +274,7 @@ struct vpr_handle {
     bool debug = false;                  // VPR_DEBUG in the environment at vpr_create: progress lines on stderr
     // host-side cost of the current / last vpr_execute: allocator calls and blocking waits (vpr_timing reports them; with
     // VPR_STALL_LOG in the environment every such call that takes more than 5 ms is printed with its site)
+    bool soft_alloc = false;            // the allocation under way is optional growth (x_malloc: larger reserve)
     struct HostStat {
         int64_t n_dev_alloc = 0, n_dev_free = 0, n_pin_alloc = 0;
         double ms_alloc = 0, ms_sync = 0, ms_idle_max = 0;
@@ -456,12 +457,22 @@ static int64_t dev_reserve_bytes() {
     static const int64_t v = [] { const char *e = getenv("VPR_DEV_RESERVE_MB"); return (e ? int64_t(atoll(e)) : int64_t(1536)) << 20; }();
     return v;
 }
+// shares of the free device memory at upload: round 0's workspace, and each of the four ladder workspaces of what that leaves
+// (VPR_ARENA_SHARE / VPR_LADDER_SHARE: diagnostic)
+static double arena_share() { static const double v = [] { const char *e = getenv("VPR_ARENA_SHARE"); return e ? atof(e) : 0.55; }(); return v; }
+static double ladder_share() { static const double v = [] { const char *e = getenv("VPR_LADDER_SHARE"); return e ? atof(e) : 0.1; }(); return v; }
 hipError_t x_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
     const double t = wall_ms();
     {
         size_t fr = 0, tt = 0;
-        if (dev_reserve_bytes() > 0 && hipMemGetInfo(&fr, &tt) == hipSuccess && int64_t(fr) < int64_t(bytes) + dev_reserve_bytes() &&
-            int64_t(bytes) + dev_reserve_bytes() < int64_t(tt)) {       // (a device smaller than the reserve: no reserve)
+        // optional growth during an execute (a ladder's larger workspace, a replay scratch that would hold a whole launch instead of
+        // sub-batches) leaves a 32nd of the device to what an execute MUST still get (the replay stamps of one large tied alignment)
+        int64_t reserve = dev_reserve_bytes();
+        if (reserve > 0 && hipMemGetInfo(&fr, &tt) == hipSuccess) {
+            if (h && h->soft_alloc) reserve = std::max<int64_t>(reserve, int64_t(tt) / 32);
+        }
+        if (reserve > 0 && tt > 0 && int64_t(fr) < int64_t(bytes) + reserve &&
+            int64_t(bytes) + reserve < int64_t(tt)) {       // (a device smaller than the reserve: no reserve)
             if (h) h->hs.n_dev_alloc++;
             *q = nullptr;
             return hipErrorOutOfMemory;
@@ -1713,7 +1724,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     // ---- arena for flag matrices, band origins and walks
     size_t free_b = 0, total_b = 0;
     HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
-    int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes : int64_t(double(free_b) * 0.6);
+    int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes : int64_t(double(free_b) * arena_share());
     if (budget < (8 << 20)) budget = 8 << 20;
     // do not allocate more than round 0 can use (its layout per alignment: make_plan)
     int64_t want = 0;
@@ -1752,7 +1763,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         int64_t b2 = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes
                                                 // (four of them: together at most half of what round 0 left, the rest is for the
                                                 //  result columns, the tie replays' scratch and the deferred edit distances)
-                                                : std::min<int64_t>(int64_t(double(free_b) * 0.125), std::max<int64_t>(want / 16, int64_t(1) << 30));
+                                                : std::min<int64_t>(int64_t(double(free_b) * ladder_share()), std::max<int64_t>(want / 16, int64_t(1) << 30));
         if (b2 < (8 << 20)) b2 = 8 << 20;
         for (int k = (h->cfg.band_mode != 0 ? 0 : 2); k < 4; k++) {   // (dense mode: only the tie rounds need one)
             h->lad[k].arena_bytes = b2;
@@ -2137,14 +2148,24 @@ struct Exec {
         if (largest * 4 + 256 > scratch_bytes || (total * 4 + 256 > scratch_bytes && scratch_bytes < h->tie_scratch_max)) {
             const int64_t nb = std::max<int64_t>(std::max<int64_t>(std::min<int64_t>(total * 4, h->tie_scratch_max), 2 * scratch_bytes), largest * 4) + 256;
             void *q = nullptr;
-            if (x_malloc(h, &q, size_t(nb), SITE) != hipSuccess) {
+            const bool must = largest * 4 + 256 > scratch_bytes;
+            int64_t got_b = nb;
+            h->soft_alloc = !must;
+            hipError_t e_sc = x_malloc(h, &q, size_t(nb), SITE);
+            h->soft_alloc = false;
+            if (e_sc != hipSuccess && must && largest * 4 + 256 < nb) {     // the whole launch does not fit: what its largest job needs does
                 (void)hipGetLastError();
-                if (largest * 4 + 256 > scratch_bytes) return fail(h, VPR_ERR_NOMEM, "tie replay scratch (%lld bytes)", (long long)nb);
+                got_b = largest * 4 + 256;
+                e_sc = x_malloc(h, &q, size_t(got_b), SITE);
+            }
+            if (e_sc != hipSuccess) {
+                (void)hipGetLastError();
+                if (must) return fail(h, VPR_ERR_NOMEM, "tie replay scratch (%lld bytes)", (long long)got_b);
                 // (the launch still fits in sub-batches: keep the block)
             } else {
                 if (scratch) h->parked.push_back(vpr_handle::Blk{scratch, size_t(scratch_bytes)});
                 scratch = static_cast<uint32_t *>(q);
-                scratch_bytes = nb;
+                scratch_bytes = got_b;
                 tc.tie_clean[se] = 0;
             }
         }
@@ -2747,7 +2768,10 @@ struct Exec {
             if (&g != &c && !(k < 2 && j == 1 - k)) continue;
             if (g.arena_bytes >= nb) continue;
             uint8_t *na2 = nullptr;
-            if (dev_alloc(h, &na2, size_t(nb) + 256) != VPR_OK) {
+            h->soft_alloc = true;
+            const int rc_grow = dev_alloc(h, &na2, size_t(nb) + 256);
+            h->soft_alloc = false;
+            if (rc_grow != VPR_OK) {
                 h->err.clear();
                 (void)hipGetLastError();
                 if (&g == &c) return false;
