@@ -290,6 +290,35 @@ def test_long_part_threshold_leaves_the_results_unchanged(monkeypatch):
     assert units["256"] < units["2048"]          # (the border really moved)
 
 
+def test_device_reserve_turns_an_exhausted_device_into_an_error():
+    """the library leaves VPR_DEV_RESERVE_MB of device memory to the runtime (kernels' private memory is allocated per queue behind
+    its back, and a queue that cannot get it is aborted together with the process): an allocation that would go below the reserve
+    fails like an exhausted device, and the caller sees VPR_ERR_NOMEM.  With the reserve set to all but 512 MB of the device (read
+    once per process: a child process) nothing sizeable can be allocated -- an error comes back, not a crash; the default runs."""
+    import subprocess
+    import sys
+    import torch
+    total_mb = torch.cuda.mem_get_info(0)[1] >> 20
+    code = ("from vcfdist_amd import api\n"
+            "b = api.Synth(n_sc=2000, seed=3, len_a=10, len_b=300, len_max=300).batch()\n"
+            "try:\n"
+            "    r = api.PrecisionRecall().run(b)\n"
+            "    print('ran', int(r.aln_dist.size))\n"
+            "except api.VprError as e:\n"
+            "    print('error', e)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for reserve, want in ((str(total_mb - 512), "error"), (None, "ran")):
+        env = dict(os.environ)
+        env.pop("VPR_DEV_RESERVE_MB", None)
+        if reserve:
+            env["VPR_DEV_RESERVE_MB"] = reserve
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        last = [ln for ln in out.stdout.splitlines() if ln.startswith(("ran", "error"))]
+        assert out.returncode == 0 and last and last[-1].startswith(want), (reserve, out.returncode, out.stdout[-400:], out.stderr[-400:])
+        if want == "error":
+            assert "(-3)" in last[-1], last[-1]          # VPR_ERR_NOMEM
+
+
 def test_repeated_executes_of_one_batch_are_identical():
     """the planner's host loop serves fail lists and tie lists in the order the device raises them, so the launch order differs
     from execute to execute: every result array has to come out the same each time (60 executes of a batch with every level,
