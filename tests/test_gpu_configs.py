@@ -295,10 +295,14 @@ def test_device_reserve_turns_an_exhausted_device_into_an_error():
     its back, and a queue that cannot get it is aborted together with the process): an allocation that would go below the reserve
     fails like an exhausted device, and the caller sees VPR_ERR_NOMEM.  With the reserve set to all but 512 MB of the device (read
     once per process: a child process) nothing sizeable can be allocated -- an error comes back, not a crash; the default runs."""
+    import ctypes
     import subprocess
     import sys
-    import torch
-    total_mb = torch.cuda.mem_get_info(0)[1] >> 20
+    api.PrecisionRecall().close()                       # (the HIP runtime is loaded and initialised by now)
+    hip = ctypes.CDLL("libamdhip64.so")
+    free_b, total_b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) == 0
+    total_mb = total_b.value >> 20
     code = ("from vcfdist_amd import api\n"
             "b = api.Synth(n_sc=2000, seed=3, len_a=10, len_b=300, len_max=300).batch()\n"
             "try:\n"

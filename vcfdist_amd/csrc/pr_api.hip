@@ -2641,13 +2641,33 @@ struct Exec {
         } else if (row_walk) {
             // striped 64-cell layout: the walk (phase A) in parallel over segments of 128 truth rows (pr_walkseg.hip; the
             // sequential row sweep, k_walk_rows, with VPR_SEQ_WALK in the environment), then the credit walk (phase B)
-            if (!seg_walk) {
-                rc = timed(3, ws_, ks, "k_walk_rows", [&] {
-                    hipLaunchKernelGGL(k_walk_rows, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
+            // Round 0's long part (sorted longest first): only the alignments of VPR_WSEG_MIN_ROWS (2 048) rows or more are latency
+            // chains worth 128 times the work; the shorter ones -- nine in ten since the long part starts at 1 024 rows -- take the row
+            // sweep, a wavefront each (chains of at most 2 047 x 0.6 us), in front of the segment walk of the long ones on the same
+            // stream: 1.7 instead of 6.8 ms of 10 000-workgroup launches per step with two batches in flight, step -0.4 ms, alone -0.9.
+            static const int wseg_min_rows = [] { const char *e = getenv("VPR_WSEG_MIN_ROWS"); return e ? atoi(e) : 2048; }();      // (0: the segment walk for all)
+            int32_t n_seg = cnt;
+            if (seg_walk && long_part && wseg_min_rows > 0) {
+                n_seg = 0;
+                while (n_seg < cnt && plan_desc(h, P, size_t(off) + size_t(n_seg)).Lt >= wseg_min_rows) n_seg++;
+            }
+            if (!seg_walk || n_seg < cnt) {
+                const int32_t k0 = seg_walk ? n_seg : 0;
+                vpr_launch_stat wr_ = ws_;
+                wr_.n_units = cnt - k0;
+                rc = timed(3, wr_, ks, "k_walk_rows", [&] {
+                    hipLaunchKernelGGL(k_walk_rows, dim3(cnt - k0), dim3(64), 0, ks, h->dB, h->d_descs, list + k0, cnt - k0,
                                        P.arena, a_i32, h->d_outs, a_path, tag);
                 });
-            } else {
-                const int64_t rows_sum = walk_rows_sum;
+                if (rc) return rc;
+            }
+            if (seg_walk && n_seg > 0) {
+                const int32_t cnt_all = cnt;
+                const int32_t cnt = n_seg;          // (the segment walk's launches below: the head of the list)
+                (void)cnt_all;
+                int64_t rows_sum = 0;
+                for (int32_t k = 0; k < cnt; k++) rows_sum += plan_desc(h, P, size_t(off) + size_t(k)).Lt;
+                ws_.n_units = cnt;
                 WsegTables T;
                 T.cap = int32_t(std::min<int64_t>(rows_sum / WSEG_ROWS + cnt + 1, 0x7fffffff));
                 void *q = nullptr;
@@ -2671,6 +2691,7 @@ struct Exec {
             }
             if (rc) return rc;
             ws_.cells_per_thread = 3;
+            ws_.n_units = cnt;
             const bool wave_credit = wave_walk || cnt <= CREDIT_WAVE_MAX;
             rc = timed(3, ws_, ks, wave_credit ? "k_credit<wave>" : "k_credit<lane>", [&] {
                 if (wave_credit)
