@@ -223,6 +223,9 @@ typedef struct vpr_timing {
     int64_t n_alignments_computed; /* alignments the kernels ran (all of them without VPR_CFG_HAP_DEDUP) */
     int64_t n_device_allocs, n_device_frees, n_host_allocs;   /* hipMalloc / hipFree / hipHostMalloc calls of the execute: all 0
                               once the handle's workspaces have settled (normally after the first execute of a batch) */
+    int64_t n_lane1_seen, n_lane1_finished, n_lane1_waves_dropped;   /* the distance-1 lane level (pr_d1.hip): alignments the zero-distance
+                              lane kernel rejected with a complete wave 0, how many of them were finished there (s = 1), and waves of
+                              64 that did not fit its blocks (they stay with the 16-cell kernels) */
 } vpr_timing;
 
 /* one kernel launch of the last vpr_execute (HIP events around the launch) */

@@ -427,3 +427,52 @@ def test_hand_derived_credit_and_sync_rules_through_the_hip_path():
         batch = api.batch_from_variants(TO.hand_case_variants(case))
         TO.check_hand_case(case, api.PrecisionRecall().run(batch))
 
+
+
+def test_distance_one_lane_level_finishes_most_rejects_and_equals_the_oracle(monkeypatch):
+    """pr_d1.hip: alignments the zero-distance lane kernel rejects with a complete wave 0 go through the distance-1 lane kernel;
+    on whole-genome-like input most of them have s = 1 and are finished there (every array still equal to the oracle's), and
+    with the level switched off (VPR_NO_D1) the 16-cell kernels give the same arrays"""
+    batch = api.Synth(n_sc=20000, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=1000, seed=11).batch()
+    monkeypatch.setenv("VPR_D1_MAX_ROWS", "1024")      # (default 256 rows: longer rejects stay with the 16-cell kernels; here all of them)
+    got, want, ntie, pr = compare(batch)
+    t = pr.timing()
+    n1 = int((got.aln_dist == 1).sum())
+    print(f"{t.n_lane1_seen} rejects with a complete wave 0, {t.n_lane1_finished} finished at the lane level, {n1} alignments with s = 1, "
+          f"{t.n_lane1_waves_dropped} waves dropped")
+    assert t.n_lane1_seen > 5000 and t.n_lane1_finished > 0.8 * t.n_lane1_seen and t.n_lane1_finished <= n1
+    assert t.n_lane1_finished > 0.9 * n1 and t.n_lane1_waves_dropped == 0
+    monkeypatch.delenv("VPR_D1_MAX_ROWS")
+    pr1 = api.PrecisionRecall()
+    assert not got.diff(pr1.run(batch)) and 0 < pr1.timing().n_lane1_seen < t.n_lane1_seen
+    monkeypatch.setenv("VPR_NO_D1", "1")
+    pr2 = api.PrecisionRecall()
+    assert not got.diff(pr2.run(batch)) and pr2.timing().n_lane1_seen == 0
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_sc=600, len_a=20, len_b=300, len_min=20, len_max=300, seed=41, var_per_base=0.02, p_snp=0.3, indel_mean=3.0),      # INS / DEL steps
+    dict(n_sc=600, len_a=20, len_b=300, len_min=20, len_max=300, seed=42, var_per_base=0.02, p_snp=0.9),                     # SUB steps
+    dict(n_sc=600, len_a=20, len_b=200, len_min=20, len_max=200, seed=43, var_per_base=0.03, p_snp=0.4, p_repeat=0.7),       # repeats: several diagonals
+])
+def test_distance_one_walks_equal_the_oracle_paths(kw):
+    """the walks of the distance-1 lane level, step for step (plane, position, truth row, sync and edit flags), incl. the extra
+    step of an INS move"""
+    batch = api.Synth(**kw).batch()
+    pr = api.PrecisionRecall(A.default_config(flags=A.CFG_KEEP_PATHS))
+    got = pr.run(batch)
+    t = pr.timing()
+    assert t.n_lane1_finished > 50
+    n_checked = n_edit = 0
+    for a in np.flatnonzero(got.aln_dist == 1)[:200]:
+        sc, aln = int(a) // 4, int(a) % 4
+        one = batch.subset(np.array([sc]))
+        ex = O.Extra(one, want=(0, aln))
+        O.run(one, extra=ex)
+        pl, q, tt, sy, ed = pr.path(sc, aln)
+        opl, oq, ot, osy, oed = ex.path_arrays()
+        assert np.array_equal(pl, opl) and np.array_equal(q, oq) and np.array_equal(tt, ot), (sc, aln)
+        assert np.array_equal(sy, osy[:len(sy)]) and np.array_equal(ed, oed[:len(ed)]), (sc, aln)
+        n_checked += 1
+        n_edit += int(ed.sum())
+    assert n_checked >= 100 and n_edit == n_checked

@@ -88,7 +88,7 @@ class VprTiming(C.Structure):
         ("n_tie_replays", C.c_int64), ("ms_tie", C.c_double),
         ("ms_wall", C.c_double), ("ms_wall_phase", C.c_double * 6), ("ms_host_alloc", C.c_double),
         ("ms_host_blocked", C.c_double), ("n_alignments_computed", C.c_int64), ("n_device_allocs", C.c_int64), ("n_device_frees", C.c_int64),
-        ("n_host_allocs", C.c_int64),
+        ("n_host_allocs", C.c_int64), ("n_lane1_seen", C.c_int64), ("n_lane1_finished", C.c_int64), ("n_lane1_waves_dropped", C.c_int64),
     ]
 
 

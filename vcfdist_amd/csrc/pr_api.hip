@@ -39,6 +39,7 @@ extern "C" int vpr_batch_skeleton_from_variants(const vpr_variants *v, vpr_owned
 #include "pr_fwdpar.hip"
 #include "pr_q16.hip"
 #include "pr_zl.hip"
+#include "pr_d1.hip"
 #include "pr_gen.hip"
 #include "pr_wide.hip"
 #include "pr_strip.hip"
@@ -372,6 +373,14 @@ struct vpr_handle {
     // once by k_prep_zl) and the log blocks (shared by the chunks of plan 0, which run one after the other)
     ZlWave *d_zl_hdr = nullptr; uint32_t *d_zl_in = nullptr; uint4 *d_zl_log = nullptr;
     std::vector<int64_t> zl_wave0;                            // first wave of every chunk of plan 0
+    // distance-1 lane kernel (pr_d1.hip): headers, position words and log of the waves of zero-level rejects (sized on the device
+    // per execute, within these blocks), the list of what it leaves to the in-place 16-cell round and {waves used, waves dropped,
+    // length of that list}
+    ZlWave *d_d1_hdr = nullptr; uint32_t *d_d1_in = nullptr; uint4 *d_d1_log = nullptr; int32_t *d_d1_fail = nullptr, *d_d1_info = nullptr;
+    int32_t *d_d1_blk = nullptr;                              // per-workgroup counts / offsets of the ordered fail lists (k_fails_*)
+    int64_t d1_in_cap = 0, d1_log_cap = 0;
+    int32_t d1_wave_cap = 0, d1_fail_cap = 0;
+    int32_t d1_max_rows = 256;                                // rejects of more truth rows stay with the 16-cell kernels (VPR_D1_MAX_ROWS)
     std::vector<ZlWave> zl_hdr_host;
     int32_t long_lt = LONG_LT;                                // rows from which an alignment belongs to the long part of plan 0
     // vpr_upload_variants: the variant tables of the batch being uploaded (the device generates the Level A arrays from
@@ -714,6 +723,8 @@ void free_batch(vpr_handle *h) {
     h->hp_tie_jobs = nullptr; h->tie_jobs_cap = 0;
     h->d_tie_dec = nullptr; h->tie_dec_cap = 0; h->d_tie_ndec = nullptr; h->plan0_pos.clear();
     h->d_zl_hdr = nullptr; h->d_zl_in = nullptr; h->d_zl_log = nullptr; h->zl_wave0.clear();
+    h->d_d1_hdr = nullptr; h->d_d1_in = nullptr; h->d_d1_log = nullptr; h->d_d1_fail = nullptr; h->d_d1_info = nullptr; h->d_d1_blk = nullptr;
+    h->d1_in_cap = h->d1_log_cap = 0; h->d1_wave_cap = h->d1_fail_cap = 0;
     h->uploaded = h->executed = false;
 }
 
@@ -822,6 +833,68 @@ __global__ void k_collect_fails(const int32_t *__restrict__ work, int n, const A
     for (int w = 0; w < wave; w++) base += wcnt[w];
     if (bad) fail_list[base + __popcll(mbad & ((1ull << lane) - 1ull))] = a;
     if (int(threadIdx.x) < wpad) fail_list[wbase + wtot + int(threadIdx.x)] = -1;
+}
+
+// The same list IN THE ORDER OF THE WORK LIST (three small launches instead of one): the zero-distance level's rejects feed lane
+// kernels (pr_d1.hip), whose 64 lanes run in lockstep -- the work list is sorted by truth rows, and a list appended in the order
+// in which the workgroups happen to reach the counter mixes alignments of a hundred rows with alignments of a thousand.
+//   k_fails_count: rejected entries per workgroup of 256 (padded to a multiple of four with pad4) -> blk[b]
+//   k_fails_scan:  exclusive prefix sums of blk[0 .. nb) in place (one workgroup), the total -> *cnt
+//   k_fails_scatter: the ids to fail_list[blk[b] ...], -1 behind them up to the padded length
+__global__ void k_fails_count(const int32_t *__restrict__ work, int n, const AlnOut *__restrict__ outs, int32_t *__restrict__ blk,
+                              int pad4, const int32_t *__restrict__ n_dev) {
+    if (n_dev) n = min(n, *n_dev);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = i < n ? work[i] : -1;
+    const bool bad = a >= 0 && !outs[a].band_ok;
+    const int npop = __popcll(__ballot(bad));
+    __shared__ int wcnt[4];
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = npop;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        blk[blockIdx.x] = pad4 ? ((tot + 3) & ~3) : tot;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_fails_scan(int32_t *__restrict__ blk, int nb, int32_t *__restrict__ cnt) {
+    __shared__ int32_t s_sum[1024];
+    const int tid = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int b = min(nb, tid * per), e = min(nb, b + per);
+    int32_t sum = 0;
+    for (int k = b; k < e; k++) sum += blk[k];
+    s_sum[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int32_t v = tid >= o ? s_sum[tid - o] : 0;
+        __syncthreads();
+        s_sum[tid] += v;
+        __syncthreads();
+    }
+    int32_t off = s_sum[tid] - sum;
+    for (int k = b; k < e; k++) { const int32_t c = blk[k]; blk[k] = off; off += c; }
+    if (tid == 1023) *cnt = s_sum[1023];
+}
+
+__global__ void k_fails_scatter(const int32_t *__restrict__ work, int n, const AlnOut *__restrict__ outs, const int32_t *__restrict__ blk,
+                                int32_t *__restrict__ fail_list, int pad4, const int32_t *__restrict__ n_dev) {
+    if (n_dev) n = min(n, *n_dev);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = i < n ? work[i] : -1;
+    const bool bad = a >= 0 && !outs[a].band_ok;
+    const unsigned long long mbad = __ballot(bad);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int wcnt[4];
+    if (lane == 0) wcnt[wave] = __popcll(mbad);
+    __syncthreads();
+    const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    const int totp = pad4 ? ((tot + 3) & ~3) : tot;
+    const int wbase = blk[blockIdx.x];
+    int base = wbase;
+    for (int w = 0; w < wave; w++) base += wcnt[w];
+    if (bad) fail_list[base + __popcll(mbad & ((1ull << lane) - 1ull))] = a;
+    if (int(threadIdx.x) < totp - tot) fail_list[wbase + tot + int(threadIdx.x)] = -1;
 }
 
 // Mirror a fail list and its length into host-pinned memory (launched on the stream that produced them, right behind
@@ -1288,11 +1361,14 @@ int prep_zero_lane(vpr_handle *h) {
     std::vector<ZlWave> &hdr = h->zl_hdr_host;      // (kept in the handle: the upload below reads it asynchronously)
     hdr.clear();
     h->zl_wave0.assign(P.chunks.size(), 0);
-    int64_t in_words = 0, log_max = 0;
+    int64_t in_words = 0, log_max = 0, in_chunk_max = 0, n_short_max = 0;
+    int32_t len_max = 0;
     for (size_t ci = 0; ci < P.chunks.size(); ci++) {
         const Chunk &ch = P.chunks[ci];
         h->zl_wave0[ci] = int64_t(hdr.size());
         const int64_t first = ch.work_off + ch.n_long, n_short = ch.count - ch.n_long;
+        const int64_t in_words0 = in_words;
+        n_short_max = std::max(n_short_max, n_short);
         const size_t w0 = hdr.size(), nw = size_t((n_short + 63) / 64);
         hdr.resize(w0 + nw);
         par_for(nw * 64, [&](size_t b0, size_t e0, int) {           // the largest lengths of every wave's 64 alignments
@@ -1313,14 +1389,39 @@ int prep_zero_lane(vpr_handle *h) {
             W.log_off = log_cur;
             in_words += 64 * (int64_t(W.mq) + W.mr + W.mt);
             log_cur += 80 * int64_t(W.mt);         // per row and lane: 8 flag bytes, a path_ptr word, an 8-byte step
+            len_max = std::max(len_max, std::max(W.mq, std::max(W.mr, W.mt)));
         }
         log_max = std::max(log_max, log_cur);
+        in_chunk_max = std::max(in_chunk_max, in_words - in_words0);
     }
     if (hdr.empty()) return VPR_OK;
     int rc;
     if ((rc = dev_alloc(h, &h->d_zl_hdr, hdr.size()))) return rc;
     if ((rc = dev_alloc(h, &h->d_zl_in, size_t(in_words)))) return rc;
     if ((rc = dev_alloc(h, &h->d_zl_log, size_t(log_max)))) return rc;
+    // The distance-1 lane level works on the zero level's rejects (pr_d1.hip): its blocks hold D1_SHARE of what the largest
+    // chunk would need if EVERY alignment were rejected (two words per QUERY / REF position instead of one, 40 B of log per
+    // row instead of 20), at least D1_FLOOR -- small batches then fit whole --; waves that do not fit stay with the
+    // in-place 16-cell round.  VPR_NO_D1 switches the level off.
+    if (!getenv("VPR_NO_D1")) {
+        if (const char *e = getenv("VPR_D1_MAX_ROWS")) h->d1_max_rows = std::max(2, atoi(e));
+        const double D1_SHARE = 0.4;
+        const int64_t D1_FLOOR = int64_t(4) << 20;
+        const int64_t slack = 64 * 5 * int64_t(len_max + 1);
+        const int64_t in_all = 2 * in_chunk_max + slack, log_all = 2 * log_max + 160 * int64_t((n_short_max + 63) / 64) + 160 * int64_t(len_max + 1);
+        h->d1_in_cap = std::min(in_all, std::max(int64_t(D1_SHARE * double(in_all)), D1_FLOOR + slack));
+        h->d1_log_cap = std::min(log_all, std::max(int64_t(D1_SHARE * double(log_all)), D1_FLOOR + slack));
+        const int64_t cap_ip = std::min<int64_t>(n_short_max, std::max<int64_t>(4096, (n_short_max / 4 + 3) & ~int64_t(3)));
+        h->d1_wave_cap = int32_t((cap_ip + 63) / 64);
+        h->d1_fail_cap = int32_t(n_short_max + n_short_max / 8 + 1024);
+        if ((rc = dev_alloc(h, &h->d_d1_hdr, size_t(h->d1_wave_cap)))) return rc;
+        if ((rc = dev_alloc(h, &h->d_d1_in, size_t(h->d1_in_cap)))) return rc;
+        if ((rc = dev_alloc(h, &h->d_d1_log, size_t(h->d1_log_cap)))) return rc;
+        if ((rc = dev_alloc(h, &h->d_d1_fail, size_t(h->d1_fail_cap)))) return rc;
+        if ((rc = dev_alloc(h, &h->d_d1_info, 16))) return rc;
+        if ((rc = dev_alloc(h, &h->d_d1_blk, size_t(h->d1_fail_cap / 256 + 8)))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->d_d1_info, 0, 64, h->stream));
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_zl_hdr, hdr.data(), hdr.size() * sizeof(ZlWave), hipMemcpyHostToDevice, h->stream));
     for (size_t ci = 0; ci < P.chunks.size(); ci++) {
         const Chunk &ch = P.chunks[ci];
@@ -2553,7 +2654,7 @@ struct Exec {
             if (zero)        // forward + backward + walk of the zero-distance alignments, one lane each (pr_zl.hip)
                 hipExtLaunchKernelGGL(k_zero_lane, dim3((cnt + 63) / 64), dim3(64), 0, ks, own_a, own_b, 0, h->d_descs, list, cnt,
                                       h->d_zl_hdr + zl_wave0, h->d_zl_in, h->d_zl_log, h->d_outs, a_path,
-                                      (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0);
+                                      (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0, h->d_d1_hdr ? h->d1_max_rows : 0);
             else if (q16)
                 hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);
@@ -2579,6 +2680,8 @@ struct Exec {
         n_fwd++;
         {
             const int32_t nc = n_dev ? n_all : cnt;
+            if (zero && h->d_d1_blk) ordered_fails(list, nc, h->d_fail + fail_off, h->d_cnt + slot, n_dev, ks);
+            else
             hipLaunchKernelGGL(k_collect_fails, dim3((nc + 255) / 256), dim3(256), 0, ks, list, nc, h->d_outs,
                                h->d_fail + fail_off, h->d_cnt + slot, zero ? 1 : 0, n_dev);
             // (the zero-distance level's list is consumed on the device, in place: the host only wants its length)
@@ -2705,6 +2808,48 @@ struct Exec {
             });
         } else {
             rc = walk_launch(P, list, cnt, ks, wave_walk, tag);
+        }
+        return rc;
+    }
+
+    // the rejected entries of a work list in the list's own order, padded per workgroup to groups of four (k_fails_*)
+    void ordered_fails(const int32_t *list, int32_t nc, int32_t *out, int32_t *cnt, const int32_t *n_dev, hipStream_t ks) {
+        const int nb = (nc + 255) / 256;
+        hipLaunchKernelGGL(k_fails_count, dim3(nb), dim3(256), 0, ks, list, nc, h->d_outs, h->d_d1_blk, 1, n_dev);
+        hipLaunchKernelGGL(k_fails_scan, dim3(1), dim3(1024), 0, ks, h->d_d1_blk, nb, cnt);
+        hipLaunchKernelGGL(k_fails_scatter, dim3(nb), dim3(256), 0, ks, list, nc, h->d_outs, h->d_d1_blk, out, 1, n_dev);
+    }
+
+    // ---- the distance-1 lane level between the zero-distance sweep and the in-place 16-cell round (pr_d1.hip): `list` is the
+    // zero level's device-built fail list (length *n_dev, at most n_all entries, the first `cap` of them are worked on).
+    // phase 1: headers, position words, the four passes, accept test, and the list of what is still rejected (d_d1_fail,
+    // length d_d1_info[2]); phase 4: the credit sections of what was finished here.
+    int enqueue_d1(const int32_t *list, const int32_t *n_dev, int32_t cap, int32_t n_all, hipStream_t ks, int ph, int ztag) {
+        const int nw = (cap + 63) / 64;
+        vpr_launch_stat ls;
+        memset(&ls, 0, sizeof(ls));
+        ls.threads = 64; ls.cells_per_thread = 1; ls.n_units = cap;
+        int rc = VPR_OK;
+        if (ph == 1) {
+            rc = timed(0, ls, ks, "k_prep_d1", [&] {
+                hipLaunchKernelGGL(k_d1_hdr, dim3(nw), dim3(64), 0, ks, h->d_descs, list, n_dev, cap, h->d_outs, h->d_d1_hdr);
+                hipLaunchKernelGGL(k_d1_scan, dim3(1), dim3(1024), 0, ks, h->d_d1_hdr, nw, h->d1_in_cap, h->d1_log_cap, h->d_d1_info);
+                hipLaunchKernelGGL(k_prep_d1, dim3(nw), dim3(256), 0, ks, h->dB, h->d_descs, list, n_dev, cap, h->d_outs, h->d_d1_hdr, h->d_d1_in);
+            });
+            if (rc) return rc;
+            rc = timed(1, ls, ks, "k_one_lane", [&] {
+                hipLaunchKernelGGL(k_one_lane, dim3(nw), dim3(64), 0, ks, h->d_descs, list, n_dev, cap, h->d_d1_hdr, h->d_d1_in, h->d_d1_log,
+                                   h->d_outs, reinterpret_cast<PathEnt *>(h->plan0.arena), (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0, h->d_d1_info);
+                hipLaunchKernelGGL(k_fwd_band_finish, dim3((cap + 255) / 256), dim3(256), 0, ks, list, cap, h->d_outs, D1_TAG, n_dev);
+            });
+            if (rc) return rc;
+            ordered_fails(list, n_all, h->d_d1_fail, h->d_d1_info + 2, n_dev, ks);
+        } else if (ph == 4) {
+            ls.cells_per_thread = 3;
+            rc = timed(3, ls, ks, "k_one_credit", [&] {
+                hipLaunchKernelGGL(k_one_credit, dim3(nw), dim3(64), 0, ks, h->dB, h->d_descs, list, n_dev, cap, h->d_d1_hdr, h->d_d1_log,
+                                   h->d_outs, h->d_secs, h->d_fp_table, h->d_jobs, h->d_njobs, h->jobs_cap, ztag);
+            });
         }
         return rc;
     }
@@ -3096,6 +3241,7 @@ struct Exec {
             const int64_t rbase = na_ + na_ / 16 + 256;                    // start of the retry rounds' fail region
             LL.fail_base = rbase; LS.fail_base = rbase + n_long;
             HIPCHK(h, hipMemsetAsync(h->d_cnt, 0, 8, st));
+            if (ci == 0 && h->d_d1_info) HIPCHK(h, hipMemsetAsync(h->d_d1_info, 0, 64, st));
             HIPCHK(h, hipMemsetAsync(h->d_tie_cnt, 0, 32, st));
             HIPCHK(h, hipMemsetAsync(h->d_tie_ndec, 0, TIE_DEC_SLOTS * 4, st));
             // the previous chunk has joined: its decision lists (slots of d_tie_ndec, regions of d_tie_dec) are free again
@@ -3143,12 +3289,20 @@ struct Exec {
                 const int32_t *n_dev = h->d_cnt + 1;
                 const int ztag = LV_TAG[LV_Z];
                 HIPCHK(h, hipMemsetAsync(h->d_cnt + SLOT_IP, 0, 4, s_short));
+                // Between the two: the distance-1 lane level (pr_d1.hip) on the zero level's fail list; what it leaves is a second
+                // device-built list, the in-place round's.
+                const bool d1 = h->d_d1_hdr != nullptr && cap_ip <= h->d1_wave_cap * 64;
+                const int32_t n_all1 = n_short + n_short / 16 + 64;
+                if (d1) HIPCHK(h, hipMemsetAsync(h->d_d1_info + 2, 0, 4, s_short));
                 for (int ph = 1; ph <= 4; ph <<= 1) {
                     if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, n_short, LV_Z, s_short, 1, n_long, false,
                                            ch.part_cells[1], ch.part_in[1], ch.part_dense[1], -1, ph))) return rc;
+                    if (d1 && (rc = enqueue_d1(h->d_fail + n_long, n_dev, cap_ip, n_all1, s_short, ph, ztag))) return rc;
                     // entries past cap_ip (more than a quarter of the part rejected) stay rejected and go to the ladder
-                    if ((rc = enqueue_part(P0, h->d_fail, n_long, cap_ip, LV_Q16, s_short, SLOT_IP, foff_ip, false, 0, 0, 0,
-                                           ztag, ph, n_dev, n_short + n_short / 16 + 64))) return rc;
+                    if ((rc = d1 ? enqueue_part(P0, h->d_d1_fail, 0, cap_ip, LV_Q16, s_short, SLOT_IP, foff_ip, false, 0, 0, 0,
+                                                ztag, ph, h->d_d1_info + 2, std::min<int32_t>(h->d1_fail_cap, n_all1 + n_all1 / 64 + 64))
+                                 : enqueue_part(P0, h->d_fail, n_long, cap_ip, LV_Q16, s_short, SLOT_IP, foff_ip, false, 0, 0, 0,
+                                                ztag, ph, n_dev, n_all1))) return rc;
                     if (ph == 1) post_flag(1, s_short);
                     if (ph == 2 && (rc = collect_part(1, short_list, n_short, s_short))) return rc;
                 }
@@ -3523,6 +3677,7 @@ struct Exec {
             });
             if (rc) return rc;
         }
+        if (h->d_d1_info) HIPCHK(h, hipMemcpyAsync(h->hp_tie_cnt + 24, h->d_d1_info, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipEventRecord(t1, st));
         phase(4);
         HIPCHK(h, hipStreamSynchronize(st));       // (the one wait every execute has: not counted as "blocked")
@@ -3549,6 +3704,19 @@ struct Exec {
         h->timing.n_band_retries = n_retry;
         h->timing.n_tie_replays = n_tie_jobs;
         h->timing.n_alignments_computed = int64_t(h->descs.size()) - h->n_aliased;
+        h->timing.n_lane1_seen = h->d_d1_info ? h->hp_tie_cnt[24 + 3] : 0;
+        h->timing.n_lane1_finished = h->d_d1_info ? h->hp_tie_cnt[24 + 4] : 0;
+        h->timing.n_lane1_waves_dropped = h->d_d1_info ? h->hp_tie_cnt[24 + 1] : 0;
+#ifdef D1_CLOCKS
+        if (h->debug && h->d_d1_info) {
+            int32_t ck[8];
+            (void)hipMemcpy(ck, h->d_d1_info + 8, 32, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[vpr] k_one_lane passes, longest wave (us): %.1f %.1f %.1f %.1f; pass 1 wave-rows %d of which four slots %d; pass 3 %d / %d\n", ck[0] * 0.01, ck[1] * 0.01,
+                    ck[2] * 0.01, ck[3] * 0.01, ck[4], ck[5], ck[6], ck[7]);
+        }
+#endif
+        if (h->debug && h->d_d1_info) fprintf(stderr, "[vpr] distance-1 lane level: %d waves, %d dropped, %d left; %d seen, %d finished (pass 1 %d, pass 2 %d, end cell %d)\n",
+                                              h->hp_tie_cnt[24], h->hp_tie_cnt[25], h->hp_tie_cnt[26], h->hp_tie_cnt[27], h->hp_tie_cnt[28], h->hp_tie_cnt[29], h->hp_tie_cnt[30], h->hp_tie_cnt[31]);
         h->timing.ms_wall = phase_ms[5];
         for (int k = 0; k < 6; k++) h->timing.ms_wall_phase[k] = phase_ms[k];
         h->timing.ms_host_alloc = h->hs.ms_alloc;

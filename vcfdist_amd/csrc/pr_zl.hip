@@ -66,6 +66,7 @@ __device__ __forceinline__ bool zw_bwd_allow(uint32_t w) { return !(w & ZW_PV) |
 #define ZE_BWD 64u
 
 #define ZL_MAXLEN 65000
+#define ZL_CLEAN_REJECT (-1)     // AlnOut::exit_min of a reject whose wave 0 is complete: the distance-1 lane kernel's input (pr_d1.hip)
 
 // K0z: wave-interleaved position words.  One workgroup per wave of 64 alignments.  The arrays are read the way they lie
 // (64 consecutive positions of ONE alignment per wave load), turned in LDS, and written the way the lane kernel reads them
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(256) k_prep_zl(DevBatch B, const AlnDesc *__re
         const int mlen = arr == 0 ? H.mq : (arr == 1 ? H.mr : H.mt);
         for (int x0 = 0; x0 < mlen; x0 += 64) {
             const int x = x0 + lane;
-#pragma unroll 4
+#pragma unroll 16
             for (int k = 0; k < 16; k++) {              // this wave's 16 alignments, 64 positions each
                 const int l = sub * 16 + k;
                 const int qs = s_qs[l], ts = s_ts[l];
@@ -145,7 +146,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int zl_u2;
 __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list, int n_list,
                                                   const ZlWave *__restrict__ hdr, const uint32_t *__restrict__ zin,
                                                   uint4 *__restrict__ zlog, AlnOut *__restrict__ outs, PathEnt *__restrict__ paths,
-                                                  int keep_paths) {
+                                                  int keep_paths, int d1_max_rows) {
     const int w = blockIdx.x, lane = threadIdx.x;
     const ZlWave H = hdr[w];
     const int wi = w * 64 + lane;
@@ -318,12 +319,13 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
         if (qri[0][s] == Lq - 1) endq = s;
         if (qri[1][s] == Lr - 1) endr = s;
     }
+    const bool clean = ok && Lt <= d1_max_rows;       // wave 0 is complete and without a tie: all that can be wrong now is s > 0 (pr_d1.hip)
     ok = ok && (endq >= 0 || endr >= 0);
     if (live) {
         AlnOut &o = outs[a];
         o.dist_q = (ok && endq >= 0) ? 0 : D_INF;
         o.dist_r = (ok && endr >= 0) ? 0 : D_INF;
-        o.exit_min = ok ? D_INF : 0;          // k_fwd_band_finish: accepted iff s = 0 here
+        o.exit_min = ok ? D_INF : (clean ? ZL_CLEAN_REJECT : 0);          // k_fwd_band_finish: accepted iff s = 0 here
     }
     if (!__any(ok)) return;
 
