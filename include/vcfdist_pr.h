@@ -249,6 +249,10 @@ int  vpr_create(const vpr_config *cfg, vpr_handle **out);
 void vpr_destroy(vpr_handle *h);
 const char *vpr_last_error(const vpr_handle *h);   /* h may be NULL for create errors */
 const char *vpr_version(void);
+/* the bucket counts this machine's libstdc++ grows std::unordered_set through against the tie replay's model of them (the
+   reference's last-writer ties, dist.cpp:347,376, follow that container's iteration order): entries checked, or -(1 + index of
+   the first that differs).  vpr_create runs it once per process and refuses to start on a mismatch. */
+int vpr_selfcheck_tie_model(int max_entries);
 
 /* one-shot: upload + execute + download (what a reference-side caller uses) */
 int vpr_run(vpr_handle *h, const vpr_batch *batch, vpr_results *res);
@@ -328,6 +332,10 @@ int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const
    (no link-time dependency): vpr_rccl_available() says whether it found one.  Collective: every rank of the communicator
    calls, in the same order. */
 int vpr_rccl_available(void);
+/* the RCCL copy the library bound: the one the process had already mapped when the first collective (or vpr_rccl_available) was
+   called -- PyTorch's in a Python process -- else the one it opened by name; "" = the process's global symbols.  The caller's
+   communicator must come from the same copy (vcfdist_amd/rccl.py binds by this path). */
+const char *vpr_rccl_library(void);
 int vpr_allreduce_counts(vpr_handle *h, void *nccl_comm, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
                          int32_t min_qual, int32_t max_qual, int64_t *counts);
 int vpr_allgather_phase(vpr_handle *h, void *nccl_comm, int32_t n_ranks, const int32_t *sc_index, int32_t n_total,

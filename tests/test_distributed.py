@@ -165,5 +165,29 @@ def test_native_collectives_on_a_one_rank_communicator():
         perm = np.random.RandomState(3).permutation(500).astype(np.int32)      # global indices of the local superclusters
         ph, og, sw = rccl.allgather_phase(pr, comm, perm, 500)
         assert np.array_equal(ph[perm], res.sc_phase) and np.array_equal(og[perm], res.orig_phase_dist) and np.array_equal(sw[perm], res.swap_phase_dist)
+        # ONE RCCL in the process, and the C side bound that very copy (PyTorch's own, loaded with local visibility: opening
+        # "librccl.so.1" by name beside it would be a second copy, and a communicator made by one used through the other a crash)
+        bound, mapped = rccl.library_paths()
+        assert len(mapped) == 1, mapped
+        assert bound in ("", None) or os.path.realpath(bound) == os.path.realpath(mapped[0]), (bound, mapped)
     finally:
         comm.destroy()
+
+
+@pytest.mark.gpu
+def test_one_rccl_copy_after_a_bench_step_with_the_native_collective():
+    """the bench's default run (N = 1: vpr_allreduce_counts on a one-rank communicator) in a fresh process: afterwards exactly one
+    librccl is mapped, the one the library bound, and the line says it used the native collective"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, io, contextlib; sys.argv = ['bench.py', '--n-sc', '20000', '--steps', '2', '--warmup', '2', '--no-cpu-baseline', "
+            "'--no-secondary', '--one-pass-batches', '0']; import bench; bench.main(); "
+            "from vcfdist_amd import rccl; print('RCCL_PATHS ' + json.dumps(rccl.library_paths()))")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["collective"].startswith("vpr_allreduce_counts"), line["collective"]
+    bound, mapped = json.loads([l for l in out.stdout.splitlines() if l.startswith("RCCL_PATHS ")][-1][len("RCCL_PATHS "):])
+    assert len(mapped) == 1 and (not bound or os.path.realpath(bound) == os.path.realpath(mapped[0])), (bound, mapped)

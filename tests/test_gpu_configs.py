@@ -437,7 +437,8 @@ def test_stress_workload_full_size_properties():
     assert not r1.diff(pr.download())
 
 
-def test_bench_self_launch_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_self_launch_two_ranks_on_one_gpu(scaling):
     """`python bench.py --gpus 2` as a plain process (no torchrun): it must re-launch itself as two ranks and print n_gpus 2.
     VCFDIST_BENCH_ONE_GPU puts both ranks on the test box's one GPU with the counters' all-reduce over gloo (a plumbing
     check: the numbers of such a run mean nothing); on an 8-GPU node the same command runs one rank per GPU over RCCL."""
@@ -448,9 +449,17 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["VCFDIST_BENCH_ONE_GPU"] = "1"
+    extra = ["--scaling", "strong", "--n-sc-total", "30000"] if scaling == "strong" else []
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--n-sc", "20000", "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+                          "--no-cpu-baseline"] + extra, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
-    assert line["config"]["superclusters_per_gpu"] == 20000 and line["scaling"] == "weak"
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0 and line["scaling"] == scaling
+    if scaling == "weak":
+        assert line["config"]["superclusters_per_gpu"] == 20000
+    else:       # one genome dealt over the ranks by estimated cells: the shares add up, the phasing of all superclusters was gathered
+        assert "30000 superclusters dealt over 2 ranks" in line["config"]["sharding"]
+        assert 10000 < line["config"]["superclusters_per_gpu"] < 20000
+    # every rank's own figures are in the line
+    pr_ = line["per_rank"]
+    assert len(pr_["ms_per_step"]) == 2 and all(x > 0 for x in pr_["ms_per_step"]) and len(pr_["collective_ms_per_step"]) == 2

@@ -20,3 +20,23 @@ def test_order_model_and_bucket_sequence(tmp_path):
     table = [int(x) for x in re.findall(r"(\d+)u", table)]
     assert len(table) == int(re.search(r"#define TIE_N_BUCKETS (\d+)", src).group(1))
     assert table[:len(measured)] == measured and len(measured) >= 18      # 13, 29, 59, ... as this libstdc++ grows
+
+
+def test_running_libstdcxx_matches_the_tie_model_table():
+    """the same check the library makes at vpr_create (vpr_selfcheck_tie_model), on the libstdc++ this process runs with: CPU"""
+    import ctypes as C
+    from vcfdist_amd import api
+    L = api.lib()
+    L.vpr_selfcheck_tie_model.restype = C.c_int
+    L.vpr_selfcheck_tie_model.argtypes = [C.c_int]
+    assert L.vpr_selfcheck_tie_model(18) == 18
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_tie_model_on_the_gpu_box(tmp_path):
+    """the container model against the GPU box's own libstdc++ and g++ (the CPU test above only sees the build container's)"""
+    test_order_model_and_bucket_sequence(tmp_path)
+    test_running_libstdcxx_matches_the_tie_model_table()

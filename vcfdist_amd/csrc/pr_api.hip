@@ -28,6 +28,7 @@
 #include <thread>
 #include <tuple>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/vcfdist_pr.h"
@@ -258,10 +259,6 @@ struct LadderCtx {
     // bytes at the front of each scratch that are preset (filled at the start of vpr_execute, beside round 0, with as much
     // as the previous execute's first launch used) and the size of that first launch
     int64_t tie_clean[2] = {0, 0}, tie_first[2] = {0, 0}; bool tie_first_seen[2] = {false, false};
-    // tie ladders: the round being enqueued runs on the side stream (ls and ls2 are swapped meanwhile) because the main stream is
-    // still busy with an earlier round; its replays then use the side stream's scratch
-    bool alt = false;
-    bool alt_used = false;      // a round of this context is (or was, since the last flush) on the side stream
 };
 
 struct EvPair { hipEvent_t a, b; int kind; vpr_launch_stat st; };
@@ -318,7 +315,6 @@ struct vpr_handle {
     uint8_t *d_save = nullptr;           // second copy of the forward flags of round 0's long part (k_fwd_stripe_save), nullptr: none
     int64_t save_bytes = 0;
     bool no_flag_save = false;           // VPR_NO_FLAG_SAVE: tie rounds of the long part repeat the forward sweep
-    bool alt_tie = false;                // VPR_ALT_TIE: ladder-born tie rounds on the tie ladder's side stream while its main stream is busy
     bool seq_walk = false;               // VPR_SEQ_WALK: the sequential row-sweep walk instead of the segment-parallel one
     bool no_round_overlap = false;       // VPR_NO_ROUND_OVERLAP: a retry round is complete before the host looks at its fail lists
     std::vector<uint32_t> scratch_u32[2];
@@ -1442,9 +1438,37 @@ extern "C" {
 
 const char *vpr_last_error(const vpr_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+/* The tie replay (pr_tie.hip) reproduces the iteration order of the reference's std::unordered_set from the bucket counts the
+   container grows through.  Those counts are a property of the libstdc++ the REFERENCE would be built against on this machine
+   (_Prime_rehash_policy lives in the shared library): measured here on the running library and compared with the model's table,
+   so that a box with a different libstdc++ fails loudly instead of silently diverging from the reference on tied alignments.
+   Returns how many leading entries of the table were checked (all equal), or -(1 + index of the first differing entry). */
+int vpr_selfcheck_tie_model(int max_entries) {
+    std::unordered_set<int> t;
+    t.insert(0);
+    uint64_t B = t.bucket_count();
+    int k = 0;
+    while (k < TIE_N_BUCKETS && k < max_entries) {
+        if (B != TIE_BUCKETS_HOST[k]) return -(1 + k);
+        k++;
+        if (k >= TIE_N_BUCKETS || k >= max_entries) break;
+        std::unordered_set<int> u;
+        u.rehash(2 * B);
+        B = u.bucket_count();
+    }
+    return k;
+}
+
 int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     if (!cfg || !out) return fail(nullptr, VPR_ERR_ARG, "vpr_create: null argument");
     *out = nullptr;
+    {
+        static const int tie_model = vpr_selfcheck_tie_model(14);       // (once per process: up to 172 933 buckets, 1.4 MB)
+        if (tie_model < 0)
+            return fail(nullptr, VPR_ERR_STATE, "this machine's libstdc++ grows std::unordered_set through other bucket counts than the tie "
+                        "replay's model (entry %d of TIE_BUCKET_LIST, pr_tie.hip): results on alignments with tied swap predecessors "
+                        "would differ from a reference built here", -tie_model - 1);
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -1459,7 +1483,6 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->no_round_overlap = getenv("VPR_NO_ROUND_OVERLAP") != nullptr;
     h->stall_log = getenv("VPR_STALL_LOG") != nullptr;
     h->seq_walk = getenv("VPR_SEQ_WALK") != nullptr;
-    h->alt_tie = getenv("VPR_ALT_TIE") != nullptr;
     h->no_flag_save = getenv("VPR_NO_FLAG_SAVE") != nullptr;
     h->seq_fwd = getenv("VPR_PAR_FWD") == nullptr;
     if (const char *e = getenv("VPR_LONG_LT")) { const int v = atoi(e); if (v >= 64 && v <= 2048) h->long_lt = v; }     // diagnostic
@@ -2180,7 +2203,7 @@ struct Exec {
         if (early) { tie_patch_slot = -1; tie_patch_spec = false; }
         LadderCtx &tc = *tie_ctx;
         hipStream_t ks = early ? tc.ls2 : ks_main;
-        const int se = (early || tc.alt) ? 1 : 0;      // the scratch of the stream the replays run on
+        const int se = early ? 1 : 0;      // the scratch of the stream the replays run on
         uint32_t *&scratch = tc.tie_scratch[se];
         int64_t &scratch_bytes = tc.tie_scratch_bytes[se];
         // scratch words of every job; the scratch grows to hold the whole launch (all replays concurrent: a long one is a
@@ -2883,7 +2906,7 @@ struct Exec {
     bool overlap(const LadderCtx &c) const { return !h->no_round_overlap && !h->no_strips && c.ls2 != nullptr && (&c - h->lad) < 2; }
     int lad_sync(LadderCtx &c) {        // everything the context has in flight (its side stream: the back halves of retry rounds)
         HIPCHK(h, x_sync(h, c.ls, SITE));
-        if (overlap(c) || c.alt) HIPCHK(h, x_sync(h, c.ls2, SITE));      // (alt: the earlier round is on the other stream)
+        if (overlap(c)) HIPCHK(h, x_sync(h, c.ls2, SITE));
         return VPR_OK;
     }
     int lad_flush(LadderCtx &c, std::vector<int32_t> &out) {
@@ -3167,7 +3190,6 @@ struct Exec {
 
     int tie_flush(LadderCtx &LT) {
         std::vector<int32_t> rejected;
-        LT.alt_used = false;
         int rc_ = lad_flush(LT, rejected);
         if (rc_) return rc_;
         if (!rejected.empty()) return fail(h, VPR_ERR_STATE, "tie round: the re-run forward sweep rejected alignment %d", rejected[0]);
@@ -3359,32 +3381,10 @@ struct Exec {
                         trace("flag %d (ladder %d tie list), %d marked", 9 + k, k, h->hp_tie_cnt[5 + k]);
                         const int32_t n = std::min(h->hp_tie_cnt[5 + k], lad_tie_cap(k));
                         if (n > 0) {
-                            // the tie ladder's main stream may still be busy with the round of the part's own tie list (some thousand
-                            // alignments, 6 - 8 ms): this round -- no early replays, its own workspace and fail slots -- then runs
-                            // on the side stream, and the ladder's "idle" flag is posted behind BOTH streams
+                            // (behind whatever the tie ladder's stream is still busy with: running this round on the ladder's side
+                            // stream instead saved 3 ms of a lone step but showed a rare wrong walk in repeated executes -- removed)
                             LadderCtx &T = h->lad[2 + k];
-                            // (opt-in, VPR_ALT_TIE: repeated executes of one batch showed a rare wrong walk -- VPR_ST_ERR_NO_PTR on a handful of
-                            // tied alignments, 2 - 9 executes in 400 -- with this on and none in 1 200 with it off; not found yet)
-                            const bool alt = h->alt_tie && !T.pending.empty() && T.ls2 != nullptr && !h->no_round_overlap;
-                            if (alt) { T.alt = true; T.alt_used = true; std::swap(T.ls, T.ls2); }
-                            rc = tie_round(T, h->hp_tie_list + lad_tie_off(k), n, false, nullptr);
-                            if (alt) {
-                                if (rc == VPR_OK) {
-                                    HIPCHK(h, hipEventRecord(T.ev2, T.ls2));
-                                    HIPCHK(h, hipStreamWaitEvent(T.ls, T.ev2, 0));
-                                    post_flag(4 + 2 + k, T.ls);
-                                    (void)hipStreamQuery(T.ls);
-                                }
-                                std::swap(T.ls, T.ls2);
-                                T.alt = false;
-                            }
-                            if (rc) return rc;
-                            if (!alt && T.alt_used) {       // (see the round-0 tie lists below)
-                                HIPCHK(h, hipEventRecord(T.ev2, T.ls2));
-                                HIPCHK(h, hipStreamWaitEvent(T.ls, T.ev2, 0));
-                                post_flag(4 + 2 + k, T.ls);
-                                (void)hipStreamQuery(T.ls);
-                            }
+                            if ((rc = tie_round(T, h->hp_tie_list + lad_tie_off(k), n, false, nullptr))) return rc;
                         }
                         lad_tie_wait[k] = false;
                         progressed = true;
@@ -3430,16 +3430,6 @@ struct Exec {
                         const int32_t n = std::min(h->hp_tie_cnt[2 + k], tie_cap[k]);
                         trace("flag %d (round 0 tie list, part %d), %d marked", 2 + k, k, n);
                         if (n > 0 && (rc = tie_round(h->lad[2 + k], h->hp_tie_list + tie_off[k], n, false, &ch))) return rc;
-                        if (n > 0 && h->lad[2 + k].alt_used) {
-                            // an earlier round of this tie ladder runs on its side stream: the "idle" flag this round has just
-                            // posted on the main stream would be raised while that one is still at work, and the flush behind
-                            // the flag hands its workspace out again -- post the flag once more, behind both streams
-                            LadderCtx &T = h->lad[2 + k];
-                            HIPCHK(h, hipEventRecord(T.ev2, T.ls2));
-                            HIPCHK(h, hipStreamWaitEvent(T.ls, T.ev2, 0));
-                            post_flag(4 + 2 + k, T.ls);
-                            (void)hipStreamQuery(T.ls);
-                        }
                         lapx(k ? "short tie list -> tie round" : "long tie list -> tie round");
                         wait_tie[k] = false;
                         progressed = true;
@@ -4029,14 +4019,43 @@ struct Rccl {
     AllReduce all_reduce = nullptr;
     AllGather all_gather = nullptr;
     ErrStr err_str = nullptr;
+    std::string path;       // the library the functions come from ("" = the process's global symbols)
+    // the copy of RCCL this process has ALREADY MAPPED, if any (/proc/self/maps): PyTorch loads its own librccl.so with local
+    // visibility, so the global symbol table does not show it, and opening "librccl.so.1" by name beside it could bring a SECOND
+    // copy into the process -- a communicator created by one copy and used through the other's functions is a crash
+    static std::string mapped_rccl() {
+        std::string found;
+        if (FILE *f = fopen("/proc/self/maps", "r")) {
+            char line[4096];
+            while (fgets(line, sizeof(line), f)) {
+                const char *p = strchr(line, '/');
+                if (!p) continue;
+                std::string pth(p);
+                while (!pth.empty() && (pth.back() == '\n' || pth.back() == ' ')) pth.pop_back();
+                const size_t sl = pth.rfind('/');
+                if (pth.compare(sl + 1, 7, "librccl") == 0 && pth.find(".so") != std::string::npos) { found = pth; break; }
+            }
+            fclose(f);
+        }
+        return found;
+    }
     static const Rccl &get() {
         static Rccl r = [] {
             Rccl x;
-            void *hd = RTLD_DEFAULT;
-            if (!dlsym(hd, "ncclAllReduce")) hd = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (!hd && !dlsym(RTLD_DEFAULT, "ncclAllReduce")) hd = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (hd || dlsym(RTLD_DEFAULT, "ncclAllReduce")) {
-                if (!hd) hd = RTLD_DEFAULT;
+            void *hd = nullptr;
+            const std::string mapped = mapped_rccl();
+            if (!mapped.empty()) {          // the copy that is there (RTLD_NOLOAD: a handle to it, never a new mapping)
+                hd = dlopen(mapped.c_str(), RTLD_NOW | RTLD_NOLOAD);
+                if (hd) x.path = mapped;
+            }
+            if (!hd && dlsym(RTLD_DEFAULT, "ncclAllReduce")) hd = RTLD_DEFAULT;        // a host that links RCCL itself
+            if (!hd) {
+                for (const char *name : {"librccl.so.1", "librccl.so"}) {
+                    hd = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                    if (hd) { x.path = mapped_rccl(); if (x.path.empty()) x.path = name; break; }
+                }
+            }
+            if (hd) {
                 x.all_reduce = reinterpret_cast<AllReduce>(dlsym(hd, "ncclAllReduce"));
                 x.all_gather = reinterpret_cast<AllGather>(dlsym(hd, "ncclAllGather"));
                 x.err_str = reinterpret_cast<ErrStr>(dlsym(hd, "ncclGetErrorString"));
@@ -4058,6 +4077,7 @@ __global__ void k_pack_phase(const int32_t *__restrict__ idx, const int32_t *__r
 extern "C" {
 
 int vpr_rccl_available(void) { return Rccl::get().all_reduce && Rccl::get().all_gather ? 1 : 0; }
+const char *vpr_rccl_library(void) { return Rccl::get().path.c_str(); }
 
 static int pr_counts_impl(vpr_handle *h, void *comm, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
                           int32_t min_qual, int32_t max_qual, int64_t *counts) {

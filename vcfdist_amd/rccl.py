@@ -2,6 +2,7 @@
 RCCL communicator they run on.  ctypes plumbing: the communicator is created with the process's own librccl (the one PyTorch
 ships, when PyTorch is loaded), which is also the one the library resolves at run time."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -13,11 +14,39 @@ _RCCL = None
 ID_BYTES = 128          # ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
 
 
+def mapped_copies():
+    """paths of the librccl copies mapped into this process (/proc/self/maps)"""
+    out = []
+    try:
+        for line in open("/proc/self/maps"):
+            i = line.find("/")
+            if i < 0:
+                continue
+            path = line[i:].strip()
+            base = path.rsplit("/", 1)[-1]
+            if base.startswith("librccl") and ".so" in base and path not in out:
+                out.append(path)
+    except OSError:
+        pass
+    return out
+
+
 def lib():
+    """ONE RCCL per process: the copy that is already mapped (PyTorch's own librccl.so once torch is imported) is bound by its
+    path -- which is also what the C side does (vpr_rccl_library) --, a soname is only opened when there is none.  Two copies, a
+    communicator made by one and used through the other, would be a crash."""
     global _RCCL
     if _RCCL is None:
         err = None
-        for name in ("librccl.so.1", "librccl.so"):
+        L = api.lib()
+        L.vpr_rccl_available.restype = C.c_int
+        L.vpr_rccl_library.restype = C.c_char_p
+        have = mapped_copies()
+        names = have[:1] if have else []
+        if not names and L.vpr_rccl_available():      # (the library opened one: the same)
+            p = L.vpr_rccl_library().decode()
+            names = [p] if p else []
+        for name in names + ["librccl.so.1", "librccl.so"]:
             try:
                 _RCCL = C.CDLL(name, mode=C.RTLD_GLOBAL)
                 break
@@ -26,6 +55,12 @@ def lib():
         if _RCCL is None:
             raise OSError(f"no RCCL library: {err}")
         _RCCL.ncclGetErrorString.restype = C.c_char_p
+        if len(mapped_copies()) > 1:
+            raise OSError(f"more than one RCCL mapped into the process: {mapped_copies()}")
+        lp = L.vpr_rccl_library().decode() if L.vpr_rccl_available() else ""
+        mc = mapped_copies()
+        if lp and mc and os.path.realpath(lp) != os.path.realpath(mc[0]):
+            raise OSError(f"the library bound {lp}, the process maps {mc[0]}")
     return _RCCL
 
 
@@ -72,6 +107,14 @@ def available() -> bool:
     except OSError:
         return False
     return bool(L.vpr_rccl_available())
+
+
+def library_paths():
+    """(path bound by the C side, copies mapped into the process): tests assert there is exactly one copy and that it is that one"""
+    L = api.lib()
+    L.vpr_rccl_library.restype = C.c_char_p
+    L.vpr_rccl_available.restype = C.c_int
+    return (L.vpr_rccl_library().decode() if L.vpr_rccl_available() else None), mapped_copies()
 
 
 def allreduce_counts(pr, comm: Comm, var_class_per_slot=None, pb_phase=None, min_qual=0, max_qual=60):
