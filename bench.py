@@ -133,7 +133,23 @@ def cpu_baseline(batch, target_s=15.0, probe=True):
         idx = np.flatnonzero(octv == k)
         # (superclusters of 8 192+ bases: the port's dense matrices take gigabytes per alignment -- at most eight at a time)
         thr_k = threads if 2 ** k < 8192 else min(threads, 8)
-        m = int(min(len(idx), max(thr_k if len(idx) >= thr_k else 1, budget * thr_k / est(k))))
+        est_k = est(k)
+        if not probe and 2 ** k >= 1024:
+            # (the secondary workloads: the cost model above is for small variants -- with SV-sized indels a supercluster costs ten
+            # times as much --, so one supercluster of the stratum is timed first and the sample is sized from it; where that one
+            # alone uses up the stratum's budget it IS the sample)
+            one = np.sort(rng.choice(idx, size=1))
+            t0 = time.perf_counter()
+            oracle_lib.run(batch.subset(one))
+            est_k = time.perf_counter() - t0
+            if est_k >= budget or len(idx) == 1:
+                est_total += len(idx) * est_k / min(thr_k, len(idx))
+                n_samp += 1
+                strata.append({"octave": f"[{2 ** k}, {2 ** (k + 1)})", "superclusters": int(len(idx)), "sampled": 1, "threads": 1,
+                               "seconds": round(est_k, 3), "est_batch_seconds": round(len(idx) * est_k / min(thr_k, len(idx)), 3),
+                               "note": f"one supercluster on one thread; the stratum's time on {min(thr_k, len(idx))} threads is extrapolated"})
+                continue
+        m = int(min(len(idx), max(thr_k if len(idx) >= thr_k else 1, budget * thr_k / est_k)))
         samp = np.sort(rng.choice(idx, size=m, replace=False))
         parts = [batch.subset(c) for c in np.array_split(samp, min(thr_k, m)) if len(c)]
         t0 = time.perf_counter()

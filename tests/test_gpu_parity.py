@@ -120,9 +120,10 @@ def test_sv_sized_sections_use_deferred_edit_distance():
     ref = "".join(rng.choice(list("ACGT"), L))
     ins = "".join(rng.choice(list("ACGT"), 300))
     S, I, D = A.TYPE_SUB, A.TYPE_INS, A.TYPE_DEL
-    # truth: 200-base deletion; query: a slightly different 190-base deletion nearby + a 300-base insertion
-    t = [(400, D, ref[400:600], "", 40.0), (900, I, "", ins, 40.0)]
-    q = [(405, D, ref[405:595], "", 30.0), (900, I, "", ins[:280], 30.0)]
+    # truth: a 200-base deletion with a 300-base insertion right behind it (ONE sync section whose reference and truth segments
+    # are both longer than the inline limit); query: a slightly different 190-base deletion + 280 bases of the insertion
+    t = [(400, D, ref[400:600], "", 40.0), (600, I, "", ins, 40.0)]
+    q = [(405, D, ref[405:595], "", 30.0), (600, I, "", ins[:280], 30.0)]
     v = A.Variants.from_sites([ref], [dict(ctg=0, beg=300, end=1100, vars=[q, q, t, t])])
     batch = api.batch_from_variants(v)
     got, want, ntie, pr = compare(batch)

@@ -60,11 +60,31 @@ WARN_TEXT = (       # dist.cpp:1203-1223, raised per alignment as VPR_ST_WARN_* 
 )
 
 
-def print_warnings(name, aln_status):
-    """the reference's WARN lines for the conditions calc_prec_recall flags (one line per alignment and condition)"""
+ERR_TEXT = ((A.ST_ERR_LIMIT, "exceeds an implementation limit of the GPU path (more than eight swap sources on one position, or an alignment "
+                             "the dense kernels cannot place)"),
+            (A.ST_ERR_NO_PTR, "ended in a walk without a path pointer"), (A.ST_ERR_UNFINISHED, "was left unfinished"))
+
+
+def print_warnings(name, aln_status, strict=False):
+    """the reference's WARN lines for the conditions calc_prec_recall flags (one line per alignment and condition), and -- LOUDLY --
+    the alignments this implementation did NOT evaluate (VPR_ST_ERR_*: the reference has no such limits and evaluates them).
+    Their variants stay ERRTYPE_UN and are missing from the counts; their superclusters' phasing is taken from what was
+    evaluated.  -> number of superclusters with such an alignment; with strict the run ends instead (--strict)."""
     for bit, text in WARN_TEXT:
         for a in np.nonzero(aln_status & np.uint32(bit))[0]:
             print("[WARN  vcfdist] " + text % (name, int(a) // 4), file=sys.stderr)
+    bad_sc = set()
+    for bit, text in ERR_TEXT:
+        idx = np.nonzero(aln_status & np.uint32(bit))[0]
+        if len(idx) == 0:
+            continue
+        scs = sorted({int(a) // 4 for a in idx})
+        bad_sc.update(scs)
+        print(f"[WARN  vcfdist_amd] contig '{name}': {len(idx)} alignment(s) in {len(scs)} supercluster(s) {text}: NOT EVALUATED -- their variants are "
+              f"left out of every count and table (superclusters {', '.join(map(str, scs[:12]))}{' ...' if len(scs) > 12 else ''})", file=sys.stderr)
+    if bad_sc and strict:
+        raise SystemExit(f"ERROR: contig '{name}': {len(bad_sc)} supercluster(s) not evaluated (--strict)")
+    return len(bad_sc)
 
 
 def prepare_contig(name, seq, slots, args, device=0):
@@ -111,8 +131,15 @@ def evaluate_contig(prep, args, device=0, part=None):
     pr = api.PrecisionRecall(cfg)
     phase_sets = transfer_phase_sets(slots, cl, sc)
     cls = [S.var_class(h.type, h.ref_len, h.alt_len, args.sv_threshold) for h in haps]
+    def mask_unevaluated(r):
+        """a supercluster with an alignment the GPU path did not evaluate (VPR_ST_ERR_*): its phase distances come from alignments
+        that were cut short -- it takes no side in the contig's phasing (print_warnings reports it)"""
+        bad = np.unique(np.nonzero(r.aln_status & np.uint32(A.ST_ERR_LIMIT | A.ST_ERR_NO_PTR | A.ST_ERR_UNFINISHED))[0] // 4)
+        if len(bad):
+            r.sc_phase[bad] = A.PHASE_NONE
     if part is None:
         res = pr.run(prep["batch"])
+        mask_unevaluated(res)
         pb, sw, fl = S.phase(res.sc_phase, phase_sets)
         counts = S.pr_counts(pr, cls, pb, args.min_qual, args.max_qual)
     else:
@@ -121,7 +148,16 @@ def evaluate_contig(prep, args, device=0, part=None):
         whole = prep["batch"]
         idx = shard.deal(shard.estimate_cells(whole), world)[rank]
         mine = whole.subset(idx)
-        local = pr.run(mine) if len(idx) else A.Results(0, [0, 0, 0, 0])
+        # (every rank enters the collectives below: a rank whose share fails tells the others first, and all end together --
+        # a lone SystemExit would leave the rest waiting in all_gather for ever)
+        err = None
+        try:
+            local = pr.run(mine) if len(idx) else A.Results(0, [0, 0, 0, 0])
+        except api.VprError as e:
+            err, local = e, None
+        if shard.any_rank(err is not None, device=cdev):
+            raise api.VprError(str(err) if err is not None else "another rank's share of the contig failed")
+        mask_unevaluated(local)
         sc_phase, _, _ = shard.allgather_phase(local, idx, sc.n, device=cdev)
         pb, sw, fl = S.phase(sc_phase, phase_sets)
         if len(idx):
@@ -132,7 +168,7 @@ def evaluate_contig(prep, args, device=0, part=None):
         res = shard.gather_results(local, idx, whole.var_off, device=cdev)
         if rank != 0:
             return counts, sc.n, (sc.clusters, sc, res, phase_sets, pb, sw, fl)
-    print_warnings(name, res.aln_status)
+    print_warnings(name, res.aln_status, strict=getattr(args, "strict", False))
     print(f"[vcfdist_amd] {name}: {sum(len(h.pos) for h in haps)} hap-variants, {sum(c.n for c in cl)} clusters, {sc.n} superclusters, "
           f"{len(sw)} switch / {len(fl)} flip errors", file=sys.stderr)
     return counts, sc.n, (sc.clusters, sc, res, phase_sets, pb, sw, fl)
@@ -194,6 +230,10 @@ def main(argv=None):
     ap.add_argument("--reach-min-gap", type=int, default=10)
     ap.add_argument("-p", "--prefix", default="./", help="prefix of the output files")
     ap.add_argument("-n", "--no-output-files", action="store_true")
+    ap.add_argument("--strict", action="store_true",
+                    help="end with an error when a supercluster exceeds an implementation limit of the GPU path (more than eight swap "
+                         "sources on one position, an alignment the dense kernels cannot place) instead of warning and leaving its "
+                         "variants out of the counts and tables")
     ap.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK, else 0)")
     ap.add_argument("--shard", default="superclusters", choices=["superclusters", "contigs"],
                     help="several ranks (torch.distributed.run, one per GPU): deal every contig's superclusters over the ranks "

@@ -472,7 +472,10 @@ hipError_t x_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
         size_t fr = 0, tt = 0;
         // optional growth during an execute (a ladder's larger workspace, a replay scratch that would hold a whole launch instead of
         // sub-batches) leaves a 32nd of the device to what an execute MUST still get (the replay stamps of one large tied alignment)
-        int64_t reserve = dev_reserve_bytes();
+        // (the reserve is about workspaces, arenas and their growth: a small array of an upload -- offsets, counters, lists -- is
+        // neither what exhausts the device nor worth a hipMemGetInfo call each; on a device shared with other handles such an
+        // array used to fail with less than the reserve free)
+        int64_t reserve = bytes >= (size_t(64) << 20) || (h && h->soft_alloc) ? dev_reserve_bytes() : 0;
         if (reserve > 0 && hipMemGetInfo(&fr, &tt) == hipSuccess) {
             if (h && h->soft_alloc) reserve = std::max<int64_t>(reserve, int64_t(tt) / 32);
         }
@@ -1434,6 +1437,13 @@ int prep_zero_lane(vpr_handle *h) {
 
 }  // namespace
 
+namespace {
+// page-locked result blocks handed out by vpr_results_alloc (base -> bytes), until vpr_host_free: vpr_download takes its
+// single-copy path only into one of these
+std::mutex g_result_blocks_m;
+std::unordered_map<void *, size_t> g_result_blocks;
+}  // namespace
+
 extern "C" {
 
 const char *vpr_last_error(const vpr_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -1933,8 +1943,12 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
             if (ch.n_long > 0)
                 need = std::max<int64_t>(need, ch.n_long < ch.count ? int64_t(h->plan0.off128[size_t(ch.work_off + ch.n_long)]) * 128 : h->plan0.arena_used);
         if (need > 0 && need <= (int64_t(1) << 30)) {
-            if ((rc = dev_alloc(h, &h->d_save, size_t(need) + 256))) return rc;
-            h->save_bytes = need;
+            // (optional: without the copy the tie rounds of the long part repeat the forward sweep, as with VPR_NO_FLAG_SAVE)
+            h->soft_alloc = true;
+            const int rc_save = dev_alloc(h, &h->d_save, size_t(need) + 256);
+            h->soft_alloc = false;
+            if (rc_save == VPR_OK) h->save_bytes = need;
+            else { h->d_save = nullptr; h->err.clear(); (void)hipGetLastError(); }
         }
     }
     h->level0 = h->level;
@@ -3857,8 +3871,15 @@ int vpr_download(vpr_handle *h, vpr_results *res) {
     // batches of one size keeps its block: the columns lie at the same offsets) -- takes ONE copy: every pointer of *res has to
     // sit where the device's column sits in the result region.
     uint8_t *mirror = h->res_mirror;
-    if (!mirror && h->res_bytes && na && res->aln_dist)
-        mirror = reinterpret_cast<uint8_t *>(res->aln_dist) - (reinterpret_cast<const uint8_t *>(R.aln_dist) - h->res_dev);
+    if (!mirror && h->res_bytes && na && res->aln_dist) {
+        // (an inferred base counts only if it IS a block vpr_results_alloc handed out, alive and at least as large as the result
+        // region: a caller's own contiguous layout without the trailing padding, or a smaller block of an earlier upload, must
+        // not be overrun by the single copy)
+        uint8_t *cand = reinterpret_cast<uint8_t *>(res->aln_dist) - (reinterpret_cast<const uint8_t *>(R.aln_dist) - h->res_dev);
+        std::lock_guard<std::mutex> g(g_result_blocks_m);
+        const auto it = g_result_blocks.find(cand);
+        if (it != g_result_blocks.end() && it->second >= h->res_bytes) mirror = cand;
+    }
     if (mirror && h->res_bytes) {
         auto at = [&](const void *dst, const void *src) {
             return static_cast<const uint8_t *>(dst) - mirror == static_cast<const uint8_t *>(src) - h->res_dev;
@@ -3931,6 +3952,7 @@ int vpr_results_alloc(vpr_handle *h, vpr_results *res, void **block) {
             res->callq[s][w] = reinterpret_cast<float *>(mir(R.v[s][w].callq));
         }
     h->res_mirror = m;
+    { std::lock_guard<std::mutex> g(g_result_blocks_m); g_result_blocks[p] = h->res_bytes; }
     *block = p;
     return VPR_OK;
 }
@@ -3948,7 +3970,10 @@ void *vpr_host_alloc(size_t bytes) {
 }
 
 void vpr_host_free(void *p) {
-    if (p) (void)hipHostFree(p);
+    if (p) {
+        { std::lock_guard<std::mutex> g(g_result_blocks_m); g_result_blocks.erase(p); }
+        (void)hipHostFree(p);
+    }
 }
 
 int vpr_get_tally(const vpr_handle *h, int64_t out[6]) {

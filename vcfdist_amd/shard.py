@@ -164,3 +164,14 @@ def deal_contigs(weights, world: int):
         out[r].append(k)
         load[r] += int(weights[k])
     return [sorted(o) for o in out]
+
+
+def any_rank(flag: bool, device=None) -> bool:
+    """True on every rank iff `flag` is set on at least one (one all-reduce, MAX); no process group: the flag itself"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
