@@ -463,3 +463,35 @@ def test_bench_self_launch_two_ranks_on_one_gpu(scaling):
     # every rank's own figures are in the line
     pr_ = line["per_rank"]
     assert len(pr_["ms_per_step"]) == 2 and all(x > 0 for x in pr_["ms_per_step"]) and len(pr_["collective_ms_per_step"]) == 2
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_sc=30000, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=3000, seed=51),        # long part + short part
+    dict(n_sc=3000, len_a=5, len_b=200, len_min=5, len_max=200, seed=52, var_per_base=0.05),      # no long part
+    dict(n_sc=7, len_a=1100, len_b=1500, len_min=1100, len_max=1500, seed=53),                    # long part only
+])
+def test_device_planner_equals_the_host_planner(kw, monkeypatch):
+    """round 0's plan built on the device (radix sort by rows, scan of the workspace needs, wave headers: plan0_device) against
+    make_plan on the host (VPR_HOST_PLAN): same results, same walks (vpr_download_path looks an alignment's place in the plan
+    up), from host arrays and from variant tables"""
+    syn = api.Synth(**kw)
+    batch = syn.batch()
+    cfg = A.default_config(flags=A.CFG_KEEP_PATHS)
+    pr_d = api.PrecisionRecall(cfg)
+    got_d = pr_d.run(batch)
+    monkeypatch.setenv("VPR_HOST_PLAN", "1")
+    pr_h = api.PrecisionRecall(cfg)
+    got_h = pr_h.run(batch)
+    monkeypatch.delenv("VPR_HOST_PLAN")
+    assert not got_d.diff(got_h)
+    td, th = pr_d.timing(), pr_h.timing()
+    assert td.cells_touched == th.cells_touched and td.n_band_retries == th.n_band_retries
+    rng = np.random.RandomState(5)
+    for sc in rng.choice(batch.n_sc, size=min(batch.n_sc, 40), replace=False):
+        for aln in range(4):
+            a, b = pr_d.path(int(sc), aln), pr_h.path(int(sc), aln)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (sc, aln)
+    pr_v = api.PrecisionRecall()
+    pr_v.upload_variants(syn.struct, batch)
+    pr_v.execute()
+    assert not got_d.diff(pr_v.download())

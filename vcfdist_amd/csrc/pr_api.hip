@@ -33,6 +33,7 @@
 
 #include "../../include/vcfdist_pr.h"
 #include "pr_device.h"
+#include "pr_plan.h"
 extern "C" int vpr_batch_skeleton_from_variants(const vpr_variants *v, vpr_owned_batch **out);   // generate.cpp
 #include "pr_kernels.hip"
 #include "pr_band.hip"
@@ -209,6 +210,15 @@ struct BaseDescs {
     bool empty() const { return n == 0; }
     void clear() { n = 0; }
     AlnDesc operator[](size_t a) const { return base_desc(O, int64_t(a)); }
+    // the three lengths of alignment a alone (base_desc also sums variant offsets and places the section table: a planning
+    // pass over four million alignments only wants these)
+    void lens(size_t a, int32_t &Lq, int32_t &Lr, int32_t &Lt) const {
+        const size_t sc = a >> 2;
+        const int i = int(a & 3), qs = i >> 1, ts = 2 + (i & 1);
+        Lq = int32_t(O.hap_off[qs][sc + 1] - O.hap_off[qs][sc]);
+        Lt = int32_t(O.hap_off[ts][sc + 1] - O.hap_off[ts][sc]);
+        Lr = int32_t(O.ref_off[sc + 1] - O.ref_off[sc]);
+    }
 };
 
 struct Launch { int cls; int64_t work_off; int32_t count; };   // dense: one k_fwd/k_bwd launch of a class
@@ -374,6 +384,7 @@ struct vpr_handle {
     // length of that list}
     ZlWave *d_d1_hdr = nullptr; uint32_t *d_d1_in = nullptr; uint4 *d_d1_log = nullptr; int32_t *d_d1_fail = nullptr, *d_d1_info = nullptr;
     int32_t *d_d1_blk = nullptr;                              // per-workgroup counts / offsets of the ordered fail lists (k_fails_*)
+    hipEvent_t ev_offsets = nullptr;                          // upload: the batch's offsets are on the device (plan0_device waits for it)
     int64_t d1_in_cap = 0, d1_log_cap = 0;
     int32_t d1_wave_cap = 0, d1_fail_cap = 0;
     int32_t d1_max_rows = 256;                                // rejects of more truth rows stay with the 16-cell kernels (VPR_D1_MAX_ROWS)
@@ -422,6 +433,91 @@ __global__ void k_build_plan(BatchOffsets O, const int32_t *__restrict__ work, c
     (void)window_layout(d, dl, int64_t(off128[k]) * 128, tag_or);
     plan_descs[k] = d;
     descs[a] = d;
+}
+
+// ---------------------------------------------------------------------------
+// Planning round 0 on the device (plan0_device below): keys, needs, the plan order's offsets, the lane level's wave headers.
+// ---------------------------------------------------------------------------
+// per alignment a (input order): sort key = truth rows of a short alignment, 0xffff for a long one (they sort to the front and
+// are then replaced by the host's order: longest matrices first), its own id, and its workspace need in 128-byte units
+__global__ void k_plan_keys(BatchOffsets O, int n_al, int lv, int long_lt, uint16_t *__restrict__ keys, int32_t *__restrict__ vals,
+                            uint32_t *__restrict__ need) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_al) return;
+    const int sc = a >> 2, i = a & 3, qs = i >> 1, ts = 2 + (i & 1);
+    AlnDesc d{};
+    d.Lq = int32_t(O.hap_off[qs][sc + 1] - O.hap_off[qs][sc]);
+    d.Lt = int32_t(O.hap_off[ts][sc + 1] - O.hap_off[ts][sc]);
+    d.Lr = int32_t(O.ref_off[sc + 1] - O.ref_off[sc]);
+    d.path_cap = d.Lq + d.Lr + d.Lt + 4;
+    const int dl = (lv <= LV_Q16 && d.Lt >= long_lt) ? 2 /* LONG_LV */ : lv;
+    keys[a] = d.Lt >= long_lt ? uint16_t(0xffff) : uint16_t(d.Lt);
+    vals[a] = a;
+    need[a] = uint32_t(window_layout(d, dl, 0, 0) / 128);
+}
+__global__ void k_plan_gather(const int32_t *__restrict__ order, const uint32_t *__restrict__ need, uint32_t *__restrict__ out,
+                              int32_t *__restrict__ pos, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int a = order[k];
+    out[k] = need[a];
+    pos[a] = k;          // (the inverse: an alignment's place in the plan, vpr_handle::plan0_pos)
+}
+// wave headers of the lane level's short part (order: the part's work list): largest lengths per 64 alignments ...
+__global__ void __launch_bounds__(64) k_zl_hdr(BatchOffsets O, const int32_t *__restrict__ order, int n_short, ZlWave *__restrict__ hdr) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const int j = w * 64 + lane;
+    int lq = 0, lr = 0, lt = 0;
+    if (j < n_short) {
+        const int a = order[j];
+        const int sc = a >> 2, i = a & 3, qs = i >> 1, ts = 2 + (i & 1);
+        lq = int32_t(O.hap_off[qs][sc + 1] - O.hap_off[qs][sc]);
+        lt = int32_t(O.hap_off[ts][sc + 1] - O.hap_off[ts][sc]);
+        lr = int32_t(O.ref_off[sc + 1] - O.ref_off[sc]);
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        lq = max(lq, __shfl_xor(lq, o)); lr = max(lr, __shfl_xor(lr, o)); lt = max(lt, __shfl_xor(lt, o));
+    }
+    if (lane == 0) {
+        ZlWave W;
+        W.in_off = 0; W.log_off = 0; W.mq = lq; W.mr = lr; W.mt = lt; W.pad = 0;
+        hdr[w] = W;
+    }
+}
+// ... and their offsets (one workgroup).  totals: {position words, log units (16 B), largest length}
+__global__ void __launch_bounds__(1024) k_zl_scan(ZlWave *__restrict__ hdr, int n_waves, int64_t *__restrict__ totals) {
+    __shared__ int64_t s_in[1024], s_log[1024];
+    __shared__ int s_len;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_len = 0;
+    const int per = (n_waves + 1023) / 1024;
+    const int b = min(n_waves, tid * per), e = min(n_waves, b + per);
+    int64_t si = 0, sl = 0;
+    int lm = 0;
+    for (int k = b; k < e; k++) {
+        const ZlWave W = hdr[k];
+        si += 64 * (int64_t(W.mq) + W.mr + W.mt); sl += 80 * int64_t(W.mt);
+        lm = max(lm, max(W.mq, max(W.mr, W.mt)));
+    }
+    s_in[tid] = si; s_log[tid] = sl;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int64_t ai = tid >= o ? s_in[tid - o] : 0, al = tid >= o ? s_log[tid - o] : 0;
+        __syncthreads();
+        s_in[tid] += ai; s_log[tid] += al;
+        __syncthreads();
+    }
+    int64_t oi = s_in[tid] - si, ol = s_log[tid] - sl;
+    for (int k = b; k < e; k++) {
+        ZlWave W = hdr[k];
+        W.in_off = oi; W.log_off = ol;
+        oi += 64 * (int64_t(W.mq) + W.mr + W.mt); ol += 80 * int64_t(W.mt);
+        hdr[k] = W;
+    }
+    if (lm) atomicMax(&s_len, lm);
+    __syncthreads();
+    if (tid == 1023) { totals[0] = s_in[1023]; totals[1] = s_log[1023]; totals[2] = s_len; }
 }
 
 int fail(vpr_handle *h, int code, const char *fmt, ...) {
@@ -1112,8 +1208,10 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
     par_for(n_al, [&](size_t b, size_t e, int tid) {
         Sums &S1 = sums1[size_t(tid)];
         std::vector<int32_t> &bigs = big_of[size_t(tid)];
+        AlnDesc d{};
         for (size_t i = b; i < e; i++) {
-            AlnDesc d = h->descs[size_t(alns[i])];
+            h->descs.lens(size_t(alns[i]), d.Lq, d.Lr, d.Lt);       // (all this pass looks at: window_layout reads the lengths and path_cap)
+            d.path_cap = d.Lq + d.Lr + d.Lt + 4;
             lt[i] = d.Lt; lq[i] = d.Lq; lr[i] = d.Lr;
             const int dl = level_of(d);
             if (lv == LV_DENSE || d.Lt >= LLT) bigs.push_back(int32_t(i));
@@ -1352,6 +1450,8 @@ int make_plan(vpr_handle *h, const std::vector<int32_t> &alns, int lv, Plan &P, 
 }
 
 
+int zl_finish(vpr_handle *h, size_t n_waves, int64_t in_words, int64_t log_max, int64_t in_chunk_max, int64_t n_short_max, int32_t len_max);
+
 // Zero-distance lane kernel (pr_zl.hip): cut the short part of every chunk of plan 0 into waves of 64 alignments, size
 // each wave's interleaved input block and log blocks, and write the position words (k_prep_zl; behind K0 and the
 // descriptor scatter on the upload stream).
@@ -1375,8 +1475,9 @@ int prep_zero_lane(vpr_handle *h) {
                 ZlWave W;
                 memset(&W, 0, sizeof(W));
                 for (int64_t j = int64_t(wv) * 64; j < std::min<int64_t>(n_short, int64_t(wv) * 64 + 64); j++) {
-                    const AlnDesc d = h->descs[size_t(P.work[size_t(first + j)])];
-                    W.mq = std::max(W.mq, d.Lq); W.mr = std::max(W.mr, d.Lr); W.mt = std::max(W.mt, d.Lt);
+                    int32_t Lq, Lr, Lt;
+                    h->descs.lens(size_t(P.work[size_t(first + j)]), Lq, Lr, Lt);
+                    W.mq = std::max(W.mq, Lq); W.mr = std::max(W.mr, Lr); W.mt = std::max(W.mt, Lt);
                 }
                 hdr[w0 + wv] = W;
             }
@@ -1396,6 +1497,15 @@ int prep_zero_lane(vpr_handle *h) {
     if (hdr.empty()) return VPR_OK;
     int rc;
     if ((rc = dev_alloc(h, &h->d_zl_hdr, hdr.size()))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_zl_hdr, hdr.data(), hdr.size() * sizeof(ZlWave), hipMemcpyHostToDevice, h->stream));
+    return zl_finish(h, hdr.size(), in_words, log_max, in_chunk_max, n_short_max, len_max);
+}
+
+// the lane levels' blocks for wave headers that are on the device (h->d_zl_hdr, h->zl_wave0 set): position words, logs, the
+// distance-1 level's blocks; then the position words are written (k_prep_zl, on the upload stream)
+int zl_finish(vpr_handle *h, size_t n_waves, int64_t in_words, int64_t log_max, int64_t in_chunk_max, int64_t n_short_max, int32_t len_max) {
+    const Plan &P = h->plan0;
+    int rc;
     if ((rc = dev_alloc(h, &h->d_zl_in, size_t(in_words)))) return rc;
     if ((rc = dev_alloc(h, &h->d_zl_log, size_t(log_max)))) return rc;
     // The distance-1 lane level works on the zero level's rejects (pr_d1.hip): its blocks hold D1_SHARE of what the largest
@@ -1421,7 +1531,6 @@ int prep_zero_lane(vpr_handle *h) {
         if ((rc = dev_alloc(h, &h->d_d1_blk, size_t(h->d1_fail_cap / 256 + 8)))) return rc;
         HIPCHK(h, hipMemsetAsync(h->d_d1_info, 0, 64, h->stream));
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_zl_hdr, hdr.data(), hdr.size() * sizeof(ZlWave), hipMemcpyHostToDevice, h->stream));
     for (size_t ci = 0; ci < P.chunks.size(); ci++) {
         const Chunk &ch = P.chunks[ci];
         const int64_t n_short = ch.count - ch.n_long;
@@ -1430,11 +1539,160 @@ int prep_zero_lane(vpr_handle *h) {
                            P.d_work + ch.work_off + ch.n_long, int(n_short), h->d_zl_hdr + h->zl_wave0[ci], h->d_zl_in);
     }
     HIPCHK(h, hipGetLastError());
-    if (h->debug) fprintf(stderr, "[vpr] zero-distance lane level: %zu waves, %.2f GB position words, %.2f GB log\n", hdr.size(),
+    if (h->debug) fprintf(stderr, "[vpr] zero-distance lane level: %zu waves, %.2f GB position words, %.2f GB log\n", n_waves,
                           double(in_words) * 4e-9, double(log_max) * 16e-9);
     return VPR_OK;
 }
 
+}  // namespace
+
+namespace {
+// ---------------------------------------------------------------------------
+// Round 0's plan of a whole batch built ON THE DEVICE (the usual case: every alignment of the batch, in input order, 16-cell
+// layout for the short part, everything in one chunk).  What make_plan does on the host for four million alignments -- a
+// counting sort by rows, the prefix sums of the workspace needs in plan order, the wave headers of the lane level: 40 of the
+// 60 ms a host thread spends per uploaded batch -- is a radix sort, a scan and two small kernels here (pr_plan.hip, k_plan_*,
+// k_zl_*), on a stream of their own beside the K0 kernels; the host keeps one light pass (levels, sums, the few thousand long
+// alignments, the checks), and gets the order, the offsets and the inverse back with three copies.  Results identical to
+// make_plan's (tests: VPR_HOST_PLAN=1 selects the host planner; the arrays are compared).
+//   ev_off: recorded on the upload stream behind the copies of the batch's offsets.  *done: false = not applicable here
+//   (several chunks, an alignment that does not fit): the caller plans on the host.
+// ---------------------------------------------------------------------------
+int plan0_device(vpr_handle *h, int lv0, hipEvent_t ev_off, bool *done) {
+    *done = false;
+    const size_t na = h->descs.size();
+    if (na == 0 || na > size_t(0x7fffff00) || lv0 > LV_Q16) return VPR_OK;
+    Plan &P = h->plan0;
+    const int LLT = h->long_lt;
+    const int64_t cap128 = h->arena_bytes / 128;
+    // ---- host pass: levels, sums, needs' total, the long alignments
+    struct Sums { int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}, part_rows[2] = {0, 0}, need128 = 0; bool bad = false; };
+    std::vector<Sums> sums1(PAR_MAX);
+    std::vector<std::vector<std::pair<int64_t, int32_t>>> big_of(PAR_MAX);
+    par_for(na, [&](size_t b, size_t e, int tid) {
+        Sums &S1 = sums1[size_t(tid)];
+        auto &bigs = big_of[size_t(tid)];
+        AlnDesc d{};
+        for (size_t a = b; a < e; a++) {
+            h->descs.lens(a, d.Lq, d.Lr, d.Lt);
+            d.path_cap = d.Lq + d.Lr + d.Lt + 4;
+            const int dl = plan_level_of(lv0, LLT, d.Lt);
+            const int W = LV_WINDOW[dl], part = d.Lt >= LLT ? 0 : 1;
+            S1.part_cells[part] += int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt;
+            S1.part_in[part] += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
+            S1.part_dense[part] += int64_t(d.Lq + d.Lr) * d.Lt;
+            S1.part_rows[part] += d.Lt;
+            h->level[a] = uint8_t(dl);
+            if (d.Lt >= LLT)
+                bigs.emplace_back(-(int64_t(round_up(std::min(W, d.Lq), 16) + round_up(std::min(W, d.Lr), 16)) * d.Lt), int32_t(a));
+            const int64_t need = window_layout(d, dl, 0, 0);
+            S1.need128 += need / 128;
+            if (need > h->arena_bytes || (d.Lt < LLT && d.Lt > 0xfffe) || d.Lq < 1 || d.Lr < 1 || d.Lt < 1) S1.bad = true;
+        }
+    });
+    int64_t total = 0;
+    bool bad = false;
+    for (const Sums &T : sums1) { total += T.need128; bad = bad || T.bad; }
+    if (bad || total > cap128 || total > int64_t(0xfffffff0)) return VPR_OK;       // (several chunks / an error message: the host planner)
+    std::vector<std::pair<int64_t, int32_t>> big;
+    for (auto &bl : big_of) big.insert(big.end(), bl.begin(), bl.end());
+    std::sort(big.begin(), big.end());
+    const size_t n = na, n_big = big.size(), n_short = n - n_big;
+    // ---- the plan's fields
+    {
+        std::vector<int32_t> kw; std::vector<uint32_t> ko;
+        kw.swap(P.work); ko.swap(P.off128);
+        P = Plan();
+        P.work.swap(kw); P.off128.swap(ko);
+    }
+    P.lv = lv0; P.arena = h->d_arena; P.tag_or = 0; P.long_lt = LLT; P.lazy = true;
+    P.total_need = total * 128; P.arena_used = total * 128;
+    {
+        Chunk ch;
+        ch.work_off = 0; ch.count = int32_t(n);
+        ch.n_long = int32_t(std::min<size_t>(n_big, n));
+        const bool no_long = ch.n_long == 0;
+        for (const Sums &T : sums1)
+            for (int q = 0; q < 2; q++) {
+                const int part = no_long ? 1 : q;
+                ch.part_cells[part] += T.part_cells[q]; ch.part_in[part] += T.part_in[q];
+                ch.part_dense[part] += T.part_dense[q]; ch.part_rows[part] += T.part_rows[q];
+                ch.cells += T.part_cells[q]; ch.in_bytes += T.part_in[q];
+            }
+        P.chunks.push_back(std::move(ch));
+    }
+    // ---- device: keys -> order -> offsets -> inverse -> wave headers
+    int rc;
+    hipStream_t ps = h->cls_stream[0];          // (the class streams are idle during an upload)
+    uint16_t *d_key = nullptr, *d_key2 = nullptr;
+    int32_t *d_val = nullptr, *d_pos = nullptr;
+    uint32_t *d_need = nullptr, *d_need2 = nullptr, *d_off = nullptr;
+    int64_t *d_tot = nullptr;
+    if ((rc = dev_alloc(h, &P.d_descs, n))) return rc;
+    if ((rc = dev_alloc(h, &P.d_work, n))) return rc;
+    if ((rc = dev_alloc(h, &d_key, n))) return rc;
+    if ((rc = dev_alloc(h, &d_key2, n))) return rc;
+    if ((rc = dev_alloc(h, &d_val, n))) return rc;
+    if ((rc = dev_alloc(h, &d_pos, n))) return rc;
+    if ((rc = dev_alloc(h, &d_need, n))) return rc;
+    if ((rc = dev_alloc(h, &d_need2, n))) return rc;
+    if ((rc = dev_alloc(h, &d_off, n))) return rc;
+    if ((rc = dev_alloc(h, &d_tot, 4))) return rc;
+    size_t tmp_sort = 0, tmp_scan = 0;
+    if (vplan_sort_pairs_desc(nullptr, &tmp_sort, d_key, d_key2, d_val, P.d_work, n, ps) != 0 ||
+        vplan_exclusive_scan_u32(nullptr, &tmp_scan, d_need2, d_off, n, ps) != 0)
+        return fail(h, VPR_ERR_DEVICE, "device planner: workspace query failed");
+    uint8_t *d_tmp = nullptr;
+    if ((rc = dev_alloc(h, &d_tmp, std::max(tmp_sort, tmp_scan) + 256))) return rc;
+    void *pin = nullptr;
+    { int rc_pin = pin_alloc(h, &pin, n * 12 + n_big * 4 + 64); if (rc_pin) return rc_pin; }
+    int32_t *hp_work = static_cast<int32_t *>(pin);
+    uint32_t *hp_off = reinterpret_cast<uint32_t *>(hp_work + n);
+    int32_t *hp_pos = reinterpret_cast<int32_t *>(hp_off + n);
+    int32_t *hp_big = hp_pos + n;
+    int64_t *hp_tot = reinterpret_cast<int64_t *>((reinterpret_cast<uintptr_t>(hp_big + n_big) + 15) & ~uintptr_t(15));
+    for (size_t k = 0; k < n_big; k++) hp_big[k] = big[k].second;
+    BatchOffsets DO;
+    for (int s_ = 0; s_ < 4; s_++) { DO.hap_off[s_] = h->dB.hap_off[s_]; DO.var_off[s_] = h->dB.var_off[s_]; }
+    DO.ref_off = h->dB.ref_off;
+    auto blocks = [](int64_t n_) { return dim3(unsigned((n_ + 255) / 256)); };
+    HIPCHK(h, hipStreamWaitEvent(ps, ev_off, 0));
+    hipLaunchKernelGGL(k_plan_keys, blocks(int64_t(n)), dim3(256), 0, ps, DO, int(n), lv0, LLT, d_key, d_val, d_need);
+    if (vplan_sort_pairs_desc(d_tmp, &tmp_sort, d_key, d_key2, d_val, P.d_work, n, ps) != 0) return fail(h, VPR_ERR_DEVICE, "device planner: sort failed");
+    if (n_big) HIPCHK(h, hipMemcpyAsync(P.d_work, hp_big, n_big * 4, hipMemcpyHostToDevice, ps));      // the long part in the host's order
+    hipLaunchKernelGGL(k_plan_gather, blocks(int64_t(n)), dim3(256), 0, ps, P.d_work, d_need, d_need2, d_pos, int(n));
+    if (vplan_exclusive_scan_u32(d_tmp, &tmp_scan, d_need2, d_off, n, ps) != 0) return fail(h, VPR_ERR_DEVICE, "device planner: scan failed");
+    HIPCHK(h, hipMemcpyAsync(hp_work, P.d_work, n * 4, hipMemcpyDeviceToHost, ps));
+    HIPCHK(h, hipMemcpyAsync(hp_off, d_off, n * 4, hipMemcpyDeviceToHost, ps));
+    HIPCHK(h, hipMemcpyAsync(hp_pos, d_pos, n * 4, hipMemcpyDeviceToHost, ps));
+    const size_t nw = lv0 == LV_Z ? (n_short + 63) / 64 : 0;
+    if (nw) {
+        if ((rc = dev_alloc(h, &h->d_zl_hdr, nw))) return rc;
+        hipLaunchKernelGGL(k_zl_hdr, dim3(unsigned(nw)), dim3(64), 0, ps, DO, P.d_work + n_big, int(n_short), h->d_zl_hdr);
+        hipLaunchKernelGGL(k_zl_scan, dim3(1), dim3(1024), 0, ps, h->d_zl_hdr, int(nw), d_tot);
+        HIPCHK(h, hipMemcpyAsync(hp_tot, d_tot, 32, hipMemcpyDeviceToHost, ps));
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, x_sync(h, ps, SITE));
+    // ---- the host's copies (plan_desc, the tie rounds and vpr_download_path look single entries up)
+    P.work.resize(n); P.off128.resize(n);
+    h->plan0_pos.resize(na);
+    par_for(n, [&](size_t b0, size_t e0, int) {
+        memcpy(P.work.data() + b0, hp_work + b0, (e0 - b0) * 4);
+        memcpy(P.off128.data() + b0, hp_off + b0, (e0 - b0) * 4);
+        memcpy(h->plan0_pos.data() + b0, hp_pos + b0, (e0 - b0) * 4);
+    });
+    // ---- descriptors in both orders; the lane level's blocks and position words (behind K0 on the upload stream)
+    hipLaunchKernelGGL(k_build_plan, blocks(int64_t(n)), dim3(256), 0, h->stream, DO, P.d_work, d_off, int(n), P.lv, P.long_lt, P.tag_or,
+                       P.d_descs, h->d_descs);
+    if (nw) {
+        h->zl_wave0.assign(1, 0);
+        const int64_t in_words = hp_tot[0], log_max = hp_tot[1];
+        if ((rc = zl_finish(h, nw, in_words, log_max, in_words, int64_t(n_short), int32_t(hp_tot[2])))) return rc;
+    }
+    *done = true;
+    return VPR_OK;
+}
 }  // namespace
 
 namespace {
@@ -1574,6 +1832,7 @@ void vpr_destroy(vpr_handle *h) {
         if (h->ev_side[k]) (void)hipEventDestroy(h->ev_side[k]);
     }
     if (h->ev_spec) (void)hipEventDestroy(h->ev_spec);
+    if (h->ev_offsets) (void)hipEventDestroy(h->ev_offsets);
     delete h;
 }
 
@@ -1650,6 +1909,8 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     }
     if ((rc = dev_alloc(h, &h->d_err, 1))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_err, 0, 4, h->stream));
+    if (!h->ev_offsets) HIPCHK(h, hipEventCreateWithFlags(&h->ev_offsets, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->ev_offsets, h->stream));       // the batch's offsets are on the device: what the device planner reads
     if (h->gen_src) {       // the strings, pointers and flags are written on the device from the variant tables (pr_gen.hip)
         const vpr_variants *v = h->gen_src;
         GenTables G;
@@ -1693,7 +1954,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         }
         O.ref_seq = const_cast<uint8_t *>(D.ref_seq);
         for (int q = 0; q < 2; q++) { O.ref_ptr[q] = const_cast<int32_t *>(D.ref_ptr[q]); O.ref_flag[q] = const_cast<uint8_t *>(D.ref_flag[q]); }
-        if (n > 0) hipLaunchKernelGGL(k_generate, dim3(unsigned((n + 255) / 256), 4), dim3(256), 0, h->stream, D, G, O);
+        if (n > 0) hipLaunchKernelGGL(k_generate, dim3(unsigned((n + 4 * GEN_SC_PER_WAVE - 1) / (4 * GEN_SC_PER_WAVE)), 4), dim3(256), 0, h->stream, D, G, O);
         HIPCHK(h, hipGetLastError());
     }
     lap("inputs copied");
@@ -1718,7 +1979,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     for (int s = 0; s < 4; s++)
         if (hap_len[s] > 0)
             hipLaunchKernelGGL(k_prep_ins, blocks(hap_len[s]), dim3(256), 0, h->stream, D, s, hap_len[s]);
-    if (n > 0) hipLaunchKernelGGL(k_prep_suffix, dim3((n + 63) / 64, 6), dim3(64), 0, h->stream, D);
+    if (n > 0) hipLaunchKernelGGL(k_prep_suffix, dim3((n + 4 * SUFFIX_SC_PER_WAVE - 1) / (4 * SUFFIX_SC_PER_WAVE), 6), dim3(256), 0, h->stream, D);
     {
         void *pd = nullptr;
         { int rc_pin = pin_alloc(h, &pd, size_t(std::max(n, 1)) * 4 * sizeof(int2)); if (rc_pin) return rc_pin; }
@@ -1930,8 +2191,10 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     const int lv0 = h->cfg.band_mode == 0 ? LV_DENSE
                     : h->cfg.band_mode == 2 ? LV_C1
                     : h->cfg.band_mode == 3 ? LV_Q16 : LV_Z;
-    if ((rc = make_plan(h, all, lv0, h->plan0, h->d_arena, h->arena_bytes, 0, true))) return rc;
-    lap("make_plan");
+    bool dev_plan = false;
+    if (np == na && lv0 <= LV_Q16 && !getenv("VPR_HOST_PLAN") && (rc = plan0_device(h, lv0, h->ev_offsets, &dev_plan))) return rc;
+    if (!dev_plan && (rc = make_plan(h, all, lv0, h->plan0, h->d_arena, h->arena_bytes, 0, true))) return rc;
+    lap(dev_plan ? "plan on the device" : "make_plan");
     // the long part's forward flags are kept a second time (tie rounds copy them back instead of repeating the sweep:
     // k_fwd_stripe_save / k_restore_stripe): a region as large as the part's share of the workspace -- the front of every
     // chunk -- unless that is more than 1 GB (a batch of tens of thousands of long alignments is a throughput problem, not a
@@ -1952,10 +2215,12 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         }
     }
     h->level0 = h->level;
-    h->plan0_pos.assign(na, -1);
-    par_for(np, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) h->plan0_pos[size_t(h->plan0.work[k])] = int32_t(k); });
-    if ((rc = dev_alloc(h, &h->plan0.d_descs, np))) return rc;
-    if ((rc = dev_alloc(h, &h->plan0.d_work, np))) return rc;
+    if (!dev_plan) {
+        h->plan0_pos.assign(na, -1);
+        par_for(np, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) h->plan0_pos[size_t(h->plan0.work[k])] = int32_t(k); });
+        if ((rc = dev_alloc(h, &h->plan0.d_descs, np))) return rc;
+        if ((rc = dev_alloc(h, &h->plan0.d_work, np))) return rc;
+    }
     lap("plan0_pos");
     if (h->n_aliased) {
         BatchOffsets DO;
@@ -1963,7 +2228,9 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         DO.ref_off = D.ref_off;
         hipLaunchKernelGGL(k_alias_descs, blocks(int64_t(na)), dim3(256), 0, h->stream, DO, h->d_alias, b->n_sc, h->d_descs);
     }
-    if (np && h->plan0.lazy) {
+    if (dev_plan) {
+        // (descriptors, wave headers and position words are already enqueued: plan0_device)
+    } else if (np && h->plan0.lazy) {
         // the plan crosses the link as (alignment, workspace offset) pairs; the device builds both descriptor tables
         void *pw = nullptr;
         { int rc_pin = pin_alloc(h, &pw, np * 8); if (rc_pin) return rc_pin; }
@@ -1988,7 +2255,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         HIPCHK(h, hipMemcpyAsync(h->plan0.d_work, h->plan0.work.data(), np * 4, hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_scatter_descs, blocks(int64_t(np)), dim3(256), 0, h->stream, h->plan0.d_descs, int(np), h->d_descs);
     }
-    if (lv0 == LV_Z && (rc = prep_zero_lane(h))) return rc;
+    if (lv0 == LV_Z && !dev_plan && (rc = prep_zero_lane(h))) return rc;
 
     HIPCHK(h, x_sync(h, h->stream, SITE));
     HIPCHK(h, hipGetLastError());

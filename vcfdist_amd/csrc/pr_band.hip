@@ -107,23 +107,48 @@ __device__ __forceinline__ int query_center(const int32_t *__restrict__ t2r, con
 
 // suffix sums of |pointer step - 1| (an inserted base contributes 1, a crossed deletion its length):
 // which = 0..3: hap slot (hap -> ref pointers), 4..5: ref -> query hap (which - 4)
-__global__ void k_prep_suffix(DevBatch B) {      // blockIdx.y: the array (a supercluster is a serial chain: the six arrays side by side)
+#define SUFFIX_SC_PER_WAVE 8
+__global__ void __launch_bounds__(256) k_prep_suffix(DevBatch B) {
+    // blockIdx.y: the array.  One WAVEFRONT per supercluster (eight superclusters after each other): lane l of step j holds
+    // position L - 1 - 64 j - l, so the loads are whole lines and the suffix sum is a wave scan plus a carry -- a thread per
+    // supercluster walked its own chain of dependent loads, and the launch lasted as long as the longest supercluster of the batch
     const int which = blockIdx.y;
-    const int sc = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sc >= B.n_sc) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t *off = which < 4 ? B.hap_off[which] : B.ref_off;
     const int32_t *ptr = which < 4 ? B.hap_ptr[which] : B.ref_ptr[which - 4];
     int32_t *out = which < 4 ? B.vs_hap[which] : B.vs_ref[which - 4];
-    const int64_t b = off[sc], e = off[sc + 1];
-    int32_t acc = 0;
-    int dmin = 0x7fffffff, dmax = -0x7fffffff;
-    for (int64_t i = e - 1; i >= b; i--) {
-        if (i > b) { const int w = ptr[i] - ptr[i - 1] - 1; acc += w < 0 ? -w : w; }
-        out[i] = acc;
-        const int dd = int(i - b) - ptr[i];
-        dmin = min(dmin, dd); dmax = max(dmax, dd);
+    const int sc0 = (blockIdx.x * 4 + wave) * SUFFIX_SC_PER_WAVE;
+    for (int k = 0; k < SUFFIX_SC_PER_WAVE; k++) {
+        const int sc = sc0 + k;
+        if (sc >= B.n_sc) return;
+        const int64_t b = off[sc];
+        const int L = int(off[sc + 1] - b);
+        int32_t carry = 0;
+        int dmin = 0x7fffffff, dmax = -0x7fffffff;
+        for (int top = L; top > 0; top -= 64) {
+            const int i = top - 1 - lane;              // this lane's position (descending over the lanes)
+            int w = 0, p = 0;
+            if (i >= 0) {
+                p = ptr[b + i];
+                if (i > 0) { const int d = p - ptr[b + i - 1] - 1; w = d < 0 ? -d : d; }
+                const int dd = i - p;
+                dmin = min(dmin, dd); dmax = max(dmax, dd);
+            }
+            int sfx = w;                               // inclusive scan over the lanes = suffix sum over the positions
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(sfx, o);
+                if (lane >= o) sfx += t;
+            }
+            if (i >= 0) out[b + i] = carry + sfx;
+            carry += __shfl(sfx, 63);
+        }
+        if (which < 4) {
+#pragma unroll
+            for (int o = 32; o; o >>= 1) { dmin = min(dmin, __shfl_xor(dmin, o)); dmax = max(dmax, __shfl_xor(dmax, o)); }
+            if (lane == 0) B.dspan[which][sc] = make_int2(dmin, dmax);
+        }
     }
-    if (which < 4) B.dspan[which][sc] = make_int2(dmin, dmax);
 }
 
 // exact budgets of the exit test (pr_device.h: xb_q / xb_r), needs vs_hap of k_prep_suffix.  dir 0: hap positions of

@@ -180,13 +180,13 @@ __global__ void __launch_bounds__(256) k_prep_d1(DevBatch B, const AlnDesc *__re
                         const int slot = pl == 2 ? ts : qs;
                         const int64_t o = (pl == 0 ? s_qo[l] : (pl == 1 ? ro : s_to[l])) + x;
                         const uint8_t *seq = pl == 1 ? B.ref_seq : B.hap_seq[slot];
-                        const uint8_t *flg = pl == 1 ? B.ref_flag[qs] : B.hap_flag[slot];
-                        const int32_t *ptr = pl == 1 ? B.ref_ptr[qs] : B.hap_ptr[slot];
-                        const int p = ptr[o], f = flg[o];
-                        const int r = pl == 1 ? x : p;
-                        const uint32_t ins = (r >= 0 && r < Lr && (B.has_ins[qs][ro + r] | B.has_ins[ts][ro + r])) ? ZW_INS : 0u;
+                        const int2 *wk = pl == 0 ? B.wk_q[qs] : (pl == 1 ? B.wk_r[qs] : B.wk_t[ts - 2]);      // (see k_prep_zl)
+                        const int2 k2 = wk[o];
+                        const int p = k2.x, f = pl == 1 ? int(B.ref_flag[qs][o]) : (k2.y & 0xff);
+                        const uint32_t ins = ((k2.y >> 8) & ((1 << qs) | (1 << ts))) ? ZW_INS : 0u;
                         v = uint32_t((p + 1) & 0xffff) | (uint32_t(seq[o] & 0x7f) << 16) | flagbits(f) | ins;
-                        if (pl == 0 && x > 0 && ((p != ptr[o - 1] + 1) || (f & PB))) v |= ZW_TP;       // dist.cpp:572-574
+                        if (pl == 0 && x > 0 && ((p != wk[o - 1].x + 1) || (f & PB))) v |= ZW_TP;       // dist.cpp:572-574
+                        (void)Lr;
                     }
                 }
                 tile[lane][l] = v;
@@ -211,9 +211,9 @@ __global__ void __launch_bounds__(64, 3) k_one_lane(const AlnDesc *__restrict__ 
                                                     const uint32_t *__restrict__ zin, uint4 *__restrict__ zlog,
                                                     AlnOut *__restrict__ outs, PathEnt *__restrict__ paths, int keep_paths,
                                                     int32_t *__restrict__ info) {
-    // (the fail list is roughly ascending by truth rows, as the zero level's work list is: the last waves are the longest chains of
-    // dependent rows and go first, beside the throughput work of the others)
-    const int w = int(gridDim.x) - 1 - int(blockIdx.x), lane = threadIdx.x;
+    // (the fail list keeps the order of the zero level's work list -- longest first: the longest chains of dependent rows start
+    // first and run beside the throughput work of the others)
+    const int w = blockIdx.x, lane = threadIdx.x;
     const ZlWave H = hdr[w];
     if (H.mt <= 0) return;
     const int n_list = min(*n_dev, n_cap);

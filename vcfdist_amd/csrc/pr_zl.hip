@@ -110,17 +110,19 @@ __global__ void __launch_bounds__(256) k_prep_zl(DevBatch B, const AlnDesc *__re
                 const int len = arr == 0 ? s_lq[l] : (arr == 1 ? Lr : s_lt[l]);
                 uint32_t v = 0x7f0000u;
                 if (x < len) {
+                    // (pointer, flags and "an insertion of hap slot s sits at this position's reference base" come in one 8-byte
+                    // record of the walk constants, k_prep_wk: no second, dependent round trip for the insertion marks)
                     const int64_t ro = s_ro[l];
                     const int slot = arr == 2 ? ts : qs;
                     const int64_t o = (arr == 0 ? s_qo[l] : (arr == 1 ? ro : s_to[l])) + x;
                     const uint8_t *seq = arr == 1 ? B.ref_seq : B.hap_seq[slot];
-                    const uint8_t *flg = arr == 1 ? B.ref_flag[qs] : B.hap_flag[slot];
-                    const int32_t *ptr = arr == 1 ? B.ref_ptr[qs] : B.hap_ptr[slot];
-                    const int p = ptr[o], f = flg[o];
-                    const int r = arr == 1 ? x : p;     // the reference base whose insertions count
-                    const uint32_t ins = (r >= 0 && r < Lr && (B.has_ins[qs][ro + r] | B.has_ins[ts][ro + r])) ? ZW_INS : 0u;
+                    const int2 *wk = arr == 0 ? B.wk_q[qs] : (arr == 1 ? B.wk_r[qs] : B.wk_t[ts - 2]);
+                    const int2 k2 = wk[o];
+                    const int p = k2.x, f = arr == 1 ? int(B.ref_flag[qs][o]) : (k2.y & 0xff);
+                    const uint32_t ins = ((k2.y >> 8) & ((1 << qs) | (1 << ts))) ? ZW_INS : 0u;
                     v = uint32_t((p + 1) & 0xffff) | (uint32_t(seq[o] & 0x7f) << 16) | flagbits(f) | ins;
-                    if (arr == 0 && x > 0 && ((p != ptr[o - 1] + 1) || (f & PB))) v |= ZW_TP;       // dist.cpp:572-574
+                    if (arr == 0 && x > 0 && ((p != wk[o - 1].x + 1) || (f & PB))) v |= ZW_TP;       // dist.cpp:572-574
+                    (void)Lr;
                 }
                 tile[lane][l] = v;
             }
