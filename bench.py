@@ -297,6 +297,10 @@ def main():
     ap.add_argument("--one-pass-batches", type=int, default=None,
                     help="batches of the one-pass leg (upload from the variant tables + execute + download each; 0 = skip; "
                          "default 9 for wgs_synth, 0 for the other workloads)")
+    ap.add_argument("--one-pass-in-flight", type=int, default=None,
+                    help="batches in flight in the one-pass leg (default 3 for wgs_synth: a fresh batch keeps its host thread ~50 ms in "
+                         "vpr_upload_variants and the device ~35 ms -- K0 + the step --, so a third thread fills the device: 103 M/s "
+                         "against 87 with two; the headline keeps two)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the legs measured after the headline (N = 1, default workload only): two batches in flight, and the "
                          "sv_synth / stress_synth workloads (BASELINE configs[2] / configs[4]) on small batches")
@@ -402,7 +406,7 @@ def main():
         # measured 133 ms per step; the first two handles never did, and the warm-up steps are watched for it below.
         args.in_flight = 2 if args.workload == "wgs_synth" else 1
     if args.one_pass_batches is None:
-        args.one_pass_batches = 9 if args.workload == "wgs_synth" else 0
+        args.one_pass_batches = 12 if args.workload == "wgs_synth" else 0
     # (every resident batch goes through at least one untimed step: a handle's workspaces settle in its first execute)
     n_fl = max(1, min(args.in_flight, args.steps, max(args.warmup, 1)))
 
@@ -677,8 +681,14 @@ def main():
     if world == 1 and not strong and args.one_pass_batches > 0:
         nb = args.one_pass_batches
         op_parts = [0.0, 0.0, 0.0]
+        n_op = args.one_pass_in_flight if args.one_pass_in_flight else (3 if args.workload == "wgs_synth" else n_fl)
+        op_slots = list(slots)
+        while len(op_slots) < n_op:         # (further batches, only for this leg: after the headline's timed region)
+            op_slots.append(make_slot(len(op_slots)))
+        op_slots = op_slots[:max(n_op, 1)]
+        n_op = len(op_slots)
 
-        for S in slots:                     # (the SNP / INDEL / SV class is a column of the variant tables: print.cpp:362-372)
+        for S in op_slots:                  # (the SNP / INDEL / SV class is a column of the variant tables: print.cpp:362-372)
             S.cls = S.syn.var_class()
 
         def op_step(S):
@@ -696,16 +706,16 @@ def main():
         def op_run(n):
             def worker(j):
                 try:
-                    for i in range(j, n, n_fl):
-                        op_step(slots[j])
+                    for i in range(j, n, n_op):
+                        op_step(op_slots[j])
                 except BaseException as e:
                     failed.append(e)
-            ths = [threading.Thread(target=worker, args=(j,)) for j in range(n_fl)]
+            ths = [threading.Thread(target=worker, args=(j,)) for j in range(n_op)]
             for th in ths:
                 th.start()
             for th in ths:
                 th.join()
-        op_run(n_fl)                        # warm-up: one batch per slot
+        op_run(2 * n_op)                    # warm-up: two batches per slot (the first execute of a handle settles its workspaces)
         if failed:
             sys.stderr.write(f"one-pass leg failed: {failed[0]!r}\n")
             sys.stderr.flush()
@@ -720,14 +730,17 @@ def main():
             os._exit(1)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t1
-        one_pass = {"value": round(4 * args.n_sc * nb / dt, 1), "unit": "supercluster-alignments/s", "batches": nb, "in_flight": n_fl,
+        one_pass = {"value": round(4 * args.n_sc * nb / dt, 1), "unit": "supercluster-alignments/s", "batches": nb, "in_flight": n_op,
                     "ms_per_batch": round(dt / nb * 1e3, 2),
                     "host_thread_ms_per_batch": {"upload_variants": round(op_parts[0] / nb * 1e3, 2), "vpr_execute": round(op_parts[1] / nb * 1e3, 2),
                                                  "download_and_counters": round(op_parts[2] / nb * 1e3, 2)},
                     "note": "every batch from its variant tables in host memory: host sizing pass, upload, generate_ptrs_strs on the "
                             "device, position constants, planning, execute, download, counters"}
-        for S in slots:                     # (the timed batches replaced the resident ones; what follows reads the last step's results)
+        for S in op_slots:                  # (the timed batches replaced the resident ones; what follows reads the last step's results)
             S.host_res = None
+        S = None
+        del op_slots[len(slots):]           # (the leg's own handles: released)
+        gc.collect()
 
     # ---- legs after the headline (rank 0 at N = 1 only; nothing here enters `value`)
     two_fl = None

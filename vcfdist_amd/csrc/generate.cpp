@@ -55,7 +55,7 @@ static int host_threads() {
 // The arrays of a marshalled batch live in two page-locked staging blocks (vpr_host_alloc: vpr_upload's copies then run
 // as DMA at the link rate, beside the host's planning, instead of through the driver's bounce buffers): `small` holds the
 // offsets and the variant tables, whose sizes are known up front, `big` the strings, pointers and flags sized by pass 1.
-// Freed blocks are kept (the two most recent) and reused by the next batch: page-locking costs about as much as filling.
+// Freed blocks are kept (up to four) and reused by the next batch: page-locking costs about as much as filling.
 struct vpr_owned_batch {
     int64_t *hap_off[VPR_HAPS], *ref_off, *var_off[VPR_HAPS];
     uint8_t *hap_seq[VPR_HAPS], *hap_flag[VPR_HAPS], *ref_seq, *ref_flag[2];
@@ -69,13 +69,21 @@ namespace {
 
 using Block = vpr_owned_batch::Block;
 std::mutex g_cache_mu;
-Block g_cache[2];
+Block g_cache[4];
 
 Block block_get(size_t bytes) {
+    // (sizes in steps of an eighth: batches of one stream differ by a few per cent, and two threads marshalling batches of
+    // slightly different sizes must not take each other's block -- the smaller request grabbing the larger block left the
+    // larger request to page-lock a new one, 15 ms, and to free the displaced one, 8 ms, every batch)
+    size_t step = size_t(1) << 20;
+    while (step * 8 < bytes) step <<= 1;
+    bytes = (std::max<size_t>(bytes, 1) + step - 1) / step * step;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
+        Block *best = nullptr;
         for (Block &c : g_cache)
-            if (c.p && c.bytes >= bytes) { Block b = c; c = Block(); return b; }
+            if (c.p && c.bytes >= bytes && (!best || c.bytes < best->bytes)) best = &c;
+        if (best) { Block b = *best; *best = Block(); return b; }
     }
     Block b;
     b.bytes = bytes ? bytes : 1;
@@ -98,7 +106,11 @@ void block_put(Block &b) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         Block *slot = nullptr;
         for (Block &c : g_cache) if (!c.p) { slot = &c; break; }
-        if (!slot) { slot = g_cache[0].bytes <= g_cache[1].bytes ? &g_cache[0] : &g_cache[1]; if (slot->bytes >= b.bytes) slot = nullptr; }
+        if (!slot) {
+            slot = &g_cache[0];
+            for (Block &c : g_cache) if (c.bytes < slot->bytes) slot = &c;       // the smallest kept block makes room for a larger one
+            if (slot->bytes >= b.bytes) slot = nullptr;
+        }
         if (slot) { std::swap(*slot, b); }
     }
     block_release(b);       // whatever was not kept (the displaced block, or this one)
@@ -268,9 +280,23 @@ static int batch_from_variants_impl(const vpr_variants *v, vpr_owned_batch **out
         for (auto &x : th) x.join();
     }
     if (err) { vpr_owned_batch_free(B); return err; }
-    for (int h = 0; h < VPR_HAPS; h++)
-        for (int sc = 0; sc < n; sc++) B->hap_off[h][sc + 1] += B->hap_off[h][sc];
-    for (int sc = 0; sc < n; sc++) B->ref_off[sc + 1] += B->ref_off[sc];
+    {   // lengths -> offsets: every thread sums its slice, the slices' bases are a short serial pass, every thread then runs its
+        // prefix sums from its base (five serial passes over a million superclusters were most of the sizing pass)
+        std::vector<int64_t> base(size_t(nthreads + 1) * 5, 0);
+        auto slice = [&](int t, int &sc0, int &sc1) { sc0 = int(int64_t(n) * t / nthreads); sc1 = int(int64_t(n) * (t + 1) / nthreads); };
+        auto arr = [&](int k) -> int64_t * { return k < VPR_HAPS ? B->hap_off[k] : B->ref_off; };
+        auto sum_job = [&](int t) {
+            int sc0, sc1; slice(t, sc0, sc1);
+            for (int k = 0; k < 5; k++) { int64_t s_ = 0; const int64_t *a = arr(k); for (int sc = sc0; sc < sc1; sc++) s_ += a[sc + 1]; base[size_t(t + 1) * 5 + k] = s_; }
+        };
+        auto scan_job = [&](int t) {
+            int sc0, sc1; slice(t, sc0, sc1);
+            for (int k = 0; k < 5; k++) { int64_t run = base[size_t(t) * 5 + k]; int64_t *a = arr(k); for (int sc = sc0; sc < sc1; sc++) { run += a[sc + 1]; a[sc + 1] = run; } }
+        };
+        { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(sum_job, t); for (auto &x : th) x.join(); }
+        for (int t = 1; t <= nthreads; t++) for (int k = 0; k < 5; k++) base[size_t(t) * 5 + k] += base[size_t(t - 1) * 5 + k];
+        { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(scan_job, t); for (auto &x : th) x.join(); }
+    }
 
     auto carve_big = [&](Carver &c) {
         for (int h = 0; h < VPR_HAPS; h++) {
