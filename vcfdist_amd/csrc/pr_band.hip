@@ -523,6 +523,9 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
         }
         int rowo[2] = {lane, lane};   // byte offset of this lane's cell inside the stripe's LDS block
         const bool st_ok[2] = {lane < d.pitch[0], lane < d.pitch[1]};
+        // the first swap source of every cell of the stripe sits one window column to the left in the other plane (no indel inside
+        // the two windows): nearly every stripe
+        const bool swap_near = __all((s0[0] < 0 || s0[0] - lo[1] == lane - 1) && (s0[1] < 0 || s0[1] - lo[0] == lane - 1));
 
         for (int r = 0; r < rows; r++) {
             const int t = t0 + r;
@@ -565,7 +568,6 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
             bool match[2], need_multi = false;
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                const int o = 1 - p;
                 if (first) {
                     const int sh = lo[p] - plo[p];
                     up[p] = lane_get(lane + sh, Dp[p], D_INF);
@@ -574,9 +576,15 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
                     up[p] = Dp[p];
                     dg[p] = wave_shr1(Dp[p], D_INF);
                 }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int o = 1 - p;
                 match[p] = base[p] == Tt;
                 const bool on = match[p] && at && s0[p] >= 0;
-                const int sv = lane_get(s0[p] - (first ? plo[o] : lo[o]), Dp[o], D_INF);
+                // (swap_near: every swap source of the stripe is the other plane's left neighbour column -- its value is that plane's
+                // diagonal value, already here; the permute through LDS was on the row-to-row dependency chain)
+                const int sv = (swap_near && !first) ? dg[o] : lane_get(s0[p] - (first ? plo[o] : lo[o]), Dp[o], D_INF);
                 sw[p] = on ? sv : D_INF;
                 need_multi = need_multi || (on && multi[p]);
             }
@@ -628,6 +636,7 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
             int iq = v[0], ir = v[1];
             wave_prefix_min2(iq, ir);
             const int inc[2] = {iq, ir};
+            bool may_exit = false;
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 const int carry = wave_shr1(inc[p], D_INF);
@@ -637,8 +646,17 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
                 f |= (left + 1 == Dn) ? F_INS : 0;
                 if (st_ok[p]) fbuf[p][rowo[p]] = uint8_t(f);
                 rowo[p] += d.pitch[p];
-                exit_min = min(exit_min, exit_key(last ? ex_last[p] : ex_in[p], p, Dn, rhoc[p], vac[p], tau, vt, taun, vtn));
+                // first tier of the exit test: an exit key is D + cost + a bound >= D, so a cell whose D has reached the lane's
+                // smallest key so far cannot lower it
+                may_exit = may_exit || ((last ? ex_last[p] : ex_in[p]) != 0 && Dn < exit_min);
                 Dp[p] = Dn;
+            }
+            // (second tier, the keys themselves -- 50 of the row's ~250 instructions --, only in rows where some cell can still
+            // lower its lane's minimum: the cells at the window's edge keep about the same D from row to row)
+            if (__any(may_exit)) {
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+                    exit_min = min(exit_min, exit_key(last ? ex_last[p] : ex_in[p], p, Dp[p], rhoc[p], vac[p], tau, vt, taun, vtn));
             }
         }
         asm volatile("" ::: "memory");      // (the stripe's flag rows leave LDS at the start of the next stripe)
@@ -846,6 +864,9 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
             zkey[p] = f_swp_key(rank_of(uint32_t(bkc[p]) >> 24));
         }
         const int sh[2] = {plo[0] - lo[0], plo[1] - lo[1]};   // origin shift against the stripe above (first row)
+        // every swap target of the stripe sits in the lane next door of the other plane's row (no indel inside the two windows)
+        const bool swap_near = __all((zl[0] == int(FK_NONE24) || 63 - (zl[0] - lo[1]) == lane - 1) &&
+                                     (zl[1] == int(FK_NONE24) || 63 - (zl[1] - lo[0]) == lane - 1));
         stage_load(s - 1);                                     // prefetch the stripe below into registers
         asm volatile("" ::: "memory");
         const uint8_t *fcur[2] = {fin[s & 1][0], fin[s & 1][1]};
@@ -856,32 +877,45 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
             int best[2], lk[2], f0[2];
             uint32_t bm[2];
             MP g[2];
+            int up_sv[2], up_fv[2], dn_sv[2], dn_fv[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                if (first) {
+                    up_sv[p] = lane_get(lane + sh[p] - 1, sc1[p], S_NEG);
+                    up_fv[p] = lane_get(lane + sh[p] - 1, f1[p], 0);
+                    dn_sv[p] = lane_get(lane + sh[p], sc1[p], S_NEG);
+                    dn_fv[p] = lane_get(lane + sh[p], f1[p], 0);
+                } else {
+                    up_sv[p] = wave_shr1(sc1[p], S_NEG);
+                    up_fv[p] = wave_shr1(f1[p], 0);
+                    dn_sv[p] = sc1[p];
+                    dn_fv[p] = f1[p];
+                }
+            }
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 const int o = 1 - p;
-                int up_s, up_f, dn_s, dn_f;
-                if (first) {
-                    up_s = lane_get(lane + sh[p] - 1, sc1[p], S_NEG);
-                    up_f = lane_get(lane + sh[p] - 1, f1[p], 0);
-                    dn_s = lane_get(lane + sh[p], sc1[p], S_NEG);
-                    dn_f = lane_get(lane + sh[p], f1[p], 0);
-                } else {
-                    up_s = wave_shr1(sc1[p], S_NEG);
-                    up_f = wave_shr1(f1[p], 0);
-                    dn_s = sc1[p];
-                    dn_f = f1[p];
-                }
+                const int up_s = up_sv[p], up_f = up_fv[p], dn_s = dn_sv[p], dn_f = dn_fv[p];
                 int b = S_NEG;
                 uint32_t m = 0;
                 if (f_diag(up_f)) { b = up_s + tp_right[p]; m = f_diag(up_f); }
                 if (dn_f & F_DEL) {
                     if (dn_s > b) { b = dn_s; m = F_DEL; } else if (dn_s == b) m |= F_DEL;
                 }
-                // swap successor z = (other plane, zl, t+1): its lane in the alignment of row t+1
+                // swap successor z = (other plane, zl, t+1): its lane in the alignment of row t+1.  (swap_near: in every cell of
+                // the stripe it is the other plane's diagonal successor -- the value one lane over, already here: no permute through
+                // LDS on the row-to-row dependency chain)
                 const int olo = first ? plo[o] : lo[o];
                 const int zlane = 63 - (zl[p] - olo);
-                const int zf = lane_get(zl[p] == int(FK_NONE24) ? -1 : zlane, f1[o], 0);
-                const int zs = lane_get(zl[p] == int(FK_NONE24) ? -1 : zlane, sc1[o], S_NEG);
+                const bool znone = zl[p] == int(FK_NONE24);
+                int zf, zs;
+                if (swap_near && !first) {
+                    zf = znone ? 0 : up_fv[o];
+                    zs = znone ? S_NEG : up_sv[o];
+                } else {
+                    zf = lane_get(znone ? -1 : zlane, f1[o], 0);
+                    zs = lane_get(znone ? -1 : zlane, sc1[o], S_NEG);
+                }
                 if ((uint32_t(zf) & F_SWP_KEY_MASK) == zkey[p]) {
                     const int v = zs + ((bkc[p] >> 27) & 1);
                     if (v >= 0 && (zf & F_TIE)) tie_used++;
@@ -896,9 +930,16 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
                 lk[p] = (f0r & F_INS) ? tp_right[p] : -1;
                 g[p].A = b; g[p].B = lk[p];
             }
-            MP hq = g[0], hr = g[1];
-            wave_prefix_mp2(hq, hr);
-            const int inc[2] = {wave_shr1(hq.A, S_NEG), wave_shr1(hr.A, S_NEG)};
+            // The in-row INS chain (a score flows from (x + 1, t) to (x, t) where the former carries F_INS) is a max-plus scan
+            // over the row: 60 of the row's ~210 instructions.  It moves something only when a cell that IS on an optimal path
+            // (best >= 0) was entered by an INS edge -- a row of the walk's insertion steps; everywhere else the row's scores
+            // are `best` as they stand.
+            int inc[2] = {S_NEG, S_NEG};
+            if (__any((best[0] >= 0 && (f0[0] & F_INS)) || (best[1] >= 0 && (f0[1] & F_INS)))) {
+                MP hq = g[0], hr = g[1];
+                wave_prefix_mp2(hq, hr);
+                inc[0] = wave_shr1(hq.A, S_NEG); inc[1] = wave_shr1(hr.A, S_NEG);
+            }
             uint32_t outm[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
