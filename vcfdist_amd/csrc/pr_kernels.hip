@@ -993,8 +993,12 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
     }
     auto row_get = [&](int t) -> int2 {
         if (t >= rbase + 64) {   // uniform
-            rbase += 64;
-            rcur = rnxt;
+            if (t < rbase + 128) { rbase += 64; rcur = rnxt; }
+            else {               // (a diagonal run skipped a chunk)
+                rbase = t & ~63;
+                rcur = make_int2(0, 0);
+                if (rbase + lane < t_size) rcur = wt_[rbase + lane];
+            }
             rnxt = make_int2(0, 0);
             if (rbase + 64 + lane < t_size) rnxt = wt_[rbase + 64 + lane];
         }
@@ -1020,7 +1024,49 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
                                 (hi == ri) ? 0 : q2r[0], t2r[0]};   // sync, no edit
     n = 1;
     bool ok = true;
+    int skip_run = 0;       // WAVE: steps until the next attempt at a diagonal run
     while ((hi == ri && qri < r_size - 1) || (hi == qi && qri < q_size - 1) || ti < t_size - 1) {
+        if (WAVE) {
+            // DIAGONAL RUNS.  Nearly all of a long alignment's walk is MAT steps down one diagonal of one plane.  Lane l looks at
+            // the cell l steps down that diagonal (one scattered byte per lane: ONE round trip for up to 64 steps, where the
+            // step-by-step walk pays a dependent lookup per step); the leading lanes whose cell takes MAT by the walk's priority
+            // (dist.cpp:907-935: on the REF plane only without a swap) are a run, and the run's path entries -- the cells
+            // ENTERED by its steps, with their sync flags (dist.cpp:949-968) -- are written side by side.
+            const int lim = min(min((hi == ri ? r_size : q_size) - 1 - qri, t_size - 1 - ti), 64);
+            if (skip_run > 0) skip_run--;
+            else if (lim >= 2) {
+                const int tq = qri + lane, tt = ti + lane;
+                bool plain = false;
+                if (lane < lim) {
+                    int colr = tq;
+                    bool in_w = true;
+                    if (banded) { colr = tq - blo[hi * t_size + tt]; in_w = colr >= 0 && colr < d.band_w; }
+                    if (in_w) {
+                        const int pb = mat[hi][size_t(tt) * d.pitch[hi] + colr] & 31;
+                        plain = (pb & F_MAT) && !(hi == ri && (pb & F_SWP));
+                    }
+                }
+                const unsigned long long stop = ~__ballot(plain);
+                const int run = stop ? int(__builtin_ctzll(stop)) : 64;
+                if (run >= 2 && n + run <= d.path_cap) {
+                    if (lane < run) {
+                        const int xq = qri + lane + 1, xt = ti + lane + 1;
+                        const int2 rw = wt_[xt];
+                        const int2 cw = (hi == ri) ? wr_[xq] : wq_[xq];
+                        const int tflv = rw.y & 0xff, tr = rw.x;
+                        const int qflv = cw.y & 0xff, qr = (hi == ri) ? xq : cw.x;
+                        const bool ins_loc = ((rw.y | cw.y) & insmask) != 0;
+                        const bool in_t = (tflv & PV) && !(tflv & PB);
+                        const bool in_q = hi == qi && (qflv & PV) && !(qflv & PB);
+                        const bool sync = !in_t && !in_q && !ins_loc && tr == qr;
+                        path[n + lane] = PathEnt{uint32_t(xq) | (uint32_t(hi) << 31), uint32_t(xt) | (uint32_t(sync) << 31), qr, tr};
+                    }
+                    n += run; qri += run; ti += run;
+                    continue;
+                }
+                skip_run = 3;
+            }
+        }
         int p;
         if (WAVE && wide) {
             // dense rows / windows wider than the tile: the tile holds WALK_TW columns of each plane around the walk's
