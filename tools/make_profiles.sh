@@ -3,7 +3,7 @@
 #   bash tools/make_profiles.sh r02 wgs_synth 1000000   -> gpurun_out/profiles_r02_wgs_synth/{r02_kernel_stats_*.csv, r02_counters_*.json}
 # Counter passes use --kernel-trace + --pmc only (never combined with other trace domains).
 set -u
-TAG=${1:-r02}; WL=${2:-wgs_synth}; NSC=${3:-1000000}
+TAG=${1:-r05}; WL=${2:-wgs_synth}; NSC=${3:-1000000}
 R=$(pwd)
 OUT=$R/gpurun_out/profiles_${TAG}_${WL}
 mkdir -p "$OUT"

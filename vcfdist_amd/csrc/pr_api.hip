@@ -385,6 +385,13 @@ struct vpr_handle {
     ZlWave *d_d1_hdr = nullptr; uint32_t *d_d1_in = nullptr; uint4 *d_d1_log = nullptr; int32_t *d_d1_fail = nullptr, *d_d1_info = nullptr;
     int32_t *d_d1_blk = nullptr;                              // per-workgroup counts / offsets of the ordered fail lists (k_fails_*)
     hipEvent_t ev_offsets = nullptr;                          // upload: the batch's offsets are on the device (plan0_device waits for it)
+    // what the upload's one host pass over the superclusters found for round 0's plan (plan0_device): the parts' sums, the total
+    // workspace need in 128-byte units, the long alignments (-matrix bytes, alignment), "some alignment cannot be placed"
+    struct Plan0Pass {
+        bool valid = false, bad = false;
+        int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}, part_rows[2] = {0, 0}, need128 = 0, need_max = 0;
+        std::vector<std::pair<int64_t, int32_t>> big;
+    } p0;
     int64_t d1_in_cap = 0, d1_log_cap = 0;
     int32_t d1_wave_cap = 0, d1_fail_cap = 0;
     int32_t d1_max_rows = 256;                                // rejects of more truth rows stay with the 16-cell kernels (VPR_D1_MAX_ROWS)
@@ -1565,37 +1572,15 @@ int plan0_device(vpr_handle *h, int lv0, hipEvent_t ev_off, bool *done) {
     Plan &P = h->plan0;
     const int LLT = h->long_lt;
     const int64_t cap128 = h->arena_bytes / 128;
-    // ---- host pass: levels, sums, needs' total, the long alignments
-    struct Sums { int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}, part_rows[2] = {0, 0}, need128 = 0; bool bad = false; };
-    std::vector<Sums> sums1(PAR_MAX);
-    std::vector<std::vector<std::pair<int64_t, int32_t>>> big_of(PAR_MAX);
-    par_for(na, [&](size_t b, size_t e, int tid) {
-        Sums &S1 = sums1[size_t(tid)];
-        auto &bigs = big_of[size_t(tid)];
-        AlnDesc d{};
-        for (size_t a = b; a < e; a++) {
-            h->descs.lens(a, d.Lq, d.Lr, d.Lt);
-            d.path_cap = d.Lq + d.Lr + d.Lt + 4;
-            const int dl = plan_level_of(lv0, LLT, d.Lt);
-            const int W = LV_WINDOW[dl], part = d.Lt >= LLT ? 0 : 1;
-            S1.part_cells[part] += int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt;
-            S1.part_in[part] += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
-            S1.part_dense[part] += int64_t(d.Lq + d.Lr) * d.Lt;
-            S1.part_rows[part] += d.Lt;
-            h->level[a] = uint8_t(dl);
-            if (d.Lt >= LLT)
-                bigs.emplace_back(-(int64_t(round_up(std::min(W, d.Lq), 16) + round_up(std::min(W, d.Lr), 16)) * d.Lt), int32_t(a));
-            const int64_t need = window_layout(d, dl, 0, 0);
-            S1.need128 += need / 128;
-            if (need > h->arena_bytes || (d.Lt < LLT && d.Lt > 0xfffe) || d.Lq < 1 || d.Lr < 1 || d.Lt < 1) S1.bad = true;
-        }
-    });
-    int64_t total = 0;
-    bool bad = false;
-    for (const Sums &T : sums1) { total += T.need128; bad = bad || T.bad; }
-    if (bad || total > cap128 || total > int64_t(0xfffffff0)) return VPR_OK;       // (several chunks / an error message: the host planner)
-    std::vector<std::pair<int64_t, int32_t>> big;
-    for (auto &bl : big_of) big.insert(big.end(), bl.begin(), bl.end());
+    // ---- what the upload's pass over the superclusters left (vpr_handle::Plan0Pass): levels are set, sums and the long list here
+    if (!h->p0.valid) return VPR_OK;
+    const vpr_handle::Plan0Pass &S0 = h->p0;
+    const int64_t total = S0.need128;
+    if (S0.bad || S0.need_max > h->arena_bytes || total > cap128 || total > int64_t(0xfffffff0)) {      // (several chunks / an error message: the host planner)
+        h->level.assign(na, uint8_t(LV_DENSE));
+        return VPR_OK;
+    }
+    std::vector<std::pair<int64_t, int32_t>> big = S0.big;
     std::sort(big.begin(), big.end());
     const size_t n = na, n_big = big.size(), n_short = n - n_big;
     // ---- the plan's fields
@@ -1612,13 +1597,12 @@ int plan0_device(vpr_handle *h, int lv0, hipEvent_t ev_off, bool *done) {
         ch.work_off = 0; ch.count = int32_t(n);
         ch.n_long = int32_t(std::min<size_t>(n_big, n));
         const bool no_long = ch.n_long == 0;
-        for (const Sums &T : sums1)
-            for (int q = 0; q < 2; q++) {
-                const int part = no_long ? 1 : q;
-                ch.part_cells[part] += T.part_cells[q]; ch.part_in[part] += T.part_in[q];
-                ch.part_dense[part] += T.part_dense[q]; ch.part_rows[part] += T.part_rows[q];
-                ch.cells += T.part_cells[q]; ch.in_bytes += T.part_in[q];
-            }
+        for (int q = 0; q < 2; q++) {
+            const int part = no_long ? 1 : q;
+            ch.part_cells[part] += S0.part_cells[q]; ch.part_in[part] += S0.part_in[q];
+            ch.part_dense[part] += S0.part_dense[q]; ch.part_rows[part] += S0.part_rows[q];
+            ch.cells += S0.part_cells[q]; ch.in_bytes += S0.part_in[q];
+        }
         P.chunks.push_back(std::move(ch));
     }
     // ---- device: keys -> order -> offsets -> inverse -> wave headers
@@ -2009,10 +1993,20 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     {
         for (int s = 0; s < 4; s++) sec_total += 2 * b->var_off[s][n];
         sec_total += 16 * int64_t(n);
-        struct Acc { int64_t jobs = 0, cells = 0, bytes = 0; int bad = -1; };
+        // ONE pass over the superclusters: the checks and sums of the batch and -- for a windowed round 0 over all alignments, the
+        // usual case -- everything the host contributes to round 0's plan (plan0_device): the level of every alignment, the
+        // parts' sums, the total workspace need (which is also what the arena has to hold), the long alignments.  (Three
+        // passes over four million alignments until round 4, two of them through the full descriptors.)
+        const int lv0_ = h->cfg.band_mode == 0 ? LV_DENSE : h->cfg.band_mode == 2 ? LV_C1 : h->cfg.band_mode == 3 ? LV_Q16 : LV_Z;
+        const bool plan_pass = lv0_ <= LV_Q16 && !(h->cfg.flags & VPR_CFG_HAP_DEDUP) && n > 0;
+        const int LLT = h->long_lt;
+        h->p0 = vpr_handle::Plan0Pass();
+        if (plan_pass) h->level.resize(size_t(n) * 4);
+        struct Acc { int64_t jobs = 0, cells = 0, bytes = 0; int bad = -1; vpr_handle::Plan0Pass P; };
         std::vector<Acc> acc(PAR_MAX);
         par_for(size_t(n), [&](size_t b0, size_t e0, int tid) {
             Acc &A = acc[size_t(tid)];
+            AlnDesc d{};
             for (size_t scu = b0; scu < e0; scu++) {
                 const int sc = int(scu);
                 const int64_t Lr = b->ref_off[sc + 1] - b->ref_off[sc];
@@ -2026,6 +2020,22 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
                     const int64_t Lq = Lh[i >> 1], Lt = Lh[2 + (i & 1)];
                     A.jobs += std::min(Lr, Lt) / 33;
                     A.cells += (Lq + Lr) * Lt;
+                    if (!plan_pass) continue;
+                    d.Lq = int32_t(Lq); d.Lr = int32_t(Lr); d.Lt = int32_t(Lt);
+                    d.path_cap = d.Lq + d.Lr + d.Lt + 4;
+                    const int dl = plan_level_of(lv0_, LLT, d.Lt);
+                    const int W = LV_WINDOW[dl], part = d.Lt >= LLT ? 0 : 1;
+                    A.P.part_cells[part] += int64_t(std::min(W, d.Lq) + std::min(W, d.Lr)) * d.Lt;
+                    A.P.part_in[part] += 6 * int64_t(d.Lq) + 6 * int64_t(d.Lt) + 6 * int64_t(d.Lr);
+                    A.P.part_dense[part] += int64_t(d.Lq + d.Lr) * d.Lt;
+                    A.P.part_rows[part] += d.Lt;
+                    h->level[size_t(sc) * 4 + size_t(i)] = uint8_t(dl);
+                    if (d.Lt >= LLT)
+                        A.P.big.emplace_back(-(int64_t(round_up(std::min(W, d.Lq), 16) + round_up(std::min(W, d.Lr), 16)) * d.Lt), int32_t(sc * 4 + i));
+                    const int64_t need = window_layout(d, dl, 0, 0);
+                    A.P.need128 += need / 128;
+                    A.P.need_max = std::max(A.P.need_max, need);
+                    if ((d.Lt < LLT && d.Lt > 0xfffe) || d.Lq < 1 || d.Lr < 1 || d.Lt < 1) A.P.bad = true;
                 }
             }
         });
@@ -2033,7 +2043,15 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         for (const Acc &A : acc) {
             jobs_total += A.jobs; cells += A.cells; bytes_alg += A.bytes;
             if (A.bad >= 0 && (bad < 0 || A.bad < bad)) bad = A.bad;
+            for (int q = 0; q < 2; q++) {
+                h->p0.part_cells[q] += A.P.part_cells[q]; h->p0.part_in[q] += A.P.part_in[q];
+                h->p0.part_dense[q] += A.P.part_dense[q]; h->p0.part_rows[q] += A.P.part_rows[q];
+            }
+            h->p0.need128 += A.P.need128; h->p0.need_max = std::max(h->p0.need_max, A.P.need_max);
+            h->p0.bad = h->p0.bad || A.P.bad;
+            h->p0.big.insert(h->p0.big.end(), A.P.big.begin(), A.P.big.end());
         }
+        h->p0.valid = plan_pass;
         if (bad >= 0) return fail(h, VPR_ERR_ARG, "supercluster %d has an empty string", bad);
     }
     bytes_alg += 2 * cells;
@@ -2127,6 +2145,8 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         const int bm = h->cfg.band_mode;
         const bool q16ok = (bm == 1 || bm == 3);
         std::vector<int64_t> wants(PAR_MAX, 0);
+        if (h->p0.valid) wants[0] = h->p0.need128 * 128 + 4096;       // (exactly what round 0's plan will ask for)
+        else
         par_for(h->descs.size(), [&](size_t b0, size_t e0, int tid) {
           int64_t want = 0;
           for (size_t k = b0; k < e0; k++) {
@@ -2187,7 +2207,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         par_for(na, [&](size_t b0, size_t e0, int) { for (size_t k = b0; k < e0; k++) all[k] = int32_t(k); });
     }
     const size_t np = all.size();      // alignments that are computed
-    h->level.assign(na, uint8_t(LV_DENSE));
+    if (!h->p0.valid) h->level.assign(na, uint8_t(LV_DENSE));      // (else: set by the upload's pass over the superclusters)
     const int lv0 = h->cfg.band_mode == 0 ? LV_DENSE
                     : h->cfg.band_mode == 2 ? LV_C1
                     : h->cfg.band_mode == 3 ? LV_Q16 : LV_Z;
