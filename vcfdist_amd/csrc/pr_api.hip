@@ -265,10 +265,10 @@ struct LadderCtx {
     // tie ladders only: a side stream for the early replays (they run beside the repeated forward sweep), the event that
     // joins it back, and the replay scratch of each of the two streams (grown on demand, released with the batch)
     hipStream_t ls2 = nullptr; hipEvent_t ev2 = nullptr;
-    uint32_t *tie_scratch[3] = {nullptr, nullptr, nullptr}; int64_t tie_scratch_bytes[3] = {0, 0, 0};      // [2]: the speculative replays' (own stream)
+    uint32_t *tie_scratch[2] = {nullptr, nullptr}; int64_t tie_scratch_bytes[2] = {0, 0};
     // bytes at the front of each scratch that are preset (filled at the start of vpr_execute, beside round 0, with as much
     // as the previous execute's first launch used) and the size of that first launch
-    int64_t tie_clean[3] = {0, 0, 0}, tie_first[3] = {0, 0, 0}; bool tie_first_seen[3] = {false, false, false};
+    int64_t tie_clean[2] = {0, 0}, tie_first[2] = {0, 0}; bool tie_first_seen[2] = {false, false};
 };
 
 struct EvPair { hipEvent_t a, b; int kind; vpr_launch_stat st; };
@@ -347,7 +347,6 @@ struct vpr_handle {
                                                               // own workspaces, beside the arena)
     hipEvent_t ev_slot[2 + 4 * LadderCtx::N_SLOTS] = {};      // "fail list of slot k is complete"
     hipStream_t tie_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // tie ladder k: [2k] main, [2k+1] early replays (high priority)
-    hipStream_t spec_stream = nullptr;    // the speculative replays of the long part: a tie round's own early replays must not queue behind them
     hipEvent_t ev_tie2[2] = {nullptr, nullptr};
     hipEvent_t ev_side[2] = {nullptr, nullptr};               // retry ladder k: "the forward sweeps of the round are enqueued"
     hipEvent_t ev_tie[2] = {nullptr, nullptr};                // "the tie list of the long / short part of round 0 is published"
@@ -395,7 +394,6 @@ struct vpr_handle {
     } p0;
     int64_t d1_in_cap = 0, d1_log_cap = 0;
     int32_t d1_wave_cap = 0, d1_fail_cap = 0;
-    bool no_spec_wait_jobs = false;                           // VPR_SPEC_WAIT_ALL: tie rounds wait for the whole speculative launch (as until round 4)
     int32_t d1_max_rows = 256;                                // rejects of more truth rows stay with the 16-cell kernels (VPR_D1_MAX_ROWS)
     std::vector<ZlWave> zl_hdr_host;
     int32_t long_lt = LONG_LT;                                // rows from which an alignment belongs to the long part of plan 0
@@ -812,7 +810,7 @@ void free_batch(vpr_handle *h) {
     h->d_hist = nullptr; h->hist_cap = 0; h->d_pb = nullptr;
     for (int k = 0; k < 4; k++) {      // (the replay scratches are the handle's, not the batch's: they survive)
         LadderCtx keep;
-        for (int e = 0; e < 3; e++) {
+        for (int e = 0; e < 2; e++) {
             keep.tie_scratch[e] = h->lad[k].tie_scratch[e]; keep.tie_scratch_bytes[e] = h->lad[k].tie_scratch_bytes[e];
             keep.tie_first[e] = h->lad[k].tie_first[e];
         }
@@ -1738,7 +1736,6 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->stall_log = getenv("VPR_STALL_LOG") != nullptr;
     h->seq_walk = getenv("VPR_SEQ_WALK") != nullptr;
     h->no_flag_save = getenv("VPR_NO_FLAG_SAVE") != nullptr;
-    h->no_spec_wait_jobs = getenv("VPR_SPEC_WAIT_ALL") != nullptr;
     h->seq_fwd = getenv("VPR_PAR_FWD") == nullptr;
     if (const char *e = getenv("VPR_LONG_LT")) { const int v = atoi(e); if (v >= 64 && v <= 2048) h->long_lt = v; }     // diagnostic
     memset(&h->dB, 0, sizeof(h->dB));
@@ -1771,8 +1768,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
         if (hipEventCreateWithFlags(&h->ev_slot[k], hipEventDisableTiming) != hipSuccess)
             return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     for (int k = 0; k < 4; k++)
-        if ((k == 0 && hipStreamCreateWithPriority(&h->spec_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) ||
-            hipStreamCreateWithPriority(&h->tie_stream[k], hipStreamNonBlocking, prio_hi) != hipSuccess)
+        if (hipStreamCreateWithPriority(&h->tie_stream[k], hipStreamNonBlocking, prio_hi) != hipSuccess)
             return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
     for (int k = 0; k < 2; k++)
         if (hipEventCreateWithFlags(&h->ev_tie[k], hipEventDisableTiming) != hipSuccess ||
@@ -1801,7 +1797,7 @@ void vpr_destroy(vpr_handle *h) {
     free_batch(h);
     for (auto &b : h->dev_cache) (void)x_free(h, b.p, SITE);
     for (int k = 0; k < 4; k++)
-        for (int e = 0; e < 3; e++) if (h->lad[k].tie_scratch[e]) (void)x_free(h, h->lad[k].tie_scratch[e], SITE);
+        for (int e = 0; e < 2; e++) if (h->lad[k].tie_scratch[e]) (void)x_free(h, h->lad[k].tie_scratch[e], SITE);
     for (auto &b : h->pin_cache) (void)hipHostFree(b.p);
     if (h->d_ctg_seq) (void)x_free(h, h->d_ctg_seq, SITE);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1814,7 +1810,6 @@ void vpr_destroy(vpr_handle *h) {
     for (int k = 0; k < 2 + 4 * LadderCtx::N_SLOTS; k++)
         if (h->ev_slot[k]) (void)hipEventDestroy(h->ev_slot[k]);
     for (int k = 0; k < 4; k++) if (h->tie_stream[k]) (void)hipStreamDestroy(h->tie_stream[k]);
-    if (h->spec_stream) (void)hipStreamDestroy(h->spec_stream);
     for (int k = 0; k < 2; k++) {
         if (h->ev_tie[k]) (void)hipEventDestroy(h->ev_tie[k]);
         if (h->ev_tie2[k]) (void)hipEventDestroy(h->ev_tie2[k]);
@@ -2375,8 +2370,6 @@ struct Exec {
     bool tie_patch_spec = false;                   // the part has alignments whose decisions are in the speculative list
     int spec_slot = -1; int64_t spec_off = 0, spec_cap = 0;
     std::unordered_map<int32_t, int> spec_set;     // alignments with a speculative replay in flight / done
-    std::unordered_map<int32_t, TieJob *> spec_job;    // ... and the record of that replay (host-pinned: its `pad2` turns 1 when it is done)
-    std::vector<TieJob *> spec_needed;             // the speculative replays the tie round being enqueued takes its decisions from
     LadderCtx *tie_ctx;                            // the tie ladder whose round is being enqueued
     bool lad_tie_wait[2] = {false, false};         // a retry ladder's tie list is on its way
     std::vector<std::pair<TieJob *, size_t>> tie_job_blocks;   // (debug) the job blocks of this execute
@@ -2466,7 +2459,7 @@ struct Exec {
         if (idle_polls % 2048) return VPR_OK;            // about every 40 ms without progress
         hipStream_t ss[] = {h->stream, h->cls_stream[0], h->cls_stream[1], h->cls_stream[2], h->cls_stream[3], h->cls_stream[4],
                             h->cls_stream[5], h->cls_stream[6], h->cls_stream[7],
-                            h->tie_stream[0], h->tie_stream[1], h->tie_stream[2], h->tie_stream[3], h->spec_stream};
+                            h->tie_stream[0], h->tie_stream[1], h->tie_stream[2], h->tie_stream[3]};
         bool busy = false;
         for (hipStream_t s_ : ss) {
             const hipError_t e = hipStreamQuery(s_);
@@ -2507,11 +2500,11 @@ struct Exec {
         });
     }
 
-    int tie_replay(const Plan &P, int64_t off, int32_t cnt, hipStream_t ks_main, bool early, bool spec = false) {
-        if (early) { tie_patch_slot = -1; tie_patch_spec = false; spec_needed.clear(); }
+    int tie_replay(const Plan &P, int64_t off, int32_t cnt, hipStream_t ks_main, bool early) {
+        if (early) { tie_patch_slot = -1; tie_patch_spec = false; }
         LadderCtx &tc = *tie_ctx;
-        hipStream_t ks = spec ? h->spec_stream : (early ? tc.ls2 : ks_main);
-        const int se = spec ? 2 : (early ? 1 : 0);      // the scratch of the stream the replays run on
+        hipStream_t ks = early ? tc.ls2 : ks_main;
+        const int se = early ? 1 : 0;      // the scratch of the stream the replays run on
         uint32_t *&scratch = tc.tie_scratch[se];
         int64_t &scratch_bytes = tc.tie_scratch_bytes[se];
         // scratch words of every job; the scratch grows to hold the whole launch (all replays concurrent: a long one is a
@@ -2524,12 +2517,7 @@ struct Exec {
             const AlnDesc d = plan_desc(h, P, size_t(off) + k);
             const auto it = tie_early.find(P.work[size_t(off) + k]);
             if ((it != tie_early.end()) != early) continue;
-            if (early && it->second.mode == 3) {
-                tie_patch_spec = true;
-                const auto sj = spec_job.find(P.work[size_t(off) + k]);
-                if (sj != spec_job.end()) spec_needed.push_back(sj->second);
-                continue;
-            }
+            if (early && it->second.mode == 3) { tie_patch_spec = true; continue; }
             Need N;
             N.k = k;
             // stamp words: both planes, diagonal-major; the diagonals a cell within the alignment's distance of the
@@ -2621,7 +2609,6 @@ struct Exec {
                 tie_dec_cur = 0;
             }
             dec = h->d_tie_dec + tie_dec_cur;
-            HIPCHK(h, hipMemsetAsync(dec, 0xff, size_t(dec_cap) * sizeof(int4), ks));      // (k_tie_patch may read it while replays still append)
             n_dec = h->d_tie_ndec + tie_dec_slot;
             tie_patch_slot = tie_dec_slot++; tie_patch_off = tie_dec_cur; tie_patch_cap = dec_cap;
             tie_dec_cur += dec_cap;
@@ -2672,7 +2659,7 @@ struct Exec {
             if (rc) return rc;
             k0 = k1;
         }
-        if (early && !spec) { HIPCHK(h, hipEventRecord(tc.ev2, ks)); (void)hipStreamQuery(ks); }
+        if (early) { HIPCHK(h, hipEventRecord(tc.ev2, ks)); (void)hipStreamQuery(ks); }
         return VPR_OK;
     }
 
@@ -2685,22 +2672,7 @@ struct Exec {
             tie_patch_slot = -1;
         }
         if (tie_patch_spec && spec_slot >= 0) {
-            // not the whole speculative launch (hipStreamWaitEvent on ev_spec): it lasts as long as its longest replay -- 8.8 ms for a
-            // 3 763-row alignment whose ties nobody consulted -- but the replays of the alignments of THIS round
-            if (h->debug) {
-                fprintf(stderr, "[vpr] tie round takes the decisions of %zu speculative replays:", spec_needed.size());
-                for (size_t k = 0; k < spec_needed.size() && k < 40; k++) fprintf(stderr, " sc %d aln %d", spec_needed[k]->a >> 2, spec_needed[k]->a & 3);
-                fprintf(stderr, "\n");
-            }
-            if (spec_needed.empty() || h->no_spec_wait_jobs) HIPCHK(h, hipStreamWaitEvent(ks, h->ev_spec, 0));
-            else {
-                void *pb = nullptr;
-                { int rc_pin = exec_pin(h, &pb, spec_needed.size() * sizeof(TieJob *)); if (rc_pin) return rc_pin; }
-                memcpy(pb, spec_needed.data(), spec_needed.size() * sizeof(TieJob *));
-                hipLaunchKernelGGL(k_wait_jobs, blocks(int64_t(spec_needed.size())), dim3(256), 0, ks, static_cast<TieJob *const *>(pb),
-                                   int(spec_needed.size()), h->d_outs);
-            }
-            spec_needed.clear();
+            HIPCHK(h, hipStreamWaitEvent(ks, h->ev_spec, 0));
             hipLaunchKernelGGL(k_tie_patch, blocks(spec_cap), dim3(256), 0, ks, h->d_descs, h->d_tie_dec + spec_off,
                                h->d_tie_ndec + spec_slot, int(spec_cap), P.arena, tag);
             tie_patch_spec = false;
@@ -3548,14 +3520,13 @@ struct Exec {
         const size_t j0 = tie_job_cur;
         tie_full = false;
         if (h->debug) fprintf(stderr, "[vpr] speculative replays: %d long alignments\n", n);
-        int rc_ = tie_replay(spec_plan, 0, n, LT.ls, true, true);
+        int rc_ = tie_replay(spec_plan, 0, n, LT.ls, true);
         if (rc_) return rc_;
         spec_slot = tie_patch_slot; spec_off = tie_patch_off; spec_cap = tie_patch_cap;
         tie_patch_slot = -1;
-        HIPCHK(h, hipEventRecord(h->ev_spec, h->spec_stream));
-        (void)hipStreamQuery(h->spec_stream);
+        HIPCHK(h, hipEventRecord(h->ev_spec, LT.ls2));
+        (void)hipStreamQuery(LT.ls2);
         for (int32_t k = 0; k < n; k++) spec_set[lst[k].x] = 1;
-        for (size_t j = j0; j < tie_job_cur; j++) spec_job[h->hp_tie_jobs[j].a] = h->hp_tie_jobs + j;
         tie_early.clear();
         tie_job_blocks.emplace_back(h->hp_tie_jobs + j0, tie_job_cur - j0);
         tie_job_total += tie_job_cur - j0;
@@ -3604,13 +3575,12 @@ struct Exec {
             HIPCHK(h, hipStreamWaitEvent(LL.ls, h->ev_fork, 0));
             HIPCHK(h, hipStreamWaitEvent(LS.ls, h->ev_fork, 0));
             for (int k = 0; k < 4; k++) HIPCHK(h, hipStreamWaitEvent(h->tie_stream[k], h->ev_fork, 0));
-            HIPCHK(h, hipStreamWaitEvent(h->spec_stream, h->ev_fork, 0));
             for (int k = 2; k < 4; k++)          // preset the replay scratches beside round 0 (see LadderCtx::tie_clean)
-                for (int e = 0; e < 3; e++) {
+                for (int e = 0; e < 2; e++) {
                     LadderCtx &c = h->lad[k];
                     c.tie_clean[e] = 0;
                     if (ci == 0 && c.tie_scratch[e] && c.tie_first[e] > 0 && c.tie_first[e] <= c.tie_scratch_bytes[e]) {
-                        HIPCHK(h, hipMemsetAsync(c.tie_scratch[e], 0xff, size_t(c.tie_first[e]), e == 2 ? h->spec_stream : (e ? c.ls2 : c.ls)));
+                        HIPCHK(h, hipMemsetAsync(c.tie_scratch[e], 0xff, size_t(c.tie_first[e]), e ? c.ls2 : c.ls));
                         c.tie_clean[e] = c.tie_first[e];
                     }
                     c.tie_first_seen[e] = false;
@@ -3622,7 +3592,7 @@ struct Exec {
             // help: the bulk kernels' millions of workgroups starve a concurrent launch until they drain.)
             const int32_t n_short = ch.count - n_long;
             bool wait_spec = false;
-            spec_set.clear(); spec_job.clear(); spec_slot = -1;
+            spec_set.clear(); spec_slot = -1;
             const int SLOT_IP = LS.slot0 + LadderCtx::N_SLOTS - 1;          // fail slot of the in-place round
             const int64_t foff_ip = rbase + na_ - n_short;                 // tail of the ladders' fail region
             const int32_t cap_ip = std::min<int32_t>(n_short, std::max<int32_t>(4096, (n_short / 4 + 3) & ~3));
@@ -3791,7 +3761,6 @@ struct Exec {
             HIPCHK(h, hipEventRecord(h->ev_join[6], LL.ls2));
             HIPCHK(h, hipEventRecord(h->ev_join[7], LS.ls2));
             for (int k = 0; k < 8; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
-            if (spec_slot >= 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_spec, 0));      // (no tie round may have waited for all of it)
             if (ci + 1 < P0.chunks.size()) HIPCHK(h, x_sync(h, st, SITE));
             if (ci + 1 == P0.chunks.size()) { h->res0_off = ch.work_off; h->res0_cnt = ch.count; }
         }

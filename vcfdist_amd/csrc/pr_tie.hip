@@ -745,24 +745,6 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
         jobs[j].dbg_nres = lds_nres; jobs[j].dbg_lastw = dbg_lastw;
         for (int k = 0; k < 8; k++) jobs[j].dbg_t[k] = int32_t(dbg_t[k] / 100);
     }
-    // "this job's decisions are all in the list": a tie round waits for the jobs of ITS alignments (k_wait_jobs) instead of for the
-    // whole launch -- the launch lasts as long as its longest replay, which is seldom one the backward sweeps consulted
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(&jobs[j].pad2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// wait until the replays `need[0 .. n)` (records in host-pinned memory) have finished.  Bounded (about two seconds): a job that
-// never reports marks its alignment VPR_ST_ERR_UNFINISHED instead of hanging the device
-__global__ void k_wait_jobs(TieJob *const *__restrict__ need, int n, AlnOut *__restrict__ outs) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    TieJob *J = need[k];
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(&J->pad2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
-        __builtin_amdgcn_s_sleep(64);
-        if (wall_clock64() - t0 > 200000000ull) { atomicOr(&outs[J->a].status, VPR_ST_ERR_UNFINISHED); break; }
-    }
 }
 
 // apply a launch's decision list to the flags the repeated forward sweep has just written (tie-round descriptors)
@@ -772,7 +754,6 @@ __global__ void k_tie_patch(const AlnDesc *__restrict__ descs, const int4 *__res
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(*n_dec, dec_cap)) return;
     const int4 e = dec[i];
-    if (e.x < 0) return;        // (a slot a replay that is still running has reserved but not written: the list is preset to -1)
     const AlnDesc d = descs[e.x];
     if (d.band_pad != tag) return;
     uint8_t *fp = tie_flag_ptr(d, ws, reinterpret_cast<const int32_t *>(ws), int(uint32_t(e.y) >> 31), e.y & 0x7fffffff, e.z);
