@@ -385,6 +385,8 @@ struct vpr_handle {
     ZlWave *d_d1_hdr = nullptr; uint32_t *d_d1_in = nullptr; uint4 *d_d1_log = nullptr; int32_t *d_d1_fail = nullptr, *d_d1_info = nullptr;
     int32_t *d_d1_blk = nullptr;                              // per-workgroup counts / offsets of the ordered fail lists (k_fails_*)
     hipEvent_t ev_offsets = nullptr;                          // upload: the batch's offsets are on the device (plan0_device waits for it)
+    hipEvent_t ev_cred[2] = {nullptr, nullptr};               // the lane levels' credit walks on a side stream: fork / join
+    bool side_credit = true;                                  // (VPR_NO_SIDE_CREDIT: behind the 16-cell round on the part's stream, as until round 4)
     // what the upload's one host pass over the superclusters found for round 0's plan (plan0_device): the parts' sums, the total
     // workspace need in 128-byte units, the long alignments (-matrix bytes, alignment), "some alignment cannot be placed"
     struct Plan0Pass {
@@ -1736,6 +1738,9 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->stall_log = getenv("VPR_STALL_LOG") != nullptr;
     h->seq_walk = getenv("VPR_SEQ_WALK") != nullptr;
     h->no_flag_save = getenv("VPR_NO_FLAG_SAVE") != nullptr;
+    h->side_credit = getenv("VPR_NO_SIDE_CREDIT") == nullptr;
+    for (int k = 0; k < 2; k++)
+        if (hipEventCreateWithFlags(&h->ev_cred[k], hipEventDisableTiming) != hipSuccess) return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     h->seq_fwd = getenv("VPR_PAR_FWD") == nullptr;
     if (const char *e = getenv("VPR_LONG_LT")) { const int v = atoi(e); if (v >= 64 && v <= 2048) h->long_lt = v; }     // diagnostic
     memset(&h->dB, 0, sizeof(h->dB));
@@ -1817,6 +1822,7 @@ void vpr_destroy(vpr_handle *h) {
     }
     if (h->ev_spec) (void)hipEventDestroy(h->ev_spec);
     if (h->ev_offsets) (void)hipEventDestroy(h->ev_offsets);
+    for (int k = 0; k < 2; k++) if (h->ev_cred[k]) (void)hipEventDestroy(h->ev_cred[k]);
     delete h;
 }
 
@@ -3617,10 +3623,24 @@ struct Exec {
                 const bool d1 = h->d_d1_hdr != nullptr && cap_ip <= h->d1_wave_cap * 64;
                 const int32_t n_all1 = n_short + n_short / 16 + 64;
                 if (d1) HIPCHK(h, hipMemsetAsync(h->d_d1_info + 2, 0, 4, s_short));
+                // The credit walks of what the two lane kernels finished only need those kernels: on a side stream beside the in-place
+                // 16-cell round instead of behind it (the short part is one of the step's three chains)
+                hipStream_t s_cred = h->side_credit ? h->cls_stream[7] : s_short;       // (a dense class's stream: idle in a windowed round 0)
                 for (int ph = 1; ph <= 4; ph <<= 1) {
-                    if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, n_short, LV_Z, s_short, 1, n_long, false,
-                                           ch.part_cells[1], ch.part_in[1], ch.part_dense[1], -1, ph))) return rc;
-                    if (d1 && (rc = enqueue_d1(h->d_fail + n_long, n_dev, cap_ip, n_all1, s_short, ph, ztag))) return rc;
+                    if (ph != 4 || s_cred == s_short) {
+                        if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, n_short, LV_Z, s_short, 1, n_long, false,
+                                               ch.part_cells[1], ch.part_in[1], ch.part_dense[1], -1, ph))) return rc;
+                        if (d1 && (rc = enqueue_d1(h->d_fail + n_long, n_dev, cap_ip, n_all1, s_short, ph, ztag))) return rc;
+                    }
+                    if (ph == 1 && s_cred != s_short) {
+                        HIPCHK(h, hipEventRecord(h->ev_cred[0], s_short));
+                        HIPCHK(h, hipStreamWaitEvent(s_cred, h->ev_cred[0], 0));
+                        if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, n_short, LV_Z, s_cred, 1, n_long, false,
+                                               ch.part_cells[1], ch.part_in[1], ch.part_dense[1], -1, 4))) return rc;
+                        if (d1 && (rc = enqueue_d1(h->d_fail + n_long, n_dev, cap_ip, n_all1, s_cred, 4, ztag))) return rc;
+                        HIPCHK(h, hipEventRecord(h->ev_cred[1], s_cred));
+                    }
+                    if (ph == 4 && s_cred != s_short) HIPCHK(h, hipStreamWaitEvent(s_short, h->ev_cred[1], 0));
                     // entries past cap_ip (more than a quarter of the part rejected) stay rejected and go to the ladder
                     if ((rc = d1 ? enqueue_part(P0, h->d_d1_fail, 0, cap_ip, LV_Q16, s_short, SLOT_IP, foff_ip, false, 0, 0, 0,
                                                 ztag, ph, h->d_d1_info + 2, std::min<int32_t>(h->d1_fail_cap, n_all1 + n_all1 / 64 + 64))
