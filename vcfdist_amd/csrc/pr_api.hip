@@ -299,6 +299,10 @@ struct vpr_handle {
     std::vector<Blk> parked;             // device blocks outgrown during an execute: to dev_cache when the batch is released
     int64_t dev_total = 0;               // the device's memory (vpr_create)
     int64_t tie_scratch_max = 0, lad_arena_max = 0;   // bounds of the replay scratches / ladder workspaces that grow on demand
+    // The batch's memory plan (vpr_upload): of the device memory free at that point the library leaves mem_reserve alone,
+    // round 0's workspace takes what its plan asks for (at most arena_share() of the rest), and what remains is split
+    // between the ladders' workspaces and the replay scratches, which start small and grow on demand inside their halves.
+    int64_t mem_reserve = 0, lad_budget = 0, tie_budget = 0, lad_bytes = 0, tie_bytes = 0;
     std::vector<size_t> alloc_bytes;     // sizes of `allocs`
     std::vector<void *> allocs;
     uint8_t *pool_cur = nullptr;         // bump pointer into the newest block
@@ -411,6 +415,7 @@ struct vpr_handle {
     int32_t *d_ed_scratch = nullptr; size_t ed_scratch_ints = 0;
     std::vector<EvPair> events;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;   // timing events, reused by every execute
+    std::vector<hipStream_t> pad_streams;                  // (diagnostic, VPR_STREAM_PAD)
     DevResults dR;                       // final results, produced on the device
     vpr_timing timing;
     bool uploaded = false, executed = false;
@@ -567,10 +572,12 @@ static int64_t dev_reserve_bytes() {
     static const int64_t v = [] { const char *e = getenv("VPR_DEV_RESERVE_MB"); return (e ? int64_t(atoll(e)) : int64_t(1536)) << 20; }();
     return v;
 }
-// shares of the free device memory at upload: round 0's workspace, and each of the four ladder workspaces of what that leaves
-// (VPR_ARENA_SHARE / VPR_LADDER_SHARE: diagnostic)
-static double arena_share() { static const double v = [] { const char *e = getenv("VPR_ARENA_SHARE"); return e ? atof(e) : 0.55; }(); return v; }
-static double ladder_share() { static const double v = [] { const char *e = getenv("VPR_LADDER_SHARE"); return e ? atof(e) : 0.1; }(); return v; }
+// The batch's memory plan: the share of the DEVICE the library leaves free (VPR_DEV_FREE_SHARE), and the share of the rest
+// round 0's workspace may take (VPR_ARENA_SHARE; it takes what its plan asks for when that is less).  What remains is the
+// ladders' and the replays' (vpr_upload).  VPR_LADDER_SHARE scales the ladders' first workspaces (diagnostic).
+static double free_share() { static const double v = [] { const char *e = getenv("VPR_DEV_FREE_SHARE"); return e ? atof(e) : 0.11; }(); return v; }
+static double arena_share() { static const double v = [] { const char *e = getenv("VPR_ARENA_SHARE"); return e ? atof(e) : 0.7; }(); return v; }
+static double ladder_share() { static const double v = [] { const char *e = getenv("VPR_LADDER_SHARE"); return e ? atof(e) : 1.0; }(); return v; }
 hipError_t x_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
     const double t = wall_ms();
     {
@@ -582,7 +589,7 @@ hipError_t x_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
         // array used to fail with less than the reserve free)
         int64_t reserve = bytes >= (size_t(64) << 20) || (h && h->soft_alloc) ? dev_reserve_bytes() : 0;
         if (reserve > 0 && hipMemGetInfo(&fr, &tt) == hipSuccess) {
-            if (h && h->soft_alloc) reserve = std::max<int64_t>(reserve, int64_t(tt) / 32);
+            if (h && h->soft_alloc) reserve = std::max<int64_t>(reserve, std::max<int64_t>(int64_t(tt) / 32, h->mem_reserve));
         }
         if (reserve > 0 && tt > 0 && int64_t(fr) < int64_t(bytes) + reserve &&
             int64_t(bytes) + reserve < int64_t(tt)) {       // (a device smaller than the reserve: no reserve)
@@ -1745,9 +1752,17 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     if (const char *e = getenv("VPR_LONG_LT")) { const int v = atoi(e); if (v >= 64 && v <= 2048) h->long_lt = v; }     // diagnostic
     memset(&h->dB, 0, sizeof(h->dB));
     memset(&h->timing, 0, sizeof(h->timing));
-    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
+    // (diagnostic) VPR_STREAM_PRIO: one letter per stream -- class streams 0..7, tie streams 0..3, the handle's main stream --
+    // h(igh), n(ormal), l(ow)
+    const char *prio_map = getenv("VPR_STREAM_PRIO");
+    if (prio_map && strlen(prio_map) != size_t(N_CLASSES + 5)) prio_map = nullptr;
+    if (hipSetDevice(cfg->device) != hipSuccess) { delete h; return fail(nullptr, VPR_ERR_DEVICE, "hipSetDevice failed"); }
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    auto prio_of = [&](int idx, int dflt) { return !prio_map ? dflt : (prio_map[idx] == 'h' ? prio_hi : (prio_map[idx] == 'l' ? prio_lo : (prio_hi + prio_lo) / 2)); };
+    if (hipStreamCreateWithPriority(&h->stream, hipStreamDefault, prio_of(N_CLASSES + 4, (prio_hi + prio_lo) / 2)) != hipSuccess) {
         delete h;
-        return fail(nullptr, VPR_ERR_DEVICE, "hipSetDevice/hipStreamCreate failed");
+        return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
     }
     {   // bounds of what grows on demand during an execute: fractions of the DEVICE's memory, fixed here
         size_t free_b = 0, total_b = 0;
@@ -1758,12 +1773,28 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     }
     // Streams 0, 2, 3 carry latency chains (long alignments, retry ladders) and get the highest priority, so their
     // few workgroups are dispatched ahead of the millions of the bulk stream (1) instead of behind them.
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (const char *e = getenv("VPR_STREAM_PAD")) {
+        // (diagnostic) "lo:hi,lo:hi,...": the i-th handle of the process creates that many idle streams of either priority
+        // before its own, which shifts the hardware queues the runtime maps its streams onto
+        static std::atomic<int> n_handles{0};
+        const int me = n_handles.fetch_add(1);
+        const char *p = e;
+        for (int i = 0; i < me && p; i++) { p = strchr(p, ','); if (p) p++; }
+        if (p) {
+            const int n_lo = atoi(p);
+            const char *c = strchr(p, ':');
+            const char *stop = strchr(p, ',');
+            const int n_hi = (c && (!stop || c < stop)) ? atoi(c + 1) : 0;
+            for (int k = 0; k < n_lo + n_hi && k < 64; k++) {
+                hipStream_t st = nullptr;
+                if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, k < n_lo ? prio_lo : prio_hi) == hipSuccess) h->pad_streams.push_back(st);
+            }
+        }
+    }
     for (int k = 0; k < N_CLASSES; k++) {
         // (tried: the retry rounds' side streams 5, 6 at high priority -- their back halves then start 2 ms earlier and the step
         // with two batches in flight gets 2 ms LONGER: they take the bulk kernels' slots)
-        const int prio = (k == 0 || k == 2 || k == 3) ? prio_hi : prio_lo;
+        const int prio = prio_of(k, (k == 0 || k == 2 || k == 3) ? prio_hi : prio_lo);
         if (hipStreamCreateWithPriority(&h->cls_stream[k], hipStreamNonBlocking, prio) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming) != hipSuccess) {
             return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
@@ -1773,7 +1804,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
         if (hipEventCreateWithFlags(&h->ev_slot[k], hipEventDisableTiming) != hipSuccess)
             return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     for (int k = 0; k < 4; k++)
-        if (hipStreamCreateWithPriority(&h->tie_stream[k], hipStreamNonBlocking, prio_hi) != hipSuccess)
+        if (hipStreamCreateWithPriority(&h->tie_stream[k], hipStreamNonBlocking, prio_of(N_CLASSES + k, prio_hi)) != hipSuccess)
             return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
     for (int k = 0; k < 2; k++)
         if (hipEventCreateWithFlags(&h->ev_tie[k], hipEventDisableTiming) != hipSuccess ||
@@ -1815,6 +1846,7 @@ void vpr_destroy(vpr_handle *h) {
     for (int k = 0; k < 2 + 4 * LadderCtx::N_SLOTS; k++)
         if (h->ev_slot[k]) (void)hipEventDestroy(h->ev_slot[k]);
     for (int k = 0; k < 4; k++) if (h->tie_stream[k]) (void)hipStreamDestroy(h->tie_stream[k]);
+    for (hipStream_t st : h->pad_streams) (void)hipStreamDestroy(st);
     for (int k = 0; k < 2; k++) {
         if (h->ev_tie[k]) (void)hipEventDestroy(h->ev_tie[k]);
         if (h->ev_tie2[k]) (void)hipEventDestroy(h->ev_tie2[k]);
@@ -2143,7 +2175,16 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     // ---- arena for flag matrices, band origins and walks
     size_t free_b = 0, total_b = 0;
     HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
-    int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes : int64_t(double(free_b) * arena_share());
+    // what the batch may take: the free memory (the blocks kept from the previous batch count: the allocations below take
+    // them first) less the tenth of the device the library leaves alone; on a device mostly taken by others, half of what is free
+    int64_t avail = int64_t(free_b);
+    for (const auto &c : h->dev_cache) avail += int64_t(c.bytes);
+    int64_t scratch_kept = 0;            // (the replay scratches have the handle's lifetime: part of the plan, and taken already)
+    for (int k = 0; k < 4; k++) for (int e = 0; e < 2; e++) scratch_kept += h->lad[k].tie_scratch_bytes[e];
+    avail += scratch_kept;
+    h->mem_reserve = int64_t(double(total_b) * free_share());
+    avail = std::max<int64_t>(avail - h->mem_reserve, avail / 2);
+    int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes : int64_t(double(avail) * arena_share());
     if (budget < (8 << 20)) budget = 8 << 20;
     // do not allocate more than round 0 can use (its layout per alignment: make_plan)
     int64_t want = 0;
@@ -2177,17 +2218,23 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     }
     h->arena_bytes = budget;
     if ((rc = dev_alloc(h, &h->d_arena, size_t(budget) + 256))) return rc;
-    // workspaces of the two retry ladders, which run beside round 0 (cfg.workspace_bytes bounds each workspace;
-    // otherwise they start small and grow on demand, vpr_execute)
+    // What round 0 left is split between the ladders' workspaces and the replay scratches.  The ladders (two retry ladders
+    // beside round 0, two for the tie rounds) start with a sixteenth of round 0's need each -- the short part's with at most
+    // 2 GB -- and grow on demand inside their half (lad_grow); the replay scratches are allocated by the first tie round
+    // (cfg.workspace_bytes bounds each workspace instead).
     {
-        HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
-        int64_t b2 = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes
-                                                // (four of them: together at most half of what round 0 left, the rest is for the
-                                                //  result columns, the tie replays' scratch and the deferred edit distances)
-                                                : std::min<int64_t>(int64_t(double(free_b) * ladder_share()), std::max<int64_t>(want / 16, int64_t(1) << 30));
-        if (b2 < (8 << 20)) b2 = 8 << 20;
+        const int64_t rest = std::max<int64_t>(avail - budget, 0);
+        h->lad_budget = rest / 2; h->tie_budget = rest - rest / 2;
+        h->lad_bytes = 0; h->tie_bytes = scratch_kept;
         for (int k = (h->cfg.band_mode != 0 ? 0 : 2); k < 4; k++) {   // (dense mode: only the tie rounds need one)
+            int64_t b2 = h->cfg.workspace_bytes;
+            if (b2 <= 0) {
+                b2 = std::min<int64_t>(h->lad_budget / 4, int64_t(ladder_share() * double(std::max<int64_t>(want / 16, int64_t(1) << 30))));
+                if (k & 1) b2 = std::min<int64_t>(b2, int64_t(2) << 30);
+            }
+            if (b2 < (8 << 20)) b2 = 8 << 20;
             h->lad[k].arena_bytes = b2;
+            h->lad_bytes += b2;
             if ((rc = dev_alloc(h, &h->lad[k].arena, size_t(b2) + 256))) return rc;
         }
     }
@@ -2576,10 +2623,15 @@ struct Exec {
         // moment).  The outgrown block is PARKED, not freed (kernels of this stream may still use it, and hipFree both waits
         // for the whole device and takes seconds for a block of gigabytes): free_batch moves it to the kept blocks.  The
         // scratches themselves have the handle's lifetime.
-        if (largest * 4 + 256 > scratch_bytes || (total * 4 + 256 > scratch_bytes && scratch_bytes < h->tie_scratch_max)) {
-            const int64_t nb = std::max<int64_t>(std::max<int64_t>(std::min<int64_t>(total * 4, h->tie_scratch_max), 2 * scratch_bytes), largest * 4) + 256;
+        // Inside the replays' half of the batch's memory plan: a scratch takes at most two thirds of what is left of it (the
+        // launches of the other contexts want theirs), the outgrown block counts until the batch is released; what the
+        // largest job needs is granted whatever the plan says.
+        const bool must = largest * 4 + 256 > scratch_bytes;
+        const int64_t room = std::max<int64_t>(h->tie_budget - h->tie_bytes, 0) / 3 * 2;
+        const int64_t nb_plan = std::min<int64_t>(std::max<int64_t>(std::min<int64_t>(total * 4, h->tie_scratch_max), 2 * scratch_bytes), room);
+        if (must || (total * 4 + 256 > scratch_bytes && scratch_bytes < h->tie_scratch_max && nb_plan > scratch_bytes + scratch_bytes / 2)) {
+            const int64_t nb = std::max<int64_t>(nb_plan, largest * 4) + 256;
             void *q = nullptr;
-            const bool must = largest * 4 + 256 > scratch_bytes;
             int64_t got_b = nb;
             h->soft_alloc = !must;
             hipError_t e_sc = x_malloc(h, &q, size_t(nb), SITE);
@@ -2597,6 +2649,7 @@ struct Exec {
                 if (scratch) h->parked.push_back(vpr_handle::Blk{scratch, size_t(scratch_bytes)});
                 scratch = static_cast<uint32_t *>(q);
                 scratch_bytes = got_b;
+                h->tie_bytes += got_b;
                 tc.tie_clean[se] = 0;
             }
         }
@@ -3257,23 +3310,39 @@ struct Exec {
     // on depends on which is idle at that moment, so they grow together and one execute settles the sizes of both.  The
     // old blocks stay allocated until the batch is released (dev_alloc: the plans in flight point into them), so nothing
     // has to be waited for.
-    bool lad_grow(LadderCtx &c, int64_t nb) {
+    // must: what one alignment of the round needs -- granted outside the ladders' half of the memory plan if it has to be
+    bool lad_grow(LadderCtx &c, int64_t nb, int64_t must = 0) {
         const int k = int(&c - h->lad);
         for (int j = 0; j < 4; j++) {
             LadderCtx &g = h->lad[j];
-            if (&g != &c && !(k < 2 && j == 1 - k)) continue;
+            const bool sibling = &g != &c;
+            if (sibling && !(k < 2 && j == 1 - k)) continue;
             if (g.arena_bytes >= nb) continue;
+            // (inside the ladders' half of the batch's memory plan: the outgrown block stays allocated, so the new one counts whole)
+            const int64_t need = sibling ? 0 : must;
+            int64_t nb_g = std::max<int64_t>(std::min<int64_t>(nb, h->lad_budget - h->lad_bytes), need);
+            if (nb_g < g.arena_bytes + g.arena_bytes / 2 && need <= g.arena_bytes) {
+                if (!sibling) return false;
+                continue;
+            }
             uint8_t *na2 = nullptr;
             h->soft_alloc = true;
-            const int rc_grow = dev_alloc(h, &na2, size_t(nb) + 256);
+            int rc_grow = dev_alloc(h, &na2, size_t(nb_g) + 256);
             h->soft_alloc = false;
+            if (rc_grow != VPR_OK && need > g.arena_bytes && need < nb_g) {      // what it must have, then
+                h->err.clear();
+                (void)hipGetLastError();
+                nb_g = need;
+                rc_grow = dev_alloc(h, &na2, size_t(nb_g) + 256);
+            }
             if (rc_grow != VPR_OK) {
                 h->err.clear();
                 (void)hipGetLastError();
-                if (&g == &c) return false;
+                if (!sibling) return false;
                 continue;
             }
-            g.arena = na2; g.arena_bytes = nb; g.arena_cur = 0;
+            h->lad_bytes += nb_g;
+            g.arena = na2; g.arena_bytes = nb_g; g.arena_cur = 0;
         }
         return true;
     }
@@ -3342,7 +3411,7 @@ struct Exec {
             }
             if (rc == VPR_ERR_NOMEM && h->cfg.workspace_bytes <= 0) {
                 // one alignment does not fit the ladder's workspace: grow it to twice that need
-                if (lad_grow(c, std::max<int64_t>(2 * h->last_need, 2 * c.arena_bytes)))
+                if (lad_grow(c, std::max<int64_t>(2 * h->last_need, 2 * c.arena_bytes), h->last_need + (1 << 20)))
                     rc = make_plan(h, by_lv[lv], lv, P, c.arena, c.arena_bytes, tag_or);
             }
             if (rc) return rc;
@@ -3841,6 +3910,8 @@ struct Exec {
                         js[k].mode, js[k].n_used, js[k].dbg_nres, js[k].dbg_lastw);
                 fprintf(stderr, "[vpr]     us: BFS %d, patch %d, order A %d B %d suffix %d C %d, seeding %d, setup %d\n", js[k].dbg_t[0], js[k].dbg_t[1],
                         js[k].dbg_t[2], js[k].dbg_t[3], js[k].dbg_t[4], js[k].dbg_t[5], js[k].dbg_t[6], js[k].dbg_t[7]);
+                fprintf(stderr, "[vpr]     narrow steps %d: %d not in one row, %d shrinking or growing, %d not reproduced, %d look-ahead steps committing %d levels\n",
+                        js[k].dbg_la[0], js[k].dbg_la[1], js[k].dbg_la[2], js[k].dbg_la[3], js[k].dbg_la[4], js[k].dbg_la[5]);
             }
         }
     }

@@ -68,6 +68,7 @@ struct TieJob {
     uint8_t *old_arena;
     int32_t dbg_us, dbg_steps, dbg_cells, dbg_waves, dbg_nres, dbg_lastw;
     int32_t dbg_oob[4];   // (debug) first cell outside the stamp grids: plane, position, row, wave
+    int32_t dbg_la[6];    // (debug) narrow steps: all, not in one row, frontier not reproduced (count / slots), look-ahead steps, levels they committed
     int32_t dbg_t[8];     // us in: BFS, patch, order A, B, suffix, C, seeding, setup   // written by the kernel (the jobs live in host-pinned memory): VPR_DEBUG
 };
 #define TIE_BUF_WORDS 10
@@ -105,6 +106,7 @@ __device__ __forceinline__ uint8_t *tie_flag_ptr(const AlnDesc &d, uint8_t *ws, 
 // per-wave counts through LDS across waves), so the result does not depend on the number of waves.  A narrow frontier
 // (<= 64 entries: a chain of dependent steps) is expanded by wave 0 alone, which publishes the queue state to the others.
 #define TIE_NW 4
+#define TIE_LA 4   // levels of a narrow stretch a lane looks at per step
 #define TIE_NT (64 * TIE_NW)
 
 __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc *__restrict__ descs,
@@ -145,6 +147,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
     const int s_fin = outs[a].s;
     const unsigned long long clk0 = wall_clock64();
     int dbg_steps = 0, dbg_cells = 0, dbg_waves = 0, dbg_lastw = -1, dbg_nres0 = 0;
+    int dbg_la[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = clk0;
     auto lap = [&](int k) { const unsigned long long now = wall_clock64(); dbg_t[k] += now - tk; tk = now; };
     const uint8_t *seq0 = B.hap_seq[d.qs] + d.q_off, *seq1 = B.ref_seq + d.r_off;
@@ -327,86 +330,141 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
             const int n = navail;
             // (wave 0 alone; the others wait for the queue state it publishes)
             if (wv == 0) {
-                // Narrow stretches (a lone run of matches behind the last edit; all of wave 0) are chains of levels of a few
-                // cells each.  When the chunk is the whole queue and all its cells sit in one truth row, lanes j * n + i look
-                // ahead at slot i of level j (the slot's cell moved j steps down its diagonal).  Level j only touches row
-                // t + j + 1, which no earlier level of the batch touches, so if every slot's candidate pushes are valid /
-                // invalid / already pushed exactly as on level 0 and its swap target moves along, level j repeats level 0's
-                // outcome, and all those levels are committed at once.
-                const bool ff = n <= 32;
-                const int nk = ff ? 64 / n : 1;
-                const int jl = ff ? lane / n : 0, il = ff ? lane - jl * n : lane;
+                // Narrow stretches (runs of matches behind the last edits; all of wave 0) are chains of levels of a few cells
+                // each.  When the chunk is the whole queue, lanes j * n + i look ahead at slot i of level j (the slot's cell
+                // moved j steps down its diagonal).  If level 0 reproduces the frontier slot by slot one step down the
+                // diagonals, the slots sit on distinct diagonals and every later level's candidates meet each other exactly
+                // as level 0's do; what can differ is validity (a mismatch, a variant's edge, the last row) and cells pushed
+                // before the batch -- a slot that trails another one down the same diagonal first reaches that slot's own
+                // cell, which has its stamp.  So if every slot's candidate pushes of level j are valid / invalid / pushed before
+                // the batch exactly as on level 0 and its swap target moves along, level j repeats level 0's outcome; the
+                // levels up to the first one that differs are committed at once.  The slots need not share a row (after a
+                // wave's seeds, a handful of runs at different rows is the common frontier: 721 of 814 narrow steps of the
+                // whole-genome batch's slowest replay).
+                // Every lane looks at TIE_LA levels of its slot: levels k * nk + jl, k = 0 .. TIE_LA - 1 (a step costs four or five
+                // trips to the L2 whatever it commits, and the loads of the further levels travel with those of the first).
+                const int nk = 64 / n;
+                const int jl = lane / n, il = lane - jl * n;
                 const bool act = lane < nk * n;
                 uint2 x = make_uint2(0u, 0u);
                 if (act) x = qc[head + il];
-                const int p = int(x.x >> 31), q = int(x.x & 0x7fffffffu) + jl, t = int(x.y) + jl;
+                const int p = int(x.x >> 31), q0 = int(x.x & 0x7fffffffu), t0 = int(x.y);
                 const int Lme = p ? Lr : Lq, Loth = p ? Lq : Lr;
-                bool ty = false, tz = false;
-                uint32_t iy = 0, iz = 0;
-                int zq = 0;
-                const bool oob_before = oob;
-                if (act && t + 1 < Lt && q < Lme) {
-                    const uint8_t tb = Ts[t + 1];
-                    if (q + 1 < Lme && (p ? seq1 : seq0)[q + 1] == tb) { ty = true; iy = sidx(p, q + 1, t + 1); }
-                    zq = (p ? ptr1 : ptr0)[q] + 1;
-                    const int fx = (p ? flg1 : flg0)[q], ft = Tf[t];
-                    if (fwd_allow(fx) && fwd_allow(ft) && zq >= 0 && zq < Loth && (p ? seq0 : seq1)[zq] == tb) {
-                        tz = true;
-                        iz = sidx(1 - p, zq, t + 1);
+                const uint8_t *sme = p ? seq1 : seq0, *soth = p ? seq0 : seq1;
+                const int32_t *pme = p ? ptr1 : ptr0;
+                const uint8_t *fme = p ? flg1 : flg0;
+                const bool l0 = lane < n;                 // the lanes of the level actually popped now
+                bool ty[TIE_LA], tz[TIE_LA], out[TIE_LA];
+                uint32_t iy[TIE_LA], iz[TIE_LA];
+                int zq[TIE_LA];
+                uint8_t tb[TIE_LA], sq[TIE_LA], so[TIE_LA];
+                int fx[TIE_LA], ft[TIE_LA];
+#pragma unroll
+                for (int k = 0; k < TIE_LA; k++) {       // (clamped, unconditional: the loads go out together)
+                    const int q = q0 + k * nk + jl, t = t0 + k * nk + jl;
+                    tb[k] = Ts[min(t + 1, Lt - 1)];
+                    ft[k] = Tf[min(t, Lt - 1)];
+                    sq[k] = sme[min(q + 1, Lme - 1)];
+                    zq[k] = pme[min(q, Lme - 1)] + 1;
+                    fx[k] = fme[min(q, Lme - 1)];
+                }
+#pragma unroll
+                for (int k = 0; k < TIE_LA; k++) so[k] = soth[min(max(zq[k], 0), Loth - 1)];
+#pragma unroll
+                for (int k = 0; k < TIE_LA; k++) {
+                    const int q = q0 + k * nk + jl, t = t0 + k * nk + jl;
+                    const bool in = act && t + 1 < Lt && q < Lme;
+                    ty[k] = in && q + 1 < Lme && sq[k] == tb[k];
+                    tz[k] = in && fwd_allow(fx[k]) && fwd_allow(ft[k]) && zq[k] >= 0 && zq[k] < Loth && so[k] == tb[k];
+                    out[k] = false;
+                    iy[k] = 0u; iz[k] = 0u;
+                    if (k == 0 && l0) {       // (a cell outside the stamp grids fails the job)
+                        if (ty[k]) iy[k] = sidx(p, q + 1, t + 1);
+                        if (tz[k]) iz[k] = sidx(1 - p, zq[k], t + 1);
+                    } else {                  // (a look-ahead lane whose hypothetical target lies outside only ends the batch of levels)
+                        if (ty[k]) { const uint32_t dg = uint32_t(q - t - J.dlo[p]); if (dg >= uint32_t(J.dn[p])) { out[k] = true; iy[k] = s_dummy; } else iy[k] = (p ? sbase1 : 0u) + dg * uint32_t(Lt) + uint32_t(t + 1); }
+                        if (tz[k]) { const uint32_t dg = uint32_t(zq[k] - (t + 1) - J.dlo[1 - p]); if (dg >= uint32_t(J.dn[1 - p])) { out[k] = true; iz[k] = s_dummy; } else iz[k] = (p ? 0u : sbase1) + dg * uint32_t(Lt) + uint32_t(t + 1); }
                     }
                 }
-                const bool l0 = lane < n;                 // the lanes of the level actually popped now
-                // (a look-ahead lane whose hypothetical target lies outside the stamp grids only ends the batch of levels)
-                const bool la_oob = !l0 && oob && !oob_before;
-                if (la_oob) oob = false;
                 const uint32_t cy = cid + 2u * uint32_t(lane), cz = cy + 1u;
                 uint32_t oy = TIE_NEVER, oz = TIE_NEVER;
-                if (l0 && ty) oy = atomicMin(stamp + iy, cy);
-                if (l0 && tz) oz = atomicMin(stamp + iz, cz);
+                if (l0 && ty[0]) oy = atomicMin(stamp + iy[0], cy);
+                if (l0 && tz[0]) oz = atomicMin(stamp + iz[0], cz);
+                // (the look-ahead lanes' stamps are read beside the atomics: a cell both touch is a pushed cell either way, and the
+                // level that reaches the slot it belongs to ends the batch before)
+                uint32_t vy[TIE_LA], vz[TIE_LA];
+#pragma unroll
+                for (int k = 0; k < TIE_LA; k++) {
+                    vy[k] = 0u; vz[k] = 0u;
+                    if (k == 0 && l0) continue;
+                    if (ty[k]) vy[k] = tie_ld(stamp + iy[k]);
+                    if (tz[k]) vz[k] = tie_ld(stamp + iz[k]);
+                }
                 tie_wait();
-                const uint32_t vy = ty ? tie_ld(stamp + iy) : 0u, vz = tz ? tie_ld(stamp + iz) : 0u;
-                const bool wy = l0 && ty && vy == cy;
-                const bool wz = l0 && tz && vz == cz;
+                if (l0) { vy[0] = ty[0] ? tie_ld(stamp + iy[0]) : 0u; vz[0] = tz[0] ? tie_ld(stamp + iz[0]) : 0u; }
+                const bool wy = l0 && ty[0] && vy[0] == cy;
+                const bool wz = l0 && tz[0] && vz[0] == cz;
                 const unsigned long long by = __ballot(wy), bz = __ballot(wz);
                 const int tot = __popcll(by) + __popcll(bz);
                 int nlev = 1;
                 const bool over = n_cur + tot > cap;
                 if (over) fail = true;
+                const int q = q0, t = t0;                 // (level 0's cell, for the lanes that pop it)
                 if (!over) {
                 const int ry = __popcll(by & lt_mask) + __popcll(bz & lt_mask);    // rank of this lane's first winner
                 const bool one_row = !__any(l0 && int(x.y) != __shfl(int(x.y), 0));
-                if (ff && one_row && tot == n && n_cur + nk * n <= cap) {
-                    // level 0 must reproduce the frontier, slot by slot, one step down the diagonals
-                    const uint32_t ycode = x.x + 1u, zcode = (uint32_t(1 - p) << 31) | uint32_t(zq);
+                dbg_la[0]++; if (!one_row) dbg_la[1]++; if (tot != n) dbg_la[2]++;
+                if (tot == n && n_cur + nk * n <= cap) {
+                    // level 0 must reproduce the frontier, slot by slot, one step down the diagonals (same plane, next
+                    // position, next row: the slots then sit on distinct diagonals, whatever their rows)
+                    const uint32_t ycode = x.x + 1u, zcode = (uint32_t(1 - p) << 31) | uint32_t(zq[0]);
                     const uint32_t sy = uint32_t(__shfl(int(x.x), ry)) + 1u, sz = uint32_t(__shfl(int(x.x), ry + (wy ? 1 : 0))) + 1u;
-                    const bool stable = !__any((wy && ycode != sy) || (wz && zcode != sz));
+                    const int ty_row = __shfl(int(x.y), ry), tz_row = __shfl(int(x.y), ry + (wy ? 1 : 0));
+                    const bool stable = !__any((wy && (ycode != sy || t0 != ty_row)) || (wz && (zcode != sz || t0 != tz_row)));
+                    if (!stable) dbg_la[3]++;
                     if (stable) {
                         // outcome class of a candidate push: 0 invalid, 1 pushed, 2 same cell as an earlier candidate of the
                         // level, 3 cell pushed before this level
-                        const int ky = !ty ? 0 : (wy ? 1 : (oy < cid ? 3 : 2)), kz = !tz ? 0 : (wz ? 1 : (oz < cid ? 3 : 2));
-                        const int ky0 = __shfl(ky, il), kz0 = __shfl(kz, il), zq0 = __shfl(zq, il);
-                        // a look-ahead lane has only read its targets' stamps: untouched (classes 1, 2) or not (class 3)
-                        const bool same = !la_oob && (ty == (ky0 != 0)) && (tz == (kz0 != 0)) && (!tz || zq == zq0 + jl) &&
-                                          (!ty || ((vy == TIE_NEVER) == (ky0 != 3))) && (!tz || ((vz == TIE_NEVER) == (kz0 != 3)));
-                        const unsigned long long bad = __ballot(act && !l0 && !same);
-                        nlev = bad ? int(__builtin_ctzll(bad)) / n : nk;
+                        const int ky = !ty[0] ? 0 : (wy ? 1 : (oy < cid ? 3 : 2)), kz = !tz[0] ? 0 : (wz ? 1 : (oz < cid ? 3 : 2));
+                        const int ky0 = __shfl(ky, il), kz0 = __shfl(kz, il), zq0 = __shfl(zq[0], il);
                         const int ry0 = __shfl(ry, il);
-                        if (jl >= 1 && jl < nlev) {
-                            const uint32_t c0 = cid + 2u * uint32_t(n) * uint32_t(jl) + 2u * uint32_t(il);
-                            const int pos = n_cur + jl * n + ry0;
+                        const int k_max = (n_cur + TIE_LA * nk * n <= cap) ? TIE_LA : 1;
+                        // a look-ahead lane has only read its targets' stamps: untouched (classes 1, 2) or not (class 3)
+                        nlev = 0;
+                        bool open = true;
+#pragma unroll
+                        for (int k = 0; k < TIE_LA; k++) {
+                            const int L = k * nk + jl;
+                            const bool same = !out[k] && (ty[k] == (ky0 != 0)) && (tz[k] == (kz0 != 0)) && (!tz[k] || zq[k] == zq0 + L) &&
+                                              (!ty[k] || ((vy[k] == TIE_NEVER) == (ky0 != 3))) && (!tz[k] || ((vz[k] == TIE_NEVER) == (kz0 != 3)));
+                            const unsigned long long bad = __ballot(act && !(k == 0 && l0) && !same);
+                            if (open && k < k_max) {
+                                if (bad) { nlev = k * nk + int(__builtin_ctzll(bad)) / n; open = false; }
+                                else nlev = (k + 1) * nk;
+                            } else open = false;
+                        }
+                        if (nlev < 1) nlev = 1;       // (k = 0, jl = 0 is the popped level itself)
+                        dbg_la[4]++; dbg_la[5] += nlev;
+#pragma unroll
+                        for (int k = 0; k < TIE_LA; k++) {
+                            const int L = k * nk + jl;
+                            if (!act || L < 1 || L >= nlev) continue;
+                            const uint32_t c0 = cid + 2u * uint32_t(n) * uint32_t(L) + 2u * uint32_t(il);
+                            const int pos = n_cur + L * n + ry0;
+                            const int ql = q0 + L, tl = t0 + L;
                             if (ky0 == 1) {
-                                stamp[iy] = c0; qc[pos] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1));
-                                if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1);
+                                stamp[iy[k]] = c0; qc[pos] = make_uint2((uint32_t(p) << 31) | uint32_t(ql + 1), uint32_t(tl + 1));
+                                if (is_multi(p, ql + 1)) note_tie(p, ql + 1, tl + 1);
                             }
                             if (kz0 == 1) {
-                                stamp[iz] = c0 + 1u; qc[pos + (ky0 == 1 ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1));
-                                if (is_multi(1 - p, zq)) note_tie(1 - p, zq, t + 1);
+                                stamp[iz[k]] = c0 + 1u; qc[pos + (ky0 == 1 ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq[k]), uint32_t(tl + 1));
+                                if (is_multi(1 - p, zq[k])) note_tie(1 - p, zq[k], tl + 1);
                             }
                         }
                     }
                 }
                 if (wy) { qc[n_cur + ry] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1); }
-                if (wz) { qc[n_cur + ry + (wy ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq), uint32_t(t + 1)); if (is_multi(1 - p, zq)) note_tie(1 - p, zq, t + 1); }
+                if (wz) { qc[n_cur + ry + (wy ? 1 : 0)] = make_uint2((uint32_t(1 - p) << 31) | uint32_t(zq[0]), uint32_t(t + 1)); if (is_multi(1 - p, zq[0])) note_tie(1 - p, zq[0], t + 1); }
                 }
                 tie_wait();
                 if (__any(oob)) fail = true;
@@ -744,6 +802,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
         jobs[j].dbg_steps = dbg_steps; jobs[j].dbg_cells = dbg_cells; jobs[j].dbg_waves = dbg_waves;
         jobs[j].dbg_nres = lds_nres; jobs[j].dbg_lastw = dbg_lastw;
         for (int k = 0; k < 8; k++) jobs[j].dbg_t[k] = int32_t(dbg_t[k] / 100);
+        for (int k = 0; k < 6; k++) jobs[j].dbg_la[k] = dbg_la[k];
     }
 }
 
