@@ -416,6 +416,8 @@ struct vpr_handle {
     std::vector<EvPair> events;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;   // timing events, reused by every execute
     std::vector<hipStream_t> pad_streams;                  // (diagnostic, VPR_STREAM_PAD)
+    int zl_lds_bytes = 0;                // (diagnostic, VPR_ZL_LDS_KB) LDS the zero level's waves ask for and never touch: caps how many of them a compute unit holds
+    int lane_prio_rows = 256;            // waves of the lane levels with at least this many rows issue ahead of the others (k_zero_lane; a quarter for k_one_lane)
     DevResults dR;                       // final results, produced on the device
     vpr_timing timing;
     bool uploaded = false, executed = false;
@@ -1746,6 +1748,8 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->seq_walk = getenv("VPR_SEQ_WALK") != nullptr;
     h->no_flag_save = getenv("VPR_NO_FLAG_SAVE") != nullptr;
     h->side_credit = getenv("VPR_NO_SIDE_CREDIT") == nullptr;
+    if (const char *e = getenv("VPR_ZL_LDS_KB")) h->zl_lds_bytes = std::max(0, std::min(64, atoi(e))) * 1024;
+    if (const char *e = getenv("VPR_LANE_PRIO_ROWS")) h->lane_prio_rows = std::max(1, atoi(e));     // diagnostic
     for (int k = 0; k < 2; k++)
         if (hipEventCreateWithFlags(&h->ev_cred[k], hipEventDisableTiming) != hipSuccess) return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
     h->seq_fwd = getenv("VPR_PAR_FWD") == nullptr;
@@ -2614,6 +2618,7 @@ struct Exec {
             needs.push_back(N);
         }
         if (needs.empty()) return VPR_OK;
+        trace("    replay: %zu jobs sized", needs.size());
         // largest first: a launch lasts as long as its largest job, so when the scratch forces sub-batches the big jobs
         // should share theirs with each other, not spread over all of them
         std::stable_sort(needs.begin(), needs.end(), [](const Need &x, const Need &y) { return x.cells > y.cells; });
@@ -2709,16 +2714,28 @@ struct Exec {
             tc.tie_clean[se] = 0;
             vpr_launch_stat ts_;
             memset(&ts_, 0, sizeof(ts_));
-            ts_.threads = TIE_NT; ts_.n_units = nj; ts_.cells_per_thread = early ? 1 : 0;
+            // eight waves per job when the launch's jobs are large (a megaword of stamps and logs on average: the alignments of
+            // 10 000+ rows of the stress workload, whose passes over a wave's cells are then half as long -- its step 312 ->
+            // 301 ms); four for the thousands of small jobs of a whole-genome batch, where eight cost the step 0.6 ms
+            // (VPR_TIE_WIDE_WORDS moves the border: diagnostic)
+            static const int64_t wide_words = [] { const char *e = getenv("VPR_TIE_WIDE_WORDS"); return e ? atoll(e) : (int64_t(1) << 20); }();
+            const bool wide_job = words / std::max<int32_t>(nj, 1) >= wide_words;
+            ts_.threads = wide_job ? 512 : 256; ts_.n_units = nj; ts_.cells_per_thread = early ? 1 : 0;
             int rc = timed(6, ts_, ks, early ? "k_tie_replay<early>" : "k_tie_replay", [&] {
-                hipLaunchKernelGGL(k_tie_replay, dim3(nj), dim3(TIE_NT), 0, ks, h->dB, h->d_descs, jobs, nj, P.arena,
-                                   reinterpret_cast<const int32_t *>(P.arena), h->d_outs, scratch, h->d_tie_cnt + 1,
-                                   dec, n_dec, int(dec_cap));
+                if (wide_job)
+                    hipLaunchKernelGGL(k_tie_replay<8>, dim3(nj), dim3(512), 0, ks, h->dB, h->d_descs, jobs, nj, P.arena,
+                                       reinterpret_cast<const int32_t *>(P.arena), h->d_outs, scratch, h->d_tie_cnt + 1,
+                                       dec, n_dec, int(dec_cap));
+                else
+                    hipLaunchKernelGGL(k_tie_replay<4>, dim3(nj), dim3(256), 0, ks, h->dB, h->d_descs, jobs, nj, P.arena,
+                                       reinterpret_cast<const int32_t *>(P.arena), h->d_outs, scratch, h->d_tie_cnt + 1,
+                                       dec, n_dec, int(dec_cap));
             });
             if (rc) return rc;
             k0 = k1;
         }
         if (early) { HIPCHK(h, hipEventRecord(tc.ev2, ks)); (void)hipStreamQuery(ks); }
+        trace("    replay launched");
         return VPR_OK;
     }
 
@@ -3035,9 +3052,12 @@ struct Exec {
                 hipLaunchKernelGGL(k_fwd_stripe_only, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs, FT.fallback);
             } else
             if (zero)        // forward + backward + walk of the zero-distance alignments, one lane each (pr_zl.hip)
-                hipExtLaunchKernelGGL(k_zero_lane, dim3((cnt + 63) / 64), dim3(64), 0, ks, own_a, own_b, 0, h->d_descs, list, cnt,
+                // (tried: this launch -- the first of its batch, 62 000 long-lived waves that take the wave slots the other batch's
+                // next kernels wait for -- on a stream of its own below the short part's priority: the waiting stream's queue then
+                // keeps the lower one from being served, 30 ms per step instead of 18.6, a lone step 38 instead of 23.6)
+                hipExtLaunchKernelGGL(k_zero_lane, dim3((cnt + 63) / 64), dim3(64), h->zl_lds_bytes, ks, own_a, own_b, 0, h->d_descs, list, cnt,
                                       h->d_zl_hdr + zl_wave0, h->d_zl_in, h->d_zl_log, h->d_outs, a_path,
-                                      (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0, h->d_d1_hdr ? h->d1_max_rows : 0);
+                                      (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0, h->d_d1_hdr ? h->d1_max_rows : 0, h->lane_prio_rows);
             else if (q16)
                 hipLaunchKernelGGL(k_fwd_q16, dim3((cnt + 3) / 4), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    P.arena, a_i32, h->d_outs, n_dev);
@@ -3222,7 +3242,8 @@ struct Exec {
             if (rc) return rc;
             rc = timed(1, ls, ks, "k_one_lane", [&] {
                 hipLaunchKernelGGL(k_one_lane, dim3(nw), dim3(64), 0, ks, h->d_descs, list, n_dev, cap, h->d_d1_hdr, h->d_d1_in, h->d_d1_log,
-                                   h->d_outs, reinterpret_cast<PathEnt *>(h->plan0.arena), (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0, h->d_d1_info);
+                                   h->d_outs, reinterpret_cast<PathEnt *>(h->plan0.arena), (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0, h->d_d1_info,
+                                   std::max(1, h->lane_prio_rows / 4));
                 hipLaunchKernelGGL(k_fwd_band_finish, dim3((cap + 255) / 256), dim3(256), 0, ks, list, cap, h->d_outs, D1_TAG, n_dev);
             });
             if (rc) return rc;
@@ -3391,7 +3412,9 @@ struct Exec {
             c.plans.emplace_back();
             Plan &P = c.plans.back();
             const int tag_or = tie ? TIE_TAG_BIT : 0;
+            trace("    level %d: %zu alignments, planning", lv, by_lv[lv].size());
             int rc = make_plan(h, by_lv[lv], lv, P, c.arena + c.arena_cur, c.arena_bytes - c.arena_cur, tag_or);
+            trace("    planned");
             if (rc == VPR_OK && P.chunks.size() > 1 && c.arena_cur > 0) rc = VPR_ERR_NOMEM;   // retry with the whole workspace
             if (rc == VPR_ERR_NOMEM && c.arena_cur > 0) {
                 { const int rs = lad_sync(c); if (rs) return rs; }
@@ -3428,6 +3451,7 @@ struct Exec {
                                h->d_cnt + c.slot0, zero_slots ? LadderCtx::N_SLOTS : 0);
             zero_slots = false;
             h->dirty.insert(h->dirty.end(), P.work.begin(), P.work.end());
+            trace("    staged");
             // A retry round whose plan is one workspace chunk: the forward sweeps (and fail lists) of all its plans first, then
             // the flag the host waits for, then the backward sweeps, tie lists and walks of what was accepted -- the host starts
             // the next round while those still run (on the ladder's other context when that is idle: the main loop).

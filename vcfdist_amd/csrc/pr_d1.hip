@@ -210,12 +210,13 @@ __global__ void __launch_bounds__(64, 3) k_one_lane(const AlnDesc *__restrict__ 
                                                     const int32_t *__restrict__ n_dev, int n_cap, const ZlWave *__restrict__ hdr,
                                                     const uint32_t *__restrict__ zin, uint4 *__restrict__ zlog,
                                                     AlnOut *__restrict__ outs, PathEnt *__restrict__ paths, int keep_paths,
-                                                    int32_t *__restrict__ info) {
+                                                    int32_t *__restrict__ info, int prio_rows) {
     // (the fail list keeps the order of the zero level's work list -- longest first: the longest chains of dependent rows start
     // first and run beside the throughput work of the others)
     const int w = blockIdx.x, lane = threadIdx.x;
     const ZlWave H = hdr[w];
     if (H.mt <= 0) return;
+    if (H.mt >= prio_rows) __builtin_amdgcn_s_setprio(2);
     const int n_list = min(*n_dev, n_cap);
     const int wi = w * 64 + lane;
     int a_ = wi < n_list ? list[wi] : -1;

@@ -10,8 +10,8 @@
 // cell by cell and rewrites the choice field of every tied cell with the predecessor the reference keeps; the
 // backward sweep, walk and credit then run on the corrected flags.
 //
-// One workgroup (TIE_NW waves) per alignment.  What is replayed, exactly:
-//   * BFS of a wave (dist.cpp:317-381): the FIFO is a log in HBM; up to TIE_U x TIE_NT entries are popped per step, thread e
+// One workgroup (TIE_NW waves: four or eight, the template parameter) per alignment.  What is replayed, exactly:
+//   * BFS of a wave (dist.cpp:317-381): the FIFO is a log in HBM; up to TIE_U x 64 TIE_NW entries are popped per step, thread e
 //     expands entry e (MAT child, then SWP child, as the reference pushes them).  "not done and not in curr_wave"
 //     == "never pushed before": every candidate push carries a running candidate id, an atomicMin on the cell's
 //     stamp keeps the first one, and the lanes whose id survived append their cell in id order (ballot prefix).
@@ -101,19 +101,19 @@ __device__ __forceinline__ uint8_t *tie_flag_ptr(const AlnDesc &d, uint8_t *ws, 
 
 #define TIE_U 4    // chunks a wide pass keeps in flight per wave (more does not help: a wave sustains about one scattered access per 10 cycles)
 // One workgroup of TIE_NW waves per alignment.  Every pass over a wave's cells (expansion of a wide frontier, the order
-// passes, the seeding of the next wave) is strided over the workgroup: entry e of a pass belongs to thread e mod TIE_NT of
-// chunk e / TIE_NT, candidate ids and append positions are functions of e alone (appends: ballot prefix inside a wave,
+// passes, the seeding of the next wave) is strided over the workgroup: entry e of a pass belongs to thread e mod (64 TIE_NW) of
+// chunk e / (64 TIE_NW), candidate ids and append positions are functions of e alone (appends: ballot prefix inside a wave,
 // per-wave counts through LDS across waves), so the result does not depend on the number of waves.  A narrow frontier
 // (<= 64 entries: a chain of dependent steps) is expanded by wave 0 alone, which publishes the queue state to the others.
-#define TIE_NW 4
 #define TIE_LA 4   // levels of a narrow stretch a lane looks at per step
-#define TIE_NT (64 * TIE_NW)
 
-__global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc *__restrict__ descs,
+template <int TIE_NW>
+__global__ void __launch_bounds__(64 * TIE_NW) k_tie_replay(DevBatch B, const AlnDesc *__restrict__ descs,
                                                    TieJob *__restrict__ jobs, int n_jobs, uint8_t *ws,
                                                    const int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs,
                                                    uint32_t *scratch, int32_t *__restrict__ n_overflow,
                                                    int4 *__restrict__ dec, int32_t *__restrict__ n_dec, int dec_cap) {
+    constexpr int NT_ = 64 * TIE_NW;
     // positions with more than one allowed swap source (the only cells that can be tied), one bit per position and plane
     __shared__ uint32_t mmask[2][1024];
     __shared__ int lds_ntie, lds_nres;
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
     for (int p = 0; p < 2 && !fail; p++) {
         const int L = p ? Lr : Lq;
         const int4 *cd = p ? cand1 : cand0;
-        for (int x0 = wv * 64; x0 < L; x0 += TIE_NT) {
+        for (int x0 = wv * 64; x0 < L; x0 += NT_) {
             const int x = x0 + lane;
             const bool multi = x < L && cd[x].y >= 0;
             const unsigned long long bal = __ballot(multi);
@@ -234,15 +234,15 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
         while (head < n_cur) {
             const int navail = n_cur - head;
             if (navail > 64) {
-                // ---- wide: up to TIE_U chunks of TIE_NT entries in flight, appended in entry order
-                const int n = min(TIE_NT * TIE_U, navail);
+                // ---- wide: up to TIE_U chunks of NT_ entries in flight, appended in entry order
+                const int n = min(NT_ * TIE_U, navail);
                 uint2 x[TIE_U];
                 bool ty[TIE_U], tz[TIE_U];
                 uint32_t iy[TIE_U], iz[TIE_U];
                 int zq[TIE_U];
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const int e = u * TIE_NT + tid;
+                    const int e = u * NT_ + tid;
                     x[u] = make_uint2(0u, 0u);
                     if (e < n) x[u] = qc[head + e];
                 }
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
                     const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
-                    const bool in = (u * TIE_NT + tid < n) && t + 1 < Lt;
+                    const bool in = (u * NT_ + tid < n) && t + 1 < Lt;
                     tb[u] = 0; sq[u] = 1; zq[u] = 0; fx[u] = PV; ft[u] = PV;
                     if (in) {
                         tb[u] = Ts[t + 1];
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
                     const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
-                    const bool in = (u * TIE_NT + tid < n) && t + 1 < Lt;
+                    const bool in = (u * NT_ + tid < n) && t + 1 < Lt;
                     ty[u] = in && sq[u] == tb[u] && q + 1 < (p ? Lr : Lq);
                     tz[u] = in && fwd_allow(fx[u]) && fwd_allow(ft[u]) && zq[u] >= 0 && zq[u] < (p ? Lq : Lr) && so[u] == tb[u];
                     iy[u] = ty[u] ? sidx(p, q + 1, t + 1) : 0u;
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
                 }
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const uint32_t cy = cid + 2u * uint32_t(u * TIE_NT + tid);
+                    const uint32_t cy = cid + 2u * uint32_t(u * NT_ + tid);
                     if (ty[u]) (void)atomicMin(stamp + iy[u], cy);
                     if (tz[u]) (void)atomicMin(stamp + iz[u], cy + 1u);
                 }
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
                 bool wy[TIE_U], wz[TIE_U];
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const uint32_t cy = cid + 2u * uint32_t(u * TIE_NT + tid);
+                    const uint32_t cy = cid + 2u * uint32_t(u * NT_ + tid);
                     wy[u] = ty[u] && tie_ld(stamp + iy[u]) == cy;
                     wz[u] = tz[u] && tie_ld(stamp + iz[u]) == cy + 1u;
                 }
@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
             if (tid == 0) lds_ntie = 0;
             const bool scan_all = ntie > tcap;         // the list overflowed: look at every cell of the wave
             const int nn = scan_all ? n_cur : ntie;
-            for (int i0 = 0; i0 < nn; i0 += TIE_NT) {
+            for (int i0 = 0; i0 < nn; i0 += NT_) {
                 const int i = i0 + tid;
                 if (i >= nn) continue;
                 const uint2 z = scan_all ? qc[i] : Ta[i];
@@ -552,24 +552,24 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
             tag++;
             const unsigned long long tagw = (unsigned long long)(~tag) << 32;
             // pass 0: bucket member counts cleared
-            for (int b0 = tid; b0 < int(n_bkt); b0 += TIE_NT) bcount[b0] = 0u;
+            for (int b0 = tid; b0 < int(n_bkt); b0 += NT_) bcount[b0] = 0u;
             tie_wait();
             __syncthreads();
             // pass A: bucket of every element, first insertion per bucket, bucket member lists; H cleared
             bool blist_full = false;
-            for (int i0 = 0; i0 < m; i0 += TIE_NT * TIE_U) {
+            for (int i0 = 0; i0 < m; i0 += NT_ * TIE_U) {
                 uint32_t e[TIE_U], bk[TIE_U], slot[TIE_U];
                 uint2 c[TIE_U];
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const int i = i0 + u * TIE_NT + tid;
+                    const int i = i0 + u * NT_ + tid;
                     e[u] = (i < m) ? ((have_lam && i < done) ? oc[i] : uint32_t(i)) : 0u;
                 }
 #pragma unroll
-                for (int u = 0; u < TIE_U; u++) c[u] = (i0 + u * TIE_NT + tid < m) ? qc[e[u]] : make_uint2(0u, 0u);
+                for (int u = 0; u < TIE_U; u++) c[u] = (i0 + u * NT_ + tid < m) ? qc[e[u]] : make_uint2(0u, 0u);
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const int i = i0 + u * TIE_NT + tid;
+                    const int i = i0 + u * NT_ + tid;
                     bk[u] = 0u; slot[u] = 0u;
                     if (i >= m) continue;
                     const unsigned long long hv = ((c[u].x >> 31) ? hi_r : hi_q) ^
@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
                 }
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const int i = i0 + u * TIE_NT + tid;
+                    const int i = i0 + u * NT_ + tid;
                     if (i >= m) continue;
                     if (slot[u] < TIE_BLIST) blist[size_t(bk[u]) * TIE_BLIST + slot[u]] = uint32_t(i); else blist_full = true;
                 }
@@ -592,17 +592,17 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
             blist_full = wg_any(blist_full);     // (its barrier also ends pass A for every wave)
             lap(2);
             // pass B: F_i = first insertion index of the element's bucket; histogram of F
-            for (int i0 = 0; i0 < m; i0 += TIE_NT * TIE_U) {
+            for (int i0 = 0; i0 < m; i0 += NT_ * TIE_U) {
                 uint32_t b[TIE_U];
                 unsigned long long fw[TIE_U];
 #pragma unroll
-                for (int u = 0; u < TIE_U; u++) b[u] = (i0 + u * TIE_NT + tid < m) ? Ka[i0 + u * TIE_NT + tid] : 0u;
+                for (int u = 0; u < TIE_U; u++) b[u] = (i0 + u * NT_ + tid < m) ? Ka[i0 + u * NT_ + tid] : 0u;
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++)
-                    fw[u] = (i0 + u * TIE_NT + tid < m) ? __hip_atomic_load(bfirst + b[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    fw[u] = (i0 + u * NT_ + tid < m) ? __hip_atomic_load(bfirst + b[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 #pragma unroll
                 for (int u = 0; u < TIE_U; u++) {
-                    const int i = i0 + u * TIE_NT + tid;
+                    const int i = i0 + u * NT_ + tid;
                     if (i >= m) continue;
                     const uint32_t f = uint32_t(fw[u] & 0xffffffffull);
                     Fa[i] = f;
@@ -654,12 +654,12 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
             lap(4);
             if (!blist_full) {
                 // pass C: position = G[F_i] + members of the element's bucket inserted later (from the bucket's member list)
-                for (int i0 = 0; i0 < m; i0 += TIE_NT * TIE_U) {
+                for (int i0 = 0; i0 < m; i0 += NT_ * TIE_U) {
                     uint32_t f[TIE_U], bk[TIE_U], e[TIE_U], g[TIE_U], cn[TIE_U];
                     uint4 ml[TIE_U], mh[TIE_U];
 #pragma unroll
                     for (int u = 0; u < TIE_U; u++) {
-                        const int i = i0 + u * TIE_NT + tid;
+                        const int i = i0 + u * NT_ + tid;
                         const bool act = i < m;
                         f[u] = act ? Fa[i] : 0u;
                         bk[u] = act ? Ka[i] : 0u;
@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
                     }
 #pragma unroll
                     for (int u = 0; u < TIE_U; u++) {
-                        const bool act = i0 + u * TIE_NT + tid < m;
+                        const bool act = i0 + u * NT_ + tid < m;
                         g[u] = act ? tie_ld(Ha + f[u]) : 0u;
                         cn[u] = act ? tie_ld(bcount + bk[u]) : 0u;
                         const uint4 *mp = reinterpret_cast<const uint4 *>(blist + size_t(bk[u]) * TIE_BLIST);
@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
                     }
 #pragma unroll
                     for (int u = 0; u < TIE_U; u++) {
-                        const int i = i0 + u * TIE_NT + tid;
+                        const int i = i0 + u * NT_ + tid;
                         if (i >= m) continue;
                         const uint32_t mem[8] = {ml[u].x, ml[u].y, ml[u].z, ml[u].w, mh[u].x, mh[u].y, mh[u].z, mh[u].w};
                         uint32_t rank = 0;
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
             } else {
                 // (a bucket with more than TIE_BLIST members: the same positions from per-bucket counters, chunk by chunk
                 // from the back)
-                for (int i0 = tid; i0 < m; i0 += TIE_NT) Ka[i0] = 0u;
+                for (int i0 = tid; i0 < m; i0 += NT_) Ka[i0] = 0u;
                 tie_wait();
                 __syncthreads();
                 const int top = (m - 1) & ~63;
@@ -726,21 +726,21 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
         // ---- next wave: INS, DEL, SUB targets of every popped cell, in iteration order (dist.cpp:395-424)
         int n_next = 0;
         wave_lo = cid;
-        for (int k0 = 0; k0 < n && !fail; k0 += TIE_NT * TIE_U) {
+        for (int k0 = 0; k0 < n && !fail; k0 += NT_ * TIE_U) {
             uint32_t e[TIE_U];
             uint2 x[TIE_U];
             bool t0[TIE_U], t1[TIE_U], t2[TIE_U];
             uint32_t j0[TIE_U], j1[TIE_U], j2[TIE_U];
 #pragma unroll
-            for (int u = 0; u < TIE_U; u++) e[u] = (k0 + u * TIE_NT + tid < n) ? oc[k0 + u * TIE_NT + tid] : 0u;
+            for (int u = 0; u < TIE_U; u++) e[u] = (k0 + u * NT_ + tid < n) ? oc[k0 + u * NT_ + tid] : 0u;
 #pragma unroll
-            for (int u = 0; u < TIE_U; u++) x[u] = (k0 + u * TIE_NT + tid < n) ? qc[e[u]] : make_uint2(0u, 0u);
+            for (int u = 0; u < TIE_U; u++) x[u] = (k0 + u * NT_ + tid < n) ? qc[e[u]] : make_uint2(0u, 0u);
 #pragma unroll
             for (int u = 0; u < TIE_U; u++) {
-                const bool act = k0 + u * TIE_NT + tid < n;
+                const bool act = k0 + u * NT_ + tid < n;
                 const int p = int(x[u].x >> 31), q = int(x[u].x & 0x7fffffffu), t = int(x[u].y);
                 t0[u] = act && q + 1 < (p ? Lr : Lq); t1[u] = act && t + 1 < Lt; t2[u] = t0[u] && t1[u];
-                const uint32_t c0 = cid + 3u * uint32_t(u * TIE_NT + tid);
+                const uint32_t c0 = cid + 3u * uint32_t(u * NT_ + tid);
                 j0[u] = t0[u] ? sidx(p, q + 1, t) : 0u; j1[u] = t1[u] ? sidx(p, q, t + 1) : 0u; j2[u] = t2[u] ? sidx(p, q + 1, t + 1) : 0u;
                 if (t0[u]) (void)atomicMin(stamp + j0[u], c0);
                 if (t1[u]) (void)atomicMin(stamp + j1[u], c0 + 1u);
@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
             bool w0[TIE_U], w1[TIE_U], w2[TIE_U];
 #pragma unroll
             for (int u = 0; u < TIE_U; u++) {
-                const uint32_t c0 = cid + 3u * uint32_t(u * TIE_NT + tid);
+                const uint32_t c0 = cid + 3u * uint32_t(u * NT_ + tid);
                 w0[u] = t0[u] && tie_ld(stamp + j0[u]) == c0;
                 w1[u] = t1[u] && tie_ld(stamp + j1[u]) == c0 + 1u;
                 w2[u] = t2[u] && tie_ld(stamp + j2[u]) == c0 + 2u;
@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(TIE_NT) k_tie_replay(DevBatch B, const AlnDesc
                 if (w2[u]) { qn[pos++] = make_uint2((uint32_t(p) << 31) | uint32_t(q + 1), uint32_t(t + 1)); if (is_multi(p, q + 1)) note_tie(p, q + 1, t + 1); }
                 n_next += tot;
             }
-            cid += 3u * uint32_t(min(TIE_NT * TIE_U, n - k0));
+            cid += 3u * uint32_t(min(NT_ * TIE_U, n - k0));
             if (cid > 0xf0000000u || any_oob_) fail = true;
             tie_wait();
             __syncthreads();            // (lds_cnt is reused by the next chunk)

@@ -148,9 +148,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned int zl_u2;
 __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list, int n_list,
                                                   const ZlWave *__restrict__ hdr, const uint32_t *__restrict__ zin,
                                                   uint4 *__restrict__ zlog, AlnOut *__restrict__ outs, PathEnt *__restrict__ paths,
-                                                  int keep_paths, int d1_max_rows) {
+                                                  int keep_paths, int d1_max_rows, int prio_rows) {
     const int w = blockIdx.x, lane = threadIdx.x;
     const ZlWave H = hdr[w];
+    // The launch lasts as long as its longest wave (the work list is sorted longest first: ~1 000 rows x three dependent passes),
+    // and a wave that shares its SIMD with five others advances at half a lone wave's pace: the long ones go first.
+    if (H.mt >= prio_rows) __builtin_amdgcn_s_setprio(2);
     const int wi = w * 64 + lane;
     const int a_ = wi < n_list ? list[wi] : -1;
     const bool live = a_ >= 0;
