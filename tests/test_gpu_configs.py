@@ -290,6 +290,38 @@ def test_long_part_threshold_leaves_the_results_unchanged(monkeypatch):
     assert units["256"] < units["2048"]          # (the border really moved)
 
 
+def test_round_five_switches_leave_the_results_unchanged(monkeypatch):
+    """a batch whose alignments meet container-order ties at every level (replays before and behind the repeated sweeps, lane
+    levels, 16-cell round, 64-cell rounds): the oracle's arrays at the defaults, and the same arrays with eight waves per replay
+    job for every launch, with every lane-level wave at raised issue priority, with the zero level's occupancy capped, with the
+    lane levels' credit walks behind the 16-cell round instead of beside it, with the tie rounds' streams in the normal
+    priority class and an idle stream in front of the handle's, and with half of the device set aside by the memory plan."""
+    batch = api.Synth(n_sc=400, len_mode=0, len_a=40.0, len_b=2400.0, len_min=40, len_max=2400, seed=5150, p_repeat=0.35).batch()
+    got, want, _, pr = compare(batch, A.default_config(band_mode=1))
+    names = {s.kernel.decode() for s in pr.launch_stats()}
+    assert any(n.startswith("k_tie_replay") for n in names) and "k_zero_lane" in names and "k_one_lane" in names
+    for var, val in (("VPR_TIE_WIDE_WORDS", "1"), ("VPR_LANE_PRIO_ROWS", "1"), ("VPR_ZL_LDS_KB", "10"), ("VPR_NO_SIDE_CREDIT", "1"),
+                     ("VPR_STREAM_PRIO", "hlhhllllnnnnn"), ("VPR_STREAM_PAD", "1:1,1:1,1:1,1:1,1:1,1:1,1:1,1:1"), ("VPR_DEV_FREE_SHARE", "0.5")):
+        monkeypatch.setenv(var, val)
+        other = api.PrecisionRecall(A.default_config(band_mode=1)).run(batch)
+        monkeypatch.delenv(var)
+        assert not got.diff(other), var
+
+
+def test_memory_plan_leaves_its_share_of_the_device_free():
+    """vpr_upload plans the batch's device memory: after an upload and two executes of a batch of long
+    alignments -- ladders and replay scratches have grown to what they wanted -- at least VPR_DEV_FREE_SHARE of the device
+    (11 %) is still free, and the results are the oracle's"""
+    import ctypes
+    batch = api.Synth(n_sc=300, len_mode=0, len_a=600.0, len_b=5000.0, len_min=600, len_max=5000, seed=77011, p_repeat=0.3).batch()
+    got, want, _, pr = compare(batch, A.default_config(band_mode=1))
+    pr.execute()
+    hip = ctypes.CDLL("libamdhip64.so")          # (the runtime the library itself is linked against: already in the process)
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    assert free.value >= 0.105 * total.value, (free.value, total.value)
+
+
 def test_device_reserve_turns_an_exhausted_device_into_an_error():
     """the library leaves VPR_DEV_RESERVE_MB of device memory to the runtime (kernels' private memory is allocated per queue behind
     its back, and a queue that cannot get it is aborted together with the process): an allocation that would go below the reserve
