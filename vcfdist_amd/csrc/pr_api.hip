@@ -303,6 +303,9 @@ struct vpr_handle {
     // round 0's workspace takes what its plan asks for (at most arena_share() of the rest), and what remains is split
     // between the ladders' workspaces and the replay scratches, which start small and grow on demand inside their halves.
     int64_t mem_reserve = 0, lad_budget = 0, tie_budget = 0, lad_bytes = 0, tie_bytes = 0;
+    // what each ladder's workspace had grown to when the last batch was released, as a fraction of that batch's round-0 need:
+    // the next batch's ladders start there instead of growing during its first execute
+    double lad_hw[4] = {0, 0, 0, 0}; int64_t want0 = 0;
     std::vector<size_t> alloc_bytes;     // sizes of `allocs`
     std::vector<void *> allocs;
     uint8_t *pool_cur = nullptr;         // bump pointer into the newest block
@@ -820,6 +823,7 @@ void free_batch(vpr_handle *h) {
     for (int k = 0; k < 4; k++) h->d_cls[k] = nullptr;
     h->d_hist = nullptr; h->hist_cap = 0; h->d_pb = nullptr;
     for (int k = 0; k < 4; k++) {      // (the replay scratches are the handle's, not the batch's: they survive)
+        if (h->want0 > 0 && h->lad[k].arena_bytes > 0) h->lad_hw[k] = double(h->lad[k].arena_bytes) / double(h->want0);
         LadderCtx keep;
         for (int e = 0; e < 2; e++) {
             keep.tie_scratch[e] = h->lad[k].tie_scratch[e]; keep.tie_scratch_bytes[e] = h->lad[k].tie_scratch_bytes[e];
@@ -2181,8 +2185,9 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
     // what the batch may take: the free memory (the blocks kept from the previous batch count: the allocations below take
     // them first) less the tenth of the device the library leaves alone; on a device mostly taken by others, half of what is free
-    int64_t avail = int64_t(free_b);
-    for (const auto &c : h->dev_cache) avail += int64_t(c.bytes);
+    int64_t avail = int64_t(free_b), avail_cache = 0;
+    for (const auto &c : h->dev_cache) avail_cache += int64_t(c.bytes);
+    avail += avail_cache;
     int64_t scratch_kept = 0;            // (the replay scratches have the handle's lifetime: part of the plan, and taken already)
     for (int k = 0; k < 4; k++) for (int e = 0; e < 2; e++) scratch_kept += h->lad[k].tie_scratch_bytes[e];
     avail += scratch_kept;
@@ -2230,12 +2235,26 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         const int64_t rest = std::max<int64_t>(avail - budget, 0);
         h->lad_budget = rest / 2; h->tie_budget = rest - rest / 2;
         h->lad_bytes = 0; h->tie_bytes = scratch_kept;
+        h->want0 = want;
+        // (a handle that has released a batch knows what its ladders grew to: the same fraction of this batch's round-0 need,
+        // all four scaled down together if that is more than the ladders' half)
+        int64_t first[4] = {0, 0, 0, 0}, first_sum = 0;
+        for (int k = 0; k < 4; k++) {
+            int64_t b2 = std::min<int64_t>(h->lad_budget / 4, int64_t(ladder_share() * double(std::max<int64_t>(want / 16, int64_t(1) << 30))));
+            if (k & 1) b2 = std::min<int64_t>(b2, int64_t(2) << 30);
+            first[k] = std::max<int64_t>(b2, std::min<int64_t>(int64_t(h->lad_hw[k] * double(want)), h->lad_arena_max));
+            first_sum += first[k];
+        }
+        const double shrink = first_sum > h->lad_budget && first_sum > 0 ? double(h->lad_budget) / double(first_sum) : 1.0;
+        if (h->debug)
+            fprintf(stderr, "[vpr] memory plan: free %.1f GB + kept blocks %.1f + scratches %.1f, reserve %.1f -> %.1f to plan; round 0 wants %.1f, gets %.1f; "
+                            "ladders' half %.1f (first workspaces %.1f %.1f %.1f %.1f), replays' half %.1f\n",
+                    double(free_b) / 1e9, double(avail_cache) / 1e9, double(scratch_kept) / 1e9, double(h->mem_reserve) / 1e9, double(avail) / 1e9,
+                    double(want) / 1e9, double(budget) / 1e9, double(h->lad_budget) / 1e9, double(first[0]) * shrink / 1e9, double(first[1]) * shrink / 1e9,
+                    double(first[2]) * shrink / 1e9, double(first[3]) * shrink / 1e9, double(h->tie_budget) / 1e9);
         for (int k = (h->cfg.band_mode != 0 ? 0 : 2); k < 4; k++) {   // (dense mode: only the tie rounds need one)
             int64_t b2 = h->cfg.workspace_bytes;
-            if (b2 <= 0) {
-                b2 = std::min<int64_t>(h->lad_budget / 4, int64_t(ladder_share() * double(std::max<int64_t>(want / 16, int64_t(1) << 30))));
-                if (k & 1) b2 = std::min<int64_t>(b2, int64_t(2) << 30);
-            }
+            if (b2 <= 0) b2 = int64_t(double(first[k]) * shrink);
             if (b2 < (8 << 20)) b2 = 8 << 20;
             h->lad[k].arena_bytes = b2;
             h->lad_bytes += b2;
