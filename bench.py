@@ -404,7 +404,11 @@ def main():
         # one at a time; every run of 12 on fresh boxes within 2 %).  Round 3 kept THREE: the third handle's first launches
         # then waited up to seconds behind the other handles' streams (39 streams on 8 hardware queues) and the driver's run
         # measured 133 ms per step; the first two handles never did, and the warm-up steps are watched for it below.
-        args.in_flight = 2 if args.workload == "wgs_synth" else 1
+        # Round 5: three again -- 16.4 - 16.5 ms per step against 18.4 - 18.5 with two (100-step runs on one box; 17.0 - 18.1
+        # against 18.4 - 18.7 over the driver's 20 steps, which include the pipeline's fill), six driver-command runs without a
+        # stalled step (slowest step of any run 74 ms); a handle's kernels of a step now span 17 ms instead of 27, and the
+        # warm-up steps are still watched.
+        args.in_flight = 3 if args.workload == "wgs_synth" else 1
     if args.one_pass_batches is None:
         args.one_pass_batches = 12 if args.workload == "wgs_synth" else 0
     # (every resident batch goes through at least one untimed step: a handle's workspaces settle in its first execute)
@@ -786,7 +790,14 @@ def main():
             two_fl = None
         except Exception as e:      # (a leg must not cost the headline)
             two_fl = {"error": repr(e)}
-        # (b) the other single-GPU configurations of BASELINE.json on small batches
+        # (b) the other single-GPU configurations of BASELINE.json on small batches.  The headline's other resident batches go
+        # first: every live handle holds a dozen streams, and these legs -- latency chains on a handle of their own -- ran 1.6 x
+        # slower beside three idle handles than beside two (sv_synth 0.60 - 0.67 s against 0.37)
+        S = None
+        for S_ in slots:
+            if S_ is not S_last:
+                S_.pr.close()
+        gc.collect()
         for wl, n_sc_, st_ in (("sv_synth", 200, 2), ("stress_synth", 20000, 2)):
             try:
                 secondary.append(secondary_leg(api, summary, wl, n_sc_, args.seed, st_, local_rank,

@@ -3011,9 +3011,10 @@ struct Exec {
         ls.bytes_algorithmic = ls.cells + part_in;
         int rc = VPR_OK;
         if (phases & 1) {
-        if (zero) {     // the lane kernel moves bytes per truth ROW, not per window cell: position words 24 B, cell records 8 B written
-            // + 8 B read, path_ptr words 4 + 4 B, walk steps 8 B (pr_zl.hip); part_in = 6 * (Lq + Lt + Lr) summed over the part
-            ls.bytes_algorithmic = 56 * zl_rows;
+        if (zero) {     // the lane kernel moves bytes per truth ROW, not per window cell: position words 16 B, cell records 8 B written
+            // + 8 B read, path_ptr words 4 B (pr_zl.hip; the walk -- k_zero_walk since round 5 -- has the other 20 of the former 56:
+            // two position words, the path_ptr word, the 8-byte step)
+            ls.bytes_algorithmic = 36 * zl_rows;
             ls.cells = 8 * zl_rows;                               // cell slots per row
         }
         cells_touched += ls.cells;
@@ -3146,6 +3147,16 @@ struct Exec {
             });
             if (rc) return rc;
             ws_.cells_per_thread = 3;
+            if (zero) {      // the walk of what the zero level finished (its third pass until round 5: pr_zl.hip), then the credit walk
+                ws_.bytes_algorithmic = 20 * zl_rows;
+                rc = timed(3, ws_, ks, "k_zero_walk", [&] {
+                    hipLaunchKernelGGL(k_zero_walk, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->d_descs, list, cnt, h->d_zl_hdr + zl_wave0,
+                                       h->d_zl_in, h->d_zl_log, h->d_outs, a_path, (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0, tag,
+                                       h->lane_prio_rows);
+                });
+                if (rc) return rc;
+                ws_.bytes_algorithmic = 0;
+            }
             if (zero) rc = timed(3, ws_, ks, "k_zero_credit", [&] {
                 hipLaunchKernelGGL(k_zero_credit, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, list, cnt,
                                    h->d_zl_hdr + zl_wave0, h->d_zl_log, h->d_outs, h->d_secs, h->d_fp_table, h->d_jobs,
@@ -3269,6 +3280,12 @@ struct Exec {
             ordered_fails(list, n_all, h->d_d1_fail, h->d_d1_info + 2, n_dev, ks);
         } else if (ph == 4) {
             ls.cells_per_thread = 3;
+            rc = timed(3, ls, ks, "k_one_walk", [&] {
+                hipLaunchKernelGGL(k_one_walk, dim3(nw), dim3(64), 0, ks, h->d_descs, list, n_dev, cap, h->d_d1_hdr, h->d_d1_in, h->d_d1_log,
+                                   h->d_outs, reinterpret_cast<PathEnt *>(h->plan0.arena), (h->cfg.flags & VPR_CFG_KEEP_PATHS) ? 1 : 0, h->d_d1_info,
+                                   std::max(1, h->lane_prio_rows / 4));
+            });
+            if (rc) return rc;
             rc = timed(3, ls, ks, "k_one_credit", [&] {
                 hipLaunchKernelGGL(k_one_credit, dim3(nw), dim3(64), 0, ks, h->dB, h->d_descs, list, n_dev, cap, h->d_d1_hdr, h->d_d1_log,
                                    h->d_outs, h->d_secs, h->d_fp_table, h->d_jobs, h->d_njobs, h->jobs_cap, ztag);
@@ -3745,6 +3762,8 @@ struct Exec {
                         if (d1 && (rc = enqueue_d1(h->d_fail + n_long, n_dev, cap_ip, n_all1, s_short, ph, ztag))) return rc;
                     }
                     if (ph == 1 && s_cred != s_short) {
+                        // (forking right behind the zero level instead -- its walk beside the distance-1 level -- slows `k_prep_d1` from
+                        // 0.7 to 1.8 ms and the step by 0.5: the walk's 62 000 waves take the slots the chain's next launch wants)
                         HIPCHK(h, hipEventRecord(h->ev_cred[0], s_short));
                         HIPCHK(h, hipStreamWaitEvent(s_cred, h->ev_cred[0], 0));
                         if ((rc = enqueue_part(P0, P0.d_work, ch.work_off + n_long, n_short, LV_Z, s_cred, 1, n_long, false,

@@ -694,7 +694,48 @@ __global__ void __launch_bounds__(64, 3) k_one_lane(const AlnDesc *__restrict__ 
     }
 
     lapck(2);
-    // ---------------- pass 4: walk (dist.cpp:905-982) + sync flags (dist.cpp:949-968) along the move bytes
+    // (pass 4, the walk, is a kernel of its own -- k_one_walk, on the side stream in front of k_one_credit -- like the zero level's:
+    // this launch is on the short part's chain)
+    if (ok) { AlnOut &o = outs[a]; o.beg_plane = beg_plane; o.path_len = -1; }       // (-1: walk pending)
+}
+
+// ===========================================================================
+// K1Lw: pass 4 of the distance-1 lane level -- the walk + sync flags (dist.cpp:865-998) along the move bytes k_one_lane left; the
+// steps are the 8-byte records of k_zero_walk plus an edit bit and "truth row one behind the index" (after an INS step)
+// ===========================================================================
+__global__ void __launch_bounds__(64, 8) k_one_walk(const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list,
+                                                    const int32_t *__restrict__ n_dev, int n_cap, const ZlWave *__restrict__ hdr,
+                                                    const uint32_t *__restrict__ zin, uint4 *__restrict__ zlog,
+                                                    AlnOut *__restrict__ outs, PathEnt *__restrict__ paths, int keep_paths,
+                                                    int32_t *__restrict__ info, int prio_rows) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const ZlWave H = hdr[w];
+    if (H.mt <= 0) return;
+    if (H.mt >= prio_rows) __builtin_amdgcn_s_setprio(2);
+    const int n_list = min(*n_dev, n_cap);
+    const int wi = w * 64 + lane;
+    const int a_ = wi < n_list ? list[wi] : -1;
+    const int a = max(a_, 0);
+    const AlnDesc *dp = descs + a;
+    const bool ok = a_ >= 0 && outs[a].band_ok == D1_TAG && outs[a].path_len == -1;
+    const int Lq = ok ? dp->Lq : 1, Lr = ok ? dp->Lr : 1;
+    const int L[2] = {Lq, Lr};
+    const int nrow = ok ? dp->Lt : 0;
+    int bmax = nrow;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) bmax = max(bmax, __shfl_xor(bmax, o));
+    if (bmax == 0) return;
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(zin + H.in_off), 0, 256 * (2 * H.mq + 2 * H.mr + H.mt), 0x00020000);
+    const auto rlog = __builtin_amdgcn_make_buffer_rsrc(zlog + H.log_off, 0, 2560 * (H.mt + 1), 0x00020000);
+    const uint32_t lane4 = uint32_t(lane) << 2, lane8 = uint32_t(lane) << 3, lane16 = uint32_t(lane) << 4;
+    const uint32_t posW[2] = {0u, uint32_t(2 * H.mq) << 8};
+    const uint32_t post = uint32_t(2 * H.mq + 2 * H.mr) << 8;
+    const uint32_t logB1 = uint32_t(H.mt + 1) << 10;
+    auto in_at = [&](uint32_t off) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b32(rin, off, 0, 0); };
+    auto word_at = [&](int p, int x, bool on) -> uint32_t { return in_at(on ? posW[p] + (uint32_t(x) << 8) + lane4 : ZL_OOB); };
+    auto t_at = [&](int t, bool on) -> uint32_t { return in_at(on ? post + (uint32_t(t) << 8) + lane4 : ZL_OOB); };
+    const int beg_plane = ok ? outs[a].beg_plane : 0;
+    auto lapck = [&](int) {};
     {
         PathEnt *path = paths + dp->path_off;
         const uint32_t logS0 = logB1;           // the steps replace the F0 flag bytes

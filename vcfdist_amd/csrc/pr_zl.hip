@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
     const auto rlog = __builtin_amdgcn_make_buffer_rsrc(zlog + H.log_off, 0, 1280 * H.mt, 0x00020000);
     const uint32_t lane4 = uint32_t(lane) << 2, lane8 = uint32_t(lane) << 3;
     const uint32_t pos0[2] = {0u, uint32_t(H.mq) << 8}, post = uint32_t(H.mq + H.mr) << 8;
-    const uint32_t logP0 = uint32_t(H.mt) << 9, logS0 = logP0 + (uint32_t(H.mt) << 8);
+    const uint32_t logP0 = uint32_t(H.mt) << 9;
     auto in_at = [&](uint32_t off) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b32(rin, off, 0, 0); };
     // (a one-row alignment only exists where a region was cut at the contig end, include/vcfdist_pr.h: the reference's
     // backward pass never terminates on it -- left to the general kernels)
@@ -429,6 +429,42 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
     // (QUERY, 0, 0) on a path to the end?  dist.cpp:811-814
     const int beg_plane = sc[0][0] >= 0 ? VPR_PLANE_QUERY : VPR_PLANE_REF;
 
+    // (the walk -- a third pass of dependent loads, the address of a row's position word comes out of the row before -- is a
+    // kernel of its own, k_zero_walk, on the side stream of the credit walks: this launch is on the short part's chain, that one
+    // runs beside the distance-1 level and the in-place 16-cell round)
+    if (ok) outs[a].beg_plane = beg_plane;
+}
+
+// ===========================================================================
+// KZw: the walk of the alignments k_zero_lane finished (get_prec_recall_path_sync, dist.cpp:905-982, sync flags :949-968), one
+// lane per alignment over the wave's log: path_ptr words in, step records out (what k_zero_credit reads).
+// ===========================================================================
+__global__ void __launch_bounds__(64, 8) k_zero_walk(const AlnDesc *__restrict__ descs, const int32_t *__restrict__ list, int n_list,
+                                                  const ZlWave *__restrict__ hdr, const uint32_t *__restrict__ zin,
+                                                  uint4 *__restrict__ zlog, AlnOut *__restrict__ outs, PathEnt *__restrict__ paths,
+                                                  int keep_paths, int tag, int prio_rows) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const ZlWave H = hdr[w];
+    if (H.mt >= prio_rows) __builtin_amdgcn_s_setprio(2);
+    const int wi = w * 64 + lane;
+    const int a_ = wi < n_list ? list[wi] : -1;
+    const bool live = a_ >= 0;
+    const int a = max(a_, 0);
+    const AlnDesc *dp = descs + a;
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(zin + H.in_off), 0, 256 * (H.mq + H.mr + H.mt), 0x00020000);
+    const auto rlog = __builtin_amdgcn_make_buffer_rsrc(zlog + H.log_off, 0, 1280 * H.mt, 0x00020000);
+    const uint32_t lane4 = uint32_t(lane) << 2, lane8 = uint32_t(lane) << 3;
+    const uint32_t pos0[2] = {0u, uint32_t(H.mq) << 8}, post = uint32_t(H.mq + H.mr) << 8;
+    const uint32_t logP0 = uint32_t(H.mt) << 9, logS0 = logP0 + (uint32_t(H.mt) << 8);
+    auto in_at = [&](uint32_t off) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b32(rin, off, 0, 0); };
+    // finished by k_zero_lane: accepted by its exit test (k_fwd_band_finish) at this level
+    const bool ok = live && dp->band_pad == tag && outs[a].band_ok == tag;
+    const int nrow = ok ? dp->Lt : 0;
+    int bmax = nrow;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) bmax = max(bmax, __shfl_xor(bmax, o));
+    if (bmax == 0) return;
+    const int beg_plane = ok ? outs[a].beg_plane : 0;
     // ---------------- walk (dist.cpp:905-982) + sync flags (dist.cpp:949-968)
     PathEnt *path = paths + dp->path_off;
     int hi = beg_plane, slot = 0, mv_in = 0, x = 0;
@@ -475,7 +511,6 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
     }
     if (ok) {
         AlnOut &o = outs[a];
-        o.beg_plane = beg_plane;
         o.path_len = wok ? nrow : 0;
         if (!wok) o.n_sec = 0;
         if (status) atomicOr(&o.status, status);
