@@ -404,7 +404,7 @@ def main():
         # one at a time; every run of 12 on fresh boxes within 2 %).  Round 3 kept THREE: the third handle's first launches
         # then waited up to seconds behind the other handles' streams (39 streams on 8 hardware queues) and the driver's run
         # measured 133 ms per step; the first two handles never did, and the warm-up steps are watched for it below.
-        # Round 5: three again -- 16.4 - 16.5 ms per step against 18.4 - 18.5 with two (100-step runs on one box; 17.0 - 18.1
+        # Round 5: three again -- 16.4 - 16.5 ms per step against 18.4 - 18.5 with two (100-step runs on one box; 17.0 - 18.7
         # against 18.4 - 18.7 over the driver's 20 steps, which include the pipeline's fill), six driver-command runs without a
         # stalled step (slowest step of any run 74 ms); a handle's kernels of a step now span 17 ms instead of 27, and the
         # warm-up steps are still watched.
