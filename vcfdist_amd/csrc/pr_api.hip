@@ -1768,7 +1768,9 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     auto prio_of = [&](int idx, int dflt) { return !prio_map ? dflt : (prio_map[idx] == 'h' ? prio_hi : (prio_map[idx] == 'l' ? prio_lo : (prio_hi + prio_lo) / 2)); };
-    if (hipStreamCreateWithPriority(&h->stream, hipStreamDefault, prio_of(N_CLASSES + 4, (prio_hi + prio_lo) / 2)) != hipSuccess) {
+    // (non-blocking: a stream that synchronises with the null stream takes a process-wide lock on every launch -- with three host
+    // threads uploading batches that cost the one-pass leg 5 - 7 %; the library never relies on the null stream.  VPR_MAIN_BLOCKING: as before)
+    if (hipStreamCreateWithPriority(&h->stream, getenv("VPR_MAIN_BLOCKING") ? hipStreamDefault : hipStreamNonBlocking, prio_of(N_CLASSES + 4, (prio_hi + prio_lo) / 2)) != hipSuccess) {
         delete h;
         return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
     }
@@ -1908,6 +1910,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
             HIPCHK(h, hipMemsetAsync(D.sc_limit, 0, size_t(std::max(b->n_sc, 1)), h->stream));
         }
     }
+    lap("  inputs: haplotype arrays");
     if ((rc = dev_upload(h, &D.ref_off, b->ref_off, n + 1))) return rc;
     if ((rc = dev_upload(h, &D.ref_seq, b->ref_seq, ref_len))) return rc;
     if ((rc = dev_alloc(h, &D.sc_ref, ref_len))) return rc;
@@ -1937,6 +1940,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         HIPCHK(h, hipMemsetAsync(D.cand2_q[q], 0xff, std::max<int64_t>(hap_len[q], 1) * sizeof(int4), h->stream));
         HIPCHK(h, hipMemsetAsync(D.cand2_r[q], 0xff, std::max<int64_t>(ref_len, 1) * sizeof(int4), h->stream));
     }
+    lap("  inputs: reference arrays, constants' blocks");
     if ((rc = dev_alloc(h, &h->d_err, 1))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_err, 0, 4, h->stream));
     if (!h->ev_offsets) HIPCHK(h, hipEventCreateWithFlags(&h->ev_offsets, hipEventDisableTiming));
@@ -2006,6 +2010,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         if (hap_len[q] > 0) hipLaunchKernelGGL(k_prep_pack, blocks(hap_len[q]), dim3(256), 0, h->stream, D, q, 0, hap_len[q]);
         if (ref_len > 0) hipLaunchKernelGGL(k_prep_pack, blocks(ref_len), dim3(256), 0, h->stream, D, q, 1, ref_len);
     }
+    lap("  prep: scof, cand, pack");
     for (int s = 0; s < 4; s++)
         if (hap_len[s] > 0)
             hipLaunchKernelGGL(k_prep_ins, blocks(hap_len[s]), dim3(256), 0, h->stream, D, s, hap_len[s]);
@@ -2018,6 +2023,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
             if (n > 0) HIPCHK(h, hipMemcpyAsync(h->hp_dspan[s], D.dspan[s], size_t(n) * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
         }
     }
+    lap("  prep: ins, suffix, spans");
     for (int q = 0; q < 2; q++) {
         if (hap_len[q] > 0) hipLaunchKernelGGL(k_prep_xb, blocks(hap_len[q]), dim3(256), 0, h->stream, D, q, 0, hap_len[q]);
         if (ref_len > 0) hipLaunchKernelGGL(k_prep_xb, blocks(ref_len), dim3(256), 0, h->stream, D, q, 1, ref_len);
