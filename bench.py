@@ -280,8 +280,8 @@ def launch_command(n_gpus, argv, port=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-sc", type=int, default=1000000, help="superclusters per GPU")
     ap.add_argument("--workload", default="wgs_synth")
     ap.add_argument("--seed", type=int, default=0x5eed)
