@@ -3175,11 +3175,27 @@ struct Exec {
                                    h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs, h->d_njobs,
                                    h->jobs_cap, dtag, tag, n_dev);
             });
-            else rc = timed(3, ws_, ks, "k_credit<lane>", [&] {
-                hipLaunchKernelGGL(k_credit<false>, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
-                                   list, cnt, h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs,
-                                   h->d_njobs, h->jobs_cap, dtag, tag, n_dev);
-            });
+            else {
+                // a device-built list is sorted longest first (ordered_fails): its head -- the alignments of up to 1 023 rows, whose
+                // lane walks ARE the launch's duration -- gets a wavefront each (0.45 us per row against 1.3), the rest a lane
+                static const int head_max = [] { const char *e = getenv("VPR_CREDIT_HEAD"); return e ? atoi(e) : 4096; }();
+                const int32_t head = (n_dev && cnt > 2 * head_max) ? head_max : 0;
+                if (head > 0) {
+                    vpr_launch_stat wh_ = ws_;
+                    wh_.n_units = head;
+                    rc = timed(3, wh_, ks, "k_credit<wave>", [&] {
+                        hipLaunchKernelGGL(k_credit<true>, dim3(head), dim3(64), 0, ks, h->dB, h->d_descs, list, head,
+                                           h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs, h->d_njobs,
+                                           h->jobs_cap, dtag, tag, n_dev, 0);
+                    });
+                    if (rc) return rc;
+                }
+                rc = timed(3, ws_, ks, "k_credit<lane>", [&] {
+                    hipLaunchKernelGGL(k_credit<false>, dim3((cnt - head + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs,
+                                       list, cnt, h->d_outs, a_path, h->d_secs, h->d_fp_table, h->d_jobs,
+                                       h->d_njobs, h->jobs_cap, dtag, tag, n_dev, int(head));
+                });
+            }
         } else if (row_walk) {
             // striped 64-cell layout: the walk (phase A) in parallel over segments of 128 truth rows (pr_walkseg.hip; the
             // sequential row sweep, k_walk_rows, with VPR_SEQ_WALK in the environment), then the credit walk (phase B)

@@ -1179,9 +1179,11 @@ __global__ void __launch_bounds__(64) k_credit(DevBatch B, const AlnDesc *__rest
                        const PathEnt *__restrict__ paths, Section *__restrict__ secs,
                        int32_t *const *__restrict__ fp_group,
                        EdJob *__restrict__ jobs, int32_t *__restrict__ n_jobs, int32_t jobs_cap, int my_w, int ok_tag,
-                       const int32_t *__restrict__ n_dev) {
+                       const int32_t *__restrict__ n_dev, int first = 0) {
+    // first: the launch takes the list's entries from there on (the head of a device-built list, longest first, goes to the
+    // wave variant: vpr_execute)
     if (n_dev) n_work = min(n_work, *n_dev);
-    const int wi = WAVE ? int(blockIdx.x) : int(blockIdx.x * blockDim.x + threadIdx.x);
+    const int wi = first + (WAVE ? int(blockIdx.x) : int(blockIdx.x * blockDim.x + threadIdx.x));
     if (wi >= n_work) return;
     if (WAVE) __builtin_amdgcn_s_setprio(2);   // one wave per long alignment: a latency chain
     const int a = work[wi];
