@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_SIMD, SCLK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; shader clock of the committed SQ_BUSY_CYCLES counters
-PROFILE_TAG = "r05"    # profiles/<tag>_counters_<workload>.json: tools/make_profiles.sh
+PROFILE_TAG = "r06"    # profiles/<tag>_counters_<workload>.json: tools/make_profiles.sh
 
 
 def newest_profile(kind, workload=None):
@@ -62,14 +62,23 @@ def counter_roofline(kname, workload, n_sc, avg_s, n_simd, sclk_hz):
         return None
     try:
         prof = json.load(open(f))
-        if prof["workload"] != workload or prof["superclusters_per_gpu"] != n_sc or kname not in prof["kernels"]:
+        if prof["workload"] != workload or prof["superclusters_per_gpu"] != n_sc:
             return None
+        if kname not in prof["kernels"]:
+            # the library's launch statistics name a launch by its role (`k_tie_replay<early>`: the speculative replays), the
+            # kernel trace by the instantiation (`k_tie_replay<4>` / `<8>`: waves per job): the instantiation with the most time
+            base = kname.split("<")[0]
+            cands = [n for n in prof["kernels"] if n.split("<")[0] == base]
+            if not cands:
+                return None
+            kname = max(cands, key=lambda n: prof["kernels"][n].get("busy_cycles_8xcd", 0))
         k = prof["kernels"][kname]
         traffic = int((2 * k["fetch_kb"] + k["write_kb"]) * 1024)
         valu = None
         if k.get("valu_active_per_wave") and k.get("waves"):
             valu = k["valu_active_per_wave"] * 4 * k["waves"] / (n_simd * avg_s * sclk_hz)
-        return {"traffic": traffic, "valu_issue_frac": valu, "source": "profiles/" + os.path.basename(f), "k": k, "prof": prof}
+        return {"traffic": traffic, "valu_issue_frac": valu, "source": "profiles/" + os.path.basename(f), "k": k, "prof": prof,
+                "counter_kernel": kname}
     except (OSError, KeyError, ValueError):
         return None
 
@@ -83,6 +92,10 @@ def make_workload(api, n_sc, seed, workload):
         # SV-sized indels (geometric, mean 600, capped at a quarter of the span), small variants in between
         return api.Synth(n_sc=n_sc, seed=seed, len_mode=0, len_a=2000.0, len_b=12000.0, len_min=2000, len_max=12000,
                          var_per_base=0.002, p_snp=0.7, indel_mean=600.0)
+    if workload == "joint_synth":    # configs[3]: whole-genome SNP + INDEL + SV joint evaluation (`-l 10000 -s 10002`): the
+        # whole-genome length mix, 0.75 % of the superclusters carry one SV-sized indel (50 b .. 10 kb, log-uniform)
+        return api.Synth(n_sc=n_sc, seed=seed, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=10002,
+                         p_sv=0.0075, sv_min=50, sv_max=10000)
     raise SystemExit(f"unknown workload {workload}")
 
 
@@ -103,6 +116,48 @@ def cpu_limit():
             pass
     lw = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)     # (ranks of one node share the quota)
     return max(1, n // max(lw, 1))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def calibrate(strata, n_sc):
+    """the port's time on the reference's four demo workloads over the reference's own (tools/calibrate_cpu.py,
+    measured in the build container) misses +-15 % on some of them -- the port is faster than the reference on small
+    superclusters and slower on 10 kb ones.  So every stratum's CPU time is divided by the ratio of ITS size class: the ratio
+    as a function of the supercluster length, interpolated in log2(length) between the four workloads (each placed at its
+    cost-weighted span, sum L^3 / sum L^2: where its time is spent), constant outside them.  `calibrated_value` is then an
+    estimate of the REFERENCE's rate on this host."""
+    cal_f = newest_profile("cpu_calibration")
+    if not cal_f:
+        return {"calibration_port_over_reference_time": None, "calibration_note": "no profiles/r*_cpu_calibration.json"}
+    try:
+        cal = json.load(open(cal_f))
+        ratios = {k: v["oracle_over_reference"] for k, v in cal.items()}
+        out = {"calibration_port_over_reference_time": ratios, "calibration_source": "profiles/" + os.path.basename(cal_f)}
+        missed = {k: r for k, r in ratios.items() if not 0.85 <= r <= 1.15}
+        out["calibration_within_15_percent"] = not missed
+        pts = sorted((np.log2(v["cost_weighted_span"]), v["oracle_over_reference"]) for v in cal.values() if v.get("cost_weighted_span"))
+        if len(pts) >= 2 and strata:
+            xs, ys = np.array([p[0] for p in pts]), np.array([p[1] for p in pts])
+            tot = sum(st["est_batch_seconds"] / float(np.interp(st["k"] + 0.585, xs, ys)) for st in strata)     # (octave centre 1.5 x 2^k)
+            thr = max(st["threads"] for st in strata)
+            out["calibrated_value"] = round(4 * n_sc / tot, 3) if tot > 0 else None
+            out["calibrated_note"] = ("each stratum's measured time / the port-over-reference ratio of its size class (interpolated in "
+                                      "log2 of the span between the demo workloads' cost-weighted spans "
+                                      f"{[round(2 ** float(x)) for x in xs]} -> ratios {[float(y) for y in ys]}): the reference's estimated rate on this host")
+        elif missed:
+            out["calibration_note"] = f"outside SURVEY 8(d)'s +-15 % on {sorted(missed)}; no span figures in the calibration file to scale by"
+        return out
+    except (OSError, KeyError, ValueError, TypeError) as e:
+        return {"calibration_port_over_reference_time": None, "calibration_note": f"calibration file unreadable ({e!r})"}
 
 
 def cpu_baseline(batch, target_s=15.0, probe=True):
@@ -145,7 +200,7 @@ def cpu_baseline(batch, target_s=15.0, probe=True):
             if est_k >= budget or len(idx) == 1:
                 est_total += len(idx) * est_k / min(thr_k, len(idx))
                 n_samp += 1
-                strata.append({"octave": f"[{2 ** k}, {2 ** (k + 1)})", "superclusters": int(len(idx)), "sampled": 1, "threads": 1,
+                strata.append({"k": k, "octave": f"[{2 ** k}, {2 ** (k + 1)})", "superclusters": int(len(idx)), "sampled": 1, "threads": 1,
                                "seconds": round(est_k, 3), "est_batch_seconds": round(len(idx) * est_k / min(thr_k, len(idx)), 3),
                                "note": f"one supercluster on one thread; the stratum's time on {min(thr_k, len(idx))} threads is extrapolated"})
                 continue
@@ -158,15 +213,17 @@ def cpu_baseline(batch, target_s=15.0, probe=True):
         dt = time.perf_counter() - t0
         est_total += len(idx) * dt / m
         n_samp += m
-        strata.append({"octave": f"[{2 ** k}, {2 ** (k + 1)})", "superclusters": int(len(idx)), "sampled": m, "threads": len(parts),
+        strata.append({"k": k, "octave": f"[{2 ** k}, {2 ** (k + 1)})", "superclusters": int(len(idx)), "sampled": m, "threads": len(parts),
                        "seconds": round(dt, 3), "est_batch_seconds": round(len(idx) * dt / m, 3)})
     wall = time.perf_counter() - t_all
     if not probe:       # (the secondary workloads: the stratified estimate only)
+        cal = calibrate(strata, n)
         return {"value": round(4 * n / est_total, 3), "unit": "supercluster-alignments/s", "cores": threads, "kind": "port",
                 "sample": f"{n_samp} superclusters in {len(octaves)} strata by octave of length, {wall:.1f} s wall on {threads} threads "
                           f"(oracle/pr_oracle.cpp); value = batch alignments / sum over strata of (stratum size / measured rate)",
                 "est_batch_seconds_all_threads": round(est_total, 2),
-                "single_thread_value": round(4 * n / (est_total * threads), 3)}
+                "single_thread_value": round(4 * n / (est_total * threads), 3),
+                "calibrated_value": cal.get("calibrated_value")}
     # single-thread probe on the most populated octave (for the per-core rate)
     k_top = max(octaves, key=lambda k: int((octv == k).sum()))
     idx = np.flatnonzero(octv == k_top)
@@ -174,7 +231,7 @@ def cpu_baseline(batch, target_s=15.0, probe=True):
     t0 = time.perf_counter()
     oracle_lib.run(batch.subset(probe))
     dt1 = time.perf_counter() - t0
-    return {
+    return dict({
         "value": round(4 * n / est_total, 1), "unit": "supercluster-alignments/s", "cores": threads, "kind": "port",
         "sample": f"{n_samp} superclusters in {len(octaves)} strata by octave of length, {wall:.1f} s wall on {threads} threads "
                   f"(oracle/pr_oracle.cpp, one slice per thread); value = batch alignments / sum over strata of (stratum size / measured rate)",
@@ -185,7 +242,8 @@ def cpu_baseline(batch, target_s=15.0, probe=True):
         "single_thread_note": "whole mix: batch alignments / (sum over strata of estimated seconds x threads used)",
         "single_thread_value_most_populated_octave": round(4 * len(probe) / dt1, 1),
         "single_thread_sample": f"{len(probe)} superclusters of the most populated octave [{2 ** k_top}, {2 ** (k_top + 1)}), {dt1:.2f} s",
-    }
+        "cpu_model": cpu_model(),
+    }, **calibrate(strata, n))
 
 
 def secondary_leg(api, summary, workload, n_sc, seed, steps, device, cpu_target_s=0.0):
@@ -356,6 +414,7 @@ def main():
     # The path's collectives through the C ABI (vpr_allreduce_counts / vpr_allgather_phase: RCCL on the library's own stream, on
     # a communicator of this job's ranks; at N = 1 a communicator of one rank, so that the default run exercises the same entry
     # point).  torch.distributed only carries the communicator's id to the ranks.  Any failure: torch.distributed's all_reduce.
+    comm_ranks = None
     native_comm, collective = None, "torch.distributed all_reduce (" + (dist.get_backend() if dist is not None else "single rank: none") + ")"
     if not (dist is not None and dist.get_backend() == "gloo") and not os.environ.get("VCFDIST_BENCH_TORCH_COLLECTIVE"):
         try:
@@ -388,6 +447,7 @@ def main():
                         mine_ok = mine_ok and bool(int(okt.item()))
                     if mine_ok:
                         native_comm = box[0]
+                        comm_ranks = native_comm.count()        # (ncclCommCount: the communicator's own idea of its size)
                         torch.cuda.synchronize()
                         collective = "vpr_allreduce_counts (RCCL through the C ABI, library stream)"
                     else:
@@ -800,7 +860,7 @@ def main():
             if S_ is not S_last:
                 S_.pr.close()
         gc.collect()
-        for wl, n_sc_, st_ in (("sv_synth", 200, 2), ("stress_synth", 20000, 2)):
+        for wl, n_sc_, st_ in (("sv_synth", 200, 2), ("stress_synth", 20000, 2), ("joint_synth", 100000, 2)):
             try:
                 secondary.append(secondary_leg(api, summary, wl, n_sc_, args.seed, st_, local_rank,
                                                cpu_target_s=0.0 if args.no_cpu_baseline else 5.0))
@@ -900,6 +960,7 @@ def main():
             "frac_main_launch": round(bt_cr["traffic"] / (bt[1] / max(bt[0], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if bt_cr and bt[1] > 0 else
                                 (round((bt[2] / max(bt[0], 1)) / (bt[1] / max(bt[0], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if bt[1] > 0 and bt[2] > 0 else None),
             "valu_issue_frac_main_launch": None if not bt_cr or bt_cr["valu_issue_frac"] is None else round(bt_cr["valu_issue_frac"], 4),
+            "counter_kernel": bt_cr["counter_kernel"] if bt_cr else None,
             "note": "largest accumulated launch time of any kernel over the timed steps (the throughput-dominant sweep kernel is `kernel` above)"}
         per_kernel = {k[1]: {"launches": v[0], "ms": round(v[1], 3), "other_launches": v[5], "other_ms": round(v[6], 3)}
                       for k, v in sorted(stats_acc.items())}
@@ -910,7 +971,8 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": args.workload, "superclusters_per_gpu": args.n_sc,
                        "span_dist": {"wgs_synth": "lognormal(median 20, sigma 1.2) clip [4,10000]", "stress_synth": "loguniform [32,16384]",
-                                     "sv_synth": "loguniform [2000,12000], indels geometric mean 600"}.get(args.workload),
+                                     "sv_synth": "loguniform [2000,12000], indels geometric mean 600",
+                                     "joint_synth": "lognormal(median 20, sigma 1.2) clip [4,10002], 0.75 % of the superclusters with one SV-sized indel (50..10000)"}.get(args.workload),
                        "sharding": (f"{args.n_sc_total} superclusters dealt over {world} ranks by estimated cells, phasing all-gathered"
                                     if strong else f"{world} ranks x independent superclusters")},
             "dense_cells_per_s": round(tm.cells_dense * world * args.steps / elapsed, 1),
@@ -924,7 +986,7 @@ def main():
                                                        "max": round(float(d.max()), 3)})(
                 np.diff(np.sort(np.array([t0] + [e for _, _, e in timed_log]))) * 1e3),
             "in_flight": n_fl,
-            "collective": collective,
+            "collective": collective, "comm_ranks": comm_ranks,
             "per_rank": dict(per_rank, note="each rank's own wall clock per step over the timed region, and the host time of its counters + "
                                              "collective call per step (with batches in flight it overlaps the other batch's kernels)"),
             "bookkeeping_ms_per_step": round(acct_s[0] / max(args.steps, 1) * 1e3, 3),   # (reading the launch statistics: inside the timed region)
@@ -969,21 +1031,34 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only: the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(batch, target_s=8.0)
             out["cpu_baseline"]["host"] = f"{os.cpu_count()} logical cores visible, {cpu_limit()} allowed (cgroup quota)"
-            try:    # how the port compares with the reference binary: its time on the reference's own demo workloads over the
-                # times BASELINE.md publishes for them (tools/calibrate_cpu.py, measured in the build container)
-                cal_f = newest_profile("cpu_calibration")
-                cal = json.load(open(cal_f))
-                ratios = {k: v["oracle_over_reference"] for k, v in cal.items()}
-                out["cpu_baseline"]["calibration_port_over_reference_time"] = ratios
-                out["cpu_baseline"]["calibration_source"] = "profiles/" + os.path.basename(cal_f)
-                missed = {k: r for k, r in ratios.items() if not 0.85 <= r <= 1.15}
-                out["cpu_baseline"]["calibration_within_15_percent"] = not missed
-                if missed:
-                    out["cpu_baseline"]["calibration_note"] = (f"outside SURVEY 8(d)'s +-15 % on {sorted(missed)}: the port is FASTER than the reference "
-                                                              "where the ratio is below 1 (its baseline then flatters the CPU, not the GPU)")
-            except (OSError, KeyError, ValueError, TypeError) as e:
-                out["cpu_baseline"]["calibration_port_over_reference_time"] = None
-                out["cpu_baseline"]["calibration_note"] = f"no profiles/r*_cpu_calibration.json readable ({e!r})"
+            if out["cpu_baseline"].get("calibrated_value"):
+                out["cpu_baseline"]["calibrated_single_thread_value"] = round(out["cpu_baseline"]["calibrated_value"] / out["cpu_baseline"]["cores"], 1)
+        # ---- the compact digest, LAST in the line (the driver keeps the line's tail): what the legs above measured
+        def _sec(x):
+            if "error" in x:
+                return {"workload": x.get("workload"), "error": x["error"][:80]}
+            r_ = x.get("roofline") or {}
+            c_ = x.get("cpu_baseline") or {}
+            return {"workload": x["workload"], "n_sc": x["superclusters"], "ms_per_step": x["ms_per_step"], "value": x["value"],
+                    "kernel": r_.get("kernel"), "frac": r_.get("frac"), "traffic": r_.get("traffic"),
+                    "cpu": c_.get("value"), "cpu_calibrated": c_.get("calibrated_value")}
+        cb = out.get("cpu_baseline") or {}
+        out["summary"] = {
+            "value": out["value"], "ms_per_step": out["ms_per_step"], "in_flight": n_fl, "n_gpus": world,
+            "comm_ranks": comm_ranks, "per_rank_ms_per_step": per_rank["ms_per_step"],
+            "one_pass": None if not one_pass else {"value": one_pass["value"], "ms_per_batch": one_pass["ms_per_batch"],
+                                                   "upload_variants_ms": one_pass["host_thread_ms_per_batch"]["upload_variants"]},
+            "one_at_a_time_ms_per_step": None if not one_at_a_time else one_at_a_time["ms_per_step"],
+            "roofline": {"kernel": roof["kernel"], "frac": roof["frac"], "traffic": roof["traffic"], "avg_launch_ms": roof["avg_launch_ms"],
+                         "alone_ms": None if not roof["alone"] else roof["alone"]["avg_launch_ms"],
+                         "alone_frac": None if not roof["alone"] else roof["alone"]["frac"], "valu_issue_frac": roof["valu_issue_frac"]},
+            "by_time": {k_: roof["by_time"][k_] for k_ in ("kernel", "ms_per_step", "traffic_main_launch", "frac_main_launch", "valu_issue_frac_main_launch")},
+            "tie_replays": {"per_step": int(tm.n_tie_replays), "kernel_ms_per_step": round(tm.ms_tie, 3)},
+            "secondary": [_sec(x) for x in secondary],
+            "cpu_baseline": {"value": cb.get("value"), "cores": cb.get("cores"), "single_thread": cb.get("single_thread_value"),
+                             "calibrated_value": cb.get("calibrated_value"), "within_15_percent": cb.get("calibration_within_15_percent"),
+                             "cpu_model": cb.get("cpu_model")},
+        }
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

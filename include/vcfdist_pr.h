@@ -400,6 +400,9 @@ typedef struct vpr_synth_params {
     double   p_keep, p_drop;/* truth = query site kept / dropped / (rest) perturbed */
     int32_t  max_qual;      /* quals uniform integer 1..max_qual */
     int32_t  reserved;
+    double   p_sv;          /* fraction of superclusters that carry one SV-sized indel beside their small variants (joint
+                               SNP + INDEL + SV evaluation, BASELINE configs[3]); 0 = none */
+    int32_t  sv_min, sv_max;/* its length: log-uniform [sv_min, sv_max]; a deletion lengthens the span by its length (up to len_max) */
 } vpr_synth_params;
 typedef struct vpr_synth vpr_synth;
 void vpr_synth_default_params(vpr_synth_params *p);

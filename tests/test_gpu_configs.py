@@ -469,8 +469,81 @@ def test_stress_workload_full_size_properties():
     assert not r1.diff(pr.download())
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_self_launch_two_ranks_on_one_gpu(scaling):
+# ----------------------------------------------------------------------------------------------------------------------
+# config 4 of BASELINE.json (configs[3]): whole-genome SNP + INDEL + SV joint evaluation -- the whole-genome length mix with SV-sized
+# indels (50 b - 10 kb, `-l 10000 -s 10002`, globals.cpp:478-481) in a fraction of the superclusters: the lane levels, the window
+# ladder, the dense strips and the deferred edit distances in ONE plan (dist.cpp:1738-1903 treats every supercluster alike)
+# ----------------------------------------------------------------------------------------------------------------------
+JOINT = dict(len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=10002, sv_min=50, sv_max=10000)
+
+
+def _summary_rows(pr, syn, batch, res):
+    from vcfdist_amd import summary as S
+    cls = syn.var_class()
+    pb, _, _ = S.phase(res.sc_phase, np.ones(batch.n_sc, np.int32))
+    got = S.pr_counts(pr, cls, pb)
+    return cls, pb, got, S.pr_summary(got)
+
+
+@pytest.mark.parametrize("seed,n_sc,p_sv", [(0x5eed, 400, 0.06), (0x5eed + 11, 1500, 0.012)])
+def test_joint_small_variant_and_sv_workload_against_the_oracle(seed, n_sc, p_sv):
+    import oracle_lib as O
+    from vcfdist_amd import summary as S
+    syn = api.Synth(n_sc=n_sc, seed=seed, p_sv=p_sv, **JOINT)
+    batch = syn.batch()
+    got, want, n_nonmax, pr = compare(batch)
+    assert not (got.aln_status & (A.ST_ERR_NO_PTR | A.ST_ERR_UNFINISHED | A.ST_ERR_LIMIT)).any()
+    t = pr.timing()
+    names = {s.kernel.decode() for s in pr.launch_stats()}
+    hl = np.maximum.reduce([np.diff(batch.hap_off[h]) for h in range(4)])
+    print(f"{batch.n_sc} superclusters, {int((hl > 1000).sum())} with a haplotype of 1000+ bases (largest {int(hl.max())}), "
+          f"{batch.dense_cells():.2e} dense cells, largest distance {int(got.aln_dist.max())}, {t.n_band_retries} retries, "
+          f"wf_ed {t.ms_ed:.2f} ms, kernels {t.ms_total:.1f} ms: {sorted(names)}")
+    # one plan held the lane level, the window ladder and the dense level of wide alignments
+    assert "k_zero_lane" in names and t.n_band_retries > 0 and got.aln_dist.max() >= 50
+    assert any(n.startswith("k_fwd<") or n == "k_fwd_strip" for n in names)
+    # the summary's SV row is populated and equals the oracle's tally of the oracle's results
+    cls, pb, counts, rows = _summary_rows(pr, syn, batch, got)
+    assert np.array_equal(counts, O.oracle_pr_counts(O.lib(), batch.var_off, want, cls, pb))
+    sv_none = [r for r in rows if S.NAMES[r.vartype] == "SV" and not r.best][0]
+    assert sv_none.truth_tp + sv_none.truth_fn > 0 and sv_none.query_tp + sv_none.query_fp > 0
+    assert [r.key() for r in rows] == [r.key() for r in S.pr_summary(counts, L=O.lib(), prefix="vso")]
+
+
+def test_joint_workload_full_size_properties():
+    """a bench-sized joint batch (beyond the oracle): no alignment comes back unevaluated, a permuted batch gives the permuted
+    results, repeated executes are identical, the SV row is populated"""
+    from vcfdist_amd import summary as S
+    syn = api.Synth(n_sc=120000, seed=0x5eed + 2, p_sv=0.0075, **JOINT)
+    b = syn.batch()
+    pr = api.PrecisionRecall()
+    r1 = pr.run(b)
+    assert not (r1.aln_status & (A.ST_ERR_NO_PTR | A.ST_ERR_UNFINISHED | A.ST_ERR_LIMIT)).any()
+    cls, pb, counts, rows = _summary_rows(pr, syn, b, r1)
+    sv_none = [r for r in rows if S.NAMES[r.vartype] == "SV" and not r.best][0]
+    assert sv_none.truth_tp > 0 and sv_none.truth_fn > 0 and sv_none.query_fp > 0
+    print(f"SV row: truth_tp {sv_none.truth_tp} query_tp {sv_none.query_tp} truth_fn {sv_none.truth_fn} query_fp {sv_none.query_fp}; "
+          f"largest distance {int(r1.aln_dist.max())}, kernels {pr.timing().ms_total:.1f} ms")
+    perm = np.random.RandomState(4).permutation(b.n_sc)
+    r2 = api.PrecisionRecall().run(b.subset(perm))
+    assert np.array_equal(r1.aln_dist.reshape(-1, 4)[perm].ravel(), r2.aln_dist)
+    assert np.array_equal(r1.aln_status.reshape(-1, 4)[perm].ravel(), r2.aln_status)
+    assert np.array_equal(r1.sc_phase[perm], r2.sc_phase)
+    for h in range(4):
+        off = b.var_off[h]
+        cnt = np.diff(off)[perm]
+        idx = np.repeat(off[:-1][perm] - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(int(cnt.sum()))
+        for w in range(2):
+            assert np.array_equal(r1.errtype[h][w][idx], r2.errtype[h][w])
+            assert np.array_equal(r1.credit[h][w][idx].view(np.uint32), r2.credit[h][w].view(np.uint32))
+            assert np.array_equal(r1.sync_group[h][w][idx], r2.sync_group[h][w])
+            assert np.array_equal(r1.ref_ed[h][w][idx], r2.ref_ed[h][w])
+    pr.execute()
+    assert not r1.diff(pr.download())
+
+
+@pytest.mark.parametrize("scaling,workload", [("weak", "wgs_synth"), ("strong", "wgs_synth"), ("strong", "joint_synth")])
+def test_bench_self_launch_two_ranks_on_one_gpu(scaling, workload):
     """`python bench.py --gpus 2` as a plain process (no torchrun): it must re-launch itself as two ranks and print n_gpus 2.
     VCFDIST_BENCH_ONE_GPU puts both ranks on the test box's one GPU with the counters' all-reduce over gloo (a plumbing
     check: the numbers of such a run mean nothing); on an 8-GPU node the same command runs one rank per GPU over RCCL."""
@@ -483,10 +556,14 @@ def test_bench_self_launch_two_ranks_on_one_gpu(scaling):
     env["VCFDIST_BENCH_ONE_GPU"] = "1"
     extra = ["--scaling", "strong", "--n-sc-total", "30000"] if scaling == "strong" else []
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--n-sc", "20000", "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline"] + extra, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+                          "--no-cpu-baseline", "--workload", workload] + extra, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0 and line["scaling"] == scaling
+    assert line["config"]["workload"] == workload and list(line)[-1] == "summary" and line["summary"]["n_gpus"] == 2
+    if workload == "joint_synth":   # the SV row of the joint evaluation is populated on the summed counters
+        sv = [r for r in line["pr_summary_rank0"] if r["type"] == "SV"][0]
+        assert sv["truth_tp"] + sv["truth_fn"] > 0
     if scaling == "weak":
         assert line["config"]["superclusters_per_gpu"] == 20000
     else:       # one genome dealt over the ranks by estimated cells: the shares add up, the phasing of all superclusters was gathered

@@ -38,7 +38,13 @@ for name in (sys.argv[1:] or ["biwfa", "gap50", "gap200"]):
     batch = O.generate(v)          # generate_ptrs_strs is inside the reference's timed stage
     O.run(batch)
     dt = time.perf_counter() - t0
+    Ls = np.maximum(np.diff(batch.ref_off), 1).astype(np.float64)
     out[name] = {"superclusters": int(sc.n), "reference_superclusters": REF_NSC[name], "oracle_s": round(dt, 3), "reference_s": REF_S[name],
-                 "oracle_over_reference": round(dt / REF_S[name], 3)}
+                 "oracle_over_reference": round(dt / REF_S[name], 3),
+                 # where this workload's time is spent: the span length weighted by the cost model L^2 (bench.py interpolates the
+                 # ratio over octaves of the supercluster length between the four workloads' figures)
+                 "cost_weighted_span": round(float((Ls ** 3).sum() / (Ls ** 2).sum()), 1), "median_span": float(np.median(Ls))}
     print(name, out[name], flush=True)
 print(json.dumps(out))
+if os.environ.get("CALIBRATION_OUT"):
+    json.dump(out, open(os.environ["CALIBRATION_OUT"], "w"), indent=1)

@@ -108,6 +108,7 @@ class VprSynthParams(C.Structure):
         ("p_repeat", C.c_double), ("var_per_base", C.c_double), ("p_snp", C.c_double),
         ("indel_mean", C.c_double), ("p_hom", C.c_double), ("p_keep", C.c_double),
         ("p_drop", C.c_double), ("max_qual", C.c_int32), ("reserved", C.c_int32),
+        ("p_sv", C.c_double), ("sv_min", C.c_int32), ("sv_max", C.c_int32),
     ]
 
 

@@ -112,6 +112,9 @@ void vpr_synth_default_params(vpr_synth_params *p) {
     p->p_keep = 0.9;
     p->p_drop = 0.05;
     p->max_qual = 60;
+    p->p_sv = 0.0;
+    p->sv_min = 50;
+    p->sv_max = 10000;
 }
 
 int vpr_synth_create(const vpr_synth_params *pp, vpr_synth **out) {
@@ -128,6 +131,16 @@ int vpr_synth_create(const vpr_synth_params *pp, vpr_synth **out) {
 
     for (int sc = 0; sc < P.n_sc; sc++) {
         Rng rng(P.seed * 0x9e3779b97f4a7c15ULL + uint64_t(sc) * 0xd1342543de82ef95ULL + 1);
+        // joint small-variant + SV workloads (BASELINE configs[3]): a stream of its own decides whether this supercluster
+        // carries one SV-sized indel, so that the small-variant mix of a seed is the same with and without SVs
+        Rng rsv(P.seed * 0xc2b2ae3d27d4eb4fULL + uint64_t(sc) * 0x9e3779b97f4a7c15ULL + 7);
+        int sv_len = 0;
+        bool sv_ins = false;
+        if (P.p_sv > 0 && rsv.uni() < P.p_sv) {
+            const double lo = std::log(double(std::max(P.sv_min, 1))), hi = std::log(double(std::max(P.sv_max, P.sv_min)));
+            sv_len = std::max(1, int(std::exp(lo + rsv.uni() * (hi - lo)) + 0.5));
+            sv_ins = rsv.below(2) != 0;
+        }
         // --- span length
         double Lf;
         if (P.len_mode == 0) Lf = std::exp(std::log(P.len_a) + rng.uni() * (std::log(P.len_b) - std::log(P.len_a)));
@@ -135,6 +148,12 @@ int vpr_synth_create(const vpr_synth_params *pp, vpr_synth **out) {
         else Lf = P.len_a;
         int L = int(Lf + 0.5);
         L = std::max(std::max(P.len_min, 4), std::min(L, P.len_max));
+        if (sv_len && !sv_ins) {        // a deletion lies inside the span: the small-variant span + the deleted bases
+            L = std::max(8, std::min(L + sv_len, P.len_max));
+            sv_len = std::min(sv_len, L - 4);
+        } else if (sv_len) {
+            L = std::max(L, 8);
+        }
 
         if (int64_t(S->ctg_seq.size()) - ctg_start + L > (int64_t(1) << 30)) {
             S->ctg_off.push_back(S->ctg_seq.size());
@@ -191,6 +210,26 @@ int vpr_synth_create(const vpr_synth_params *pp, vpr_synth **out) {
                 }
             }
             sites.push_back(s);
+        }
+        if (sv_len > 0) {               // the SV site: small sites whose footprint touches it give way
+            Site v;
+            v.qual = float(1 + rsv.below(std::max(1, P.max_qual)));
+            v.hapmask = (rsv.uni() < P.p_hom) ? 3 : (rsv.below(2) ? 1 : 2);
+            if (sv_ins) {
+                v.type = VPR_TYPE_INS;
+                v.pos = 1 + rsv.below(L - 2);
+                v.alt.resize(sv_len);
+                for (int j = 0; j < sv_len; j++) v.alt[j] = unit ? ref[(v.pos + j) % L] : BASES[rsv.below(4)];
+            } else {
+                v.type = VPR_TYPE_DEL;
+                v.pos = 1 + rsv.below(L - 2 - sv_len);
+                v.ref = ref.substr(v.pos, sv_len);
+            }
+            std::vector<Site> keep;
+            for (const Site &s : sites)
+                if (!(s.pos + s.rlen() + 1 > v.pos && s.pos < v.pos + v.rlen() + 1)) keep.push_back(s);
+            keep.push_back(v);
+            sites.swap(keep);
         }
         std::stable_sort(sites.begin(), sites.end(), [](const Site &a, const Site &b) { return a.pos < b.pos; });
         // drop overlapping sites (footprint = [pos, pos+rlen], one clear base after)

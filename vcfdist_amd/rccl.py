@@ -46,21 +46,24 @@ def lib():
         if not names and L.vpr_rccl_available():      # (the library opened one: the same)
             p = L.vpr_rccl_library().decode()
             names = [p] if p else []
+        cand = None
         for name in names + ["librccl.so.1", "librccl.so"]:
             try:
-                _RCCL = C.CDLL(name, mode=C.RTLD_GLOBAL)
+                cand = C.CDLL(name, mode=C.RTLD_GLOBAL)
                 break
             except OSError as e:
                 err = e
-        if _RCCL is None:
+        if cand is None:
             raise OSError(f"no RCCL library: {err}")
-        _RCCL.ncclGetErrorString.restype = C.c_char_p
+        cand.ncclGetErrorString.restype = C.c_char_p
+        # (the checks run before the handle is cached: a failed check must fail every later call as well -- ADVICE r5)
         if len(mapped_copies()) > 1:
             raise OSError(f"more than one RCCL mapped into the process: {mapped_copies()}")
         lp = L.vpr_rccl_library().decode() if L.vpr_rccl_available() else ""
         mc = mapped_copies()
         if lp and mc and os.path.realpath(lp) != os.path.realpath(mc[0]):
             raise OSError(f"the library bound {lp}, the process maps {mc[0]}")
+        _RCCL = cand
     return _RCCL
 
 
@@ -91,6 +94,14 @@ class Comm:
         L = lib()
         L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
         _chk(L.ncclCommInitRank(C.byref(self._c), world, u, rank), "ncclCommInitRank")
+
+    def count(self) -> int:
+        """ranks of the communicator as RCCL itself reports them (ncclCommCount)"""
+        n = C.c_int(0)
+        L = lib()
+        L.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        _chk(L.ncclCommCount(self._c, C.byref(n)), "ncclCommCount")
+        return int(n.value)
 
     def destroy(self):
         if self._c:
