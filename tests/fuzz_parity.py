@@ -48,12 +48,17 @@ def random_workload(seed, shape=None):
         kw = dict(n_sc=int(rng.integers(2, 6)), len_a=lo, len_b=hi, len_min=lo, len_max=hi,
                   var_per_base=float(rng.uniform(0.0005, 0.004)), indel_mean=float(rng.uniform(40, 600)),
                   p_snp=float(rng.uniform(0.2, 0.7)), p_keep=float(rng.uniform(0.6, 1.0)))
+    elif shape == 7:    # the joint workload (BASELINE configs[3]): whole-genome mix, a fraction of the superclusters with one SV-sized indel
+        kw = dict(n_sc=int(rng.integers(150, 500)), len_mode=1, len_a=float(rng.uniform(10, 40)), len_b=float(rng.uniform(0.8, 1.4)),
+                  len_min=4, len_max=10002, p_sv=float(rng.uniform(0.02, 0.08)), sv_min=50, sv_max=int(rng.integers(300, 8000)),
+                  p_keep=float(rng.uniform(0.7, 0.95)), p_drop=float(rng.uniform(0.0, 0.1)), p_hom=float(rng.uniform(0.3, 0.9)),
+                  p_repeat=float(rng.uniform(0.1, 0.6)))
     else:               # everything perturbed (few zero-distance alignments)
         kw = dict(n_sc=int(rng.integers(500, 3000)), len_a=8, len_b=400, len_min=8, len_max=400,
                   p_keep=float(rng.uniform(0.3, 0.7)), p_drop=float(rng.uniform(0.1, 0.3)),
                   var_per_base=float(rng.uniform(0.01, 0.08)))
     kw["seed"] = seed
-    band_mode = int(rng.choice([1, 1, 2])) if shape in (3, 6) else int(rng.choice([1, 1, 1, 3, 2, 0]))
+    band_mode = int(rng.choice([1, 1, 2])) if shape in (3, 6, 7) else int(rng.choice([1, 1, 1, 3, 2, 0]))
     return shape, kw, band_mode
 
 

@@ -153,7 +153,7 @@ def evaluate_contig(prep, args, device=0, part=None):
         err = None
         try:
             local = pr.run(mine) if len(idx) else A.Results(0, [0, 0, 0, 0])
-        except api.VprError as e:
+        except Exception as e:      # noqa: BLE001 -- whatever it is (VprError, MemoryError, OSError ...), the other ranks must hear of it
             err, local = e, None
         if shard.any_rank(err is not None, device=cdev):
             raise api.VprError(str(err) if err is not None else "another rank's share of the contig failed")
@@ -167,6 +167,10 @@ def evaluate_contig(prep, args, device=0, part=None):
             counts = np.zeros((2, 4, 3, nq), np.int64)
         res = shard.gather_results(local, idx, whole.var_off, device=cdev)
         if rank != 0:
+            # (--strict ends the run on EVERY rank: the gathered status column is the same everywhere, rank 0 prints the report
+            # below and the others leave with it instead of waiting in the next contig's collective -- ADVICE r5)
+            if getattr(args, "strict", False) and (res.aln_status & np.uint32(A.ST_ERR_LIMIT | A.ST_ERR_NO_PTR | A.ST_ERR_UNFINISHED)).any():
+                raise SystemExit(1)
             return counts, sc.n, (sc.clusters, sc, res, phase_sets, pb, sw, fl)
     print_warnings(name, res.aln_status, strict=getattr(args, "strict", False))
     print(f"[vcfdist_amd] {name}: {sum(len(h.pos) for h in haps)} hap-variants, {sum(c.n for c in cl)} clusters, {sc.n} superclusters, "

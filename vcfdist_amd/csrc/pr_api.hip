@@ -280,6 +280,7 @@ struct vpr_handle {
     vpr_config cfg;
     std::string err;
     bool debug = false;                  // VPR_DEBUG in the environment at vpr_create: progress lines on stderr
+    bool no_level_skip = false;          // VPR_NO_LEVEL_SKIP: a reject always tries the next wider window (lad_start)
     // host-side cost of the current / last vpr_execute: allocator calls and blocking waits (vpr_timing reports them; with
     // VPR_STALL_LOG in the environment every such call that takes more than 5 ms is printed with its site)
     bool soft_alloc = false;            // the allocation under way is optional growth (x_malloc: larger reserve)
@@ -583,6 +584,44 @@ static int64_t dev_reserve_bytes() {
 static double free_share() { static const double v = [] { const char *e = getenv("VPR_DEV_FREE_SHARE"); return e ? atof(e) : 0.11; }(); return v; }
 static double arena_share() { static const double v = [] { const char *e = getenv("VPR_ARENA_SHARE"); return e ? atof(e) : 0.7; }(); return v; }
 static double ladder_share() { static const double v = [] { const char *e = getenv("VPR_LADDER_SHARE"); return e ? atof(e) : 1.0; }(); return v; }
+// The process's own books of device memory (all handles): what the library holds, and what it has handed back in the last
+// seconds.  hipMemGetInfo lags behind large hipFree calls -- a handle that has just released 250 GB of kept blocks was told
+// "51 GB free" 15 ms later and planned its next batch for a device a third the size --, so the
+// memory plan adds what the books say was freed recently, up to what the books say can be free at all (books_free).
+struct DevBooks {
+    std::mutex mu;
+    std::unordered_map<void *, size_t> blocks;
+    int64_t live = 0;                                   // bytes of hipMalloc'ed blocks of this process's handles
+    int64_t foreign0 = -1;                              // what others held when the first plan was made (torch, other processes)
+    std::deque<std::pair<double, int64_t>> freed;       // (time, bytes) of the frees of the last seconds
+    void add(void *q, size_t b) { std::lock_guard<std::mutex> g(mu); blocks[q] = b; live += int64_t(b); }
+    bool sub(void *q) {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = blocks.find(q);
+        if (it == blocks.end()) return false;
+        live -= int64_t(it->second);
+        freed.emplace_back(wall_ms(), int64_t(it->second));
+        blocks.erase(it);
+        return true;
+    }
+    // free bytes the plan may count on, given the driver's figure
+    int64_t books_free(int64_t reported_free, int64_t total, double window_ms = 20000.0) {
+        std::lock_guard<std::mutex> g(mu);
+        const double now = wall_ms();
+        while (!freed.empty() && now - freed.front().first > window_ms) freed.pop_front();
+        int64_t recent = 0;
+        for (const auto &f : freed) recent += f.second;
+        if (foreign0 < 0) foreign0 = std::max<int64_t>(total - reported_free - live - recent, 0);
+        const int64_t by_books = total - live - foreign0;
+        return std::max(reported_free, std::min(reported_free + recent, by_books));
+    }
+};
+static DevBooks &dev_books(int dev = -1) {      // one set of books per device (-1: the calling thread's current device)
+    static DevBooks b[16];
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return b[dev & 15];
+}
+
 hipError_t x_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
     const double t = wall_ms();
     {
@@ -605,6 +644,7 @@ hipError_t x_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
     }
     const hipError_t e = hipMalloc(q, bytes);
     const double dt = wall_ms() - t;
+    if (e == hipSuccess) dev_books().add(*q, bytes);
     if (h) { h->hs.n_dev_alloc++; h->hs.ms_alloc += dt; }
     slow_call(h, "hipMalloc", site, bytes, dt);
     // debugging aid (VPR_POISON=<byte>): new device memory holds that byte instead of whatever the driver left there, so that
@@ -616,6 +656,8 @@ hipError_t x_free(vpr_handle *h, void *q, const char *site) {
     const double t = wall_ms();
     const hipError_t e = hipFree(q);
     const double dt = wall_ms() - t;
+    if (!dev_books().sub(q))
+        for (int dv = 0; dv < 16 && !dev_books(dv).sub(q); dv++) {}
     if (h) { h->hs.n_dev_free++; h->hs.ms_alloc += dt; }
     slow_call(h, "hipFree", site, 0, dt);
     return e;
@@ -1545,13 +1587,25 @@ int zl_finish(vpr_handle *h, size_t n_waves, int64_t in_words, int64_t log_max, 
         const int64_t cap_ip = std::min<int64_t>(n_short_max, std::max<int64_t>(4096, (n_short_max / 4 + 3) & ~int64_t(3)));
         h->d1_wave_cap = int32_t((cap_ip + 63) / 64);
         h->d1_fail_cap = int32_t(n_short_max + n_short_max / 8 + 1024);
-        if ((rc = dev_alloc(h, &h->d_d1_hdr, size_t(h->d1_wave_cap)))) return rc;
-        if ((rc = dev_alloc(h, &h->d_d1_in, size_t(h->d1_in_cap)))) return rc;
-        if ((rc = dev_alloc(h, &h->d_d1_log, size_t(h->d1_log_cap)))) return rc;
-        if ((rc = dev_alloc(h, &h->d_d1_fail, size_t(h->d1_fail_cap)))) return rc;
-        if ((rc = dev_alloc(h, &h->d_d1_info, 16))) return rc;
-        if ((rc = dev_alloc(h, &h->d_d1_blk, size_t(h->d1_fail_cap / 256 + 8)))) return rc;
-        HIPCHK(h, hipMemsetAsync(h->d_d1_info, 0, 64, h->stream));
+        // (the level is optional -- VPR_NO_D1 gives the same results --, so its blocks, several GB on a million superclusters, are
+        // optional growth: where the device has no room for them the upload goes on without the level.  ADVICE r5)
+        h->soft_alloc = true;
+        rc = dev_alloc(h, &h->d_d1_hdr, size_t(h->d1_wave_cap));
+        if (!rc) rc = dev_alloc(h, &h->d_d1_in, size_t(h->d1_in_cap));
+        if (!rc) rc = dev_alloc(h, &h->d_d1_log, size_t(h->d1_log_cap));
+        if (!rc) rc = dev_alloc(h, &h->d_d1_fail, size_t(h->d1_fail_cap));
+        if (!rc) rc = dev_alloc(h, &h->d_d1_info, 16);
+        if (!rc) rc = dev_alloc(h, &h->d_d1_blk, size_t(h->d1_fail_cap / 256 + 8));
+        h->soft_alloc = false;
+        if (rc) {
+            if (h->debug) fprintf(stderr, "[vpr] distance-1 lane level: no room for its blocks (%.2f GB), the level is off for this batch\n",
+                                  double(h->d1_in_cap) * 4e-9 + double(h->d1_log_cap) * 16e-9);
+            h->d_d1_hdr = nullptr; h->d_d1_in = nullptr; h->d_d1_log = nullptr; h->d_d1_fail = nullptr; h->d_d1_info = nullptr; h->d_d1_blk = nullptr;
+            h->err.clear();
+            (void)hipGetLastError();
+        } else {
+            HIPCHK(h, hipMemsetAsync(h->d_d1_info, 0, 64, h->stream));
+        }
     }
     for (size_t ci = 0; ci < P.chunks.size(); ci++) {
         const Chunk &ch = P.chunks[ci];
@@ -1746,6 +1800,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     vpr_handle *h = new vpr_handle();
     h->cfg = *cfg;
     h->debug = getenv("VPR_DEBUG") != nullptr;
+    h->no_level_skip = getenv("VPR_NO_LEVEL_SKIP") != nullptr;
     h->no_strips = getenv("VPR_NO_STRIPS") != nullptr;
     h->no_round_overlap = getenv("VPR_NO_ROUND_OVERLAP") != nullptr;
     h->stall_log = getenv("VPR_STALL_LOG") != nullptr;
@@ -2189,6 +2244,11 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     // ---- arena for flag matrices, band origins and walks
     size_t free_b = 0, total_b = 0;
     HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+    {   // (the driver's figure lags behind this process's own large frees: dev_books)
+        const int64_t fb = dev_books().books_free(int64_t(free_b), int64_t(total_b));
+        if (h->debug && fb != int64_t(free_b)) fprintf(stderr, "[vpr] memory plan: the driver reports %.1f GB free, the books %.1f\n", double(free_b) / 1e9, double(fb) / 1e9);
+        free_b = size_t(fb);
+    }
     // what the batch may take: the free memory (the blocks kept from the previous batch count: the allocations below take
     // them first) less the tenth of the device the library leaves alone; on a device mostly taken by others, half of what is free
     int64_t avail = int64_t(free_b), avail_cache = 0;
@@ -2199,6 +2259,16 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     avail += scratch_kept;
     h->mem_reserve = int64_t(double(total_b) * free_share());
     avail = std::max<int64_t>(avail - h->mem_reserve, avail / 2);
+    // What the upload allocates BEHIND this plan comes off first (the ladders' and replays' halves were promised memory
+    // the lane levels then took): the lane levels' interleaved position words (4 B per position of the short part) and logs
+    // (20 B per truth row), padded to the waves' longest alignments (measured: < 15 %), the distance-1 level's blocks (0.8 of
+    // both, zl_finish), the device planner's temporaries (28 B per alignment) and the saved forward flags of the long part.
+    int64_t lane_est = 0;
+    if (h->p0.valid && h->cfg.band_mode != 0 && h->cfg.band_mode != 2) {
+        const double zl = 1.15 * (double(h->p0.part_in[1]) / 6.0 * 4.0 + 20.0 * double(h->p0.part_rows[1]));
+        lane_est = int64_t(zl * (getenv("VPR_NO_D1") ? 1.0 : 1.8)) + 28 * int64_t(h->descs.size());
+        avail = std::max<int64_t>(avail - lane_est, avail / 2);
+    }
     int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes : int64_t(double(avail) * arena_share());
     if (budget < (8 << 20)) budget = 8 << 20;
     // do not allocate more than round 0 can use (its layout per alignment: make_plan)
@@ -2253,9 +2323,9 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
         }
         const double shrink = first_sum > h->lad_budget && first_sum > 0 ? double(h->lad_budget) / double(first_sum) : 1.0;
         if (h->debug)
-            fprintf(stderr, "[vpr] memory plan: free %.1f GB + kept blocks %.1f + scratches %.1f, reserve %.1f -> %.1f to plan; round 0 wants %.1f, gets %.1f; "
+            fprintf(stderr, "[vpr] memory plan: free %.1f GB + kept blocks %.1f + scratches %.1f, reserve %.1f, lane levels %.1f -> %.1f to plan; round 0 wants %.1f, gets %.1f; "
                             "ladders' half %.1f (first workspaces %.1f %.1f %.1f %.1f), replays' half %.1f\n",
-                    double(free_b) / 1e9, double(avail_cache) / 1e9, double(scratch_kept) / 1e9, double(h->mem_reserve) / 1e9, double(avail) / 1e9,
+                    double(free_b) / 1e9, double(avail_cache) / 1e9, double(scratch_kept) / 1e9, double(h->mem_reserve) / 1e9, double(lane_est) / 1e9, double(avail) / 1e9,
                     double(want) / 1e9, double(budget) / 1e9, double(h->lad_budget) / 1e9, double(first[0]) * shrink / 1e9, double(first[1]) * shrink / 1e9,
                     double(first[2]) * shrink / 1e9, double(first[3]) * shrink / 1e9, double(h->tie_budget) / 1e9);
         for (int k = (h->cfg.band_mode != 0 ? 0 : 2); k < 4; k++) {   // (dense mode: only the tie rounds need one)
@@ -3179,7 +3249,9 @@ struct Exec {
                 // a device-built list is sorted longest first (ordered_fails): its head -- the alignments of up to 1 023 rows, whose
                 // lane walks ARE the launch's duration -- gets a wavefront each (0.45 us per row against 1.3), the rest a lane
                 static const int head_max = [] { const char *e = getenv("VPR_CREDIT_HEAD"); return e ? atoi(e) : 4096; }();
-                const int32_t head = (n_dev && cnt > 2 * head_max) ? head_max : 0;
+                // (sorted only when ordered_fails built it, i.e. with the distance-1 level's blocks in place: k_collect_fails lists
+                // the rejects in arrival order, and a head of arbitrary short alignments would only cost wave slots -- ADVICE r5)
+                const int32_t head = (n_dev && h->d_d1_blk && cnt > 2 * head_max) ? head_max : 0;
                 if (head > 0) {
                     vpr_launch_stat wh_ = ws_;
                     wh_.n_units = head;
@@ -3323,7 +3395,7 @@ struct Exec {
         if (nf > 0) {
             const size_t f0 = fails.size();
             fails.insert(fails.end(), h->hp_fail + fail_off, h->hp_fail + fail_off + nf);
-            if (h->debug && nf <= 64) {
+            if (h->debug && nf <= (getenv("VPR_DEBUG_REJECTS") ? atoi(getenv("VPR_DEBUG_REJECTS")) : 64)) {
                 for (size_t k = f0; k < fails.size(); k++) {
                     const int32_t a = fails[k];
                     AlnOut o;
@@ -3434,7 +3506,22 @@ struct Exec {
         std::vector<int32_t> by_lv[LV_DENSE + 1];
         // (a tie round repeats the alignment's level; the zero-distance lane kernel never marks one, so an alignment still
         // listed at LV_Z was accepted by the in-place 16-cell round)
-        for (int32_t a : fails) by_lv[std::min<int>(tie ? std::max<int>(h->level[size_t(a)], LV_Q16) : h->level[size_t(a)] + 1, LV_DENSE)].push_back(a);
+        // The next level of a reject: the next wider window -- unless the lengths alone say that no path fits it.  A path takes
+        // one plane position per truth row except along INS / DEL edges, and the windows follow the reference coordinates of the
+        // truth rows: where the truth hap is `gap` bases longer than both planes (or shorter than both), `gap` net DEL (INS)
+        // edges lie in one column (row) of the matrix, outside any window narrower than that.  Only which level is TRIED depends
+        // on this (every level's exit test is exact); an alignment whose planes differ in length by more than the gap keeps the
+        // ladder.  (configs[2] / configs[3]: SV-sized variants of one call set only -- 16 -> 64 -> 256 -> 1 024 -> dense cost four sweeps.)
+        auto next_level = [&](int32_t a) -> int {
+            int lv = h->level[size_t(a)] + 1;
+            if (h->no_level_skip || lv >= LV_DENSE) return std::min(lv, int(LV_DENSE));
+            int Lq, Lr, Lt;
+            h->descs.lens(size_t(a), Lq, Lr, Lt);
+            const int gap = std::max(Lt - std::max(Lq, Lr), std::min(Lq, Lr) - Lt);
+            while (lv < LV_DENSE && lv_window(lv) < gap) lv++;
+            return lv;
+        };
+        for (int32_t a : fails) by_lv[std::min<int>(tie ? std::max<int>(h->level[size_t(a)], LV_Q16) : next_level(a), LV_DENSE)].push_back(a);
         if (h->debug)
             fprintf(stderr, "[vpr] retry round (ladder %d): %zu -> 16, %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n",
                     int(&c - h->lad), by_lv[1].size(), by_lv[2].size(), by_lv[3].size(), by_lv[4].size(), by_lv[5].size());

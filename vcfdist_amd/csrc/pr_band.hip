@@ -152,7 +152,14 @@ __global__ void __launch_bounds__(256) k_prep_suffix(DevBatch B) {
 }
 
 // exact budgets of the exit test (pr_device.h: xb_q / xb_r), needs vs_hap of k_prep_suffix.  dir 0: hap positions of
-// query hap h, dir 1: ref positions
+// query hap h, dir 1: ref positions.  A budget is a PAIR: the inserted bases (steps of q2r that stay on a reference base) and
+// the deleted bases (steps that jump) among the query-hap steps a path can still cross -- the first lower the reference
+// coordinate a path is ahead by, the second raise it, and the exit test prices the two directions apart (exit_key below).
+// Both come from the sums at hand: |steps| summed is vs_hap, the signed sum telescopes to pointer and position differences.
+__device__ __forceinline__ int xb_pack(int a_abs, int sg) {
+    const int del = (a_abs + sg) >> 1, ins = (a_abs - sg) >> 1;
+    return int(uint32_t(min(max(ins, 0), 0xffff)) | (uint32_t(min(max(del, 0), 0xffff)) << 16));      // 0xffff: "that or more" (exit_key)
+}
 __global__ void k_prep_xb(DevBatch B, int h, int dir, int64_t n_pos) {
     const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= n_pos) return;
@@ -162,7 +169,13 @@ __global__ void k_prep_xb(DevBatch B, int h, int dir, int64_t n_pos) {
     const int Lq = int(B.hap_off[h][sc + 1] - qo), Lr = int(B.ref_off[sc + 1] - ro);
     const int32_t *W = B.vs_hap[h] + qo, *q2r = B.hap_ptr[h] + qo, *r2q = B.ref_ptr[h] + ro;
     const uint8_t *rflag = B.ref_flag[h] + ro;
-    auto Wq = [&](int i) -> int { return i >= Lq ? 0 : W[max(i, 0)]; };
+    // the steps INTO hap positions >= i: |step - 1| summed = W[i], (step - 1) summed = (q2r[Lq - 1] - q2r[i - 1]) - (Lq - i)
+    auto Wq = [&](int i) -> int {
+        if (i >= Lq) return 0;
+        i = max(i, 1);              // (position 0 has no step in front of it: W[0] = W[1])
+        if (i >= Lq) return 0;
+        return xb_pack(W[i], (q2r[Lq - 1] - q2r[i - 1]) - (Lq - i));
+    };
     auto Bref = [&](int x) -> int {
         if (x >= Lr) return 0;
         x = max(x, 0);
@@ -324,29 +337,53 @@ __device__ __forceinline__ void stripe_origin(const int32_t *t2r, const uint16_t
 }
 
 // Exit test of the window kernels (see the header).  An optimal path that leaves the window does so over an edge from an
-// in-window cell b (distance D inside the window) to a cell c outside; it costs at least D + cost(edge) + LB(c), where
-//     LB(c) = max(0, |rho(c) - tau(c)| - BUD(c) - W_t(t_c + 1))
-// bounds every continuation from c to an end cell (where rho = tau): rho / tau are the reference coordinates of c's plane
-// position and truth row, a unit-cost edge changes rho - tau by at most 1 plus the sizes of the indel steps it crosses, a
-// zero-cost edge only by the steps it crosses; a path crosses every truth step behind t_c at most once (W_t) and every
-// query-hap step at most once, and only steps it can still reach: behind x_c from the QUERY plane (W(x_c + 1)), and from the
-// REF plane those behind the hap position a swap from x_c or later lands on -- a deletion is crossed only by the swap in
-// front of it, so a path that stands on one of its bases (or walks into it along the REF plane, as the successors of the
-// cell in front of a deletion shared with the truth do) cannot use it (Bref, k_prep_xb).  Successors, with b = (p, x, t),
-// rho = rho(b), taun / vtn = tau and W_t of row t + 1, bud = {own, other} of xb_q / xb_r:
-//     INS   (p, x + 1, t)        cost 1   |rho + 1 - tau|  - (p ? bud.y : bud.x) - vt
-//     diag  (p, x + 1, t + 1)    cost 0   |rho + 1 - taun| - (p ? bud.y : bud.x) - vtn    (QUERY: rho(x + 1) = rho + 1 + w, W(x + 2) = W(x + 1) - |w|)
-//     DEL   (p, x, t + 1)        cost 1   |rho - taun|     - bud.x - vtn
-//     swap  (1 - p, z, t + 1)    cost 0   |rho + 1 - taun| - (p ? bud.x : bud.y) - vtn    (REF -> QUERY lands on rho + 1 + w with W(z + 1) = Bref(x) - |w|)
+// in-window cell b (distance D inside the window) to a cell c outside; it costs at least D + cost(edge) + LB(c), where LB(c)
+// bounds every continuation from c = (p, x, t) to an end cell.  With rho(c) the reference coordinate of c's plane position, a
+// continuation has to cover remR = rho(end) - rho(c) reference bases in remT = Lt - 1 - t truth rows.  Every edge but INS takes a
+// truth row, every edge but DEL a plane position; a plane step advances rho by one -- except the steps of the query hap's
+// indels: a step onto an inserted base leaves rho where it is, the step across a deletion adds its length.  So along any
+// continuation      #INS - #DEL = (remR - remT) - S,      S = (deleted bases crossed) - (inserted bases crossed),
+// and its cost is at least |#INS - #DEL|.  A path crosses a query-hap step at most once and only steps it can still reach:
+// behind x from the QUERY plane, and from the REF plane those behind the hap position a swap from x or later lands on -- a
+// deletion is crossed only by the swap in front of it, so a path that stands on one of its bases (or walks into it along the
+// REF plane, as the successors of the cell in front of a deletion shared with the truth do) cannot use it (Bref, k_prep_xb).
+// With I / Dl the inserted / deleted bases among those steps, S lies in [-I, Dl] and
+//     LB(c) = max(0, v - Dl, -I - v),     v = remR - remT.
+// (Until round 6 the bound was |rho - tau| - (I + Dl) - (all indel bases of the truth hap behind t), tau the truth row's
+// reference coordinate: symmetric, so that an insertion shared by the query and the truth hap -- thousands of bases with an
+// SV -- made every bound behind it zero, and a cell at distance 0 that a plane swap reaches PAST the query's insertion (its
+// first bases match the reference behind it one time in four; always inside a tandem repeat) failed every window although
+// nothing leads from it to the end: the truth's steps are not a budget, a continuation takes ALL of them, and their signed sum
+// is in remT.  The alignments of such superclusters climbed to the dense level: joint_synth)
+// The end cells' own coordinates: rho(end) = t2r[Lt - 1] for both planes where the strings end on a shared reference base
+// (generate_ptrs_strs); `slack` = how far the two planes' last positions are from it otherwise, taken off every bound.
+// Successors of b = (p, x, t), rho = rho(b), bud = {own, other} of xb_q / xb_r (pairs, I | Dl << 16):
+//     INS   (p, x + 1, t)        cost 1   v = remR - 1 - remT       own budget   (QUERY: rho(x + 1) = rho + 1 + w with the step w
+//     diag  (p, x + 1, t + 1)    cost 0   v = remR - remT           own budget    still in the budget: a weaker bound, never a wrong one)
+//     DEL   (p, x, t + 1)        cost 1   v = remR - remT + 1       bud.x
+//     swap  (1 - p, z, t + 1)    cost 0   v = remR - remT           other budget
 // ex: which of the four leave the window (bits 1, 2, 4, 8).  Returns the smallest D + cost + LB over them, D_INF for none.
-__device__ __forceinline__ int exit_key(int ex, int p, int D, int rho, int2 bud, int tau, int vt, int taun, int vtn) {
+struct ExitEnd { int endT, slack; };      // rho of the end cells, and the slack above
+__device__ __forceinline__ ExitEnd exit_end(const int32_t *q2r, const int32_t *t2r, int Lq, int Lr, int Lt) {
+    ExitEnd e;
+    e.endT = t2r[Lt - 1];
+    const int a = q2r[Lq - 1] - e.endT, b = Lr - 1 - e.endT;
+    e.slack = max(a < 0 ? -a : a, b < 0 ? -b : b);
+    return e;
+}
+__device__ __forceinline__ int exit_lb(int v, int packed, int slack) {
+    int ins = packed & 0xffff, del = int(uint32_t(packed) >> 16);
+    ins = ins == 0xffff ? (1 << 28) : ins;
+    del = del == 0xffff ? (1 << 28) : del;
+    return max(max(v - del, -ins - v) - slack, 0);
+}
+__device__ __forceinline__ int exit_key(int ex, int p, int D, int rho, int2 bud, int remT, ExitEnd E) {
     const int b_same = p ? bud.y : bud.x, b_swap = p ? bud.x : bud.y;
-    const int a1 = rho + 1 - tau, a2 = rho + 1 - taun, a3 = rho - taun;
-    const int m2 = (a2 < 0 ? -a2 : a2) - vtn;
-    const int k_ins = 1 + max((a1 < 0 ? -a1 : a1) - b_same - vt, 0);
-    const int k_dg = max(m2 - b_same, 0);
-    const int k_del = 1 + max((a3 < 0 ? -a3 : a3) - bud.x - vtn, 0);
-    const int k_sw = max(m2 - b_swap, 0);
+    const int v = (E.endT - rho) - remT;
+    const int k_ins = 1 + exit_lb(v - 1, b_same, E.slack);
+    const int k_dg = exit_lb(v, b_same, E.slack);
+    const int k_del = 1 + exit_lb(v + 1, bud.x, E.slack);
+    const int k_sw = exit_lb(v, b_swap, E.slack);
     int k = D_INF;
     k = (ex & 1) ? min(k, k_ins) : k;
     k = (ex & 2) ? min(k, k_dg) : k;
@@ -397,7 +434,7 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
     const int4 *cand2[2] = {B.cand2_q[d.qs] + d.q_off, B.cand2_r[d.qs] + d.r_off};
     const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
     const int2 *xbp[2] = {B.xb_q[d.qs] + d.q_off, B.xb_r[d.qs] + d.r_off};   // free-shift budgets of the exit test (pr_device.h)
-    const int32_t *vst = B.vs_hap[d.ts] + d.t_off;                             // W_t(i): truth steps >= i
+    const ExitEnd xend = exit_end(q2r, t2r, Lq, Lr, Lt);      // end-cell coordinates of the exit test (exit_key)
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     int32_t *blo = blo_all + d.blo_off;
     const int n_stripes = (Lt + FS_K - 1) / FS_K;
@@ -420,15 +457,9 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
     stripe_origin(t2r, tjp, r2q, (s_begin & ~63) + lane, n_stripes, Lt, Lq, Lr, cbQ, cbR);
     stripe_origin(t2r, tjp, r2q, (s_begin & ~63) + 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
     uint32_t tchunk = 0, tlast = 0;
-    // rows (t & ~63) + lane: tau = t2r[t] and W_t(t + 1), the truth hap's budget behind row t; the same of row t + 1
-    int tauchunk = 0, vtchunk = 0, taunchunk = 0, vtnchunk = 0;
     if (s_begin == 0) {
         if (lane < Lt) {
             tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
-            tauchunk = t2r[lane];
-            vtchunk = lane + 1 < Lt ? vst[lane + 1] : 0;
-            taunchunk = lane + 1 < Lt ? t2r[lane + 1] : tauchunk;
-            vtnchunk = lane + 2 < Lt ? vst[lane + 2] : 0;
         }
     } else {    // (a block starts at a multiple of 64 rows: its first row rotates the chunk and takes row t - 1 from lane 63)
         const int tt = s_begin * FS_K - 64 + lane;
@@ -535,28 +566,18 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
                 for (int p = 0; p < 2; p++) {
                     if (st_ok[p]) fbuf[p][rowo[p]] = (lane == 0) ? F_MAT : F_INS;
                     rowo[p] += d.pitch[p];
-                    exit_min = min(exit_min, exit_key(last ? ex_last[p] : ex_in[p], p, lane, rhoc[p], vac[p],
-                                                      __builtin_amdgcn_readlane(tauchunk, 0), __builtin_amdgcn_readlane(vtchunk, 0),
-                                                      __builtin_amdgcn_readlane(taunchunk, 0), __builtin_amdgcn_readlane(vtnchunk, 0)));
+                    exit_min = min(exit_min, exit_key(last ? ex_last[p] : ex_in[p], p, lane, rhoc[p], vac[p], Lt - 1, xend));
                 }
                 continue;
             }
             if ((t & 63) == 0) {
                 tlast = __builtin_amdgcn_readlane(tchunk, 63);
                 const int tt = t + lane;
-                tchunk = 0; tauchunk = 0; vtchunk = 0; taunchunk = 0; vtnchunk = 0;
+                tchunk = 0;
                 if (tt < Lt) {
                     tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
-                    tauchunk = t2r[tt];
-                    vtchunk = tt + 1 < Lt ? vst[tt + 1] : 0;
-                    taunchunk = tt + 1 < Lt ? t2r[tt + 1] : tauchunk;
-                    vtnchunk = tt + 2 < Lt ? vst[tt + 2] : 0;
                 }
             }
-            const int tau = __builtin_amdgcn_readlane(tauchunk, t & 63);
-            const int vt = __builtin_amdgcn_readlane(vtchunk, t & 63);
-            const int taun = __builtin_amdgcn_readlane(taunchunk, t & 63);
-            const int vtn = __builtin_amdgcn_readlane(vtnchunk, t & 63);
             const uint32_t cur = __builtin_amdgcn_readlane(tchunk, t & 63);
             const uint32_t prv = ((t & 63) == 0) ? tlast : uint32_t(__builtin_amdgcn_readlane(tchunk, (t - 1) & 63));
             const uint32_t Tt = cur & 0xff;
@@ -656,7 +677,7 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
             if (__any(may_exit)) {
 #pragma unroll
                 for (int p = 0; p < 2; p++)
-                    exit_min = min(exit_min, exit_key(last ? ex_last[p] : ex_in[p], p, Dp[p], rhoc[p], vac[p], tau, vt, taun, vtn));
+                    exit_min = min(exit_min, exit_key(last ? ex_last[p] : ex_in[p], p, Dp[p], rhoc[p], vac[p], Lt - 1 - t, xend));
             }
         }
         asm volatile("" ::: "memory");      // (the stripe's flag rows leave LDS at the start of the next stripe)

@@ -87,8 +87,9 @@ struct DevBatch {
     // path through it (pr_band.hip, k_fwd_stripe).
     int32_t *vs_hap[4];
     int32_t *vs_ref[2];
-    // Exact free-shift budgets of the exit test of the 64-cell and wider window kernels (k_prep_xb; the derivation is at
-    // the exit test of k_fwd_stripe).  W(i) = vs_hap[h][i] = sum of |q2r step - 1| over query-hap steps k >= i.
+    // Budgets of the exit test of the 64-cell and wider window kernels (k_prep_xb; the derivation is at exit_key, pr_band.hip).
+    // A budget is a pair packed into one int: I | Dl << 16 = the inserted / the deleted bases among the query-hap steps a path
+    // can still cross (0xffff: that or more).  W(i) = the pair over the steps into hap positions >= i.
     //   Bref(x) = W(r2q[x] + 1), or W(r2q[x] + 2) when x is a deleted base: what a path that is on the REF plane at x can
     //             still cross on the QUERY plane (a deletion is only crossed by a swap from in front of it)
     //   xb_q[h][x] = {W(x + 1), Bref(q2r[x] + 1)}     a QUERY cell's own budget / its swap target's

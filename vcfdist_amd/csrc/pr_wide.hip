@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
     const int4 *cand2[2] = {B.cand2_q[d.qs] + d.q_off, B.cand2_r[d.qs] + d.r_off};
     const int32_t *q2r = B.hap_ptr[d.qs] + d.q_off;
     const int2 *xbp[2] = {B.xb_q[d.qs] + d.q_off, B.xb_r[d.qs] + d.r_off};     // budgets of the exit test (pr_device.h)
-    const int32_t *vst = B.vs_hap[d.ts] + d.t_off;
+    const ExitEnd xend = exit_end(q2r, t2r, Lq, Lr, Lt);      // end-cell coordinates of the exit test (exit_key)
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
     int32_t *blo = blo_all + d.blo_off;
     const int n_stripes = (Lt + WD_K - 1) / WD_K;
@@ -66,14 +66,8 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
     wide_origin<W>(t2r, tjp, r2q, lane, n_stripes, Lt, Lq, Lr, cbQ, cbR);
     wide_origin<W>(t2r, tjp, r2q, 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
     uint32_t tchunk = 0, tlast = 0;
-    // rows (t & ~63) + lane: tau = t2r[t] and W_t(t + 1), the truth hap's budget behind row t; the same of row t + 1
-    int tauchunk = 0, vtchunk = 0, taunchunk = 0, vtnchunk = 0;
     if (lane < Lt) {
         tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
-        tauchunk = t2r[lane];
-        vtchunk = lane + 1 < Lt ? vst[lane + 1] : 0;
-        taunchunk = lane + 1 < Lt ? t2r[lane + 1] : tauchunk;
-        vtnchunk = lane + 2 < Lt ? vst[lane + 2] : 0;
     }
 
     int exit_min = D_INF;
@@ -164,19 +158,11 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
             if ((t & 63) == 0 && t > 0) {
                 tlast = __builtin_amdgcn_readlane(tchunk, 63);
                 const int tt = t + lane;
-                tchunk = 0; tauchunk = 0; vtchunk = 0; taunchunk = 0; vtnchunk = 0;
+                tchunk = 0;
                 if (tt < Lt) {
                     tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
-                    tauchunk = t2r[tt];
-                    vtchunk = tt + 1 < Lt ? vst[tt + 1] : 0;
-                    taunchunk = tt + 1 < Lt ? t2r[tt + 1] : tauchunk;
-                    vtnchunk = tt + 2 < Lt ? vst[tt + 2] : 0;
                 }
             }
-            const int tau = __builtin_amdgcn_readlane(tauchunk, t & 63);
-            const int vt = __builtin_amdgcn_readlane(vtchunk, t & 63);
-            const int taun = __builtin_amdgcn_readlane(taunchunk, t & 63);
-            const int vtn = __builtin_amdgcn_readlane(vtnchunk, t & 63);
             int v[2] = {0, 0}, incl[2] = {0, 0};
             uint32_t mk[2] = {0, 0};
             if (t > 0) {
@@ -280,7 +266,7 @@ __global__ void __launch_bounds__(NW * 64) k_fwd_wide(DevBatch B, const AlnDesc 
                 }
                 if (st_ok[p]) fbuf[p][wave][rowo] = uint8_t(f);
                 // exit test, see k_fwd_stripe
-                exit_min = min(exit_min, exit_key(last ? ex_last[p] : ex_in[p], p, Dn, rhoc[p], vac[p], tau, vt, taun, vtn));
+                exit_min = min(exit_min, exit_key(last ? ex_last[p] : ex_in[p], p, Dn, rhoc[p], vac[p], Lt - 1 - t, xend));
                 Dp[p] = Dn;
                 carry_prev[p] = carry[p];
             }
