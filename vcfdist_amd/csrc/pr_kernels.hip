@@ -1024,7 +1024,8 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
                                 (hi == ri) ? 0 : q2r[0], t2r[0]};   // sync, no edit
     n = 1;
     bool ok = true;
-    int skip_run = 0;       // WAVE: steps until the next attempt at a diagonal run
+    int skip_run = 0;       // WAVE: steps until the next attempt at a run
+    int last_mv = 0;        // WAVE: move of the last single step
     while ((hi == ri && qri < r_size - 1) || (hi == qi && qri < q_size - 1) || ti < t_size - 1) {
         if (WAVE) {
             // DIAGONAL RUNS.  Nearly all of a long alignment's walk is MAT steps down one diagonal of one plane.  Lane l looks at
@@ -1032,8 +1033,47 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
             // step-by-step walk pays a dependent lookup per step); the leading lanes whose cell takes MAT by the walk's priority
             // (dist.cpp:907-935: on the REF plane only without a swap) are a run, and the run's path entries -- the cells
             // ENTERED by its steps, with their sync flags (dist.cpp:949-968) -- are written side by side.
+            // INS / DEL RUNS (round 6).  An alignment of a call set WITHOUT an SV against a haplotype with it walks thousands of INS
+            // steps along one row, or of DEL steps down one column (configs[2] / configs[3]: 10 000 edits in a row, 3.6 us each
+            // step by step).  Same idea: lane l looks at the cell l steps along the row (one coalesced load) or down the column,
+            // the leading lanes whose cell takes that move by the walk's priority are a run.  Which kind of run is tried follows the
+            // last single step's move.
             const int lim = min(min((hi == ri ? r_size : q_size) - 1 - qri, t_size - 1 - ti), 64);
+            const int lim_i = min((hi == ri ? r_size : q_size) - 1 - qri, 64), lim_d = min(t_size - 1 - ti, 64);
             if (skip_run > 0) skip_run--;
+            else if (last_mv == F_INS || last_mv == F_DEL) {
+                const bool ins = last_mv == F_INS;
+                const int lm = ins ? lim_i : lim_d;
+                int run = 0;
+                if (lm >= 2) {
+                    const int tq = ins ? qri + lane : qri, tt = ins ? ti : ti + lane;
+                    bool plain = false;
+                    if (lane < lm) {
+                        int colr = tq;
+                        bool in_w = true;
+                        if (banded) { colr = tq - blo[hi * t_size + tt]; in_w = colr >= 0 && colr < d.band_w; }
+                        if (in_w) {
+                            const int pb = mat[hi][size_t(tt) * d.pitch[hi] + colr] & 31;
+                            const bool higher = (pb & (F_MAT | F_SUB)) || (hi == ri && (pb & F_SWP));
+                            plain = !higher && (ins ? (pb & F_INS) != 0 : ((pb & F_DEL) != 0 && !(pb & F_INS)));
+                        }
+                    }
+                    const unsigned long long stop = ~__ballot(plain);
+                    run = stop ? int(__builtin_ctzll(stop)) : 64;
+                }
+                if (run >= 2 && n + run <= d.path_cap) {
+                    if (lane < run) {       // the cells ENTERED by the run's steps: edits, never sync points (dist.cpp:949-968)
+                        const int xq = ins ? qri + lane + 1 : qri, xt = ins ? ti : ti + lane + 1;
+                        const int tr = wt_[xt].x;
+                        const int qr = (hi == ri) ? xq : wq_[xq].x;
+                        path[n + lane] = PathEnt{uint32_t(xq) | (uint32_t(hi) << 31), uint32_t(xt) | (1u << 30), qr, tr};
+                    }
+                    n += run;
+                    if (ins) qri += run; else ti += run;
+                    continue;
+                }
+                skip_run = 3;
+            }
             else if (lim >= 2) {
                 const int tq = qri + lane, tt = ti + lane;
                 bool plain = false;
@@ -1141,6 +1181,7 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
         if ((hi == qi && qri >= q_size) || (hi == ri && qri >= r_size) || ti >= t_size) {
             status |= VPR_ST_ERR_NO_PTR; ok = false; break;
         }
+        last_mv = mv;
         const int consumes = mv & (F_MAT | F_SWP | F_SUB | F_DEL);
         int tflv, qflv, tr, qr;
         bool ins_loc;
