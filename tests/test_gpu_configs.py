@@ -247,7 +247,7 @@ def test_diagnostic_switches_leave_the_results_unchanged(monkeypatch):
     got, want, _, pr = compare(batch, A.default_config(band_mode=1))
     names = {s.kernel.decode() for s in pr.launch_stats()}
     assert "k_fwd_strip" in names
-    for var in ("VPR_NO_STRIPS", "VPR_NO_UB", "VPR_NO_ROUND_OVERLAP", "VPR_ED_DIAG"):
+    for var in ("VPR_NO_STRIPS", "VPR_NO_UB", "VPR_NO_ROUND_OVERLAP", "VPR_ED_DIAG", "VPR_ED_WF"):
         monkeypatch.setenv(var, "1")
         other = api.PrecisionRecall(A.default_config(band_mode=1)).run(batch)
         monkeypatch.delenv(var)

@@ -132,6 +132,36 @@ def test_sv_sized_sections_use_deferred_edit_distance():
     assert (got.ref_ed[2][0] > 32).any()
 
 
+def test_deferred_edit_distance_bit_parallel_groups_and_other_bytes(monkeypatch):
+    """k_ed_bits (pr_ed.hip): a sync section whose reference and truth segments are both longer than 4 096 bases -- the pattern
+    takes two groups of 64 blocks, the carries between them cross LDS -- with bytes other than the four bases on both sides
+    (N, a lower-case base: masks built on the spot).  Against the oracle, and equal to the wavefront kernel (VPR_ED_WF)."""
+    rng = np.random.RandomState(11)
+    L = 11500
+    ref = list(rng.choice(list("ACGT"), L))
+    for i in rng.choice(L, 40, replace=False):
+        ref[i] = "N"
+    ref = "".join(ref)
+    ins = list(rng.choice(list("ACGT"), 4600))
+    for i in rng.choice(4600, 25, replace=False):
+        ins[i] = "N"
+    ins[100] = "a"
+    ins = "".join(ins)
+    S, I, D = A.TYPE_SUB, A.TYPE_INS, A.TYPE_DEL
+    t = [(400, D, ref[400:4900], "", 40.0), (4900, I, "", ins, 40.0)]
+    q = [(405, D, ref[405:4895], "", 30.0), (4900, I, "", ins[:4580], 30.0)]
+    v = A.Variants.from_sites([ref], [dict(ctg=0, beg=300, end=5400, vars=[q, q, t, t])])
+    batch = api.batch_from_variants(v)
+    got, want, _, pr = compare(batch)
+    names = {s_.kernel.decode() for s_ in pr.launch_stats()}
+    assert "k_ed_bits" in names and int(got.ref_ed[2][0].max()) > 2000
+    monkeypatch.setenv("VPR_ED_WF", "1")
+    pr2 = api.PrecisionRecall()
+    other = pr2.run(batch)
+    monkeypatch.delenv("VPR_ED_WF")
+    assert not got.diff(other) and "k_ed_wf" in {s_.kernel.decode() for s_ in pr2.launch_stats()}
+
+
 def test_workspace_chunking_gives_identical_results():
     batch = api.Synth(n_sc=120, len_a=50, len_b=800, len_max=800, seed=12).batch()
     full = api.PrecisionRecall().run(batch)

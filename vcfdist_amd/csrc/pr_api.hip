@@ -42,6 +42,7 @@ extern "C" int vpr_batch_skeleton_from_variants(const vpr_variants *v, vpr_owned
 #include "pr_q16.hip"
 #include "pr_zl.hip"
 #include "pr_d1.hip"
+#include "pr_ed.hip"
 #include "pr_gen.hip"
 #include "pr_wide.hip"
 #include "pr_strip.hip"
@@ -280,7 +281,6 @@ struct vpr_handle {
     vpr_config cfg;
     std::string err;
     bool debug = false;                  // VPR_DEBUG in the environment at vpr_create: progress lines on stderr
-    bool no_level_skip = false;          // VPR_NO_LEVEL_SKIP: a reject always tries the next wider window (lad_start)
     // host-side cost of the current / last vpr_execute: allocator calls and blocking waits (vpr_timing reports them; with
     // VPR_STALL_LOG in the environment every such call that takes more than 5 ms is printed with its site)
     bool soft_alloc = false;            // the allocation under way is optional growth (x_malloc: larger reserve)
@@ -417,6 +417,7 @@ struct vpr_handle {
     int32_t *hp_fail = nullptr, *hp_cnt = nullptr;
     std::vector<void *> pinned;
     int32_t *d_ed_scratch = nullptr; size_t ed_scratch_ints = 0;
+    int64_t ed_max_len = -1;                               // longest ref / truth string of the batch (-1: not looked at yet)
     std::vector<EvPair> events;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;   // timing events, reused by every execute
     std::vector<hipStream_t> pad_streams;                  // (diagnostic, VPR_STREAM_PAD)
@@ -1800,7 +1801,6 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     vpr_handle *h = new vpr_handle();
     h->cfg = *cfg;
     h->debug = getenv("VPR_DEBUG") != nullptr;
-    h->no_level_skip = getenv("VPR_NO_LEVEL_SKIP") != nullptr;
     h->no_strips = getenv("VPR_NO_STRIPS") != nullptr;
     h->no_round_overlap = getenv("VPR_NO_ROUND_OVERLAP") != nullptr;
     h->stall_log = getenv("VPR_STALL_LOG") != nullptr;
@@ -2095,6 +2095,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     lap("prep kernels");
     // ---- base descriptors: a function of the offsets (BaseDescs); here only the sums and the checks
     h->descs.set(b, h->var_off);
+    h->ed_max_len = -1;
     int64_t sec_total = 0, jobs_total = 0;
     int64_t cells = 0, bytes_alg = 0;
     {
@@ -3506,22 +3507,11 @@ struct Exec {
         std::vector<int32_t> by_lv[LV_DENSE + 1];
         // (a tie round repeats the alignment's level; the zero-distance lane kernel never marks one, so an alignment still
         // listed at LV_Z was accepted by the in-place 16-cell round)
-        // The next level of a reject: the next wider window -- unless the lengths alone say that no path fits it.  A path takes
-        // one plane position per truth row except along INS / DEL edges, and the windows follow the reference coordinates of the
-        // truth rows: where the truth hap is `gap` bases longer than both planes (or shorter than both), `gap` net DEL (INS)
-        // edges lie in one column (row) of the matrix, outside any window narrower than that.  Only which level is TRIED depends
-        // on this (every level's exit test is exact); an alignment whose planes differ in length by more than the gap keeps the
-        // ladder.  (configs[2] / configs[3]: SV-sized variants of one call set only -- 16 -> 64 -> 256 -> 1 024 -> dense cost four sweeps.)
-        auto next_level = [&](int32_t a) -> int {
-            int lv = h->level[size_t(a)] + 1;
-            if (h->no_level_skip || lv >= LV_DENSE) return std::min(lv, int(LV_DENSE));
-            int Lq, Lr, Lt;
-            h->descs.lens(size_t(a), Lq, Lr, Lt);
-            const int gap = std::max(Lt - std::max(Lq, Lr), std::min(Lq, Lr) - Lt);
-            while (lv < LV_DENSE && lv_window(lv) < gap) lv++;
-            return lv;
-        };
-        for (int32_t a : fails) by_lv[std::min<int>(tie ? std::max<int>(h->level[size_t(a)], LV_Q16) : next_level(a), LV_DENSE)].push_back(a);
+        // (Round 6 tried to skip the window levels an alignment's lengths rule out -- a truth hap longer or shorter than both planes
+        // by more than a window holds the path's INS / DEL run -- and measured it on one box: sv_synth 390 - 396 ms with the skip
+        // against 328 - 337 without, joint_synth 60 against 50: the narrow levels fail within microseconds, and what reaches the
+        // dense level early runs there as a round of its own in front of the ladder's real dense round.  Taken out.)
+        for (int32_t a : fails) by_lv[std::min<int>(tie ? std::max<int>(h->level[size_t(a)], LV_Q16) : h->level[size_t(a)] + 1, LV_DENSE)].push_back(a);
         if (h->debug)
             fprintf(stderr, "[vpr] retry round (ladder %d): %zu -> 16, %zu -> 64, %zu -> 256, %zu -> 1024, %zu -> dense\n",
                     int(&c - h->lad), by_lv[1].size(), by_lv[2].size(), by_lv[3].size(), by_lv[4].size(), by_lv[5].size());
@@ -4122,6 +4112,28 @@ struct Exec {
             HIPCHK(h, x_sync(h, st, SITE));
         }
         n_jobs = std::min(n_jobs, h->jobs_cap);
+        // the bit-parallel kernel (pr_ed.hip: a wavefront per section, no host pass over the jobs) unless the batch holds a string
+        // its LDS bit planes cannot carry (VPR_ED_WF / VPR_ED_DIAG: the older kernels, which stay as that fallback)
+        if (h->ed_max_len < 0) {
+            int64_t mx = 0;
+            const size_t nsc = h->descs.size() / 4;
+            for (size_t sc = 0; sc < nsc; sc++) {
+                int32_t Lq, Lr, Lt;
+                h->descs.lens(sc * 4, Lq, Lr, Lt);          // (ref and truth segments are what a section compares)
+                mx = std::max<int64_t>(mx, std::max(Lr, Lt));
+                h->descs.lens(sc * 4 + 1, Lq, Lr, Lt);
+                mx = std::max<int64_t>(mx, Lt);
+            }
+            h->ed_max_len = mx;
+        }
+        if (n_jobs > 0 && h->ed_max_len <= EDB_MAX_TEXT && !getenv("VPR_ED_WF") && !getenv("VPR_ED_DIAG")) {
+            vpr_launch_stat es_;
+            memset(&es_, 0, sizeof(es_));
+            es_.threads = 64; es_.n_units = n_jobs;
+            return timed(4, es_, st, "k_ed_bits", [&] {
+                hipLaunchKernelGGL(k_ed_bits, dim3(n_jobs), dim3(64), 0, st, h->dB, h->d_descs, h->d_jobs, n_jobs, h->d_secs);
+            });
+        }
         if (n_jobs > 0) {
             std::vector<EdJob> jobs(n_jobs);
             HIPCHK(h, hipMemcpy(jobs.data(), h->d_jobs, size_t(n_jobs) * sizeof(EdJob), hipMemcpyDeviceToHost));
@@ -4137,7 +4149,7 @@ struct Exec {
             const size_t lds_wf = size_t(2 * (2 * max_long + 3) * 2 + max_sum + 16);
             const int64_t pitch = (max_short + 2 + 7) & ~int64_t(7);
             const size_t lds_diag = size_t(3 * pitch * 2 + max_sum + 16);
-            if (lds_wf <= 150 * 1024 && max_long < 29000 && !getenv("VPR_ED_DIAG")) {
+            if (lds_wf <= 150 * 1024 && max_long < 29000 && !getenv("VPR_ED_DIAG")) {     // (VPR_ED_WF lands here)
                 // size classes by the longer string (x 4 from class to class), largest first
                 void *ps = nullptr, *qs = nullptr;
                 { int rc_pin = exec_pin(h, &ps, size_t(n_jobs) * 4); if (rc_pin) return rc_pin; }
