@@ -213,6 +213,15 @@ def test_command_line_on_demo_files(tmp_path, capsys):
     assert got[:1] + got[2:] == want[:1] + want[2:]      # all but the ##fileDate line
     # the summary rows of the TSV carry the published SNP numbers
     assert "SNP\tNONE\t0\t8222\t8222\t1\t2\t0.999757\t0.999878\t0.999818\t37.388565\n" in rd("precision-recall-summary.tsv")
+    # parameters.txt (write_params, print.cpp:30-56): the reference's keys in its order, its formats
+    par = rd("parameters.txt").split("\n")
+    keys = [l.split(" = ")[0] for l in par]
+    assert keys == ["program", "version", "out_prefix", "command", "reference_fasta", "query_vcf", "truth_vcf", "bed_file", "write_outputs",
+                    "filters", "min_var_qual", "max_var_qual", "max_var_size", "sv_threshold", "phase_threshold", "credit_threshold",
+                    "realign_truth", "realign_query", "realign_only", "cluster_method", "cluster_min_gap", "reach_min_gap",
+                    "max_cluster_itrs", "max_threads", "max_ram", "sub", "open", "extend", "eval_sub", "eval_open", "eval_extend", "distance"]
+    assert "phase_threshold = 0.600000" in par and "credit_threshold = 0.700000" in par and "cluster_method = 'biwfa'" in par
+    assert "max_var_size = 5000" in par and "write_outputs = true" in par and par[-1] == "distance = false"
 
 
 @pytest.mark.gpu

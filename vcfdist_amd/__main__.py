@@ -332,6 +332,7 @@ def main(argv=None):
         if not args.no_output_files:
             RP.write_precision_recall(args.prefix, total, args.min_qual, args.max_qual)
             cmd = " ".join(["vcfdist"] + list(sys.argv[1:] if argv is None else argv))
+            RP.write_parameters(args.prefix, args, cmd)
             ctgs = [RP.Contig(c, ln, pl, fasta[c], sl, *tb) for c, ln, pl, sl, tb in (reports[k] for k in sorted(reports))]
             RP.write_results(args.prefix, ctgs, cmd=cmd, credit_threshold=args.credit_threshold)
         print("PRECISION-RECALL SUMMARY\n")

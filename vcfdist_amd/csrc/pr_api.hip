@@ -38,7 +38,6 @@ extern "C" int vpr_batch_skeleton_from_variants(const vpr_variants *v, vpr_owned
 #include "pr_kernels.hip"
 #include "pr_band.hip"
 #include "pr_walkseg.hip"
-#include "pr_fwdpar.hip"
 #include "pr_q16.hip"
 #include "pr_zl.hip"
 #include "pr_d1.hip"
@@ -328,8 +327,6 @@ struct vpr_handle {
     struct ExecBlk { uint8_t *p; size_t bytes; bool used; };
     std::vector<ExecBlk> exec_blks, exec_pins;
     bool no_strips = false;              // VPR_NO_STRIPS in the environment: wide alignments stay in one workgroup
-    bool seq_fwd = true;                 // unless VPR_PAR_FWD is in the environment: the sequential forward sweep of the 64-cell level; the
-                                         // block-parallel one (pr_fwdpar.hip) is exact but only pays where its runs meet: not inside long tandem repeats
     uint8_t *d_save = nullptr;           // second copy of the forward flags of round 0's long part (k_fwd_stripe_save), nullptr: none
     int64_t save_bytes = 0;
     bool no_flag_save = false;           // VPR_NO_FLAG_SAVE: tie rounds of the long part repeat the forward sweep
@@ -563,6 +560,17 @@ inline void slow_call(vpr_handle *h, const char *what, const char *site, size_t 
     if (h && h->stall_log && dt > 5.0) fprintf(stderr, "[vpr] slow host call: %s (%zu bytes) at %s: %.1f ms\n", what, bytes, site, dt);
 }
 // every allocator call and blocking wait of the library goes through these: counted and timed per execute
+// Switches of experiments that are closed (DESIGN.md section 6 has each one's measurement: stream priorities and padding, the zero
+// level's occupancy cap, the credit walk's head, the replay's wide jobs, the shares of the memory plan ...): read only by a library
+// built with -DVPR_EXPERIMENTS (make CXXFLAGS+=-DVPR_EXPERIMENTS); the shipped build runs the settings those experiments chose.
+static const char *exp_getenv(const char *name) {
+#ifdef VPR_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 static int poison_byte() {
     static const int v = [] { const char *e = getenv("VPR_POISON"); return e ? int(strtol(e, nullptr, 0)) & 0xff : -1; }();
     return v;
@@ -583,8 +591,8 @@ static int64_t dev_reserve_bytes() {
 // round 0's workspace may take (VPR_ARENA_SHARE; it takes what its plan asks for when that is less).  What remains is the
 // ladders' and the replays' (vpr_upload).  VPR_LADDER_SHARE scales the ladders' first workspaces (diagnostic).
 static double free_share() { static const double v = [] { const char *e = getenv("VPR_DEV_FREE_SHARE"); return e ? atof(e) : 0.11; }(); return v; }
-static double arena_share() { static const double v = [] { const char *e = getenv("VPR_ARENA_SHARE"); return e ? atof(e) : 0.7; }(); return v; }
-static double ladder_share() { static const double v = [] { const char *e = getenv("VPR_LADDER_SHARE"); return e ? atof(e) : 1.0; }(); return v; }
+static double arena_share() { static const double v = [] { const char *e = exp_getenv("VPR_ARENA_SHARE"); return e ? atof(e) : 0.7; }(); return v; }
+static double ladder_share() { static const double v = [] { const char *e = exp_getenv("VPR_LADDER_SHARE"); return e ? atof(e) : 1.0; }(); return v; }
 // The process's own books of device memory (all handles): what the library holds, and what it has handed back in the last
 // seconds.  hipMemGetInfo lags behind large hipFree calls -- a handle that has just released 250 GB of kept blocks was told
 // "51 GB free" 15 ms later and planned its next batch for a device a third the size --, so the
@@ -1806,18 +1814,17 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     h->stall_log = getenv("VPR_STALL_LOG") != nullptr;
     h->seq_walk = getenv("VPR_SEQ_WALK") != nullptr;
     h->no_flag_save = getenv("VPR_NO_FLAG_SAVE") != nullptr;
-    h->side_credit = getenv("VPR_NO_SIDE_CREDIT") == nullptr;
-    if (const char *e = getenv("VPR_ZL_LDS_KB")) h->zl_lds_bytes = std::max(0, std::min(64, atoi(e))) * 1024;
-    if (const char *e = getenv("VPR_LANE_PRIO_ROWS")) h->lane_prio_rows = std::max(1, atoi(e));     // diagnostic
+    h->side_credit = exp_getenv("VPR_NO_SIDE_CREDIT") == nullptr;
+    if (const char *e = exp_getenv("VPR_ZL_LDS_KB")) h->zl_lds_bytes = std::max(0, std::min(64, atoi(e))) * 1024;
+    if (const char *e = exp_getenv("VPR_LANE_PRIO_ROWS")) h->lane_prio_rows = std::max(1, atoi(e));     // diagnostic
     for (int k = 0; k < 2; k++)
         if (hipEventCreateWithFlags(&h->ev_cred[k], hipEventDisableTiming) != hipSuccess) return fail(nullptr, VPR_ERR_DEVICE, "hipEventCreate failed");
-    h->seq_fwd = getenv("VPR_PAR_FWD") == nullptr;
     if (const char *e = getenv("VPR_LONG_LT")) { const int v = atoi(e); if (v >= 64 && v <= 2048) h->long_lt = v; }     // diagnostic
     memset(&h->dB, 0, sizeof(h->dB));
     memset(&h->timing, 0, sizeof(h->timing));
     // (diagnostic) VPR_STREAM_PRIO: one letter per stream -- class streams 0..7, tie streams 0..3, the handle's main stream --
     // h(igh), n(ormal), l(ow)
-    const char *prio_map = getenv("VPR_STREAM_PRIO");
+    const char *prio_map = exp_getenv("VPR_STREAM_PRIO");
     if (prio_map && strlen(prio_map) != size_t(N_CLASSES + 5)) prio_map = nullptr;
     if (hipSetDevice(cfg->device) != hipSuccess) { delete h; return fail(nullptr, VPR_ERR_DEVICE, "hipSetDevice failed"); }
     int prio_lo = 0, prio_hi = 0;
@@ -1825,7 +1832,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     auto prio_of = [&](int idx, int dflt) { return !prio_map ? dflt : (prio_map[idx] == 'h' ? prio_hi : (prio_map[idx] == 'l' ? prio_lo : (prio_hi + prio_lo) / 2)); };
     // (non-blocking: a stream that synchronises with the null stream takes a process-wide lock on every launch -- with three host
     // threads uploading batches that cost the one-pass leg 5 - 7 %; the library never relies on the null stream.  VPR_MAIN_BLOCKING: as before)
-    if (hipStreamCreateWithPriority(&h->stream, getenv("VPR_MAIN_BLOCKING") ? hipStreamDefault : hipStreamNonBlocking, prio_of(N_CLASSES + 4, (prio_hi + prio_lo) / 2)) != hipSuccess) {
+    if (hipStreamCreateWithPriority(&h->stream, exp_getenv("VPR_MAIN_BLOCKING") ? hipStreamDefault : hipStreamNonBlocking, prio_of(N_CLASSES + 4, (prio_hi + prio_lo) / 2)) != hipSuccess) {
         delete h;
         return fail(nullptr, VPR_ERR_DEVICE, "hipStreamCreate failed");
     }
@@ -1838,7 +1845,7 @@ int vpr_create(const vpr_config *cfg, vpr_handle **out) {
     }
     // Streams 0, 2, 3 carry latency chains (long alignments, retry ladders) and get the highest priority, so their
     // few workgroups are dispatched ahead of the millions of the bulk stream (1) instead of behind them.
-    if (const char *e = getenv("VPR_STREAM_PAD")) {
+    if (const char *e = exp_getenv("VPR_STREAM_PAD")) {
         // (diagnostic) "lo:hi,lo:hi,...": the i-th handle of the process creates that many idle streams of either priority
         // before its own, which shifts the hardware queues the runtime maps its streams onto
         static std::atomic<int> n_handles{0};
@@ -2814,7 +2821,7 @@ struct Exec {
             // 10 000+ rows of the stress workload, whose passes over a wave's cells are then half as long -- its step 312 ->
             // 301 ms); four for the thousands of small jobs of a whole-genome batch, where eight cost the step 0.6 ms
             // (VPR_TIE_WIDE_WORDS moves the border: diagnostic)
-            static const int64_t wide_words = [] { const char *e = getenv("VPR_TIE_WIDE_WORDS"); return e ? atoll(e) : (int64_t(1) << 20); }();
+            static const int64_t wide_words = [] { const char *e = exp_getenv("VPR_TIE_WIDE_WORDS"); return e ? atoll(e) : (int64_t(1) << 20); }();
             const bool wide_job = words / std::max<int32_t>(nj, 1) >= wide_words;
             ts_.threads = wide_job ? 512 : 256; ts_.n_units = nj; ts_.cells_per_thread = early ? 1 : 0;
             int rc = timed(6, ts_, ks, early ? "k_tie_replay<early>" : "k_tie_replay", [&] {
@@ -3095,37 +3102,11 @@ struct Exec {
             ls.cells = 8 * zl_rows;                               // cell slots per row
         }
         cells_touched += ls.cells;
-        // the 64-cell level: block-parallel sweep (pr_fwdpar.hip) with VPR_PAR_FWD in the environment
-        const bool fwdp = lv == LV_C1 && !h->seq_fwd;
-        FwdParTables FT;
-        memset(&FT, 0, sizeof(FT));
-        if (fwdp) {
-            int64_t rows_sum = 0;
-            for (int32_t k = 0; k < cnt; k++) rows_sum += plan_desc(h, P, size_t(off) + size_t(k)).Lt;
-            FT.cap_stripes = int32_t(std::min<int64_t>(rows_sum / FS_K + cnt + 1, 0x7fffffff));
-            FT.cap_blocks = int32_t(std::min<int64_t>(rows_sum / (FS_K * FP_S) + cnt + 1, 0x7fffffff));
-            const size_t b_cnt = 256, b_pos = round_up(int64_t(cnt) * 4, 256), b_own = round_up(int64_t(FT.cap_blocks) * 8, 256),
-                         b_snap = size_t(FT.cap_stripes) * 512, b_acc = round_up(int64_t(FT.cap_stripes) * 8, 256),
-                         b_blk = round_up(int64_t(FT.cap_blocks) * 16, 256), b_end = round_up(int64_t(cnt) * 16, 256);
-            void *q = nullptr;
-            if ((rc = exec_alloc(h, &q, b_cnt + 3 * b_pos + b_own + b_snap + b_acc + b_blk + b_end))) return rc;
-            uint8_t *u = static_cast<uint8_t *>(q);
-            FT.counter = reinterpret_cast<int32_t *>(u); u += b_cnt;
-            FT.st_base = reinterpret_cast<int32_t *>(u); u += b_pos;
-            FT.bl_base = reinterpret_cast<int32_t *>(u); u += b_pos;
-            FT.fallback = reinterpret_cast<int32_t *>(u); u += b_pos;
-            FT.owner = reinterpret_cast<int2 *>(u); u += b_own;
-            FT.snap = reinterpret_cast<int32_t *>(u); u += b_snap;
-            FT.acc = reinterpret_cast<int2 *>(u); u += b_acc;
-            FT.blk = reinterpret_cast<int4 *>(u); u += b_blk;
-            FT.endc = reinterpret_cast<int4 *>(u);
-            HIPCHK(h, hipMemsetAsync(FT.counter, 0, 32, ks));
-        }
         // round 0's long part: the flags a second time; a tie round whose alignments all have such a copy: the copy instead of the sweep
-        const bool save = lv == LV_C1 && !fwdp && !tag_or && fwd_save_delta != 0;
+        const bool save = lv == LV_C1 && !tag_or && fwd_save_delta != 0;
         RestoreJob *rjobs = nullptr;
         bool restore = false;
-        if (lv == LV_C1 && !fwdp && tag_or && h->d_save && tie_resident && !n_dev) {
+        if (lv == LV_C1 && tag_or && h->d_save && tie_resident && !n_dev) {
             void *pb = nullptr;
             { int rc_pin = exec_pin(h, &pb, size_t(cnt) * sizeof(RestoreJob)); if (rc_pin) return rc_pin; }
             rjobs = static_cast<RestoreJob *>(pb);
@@ -3140,14 +3121,7 @@ struct Exec {
                 rjobs[k] = RestoreJob{{od.mat_off[0], od.mat_off[1]}, od.blo_off};
             }
         }
-        rc = timed(1, ls, ks, fwdp ? "k_fwd_par" : restore ? "k_restore_stripe" : band_fwd_name(lv), [&] {
-            if (fwdp) {
-                hipLaunchKernelGGL(k_fwdp_plan, blocks(cnt), dim3(256), 0, ks, h->d_descs, list, cnt, FT);
-                hipLaunchKernelGGL(k_fwdp_block<1>, dim3(FT.cap_blocks), dim3(64), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs, FT);
-                hipLaunchKernelGGL(k_fwdp_block<2>, dim3(FT.cap_blocks), dim3(64), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs, FT);
-                hipLaunchKernelGGL(k_fwdp_finish, dim3(cnt), dim3(64), 0, ks, h->d_descs, list, cnt, h->d_outs, FT);
-                hipLaunchKernelGGL(k_fwd_stripe_only, dim3(cnt), dim3(64), 0, ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs, FT.fallback);
-            } else
+        rc = timed(1, ls, ks, restore ? "k_restore_stripe" : band_fwd_name(lv), [&] {
             if (zero)        // forward + backward + walk of the zero-distance alignments, one lane each (pr_zl.hip)
                 // (tried: this launch -- the first of its batch, 62 000 long-lived waves that take the wave slots the other batch's
                 // next kernels wait for -- on a stream of its own below the short part's priority: the waiting stream's queue then
@@ -3168,15 +3142,8 @@ struct Exec {
                 hipLaunchKernelGGL(band_fwd_kernel(lv), dim3(cnt), dim3(lv >= LV_C4 ? W : 64), 0,
                                    ks, h->dB, h->d_descs, list, P.arena, a_i32, h->d_outs);
             hipLaunchKernelGGL(k_fwd_band_finish, dim3((cnt + 255) / 256), dim3(256), 0, ks, list, cnt, h->d_outs, tag, n_dev);
-        }, zero && !fwdp);
+        }, zero);
         if (rc) return rc;
-        if (fwdp && getenv("VPR_FWDP_STATS")) {      // (diagnostic: waits for the sweep)
-            int32_t c[8] = {0};
-            (void)hipStreamSynchronize(ks);
-            (void)hipMemcpy(c, FT.counter, 32, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[vpr] block-parallel forward sweep: %d alignments, %d stripes, %d blocks; %d fix-up runs, %d met (mean stripe %.2f), %d did not meet, "
-                            "%d alignments to the sequential sweep\n", cnt, c[0], c[1], c[2], c[3], c[3] ? double(c[4]) / c[3] : 0.0, c[5], c[6]);
-        }
         n_fwd++;
         {
             const int32_t nc = n_dev ? n_all : cnt;
@@ -3249,7 +3216,7 @@ struct Exec {
             else {
                 // a device-built list is sorted longest first (ordered_fails): its head -- the alignments of up to 1 023 rows, whose
                 // lane walks ARE the launch's duration -- gets a wavefront each (0.45 us per row against 1.3), the rest a lane
-                static const int head_max = [] { const char *e = getenv("VPR_CREDIT_HEAD"); return e ? atoi(e) : 4096; }();
+                static const int head_max = [] { const char *e = exp_getenv("VPR_CREDIT_HEAD"); return e ? atoi(e) : 4096; }();
                 // (sorted only when ordered_fails built it, i.e. with the distance-1 level's blocks in place: k_collect_fails lists
                 // the rejects in arrival order, and a head of arbitrary short alignments would only cost wave slots -- ADVICE r5)
                 const int32_t head = (n_dev && h->d_d1_blk && cnt > 2 * head_max) ? head_max : 0;
@@ -3276,7 +3243,7 @@ struct Exec {
             // chains worth 128 times the work; the shorter ones -- nine in ten since the long part starts at 1 024 rows -- take the row
             // sweep, a wavefront each (chains of at most 2 047 x 0.6 us), in front of the segment walk of the long ones on the same
             // stream: 1.7 instead of 6.8 ms of 10 000-workgroup launches per step with two batches in flight, step -0.4 ms, alone -0.9.
-            static const int wseg_min_rows = [] { const char *e = getenv("VPR_WSEG_MIN_ROWS"); return e ? atoi(e) : 2048; }();      // (0: the segment walk for all)
+            static const int wseg_min_rows = [] { const char *e = exp_getenv("VPR_WSEG_MIN_ROWS"); return e ? atoi(e) : 2048; }();      // (0: the segment walk for all)
             int32_t n_seg = cnt;
             if (seg_walk && long_part && wseg_min_rows > 0) {
                 n_seg = 0;

@@ -402,24 +402,12 @@ __device__ __forceinline__ void lds_to_global16(const void *lds_src, void *dst) 
                  : "=&v"(tmp) : "v"(uint32_t(uintptr_t(lds_src))), "v"(dst) : "memory");
 }
 
-// Tables of the block-parallel forward sweep (k_fwdp_*, below): the alignment's stripe slots
-struct FwdParOut {
-    int32_t *snap;      // [stripe][2][64]  D of the stripe's last row (window coordinates of the stripe)
-    int2 *acc;          // [stripe]         {exit_min, min_tie} over the stripe's rows, in the frame of the run that wrote them
-    int4 *blk;          // this block's record: {stripe of the block at whose end the fix-up run met the tentative one, -1: none;
-                        //                       fix-up D - tentative D there; 0; 0}
-    int4 *endc;         // the alignment's end cells: {dist_q, dist_r} of the tentative run, then of the fix-up run
-};
-
-// The forward sweep over stripes [s_begin, s_end) of one alignment.
-//   MODE 0: the whole alignment, one wavefront, row after row (s_begin = 0, s_end = n_stripes): results to outs[a].
-//   MODE 1: one block of a block-parallel sweep, TENTATIVE: it starts from a guessed row (D = distance from the window's
-//           centre) unless it is the alignment's first block, and records the D row at the end of every stripe.
-//   MODE 2: the same block again from the D row the block before it recorded, until the rows meet (see k_fwdp_*).
-template <int MODE>
+// The forward sweep of one alignment at the 64-cell level: one wavefront, stripe after stripe, row after row; results to outs[a].
+// (Rounds 3 - 5 carried a block-parallel variant of this sweep -- tentative runs from guessed rows, fix-up runs until the rows
+// meet, pr_fwdpar.hip -- behind VPR_PAR_FWD: exact, 0.43 instead of 6.2 ms for a 9 288-row alignment of ordinary sequence, no
+// gain inside tandem repeats where the runs never meet, never the default.  Removed in round 6; `git show 303eef9:vcfdist_amd/csrc/pr_fwdpar.hip`.)
 __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDesc &d, const int a, uint8_t *__restrict__ ws,
                                                  int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs,
-                                                 const int s_begin, const int s_end, const FwdParOut FP,
                                                  const int64_t save_delta = 0) {
     const int lane = threadIdx.x;
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
@@ -454,32 +442,15 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
 
     // stripe origins, 64 stripes per register chunk (lane l <-> stripe c0 + l); next chunk prefetched
     int cbQ, cbR, nbQ, nbR;
-    stripe_origin(t2r, tjp, r2q, (s_begin & ~63) + lane, n_stripes, Lt, Lq, Lr, cbQ, cbR);
-    stripe_origin(t2r, tjp, r2q, (s_begin & ~63) + 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
+    stripe_origin(t2r, tjp, r2q, lane, n_stripes, Lt, Lq, Lr, cbQ, cbR);
+    stripe_origin(t2r, tjp, r2q, 64 + lane, n_stripes, Lt, Lq, Lr, nbQ, nbR);
     uint32_t tchunk = 0, tlast = 0;
-    if (s_begin == 0) {
-        if (lane < Lt) {
-            tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
-        }
-    } else {    // (a block starts at a multiple of 64 rows: its first row rotates the chunk and takes row t - 1 from lane 63)
-        const int tt = s_begin * FS_K - 64 + lane;
-        tchunk = uint32_t(Ts[tt]) | (uint32_t(Tf[tt]) << 8);
-    }
+    if (lane < Lt) tchunk = uint32_t(Ts[lane]) | (uint32_t(Tf[lane]) << 8);
 
     int exit_min = D_INF, min_tie = D_INF;
     int Dp[2] = {lane, lane};            // row 0: D = x along the INS chain (origin 0)
     int lo[2] = {0, 0}, hi[2] = {min(Lq, FS_W) - 1, min(Lr, FS_W) - 1};
     int plo[2] = {0, 0};                 // origins of the previous stripe
-    if (s_begin > 0) {
-        lo[0] = __builtin_amdgcn_readlane(cbQ, s_begin & 63); lo[1] = __builtin_amdgcn_readlane(cbR, s_begin & 63);
-        hi[0] = min(Lq - 1, lo[0] + FS_W - 1); hi[1] = min(Lr - 1, lo[1] + FS_W - 1);
-        stripe_origin(t2r, tjp, r2q, s_begin - 1, n_stripes, Lt, Lq, Lr, plo[0], plo[1]);
-        if (MODE == 2) {        // the row the block before recorded at its end (in that stripe's window coordinates, as Dp is)
-            Dp[0] = FP.snap[size_t(s_begin - 1) * 128 + lane]; Dp[1] = FP.snap[size_t(s_begin - 1) * 128 + 64 + lane];
-        } else {                // a guess: the optimal paths are where the window is centred
-            Dp[0] = Dp[1] = lane < 32 ? 32 - lane : lane - 32;
-        }
-    }
     int nlo[2] = {0, 0}, nhi[2] = {0, 0};
     int2 kc[2], kn[2];                   // packed constants of this / the next stripe
     int rhoc[2], rhon[2];                // reference coordinate of the lane's cell
@@ -495,18 +466,14 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
             vac[p] = xbp[p][x0];
         }
     }
-    int s_last = s_begin;                // last stripe swept
-    int conv_at = -1, conv_delta = 0;    // MODE 2
+    int s_last = 0;                      // last stripe swept
 
-    for (int s = s_begin; s < s_end; s++) {
+    for (int s = 0; s < n_stripes; s++) {
         const int t0 = s * FS_K;
         const int rows = min(FS_K, Lt - t0);
         uint8_t (*fbuf)[FS_K * FS_W] = fbuf2[s & 1];
-        if (s > s_begin) flush_stripe(s - 1);
+        if (s > 0) flush_stripe(s - 1);
         s_last = s;
-        int old_snap[2] = {0, 0};
-        if (MODE == 2) { old_snap[0] = FP.snap[size_t(s) * 128 + lane]; old_snap[1] = FP.snap[size_t(s) * 128 + 64 + lane]; }
-        if (MODE != 0) { exit_min = D_INF; min_tie = D_INF; }      // (per stripe: the runs of a block-parallel sweep have their own frames)
         // ---- next stripe's window, prefetch of its constants
         const bool has_next = s + 1 < n_stripes;
         if (has_next) {
@@ -681,21 +648,6 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
             }
         }
         asm volatile("" ::: "memory");      // (the stripe's flag rows leave LDS at the start of the next stripe)
-        if (MODE != 0) {
-            int em_s = exit_min, mt_s = min_tie;
-            wave_prefix_min2(em_s, mt_s);
-            if (lane == 63) FP.acc[s] = make_int2(em_s, mt_s);
-            if (MODE == 1) {
-                FP.snap[size_t(s) * 128 + lane] = Dp[0]; FP.snap[size_t(s) * 128 + 64 + lane] = Dp[1];
-            } else {
-                // the fix-up run has met the tentative one when the two D rows differ by one constant over all cells of both
-                // planes: from here on the tentative run's flags (and rows, up to that constant) are the true ones
-                const int dref = __builtin_amdgcn_readlane(Dp[0] - old_snap[0], 0);
-                const bool same0 = lo[0] + lane > hi[0] || Dp[0] - old_snap[0] == dref;
-                const bool same1 = lo[1] + lane > hi[1] || Dp[1] - old_snap[1] == dref;
-                if (__all(same0 && same1)) { conv_at = s - s_begin; conv_delta = dref; break; }
-            }
-        }
         // ---- advance to the next stripe
         plo[0] = lo[0]; plo[1] = lo[1];
         lo[0] = nlo[0]; lo[1] = nlo[1]; hi[0] = nhi[0]; hi[1] = nhi[1];
@@ -708,16 +660,9 @@ __device__ __forceinline__ void fwd_stripe_range(const DevBatch &B, const AlnDes
     }
     flush_stripe(s_last);
     // end cells: row Lt-1 was computed with origins plo (the last stripe's)
-    if (MODE == 2 && conv_at >= 0) { if (lane == 0) *FP.blk = make_int4(conv_at, conv_delta, 0, 0); return; }
-    if (MODE == 2 && lane == 0) *FP.blk = make_int4(-1, 0, 0, 0);
-    if (s_end < n_stripes) return;
     const int eq = Lq - 1 - plo[0], er = Lr - 1 - plo[1];
     const int dq = (eq >= 0 && eq < 64) ? __builtin_amdgcn_readlane(Dp[0], eq & 63) : D_INF;
     const int dr = (er >= 0 && er < 64) ? __builtin_amdgcn_readlane(Dp[1], er & 63) : D_INF;
-    if (MODE != 0) {
-        if (lane == 0) { if (MODE == 1) { FP.endc->x = dq; FP.endc->y = dr; } else { FP.endc->z = dq; FP.endc->w = dr; } }
-        return;
-    }
     int em = exit_min, mt = min_tie;
     wave_prefix_min2(em, mt);
     if (lane == 63) {
@@ -737,7 +682,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe(DevBatch B, const AlnDesc *__
     __builtin_amdgcn_s_setprio(2);      // a latency chain (rows are sequential): win issue arbitration against the bulk kernels
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
-    fwd_stripe_range<0>(B, d, a, ws, blo_all, outs, 0, (d.Lt + FS_K - 1) / FS_K, FwdParOut{nullptr, nullptr, nullptr, nullptr});
+    fwd_stripe_range(B, d, a, ws, blo_all, outs);
 }
 // The forward sweep of round 0's long part: the flag bytes are also written save_delta bytes further on (a region as large as
 // the part's workspace).  The backward sweep replaces the flags by path_ptr bytes in place, and a tie round needs the flags again
@@ -749,7 +694,7 @@ __global__ void __launch_bounds__(64) k_fwd_stripe_save(DevBatch B, const AlnDes
     __builtin_amdgcn_s_setprio(2);
     const int a = work[blockIdx.x];
     const AlnDesc d = descs[a];
-    fwd_stripe_range<0>(B, d, a, ws, blo_all, outs, 0, (d.Lt + FS_K - 1) / FS_K, FwdParOut{nullptr, nullptr, nullptr, nullptr}, save_delta);
+    fwd_stripe_range(B, d, a, ws, blo_all, outs, save_delta);
 }
 // where round 0 left an alignment's forward flags (the saved copy) and stripe origins, relative to its workspace
 struct RestoreJob {
@@ -776,18 +721,6 @@ __global__ void __launch_bounds__(256) k_restore_stripe(const AlnDesc *__restric
     int32_t *bd = blo_all + d.blo_off;
     for (int k = tid; k < 2 * d.Lt; k += 256) bd[k] = bs[k];
 }
-// the fallback of the block-parallel sweep (k_fwdp_finish, pr_fwdpar.hip): only the launch positions whose flag is set
-__global__ void __launch_bounds__(64) k_fwd_stripe_only(DevBatch B, const AlnDesc *__restrict__ descs,
-                                                        const int32_t *__restrict__ work, uint8_t *__restrict__ ws,
-                                                        int32_t *__restrict__ blo_all, AlnOut *__restrict__ outs,
-                                                        const int32_t *__restrict__ only) {
-    if (!only[blockIdx.x]) return;
-    __builtin_amdgcn_s_setprio(2);
-    const int a = work[blockIdx.x];
-    const AlnDesc d = descs[a];
-    fwd_stripe_range<0>(B, d, a, ws, blo_all, outs, 0, (d.Lt + FS_K - 1) / FS_K, FwdParOut{nullptr, nullptr, nullptr, nullptr});
-}
-
 // ===========================================================================
 // K2s: striped banded backward max-TP sweep (W = 64), the mirror image of k_fwd_stripe: lanes are
 // reversed (lane l owns x = lo + 63 - l) so "x+1" is lane l-1 (DPP wave_shr:1) and the suffix composition of

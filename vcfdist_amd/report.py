@@ -148,3 +148,26 @@ def write_results(prefix, contigs, cmd="", file_date=None, credit_threshold=0.7)
     _check(L.vrp_write_variants((prefix + "truth.tsv").encode(), arr, n, 1), "vrp_write_variants")
     _check(L.vrp_write_summary_vcf((prefix + "summary.vcf").encode(), arr, n, cmd.encode(),
                                    file_date.encode() if file_date else None, credit_threshold), "vrp_write_summary_vcf")
+
+
+def write_parameters(prefix, args, cmd):
+    """parameters.txt (write_params, print.cpp:30-56): the run's settings, one `key = value` per line, in the reference's order and
+    formats (strings quoted, booleans true / false, the two thresholds and max_ram with %f).  Keys of stages this implementation
+    does not have keep the reference's defaults (realignment off, eval penalties 3 / 2 / 1, distance false, globals.h:41-59)."""
+    b2s = lambda b: "true" if b else "false"
+    L = api.lib()
+    L.vpr_version.restype = C.c_char_p
+    text = (
+        "program = '%s'\nversion = '%s'\nout_prefix = '%s'\ncommand = '%s'\nreference_fasta = '%s'\n"
+        "query_vcf = '%s'\ntruth_vcf = '%s'\nbed_file = '%s'\nwrite_outputs = %s\nfilters = '%s'\n"
+        "min_var_qual = %d\nmax_var_qual = %d\nmax_var_size = %d\nsv_threshold = %d\n"
+        "phase_threshold = %f\ncredit_threshold = %f\nrealign_truth = %s\nrealign_query = %s\n"
+        "realign_only = %s\ncluster_method = '%s'\ncluster_min_gap = %d\n"
+        "reach_min_gap = %d\nmax_cluster_itrs = %d\nmax_threads = %d\nmax_ram = %f\n"
+        "sub = %d\nopen = %d\nextend = %d\neval_sub = %d\neval_open = %d\neval_extend = %d\ndistance = %s" % (
+            "vcfdist_amd", L.vpr_version().decode(), prefix, cmd, args.fasta, args.query, args.truth, args.bed or "",
+            b2s(not args.no_output_files), args.filter, args.min_qual, args.max_qual, args.max_size, args.sv_threshold,
+            args.phase_threshold, args.credit_threshold, b2s(False), b2s(False), b2s(False), args.cluster, args.cluster_gap,
+            args.reach_min_gap, args.max_iterations, 64, 64.0, args.sub, args.open, args.extend, 3, 2, 1, b2s(False)))
+    with open(prefix + "parameters.txt", "w") as f:
+        f.write(text)
