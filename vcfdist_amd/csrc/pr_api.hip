@@ -2507,6 +2507,8 @@ namespace {
 // One vpr_execute call: the state its phases share and the phases themselves.  Round 0 (round0_windowed / run_dense), the
 // retry ladders (lad_start / lad_flush), the tie rounds (tie_round, tie_replay, tie_patch, spec_round), the final tie pass,
 // the deferred edit distances (K4) and the finalisation (K5) all enqueue on the handle's streams; run() is the sequence.
+const int SPEC_MAX_DIST = 256;       // largest distance of an alignment whose tie replay is started speculatively (spec_round)
+
 struct Exec {
     vpr_handle *h;
     hipStream_t st;
@@ -3698,7 +3700,18 @@ struct Exec {
         return VPR_OK;
     }
 
-    int spec_round(const int4 *lst, int32_t n) {
+    int spec_round(const int4 *lst_all, int32_t n_all) {
+        // A replay costs one dependent pass per WAVE of the reference's expansion, i.e. per unit of distance: a head start pays for
+        // the whole-genome batch's long chains (distance 8, nine waves), not for an alignment at distance 1 723 (a truth-only
+        // 1.7 kb insertion inside a tandem repeat, joint_synth: 1 724 waves, 27 ms for a replay whose tie was never consulted --
+        // and the step's tie round waits for the slowest speculative job).  Those wait for their backward sweep's verdict.
+        std::vector<int4> kept;
+        kept.reserve(size_t(n_all));
+        for (int32_t k = 0; k < n_all; k++)
+            if (lst_all[k].w <= SPEC_MAX_DIST) kept.push_back(lst_all[k]);
+        const int4 *lst = kept.data();
+        const int32_t n = int32_t(kept.size());
+        if (n == 0) return VPR_OK;
         LadderCtx &LT = h->lad[2];
         tie_ctx = &LT;
         spec_plan = Plan();
