@@ -47,387 +47,10 @@ extern "C" int vpr_batch_skeleton_from_variants(const vpr_variants *v, vpr_owned
 #include "pr_strip.hip"
 #include "pr_tie.hip"
 
-namespace {
-
-struct KernelClass { int nt, c, max_len; };
-// dense thread-chunk configurations: a plane of up to nt*c cells per row
-const KernelClass CLASSES[] = {
-    {64, 1, 64}, {64, 4, 256}, {256, 4, 1024}, {256, 8, 2048}, {1024, 8, 8192}, {1024, 16, 16384}, {1024, 32, 32768},
-    {1024, 32, 0x7fffffff},     // no one-workgroup kernel: column strips only (pr_strip.hip)
-};
-const int STRIP_CLS = 4;        // kernel classes from 1024 threads x 8 cells on (more than 2048 columns): column strips
-const int STRIP_ONLY_CLS = 7;
-const int N_CLASSES = sizeof(CLASSES) / sizeof(CLASSES[0]);
-const size_t LDS_MAX = 160 * 1024;
-// window levels an alignment climbs until its exit test passes: 16 cells (four alignments per wave, only
-// for alignments shorter than LONG_LT rows), 64, 256, 1024 cells (one wave per alignment), dense
-// LV_Z: 16 cells, zero-distance variant (accepts only alignments with s = 0); LV_Q16: 16 cells, general.
-// (enum LV_*: pr_device.h)
-const int LV_WINDOW[] = {16, 16, 64, 256, 1024, 0};   // window width = flag layout of the level
-const int LV_TAG[] = {8, 16, 64, 256, 1024, 0};       // value of band_ok / AlnDesc::band_pad that marks the level
-// truth rows from which an alignment is a latency chain
-// Alignments with LONG_LT truth rows or more are latency chains (rows are sequential): a batch holds a handful of them and
-// the longest bounds the step, so they start at LONG_LV, four waves per alignment (k_fwd_wide<4>: 0.45 us per row against
-// 1 us for the one-wave 64-cell kernels).  Everything shorter is throughput work for the lane / 16-cell kernels.
-// (Sending long alignments through the lane kernel and the 16-cell round first was measured on the SV and stress
-// workloads: no gain on the first -- what reaches the dense level there has s > 0 -- and 8x slower on the second, whose
-// rejects then climb the ladder in dozens of workspace-sized rounds.)
-const int LONG_LT = 1024;      // (2048 until round 4: the lane kernels' launches lasted as long as their longest waves, 2 047 rows of three dependent passes)
-const int LONG_LV = 2;    // LV_C1
-const int32_t CREDIT_WAVE_MAX = 16384;                // alignments of a launch up to which the credit walk takes a wavefront each
-const int64_t WSEG_MAX_ROWS = int64_t(4) << 20;      // truth rows of a launch up to which its walk runs over segments (pr_walkseg.hip)
-
-// std::vector whose resize() leaves trivially constructible elements uninitialised (the planner fills millions of
-// 96-byte descriptors from several threads; zero-filling them first costs as much as the fill)
-template <typename T>
-struct NoInitAlloc : std::allocator<T> {
-    template <typename U> struct rebind { using other = NoInitAlloc<U>; };
-    NoInitAlloc() = default;
-    template <typename U> NoInitAlloc(const NoInitAlloc<U> &) {}
-    template <typename U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }
-    template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
-};
-using DescVec = std::vector<AlnDesc, NoInitAlloc<AlnDesc>>;
-
-// fn(begin, end, thread) over [0, n) on up to PAR_MAX host threads (planning a batch of a million superclusters is a few
-// passes over 4 M descriptors: memory-latency bound on one core)
-const int PAR_MAX = 32;
-// (a pool that lives as long as the library: starting 32 threads per pass costs more than most passes, and with several
-// batches in flight on several handles the thread stacks' mmap / munmap calls serialise on the address space)
-class ParPool {
-  public:
-    static ParPool &get() { static ParPool *p = new ParPool(); return *p; }      // (never destroyed: no join at exit)
-    // run task(t) for t in [0, nt) on the workers and the calling thread
-    void run(size_t nt, const std::function<void(size_t)> &task) {
-        Job job;
-        job.task = &task; job.nt = nt;
-        {
-            std::lock_guard<std::mutex> g(m_);
-            jobs_.push_back(&job);
-        }
-        cv_.notify_all();
-        work_on(job);
-        std::unique_lock<std::mutex> g(m_);
-        job.done_cv.wait(g, [&] { return job.done == job.nt; });
-    }
-  private:
-    struct Job { const std::function<void(size_t)> *task; size_t nt = 0, next = 0, done = 0; std::condition_variable done_cv; };
-    // CPUs the process may use: the cgroup's quota where there is one (a container that sees 256 cores may be allowed 16:
-    // more runnable threads than that and the scheduler suspends the whole group for the rest of the period -- including
-    // the threads that feed the GPU)
-    static unsigned cpu_limit() {
-        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        long long quota = -1, period = 100000;
-        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-            char q[32] = {0};
-            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
-            fclose(f);
-        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
-            fclose(g);
-            if (FILE *p = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(p, "%lld", &period) != 1) period = 100000; fclose(p); }
-        }
-        if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, unsigned(std::max<long long>(1, quota / period)));
-        // one process per GPU on a node (torch.distributed.run exports the number of local ranks): they share the quota
-        if (const char *lw = getenv("LOCAL_WORLD_SIZE")) { const int n = atoi(lw); if (n > 1) hw = std::max(1u, hw / unsigned(n)); }
-        return hw;
-    }
-  public:
-    // detached workers beside the calling thread for a quota of `lim` CPUs: none when the quota is 1 - 3 (the unsigned
-    // `lim - max(2, lim / 4)` of round 3 wrapped around for lim = 1 and started 31)
-    static unsigned pool_workers(unsigned lim) {
-        const unsigned keep = std::max(2u, lim / 4);
-        return (lim > keep ? std::min<unsigned>(lim - keep, PAR_MAX) : 1u) - 1;
-    }
-  private:
-    ParPool() {
-        // (a quarter of the quota stays free for the callers themselves and the runtime's threads)
-        const unsigned n = pool_workers(cpu_limit());
-        for (unsigned t = 0; t < n; t++) std::thread([this] { worker(); }).detach();
-    }
-    void work_on(Job &job) {
-        for (;;) {
-            size_t t;
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (job.next >= job.nt) return;
-                t = job.next++;
-                if (job.next >= job.nt) jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job));
-            }
-            (*job.task)(t);
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (++job.done == job.nt) job.done_cv.notify_all();
-            }
-        }
-    }
-    void worker() {
-        for (;;) {
-            Job *job;
-            size_t t;
-            {   // (a task is claimed under the lock that found the job: a job with an unfinished task cannot go away)
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return !jobs_.empty(); });
-                job = jobs_.front();
-                t = job->next++;
-                if (job->next >= job->nt) jobs_.pop_front();
-            }
-            (*job->task)(t);
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (++job->done == job->nt) job->done_cv.notify_all();
-            }
-        }
-    }
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::deque<Job *> jobs_;
-};
-template <typename F>
-void par_for(size_t n, F fn) {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t nt = std::min<size_t>(std::min<unsigned>(hw, PAR_MAX), n / 32768);
-    if (nt <= 1) { fn(size_t(0), n, 0); return; }
-    const std::function<void(size_t)> task = [&](size_t t) { fn(n * t / nt, n * (t + 1) / nt, int(t)); };
-    ParPool::get().run(nt, task);
-}
-
-// base descriptors (no workspace layout) of the uploaded batch: computed on demand from host copies of its offsets
-struct BaseDescs {
-    std::vector<int64_t> hap_off[4], ref_off;
-    BatchOffsets O;
-    size_t n = 0;
-    void set(const vpr_batch *b, const std::vector<int64_t> *var_off) {      // var_off: the handle's copies
-        const size_t m = size_t(b->n_sc) + 1;
-        for (int s = 0; s < 4; s++) {
-            hap_off[s].assign(b->hap_off[s], b->hap_off[s] + m); O.hap_off[s] = hap_off[s].data();
-            O.var_off[s] = var_off[s].data();
-        }
-        ref_off.assign(b->ref_off, b->ref_off + m); O.ref_off = ref_off.data();
-        n = size_t(b->n_sc) * 4;
-    }
-    size_t size() const { return n; }
-    bool empty() const { return n == 0; }
-    void clear() { n = 0; }
-    AlnDesc operator[](size_t a) const { return base_desc(O, int64_t(a)); }
-    // the three lengths of alignment a alone (base_desc also sums variant offsets and places the section table: a planning
-    // pass over four million alignments only wants these)
-    void lens(size_t a, int32_t &Lq, int32_t &Lr, int32_t &Lt) const {
-        const size_t sc = a >> 2;
-        const int i = int(a & 3), qs = i >> 1, ts = 2 + (i & 1);
-        Lq = int32_t(O.hap_off[qs][sc + 1] - O.hap_off[qs][sc]);
-        Lt = int32_t(O.hap_off[ts][sc + 1] - O.hap_off[ts][sc]);
-        Lr = int32_t(O.ref_off[sc + 1] - O.ref_off[sc]);
-    }
-};
-
-struct Launch { int cls; int64_t work_off; int32_t count; };   // dense: one k_fwd/k_bwd launch of a class
-struct Chunk {
-    int64_t work_off = 0; int32_t count = 0;   // slice of the plan's work list
-    std::vector<Launch> launches;              // dense plans only
-    int64_t cells = 0, in_bytes = 0;           // touched cells / input bytes of the chunk
-    // windowed plans: the leading n_long long alignments get their own launch sequence (part 0)
-    int32_t n_long = 0;
-    int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}, part_rows[2] = {0, 0};
-};
-// a set of alignments with workspace offsets assigned, all at window level `lv` (a 16-cell plan holds its
-// long alignments, which start at LONG_LV, in front)
-struct Plan {
-    int lv = LV_DENSE;
-    DescVec descs;                  // compact, in work-list order (empty when `lazy`)
-    // lazy plan (round 0 of a windowed batch): the descriptors are a function of the batch offsets, the alignment and its
-    // workspace offset (pr_device.h: base_desc + window_layout); the host keeps 4 bytes per alignment, the device builds
-    // its copy from the same 4 bytes (k_build_plan), and plan_desc() below recomputes the few the host ever looks at
-    bool lazy = false;
-    std::vector<uint32_t> off128;   // workspace offset of every entry in 128-byte units (lazy plans)
-    int tag_or = 0, long_lt = 0;
-    std::vector<int32_t> work;      // alignment ids
-    std::vector<Chunk> chunks;
-    AlnDesc *d_descs = nullptr;     // device copy of `descs` (plan 0 only, cached)
-    int32_t *d_work = nullptr;
-    uint8_t *arena = nullptr;       // workspace the offsets refer to
-    int64_t arena_used = 0;         // bytes of it the largest chunk occupies
-    int64_t total_need = 0;         // bytes all chunks together would occupy
-};
-
-// a retry ladder's private resources (see vpr_execute)
-struct LadderCtx {
-    static const int N_SLOTS = 16;
-    hipStream_t ls = nullptr;
-    int slot0 = 0;                          // first of its N_SLOTS fail slots
-    int64_t fail_base = 0;                  // its region of the fail-list buffer
-    uint8_t *arena = nullptr; int64_t arena_bytes = 0;
-    int32_t *d_work = nullptr; size_t work_cap = 0;     // work lists of the plans in flight
-    AlnDesc *hp_descs = nullptr; int32_t *hp_work = nullptr; size_t hp_cap = 0;   // host-pinned source of k_stage
-    int slot_cur = 0; int64_t fail_cur = 0, arena_cur = 0; size_t stage_cur = 0;
-    std::vector<std::pair<int, int64_t>> pending;       // (slot, fail list offset) of the launches in flight
-    std::vector<Plan> plans;
-    // tie ladders only: a side stream for the early replays (they run beside the repeated forward sweep), the event that
-    // joins it back, and the replay scratch of each of the two streams (grown on demand, released with the batch)
-    hipStream_t ls2 = nullptr; hipEvent_t ev2 = nullptr;
-    uint32_t *tie_scratch[2] = {nullptr, nullptr}; int64_t tie_scratch_bytes[2] = {0, 0};
-    // bytes at the front of each scratch that are preset (filled at the start of vpr_execute, beside round 0, with as much
-    // as the previous execute's first launch used) and the size of that first launch
-    int64_t tie_clean[2] = {0, 0}, tie_first[2] = {0, 0}; bool tie_first_seen[2] = {false, false};
-};
-
-struct EvPair { hipEvent_t a, b; int kind; vpr_launch_stat st; };
-const int TIE_DEC_SLOTS = 64;     // early-replay launches per execute that can keep a decision list
-
-}  // namespace
-
-struct vpr_handle {
-    vpr_config cfg;
-    std::string err;
-    bool debug = false;                  // VPR_DEBUG in the environment at vpr_create: progress lines on stderr
-    // host-side cost of the current / last vpr_execute: allocator calls and blocking waits (vpr_timing reports them; with
-    // VPR_STALL_LOG in the environment every such call that takes more than 5 ms is printed with its site)
-    bool soft_alloc = false;            // the allocation under way is optional growth (x_malloc: larger reserve)
-    struct HostStat {
-        int64_t n_dev_alloc = 0, n_dev_free = 0, n_pin_alloc = 0;
-        double ms_alloc = 0, ms_sync = 0, ms_idle_max = 0;
-    } hs;
-    bool stall_log = false;
-    hipStream_t stream = nullptr;
-    hipStream_t cls_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    // batch-lifetime device allocations: pool blocks, carved by dev_alloc.  Released blocks are KEPT (dev_cache / pin_cache)
-    // and handed out again by the next upload: hipFree of a used multi-GB block takes seconds and page-locking host memory
-    // runs at ~6 GB/s, which is most of what a re-upload into a used handle cost
-    struct Blk { void *p; size_t bytes; };
-    std::vector<Blk> dev_cache, pin_cache, pinned_blk;
-    std::vector<Blk> parked;             // device blocks outgrown during an execute: to dev_cache when the batch is released
-    int64_t dev_total = 0;               // the device's memory (vpr_create)
-    int64_t tie_scratch_max = 0, lad_arena_max = 0;   // bounds of the replay scratches / ladder workspaces that grow on demand
-    // The batch's memory plan (vpr_upload): of the device memory free at that point the library leaves mem_reserve alone,
-    // round 0's workspace takes what its plan asks for (at most arena_share() of the rest), and what remains is split
-    // between the ladders' workspaces and the replay scratches, which start small and grow on demand inside their halves.
-    int64_t mem_reserve = 0, lad_budget = 0, tie_budget = 0, lad_bytes = 0, tie_bytes = 0;
-    // what each ladder's workspace had grown to when the last batch was released, as a fraction of that batch's round-0 need:
-    // the next batch's ladders start there instead of growing during its first execute
-    double lad_hw[4] = {0, 0, 0, 0}; int64_t want0 = 0;
-    std::vector<size_t> alloc_bytes;     // sizes of `allocs`
-    std::vector<void *> allocs;
-    uint8_t *pool_cur = nullptr;         // bump pointer into the newest block
-    size_t pool_left = 0, pool_next = size_t(16) << 20;   // block sizes double up to 2 GiB (a batch needs ~150 arrays)
-    DevBatch dB;
-    // host mirrors needed for planning / finalisation
-    int32_t n_sc = 0;
-    uint8_t *d_alias = nullptr;          // [superclusters] alias bits (k_hap_alias), all 0 without VPR_CFG_HAP_DEDUP
-    std::vector<uint8_t> alias;          // host copy
-    int64_t n_aliased = 0;               // alignments of the batch that are copies of another one
-    int32_t n_limit_sc = 0;              // nonzero: some supercluster of the batch is marked in DevBatch::sc_limit
-    std::vector<int64_t> var_off[4];
-    std::vector<float> var_qual[4];
-    int64_t n_var[4] = {0, 0, 0, 0};
-    BaseDescs descs;                     // base descriptors (no workspace offsets)
-    std::vector<int32_t> scratch_i32[4]; // planner scratch that keeps its pages across uploads
-    // device blocks with the lifetime of one execute (the strip tables and boundary columns of the wide dense sweeps,
-    // pr_strip.hip): taken from the batch's allocations, handed out again by the next execute
-    struct ExecBlk { uint8_t *p; size_t bytes; bool used; };
-    std::vector<ExecBlk> exec_blks, exec_pins;
-    bool no_strips = false;              // VPR_NO_STRIPS in the environment: wide alignments stay in one workgroup
-    uint8_t *d_save = nullptr;           // second copy of the forward flags of round 0's long part (k_fwd_stripe_save), nullptr: none
-    int64_t save_bytes = 0;
-    bool no_flag_save = false;           // VPR_NO_FLAG_SAVE: tie rounds of the long part repeat the forward sweep
-    bool seq_walk = false;               // VPR_SEQ_WALK: the sequential row-sweep walk instead of the segment-parallel one
-    bool no_round_overlap = false;       // VPR_NO_ROUND_OVERLAP: a retry round is complete before the host looks at its fail lists
-    std::vector<uint32_t> scratch_u32[2];
-    Plan plan0;                          // first round over all alignments, cached at upload
-    std::vector<uint8_t> level, level0;  // current / round-0 window level of every alignment
-    int64_t last_need = 0;               // workspace bytes of the alignment make_plan could not place
-    uint8_t *d_cls[4] = {nullptr, nullptr, nullptr, nullptr};   // SNP / INDEL / SV class of every variant (vpr_upload_var_class)
-    int2 *hp_dspan[4] = {nullptr, nullptr, nullptr, nullptr};   // host copy of DevBatch::dspan (page-locked)
-    uint8_t *res_dev = nullptr; size_t res_bytes = 0;           // the device region of the result columns (vpr_upload)
-    uint8_t *res_mirror = nullptr;                              // the caller's block that mirrors it (vpr_results_alloc), if any
-    unsigned long long *d_hist = nullptr;   // vpr_pr_counts: histogram words (batch lifetime, grown on demand)
-    size_t hist_cap = 0;
-    int32_t *d_pb = nullptr;                // vpr_pr_counts: the caller's phase-block phasing per supercluster
-    std::vector<int32_t> dirty;          // alignments whose device descriptor was overwritten by a retry round
-    // device side
-    AlnDesc *d_descs = nullptr;
-    AlnOut *d_outs = nullptr;
-    uint8_t *d_arena = nullptr; int64_t arena_bytes = 0;      // workspace of the round-0 plan
-    LadderCtx lad[4];                                         // two retry ladders, two tie ladders (long / short part of round 0;
-                                                              // own workspaces, beside the arena)
-    hipEvent_t ev_slot[2 + 4 * LadderCtx::N_SLOTS] = {};      // "fail list of slot k is complete"
-    hipStream_t tie_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // tie ladder k: [2k] main, [2k+1] early replays (high priority)
-    hipEvent_t ev_tie2[2] = {nullptr, nullptr};
-    hipEvent_t ev_side[2] = {nullptr, nullptr};               // retry ladder k: "the forward sweeps of the round are enqueued"
-    hipEvent_t ev_tie[2] = {nullptr, nullptr};                // "the tie list of the long / short part of round 0 is published"
-    // plans of the last execute in launch order (the last one that holds an alignment has its final walk); second = the
-    // plan's workspace, nullptr once that workspace has been reused
-    std::vector<std::pair<std::vector<int32_t>, uint8_t *>> resident;
-    // the last chunk of the round-0 plan, whose walks are still in the round-0 workspace: a view into plan0.work (searched
-    // last: a later plan of an alignment holds its final walk)
-    int64_t res0_off = 0; int32_t res0_cnt = 0;
-    Section *d_secs = nullptr; int64_t n_secs_cap = 0;
-    int32_t *d_fp[4] = {nullptr, nullptr, nullptr, nullptr};
-    int32_t **d_fp_table = nullptr;
-    EdJob *d_jobs = nullptr; int32_t jobs_cap = 0; int32_t *d_njobs = nullptr;
-    uint32_t *d_err = nullptr;
-    int32_t *d_fail = nullptr, *d_cnt = nullptr;   // fail lists + their counters
-    // tie pass (pr_tie.hip): list of marked alignments {id, level tag}, counters {marked, replay overflows}, the jobs of
-    // the replay launches (host-pinned, read by the kernel directly) and the replay scratch (grown on demand)
-    int4 *d_tie_list = nullptr, *hp_tie_list = nullptr; int32_t tie_list_cap = 0;   // {alignment, level tag, consulted ties, 0}
-    // completion flags in host-pinned memory, written by one-thread kernels behind the work they stand for: the host
-    // polls plain memory instead of HIP events (hipEventQuery in a tight loop delays the very submissions it waits for)
-    int32_t *hp_flag = nullptr; int32_t flag_seq = 0;
-    int32_t *d_tie_cnt = nullptr, *hp_tie_cnt = nullptr;     // [0] final pass, [1] replay overflows, [2] long part, [3] short part,
-                                                             // [4] speculative candidates of the long part
-    hipEvent_t ev_spec = nullptr;                            // the speculative replays of the long part are done
-    TieJob *hp_tie_jobs = nullptr; size_t tie_jobs_cap = 0;
-    int4 *d_tie_dec = nullptr; int64_t tie_dec_cap = 0;       // decision lists of the early replays (one region per launch)
-    int32_t *d_tie_ndec = nullptr;                            // their lengths [TIE_DEC_SLOTS]
-    std::vector<int32_t> plan0_pos;                           // position of every alignment in plan0's work list
-    // zero-distance lane kernel (pr_zl.hip): per-wave headers, the wave-interleaved position words (batch lifetime, written
-    // once by k_prep_zl) and the log blocks (shared by the chunks of plan 0, which run one after the other)
-    ZlWave *d_zl_hdr = nullptr; uint32_t *d_zl_in = nullptr; uint4 *d_zl_log = nullptr;
-    std::vector<int64_t> zl_wave0;                            // first wave of every chunk of plan 0
-    // distance-1 lane kernel (pr_d1.hip): headers, position words and log of the waves of zero-level rejects (sized on the device
-    // per execute, within these blocks), the list of what it leaves to the in-place 16-cell round and {waves used, waves dropped,
-    // length of that list}
-    ZlWave *d_d1_hdr = nullptr; uint32_t *d_d1_in = nullptr; uint4 *d_d1_log = nullptr; int32_t *d_d1_fail = nullptr, *d_d1_info = nullptr;
-    int32_t *d_d1_blk = nullptr;                              // per-workgroup counts / offsets of the ordered fail lists (k_fails_*)
-    hipEvent_t ev_offsets = nullptr;                          // upload: the batch's offsets are on the device (plan0_device waits for it)
-    hipEvent_t ev_cred[2] = {nullptr, nullptr};               // the lane levels' credit walks on a side stream: fork / join
-    bool side_credit = true;                                  // (VPR_NO_SIDE_CREDIT: behind the 16-cell round on the part's stream, as until round 4)
-    // what the upload's one host pass over the superclusters found for round 0's plan (plan0_device): the parts' sums, the total
-    // workspace need in 128-byte units, the long alignments (-matrix bytes, alignment), "some alignment cannot be placed"
-    struct Plan0Pass {
-        bool valid = false, bad = false;
-        int64_t part_cells[2] = {0, 0}, part_in[2] = {0, 0}, part_dense[2] = {0, 0}, part_rows[2] = {0, 0}, need128 = 0, need_max = 0;
-        std::vector<std::pair<int64_t, int32_t>> big;
-    } p0;
-    int64_t d1_in_cap = 0, d1_log_cap = 0;
-    int32_t d1_wave_cap = 0, d1_fail_cap = 0;
-    int32_t d1_max_rows = 256;                                // rejects of more truth rows stay with the 16-cell kernels (VPR_D1_MAX_ROWS)
-    std::vector<ZlWave> zl_hdr_host;
-    int32_t long_lt = LONG_LT;                                // rows from which an alignment belongs to the long part of plan 0
-    // vpr_upload_variants: the variant tables of the batch being uploaded (the device generates the Level A arrays from
-    // them, pr_gen.hip), and the contig sequence of the previous upload, which stays resident as long as the caller keeps
-    // passing the same one (a whole-genome run uploads a contig once, not once per batch)
-    const vpr_variants *gen_src = nullptr;
-    uint8_t *d_ctg_seq = nullptr; const uint8_t *ctg_src = nullptr; int64_t ctg_bytes = 0; uint64_t ctg_probe = 0;
-    // host-pinned, device-visible mirrors of d_fail / d_cnt: a publish kernel on the producing stream fills them, so the
-    // host reads a fail list after an event wait and issues no copy that the bulk kernels of the round could starve
-    int32_t *hp_fail = nullptr, *hp_cnt = nullptr;
-    std::vector<void *> pinned;
-    int32_t *d_ed_scratch = nullptr; size_t ed_scratch_ints = 0;
-    int64_t ed_max_len = -1;                               // longest ref / truth string of the batch (-1: not looked at yet)
-    std::vector<EvPair> events;
-    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;   // timing events, reused by every execute
-    std::vector<hipStream_t> pad_streams;                  // (diagnostic, VPR_STREAM_PAD)
-    int zl_lds_bytes = 0;                // (diagnostic, VPR_ZL_LDS_KB) LDS the zero level's waves ask for and never touch: caps how many of them a compute unit holds
-    int lane_prio_rows = 256;            // waves of the lane levels with at least this many rows issue ahead of the others (k_zero_lane; a quarter for k_one_lane)
-    DevResults dR;                       // final results, produced on the device
-    vpr_timing timing;
-    bool uploaded = false, executed = false;
-};
+#include "pr_host.h"
 
 namespace {
 
-std::string g_create_err;
 
 // window level an alignment has in a plan of level lv (a 16-cell plan holds its long alignments at LONG_LV)
 inline int plan_level_of(int lv, int long_lt, int Lt) { return (lv <= LV_Q16 && Lt >= long_lt) ? LONG_LV : lv; }
@@ -538,363 +161,6 @@ __global__ void __launch_bounds__(1024) k_zl_scan(ZlWave *__restrict__ hdr, int 
     if (tid == 1023) { totals[0] = s_in[1023]; totals[1] = s_log[1023]; totals[2] = s_len; }
 }
 
-int fail(vpr_handle *h, int code, const char *fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    if (h) h->err = buf; else g_create_err = buf;
-    return code;
-}
-
-#define HIPCHK(h, call)                                                                         \
-    do {                                                                                        \
-        hipError_t e_ = (call);                                                                 \
-        if (e_ != hipSuccess)                                                                   \
-            return fail(h, VPR_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-inline double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-inline void slow_call(vpr_handle *h, const char *what, const char *site, size_t bytes, double dt) {
-    if (h && h->stall_log && dt > 5.0) fprintf(stderr, "[vpr] slow host call: %s (%zu bytes) at %s: %.1f ms\n", what, bytes, site, dt);
-}
-// every allocator call and blocking wait of the library goes through these: counted and timed per execute
-// Switches of experiments that are closed (DESIGN.md section 6 has each one's measurement: stream priorities and padding, the zero
-// level's occupancy cap, the credit walk's head, the replay's wide jobs, the shares of the memory plan ...): read only by a library
-// built with -DVPR_EXPERIMENTS (make CXXFLAGS+=-DVPR_EXPERIMENTS); the shipped build runs the settings those experiments chose.
-static const char *exp_getenv(const char *name) {
-#ifdef VPR_EXPERIMENTS
-    return getenv(name);
-#else
-    (void)name;
-    return nullptr;
-#endif
-}
-static int poison_byte() {
-    static const int v = [] { const char *e = getenv("VPR_POISON"); return e ? int(strtol(e, nullptr, 0)) & 0xff : -1; }();
-    return v;
-}
-// Device memory the library leaves alone (VPR_DEV_RESERVE_MB, default 1 536): the runtime allocates on its own behind the
-// library's back -- private (scratch) memory of kernels per hardware queue, hundreds of MB each for the walk and replay kernels --
-// and a queue that cannot get it is ABORTED (HSA_STATUS_ERROR_OUT_OF_RESOURCES, the process dies: 125 000 stress superclusters
-// with the long part from 2 048 rows ended that way, 38 MB free).  An allocation that would go below the reserve fails like an
-// exhausted device instead, which every caller handles (smaller workspaces and more rounds, sub-batches of replays, VPR_ERR_NOMEM).
-// (The default keeps what fitted before fitting: a GPU's share of the stress workload, 125 000 superclusters, ends with 2.4 GB free.
-// Its upload takes 278 of 309 GB -- round 0's workspace 60 % of the free memory, four ladder workspaces an eighth of the rest each --
-// and a single tied 16 k x 16 k alignment then wants 6.9 GB of replay stamps: the shares want planning from the batch)
-static int64_t dev_reserve_bytes() {
-    static const int64_t v = [] { const char *e = getenv("VPR_DEV_RESERVE_MB"); return (e ? int64_t(atoll(e)) : int64_t(1536)) << 20; }();
-    return v;
-}
-// The batch's memory plan: the share of the DEVICE the library leaves free (VPR_DEV_FREE_SHARE), and the share of the rest
-// round 0's workspace may take (VPR_ARENA_SHARE; it takes what its plan asks for when that is less).  What remains is the
-// ladders' and the replays' (vpr_upload).  VPR_LADDER_SHARE scales the ladders' first workspaces (diagnostic).
-static double free_share() { static const double v = [] { const char *e = getenv("VPR_DEV_FREE_SHARE"); return e ? atof(e) : 0.11; }(); return v; }
-static double arena_share() { static const double v = [] { const char *e = exp_getenv("VPR_ARENA_SHARE"); return e ? atof(e) : 0.7; }(); return v; }
-static double ladder_share() { static const double v = [] { const char *e = exp_getenv("VPR_LADDER_SHARE"); return e ? atof(e) : 1.0; }(); return v; }
-// The process's own books of device memory (all handles): what the library holds, and what it has handed back in the last
-// seconds.  hipMemGetInfo lags behind large hipFree calls -- a handle that has just released 250 GB of kept blocks was told
-// "51 GB free" 15 ms later and planned its next batch for a device a third the size --, so the
-// memory plan adds what the books say was freed recently, up to what the books say can be free at all (books_free).
-struct DevBooks {
-    std::mutex mu;
-    std::unordered_map<void *, size_t> blocks;
-    int64_t live = 0;                                   // bytes of hipMalloc'ed blocks of this process's handles
-    int64_t foreign0 = -1;                              // what others held when the first plan was made (torch, other processes)
-    std::deque<std::pair<double, int64_t>> freed;       // (time, bytes) of the frees of the last seconds
-    void add(void *q, size_t b) { std::lock_guard<std::mutex> g(mu); blocks[q] = b; live += int64_t(b); }
-    bool sub(void *q) {
-        std::lock_guard<std::mutex> g(mu);
-        auto it = blocks.find(q);
-        if (it == blocks.end()) return false;
-        live -= int64_t(it->second);
-        freed.emplace_back(wall_ms(), int64_t(it->second));
-        blocks.erase(it);
-        return true;
-    }
-    // free bytes the plan may count on, given the driver's figure
-    int64_t books_free(int64_t reported_free, int64_t total, double window_ms = 20000.0) {
-        std::lock_guard<std::mutex> g(mu);
-        const double now = wall_ms();
-        while (!freed.empty() && now - freed.front().first > window_ms) freed.pop_front();
-        int64_t recent = 0;
-        for (const auto &f : freed) recent += f.second;
-        if (foreign0 < 0) foreign0 = std::max<int64_t>(total - reported_free - live - recent, 0);
-        const int64_t by_books = total - live - foreign0;
-        return std::max(reported_free, std::min(reported_free + recent, by_books));
-    }
-};
-static DevBooks &dev_books(int dev = -1) {      // one set of books per device (-1: the calling thread's current device)
-    static DevBooks b[16];
-    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
-    return b[dev & 15];
-}
-
-hipError_t x_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
-    const double t = wall_ms();
-    {
-        size_t fr = 0, tt = 0;
-        // optional growth during an execute (a ladder's larger workspace, a replay scratch that would hold a whole launch instead of
-        // sub-batches) leaves a 32nd of the device to what an execute MUST still get (the replay stamps of one large tied alignment)
-        // (the reserve is about workspaces, arenas and their growth: a small array of an upload -- offsets, counters, lists -- is
-        // neither what exhausts the device nor worth a hipMemGetInfo call each; on a device shared with other handles such an
-        // array used to fail with less than the reserve free)
-        int64_t reserve = bytes >= (size_t(64) << 20) || (h && h->soft_alloc) ? dev_reserve_bytes() : 0;
-        if (reserve > 0 && hipMemGetInfo(&fr, &tt) == hipSuccess) {
-            if (h && h->soft_alloc) reserve = std::max<int64_t>(reserve, std::max<int64_t>(int64_t(tt) / 32, h->mem_reserve));
-        }
-        if (reserve > 0 && tt > 0 && int64_t(fr) < int64_t(bytes) + reserve &&
-            int64_t(bytes) + reserve < int64_t(tt)) {       // (a device smaller than the reserve: no reserve)
-            if (h) h->hs.n_dev_alloc++;
-            *q = nullptr;
-            return hipErrorOutOfMemory;
-        }
-    }
-    const hipError_t e = hipMalloc(q, bytes);
-    const double dt = wall_ms() - t;
-    if (e == hipSuccess) dev_books().add(*q, bytes);
-    if (h) { h->hs.n_dev_alloc++; h->hs.ms_alloc += dt; }
-    slow_call(h, "hipMalloc", site, bytes, dt);
-    // debugging aid (VPR_POISON=<byte>): new device memory holds that byte instead of whatever the driver left there, so that
-    // a read of something never written shows up the same way in every run
-    if (e == hipSuccess && poison_byte() >= 0) { (void)hipMemset(*q, poison_byte(), bytes); (void)hipDeviceSynchronize(); }
-    return e;
-}
-hipError_t x_free(vpr_handle *h, void *q, const char *site) {
-    const double t = wall_ms();
-    const hipError_t e = hipFree(q);
-    const double dt = wall_ms() - t;
-    if (!dev_books().sub(q))
-        for (int dv = 0; dv < 16 && !dev_books(dv).sub(q); dv++) {}
-    if (h) { h->hs.n_dev_free++; h->hs.ms_alloc += dt; }
-    slow_call(h, "hipFree", site, 0, dt);
-    return e;
-}
-hipError_t x_host_malloc(vpr_handle *h, void **q, size_t bytes, const char *site) {
-    const double t = wall_ms();
-    const hipError_t e = hipHostMalloc(q, bytes, hipHostMallocDefault);
-    const double dt = wall_ms() - t;
-    if (h) { h->hs.n_pin_alloc++; h->hs.ms_alloc += dt; }
-    slow_call(h, "hipHostMalloc", site, bytes, dt);
-    if (e == hipSuccess && poison_byte() >= 0) memset(*q, poison_byte(), bytes);
-    return e;
-}
-hipError_t x_sync(vpr_handle *h, hipStream_t s_, const char *site) {
-    const double t = wall_ms();
-    const hipError_t e = hipStreamSynchronize(s_);
-    const double dt = wall_ms() - t;
-    if (h) h->hs.ms_sync += dt;
-    slow_call(h, "hipStreamSynchronize", site, 0, dt);
-    return e;
-}
-hipError_t x_event_sync(vpr_handle *h, hipEvent_t ev, const char *site) {
-    const double t = wall_ms();
-    const hipError_t e = hipEventSynchronize(ev);
-    const double dt = wall_ms() - t;
-    if (h) h->hs.ms_sync += dt;
-    slow_call(h, "hipEventSynchronize", site, 0, dt);
-    return e;
-}
-#define SITE_STR2(x) #x
-#define SITE_STR(x) SITE_STR2(x)
-#define SITE __FILE__ ":" SITE_STR(__LINE__)
-
-// a device block of at least `bytes` bytes: a kept one that is not wastefully larger, else a new allocation
-void *dev_block(vpr_handle *h, size_t bytes, hipError_t *err) {
-    *err = hipSuccess;
-    int best = -1;
-    for (size_t k = 0; k < h->dev_cache.size(); k++) {
-        const size_t b = h->dev_cache[k].bytes;
-        if (b >= bytes && b <= bytes + bytes / 2 + (size_t(64) << 20) && (best < 0 || b < h->dev_cache[size_t(best)].bytes)) best = int(k);
-    }
-    void *q = nullptr;
-    size_t got = bytes;
-    if (best >= 0) {
-        q = h->dev_cache[size_t(best)].p; got = h->dev_cache[size_t(best)].bytes;
-        h->dev_cache.erase(h->dev_cache.begin() + best);
-        if (poison_byte() >= 0) { (void)hipMemset(q, poison_byte(), got); (void)hipDeviceSynchronize(); }
-    } else {
-        *err = x_malloc(h, &q, bytes, SITE);
-        if (*err != hipSuccess) {        // out of memory with blocks kept aside: release them and try once more
-            for (auto &c : h->dev_cache) (void)x_free(h, c.p, SITE);
-            h->dev_cache.clear();
-            (void)hipGetLastError();
-            *err = x_malloc(h, &q, bytes, SITE);
-            if (*err != hipSuccess) return nullptr;
-        }
-    }
-    h->allocs.push_back(q);
-    h->alloc_bytes.push_back(got);
-    return q;
-}
-
-// page-locked host memory of the batch's lifetime (h->pinned_blk), from the kept blocks when one fits
-int pin_alloc(vpr_handle *h, void **out, size_t bytes) {
-    bytes = bytes ? bytes : 1;
-    int best = -1;
-    for (size_t k = 0; k < h->pin_cache.size(); k++) {
-        const size_t b = h->pin_cache[k].bytes;
-        if (b >= bytes && b <= 2 * bytes + (size_t(1) << 20) && (best < 0 || b < h->pin_cache[size_t(best)].bytes)) best = int(k);
-    }
-    if (best >= 0) {
-        *out = h->pin_cache[size_t(best)].p;
-        if (poison_byte() >= 0) memset(*out, poison_byte(), h->pin_cache[size_t(best)].bytes);
-        h->pinned_blk.push_back(h->pin_cache[size_t(best)]);
-        h->pin_cache.erase(h->pin_cache.begin() + best);
-        return VPR_OK;
-    }
-    void *q = nullptr;
-    const hipError_t e = x_host_malloc(h, &q, bytes, SITE);
-    if (e != hipSuccess) return fail(h, VPR_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-    h->pinned_blk.push_back(vpr_handle::Blk{q, bytes});
-    *out = q;
-    return VPR_OK;
-}
-
-template <typename T>
-int dev_alloc(vpr_handle *h, T **p, size_t n) {
-    *p = nullptr;
-    if (n == 0) n = 1;
-    const size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
-    if (h->cfg.flags & VPR_CFG_GUARD_ALLOC) {      // debugging aid: every array its own allocation (an access far behind one faults)
-        void *q = nullptr;
-        hipError_t e = x_malloc(h, &q, bytes, SITE);
-        if (e != hipSuccess) return fail(h, VPR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-        h->allocs.push_back(q);
-        h->alloc_bytes.push_back(0);     // (0: not kept for reuse)
-        *p = static_cast<T *>(q);
-        return VPR_OK;
-    }
-    if (bytes > h->pool_left) {
-        // a new block: the request alone when it is large (the remainder of the old block stays usable for nothing: blocks
-        // double, so at most half of what was allocated is ever lost), else the next pool size
-        const size_t blk = std::max(bytes, h->pool_next);
-        hipError_t e;
-        void *q = dev_block(h, blk, &e);
-        if (!q) return fail(h, VPR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", blk, hipGetErrorString(e));
-        if (bytes >= h->pool_next) {        // dedicated block; keep carving the previous one
-            *p = static_cast<T *>(q);
-            return VPR_OK;
-        }
-        h->pool_cur = static_cast<uint8_t *>(q);
-        h->pool_left = blk;
-        h->pool_next = std::min(h->pool_next * 2, size_t(2) << 30);
-    }
-    *p = reinterpret_cast<T *>(h->pool_cur);
-    h->pool_cur += bytes;
-    h->pool_left -= bytes;
-    return VPR_OK;
-}
-
-template <typename T>
-int dev_upload(vpr_handle *h, const T **dst, const T *src, size_t n) {
-    T *p;
-    int rc = dev_alloc(h, &p, n);
-    if (rc) return rc;
-    if (n && src) HIPCHK(h, hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));   // (null: filled on the device)
-    *dst = p;
-    return VPR_OK;
-}
-
-int exec_alloc(vpr_handle *h, void **out, size_t bytes) {
-    bytes = std::max<size_t>((bytes + 255) & ~size_t(255), 256);
-    int best = -1;
-    for (size_t k = 0; k < h->exec_blks.size(); k++) {
-        const auto &b = h->exec_blks[k];
-        if (!b.used && b.bytes >= bytes && (best < 0 || b.bytes < h->exec_blks[size_t(best)].bytes)) best = int(k);
-    }
-    if (best < 0) {
-        uint8_t *q = nullptr;
-        const int rc = dev_alloc(h, &q, bytes);
-        if (rc) return rc;
-        h->exec_blks.push_back(vpr_handle::ExecBlk{q, bytes, false});
-        best = int(h->exec_blks.size()) - 1;
-    }
-    h->exec_blks[size_t(best)].used = true;
-    *out = h->exec_blks[size_t(best)].p;
-    return VPR_OK;
-}
-
-// page-locked host memory with the lifetime of one execute (strip planning tables, the selection list of the deferred edit
-// distances): blocks of the batch's, handed out again by the next execute
-int exec_pin(vpr_handle *h, void **out, size_t bytes) {
-    bytes = std::max<size_t>((bytes + 255) & ~size_t(255), 256);
-    int best = -1;
-    for (size_t k = 0; k < h->exec_pins.size(); k++) {
-        const auto &b = h->exec_pins[k];
-        if (!b.used && b.bytes >= bytes && (best < 0 || b.bytes < h->exec_pins[size_t(best)].bytes)) best = int(k);
-    }
-    if (best < 0) {
-        void *q = nullptr;
-        const int rc = pin_alloc(h, &q, bytes + bytes / 2);
-        if (rc) return rc;
-        h->exec_pins.push_back(vpr_handle::ExecBlk{static_cast<uint8_t *>(q), bytes + bytes / 2, false});
-        best = int(h->exec_pins.size()) - 1;
-    }
-    h->exec_pins[size_t(best)].used = true;
-    *out = h->exec_pins[size_t(best)].p;
-    return VPR_OK;
-}
-
-void free_batch(vpr_handle *h) {
-    for (size_t k = 0; k < h->allocs.size(); k++) {
-        if (h->alloc_bytes[k]) h->dev_cache.push_back(vpr_handle::Blk{h->allocs[k], h->alloc_bytes[k]});
-        else (void)x_free(h, h->allocs[k], SITE);
-    }
-    h->allocs.clear(); h->alloc_bytes.clear();
-    while (h->dev_cache.size() > 96) {      // (a long run over batches of very different sizes: drop the smallest blocks)
-        size_t m = 0;
-        for (size_t k = 1; k < h->dev_cache.size(); k++) if (h->dev_cache[k].bytes < h->dev_cache[m].bytes) m = k;
-        (void)x_free(h, h->dev_cache[m].p, SITE);
-        h->dev_cache.erase(h->dev_cache.begin() + long(m));
-    }
-    h->pool_cur = nullptr; h->pool_left = 0; h->pool_next = size_t(16) << 20;
-    h->exec_blks.clear();
-    h->exec_pins.clear();
-    for (void *p : h->pinned) (void)hipHostFree(p);
-    h->pinned.clear();
-    for (auto &b : h->pinned_blk) h->pin_cache.push_back(b);
-    h->pinned_blk.clear();
-    while (h->pin_cache.size() > 48) { (void)hipHostFree(h->pin_cache.front().p); h->pin_cache.erase(h->pin_cache.begin()); }
-    h->hp_fail = nullptr; h->hp_cnt = nullptr; h->hp_flag = nullptr;
-    for (int s = 0; s < 4; s++) h->hp_dspan[s] = nullptr;
-    h->res_dev = nullptr; h->res_bytes = 0; h->res_mirror = nullptr;     // (a mirror block belongs to the caller: it just stops matching)
-    h->events.clear();
-    h->descs.clear();
-    {
-        std::vector<int32_t> kw; std::vector<uint32_t> ko;
-        kw.swap(h->plan0.work); ko.swap(h->plan0.off128);
-        h->plan0 = Plan();
-        kw.clear(); ko.clear();
-        h->plan0.work.swap(kw); h->plan0.off128.swap(ko);
-    }
-    h->dirty.clear();
-    h->d_arena = nullptr; h->d_secs = nullptr;
-    for (int k = 0; k < 4; k++) h->d_cls[k] = nullptr;
-    h->d_hist = nullptr; h->hist_cap = 0; h->d_pb = nullptr;
-    for (int k = 0; k < 4; k++) {      // (the replay scratches are the handle's, not the batch's: they survive)
-        if (h->want0 > 0 && h->lad[k].arena_bytes > 0) h->lad_hw[k] = double(h->lad[k].arena_bytes) / double(h->want0);
-        LadderCtx keep;
-        for (int e = 0; e < 2; e++) {
-            keep.tie_scratch[e] = h->lad[k].tie_scratch[e]; keep.tie_scratch_bytes[e] = h->lad[k].tie_scratch_bytes[e];
-            keep.tie_first[e] = h->lad[k].tie_first[e];
-        }
-        h->lad[k] = keep;
-    }
-    for (auto &b : h->parked) h->dev_cache.push_back(b);     // (nothing is in flight when a batch is released)
-    h->parked.clear();
-    h->resident.clear();
-    h->res0_cnt = 0;
-    h->d_ed_scratch = nullptr; h->ed_scratch_ints = 0;
-    h->d_tie_list = nullptr; h->hp_tie_list = nullptr; h->tie_list_cap = 0; h->d_tie_cnt = nullptr; h->hp_tie_cnt = nullptr;
-    h->hp_tie_jobs = nullptr; h->tie_jobs_cap = 0;
-    h->d_tie_dec = nullptr; h->tie_dec_cap = 0; h->d_tie_ndec = nullptr; h->plan0_pos.clear();
-    h->d_zl_hdr = nullptr; h->d_zl_in = nullptr; h->d_zl_log = nullptr; h->zl_wave0.clear();
-    h->d_d1_hdr = nullptr; h->d_d1_in = nullptr; h->d_d1_log = nullptr; h->d_d1_fail = nullptr; h->d_d1_info = nullptr; h->d_d1_blk = nullptr;
-    h->d1_in_cap = h->d1_log_cap = 0; h->d1_wave_cap = h->d1_fail_cap = 0;
-    h->uploaded = h->executed = false;
-}
 
 int class_of(int len) {
     for (int k = 0; k < N_CLASSES; k++)
@@ -1208,13 +474,7 @@ __global__ void k_hap_alias(DevBatch B, uint8_t *__restrict__ bits) {
     if (same(2, 3)) r |= 2;
     bits[sc] = r;
 }
-// source of alignment i (0..3) of a supercluster with alias bits b, -1: it is computed itself
-__host__ __device__ inline int alias_source(int b, int i) {
-    const int q = i >> 1, t = i & 1;
-    const int qs = (b & 1) ? 0 : q, ts = (b & 2) ? 0 : t;
-    const int src = qs * 2 + ts;
-    return src == i ? -1 : src;
-}
+// (alias_source -- source of alignment i of a supercluster with alias bits b: pr_device.h)
 __global__ void k_alias_descs(BatchOffsets O, const uint8_t *__restrict__ bits, int n_sc, AlnDesc *__restrict__ descs) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= 4 * n_sc) return;
@@ -1757,16 +1017,10 @@ int plan0_device(vpr_handle *h, int lv0, hipEvent_t ev_off, bool *done) {
 }
 }  // namespace
 
-namespace {
-// page-locked result blocks handed out by vpr_results_alloc (base -> bytes), until vpr_host_free: vpr_download takes its
-// single-copy path only into one of these
-std::mutex g_result_blocks_m;
-std::unordered_map<void *, size_t> g_result_blocks;
-}  // namespace
 
 extern "C" {
 
-const char *vpr_last_error(const vpr_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+const char *vpr_last_error(const vpr_handle *h) { return h ? h->err.c_str() : vpr_create_error(); }
 
 /* The tie replay (pr_tie.hip) reproduces the iteration order of the reference's std::unordered_set from the bucket counts the
    container grows through.  Those counts are a property of the libstdc++ the REFERENCE would be built against on this machine
@@ -2253,7 +1507,7 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
     {   // (the driver's figure lags behind this process's own large frees: dev_books)
-        const int64_t fb = dev_books().books_free(int64_t(free_b), int64_t(total_b));
+        const int64_t fb = books_free(int64_t(free_b), int64_t(total_b));
         if (h->debug && fb != int64_t(free_b)) fprintf(stderr, "[vpr] memory plan: the driver reports %.1f GB free, the books %.1f\n", double(free_b) / 1e9, double(fb) / 1e9);
         free_b = size_t(fb);
     }
@@ -4382,436 +3636,5 @@ int vpr_execute(vpr_handle *h) {
 }
 
 int32_t vpr_test_pool_workers(int32_t cpu_quota) { return int32_t(ParPool::pool_workers(unsigned(std::max(cpu_quota, 1)))); }
-
-int vpr_get_launch_stats(const vpr_handle *h, vpr_launch_stat *out, int32_t cap) {
-    if (!h) return VPR_ERR_ARG;
-    const int32_t n = int32_t(h->events.size());
-    for (int32_t k = 0; k < n && k < cap && out; k++) out[k] = h->events[k].st;
-    return n;
-}
-
-int vpr_get_timing(const vpr_handle *h, vpr_timing *t) {
-    if (!h || !t) return VPR_ERR_ARG;
-    *t = h->timing;
-    return VPR_OK;
-}
-
-int vpr_download(vpr_handle *h, vpr_results *res) {
-    if (!h || !res) return VPR_ERR_ARG;
-    if (!h->executed) return fail(h, VPR_ERR_STATE, "vpr_download before vpr_execute");
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    const DevResults &R = h->dR;
-    const size_t na = h->descs.size(), n = size_t(h->n_sc);
-    hipStream_t st = h->stream;
-    // results were finalised on the device (k_finalize / k_phase_tally): plain copies into the caller's buffers, all
-    // enqueued before the one wait (page-locked destinations, vpr_host_alloc, are written by DMA at the link rate)
-    auto get = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
-        return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
-    };
-    // A block of vpr_results_alloc -- of this upload, or of an earlier upload of a batch of the same shape (a caller that streams
-    // batches of one size keeps its block: the columns lie at the same offsets) -- takes ONE copy: every pointer of *res has to
-    // sit where the device's column sits in the result region.
-    uint8_t *mirror = h->res_mirror;
-    if (!mirror && h->res_bytes && na && res->aln_dist) {
-        // (an inferred base counts only if it IS a block vpr_results_alloc handed out, alive and at least as large as the result
-        // region: a caller's own contiguous layout without the trailing padding, or a smaller block of an earlier upload, must
-        // not be overrun by the single copy)
-        uint8_t *cand = reinterpret_cast<uint8_t *>(res->aln_dist) - (reinterpret_cast<const uint8_t *>(R.aln_dist) - h->res_dev);
-        std::lock_guard<std::mutex> g(g_result_blocks_m);
-        const auto it = g_result_blocks.find(cand);
-        if (it != g_result_blocks.end() && it->second >= h->res_bytes) mirror = cand;
-    }
-    if (mirror && h->res_bytes) {
-        auto at = [&](const void *dst, const void *src) {
-            return static_cast<const uint8_t *>(dst) - mirror == static_cast<const uint8_t *>(src) - h->res_dev;
-        };
-        bool all = at(res->aln_dist, R.aln_dist) && at(res->aln_end_plane, R.aln_end_plane) && at(res->aln_beg_plane, R.aln_beg_plane) &&
-                   at(res->aln_status, R.aln_status) && at(res->sc_phase, R.sc_phase) && at(res->orig_phase_dist, R.orig_phase_dist) &&
-                   at(res->swap_phase_dist, R.swap_phase_dist);
-        for (int s = 0; s < 4 && all; s++)
-            for (int w = 0; w < 2; w++)
-                // (a hap slot without variants has columns of length 0: whatever address the caller's views carry matches)
-                all = all && (h->n_var[s] == 0 ||
-                      (at(res->errtype[s][w], R.v[s][w].errtype) && at(res->sync_group[s][w], R.v[s][w].sync_group) &&
-                      at(res->credit[s][w], R.v[s][w].credit) && at(res->ref_ed[s][w], R.v[s][w].ref_ed) &&
-                      at(res->query_ed[s][w], R.v[s][w].query_ed) && at(res->callq[s][w], R.v[s][w].callq)));
-        if (all) {
-            HIPCHK(h, get(mirror, h->res_dev, h->res_bytes));
-            HIPCHK(h, x_sync(h, st, SITE));
-            return VPR_OK;
-        }
-    }
-    if (na) {
-        HIPCHK(h, get(res->aln_dist, R.aln_dist, na * 4));
-        HIPCHK(h, get(res->aln_end_plane, R.aln_end_plane, na));
-        HIPCHK(h, get(res->aln_beg_plane, R.aln_beg_plane, na));
-        HIPCHK(h, get(res->aln_status, R.aln_status, na * 4));
-        HIPCHK(h, get(res->sc_phase, R.sc_phase, n * 4));
-        HIPCHK(h, get(res->orig_phase_dist, R.orig_phase_dist, n * 4));
-        HIPCHK(h, get(res->swap_phase_dist, R.swap_phase_dist, n * 4));
-    }
-    for (int s = 0; s < 4; s++) {
-        const size_t nv = size_t(h->n_var[s]);
-        for (int w = 0; w < 2; w++) {
-            HIPCHK(h, get(res->errtype[s][w], R.v[s][w].errtype, nv));
-            HIPCHK(h, get(res->sync_group[s][w], R.v[s][w].sync_group, nv * 4));
-            HIPCHK(h, get(res->credit[s][w], R.v[s][w].credit, nv * 4));
-            HIPCHK(h, get(res->ref_ed[s][w], R.v[s][w].ref_ed, nv * 4));
-            HIPCHK(h, get(res->query_ed[s][w], R.v[s][w].query_ed, nv * 4));
-            HIPCHK(h, get(res->callq[s][w], R.v[s][w].callq, nv * 4));
-        }
-    }
-    HIPCHK(h, x_sync(h, st, SITE));
-    return VPR_OK;
-}
-
-int vpr_results_alloc(vpr_handle *h, vpr_results *res, void **block) {
-    if (!h || !res || !block) return VPR_ERR_ARG;
-    if (!h->uploaded || !h->res_dev) return fail(h, VPR_ERR_STATE, "vpr_results_alloc before vpr_upload");
-    void *p = nullptr;
-    if (hipHostMalloc(&p, h->res_bytes, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(h, VPR_ERR_NOMEM, "vpr_results_alloc: %zu page-locked bytes", h->res_bytes);
-    }
-    uint8_t *m = static_cast<uint8_t *>(p);
-    const DevResults &R = h->dR;
-    auto mir = [&](const void *dev) { return m + (static_cast<const uint8_t *>(dev) - h->res_dev); };
-    res->aln_dist = reinterpret_cast<int32_t *>(mir(R.aln_dist));
-    res->aln_end_plane = reinterpret_cast<uint8_t *>(mir(R.aln_end_plane));
-    res->aln_beg_plane = reinterpret_cast<uint8_t *>(mir(R.aln_beg_plane));
-    res->aln_status = reinterpret_cast<uint32_t *>(mir(R.aln_status));
-    res->sc_phase = reinterpret_cast<int32_t *>(mir(R.sc_phase));
-    res->orig_phase_dist = reinterpret_cast<int32_t *>(mir(R.orig_phase_dist));
-    res->swap_phase_dist = reinterpret_cast<int32_t *>(mir(R.swap_phase_dist));
-    for (int s = 0; s < 4; s++)
-        for (int w = 0; w < 2; w++) {
-            res->errtype[s][w] = reinterpret_cast<uint8_t *>(mir(R.v[s][w].errtype));
-            res->sync_group[s][w] = reinterpret_cast<int32_t *>(mir(R.v[s][w].sync_group));
-            res->credit[s][w] = reinterpret_cast<float *>(mir(R.v[s][w].credit));
-            res->ref_ed[s][w] = reinterpret_cast<int32_t *>(mir(R.v[s][w].ref_ed));
-            res->query_ed[s][w] = reinterpret_cast<int32_t *>(mir(R.v[s][w].query_ed));
-            res->callq[s][w] = reinterpret_cast<float *>(mir(R.v[s][w].callq));
-        }
-    h->res_mirror = m;
-    { std::lock_guard<std::mutex> g(g_result_blocks_m); g_result_blocks[p] = h->res_bytes; }
-    *block = p;
-    return VPR_OK;
-}
-
-int vpr_select_device(int32_t device) {
-    return hipSetDevice(device) == hipSuccess ? VPR_OK : VPR_ERR_DEVICE;
-}
-
-void *vpr_host_alloc(size_t bytes) {
-    void *p = nullptr;
-    // (portable: usable by every device of the process; the allocation still initialises the calling thread's current
-    // device, which a multi-GPU process selects first with vpr_select_device)
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return p;
-}
-
-void vpr_host_free(void *p) {
-    if (p) {
-        { std::lock_guard<std::mutex> g(g_result_blocks_m); g_result_blocks.erase(p); }
-        (void)hipHostFree(p);
-    }
-}
-
-int vpr_get_tally(const vpr_handle *h, int64_t out[6]) {
-    if (!h || !out || !h->executed) return VPR_ERR_ARG;
-    unsigned long long t[6];
-    if (hipMemcpy(t, h->dR.tally, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) return VPR_ERR_DEVICE;
-    for (int k = 0; k < 6; k++) out[k] = int64_t(t[k]);
-    return VPR_OK;
-}
-
-// histogram of floor(callq) per (class, errtype) of the phasing each supercluster selects, for one hap slot;
-// privatised per workgroup in LDS (a few thousand bins, heavily contended), flushed once
-__global__ void __launch_bounds__(256) k_pr_hist(const int64_t *__restrict__ var_off, int n_sc, int64_t n_var,
-                          const uint8_t *__restrict__ cls, const int32_t *__restrict__ sc_phase,
-                          const int32_t *__restrict__ pb_phase, VarCols c0, VarCols c1, int callset, int min_qual,
-                          int max_qual, unsigned long long *__restrict__ hist /* [2][3 classes][3][nq + 1] */) {
-    extern __shared__ unsigned int blk[];      // [3][3][nq + 1]
-    const int nq = max_qual - min_qual + 1, nb = 9 * (nq + 1);
-    for (int k = threadIdx.x; k < nb; k += blockDim.x) blk[k] = 0;
-    __syncthreads();
-    const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (v < n_var) {
-        int lo = 0, hi = n_sc;   // supercluster of the variant: largest sc with var_off[sc] <= v
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (var_off[mid] <= v) lo = mid; else hi = mid; }
-        const int ph = sc_phase[lo];
-        const int swap = ph == VPR_PHASE_ORIG ? 0 : (ph == VPR_PHASE_SWAP ? 1 : (pb_phase ? (pb_phase[lo] != 0) : 0));
-        const VarCols &C = swap ? c1 : c0;
-        const int e = C.errtype[v];
-        if (e < 3) {                                         // ERRTYPE_UN etc.: skipped with a warning (print.cpp:374)
-            const float q = C.callq[v];
-            int b = (q < float(min_qual)) ? -1 : int(floorf(q)) - min_qual;   // last threshold index the variant counts at
-            if (b >= nq) b = nq - 1;
-            const int t = cls[v] > 2 ? 2 : cls[v];
-            // bin nq collects the variants that count at no threshold (callq < min_qual)
-            atomicAdd(&blk[(t * 3 + e) * (nq + 1) + (b < 0 ? nq : b)], 1u);
-        }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < nb; k += blockDim.x)
-        if (blk[k]) atomicAdd(&hist[size_t(callset) * nb + k], (unsigned long long)blk[k]);
-}
-
-int vpr_upload_var_class(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS]) {
-    if (!h || !var_class) return VPR_ERR_ARG;
-    if (!h->uploaded) return fail(h, VPR_ERR_STATE, "vpr_upload_var_class before vpr_upload");
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    for (int s = 0; s < VPR_HAPS; s++) {
-        if (!h->d_cls[s]) {
-            int rc = dev_alloc(h, &h->d_cls[s], size_t(h->n_var[s]));
-            if (rc) return rc;
-        }
-        if (h->n_var[s]) HIPCHK(h, hipMemcpyAsync(h->d_cls[s], var_class[s], size_t(h->n_var[s]), hipMemcpyHostToDevice, h->stream));
-    }
-    HIPCHK(h, x_sync(h, h->stream, SITE));
-    return VPR_OK;
-}
-
-}   // extern "C"
-
-namespace {
-// RCCL, resolved at run time: the symbols the process already has (a host that links librccl, PyTorch's copy in a Python
-// process: the communicator the caller passes belongs to that one), else librccl.so.1.  The library itself has no link-time
-// dependency on RCCL: a single-GPU caller never needs it.
-struct Rccl {
-    typedef int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
-    typedef int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t);
-    typedef const char *(*ErrStr)(int);
-    AllReduce all_reduce = nullptr;
-    AllGather all_gather = nullptr;
-    ErrStr err_str = nullptr;
-    std::string path;       // the library the functions come from ("" = the process's global symbols)
-    // the copy of RCCL this process has ALREADY MAPPED, if any (/proc/self/maps): PyTorch loads its own librccl.so with local
-    // visibility, so the global symbol table does not show it, and opening "librccl.so.1" by name beside it could bring a SECOND
-    // copy into the process -- a communicator created by one copy and used through the other's functions is a crash
-    static std::string mapped_rccl() {
-        std::string found;
-        if (FILE *f = fopen("/proc/self/maps", "r")) {
-            char line[4096];
-            while (fgets(line, sizeof(line), f)) {
-                const char *p = strchr(line, '/');
-                if (!p) continue;
-                std::string pth(p);
-                while (!pth.empty() && (pth.back() == '\n' || pth.back() == ' ')) pth.pop_back();
-                const size_t sl = pth.rfind('/');
-                if (pth.compare(sl + 1, 7, "librccl") == 0 && pth.find(".so") != std::string::npos) { found = pth; break; }
-            }
-            fclose(f);
-        }
-        return found;
-    }
-    static const Rccl &get() {
-        static Rccl r = [] {
-            Rccl x;
-            void *hd = nullptr;
-            const std::string mapped = mapped_rccl();
-            if (!mapped.empty()) {          // the copy that is there (RTLD_NOLOAD: a handle to it, never a new mapping)
-                hd = dlopen(mapped.c_str(), RTLD_NOW | RTLD_NOLOAD);
-                if (hd) x.path = mapped;
-            }
-            if (!hd && dlsym(RTLD_DEFAULT, "ncclAllReduce")) hd = RTLD_DEFAULT;        // a host that links RCCL itself
-            if (!hd) {
-                for (const char *name : {"librccl.so.1", "librccl.so"}) {
-                    hd = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-                    if (hd) { x.path = mapped_rccl(); if (x.path.empty()) x.path = name; break; }
-                }
-            }
-            if (hd) {
-                x.all_reduce = reinterpret_cast<AllReduce>(dlsym(hd, "ncclAllReduce"));
-                x.all_gather = reinterpret_cast<AllGather>(dlsym(hd, "ncclAllGather"));
-                x.err_str = reinterpret_cast<ErrStr>(dlsym(hd, "ncclGetErrorString"));
-            }
-            return x;
-        }();
-        return r;
-    }
-};
-const int RCCL_INT32 = 2, RCCL_UINT64 = 5, RCCL_SUM = 0;      // ncclDataType_t / ncclRedOp_t (rccl.h)
-
-__global__ void k_pack_phase(const int32_t *__restrict__ idx, const int32_t *__restrict__ sc_phase, const int32_t *__restrict__ orig,
-                             const int32_t *__restrict__ swap, int n, int4 *__restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) out[k] = make_int4(idx[k], sc_phase[k], orig[k], swap[k]);
-}
-}  // namespace
-
-extern "C" {
-
-int vpr_rccl_available(void) { return Rccl::get().all_reduce && Rccl::get().all_gather ? 1 : 0; }
-const char *vpr_rccl_library(void) { return Rccl::get().path.c_str(); }
-
-static int pr_counts_impl(vpr_handle *h, void *comm, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
-                          int32_t min_qual, int32_t max_qual, int64_t *counts) {
-    if (!h || !counts || max_qual < min_qual) return VPR_ERR_ARG;
-    if (comm && !Rccl::get().all_reduce) return fail(h, VPR_ERR_STATE, "no RCCL in this process (librccl.so.1 not found)");
-    if (!h->executed) return fail(h, VPR_ERR_STATE, "vpr_pr_counts before vpr_execute");
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    const int nq = max_qual - min_qual + 1;
-    const size_t nh = size_t(2) * 3 * 3 * size_t(nq + 1);
-    int rc;
-    if (nh > h->hist_cap) {
-        if ((rc = dev_alloc(h, &h->d_hist, nh))) return rc;
-        h->hist_cap = nh;
-    }
-    unsigned long long *d_hist = h->d_hist;
-    int32_t *d_pb = nullptr;
-    HIPCHK(h, hipMemsetAsync(d_hist, 0, nh * 8, h->stream));
-    if (pb_phase && h->n_sc) {
-        if (!h->d_pb && (rc = dev_alloc(h, &h->d_pb, size_t(h->n_sc)))) return rc;
-        d_pb = h->d_pb;
-        HIPCHK(h, hipMemcpyAsync(d_pb, pb_phase, size_t(h->n_sc) * 4, hipMemcpyHostToDevice, h->stream));
-    }
-    if (var_class) { int rc = vpr_upload_var_class(h, var_class); if (rc) return rc; }
-    for (int s = 0; s < VPR_HAPS; s++) {
-        const int64_t nv = h->n_var[s];
-        if (!nv) continue;
-        if (!h->d_cls[s]) return fail(h, VPR_ERR_STATE, "vpr_pr_counts: no variant classes (pass var_class or call vpr_upload_var_class)");
-        hipLaunchKernelGGL(k_pr_hist, dim3(unsigned((nv + 255) / 256)), dim3(256), size_t(9) * (nq + 1) * 4, h->stream,
-                           h->dB.var_off[s], h->n_sc, nv, h->d_cls[s], h->dR.sc_phase, d_pb, h->dR.v[s][0], h->dR.v[s][1],
-                           s >> 1, min_qual, max_qual, d_hist);
-    }
-    if (comm) {     // the one collective of the path: the histogram words summed over the ranks, in place on the device
-        const int e = Rccl::get().all_reduce(d_hist, d_hist, nh, RCCL_UINT64, RCCL_SUM, comm, h->stream);
-        if (e) return fail(h, VPR_ERR_DEVICE, "ncclAllReduce failed: %s", Rccl::get().err_str ? Rccl::get().err_str(e) : "?");
-    }
-    std::vector<unsigned long long> hist(nh);
-    HIPCHK(h, hipMemcpyAsync(hist.data(), d_hist, nh * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, x_sync(h, h->stream, SITE));
-    // counts at threshold k: variants whose last threshold index is >= k (print.cpp:378-381, 425-428); a truth variant
-    // additionally counts as FN at every threshold above its own (print.cpp:429-432)
-    std::fill(counts, counts + size_t(2) * VPR_VARTYPES * 3 * size_t(nq), 0);
-    auto C = [&](int cs, int t, int e, int k) -> int64_t & { return counts[((size_t(cs) * VPR_VARTYPES + t) * 3 + e) * nq + k]; };
-    for (int cs = 0; cs < 2; cs++)
-        for (int t = 0; t < 3; t++) {
-            for (int e = 0; e < 3; e++) {
-                int64_t acc = 0;
-                for (int k = nq - 1; k >= 0; k--) {
-                    acc += int64_t(hist[((size_t(cs) * 3 + t) * 3 + e) * (nq + 1) + k]);
-                    C(cs, t, e, k) += acc;
-                    C(cs, VPR_VARTYPE_ALL, e, k) += acc;
-                }
-            }
-            if (cs == 1) {
-                int64_t below = 0;   // truth variants (any errtype) whose own threshold index is < k
-                for (int e = 0; e < 3; e++) below += int64_t(hist[((size_t(cs) * 3 + t) * 3 + e) * (nq + 1) + nq]);
-                for (int k = 0; k < nq; k++) {
-                    C(cs, t, VPR_ERRTYPE_FN, k) += below;
-                    C(cs, VPR_VARTYPE_ALL, VPR_ERRTYPE_FN, k) += below;
-                    for (int e = 0; e < 3; e++) below += int64_t(hist[((size_t(cs) * 3 + t) * 3 + e) * (nq + 1) + k]);
-                }
-            }
-        }
-    return VPR_OK;
-}
-
-int vpr_pr_counts(vpr_handle *h, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
-                  int32_t min_qual, int32_t max_qual, int64_t *counts) {
-    return pr_counts_impl(h, nullptr, var_class, pb_phase, min_qual, max_qual, counts);
-}
-
-int vpr_allreduce_counts(vpr_handle *h, void *nccl_comm, const uint8_t *const var_class[VPR_HAPS], const int32_t *pb_phase,
-                         int32_t min_qual, int32_t max_qual, int64_t *counts) {
-    if (!nccl_comm) return VPR_ERR_ARG;
-    return pr_counts_impl(h, nccl_comm, var_class, pb_phase, min_qual, max_qual, counts);
-}
-
-int vpr_allgather_phase(vpr_handle *h, void *nccl_comm, int32_t n_ranks, const int32_t *sc_index, int32_t n_total,
-                        int32_t *sc_phase, int32_t *orig_phase_dist, int32_t *swap_phase_dist) {
-    if (!h || !nccl_comm || n_ranks < 1 || !sc_index || !sc_phase || !orig_phase_dist || !swap_phase_dist) return VPR_ERR_ARG;
-    if (!h->executed) return fail(h, VPR_ERR_STATE, "vpr_allgather_phase before vpr_execute");
-    const Rccl &R = Rccl::get();
-    if (!R.all_gather) return fail(h, VPR_ERR_STATE, "no RCCL in this process (librccl.so.1 not found)");
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    const int n = h->n_sc;
-    int rc;
-    // 1. how many superclusters every rank holds; 2. their {global index, sc_phase, orig, swap} records, padded to the largest share
-    int32_t *d_cnt = nullptr;
-    void *q = nullptr;
-    if ((rc = exec_alloc(h, &q, size_t(n_ranks + 1) * 4))) return rc;
-    d_cnt = static_cast<int32_t *>(q);
-    HIPCHK(h, hipMemcpyAsync(d_cnt + n_ranks, &n, 4, hipMemcpyHostToDevice, h->stream));
-    int e = R.all_gather(d_cnt + n_ranks, d_cnt, 1, RCCL_INT32, nccl_comm, h->stream);
-    if (e) return fail(h, VPR_ERR_DEVICE, "ncclAllGather failed: %s", R.err_str ? R.err_str(e) : "?");
-    std::vector<int32_t> cnt(size_t(n_ranks), 0);
-    HIPCHK(h, hipMemcpyAsync(cnt.data(), d_cnt, size_t(n_ranks) * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, x_sync(h, h->stream, SITE));
-    int64_t m = 1, tot = 0;
-    for (int32_t c : cnt) { m = std::max<int64_t>(m, c); tot += c; }
-    if (tot > n_total) return fail(h, VPR_ERR_ARG, "vpr_allgather_phase: the ranks hold %lld superclusters, n_total is %d", (long long)tot, n_total);
-    int4 *d_send = nullptr, *d_recv = nullptr;
-    int32_t *d_idx = nullptr;
-    if ((rc = exec_alloc(h, &q, size_t(m) * 16))) return rc;
-    d_send = static_cast<int4 *>(q);
-    if ((rc = exec_alloc(h, &q, size_t(m) * 16 * size_t(n_ranks)))) return rc;
-    d_recv = static_cast<int4 *>(q);
-    if ((rc = exec_alloc(h, &q, size_t(std::max(n, 1)) * 4))) return rc;
-    d_idx = static_cast<int32_t *>(q);
-    HIPCHK(h, hipMemsetAsync(d_send, 0, size_t(m) * 16, h->stream));
-    if (n) {
-        HIPCHK(h, hipMemcpyAsync(d_idx, sc_index, size_t(n) * 4, hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_pack_phase, dim3(unsigned((n + 255) / 256)), dim3(256), 0, h->stream, d_idx, h->dR.sc_phase,
-                           h->dR.orig_phase_dist, h->dR.swap_phase_dist, n, d_send);
-    }
-    e = R.all_gather(d_send, d_recv, size_t(m) * 4, RCCL_INT32, nccl_comm, h->stream);
-    if (e) return fail(h, VPR_ERR_DEVICE, "ncclAllGather failed: %s", R.err_str ? R.err_str(e) : "?");
-    std::vector<int4> recv(size_t(m) * size_t(n_ranks));
-    HIPCHK(h, hipMemcpyAsync(recv.data(), d_recv, recv.size() * 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, x_sync(h, h->stream, SITE));
-    for (int r = 0; r < n_ranks; r++)
-        for (int32_t k = 0; k < cnt[size_t(r)]; k++) {
-            const int4 v = recv[size_t(r) * size_t(m) + size_t(k)];
-            if (v.x < 0 || v.x >= n_total) return fail(h, VPR_ERR_ARG, "vpr_allgather_phase: supercluster index %d of rank %d out of range", v.x, r);
-            sc_phase[v.x] = v.y; orig_phase_dist[v.x] = v.z; swap_phase_dist[v.x] = v.w;
-        }
-    return VPR_OK;
-}
-
-int vpr_run(vpr_handle *h, const vpr_batch *batch, vpr_results *res) {
-    int rc = vpr_upload(h, batch);
-    if (rc) return rc;
-    if ((rc = vpr_execute(h))) return rc;
-    return vpr_download(h, res);
-}
-
-int64_t vpr_download_path(const vpr_handle *h, int32_t sc, int32_t aln, int64_t cap,
-                          uint8_t *plane, int32_t *qri, int32_t *ti, uint8_t *sync, uint8_t *edit) {
-    if (!h || !h->executed || sc < 0 || sc >= h->n_sc || aln < 0 || aln > 3) return VPR_ERR_ARG;
-    // the walk scratch lives in a workspace that is reused per chunk: only the last chunk of round 0 and the
-    // retry plans are still resident (the most recent plan of an alignment holds its final walk)
-    // (an alignment that is a copy of another one of its supercluster, k_hap_alias: that one's walk)
-    const int src_ = h->alias.empty() ? -1 : alias_source(h->alias[size_t(sc)], aln);
-    const int32_t a = sc * 4 + (src_ >= 0 ? src_ : aln);
-    const uint8_t *arena = nullptr;
-    bool found = false;
-    for (auto it = h->resident.rbegin(); it != h->resident.rend() && !found; ++it)
-        if (std::find(it->first.begin(), it->first.end(), a) != it->first.end()) { arena = it->second; found = true; }
-    if (!found && h->res0_cnt > 0) {
-        const int64_t pos = h->plan0_pos[size_t(a)];
-        if (pos >= 0 && pos >= h->res0_off && pos < h->res0_off + h->res0_cnt) arena = h->plan0.arena;
-    }
-    if (!arena) return VPR_ERR_STATE;
-    AlnOut O;
-    AlnDesc d;
-    if (hipMemcpy(&O, h->d_outs + a, sizeof(O), hipMemcpyDeviceToHost) != hipSuccess) return VPR_ERR_DEVICE;
-    if (hipMemcpy(&d, h->d_descs + a, sizeof(d), hipMemcpyDeviceToHost) != hipSuccess) return VPR_ERR_DEVICE;
-    const int64_t n = std::min<int64_t>(O.path_len, cap);
-    std::vector<PathEnt> p(n);
-    if (n && hipMemcpy(p.data(), reinterpret_cast<const PathEnt *>(arena) + d.path_off, n * sizeof(PathEnt),
-                       hipMemcpyDeviceToHost) != hipSuccess)
-        return VPR_ERR_DEVICE;
-    for (int64_t k = 0; k < n; k++) {
-        plane[k] = uint8_t(p[k].a >> 31);
-        qri[k] = int32_t(p[k].a & 0x7fffffffu);
-        ti[k] = int32_t(p[k].b & 0x0fffffffu);       // (bits 28, 29: credit_walk's base-equality bits)
-        sync[k] = uint8_t(p[k].b >> 31);
-        edit[k] = uint8_t((p[k].b >> 30) & 1);
-    }
-    return O.path_len;
-}
 
 }  // extern "C"

@@ -269,4 +269,23 @@ __host__ __device__ inline int64_t window_layout(AlnDesc &d, int dl, int64_t use
     return m0 + m1 + bl + pb + 128;
 }
 
+// VPR_CFG_HAP_DEDUP: identical haplotypes of a call set make alignments of a supercluster identical (k_hap_alias, pr_api.hip);
+// source of alignment i (0..3) of a supercluster with alias bits b, -1: it is computed itself
+__host__ __device__ inline int alias_source(int b, int i) {
+    const int q = i >> 1, t = i & 1;
+    const int qs = (b & 1) ? 0 : q, ts = (b & 2) ? 0 : t;
+    const int src = qs * 2 + ts;
+    return src == i ? -1 : src;
+}
+
+// the lane levels (pr_zl.hip, pr_d1.hip): per wave of 64 alignments: offsets (in 32-bit words) of its interleaved input block and of its log blocks
+struct ZlWave {
+    int64_t in_off;       // Q block; R block at + 64 * mq, T block at + 64 * (mq + mr)
+    int64_t log_off;      // in uint4 units; 80 * mt of them: the cells' flag bytes (8 B per row and lane), one path_ptr word per
+                          // row and lane, the walk's steps (8 B per row and lane)
+    int32_t mq, mr, mt;   // largest Lq / Lr / Lt of the wave's alignments
+    int32_t pad;
+};
+struct TieJob;      // a replay job of the container-order replay (pr_tie.hip)
+
 #endif

@@ -37,14 +37,7 @@
 #define PR_ZL_HIP_
 #include <type_traits>
 
-// per wave of 64 alignments: offsets (in 32-bit words) of its interleaved input block and of its log blocks
-struct ZlWave {
-    int64_t in_off;       // Q block; R block at + 64 * mq, T block at + 64 * (mq + mr)
-    int64_t log_off;      // in uint4 units; 80 * mt of them: the cells' flag bytes (8 B per row and lane), one path_ptr word per
-                          // row and lane, the walk's steps (8 B per row and lane)
-    int32_t mq, mr, mt;   // largest Lq / Lr / Lt of the wave's alignments
-    int32_t pad;
-};
+// (struct ZlWave -- per wave of 64 alignments, the offsets of its interleaved input block and of its log blocks: pr_device.h)
 
 // position word
 #define ZW_PTR(w) (int((w) & 0xffffu) - 1)
