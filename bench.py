@@ -878,7 +878,12 @@ def main():
         # workloads of long alignments -- : the largest accumulated time.
         sweeps = {k: v for k, v in stats_acc.items() if k[0] in (1, 2) and v[0] > 0}
         bulk = {k: v for k, v in sweeps.items() if units_acc.get(k, 0) / v[0] >= 0.01 * 4 * args.n_sc}
-        (kind, kname), (nl, ms, byt, cells, dense, _, _) = max((bulk or sweeps).items(), key=lambda kv: kv[1][1])
+        # (with batches in flight a launch is stretched by whatever runs beside it, differently from run to run: among the throughput
+        # kernels the one with the longest launch ALONE -- the extra steps after the timed region -- is the dominant one)
+        def _weight(kv):
+            a_ = alone_acc.get(kv[0])
+            return (a_[1] / a_[0]) * (kv[1][0] / max(args.steps, 1)) if a_ and a_[0] > 0 else kv[1][1] / max(args.steps, 1)
+        (kind, kname), (nl, ms, byt, cells, dense, _, _) = max((bulk or sweeps).items(), key=_weight)
         avg_s = ms / nl * 1e-3
         # Three byte counts for that launch: (1) what the PMC counters of the committed rocprofv3
         # passes of this very command saw (FETCH_SIZE x 2 + WRITE_SIZE): `traffic`, and `achieved` = traffic / the

@@ -291,16 +291,20 @@ __global__ void k_fails_count(const int32_t *__restrict__ work, int n, const Aln
     }
 }
 
-__global__ void __launch_bounds__(1024) k_fails_scan(int32_t *__restrict__ blk, int nb, int32_t *__restrict__ cnt) {
-    __shared__ int32_t s_sum[1024];
+// (256 threads: a workgroup of 1 024 needs sixteen free wave slots on ONE compute unit at once, and beside a launch of tens of
+// thousands of long-lived one-wave workgroups -- the stress workload's long part -- that never happens before the launch drains:
+// this kernel waited 35 - 45 ms for a slot, twice per step, whatever its stream's priority.  Four waves find room at once.)
+#define FAILS_SCAN_NT 256
+__global__ void __launch_bounds__(FAILS_SCAN_NT) k_fails_scan(int32_t *__restrict__ blk, int nb, int32_t *__restrict__ cnt) {
+    __shared__ int32_t s_sum[FAILS_SCAN_NT];
     const int tid = threadIdx.x;
-    const int per = (nb + 1023) / 1024;
+    const int per = (nb + FAILS_SCAN_NT - 1) / FAILS_SCAN_NT;
     const int b = min(nb, tid * per), e = min(nb, b + per);
     int32_t sum = 0;
     for (int k = b; k < e; k++) sum += blk[k];
     s_sum[tid] = sum;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
+    for (int o = 1; o < FAILS_SCAN_NT; o <<= 1) {
         const int32_t v = tid >= o ? s_sum[tid - o] : 0;
         __syncthreads();
         s_sum[tid] += v;
@@ -308,7 +312,7 @@ __global__ void __launch_bounds__(1024) k_fails_scan(int32_t *__restrict__ blk, 
     }
     int32_t off = s_sum[tid] - sum;
     for (int k = b; k < e; k++) { const int32_t c = blk[k]; blk[k] = off; off += c; }
-    if (tid == 1023) *cnt = s_sum[1023];
+    if (tid == FAILS_SCAN_NT - 1) *cnt = s_sum[FAILS_SCAN_NT - 1];
 }
 
 __global__ void k_fails_scatter(const int32_t *__restrict__ work, int n, const AlnOut *__restrict__ outs, const int32_t *__restrict__ blk,
@@ -1761,6 +1765,7 @@ namespace {
 // One vpr_execute call: the state its phases share and the phases themselves.  Round 0 (round0_windowed / run_dense), the
 // retry ladders (lad_start / lad_flush), the tie rounds (tie_round, tie_replay, tie_patch, spec_round), the final tie pass,
 // the deferred edit distances (K4) and the finalisation (K5) all enqueue on the handle's streams; run() is the sequence.
+const int64_t LONG_BULK = 8192;      // long alignments from which the long part is throughput work (Exec::Exec)
 const int SPEC_MAX_DIST = 256;       // largest distance of an alignment whose tie replay is started speculatively (spec_round)
 
 struct Exec {
@@ -1806,6 +1811,16 @@ struct Exec {
           s_short(h_->cls_stream[1]), LL(h_->lad[0]), LS(h_->lad[1]) {
         tie_cap[0] = h->tie_list_cap / 8; tie_cap[1] = h->tie_list_cap / 4; tie_cap[2] = h->tie_list_cap / 8;
         tie_off[0] = 0; tie_off[1] = h->tie_list_cap / 4; tie_off[2] = h->tie_list_cap / 8;
+        // The long part's stream has the high priority so that a HANDFUL of latency chains is dispatched ahead of the short part's
+        // millions of waves.  A batch whose long part is itself bulk -- the stress workload: 35 000 alignments of 1 024+ rows, a
+        // wavefront each, more than the device holds at once -- swaps the two streams' roles: its sweeps then run below the
+        // ladders' and tie rounds' streams (the step's chain is long part -> its tie round's replays -> the retry round behind
+        // them) instead of beside them: 284 against 307 ms per step (two alternating runs each on one box).  (Also tried there:
+        // the short part's round 0 in front of the long part's launches -- its small kernels wait 35 - 45 ms each for a slot while
+        // such a launch has workgroups left to dispatch --: 311 - 314 against 305 - 307, the short part is not on the chain.)
+        int64_t n_long_all = 0;
+        for (const Chunk &ch : P0.chunks) n_long_all += ch.n_long;
+        if (n_long_all >= LONG_BULK) std::swap(s_long, s_short);
     }
 
     static dim3 blocks(int64_t n_) { return dim3(unsigned((n_ + 255) / 256)); }
@@ -2567,7 +2582,7 @@ struct Exec {
     void ordered_fails(const int32_t *list, int32_t nc, int32_t *out, int32_t *cnt, const int32_t *n_dev, hipStream_t ks) {
         const int nb = (nc + 255) / 256;
         hipLaunchKernelGGL(k_fails_count, dim3(nb), dim3(256), 0, ks, list, nc, h->d_outs, h->d_d1_blk, 1, n_dev);
-        hipLaunchKernelGGL(k_fails_scan, dim3(1), dim3(1024), 0, ks, h->d_d1_blk, nb, cnt);
+        hipLaunchKernelGGL(k_fails_scan, dim3(1), dim3(FAILS_SCAN_NT), 0, ks, h->d_d1_blk, nb, cnt);
         hipLaunchKernelGGL(k_fails_scatter, dim3(nb), dim3(256), 0, ks, list, nc, h->d_outs, h->d_d1_blk, out, 1, n_dev);
     }
 
@@ -2584,7 +2599,7 @@ struct Exec {
         if (ph == 1) {
             rc = timed(0, ls, ks, "k_prep_d1", [&] {
                 hipLaunchKernelGGL(k_d1_hdr, dim3(nw), dim3(64), 0, ks, h->d_descs, list, n_dev, cap, h->d_outs, h->d_d1_hdr);
-                hipLaunchKernelGGL(k_d1_scan, dim3(1), dim3(1024), 0, ks, h->d_d1_hdr, nw, h->d1_in_cap, h->d1_log_cap, h->d_d1_info);
+                hipLaunchKernelGGL(k_d1_scan, dim3(1), dim3(D1_SCAN_NT), 0, ks, h->d_d1_hdr, nw, h->d1_in_cap, h->d1_log_cap, h->d_d1_info);
                 hipLaunchKernelGGL(k_prep_d1, dim3(nw), dim3(256), 0, ks, h->dB, h->d_descs, list, n_dev, cap, h->d_outs, h->d_d1_hdr, h->d_d1_in);
             });
             if (rc) return rc;

@@ -87,13 +87,14 @@ __global__ void __launch_bounds__(64) k_d1_hdr(const AlnDesc *__restrict__ descs
 
 // ... and their offsets (one workgroup; a wave that does not fit the blocks any more is dropped: mt = 0, its lanes stay rejected)
 //   info[0] = waves with work, info[1] = waves dropped
-__global__ void __launch_bounds__(1024) k_d1_scan(ZlWave *__restrict__ hdr, int n_waves, int64_t in_cap, int64_t log_cap,
+#define D1_SCAN_NT 256      // (four waves find a compute unit beside a device full of long-lived one-wave workgroups: k_fails_scan, pr_api.hip)
+__global__ void __launch_bounds__(D1_SCAN_NT) k_d1_scan(ZlWave *__restrict__ hdr, int n_waves, int64_t in_cap, int64_t log_cap,
                                                   int32_t *__restrict__ info) {
-    __shared__ int64_t s_in[1024], s_log[1024];
+    __shared__ int64_t s_in[D1_SCAN_NT], s_log[D1_SCAN_NT];
     __shared__ int s_used, s_drop;
     const int tid = threadIdx.x;
     if (tid == 0) { s_used = 0; s_drop = 0; }
-    const int per = (n_waves + 1023) / 1024;
+    const int per = (n_waves + D1_SCAN_NT - 1) / D1_SCAN_NT;
     const int b = min(n_waves, tid * per), e = min(n_waves, b + per);
     int64_t si = 0, sl = 0;
     for (int k = b; k < e; k++) {
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(1024) k_d1_scan(ZlWave *__restrict__ hdr, int 
     }
     s_in[tid] = si; s_log[tid] = sl;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
+    for (int o = 1; o < D1_SCAN_NT; o <<= 1) {
         const int64_t ai = tid >= o ? s_in[tid - o] : 0, al = tid >= o ? s_log[tid - o] : 0;
         __syncthreads();
         s_in[tid] += ai; s_log[tid] += al;
