@@ -507,6 +507,15 @@ def test_joint_small_variant_and_sv_workload_against_the_oracle(seed, n_sc, p_sv
     assert [r.key() for r in rows] == [r.key() for r in S.pr_summary(counts, L=O.lib(), prefix="vso")]
 
 
+def test_joint_workload_from_variant_tables_on_the_device():
+    """the same kind of batch uploaded as variant tables (vpr_upload_variants: generate_ptrs_strs on the device, pr_gen.hip) --
+    SV-sized alleles of thousands of bases in the allele pool -- against the oracle on the host-marshalled arrays"""
+    syn = api.Synth(n_sc=300, seed=0x5eed + 21, p_sv=0.08, **JOINT)
+    batch = syn.batch()
+    got, want, _, pr = compare(batch, variants_struct=syn.struct)
+    assert got.aln_dist.max() >= 50 and not (got.aln_status & (A.ST_ERR_NO_PTR | A.ST_ERR_UNFINISHED | A.ST_ERR_LIMIT)).any()
+
+
 def test_joint_workload_full_size_properties():
     """a bench-sized joint batch (beyond the oracle): no alignment comes back unevaluated, a permuted batch gives the permuted
     results, repeated executes are identical, the SV row is populated"""

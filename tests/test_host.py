@@ -41,6 +41,35 @@ def test_struct_sizes_match_header():
     # spot-check the ctypes mirror against the C layout through a round trip of the synth params
     p = api.synth_params(n_sc=3, seed=9)
     assert p.n_sc == 3 and p.seed == 9 and abs(p.var_per_base - 1 / 200) < 1e-12 and p.max_qual == 60
+    assert p.p_sv == 0.0 and p.sv_min == 50 and p.sv_max == 10000        # (the last fields: the struct's size is right)
+
+
+def test_joint_generator_adds_svs_and_keeps_the_small_variant_mix():
+    """vpr_synth_params::p_sv (BASELINE configs[3]): a fraction of the superclusters carries one SV-sized indel, drawn from a PRNG
+    stream of its own -- the other superclusters are those of the same seed without SVs; the oracle evaluates the batch and the
+    summary's SV row is populated"""
+    import numpy as np
+    import oracle_lib as O
+    from vcfdist_amd import summary as S
+    kw = dict(n_sc=300, seed=77, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=10002)
+    plain, joint = api.Synth(**kw), api.Synth(p_sv=0.05, sv_min=50, sv_max=2000, **kw)
+    bp, bj = plain.batch(), joint.batch()
+    Lp, Lj = np.diff(bp.ref_off), np.diff(bj.ref_off)
+    cls = joint.var_class()
+    n_sv = sum(int((c == 2).sum()) for c in cls)
+    assert 0 < (Lp != Lj).sum() <= 30 and n_sv >= 10 and all(int((c == 2).sum()) == 0 for c in plain.var_class())
+    same = np.flatnonzero(Lp == Lj)
+    k = int(same[0])      # a supercluster without an SV: the same variants at the same offsets inside its span
+    for h in range(4):
+        a = bp.var_pos[h][bp.var_off[h][k]:bp.var_off[h][k + 1]] - 0
+        b = bj.var_pos[h][bj.var_off[h][k]:bj.var_off[h][k + 1]] - 0
+        assert len(a) == len(b)
+    res = O.run(bj)
+    assert not (res.aln_status & (A.ST_ERR_NO_PTR | A.ST_ERR_UNFINISHED)).any() and res.aln_dist.max() >= 50
+    pb, _, _ = S.phase(res.sc_phase, np.ones(bj.n_sc, np.int32), L=O.lib(), prefix="vso")
+    rows = S.pr_summary(O.oracle_pr_counts(O.lib(), bj.var_off, res, cls, pb), L=O.lib(), prefix="vso")
+    sv = [r for r in rows if S.NAMES[r.vartype] == "SV" and not r.best][0]
+    assert sv.truth_tp + sv.truth_fn > 0 and sv.query_tp + sv.query_fp > 0
 
 
 def test_planning_pool_never_outnumbers_a_small_cpu_quota():

@@ -1391,7 +1391,8 @@ int vpr_upload(vpr_handle *h, const vpr_batch *b) {
                 if ((Lh[0] < 1 || Lh[1] < 1 || Lh[2] < 1 || Lh[3] < 1 || Lr < 1) && A.bad < 0) A.bad = sc;
                 for (int i = 0; i < 4; i++) {
                     const int64_t Lq = Lh[i >> 1], Lt = Lh[2 + (i & 1)];
-                    A.jobs += std::min(Lr, Lt) / 33;
+                    // (deferred sections: both segments longer than 32, or one longer than ED_INLINE_LONG -- segments are disjoint)
+                    A.jobs += std::min(Lr, Lt) / 33 + Lr / (ED_INLINE_LONG + 1) + Lt / (ED_INLINE_LONG + 1);
                     A.cells += (Lq + Lr) * Lt;
                     if (!plan_pass) continue;
                     d.Lq = int32_t(Lq); d.Lr = int32_t(Lr); d.Lt = int32_t(Lt);

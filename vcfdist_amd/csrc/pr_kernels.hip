@@ -631,6 +631,7 @@ __global__ void __launch_bounds__(NT) k_bwd(DevBatch B, const AlnDesc *__restric
 // ---------------------------------------------------------------------------
 // K3: walk + sync points + credit sections; one lane per alignment.
 // ---------------------------------------------------------------------------
+#define ED_INLINE_LONG 256      // longest segment whose edit distance against one of <= 32 bases is computed inside the credit walk
 __device__ int small_ed(const uint8_t *a, int m, const uint8_t *b, int n) {
     // plain two-row Levenshtein for short segments (n <= 32); equals wf_ed (dist.cpp:1406-1506)
     int row[33];
@@ -843,6 +844,42 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
                 }
             }
         }
+        if constexpr (WAVE && !EXT) {
+            // ... and so are runs of entries that are NOT sync points (round 6: an SV that one call set lacks is thousands of edit
+            // steps in a row): where neither variant pointer moves, such an entry's iteration only counts its edit.
+            if (sync_idx < n && sync_idx >= cbase) {      // (uniform; the entry's chunk is in registers: fetch() put it there)
+                const int l = int(sync_idx - cbase);
+                const bool ns = cbase + lane_ < n && !(ccur.b >> 31) && ccur.qref >= query_var_pos && ccur.tref >= truth_var_pos;
+                const unsigned long long below = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
+                const unsigned long long stop = ~__ballot(ns) & below;
+                const int run = stop ? l - (63 - __builtin_clzll(stop)) : l + 1;
+                if (run >= 2) {
+                    const int lj = l - run + 1;
+                    const unsigned long long in_run = below & ~((1ull << lj) - 1ull);
+                    query_ed += __popcll(__ballot(ns && ((ccur.b >> 30) & 1u)) & in_run);
+                    clean = false;
+                    prev_qref = __builtin_amdgcn_readlane(ccur.qref, lj);
+                    prev_tref = __builtin_amdgcn_readlane(ccur.tref, lj);
+                    cur_b = uint32_t(__builtin_amdgcn_readlane(int(ccur.b), lj));
+                    prev_hi = int(uint32_t(__builtin_amdgcn_readlane(int(ccur.a), lj)) >> 31);
+                    prev_ti = int(cur_b & 0x0fffffffu);
+                    eq_cur = (cur_b >> 28) & 3u;
+                    sync_idx -= run;
+                    if (sync_idx < 0) break;
+                    cur_hi = prev_hi;
+                    const PathEnt e = fetch(sync_idx);
+                    cur_b = e.b;
+                    eq_next = eq_cur; eq_cur = (e.b >> 28) & 3u;
+                    nx_qref = prev_qref; nx_ti = prev_ti;
+                    prev_qri = int(e.a & 0x7fffffffu);
+                    prev_hi = int(e.a >> 31);
+                    prev_ti = int(e.b & 0x0fffffffu);
+                    prev_qref = e.qref;
+                    prev_tref = e.tref;
+                    continue;
+                }
+            }
+        }
         const int query_ref_pos = prev_qref;
         while (query_ref_pos < query_var_pos && query_var_ptr >= d.qv_beg) {
             if (cur_hi == ri) {   // FP: passed on the REF plane, dist.cpp:1157-1168
@@ -880,8 +917,11 @@ __device__ __forceinline__ void credit_walk(const DevBatch &B, const AlnDesc &d,
                 if (same) ref_ed = 0;
             }
             if (ref_ed < 0) {
-                if (tl <= 32) ref_ed = small_ed(Rs + sync_ref_idx, rl, Ts + sync_truth_idx, tl);
-                else if (rl <= 32) ref_ed = small_ed(Ts + sync_truth_idx, tl, Rs + sync_ref_idx, rl);
+                // (inline while it is cheap: the short side up to 32, the long side up to ED_INLINE_LONG.  The inline loop is
+                // long x short sequential steps of one lane: a section of 9 980 reference bases against 23 truth bases -- an SV the
+                // truth lacks, joint_synth -- held its wavefront for 8 ms; deferred, the bit-parallel kernel takes microseconds)
+                if (tl <= 32 && rl <= ED_INLINE_LONG) ref_ed = small_ed(Rs + sync_ref_idx, rl, Ts + sync_truth_idx, tl);
+                else if (rl <= 32 && tl <= ED_INLINE_LONG) ref_ed = small_ed(Ts + sync_truth_idx, tl, Rs + sync_ref_idx, rl);
                 else deferred = true;
             }
             if (has_q || has_t || deferred) {
@@ -1026,6 +1066,7 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
     bool ok = true;
     int skip_run = 0;       // WAVE: steps until the next attempt at a run
     int last_mv = 0;        // WAVE: move of the last single step
+    int singles = 0;        // WAVE: single steps since the last run
     while ((hi == ri && qri < r_size - 1) || (hi == qi && qri < q_size - 1) || ti < t_size - 1) {
         if (WAVE) {
             // DIAGONAL RUNS.  Nearly all of a long alignment's walk is MAT steps down one diagonal of one plane.  Lane l looks at
@@ -1070,6 +1111,7 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
                     }
                     n += run;
                     if (ins) qri += run; else ti += run;
+                    singles = 0;
                     continue;
                 }
                 skip_run = 3;
@@ -1102,6 +1144,7 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
                         path[n + lane] = PathEnt{uint32_t(xq) | (uint32_t(hi) << 31), uint32_t(xt) | (uint32_t(sync) << 31), qr, tr};
                     }
                     n += run; qri += run; ti += run;
+                    singles = 0;
                     continue;
                 }
                 skip_run = 3;
@@ -1113,6 +1156,16 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
             // position (the other plane's around the position it maps to) and is staged again when the walk leaves it
             const int r0 = ti - tile_t0;
             int colw = (r0 >= 0 && r0 < WALK_TR) ? qri - tblo[hi * WALK_TR] : -1;
+            // (a tile is 2 x 32 rows of loads, ~30 us: worth it for a stretch of single steps, not for the one or two between
+            // two runs -- a walk that is mostly runs left its tile with every run and staged a new one for the step behind it:
+            // the first single steps behind a run read their byte straight from the matrix)
+            if ((colw < 0 || colw >= WALK_TW) && singles < 4) {
+                const int org = banded ? blo[hi * t_size + ti] : 0;
+                const int wdt = banded ? d.band_w : (hi == 0 ? q_size : r_size);
+                const int cx = qri - org;
+                if (cx < 0 || cx >= wdt) { status |= VPR_ST_ERR_NO_PTR; ok = false; break; }
+                p = mat[hi][size_t(ti) * d.pitch[hi] + cx] & 31;
+            } else {
             if (colw < 0 || colw >= WALK_TW) {
                 tile_t0 = ti;
                 const int rows = min(WALK_TR, t_size - ti);
@@ -1139,6 +1192,7 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
                 colw = qri - tblo[hi * WALK_TR];
             }
             p = tile[(hi * WALK_TR + (ti - tile_t0)) * WALK_TW + colw] & 31;
+            }
         } else if (WAVE) {
             if (ti >= tile_t0 + WALK_TR) {   // stage the next WALK_TR rows of both planes (uniform branch)
                 tile_t0 = ti;
@@ -1182,6 +1236,7 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
             status |= VPR_ST_ERR_NO_PTR; ok = false; break;
         }
         last_mv = mv;
+        singles++;
         const int consumes = mv & (F_MAT | F_SWP | F_SUB | F_DEL);
         int tflv, qflv, tr, qr;
         bool ins_loc;
