@@ -855,10 +855,12 @@ def main():
         # (b) the other single-GPU configurations of BASELINE.json on small batches.  The headline's other resident batches go
         # first: every live handle holds a dozen streams, and these legs -- latency chains on a handle of their own -- ran 1.6 x
         # slower beside three idle handles than beside two (sv_synth 0.60 - 0.67 s against 0.37)
+        # (round 6: the last batch's handle too -- everything the line reports about it has been read by now --: the stress leg
+        # ran 307 ms per step beside that one idle handle and 284 alone)
         S = None
         for S_ in slots:
-            if S_ is not S_last:
-                S_.pr.close()
+            S_.pr.close()
+        pr = None
         gc.collect()
         for wl, n_sc_, st_ in (("sv_synth", 200, 2), ("stress_synth", 20000, 2), ("joint_synth", 100000, 2)):
             try:
