@@ -222,6 +222,24 @@ def test_command_line_on_demo_files(tmp_path, capsys):
                     "max_cluster_itrs", "max_threads", "max_ram", "sub", "open", "extend", "eval_sub", "eval_open", "eval_extend", "distance"]
     assert "phase_threshold = 0.600000" in par and "credit_threshold = 0.700000" in par and "cluster_method = 'biwfa'" in par
     assert "max_var_size = 5000" in par and "write_outputs = true" in par and par[-1] == "distance = false"
+    # the same run with the host orchestration in C++ (vcfdist_amd/csrc/main.cpp -> lib/vcfdist_gpu: readers, clustering,
+    # superclustering, the path from variant tables, phasing, counters, writers over the C ABIs): every file byte for byte
+    # (the summary VCF up to its ##fileDate line, parameters.txt up to the prefix), the same summary on stdout
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vcfdist_amd", "lib", "vcfdist_gpu")
+    prefix2 = str(tmp_path) + "/cxx_"
+    r = subprocess.run([exe] + argv[:-1] + [prefix2], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().splitlines() == [l for l in out.strip().splitlines()], r.stdout
+    rd2 = lambda name: open(prefix2 + name, "rb").read().decode()
+    for name in ("precision-recall.tsv", "precision-recall-summary.tsv", "phase-blocks.tsv", "switchflips.tsv", "phasing-summary.tsv",
+                 "superclusters.tsv", "query.tsv", "truth.tsv"):
+        assert rd2(name) == rd(name), name
+    g2 = rd2("summary.vcf").split("\n")
+    assert [l for l in g2 if not l.startswith("##fileDate") and not l.startswith("##CL")] == \
+           [l for l in got if not l.startswith("##fileDate") and not l.startswith("##CL")]
+    p2 = rd2("parameters.txt").split("\n")
+    assert [l for l in p2 if not l.startswith(("out_prefix", "command"))] == [l for l in par if not l.startswith(("out_prefix", "command"))]
 
 
 @pytest.mark.gpu

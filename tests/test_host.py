@@ -273,3 +273,26 @@ def test_compiled_cpp_caller_known_answer(tmp_path):
     for i in range(4):
         assert f"alignment {i}: s 0 end plane QUERY" in r.stdout
     assert "hap slot 2 variant 0: TP" in r.stdout
+
+
+def test_cxx_command_line_builds_reads_its_inputs_and_refuses_without_a_gpu(tmp_path):
+    """lib/vcfdist_gpu (vcfdist_amd/csrc/main.cpp: the command line with the host orchestration in C++): built by the library's
+    Makefile; on the demo inputs it parses its arguments, reads both VCFs, the BED and a FASTA through the C readers, orders the
+    contigs -- and without a HIP device stops at vpr_create with the library's "no CPU fallback" error (exit code 2).  On a GPU
+    box the same command runs through (tests/test_demo_known_answer.py compares its files with the Python driver's)."""
+    import subprocess
+    import demo_pipeline as D
+    api.build()
+    exe = os.path.join(ROOT, "vcfdist_amd", "lib", "vcfdist_gpu")
+    assert os.path.exists(exe)
+    fa = tmp_path / "s.fa"
+    with open(fa, "w") as fh:
+        fh.write(">chr1 surrogate\n" + bytes(D.surrogate_fasta(5_100_000)).decode() + "\n")
+    r = subprocess.run([exe, os.path.join(D.DEMO, "query.vcf"), os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.vcf.gz"), str(fa),
+                        "-b", os.path.join(D.DEMO, "nist-v4.2.1_chr1_5Mb.bed"), "-n"], capture_output=True, text=True, timeout=300)
+    if r.returncode == 2:
+        assert "no CPU fallback" in r.stderr
+    else:
+        assert r.returncode == 0 and "PRECISION-RECALL SUMMARY" in r.stdout, r.stdout + r.stderr
+    bad = subprocess.run([exe, "a.vcf", "b.vcf", "c.fa", "-l", "10000"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "at least two larger" in bad.stderr          # globals.cpp:478-481
