@@ -25,7 +25,10 @@ def build(force=False):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
     inc = os.path.join(os.path.dirname(HERE), "include")
     srcs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
-    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    cli = os.path.join(os.path.dirname(LIB_PATH), "vcfdist_gpu")       # (the C++ command line, csrc/main.cpp: built beside the library)
+    newest = min(os.path.getmtime(p) for p in (LIB_PATH, cli)) if os.path.exists(LIB_PATH) and os.path.exists(cli) else None
+    stale = newest is None or any(os.path.getmtime(s) > newest and not (s.endswith("main.cpp") and os.path.getmtime(s) <= os.path.getmtime(cli))
+                                  for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
     return LIB_PATH
