@@ -1,4 +1,4 @@
-"""Regenerates tests/golden/regression_seed7.npz: inputs (generator parameters) and the ORACLE's outputs for a
+"""Regenerates tests/golden/regression_seed7.npz and regression_joint61.npz: inputs (generator parameters) and the ORACLE's outputs for a
 small seeded batch.  These are regression vectors of the CPU restatement (oracle/pr_oracle.cpp), NOT outputs of
 the reference: the reference cannot be built in this image.  Run from the repo root:
     python tests/golden/make_regression.py"""
@@ -14,10 +14,13 @@ import oracle_lib as O  # noqa: E402
 from vcfdist_amd import api  # noqa: E402
 
 PARAMS = dict(n_sc=120, len_a=8, len_b=400, len_max=400, seed=7, var_per_base=0.03)
+# the joint SNP + INDEL + SV shape (BASELINE configs[3]): whole-genome mix, an SV-sized indel in a tenth of the superclusters
+PARAMS_JOINT = dict(n_sc=160, seed=61, len_mode=1, len_a=20.0, len_b=1.2, len_min=4, len_max=10002, p_sv=0.1, sv_min=50, sv_max=1500)
+FIXTURES = {"regression_seed7.npz": PARAMS, "regression_joint61.npz": PARAMS_JOINT}
 
 
-def main():
-    batch = api.Synth(**PARAMS).batch()
+def make(params, fname):
+    batch = api.Synth(**params).batch()
     ex = O.Extra(batch)
     r = O.run(batch, extra=ex)
     out = {"aln_dist": r.aln_dist, "aln_end_plane": r.aln_end_plane, "aln_beg_plane": r.aln_beg_plane,
@@ -27,7 +30,12 @@ def main():
         for w in range(2):
             for name, _ in r.PER_VAR:
                 out[f"{name}_{h}_{w}"] = getattr(r, name)[h][w]
-    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "regression_seed7.npz"), **out)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), fname), **out)
+
+
+def main():
+    for fname, params in FIXTURES.items():
+        make(params, fname)
 
 
 if __name__ == "__main__":

@@ -242,16 +242,18 @@ def test_full_size_property_swapped_haps_swap_phase():
         assert np.array_equal(r1.errtype[2][w], r2.errtype[2][1 - w])
 
 
-def test_gpu_matches_committed_regression_fixture():
-    """GPU results against tests/golden/regression_seed7.npz (oracle-generated, committed)."""
+@pytest.mark.parametrize("fixture", ["regression_seed7.npz", "regression_joint61.npz"])
+def test_gpu_matches_committed_regression_fixture(fixture):
+    """GPU results against tests/golden/regression_seed7.npz / regression_joint61.npz (oracle-generated, committed; the second is the
+    joint SNP + INDEL + SV shape of BASELINE configs[3])."""
     import importlib.util
     import os
     gd = os.path.join(os.path.dirname(__file__), "golden")
     spec = importlib.util.spec_from_file_location("make_regression", os.path.join(gd, "make_regression.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    g = np.load(os.path.join(gd, "regression_seed7.npz"))
-    batch = api.Synth(**mod.PARAMS).batch()
+    g = np.load(os.path.join(gd, fixture))
+    batch = api.Synth(**mod.FIXTURES[fixture]).batch()
     r = api.PrecisionRecall().run(batch)
     assert np.array_equal(r.aln_dist, g["aln_dist"]) and np.array_equal(r.aln_end_plane, g["aln_end_plane"])
     assert np.array_equal(r.sc_phase, g["sc_phase"])

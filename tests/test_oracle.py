@@ -278,8 +278,9 @@ def test_golden_toy_vector_file():
     assert [("QUERY", "REF")[e] for e in r.aln_end_plane] == g["end_plane"]
 
 
-def test_oracle_regression_fixture():
-    """The oracle still produces tests/golden/regression_seed7.npz (guards the checker itself)."""
+@pytest.mark.parametrize("fixture", ["regression_seed7.npz", "regression_joint61.npz"])
+def test_oracle_regression_fixture(fixture):
+    """The oracle still produces tests/golden/regression_seed7.npz / regression_joint61.npz (guards the checker itself)."""
     import os
     sys_path = os.path.join(os.path.dirname(__file__), "golden")
     import importlib.util
@@ -287,8 +288,8 @@ def test_oracle_regression_fixture():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     from vcfdist_amd import api
-    g = np.load(os.path.join(sys_path, "regression_seed7.npz"))
-    r = O.run(api.Synth(**mod.PARAMS).batch())
+    g = np.load(os.path.join(sys_path, fixture))
+    r = O.run(api.Synth(**mod.FIXTURES[fixture]).batch())
     assert np.array_equal(r.aln_dist, g["aln_dist"]) and np.array_equal(r.sc_phase, g["sc_phase"])
     for h in range(4):
         for w in range(2):
