@@ -1,7 +1,7 @@
 """VGPR / SGPR / LDS / scratch of every kernel in the built library, read from the code objects' metadata notes.
-usage: python tools/kernel_regs.py [regex]"""
+usage: python tools/kernel_regs.py [regex [library or object file]]"""
 import os, re, struct, subprocess, sys, tempfile
-LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vcfdist_amd", "lib", "libvcfdist_pr.so")
+LIB = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vcfdist_amd", "lib", "libvcfdist_pr.so")
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 data = open(LIB, "rb").read()
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"

@@ -19,6 +19,7 @@
 
 #include "../../include/vcfdist_pr.h"
 #include "pr_device.h"
+#include "pr_scan.h"
 
 // ---------------------------------------------------------------------------
 // K0b: packed per-position constants (needs the candidate lists of k_prep_cand)
@@ -188,42 +189,7 @@ __global__ void k_prep_xb(DevBatch B, int h, int dir, int64_t n_pos) {
     else B.xb_r[h][g] = make_int2(Bref(x), Bref(x + 1));
 }
 
-// ---------------------------------------------------------------------------
-// DPP wave scans (gfx9 row_shr / row_bcast / wave_shr): ~12 VALU ops instead of six ds_bpermute hops
-// ---------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_mov(int old, int src) {
-    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
-}
-// Two independent inclusive prefix-min scans over the wave, interleaved, as 12 v_min_i32_dpp: with
-// bound_ctrl off a lane whose DPP source does not exist is simply disabled and keeps its value.  hipcc emits
-// v_mov_dpp + s_nop + v_min for the builtin form (3x the instructions), and it cannot see the DPP read
-// inside an asm statement, so the two wait states a DPP read needs after a VALU write of the same register
-// are spelled out here (the other scan's step + one s_nop).
-__device__ __forceinline__ void wave_prefix_min2(int &a, int &b) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_min_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_min_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_min_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_min_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_min_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_min_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ int wave_shr1(int x, int fill) { return dpp_mov<0x138, 0xf>(fill, x); }   // lane i <- lane i-1
+// (the DPP wave scans -- dpp_mov, wave_prefix_min2, wave_shr1 -- are in pr_scan.h)
 
 // band origin of row t: REF plane centred on t2r[t], QUERY plane on r2q[t2r[t]]
 template <int W>

@@ -20,6 +20,7 @@
 
 #include "../../include/vcfdist_pr.h"
 #include "pr_device.h"
+#include "pr_scan.h"
 
 __device__ __forceinline__ bool fwd_allow(int f) { return !(f & PV) || (f & PE); }  // dist.cpp:336-339
 __device__ __forceinline__ bool bwd_allow(int f) { return !(f & PV) || (f & PB); }  // dist.cpp:600-601
@@ -103,14 +104,9 @@ __device__ __forceinline__ void lds_barrier() {
 template <int NT>
 __device__ __forceinline__ void block_excl_prefix_min2(int &a, int &b, int32_t *wsc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int ia = a, ib = b;  // inclusive within the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
-        if (lane >= o) { ia = min(ia, ta); ib = min(ib, tb); }
-    }
-    int ea = __shfl_up(ia, 1), eb = __shfl_up(ib, 1);
-    if (lane == 0) { ea = D_INF; eb = D_INF; }
+    int ia = a, ib = b;  // inclusive within the wave: a DPP scan (twelve v_min_i32_dpp, no LDS round trips)
+    wave_prefix_min2(ia, ib);
+    int ea = wave_shr1(ia, D_INF), eb = wave_shr1(ib, D_INF);
     if (NT > 64) {
         if (lane == 63) { wsc[wave * 2] = ia; wsc[wave * 2 + 1] = ib; }
         lds_barrier<NT>();

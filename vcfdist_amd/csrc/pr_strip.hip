@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *
     // its window only) bounds the true one from above.  A cell beyond the bound is on no optimal path, and neither is
     // anything reached through it: a block of 64 rows in which every cell of the strip (and what comes in from the left)
     // is beyond it is not swept -- its cells count as unreachable, its flags are never read (the backward sweep only
-    // follows flags of cells on optimal paths, and clears the rest).
+    // follows flags of cells on optimal paths).
     int s_ub = D_INF;
     if (use_ub) { const int sv = outs[a].s; if (sv >= 0 && sv < D_INF / 2) s_ub = sv; }
 
@@ -357,6 +357,18 @@ __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *
 // K2 over strips, right to left.  A strip publishes, per row and plane, {score of its first column, that
 // cell's FORWARD flag byte} (the consumer's successor cell, whose flags the producer has overwritten by then);
 // bbnd[bnd_off[i] + j * Lt + t] is the record of strip j + 1's first column.  prog counts rows from the last one.
+//
+// The cells with a score -- the cells on optimal paths -- are a thin bundle: in a row of 2 x 4 096 cells a few dozen.  A row
+// step therefore has two paths per wavefront (round 6; a row cost 6.8 us when every wave took the full one, the launch was as
+// long as the longest alignment's rows x that):
+//   * a wave none of whose cells can have a scored successor -- no score in its own columns of the row below or in the column
+//     right of them, no swap target inside the range of scored columns of the other plane (rng: the range of the row below, two
+//     LDS words per plane), not the ghost cell of a scored record -- only forms the max-plus maps of its INS links for the
+//     row's suffix scan; a wave into which nothing flows from the right either only moves its flag rows along;
+//   * the others run the cell code.
+// The suffix scan is a DPP prefix scan (wave_prefix_mp2, pr_band.hip): the columns are mirrored inside a wave (lane 0 owns the
+// wave's highest columns).  Flag rows and per-cell constants are packed four to a register: the kernel runs 16 waves per
+// compute unit on 128 registers each and used to spill.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ work,
                                                      int n, const int32_t *__restrict__ tab_base, const StripTab *__restrict__ tab,
@@ -364,58 +376,64 @@ __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *
                                                      int4 *__restrict__ bbnd, int32_t *__restrict__ prog, uint8_t *__restrict__ ws,
                                                      AlnOut *__restrict__ outs) {
     constexpr int NT = ST_NT, C = ST_C, NC = NT * C;
+    static_assert(C == 4, "a thread's flag bytes of a row are one 32-bit word per plane");
     // One workgroup per alignment, its strips one after the other from the right: the optimal paths cross the strips one
     // after the other, so strips side by side would mostly wait for each other (and hold a compute unit while they do);
     // here a strip's rows off the paths are skipped in blocks, and the sweep costs what the paths' rows cost.
     const int i = blockIdx.x;
     if (i >= n) return;
     const int ns = n_strips[i];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rel0 = ((tid & ~63) | (63 - lane)) * C;      // mirrored inside the wave
+    __shared__ __align__(16) int32_t srow[2][NC + 4];                  // scores of row t+1
+    __shared__ __align__(16) uint8_t frow[2][2][NC + 16];              // [buffer][plane]: forward flags of rows t+1 / t
+    __shared__ int32_t wsc[4 * (NT / 64)];
+    __shared__ int4 rin[66], rout[64];                   // rin[x]: record of row (t0 - 1) + x
+    __shared__ int32_t actf[2];                          // [row parity]: a cell of the row has a score
+    __shared__ int32_t rng[2][2][2];                     // [row parity][plane]: lowest / highest LDS column with a score
+    __shared__ int32_t blk_or;
     for (int j = ns - 1; j >= 0; j--) {
     const int a = work[i];
     const AlnDesc d = descs[a];
     const StripTab S = tab[tab_base[i] + j];
-    const int tid = threadIdx.x;
     const int Lq = d.Lq, Lr = d.Lr, Lt = d.Lt;
     const int Lp[2] = {Lq, Lr};
     const bool has_left = j > 0, has_right = j + 1 < ns;
     const int bal[2] = {max(S.lo[0] - 1, 0) & ~(C - 1), max(S.lo[1] - 1, 0) & ~(C - 1)};
-    __shared__ int32_t srow[2][NC + 4];                  // scores of row t+1
-    __shared__ uint8_t frow[2][2][NC + 16];              // [buffer][plane]: forward flags of rows t+1 / t
-    __shared__ int32_t wsc[4 * (NT / 64)];
-    __shared__ int4 rin[66], rout[64];                   // rin[x]: record of row (t0 - 1) + x
-    __shared__ int32_t actf[2];                          // [row parity]: a cell of the row has a score
-    __shared__ int32_t blk_or;
     const int32_t *ptr[2] = {B.hap_ptr[d.qs] + d.q_off, B.ref_ptr[d.qs] + d.r_off};
     const uint8_t *pfl[2] = {B.hap_flag[d.qs] + d.q_off, B.ref_flag[d.qs] + d.r_off};
     const int4 *cand[2] = {B.cand_q[d.qs] + d.q_off, B.cand_r[d.qs] + d.r_off};
     const int4 *cand2[2] = {B.cand2_q[d.qs] + d.q_off, B.cand2_r[d.qs] + d.r_off};
     uint8_t *mat[2] = {ws + d.mat_off[0], ws + d.mat_off[1]};
-    const int rel0 = tid * C;
     const int end_plane = outs[a].end_plane;
     const bool inb[2] = {bal[0] + rel0 < d.pitch[0], bal[1] + rel0 < d.pitch[1]};     // the chunk starts inside the flag row
     int4 *my_bnd = bbnd + bnd_off[i] + int64_t(j - 1) * Lt;              // what this strip publishes (boundary j-1 | j)
     const int4 *right_bnd = bbnd + bnd_off[i] + int64_t(j) * Lt;         // what it consumes (boundary j | j+1)
     int32_t *my_prog = prog + tab_base[i] + j;
 
-    // per-cell constants (pr_kernels.hip: k_bwd) and roles
-    int32_t zq[2][C];
-    uint8_t kc[2][C];
-    uint32_t real[2] = {0, 0}, ghost[2] = {0, 0};
+    // per-cell constants (pr_kernels.hip: k_bwd) and roles; kcw: the cells' constant bytes (bit 0 tp, bit 3 tp(z))
+    int32_t zq[2][C];             // LDS column of the cell's swap target in the other plane (NC, a spare column without flags or score: none)
+    uint32_t kcw[2] = {0, 0};
+    uint32_t keyw[2] = {0xffffffffu, 0xffffffffu};     // per cell: the forward flag bits of the target that name this cell as its swap source
+    uint32_t real[2] = {0, 0}, ghost[2] = {0, 0}, rmask[2] = {0, 0};      // rmask: byte mask of the real cells
+    int own[2] = {-1, -1};                                                // cell of the strip's first column, if it is this thread's
+    int zlo[2] = {1 << 30, 1 << 30}, zhi[2] = {-1, -1};                   // range of the cells' swap targets (LDS columns of the other plane)
 #pragma unroll
     for (int p = 0; p < 2; p++) {
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int q = bal[p] + rel0 + c;
-            zq[p][c] = -1;
-            kc[p][c] = 0;
+            zq[p][c] = NC;
+            uint32_t kc = 0;
             const bool is_real = q >= S.lo[p] && q < S.hi[p];
             const bool is_ghost = has_right && q == S.hi[p];
-            if (is_real) real[p] |= 1u << c;
+            if (is_real) { real[p] |= 1u << c; rmask[p] |= 0xffu << (8 * c); }
             if (is_ghost) ghost[p] |= 1u << c;
+            if (is_real && q == S.lo[p]) own[p] = c;
             if ((is_real || is_ghost) && q < Lp[p]) {
                 const int pq = ptr[p][q];
                 const int fq = pfl[p][q];
-                if (p == 0 && q > 0 && ((pq != ptr[0][q - 1] + 1) || (fq & PB))) kc[p][c] |= 1;  // dist.cpp:572-574
+                if (p == 0 && q > 0 && ((pq != ptr[0][q - 1] + 1) || (fq & PB))) kc |= 1;  // dist.cpp:572-574
                 const int z = pq + 1;
                 if (is_real && fwd_allow(fq) && z > 0 && z < Lp[1 - p] && bwd_allow(pfl[1 - p][z])) {
                     const int4 cc = cand[1 - p][z];
@@ -427,14 +445,16 @@ __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *
                     }
                     if (rank >= 0) {
                         zq[p][c] = z - bal[1 - p];      // (index into the other plane's LDS rows)
-                        kc[p][c] |= uint8_t(rank_bits(rank));
+                        zlo[p] = min(zlo[p], zq[p][c]); zhi[p] = max(zhi[p], zq[p][c]);
+                        keyw[p] = (keyw[p] & ~(0xffu << (8 * c))) | (f_swp_key(rank) << (8 * c));
                         if (p == 1) {  // z on the QUERY plane: leaving it scores tp(z), dist.cpp:656-658
                             const int pz = ptr[0][z];
-                            if ((pz != ptr[0][z - 1] + 1) || (pfl[0][z] & PB)) kc[p][c] |= 8;
+                            if ((pz != ptr[0][z - 1] + 1) || (pfl[0][z] & PB)) kc |= 8;
                         }
                     }
                 }
             }
+            kcw[p] |= kc << (8 * c);
         }
     }
     // tp of the QUERY-plane cell right of this chunk (constant over rows)
@@ -443,6 +463,13 @@ __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *
         const int qn = bal[0] + rel0 + C;
         if (qn < Lq && qn <= S.hi[0]) xtp_right = ((ptr[0][qn] != ptr[0][qn - 1] + 1) || (pfl[0][qn] & PB)) ? 1 : 0;
     }
+    auto byte_of = [](uint32_t w, int c) -> uint32_t { return (w >> (8 * c)) & 0xffu; };
+    auto ghost_word = [&](uint32_t w, int p, uint32_t gb) -> uint32_t {     // the real cells' bytes of w, the ghost cell's byte = gb
+        w &= rmask[p];
+#pragma unroll
+        for (int c = 0; c < C; c++) if (ghost[p] & (1u << c)) w |= (gb & 0xffu) << (8 * c);
+        return w;
+    };
 
     // the right strip's records for the rows of a block: rows [t0 - 1, t0 + 64] as far as they exist
     auto acquire_block = [&](int t0) {
@@ -467,91 +494,81 @@ __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *
             if (tid == 0) __hip_atomic_store(my_prog, Lt - t0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
+    auto load_row = [&](int p, int t) -> uint32_t {      // a thread's four flag bytes of row t (0 outside the flag row)
+        return (t >= 0 && inb[p]) ? *reinterpret_cast<const uint32_t *>(mat[p] + size_t(t) * d.pitch[p] + bal[p] + rel0) : 0u;
+    };
+    auto store_row = [&](int p, int t, uint32_t w) {
+        uint8_t *row = mat[p] + size_t(t) * d.pitch[p] + bal[p] + rel0;
+        if (real[p] == (1u << C) - 1) {
+            *reinterpret_cast<uint32_t *>(row) = w;
+        } else if (real[p]) {
+#pragma unroll
+            for (int c = 0; c < C; c++) if (real[p] & (1u << c)) row[c] = uint8_t(w >> (8 * c));
+        }
+    };
 
     int32_t sc[2][C];   // scores of row t+1 (S_NEG = unreachable)
-    uint8_t f1[2][C];   // forward flags of row t+1
-    uint8_t f0[2][C];   // forward flags of row t
+    uint32_t f1w[2];    // forward flags of row t+1
+    uint32_t f0w[2];    // forward flags of row t
+    uint32_t pf[2];     // forward flags of row t-1 (requested one row ahead)
     acquire_block((Lt - 1) & ~63);
     {
         const int t0 = (Lt - 1) & ~63;
+        const int4 Rl = has_right ? rin[Lt - 1 - (t0 - 1)] : make_int4(S_NEG, 0, S_NEG, 0);
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            FlagReg<C> v = FlagReg<C>();
-            if (inb[p]) v = load_flags<C>(mat[p] + size_t(Lt - 1) * d.pitch[p] + bal[p] + rel0);
-            unpack_flags<C>(v, f0[p]);
+            f0w[p] = ghost_word(load_row(p, Lt - 1), p, uint32_t(p == 0 ? Rl.y : Rl.w));
+            f1w[p] = 0;
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                sc[p][c] = S_NEG; f1[p][c] = 0;
-                if (!(real[p] & (1u << c))) f0[p][c] = 0;
-                if (ghost[p] & (1u << c)) { const int4 R = rin[Lt - 1 - (t0 - 1)]; f0[p][c] = uint8_t(p == 0 ? R.y : R.w); }
-                srow[p][rel0 + c] = S_NEG;
-                frow[0][p][rel0 + c] = 0;
-                frow[1][p][rel0 + c] = f0[p][c];
-            }
+            for (int c = 0; c < C; c++) sc[p][c] = S_NEG;
+            *reinterpret_cast<int4 *>(&srow[p][rel0]) = make_int4(S_NEG, S_NEG, S_NEG, S_NEG);
+            *reinterpret_cast<uint32_t *>(&frow[0][p][rel0]) = 0u;
+            *reinterpret_cast<uint32_t *>(&frow[1][p][rel0]) = f0w[p];
+            pf[p] = load_row(p, Lt - 2);
         }
         if (tid == 0) {
-            for (int p = 0; p < 2; p++) { srow[p][NC] = S_NEG; frow[0][p][NC] = 0; frow[1][p][NC] = 0; }
+            for (int p = 0; p < 2; p++) {
+                srow[p][NC] = S_NEG; frow[0][p][NC] = 0; frow[1][p][NC] = 0;
+                for (int b = 0; b < 2; b++) { rng[b][p][0] = 1 << 30; rng[b][p][1] = -1; }
+            }
             actf[0] = actf[1] = 0;
         }
     }
     lds_barrier<NT>();
     uint32_t tie_used = 0;
-    FlagReg<C> pf[2];
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-        pf[p] = FlagReg<C>();
-        if (Lt >= 2 && inb[p]) pf[p] = load_flags<C>(mat[p] + size_t(Lt - 2) * d.pitch[p] + bal[p] + rel0);
-    }
 
     for (int t = Lt - 1; t >= 0; t--) {
         const int t0 = t & ~63;
         if ((t & 63) == 63 && t != Lt - 1) {
             acquire_block(t0);
             // A whole block of 64 rows off the optimal paths -- nothing in the row above it, nothing coming in from the right
-            // in any of its rows -- is cleared without sweeping it: the flags of its rows become 0, the records for the left
-            // neighbour say "no score", and the sweep resumes below it.
+            // in any of its rows -- is not swept: the records for the left neighbour say "no score", and the sweep resumes below it.
             blk_or = 0;
             __syncthreads();
             if (tid < 64 && has_right) { const int4 Rr = rin[tid + 1]; if (Rr.x >= 0 || Rr.z >= 0) blk_or = 1; }
             if (tid == 0 && actf[(t + 1) & 1]) blk_or = 1;
             __syncthreads();
             if (!blk_or) {
-                if (tid < 64 && has_left)      // the forward flags of this strip's first column, before they are cleared
+                if (tid < 64 && has_left)      // the forward flags of this strip's first column
                     rout[tid] = make_int4(S_NEG, mat[0][size_t(t0 + tid) * d.pitch[0] + S.lo[0]], S_NEG, mat[1][size_t(t0 + tid) * d.pitch[1] + S.lo[1]]);
                 __syncthreads();
-#pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    if (!real[p]) continue;
-                    for (int r = t; r >= t0; r--) {
-                        uint8_t *row = mat[p] + size_t(r) * d.pitch[p] + bal[p] + rel0;
-                        if (real[p] == (1u << C) - 1) {
-                            *reinterpret_cast<typename FlagVec<C>::T *>(row) = typename FlagVec<C>::T();
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < C; c++) if (real[p] & (1u << c)) row[c] = 0;
-                        }
-                    }
-                }
                 publish(t0, t);
                 if (t0 > 0) {       // state for row t0 - 1: its forward flags (the ghost's from the record), nothing scored above
                     const int curm = (Lt - 1 - (t0 - 1) + 1) & 1;
                     const int4 Rg = has_right ? rin[0] : make_int4(S_NEG, 0, S_NEG, 0);
 #pragma unroll
                     for (int p = 0; p < 2; p++) {
-                        FlagReg<C> v = FlagReg<C>();
-                        if (inb[p]) v = load_flags<C>(mat[p] + size_t(t0 - 1) * d.pitch[p] + bal[p] + rel0);
-                        unpack_flags<C>(v, f0[p]);
-                        pf[p] = FlagReg<C>();
-                        if (t0 > 1 && inb[p]) pf[p] = load_flags<C>(mat[p] + size_t(t0 - 2) * d.pitch[p] + bal[p] + rel0);
+                        f0w[p] = ghost_word(load_row(p, t0 - 1), p, uint32_t(p == 0 ? Rg.y : Rg.w));
+                        f1w[p] = 0;
+                        pf[p] = load_row(p, t0 - 2);
 #pragma unroll
-                        for (int c = 0; c < C; c++) {
-                            sc[p][c] = S_NEG; f1[p][c] = 0;
-                            if (!(real[p] & (1u << c))) f0[p][c] = 0;
-                            if (ghost[p] & (1u << c)) f0[p][c] = uint8_t(p == 0 ? Rg.y : Rg.w);
-                            frow[curm][p][rel0 + c] = f0[p][c];
-                        }
+                        for (int c = 0; c < C; c++) sc[p][c] = S_NEG;
+                        *reinterpret_cast<uint32_t *>(&frow[curm][p][rel0]) = f0w[p];
                     }
-                    if (tid == 0) actf[0] = actf[1] = 0;
+                    if (tid == 0) {
+                        actf[0] = actf[1] = 0;
+                        for (int p = 0; p < 2; p++) for (int b = 0; b < 2; b++) { rng[b][p][0] = 1 << 30; rng[b][p][1] = -1; }
+                    }
                     lds_barrier<NT>();
                 }
                 t = t0;
@@ -564,117 +581,188 @@ __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *
         if (has_right) { R = rin[t - (t0 - 1)]; if (t > 0) Rm = rin[t - 1 - (t0 - 1)]; }
 
         // A row in which no cell of the strip can be on an optimal path -- none was in the row below, and nothing comes in
-        // from the strip to the right -- only clears its flags: the optimal paths of an alignment are a thin bundle, most
-        // strips are off it in most rows.
+        // from the strip to the right -- only moves the flag rows along: the optimal paths of an alignment are a thin bundle,
+        // most strips are off it in most rows.
         const bool act = t == Lt - 1 || actf[(t + 1) & 1] != 0 || R.x >= 0 || R.z >= 0;
         if (tid == 0) actf[t & 1] = 0;
         int32_t base[2][C];
-        uint8_t bm[2][C];
-        int8_t lk[2][C];      // INS link from cell c+1 into c: tp value (0/1) or -1 broken
+        uint32_t bmw[2] = {0, 0};       // moves reaching base
+        uint32_t lkw[2] = {0xffffffffu, 0xffffffffu};      // INS link from cell c+1 into c: tp value (0/1) or 0xff broken
         int inq = S_NEG, inr = S_NEG;
-        if (!act) {
-#pragma unroll
-            for (int p = 0; p < 2; p++)
-#pragma unroll
-                for (int c = 0; c < C; c++) { base[p][c] = S_NEG; bm[p][c] = 0; lk[p][c] = -1; }
-        } else {
-        MP g[2];
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int o = 1 - p;
-            int xs_r = srow[p][rel0 + C];
-            int xf_r = frow[nxt][p][rel0 + C], xf0_r = frow[cur][p][rel0 + C];
-            int xtp_r = (p == 0) ? xtp_right : 0;
-            MP G; G.A = S_NEG; G.B = 0;
-            bool first = true;
-#pragma unroll
-            for (int c = C - 1; c >= 0; c--) {
-                const int q = bal[p] + rel0 + c;
-                const int xs = (c == C - 1) ? xs_r : sc[p][c + 1];
-                const int xf = (c == C - 1) ? xf_r : f1[p][c + 1];
-                const int xtp = (c == C - 1) ? xtp_r : (kc[p][c + 1] & 1);
-                int best = S_NEG; uint8_t m = 0;
-                int l = -1;
-                if (real[p] & (1u << c)) {
-                    if (f_diag(xf)) {
-                        best = xs + xtp; m = uint8_t(f_diag(xf));
-                    }
-                    if (f1[p][c] & F_DEL) {
-                        const int v = sc[p][c];
-                        if (v > best) { best = v; m = F_DEL; } else if (v == best) m |= F_DEL;
-                    }
-                    if (zq[p][c] >= 0) {
-                        const int zf = frow[nxt][o][zq[p][c]];
-                        if ((zf & F_SWP) && f_choice_of(zf) == rank_of(kc[p][c])) {
-                            const int v = srow[o][zq[p][c]] + ((kc[p][c] >> 3) & 1);
-                            if (v >= 0 && (zf & F_TIE)) tie_used++;
-                            if (v > best) { best = v; m = F_SWP; } else if (v == best) m |= F_SWP;
-                        }
-                    }
-                    if (t == Lt - 1 && p == end_plane && q == Lp[p] - 1) { best = 0; m = F_MAT; }  // dist.cpp:538-546
-                    const int xf0 = (c == C - 1) ? xf0_r : f0[p][c + 1];
-                    l = (xf0 & F_INS) ? xtp : -1;
-                } else if (ghost[p] & (1u << c)) {
-                    best = (p == 0) ? R.x : R.z;       // its score in this row is final: nothing flows in
-                }
-                base[p][c] = best;
-                bm[p][c] = m;
-                lk[p][c] = int8_t(l);
-                MP F; F.A = best; F.B = l;
-                if (first) { G = F; first = false; } else G = mp_compose(F, G);
-            }
-            g[p] = G;
-        }
-        block_suffix_mp2<NT>(g[0], g[1], inq, inr, wsc);   // barrier: all reads of the score rows / flag buffer nxt done
-        }
-        const int inc[2] = {inq, inr};
-        uint8_t out[2][C];
-        bool anyp = false;
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            int prev = inc[p];
-            uint8_t fnew[C];
-            if (t > 0) unpack_flags<C>(pf[p], fnew);   // row t-1 flags (requested one row ago)
-#pragma unroll
-            for (int c = C - 1; c >= 0; c--) {
-                int v = base[p][c];
-                uint8_t m = bm[p][c];
-                if (lk[p][c] >= 0) {
-                    const int w = prev + lk[p][c];
-                    if (w > v) { v = w; m = F_INS; } else if (w == v) m |= F_INS;
-                }
-                if (v < 0) { v = S_NEG; m = 0; }
-                sc[p][c] = v;
-                anyp = anyp || v >= 0;
-                out[p][c] = m ? uint8_t(m | (f0[p][c] & F_KEEP)) : uint8_t(0);
-                prev = v;
-                f1[p][c] = f0[p][c];
-                if (act) srow[p][rel0 + c] = v;
-                if ((real[p] & (1u << c)) && bal[p] + rel0 + c == S.lo[p]) {       // this strip's first column: published
-                    if (p == 0) { rout[t - t0].x = v; rout[t - t0].y = f1[p][c]; } else { rout[t - t0].z = v; rout[t - t0].w = f1[p][c]; }
-                }
-                if (t > 0) {
-                    uint8_t nf = (real[p] & (1u << c)) ? fnew[c] : uint8_t(0);
-                    if (ghost[p] & (1u << c)) nf = uint8_t(p == 0 ? Rm.y : Rm.w);
-                    f0[p][c] = nf;
-                    frow[nxt][p][rel0 + c] = nf;   // nxt becomes "cur" of row t-1
-                }
-            }
-        }
+        bool full2 = false;
 #pragma unroll
         for (int p = 0; p < 2; p++)
-            if (t > 1 && inb[p]) pf[p] = load_flags<C>(mat[p] + size_t(t - 2) * d.pitch[p] + bal[p] + rel0);
+#pragma unroll
+            for (int c = 0; c < C; c++) base[p][c] = S_NEG;
+        if (act) {
+            const int xs_r[2] = {srow[0][rel0 + C], srow[1][rel0 + C]};
+            const uint32_t xf0_r[2] = {frow[cur][0][rel0 + C], frow[cur][1][rel0 + C]};
+            // can a cell of this thread have a scored successor?  (superset: see the header)
+            bool maybe = t == Lt - 1 || xs_r[0] >= 0 || xs_r[1] >= 0;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+#pragma unroll
+                for (int c = 0; c < C; c++) maybe = maybe || sc[p][c] >= 0;
+                maybe = maybe || (zlo[p] <= rng[(t + 1) & 1][1 - p][1] && zhi[p] >= rng[(t + 1) & 1][1 - p][0]);
+            }
+            if (ghost[0] | ghost[1]) maybe = maybe || R.x >= 0 || R.z >= 0;
+            const bool live1 = __any(maybe);
+            // the INS chain of the row runs through ALL cells of this wave?  (the link into cell c is the F_INS bit of cell c + 1's
+            // forward flags of this row; real cells only).  Nearly never: then the wave's map is "broken" whatever its links are
+            bool chain = false;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const uint32_t w = (f0w[p] >> 8) | (xf0_r[p] << 24);
+                chain = chain || __all(real[p] == (1u << C) - 1 && (w & 0x01010101u) == 0x01010101u);
+            }
+            MP g[2], eq, er;
+            // the threads' max-plus maps (with_base: and the cells' scores over their successors in the row below), scanned
+            auto thread_maps = [&](bool with_base) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const int o = 1 - p;
+                    const int xtp_r = (p == 0) ? xtp_right : 0;
+                    // (what the cells read from LDS is requested side by side, before any of it is used: a cell without a swap
+                    // target reads the spare column NC -- no flags, no score)
+                    uint32_t xf_r = 0, zf[C];
+                    int zs[C];
+                    if (with_base) {
+                        xf_r = frow[nxt][p][rel0 + C];
+#pragma unroll
+                        for (int c = 0; c < C; c++) { zf[c] = frow[nxt][o][zq[p][c]]; zs[c] = srow[o][zq[p][c]]; }
+                    }
+                    MP G; G.A = S_NEG; G.B = 0;
+                    bool first = true;
+#pragma unroll
+                    for (int c = C - 1; c >= 0; c--) {
+                        const uint32_t kc = byte_of(kcw[p], c);
+                        const int xtp = (c == C - 1) ? xtp_r : int(byte_of(kcw[p], c + 1) & 1u);
+                        int best = S_NEG; uint32_t m = 0;
+                        int l = -1;
+                        const bool is_real = (real[p] >> c) & 1u;
+                        if (with_base) {
+                            const int q = bal[p] + rel0 + c;
+                            const int xs = (c == C - 1) ? xs_r[p] : sc[p][c + 1];
+                            const uint32_t xf = (c == C - 1) ? xf_r : byte_of(f1w[p], c + 1);
+                            const uint32_t dg = f_diag(xf);
+                            best = dg ? xs + xtp : S_NEG; m = dg;
+                            {
+                                const bool on = (byte_of(f1w[p], c) & F_DEL) != 0;
+                                const int v = sc[p][c];
+                                const bool gt = on && v > best, eqv = on && v == best;
+                                m = gt ? uint32_t(F_DEL) : (eqv ? (m | F_DEL) : m);
+                                best = gt ? v : best;
+                            }
+                            {
+                                const bool on = (zf[c] & F_SWP_KEY_MASK) == byte_of(keyw[p], c);      // (a cell without a target has key 0xff)
+                                const int v = zs[c] + int((kc >> 3) & 1u);
+                                tie_used += (on && v >= 0 && (zf[c] & F_TIE) && is_real) ? 1u : 0u;
+                                const bool gt = on && v > best, eqv = on && v == best;
+                                m = gt ? uint32_t(F_SWP) : (eqv ? (m | F_SWP) : m);
+                                best = gt ? v : best;
+                            }
+                            if (t == Lt - 1 && p == end_plane && q == Lp[p] - 1) { best = 0; m = F_MAT; }  // dist.cpp:538-546
+                        }
+                        if (is_real) {
+                            const uint32_t xf0 = (c == C - 1) ? xf0_r[p] : byte_of(f0w[p], c + 1);
+                            l = (xf0 & F_INS) ? xtp : -1;
+                        } else {
+                            best = S_NEG; m = 0;
+                            if (ghost[p] & (1u << c)) best = (p == 0) ? R.x : R.z;       // its score in this row is final: nothing flows in
+                        }
+                        base[p][c] = best;
+                        bmw[p] = (bmw[p] & ~(0xffu << (8 * c))) | (m << (8 * c));
+                        lkw[p] = (lkw[p] & ~(0xffu << (8 * c))) | ((uint32_t(l) & 0xffu) << (8 * c));
+                        MP F; F.A = best; F.B = l;
+                        if (first) { G = F; first = false; } else G = mp_compose(F, G);
+                    }
+                    g[p] = G;
+                }
+                // suffix composition inside the wave: a prefix scan in lane order (the columns are mirrored)
+                wave_prefix_mp2(g[0], g[1]);
+                eq.A = wave_shr1(g[0].A, S_NEG); eq.B = wave_shr1(g[0].B, 0);      // everything right of this thread inside the wave
+                er.A = wave_shr1(g[1].A, S_NEG); er.B = wave_shr1(g[1].B, 0);
+            };
+            bool have_maps = false;
+            if (live1 || chain) {
+                thread_maps(live1);
+                have_maps = true;
+                if (lane == 63) *reinterpret_cast<int4 *>(&wsc[wave * 4]) = make_int4(g[0].A, g[0].B, g[1].A, g[1].B);
+            } else {
+                if (lane == 63) *reinterpret_cast<int4 *>(&wsc[wave * 4]) = make_int4(S_NEG, -1, S_NEG, -1);
+            }
+            lds_barrier<NT>();          // (all reads of the score rows / flag buffer nxt / rng of the row below are done)
+            // what flows into this wave from the waves right of it
+            int xq = S_NEG, xr = S_NEG;
+            if (wave + 1 < NT / 64) {
+                const int4 nb = *reinterpret_cast<const int4 *>(&wsc[(wave + 1) * 4]);
+                if (nb.y < 0 && nb.w < 0) { xq = nb.x; xr = nb.z; }      // both chains break inside the neighbour: its own scores
+                else {
+                    for (int w = NT / 64 - 1; w > wave; w--) {
+                        const int4 e = *reinterpret_cast<const int4 *>(&wsc[w * 4]);
+                        xq = (e.y < 0) ? e.x : max(e.x, xq + e.y);
+                        xr = (e.w < 0) ? e.z : max(e.z, xr + e.w);
+                    }
+                }
+            }
+            if (!have_maps && (xq >= 0 || xr >= 0)) { thread_maps(false); have_maps = true; }      // (wave-uniform)
+            if (have_maps) {
+                inq = (eq.B < 0) ? eq.A : max(eq.A, xq + eq.B);
+                inr = (er.B < 0) ? er.A : max(er.A, xr + er.B);
+                full2 = __any(maybe || inq >= 0 || inr >= 0);
+            }
+            if (tid == 0) { rng[(t + 1) & 1][0][0] = rng[(t + 1) & 1][1][0] = 1 << 30; rng[(t + 1) & 1][0][1] = rng[(t + 1) & 1][1][1] = -1; }
+        }
+        const int inc[2] = {inq, inr};
+        uint32_t outw[2] = {0, 0};
+        bool anyp = false;
+        if (full2) {
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                int prev = inc[p];
+                int lo = 1 << 30, hi = -1;
+#pragma unroll
+                for (int c = C - 1; c >= 0; c--) {
+                    int v = base[p][c];
+                    uint32_t m = byte_of(bmw[p], c);
+                    const int l = int(int8_t(byte_of(lkw[p], c)));
+                    if (l >= 0) {
+                        const int w = prev + l;
+                        if (w > v) { v = w; m = F_INS; } else if (w == v) m |= F_INS;
+                    }
+                    if (v < 0) { v = S_NEG; m = 0; }
+                    sc[p][c] = v;
+                    if (v >= 0) { lo = min(lo, rel0 + c); hi = max(hi, rel0 + c); }
+                    outw[p] |= (m ? (m | (byte_of(f0w[p], c) & F_KEEP)) : 0u) << (8 * c);
+                    prev = v;
+                }
+                *reinterpret_cast<int4 *>(&srow[p][rel0]) = make_int4(sc[p][0], sc[p][1], sc[p][2], sc[p][3]);
+                if (hi >= 0) { anyp = true; atomicMin(&rng[t & 1][p][0], lo); atomicMax(&rng[t & 1][p][1], hi); }
+            }
+        }
+        // (a wave off the live path: its scores were and stay S_NEG -- in the registers and in srow; the flag bytes of its cells
+        // stay what the forward sweep left: nothing reads the flags of a cell without a score, the walk follows scored cells only)
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            uint8_t *row = mat[p] + size_t(t) * d.pitch[p] + bal[p] + rel0;
-            if (real[p] == (1u << C) - 1) {
-                typename FlagVec<C>::T v;
-                __builtin_memcpy(&v, out[p], C);
-                *reinterpret_cast<typename FlagVec<C>::T *>(row) = v;
-            } else if (real[p]) {
 #pragma unroll
-                for (int c = 0; c < C; c++) if (real[p] & (1u << c)) row[c] = out[p][c];
+            for (int c = 0; c < C; c++) {
+                if (own[p] == c) {       // this strip's first column: published
+                    const int v = sc[p][c];
+                    const int fb = int(byte_of(f0w[p], c));
+                    if (p == 0) { rout[t - t0].x = v; rout[t - t0].y = fb; } else { rout[t - t0].z = v; rout[t - t0].w = fb; }
+                }
             }
+            f1w[p] = f0w[p];
+            if (t > 0) {
+                f0w[p] = ghost_word(pf[p], p, uint32_t(p == 0 ? Rm.y : Rm.w));
+                *reinterpret_cast<uint32_t *>(&frow[nxt][p][rel0]) = f0w[p];   // nxt becomes "cur" of row t-1
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++) pf[p] = load_row(p, t - 2);
+        if (full2) {
+#pragma unroll
+            for (int p = 0; p < 2; p++) store_row(p, t, outw[p]);
         }
         if (anyp) actf[t & 1] = 1;
         lds_barrier<NT>();
