@@ -2138,6 +2138,7 @@ struct Exec {
     struct StripGroup {
         int64_t off = 0; int32_t cnt = 0, grid = 0;
         int32_t *d_base = nullptr, *d_n = nullptr, *d_ok = nullptr, *d_prog = nullptr;     // d_prog: [2][grid] forward / backward
+        int32_t *d_order = nullptr;      // the forward sweep's launch order of the strips
         int64_t *d_boff = nullptr;
         StripTab *d_tab = nullptr;
         int2 *d_bnd = nullptr; int4 *d_bbnd = nullptr;
@@ -2145,15 +2146,19 @@ struct Exec {
     int strip_plan(const Plan &P, const int32_t *d_work, int64_t off, int32_t cnt, hipStream_t ks, StripGroup &G) {
         G.off = off; G.cnt = cnt;
         // slots per alignment: twice what the longer plane needs (a cut may have to move far back to a clean column)
+        auto slots_of = [](const AlnDesc &d) { return 2 * ((std::max(d.Lq, d.Lr) + ST_CAP - 1) / ST_CAP) + 2; };
+        int64_t slots_all = 0;
+        for (int32_t k = 0; k < cnt; k++) slots_all += slots_of(P.descs[size_t(off) + k]);
         void *pb = nullptr;
-        { int rc_pin = exec_pin(h, &pb, size_t(cnt + 1) * 4 + size_t(cnt) * 9 + 16); if (rc_pin) return rc_pin; }
+        { int rc_pin = exec_pin(h, &pb, size_t(cnt + 1) * 4 + size_t(cnt) * 9 + size_t(slots_all) * 4 + 16); if (rc_pin) return rc_pin; }
         int64_t *h_boff = static_cast<int64_t *>(pb);
         int32_t *h_base = reinterpret_cast<int32_t *>(h_boff + cnt);
-        uint8_t *h_fits = reinterpret_cast<uint8_t *>(h_base + cnt + 1);
+        int32_t *h_order = h_base + cnt + 1;
+        uint8_t *h_fits = reinterpret_cast<uint8_t *>(h_order + slots_all);
         int64_t slots = 0, rows = 0;
         for (int32_t k = 0; k < cnt; k++) {
             const AlnDesc &d = P.descs[size_t(off) + k];
-            const int ns = 2 * ((std::max(d.Lq, d.Lr) + ST_CAP - 1) / ST_CAP) + 2;
+            const int ns = slots_of(d);
             h_base[k] = int32_t(slots);
             h_boff[k] = rows;
             h_fits[k] = dense_fits(d) ? 1 : 0;
@@ -2163,9 +2168,24 @@ struct Exec {
         }
         h_base[cnt] = int32_t(slots);
         G.grid = int32_t(slots);
+        // The forward sweep's workgroups draw their strip from this list in launch order: strip 0 of every alignment first
+        // (largest matrix first), then every strip 1, ...  A strip that runs beside its left neighbour holds a compute unit
+        // while it waits for that neighbour's blocks (with one workgroup per compute unit and more strips than compute units,
+        // 45 % of the launch's workgroup time was such waiting); a strip that starts when a compute unit falls free finds its
+        // neighbour's column published and runs through.  (i, j - 1) still precedes (i, j): the wait cannot deadlock.
+        {
+            std::vector<int32_t> by_size(size_t(cnt), 0);
+            for (int32_t k = 0; k < cnt; k++) by_size[size_t(k)] = k;
+            auto cells = [&](int32_t k) { const AlnDesc &d = P.descs[size_t(off) + k]; return int64_t(d.Lq + d.Lr) * d.Lt; };
+            std::stable_sort(by_size.begin(), by_size.end(), [&](int32_t x, int32_t y) { return cells(x) > cells(y); });
+            int64_t w = 0;
+            for (int j = 0; w < slots; j++)
+                for (int32_t k : by_size)
+                    if (j < h_base[k + 1] - h_base[k]) h_order[w++] = h_base[k] + j;
+        }
         void *q = nullptr;
         int rc;
-        const size_t b_small = size_t(cnt + 1) * 4 + size_t(cnt) * 17 + size_t(slots) * sizeof(StripTab) + 4096;
+        const size_t b_small = size_t(cnt + 1) * 4 + size_t(cnt) * 17 + size_t(slots) * (sizeof(StripTab) + 4) + 4096;
         if ((rc = exec_alloc(h, &q, b_small))) return rc;
         uint8_t *u = static_cast<uint8_t *>(q);
         G.d_boff = reinterpret_cast<int64_t *>(u); u += size_t(cnt) * 8;
@@ -2173,6 +2193,7 @@ struct Exec {
         G.d_base = reinterpret_cast<int32_t *>(u); u += size_t(cnt + 1) * 4;
         G.d_n = reinterpret_cast<int32_t *>(u); u += size_t(cnt) * 4;
         G.d_ok = reinterpret_cast<int32_t *>(u); u += size_t(cnt) * 4;
+        G.d_order = reinterpret_cast<int32_t *>(u); u += size_t(slots) * 4;
         uint8_t *d_fits = u;
         if ((rc = exec_alloc(h, &q, size_t(slots) * 8 + 8))) return rc;       // (+ the forward sweep's ticket counter)
         G.d_prog = static_cast<int32_t *>(q);
@@ -2182,6 +2203,7 @@ struct Exec {
         HIPCHK(h, hipMemcpyAsync(G.d_boff, h_boff, size_t(cnt) * 8, hipMemcpyHostToDevice, ks));
         HIPCHK(h, hipMemcpyAsync(G.d_base, h_base, size_t(cnt + 1) * 4, hipMemcpyHostToDevice, ks));
         HIPCHK(h, hipMemcpyAsync(d_fits, h_fits, size_t(cnt), hipMemcpyHostToDevice, ks));
+        HIPCHK(h, hipMemcpyAsync(G.d_order, h_order, size_t(slots) * 4, hipMemcpyHostToDevice, ks));
         HIPCHK(h, hipMemsetAsync(G.d_prog, 0, size_t(slots) * 8 + 8, ks));
         hipLaunchKernelGGL(k_strip_plan, dim3((cnt + 63) / 64), dim3(64), 0, ks, h->dB, h->d_descs, d_work + off, cnt, G.d_base, G.d_tab,
                            G.d_n, G.d_ok, d_fits, h->d_err, h->d_outs);
@@ -2292,7 +2314,7 @@ struct Exec {
                 cells_touched += ls.cells;
                 rc = timed(1, ls, ks, "k_fwd_strip", [&] {
                     hipLaunchKernelGGL(k_fwd_strip, dim3(G.grid), dim3(ST_NT), 0, ks, h->dB, h->d_descs, d_work + g_off, g_cnt, G.d_base,
-                                       G.d_tab, G.d_n, G.d_boff, G.d_bnd, G.d_prog, P.arena, h->d_outs, (from_window && !getenv("VPR_NO_UB")) ? 1 : 0);
+                                       G.d_tab, G.d_n, G.d_order, G.d_boff, G.d_bnd, G.d_prog, P.arena, h->d_outs, (from_window && !getenv("VPR_NO_UB")) ? 1 : 0);
                 });
                 if (rc) return rc;
                 n_fwd++;

@@ -86,15 +86,17 @@ __global__ void k_strip_plan(DevBatch B, const AlnDesc *__restrict__ descs, cons
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *__restrict__ descs, const int32_t *__restrict__ work,
                                                      int n, const int32_t *__restrict__ tab_base, const StripTab *__restrict__ tab,
-                                                     const int32_t *__restrict__ n_strips, const int64_t *__restrict__ bnd_off,
+                                                     const int32_t *__restrict__ n_strips, const int32_t *__restrict__ order,
+                                                     const int64_t *__restrict__ bnd_off,
                                                      int2 *__restrict__ bnd, int32_t *__restrict__ prog, uint8_t *__restrict__ ws,
                                                      AlnOut *__restrict__ outs, int use_ub) {
     constexpr int NT = ST_NT, C = ST_C, NC = NT * C;
-    // The strip slot is a TICKET drawn at entry (a counter behind the two progress arrays, zeroed with them), not blockIdx: a
-    // strip waits for the slot before its own, and that ticket has been drawn by a workgroup that is already running -- the
-    // wait cannot deadlock whatever order the workgroups are dispatched in and however many fit on the device at once.
+    // The strip slot comes with a TICKET drawn at entry (a counter behind the two progress arrays, zeroed with them), not with
+    // blockIdx: order[ticket] lists every alignment's strip j - 1 before its strip j, a strip waits for the strip before its own,
+    // and that one's ticket has been drawn by a workgroup that is already running -- the wait cannot deadlock whatever order
+    // the workgroups are dispatched in and however many fit on the device at once.
     __shared__ int s_slot;
-    if (threadIdx.x == 0) s_slot = atomicAdd(prog + 2 * int(gridDim.x), 1);
+    if (threadIdx.x == 0) s_slot = order[atomicAdd(prog + 2 * int(gridDim.x), 1)];
     __syncthreads();
     const int slot = s_slot;
     int i;
