@@ -466,11 +466,13 @@ __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *
         if (qn < Lq && qn <= S.hi[0]) xtp_right = ((ptr[0][qn] != ptr[0][qn - 1] + 1) || (pfl[0][qn] & PB)) ? 1 : 0;
     }
     auto byte_of = [](uint32_t w, int c) -> uint32_t { return (w >> (8 * c)) & 0xffu; };
-    auto ghost_word = [&](uint32_t w, int p, uint32_t gb) -> uint32_t {     // the real cells' bytes of w, the ghost cell's byte = gb
-        w &= rmask[p];
+    uint32_t gmask[2] = {0, 0};       // byte mask of the ghost cell
 #pragma unroll
-        for (int c = 0; c < C; c++) if (ghost[p] & (1u << c)) w |= (gb & 0xffu) << (8 * c);
-        return w;
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int c = 0; c < C; c++) if (ghost[p] & (1u << c)) gmask[p] = 0xffu << (8 * c);
+    auto ghost_word = [&](uint32_t w, int p, uint32_t gb) -> uint32_t {     // the real cells' bytes of w, the ghost cell's byte = gb
+        return (w & rmask[p]) | (((gb & 0xffu) * 0x01010101u) & gmask[p]);
     };
 
     // the right strip's records for the rows of a block: rows [t0 - 1, t0 + 64] as far as they exist
@@ -496,8 +498,9 @@ __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *
             if (tid == 0) __hip_atomic_store(my_prog, Lt - t0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
+    const uint8_t *cell0[2] = {mat[0] + bal[0] + rel0, mat[1] + bal[1] + rel0};      // the thread's first cell in row 0
     auto load_row = [&](int p, int t) -> uint32_t {      // a thread's four flag bytes of row t (0 outside the flag row)
-        return (t >= 0 && inb[p]) ? *reinterpret_cast<const uint32_t *>(mat[p] + size_t(t) * d.pitch[p] + bal[p] + rel0) : 0u;
+        return (t >= 0 && inb[p]) ? *reinterpret_cast<const uint32_t *>(cell0[p] + size_t(t) * d.pitch[p]) : 0u;
     };
     auto store_row = [&](int p, int t, uint32_t w) {
         uint8_t *row = mat[p] + size_t(t) * d.pitch[p] + bal[p] + rel0;
@@ -590,8 +593,8 @@ __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *
         int32_t base[2][C];
         uint32_t bmw[2] = {0, 0};       // moves reaching base
         uint32_t lkw[2] = {0xffffffffu, 0xffffffffu};      // INS link from cell c+1 into c: tp value (0/1) or 0xff broken
-        int inq = S_NEG, inr = S_NEG;
-        bool full2 = false;
+        int inc[2] = {S_NEG, S_NEG};    // what flows into the thread's cells from the right
+        bool full2[2] = {false, false}; // (wave-uniform, per plane) the cells of the plane take the full second half
 #pragma unroll
         for (int p = 0; p < 2; p++)
 #pragma unroll
@@ -599,51 +602,52 @@ __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *
         if (act) {
             const int xs_r[2] = {srow[0][rel0 + C], srow[1][rel0 + C]};
             const uint32_t xf0_r[2] = {frow[cur][0][rel0 + C], frow[cur][1][rel0 + C]};
-            // can a cell of this thread have a scored successor?  (superset: see the header)
-            bool maybe = t == Lt - 1 || xs_r[0] >= 0 || xs_r[1] >= 0;
+            // per plane: can a cell of this thread have a scored successor?  (superset: see the header)
+            bool maybe[2], live1[2], need1[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
+                bool m = t == Lt - 1 || xs_r[p] >= 0;
 #pragma unroll
-                for (int c = 0; c < C; c++) maybe = maybe || sc[p][c] >= 0;
-                maybe = maybe || (zlo[p] <= rng[(t + 1) & 1][1 - p][1] && zhi[p] >= rng[(t + 1) & 1][1 - p][0]);
-            }
-            if (ghost[0] | ghost[1]) maybe = maybe || R.x >= 0 || R.z >= 0;
-            const bool live1 = __any(maybe);
-            // the INS chain of the row runs through ALL cells of this wave?  (the link into cell c is the F_INS bit of cell c + 1's
-            // forward flags of this row; real cells only).  Nearly never: then the wave's map is "broken" whatever its links are
-            bool chain = false;
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
+                for (int c = 0; c < C; c++) m = m || sc[p][c] >= 0;
+                m = m || (zlo[p] <= rng[(t + 1) & 1][1 - p][1] && zhi[p] >= rng[(t + 1) & 1][1 - p][0]);
+                if (ghost[p]) m = m || (p == 0 ? R.x : R.z) >= 0;
+                maybe[p] = m;
+                live1[p] = __any(m);
+                // the INS chain of the row runs through ALL cells of this wave?  (the link into cell c is the F_INS bit of cell
+                // c + 1's forward flags of this row; real cells only).  Nearly never: else the wave's map is "broken" whatever its links
                 const uint32_t w = (f0w[p] >> 8) | (xf0_r[p] << 24);
-                chain = chain || __all(real[p] == (1u << C) - 1 && (w & 0x01010101u) == 0x01010101u);
+                need1[p] = live1[p] || __all(real[p] == (1u << C) - 1 && (w & 0x01010101u) == 0x01010101u);
             }
-            MP g[2], eq, er;
-            // the threads' max-plus maps (with_base: and the cells' scores over their successors in the row below), scanned
-            auto thread_maps = [&](bool with_base) {
+            MP g[2], ex[2];         // ex: everything right of this thread inside the wave
+            bool have_maps[2] = {false, false};
+            // the threads' max-plus maps of the planes in `todo` (with_base: and the cells' scores over their successors in the
+            // row below), scanned inside the wave
+            auto thread_maps = [&](const bool (&todo)[2], const bool (&with_base)[2]) {
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
+                    g[p].A = S_NEG; g[p].B = -1;
+                    if (!todo[p]) continue;
                     const int o = 1 - p;
                     const int xtp_r = (p == 0) ? xtp_right : 0;
                     // (what the cells read from LDS is requested side by side, before any of it is used: a cell without a swap
                     // target reads the spare column NC -- no flags, no score)
                     uint32_t xf_r = 0, zf[C];
                     int zs[C];
-                    if (with_base) {
+                    if (with_base[p]) {
                         xf_r = frow[nxt][p][rel0 + C];
 #pragma unroll
                         for (int c = 0; c < C; c++) { zf[c] = frow[nxt][o][zq[p][c]]; zs[c] = srow[o][zq[p][c]]; }
                     }
+                    const int Rv = (p == 0) ? R.x : R.z;
+                    uint32_t bm = 0, lk = 0;
                     MP G; G.A = S_NEG; G.B = 0;
-                    bool first = true;
 #pragma unroll
                     for (int c = C - 1; c >= 0; c--) {
                         const uint32_t kc = byte_of(kcw[p], c);
                         const int xtp = (c == C - 1) ? xtp_r : int(byte_of(kcw[p], c + 1) & 1u);
-                        int best = S_NEG; uint32_t m = 0;
-                        int l = -1;
                         const bool is_real = (real[p] >> c) & 1u;
-                        if (with_base) {
-                            const int q = bal[p] + rel0 + c;
+                        int best = S_NEG; uint32_t m = 0;
+                        if (with_base[p]) {
                             const int xs = (c == C - 1) ? xs_r[p] : sc[p][c + 1];
                             const uint32_t xf = (c == C - 1) ? xf_r : byte_of(f1w[p], c + 1);
                             const uint32_t dg = f_diag(xf);
@@ -663,95 +667,101 @@ __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *
                                 m = gt ? uint32_t(F_SWP) : (eqv ? (m | F_SWP) : m);
                                 best = gt ? v : best;
                             }
-                            if (t == Lt - 1 && p == end_plane && q == Lp[p] - 1) { best = 0; m = F_MAT; }  // dist.cpp:538-546
+                            if (t == Lt - 1 && p == end_plane && bal[p] + rel0 + c == Lp[p] - 1) { best = 0; m = F_MAT; }  // dist.cpp:538-546
                         }
-                        if (is_real) {
-                            const uint32_t xf0 = (c == C - 1) ? xf0_r[p] : byte_of(f0w[p], c + 1);
-                            l = (xf0 & F_INS) ? xtp : -1;
-                        } else {
-                            best = S_NEG; m = 0;
-                            if (ghost[p] & (1u << c)) best = (p == 0) ? R.x : R.z;       // its score in this row is final: nothing flows in
-                        }
+                        const uint32_t xf0 = (c == C - 1) ? xf0_r[p] : byte_of(f0w[p], c + 1);
+                        const int l = (is_real && (xf0 & F_INS)) ? xtp : -1;
+                        // (a cell that is not the strip's: no score, no moves -- but the ghost cell's score in this row is given and
+                        // final: nothing flows into it)
+                        best = is_real ? best : (((ghost[p] >> c) & 1u) ? Rv : S_NEG);
+                        m = is_real ? m : 0u;
                         base[p][c] = best;
-                        bmw[p] = (bmw[p] & ~(0xffu << (8 * c))) | (m << (8 * c));
-                        lkw[p] = (lkw[p] & ~(0xffu << (8 * c))) | ((uint32_t(l) & 0xffu) << (8 * c));
+                        bm |= m << (8 * c);
+                        lk |= (uint32_t(l) & 0xffu) << (8 * c);
                         MP F; F.A = best; F.B = l;
-                        if (first) { G = F; first = false; } else G = mp_compose(F, G);
+                        G = (c == C - 1) ? F : mp_compose(F, G);
                     }
+                    bmw[p] = bm; lkw[p] = lk;
                     g[p] = G;
+                    have_maps[p] = true;
                 }
                 // suffix composition inside the wave: a prefix scan in lane order (the columns are mirrored)
                 wave_prefix_mp2(g[0], g[1]);
-                eq.A = wave_shr1(g[0].A, S_NEG); eq.B = wave_shr1(g[0].B, 0);      // everything right of this thread inside the wave
-                er.A = wave_shr1(g[1].A, S_NEG); er.B = wave_shr1(g[1].B, 0);
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+                    if (todo[p]) { ex[p].A = wave_shr1(g[p].A, S_NEG); ex[p].B = wave_shr1(g[p].B, 0); }
             };
-            bool have_maps = false;
-            if (live1 || chain) {
-                thread_maps(live1);
-                have_maps = true;
-                if (lane == 63) *reinterpret_cast<int4 *>(&wsc[wave * 4]) = make_int4(g[0].A, g[0].B, g[1].A, g[1].B);
-            } else {
-                if (lane == 63) *reinterpret_cast<int4 *>(&wsc[wave * 4]) = make_int4(S_NEG, -1, S_NEG, -1);
+            int4 sum = make_int4(S_NEG, -1, S_NEG, -1);      // the wave's maps, both planes
+            if (need1[0] || need1[1]) {
+                thread_maps(need1, live1);
+                if (need1[0]) { sum.x = g[0].A; sum.y = g[0].B; }
+                if (need1[1]) { sum.z = g[1].A; sum.w = g[1].B; }
             }
+            if (lane == 63) *reinterpret_cast<int4 *>(&wsc[wave * 4]) = sum;
             lds_barrier<NT>();          // (all reads of the score rows / flag buffer nxt / rng of the row below are done)
             // what flows into this wave from the waves right of it
-            int xq = S_NEG, xr = S_NEG;
+            int xin[2] = {S_NEG, S_NEG};
             if (wave + 1 < NT / 64) {
                 const int4 nb = *reinterpret_cast<const int4 *>(&wsc[(wave + 1) * 4]);
-                if (nb.y < 0 && nb.w < 0) { xq = nb.x; xr = nb.z; }      // both chains break inside the neighbour: its own scores
+                if (nb.y < 0 && nb.w < 0) { xin[0] = nb.x; xin[1] = nb.z; }      // both chains break inside the neighbour: its own scores
                 else {
                     for (int w = NT / 64 - 1; w > wave; w--) {
                         const int4 e = *reinterpret_cast<const int4 *>(&wsc[w * 4]);
-                        xq = (e.y < 0) ? e.x : max(e.x, xq + e.y);
-                        xr = (e.w < 0) ? e.z : max(e.z, xr + e.w);
+                        xin[0] = (e.y < 0) ? e.x : max(e.x, xin[0] + e.y);
+                        xin[1] = (e.w < 0) ? e.z : max(e.z, xin[1] + e.w);
                     }
                 }
             }
-            if (!have_maps && (xq >= 0 || xr >= 0)) { thread_maps(false); have_maps = true; }      // (wave-uniform)
-            if (have_maps) {
-                inq = (eq.B < 0) ? eq.A : max(eq.A, xq + eq.B);
-                inr = (er.B < 0) ? er.A : max(er.A, xr + er.B);
-                full2 = __any(maybe || inq >= 0 || inr >= 0);
+            const bool late[2] = {!have_maps[0] && xin[0] >= 0, !have_maps[1] && xin[1] >= 0};      // (wave-uniform)
+            if (late[0] || late[1]) { const bool nob[2] = {false, false}; thread_maps(late, nob); }
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                if (have_maps[p]) {
+                    inc[p] = (ex[p].B < 0) ? ex[p].A : max(ex[p].A, xin[p] + ex[p].B);
+                    full2[p] = __any(maybe[p] || inc[p] >= 0);
+                }
             }
             if (tid == 0) { rng[(t + 1) & 1][0][0] = rng[(t + 1) & 1][1][0] = 1 << 30; rng[(t + 1) & 1][0][1] = rng[(t + 1) & 1][1][1] = -1; }
         }
-        const int inc[2] = {inq, inr};
-        uint32_t outw[2] = {0, 0};
         bool anyp = false;
-        if (full2) {
+        // (a plane of a wave off the live path: its scores were and stay S_NEG -- in the registers and in srow; the flag bytes of
+        // its cells stay what the forward sweep left: nothing reads the flags of a cell without a score, the walk follows scored
+        // cells only)
 #pragma unroll
-            for (int p = 0; p < 2; p++) {
+        for (int p = 0; p < 2; p++) {
+            if (full2[p]) {
                 int prev = inc[p];
                 int lo = 1 << 30, hi = -1;
+                uint32_t outw = 0;
 #pragma unroll
                 for (int c = C - 1; c >= 0; c--) {
                     int v = base[p][c];
                     uint32_t m = byte_of(bmw[p], c);
                     const int l = int(int8_t(byte_of(lkw[p], c)));
-                    if (l >= 0) {
-                        const int w = prev + l;
-                        if (w > v) { v = w; m = F_INS; } else if (w == v) m |= F_INS;
-                    }
-                    if (v < 0) { v = S_NEG; m = 0; }
+                    const int w = prev + l;
+                    const bool gt = l >= 0 && w > v, eqv = l >= 0 && w == v;
+                    m = gt ? uint32_t(F_INS) : (eqv ? (m | F_INS) : m);
+                    v = gt ? w : v;
+                    m = v < 0 ? 0u : m;
+                    v = v < 0 ? S_NEG : v;
                     sc[p][c] = v;
-                    if (v >= 0) { lo = min(lo, rel0 + c); hi = max(hi, rel0 + c); }
-                    outw[p] |= (m ? (m | (byte_of(f0w[p], c) & F_KEEP)) : 0u) << (8 * c);
+                    lo = v >= 0 ? min(lo, rel0 + c) : lo;
+                    hi = v >= 0 ? max(hi, rel0 + c) : hi;
+                    outw |= (m ? (m | (byte_of(f0w[p], c) & F_KEEP)) : 0u) << (8 * c);
                     prev = v;
                 }
                 *reinterpret_cast<int4 *>(&srow[p][rel0]) = make_int4(sc[p][0], sc[p][1], sc[p][2], sc[p][3]);
                 if (hi >= 0) { anyp = true; atomicMin(&rng[t & 1][p][0], lo); atomicMax(&rng[t & 1][p][1], hi); }
+                store_row(p, t, outw);
             }
-        }
-        // (a wave off the live path: its scores were and stay S_NEG -- in the registers and in srow; the flag bytes of its cells
-        // stay what the forward sweep left: nothing reads the flags of a cell without a score, the walk follows scored cells only)
+            if (own[p] >= 0) {       // this strip's first column: published
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                if (own[p] == c) {       // this strip's first column: published
-                    const int v = sc[p][c];
-                    const int fb = int(byte_of(f0w[p], c));
-                    if (p == 0) { rout[t - t0].x = v; rout[t - t0].y = fb; } else { rout[t - t0].z = v; rout[t - t0].w = fb; }
+                for (int c = 0; c < C; c++) {
+                    if (own[p] == c) {
+                        const int v = sc[p][c];
+                        const int fb = int(byte_of(f0w[p], c));
+                        if (p == 0) { rout[t - t0].x = v; rout[t - t0].y = fb; } else { rout[t - t0].z = v; rout[t - t0].w = fb; }
+                    }
                 }
             }
             f1w[p] = f0w[p];
@@ -759,12 +769,7 @@ __global__ void __launch_bounds__(ST_NT) k_bwd_strip(DevBatch B, const AlnDesc *
                 f0w[p] = ghost_word(pf[p], p, uint32_t(p == 0 ? Rm.y : Rm.w));
                 *reinterpret_cast<uint32_t *>(&frow[nxt][p][rel0]) = f0w[p];   // nxt becomes "cur" of row t-1
             }
-        }
-#pragma unroll
-        for (int p = 0; p < 2; p++) pf[p] = load_row(p, t - 2);
-        if (full2) {
-#pragma unroll
-            for (int p = 0; p < 2; p++) store_row(p, t, outw[p]);
+            pf[p] = load_row(p, t - 2);
         }
         if (anyp) actf[t & 1] = 1;
         lds_barrier<NT>();
