@@ -2960,8 +2960,12 @@ struct Exec {
             marked.push_back(e.x);
             if (resident && !full && e.z > 0) {
                 const int32_t pos = h->plan0_pos[size_t(e.x)];
-                const int dtag = plan_desc(h, h->plan0, size_t(pos)).band_pad;
-                if (pos >= resident->work_off && pos < resident->work_off + resident->count &&
+                const AlnDesc &d0 = plan_desc(h, h->plan0, size_t(pos));
+                const int dtag = d0.band_pad;
+                // (the backward sweep over column strips leaves the forward flags of the cells it does not score, pr_strip.hip: an
+                // early replay, which finds the consulted ties by their flag bytes, cannot read that workspace)
+                const bool strips = d0.band_w == 0 && class_of(std::max(d0.Lq, d0.Lr)) >= STRIP_CLS && !h->no_strips;
+                if (pos >= resident->work_off && pos < resident->work_off + resident->count && !strips &&
                     (dtag == e.y || (dtag == LV_TAG[LV_Z] && e.y == LV_TAG[LV_Q16])))
                     tie_early[e.x] = TieEarly{e.z, pos, &h->plan0, spec_set.count(e.x) ? 3 : 1};
             }

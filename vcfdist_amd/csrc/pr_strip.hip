@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *
     const int Lp[2] = {Lq, Lr};
     const bool has_left = j > 0, has_right = j + 1 < ns;
     const int bal[2] = {max(S.lo[0] - 1, 0) & ~(C - 1), max(S.lo[1] - 1, 0) & ~(C - 1)};    // column of thread 0's first cell
-    __shared__ int32_t rowD[2][NC + 4];
+    __shared__ __align__(16) int32_t rowD[2][NC + 4];      // (column NC: a spare that stays D_INF)
     __shared__ int32_t wsc[2 * (NT / 64)];
     __shared__ int2 bin[64], bout[64];
     __shared__ int32_t blk_min;
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *
             if (real[p] & (1u << c)) mat[p][q] = (q == 0) ? F_MAT : F_INS;
         }
     }
-    if (tid == 0) bout[0] = make_int2(S.hi[0] - 1, S.hi[1] - 1);
+    if (tid == 0) { bout[0] = make_int2(S.hi[0] - 1, S.hi[1] - 1); rowD[0][NC] = D_INF; rowD[1][NC] = D_INF; }
     __syncthreads();
 
     auto publish = [&](int t0, int t_last) {       // rows [t0, t_last] of this strip's last column
@@ -250,6 +250,50 @@ __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *
         int32_t bv[2][C];     // base - q
         uint8_t mk[2][C];     // flags achieving base
         int cmin[2];
+        // Nearly every row has no cell with several swap sources whose base matches the truth base: then a cell's one source is
+        // read without asking (a cell without a source reads the spare column NC = D_INF), all eight reads go out side by side,
+        // and the cell code is straight-line (round 6: the row step is issue-bound, 16 waves on four SIMDs).  A wave with such a
+        // cell takes the general code for the row.
+        bool hard = false;
+        if (at && (multi[0] | multi[1])) {
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int c = 0; c < C; c++) hard = hard || (((multi[p] >> c) & 1u) && sb[p][c] == Tt);
+        }
+        if (!__any(hard)) {
+            int swv[2][C];
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int c = 0; c < C; c++) swv[p][c] = rowD[1 - p][c0[p][c] >= 0 ? c0[p][c] - bal[1 - p] : NC];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                int diag = (rel0 > 0) ? rowD[p][rel0 - 1] : D_INF;
+                int run = D_INF;
+                const int gval = (p == 0) ? gin.x : gin.y;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const int q = bal[p] + rel0 + c;
+                    const int up = dp[p][c];
+                    const bool match = sb[p][c] == Tt;
+                    const int cm = diag + (match ? 0 : 1);
+                    const int sw = (match && at && c0[p][c] >= 0) ? swv[p][c] : D_INF;
+                    const int b = min(min(cm, up + 1), sw);
+                    uint32_t m = ((match && diag == b) ? uint32_t(F_MAT) : 0u) | ((diag + 1 == b) ? uint32_t(F_SUB) : 0u) |
+                                 ((up + 1 == b) ? uint32_t(F_DEL) : 0u) | ((sw == b) ? uint32_t(F_SWP) : 0u);
+                    int nb = b - q;
+                    const bool is_ghost = (ghost[p] >> c) & 1u, off = has_left && q < S.lo[p];      // (off: left of the strip; the ghost is one of them)
+                    nb = is_ghost ? gval - q : (off ? D_INF : nb);
+                    m = off ? 0u : m;
+                    mk[p][c] = uint8_t(m);
+                    bv[p][c] = nb;
+                    run = min(run, nb);
+                    diag = up;
+                }
+                cmin[p] = run;
+            }
+        } else {
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int32_t *other = rowD[1 - p];
@@ -308,6 +352,7 @@ __global__ void __launch_bounds__(ST_NT) k_fwd_strip(DevBatch B, const AlnDesc *
                 diag = up;
             }
             cmin[p] = run;
+        }
         }
         int carryQ = cmin[0], carryR = cmin[1];
         block_excl_prefix_min2<NT>(carryQ, carryR, wsc);   // barrier inside: all reads of rowD are done
