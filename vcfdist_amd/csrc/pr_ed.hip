@@ -9,9 +9,9 @@
 // programming", JACM 46(3), 1999; the block form with horizontal carries between blocks, section 4) packs 64 rows of a DP
 // column into two machine words of vertical differences: a column of a block costs ~25 word operations whatever the distance.
 //
-// Mapping: ONE WAVEFRONT per section.  The shorter string is the pattern: lane l owns block l of it (64 rows: the words Pv /
-// Mv of vertical +1 / -1 differences and the match masks of its 64 characters), the longer string is the text, one column per
-// step.  The blocks of a column depend on each other only through the horizontal difference at a block's last row (hout ->
+// Mapping: ONE WAVEFRONT per section.  One string is the pattern (the one that makes fewer steps, below): lane l owns block l of
+// it (64 rows: the words Pv / Mv of vertical +1 / -1 differences and the match masks of its 64 characters), the other is the text,
+// one column per step.  The blocks of a column depend on each other only through the horizontal difference at a block's last row (hout ->
 // the next block's hin), so the wave runs a software pipeline down the lanes: in step s lane l advances column s - l, taking
 // its hin and the column's character from lane l - 1's previous step (DPP wave shift).  n + 63 steps for a pattern of up to
 // 4 096 characters; longer patterns take groups of 64 blocks one after the other, the last lane's hout of every column kept
@@ -58,12 +58,17 @@ __global__ void __launch_bounds__(64) k_ed_bits(DevBatch B, const AlnDesc *__res
         }
         nx -= suf; ny -= suf;
     }
-    const uint8_t *P = X, *T = Y;       // pattern = the shorter string
+    // Which string is the pattern: the distance is symmetric, the pipeline is not -- a group of up to 64 pattern blocks takes
+    // (text length + its blocks - 1) steps, so a pattern of a characters against a text of b costs groups(a) * (b - 1) + blocks(a)
+    // steps.  Nearly always the LONGER string as the pattern wins (a 9 980-base segment against 23 bases: three groups of 86 steps
+    // instead of one of 10 042; until the end of round 6 the shorter string was the pattern whatever the lengths).
+    auto steps = [](int a, int b) -> long long { const int nb = (a + 63) >> 6; return (long long)((nb + 63) >> 6) * (b - 1) + nb; };
+    const uint8_t *P = X, *T = Y;
     int m = nx, n = ny;
-    if (m > n) { P = Y; T = X; m = ny; n = nx; }
+    if (nx == 0 || (ny > 0 && steps(ny, nx) < steps(nx, ny))) { P = Y; T = X; m = ny; n = nx; }
     int dist;
-    if (m == 0) {
-        dist = n;
+    if (m == 0 || n == 0) {
+        dist = max(m, n);
     } else {
         const int n_blocks = (m + 63) >> 6, n_groups = (n_blocks + 63) >> 6;
         const int last_block = (m - 1) >> 6, last_bit = (m - 1) & 63;
