@@ -756,6 +756,7 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
     stage_load(n_stripes - 1);
     stage_commit((n_stripes - 1) & 1);
     uint32_t tie_used = 0;
+    asm volatile("" ::"v"(bkc[0]), "v"(bkc[1]), "v"(lbQ), "v"(lbR) : "memory");      // (no load in flight at the loop's entry: see the stripe's end)
 
     for (int s = n_stripes - 1; s >= 0; s--) {
         const int t0 = s * FS_K, t1 = min(t0 + FS_K, Lt) - 1;
@@ -879,14 +880,17 @@ __global__ void __launch_bounds__(64) k_bwd_stripe(DevBatch B, const AlnDesc *__
             (void)outm;
         }
         stage_commit((s - 1) & 1);   // the prefetched rows of the stripe below (requested a stripe ago)
-        // ---- flush this stripe's path_ptr rows (in place of the forward flags), 16 bytes per lane
-        asm volatile("" ::: "memory");
+        // (... and its constants: every load of the stripe has landed before the stores below go out.  The compiler keeps no
+        // record across the loop's back edge of which loads are done: with a store or a load still in its books there it put a
+        // `s_waitcnt vmcnt(0)` in front of the first use of bkc -- right behind the NEXT stripe's loads: a full round trip per
+        // stripe of eight rows, and another one per store in front of the next store's data)
+        asm volatile("" ::"v"(bkn[0]), "v"(bkn[1]) : "memory");
+        // ---- flush this stripe's path_ptr rows (in place of the forward flags), 16 bytes per lane (lds_to_global16: issued
+        // without the compiler's knowledge; the rows are next read by the walk, another kernel)
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int nbytes = (t1 - t0 + 1) * d.pitch[p];
-            if (lane * 16 < nbytes)
-                *reinterpret_cast<uint4 *>(mat[p] + size_t(t0) * d.pitch[p] + lane * 16) =
-                    *reinterpret_cast<const uint4 *>(&fout[p][lane * 16]);
+            if (lane * 16 < nbytes) lds_to_global16(&fout[p][lane * 16], mat[p] + size_t(t0) * d.pitch[p] + lane * 16);
         }
         asm volatile("" ::: "memory");
         // ---- advance to the stripe below

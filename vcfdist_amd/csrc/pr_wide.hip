@@ -380,6 +380,7 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
     uint32_t tie_used = 0;
     stage_load(n_stripes - 1);
     stage_commit((n_stripes - 1) & 1);
+    asm volatile("" ::"v"(bkc[0]), "v"(bkc[1]), "v"(bkrc[0]), "v"(bkrc[1]) : "memory");      // (no load in flight at the loop's entry: see the stripe's end)
     lds_barrier<NW * 64>();
 
     // final score of window column cz (of the origin row t+1 was computed with) in row t+1
@@ -516,14 +517,16 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
         }
         // ---- stripe end: flush the path_ptr rows in place of the forward flags, park the prefetched rows below
         lds_barrier<NW * 64>();
+        stage_commit(above);     // the stripe below lands in the buffer the stripe above no longer needs (last read in this stripe's first row)
+        // (every load of the stripe has landed before the stores go out, and the stores are issued without the compiler's knowledge:
+        // see k_bwd_stripe -- the conservative waits cost this kernel three round trips per stripe of eight rows, 12.9 ms for a
+        // 10 000-row alignment whose forward sweep takes 7)
+        asm volatile("" ::"v"(bkn[0]), "v"(bkn[1]), "v"(bkrn[0]), "v"(bkrn[1]) : "memory");
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int nbytes = (t1 - t0 + 1) * pitch[p];
-            if (tid * 16 < nbytes)
-                *reinterpret_cast<uint4 *>(mat[p] + size_t(t0) * pitch[p] + tid * 16) =
-                    *reinterpret_cast<const uint4 *>(&fout[p][tid * 16]);
+            if (tid * 16 < nbytes) lds_to_global16(&fout[p][tid * 16], mat[p] + size_t(t0) * pitch[p] + tid * 16);
         }
-        stage_commit(above);     // the stripe below lands in the buffer the stripe above no longer needs
         lds_barrier<NW * 64>();
         plo[0] = lo[0]; plo[1] = lo[1];
         lo[0] = nlo[0]; lo[1] = nlo[1];
