@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
     const int pitch[2] = {d.pitch[0], d.pitch[1]};
     __shared__ __align__(16) uint8_t fin[2][2][WD_K * W];    // [buffer][plane] forward flags of a stripe, [row][pitch]
     __shared__ __align__(16) uint8_t fout[2][WD_K * W];      // [plane] path_ptr bytes of the current stripe
-    __shared__ int32_t rowA[2][2][W], rowB[2][2][W];         // [row parity][plane][column] local inclusive compositions
-    __shared__ int32_t totA[2][2][16], totB[2][2][16];       // [row parity][plane][wave] the wave's total map
+    __shared__ int2 rowM[2][2][W];                           // [row parity][plane][column] local inclusive compositions {A, B}: one 8-byte access
+    __shared__ int4 totM[2][16];                             // [row parity][wave] the wave's total maps {A, B} of the two planes
 
     uint4 pfv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     auto stage_load = [&](int s_) {    // request stripe s_'s forward-flag rows (16 B per thread and plane)
@@ -387,7 +387,8 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
     auto gather_s = [&](int par, int p, int cz) -> int {
         const bool ok = unsigned(cz) < unsigned(W);
         const int cc = ok ? cz : 0;
-        const int A = rowA[par][p][cc], Bv = rowB[par][p][cc];
+        const int2 AB = rowM[par][p][cc];
+        const int A = AB.x, Bv = AB.y;
         const int wsrc = (W - 1 - cc) >> 6;
         const int car0 = __builtin_amdgcn_ds_bpermute(((wsrc - 1) & 63) << 2, pinA[p]);
         const int car = wsrc > 0 ? car0 : S_NEG;
@@ -418,6 +419,15 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
             zkey[p] = f_swp_key(rank_of(uint32_t(bkc[p]) >> 24));
         }
         stage_load(s - 1);                                     // prefetch the stripe below into registers
+        // the swap target's column in the other plane's staged rows of this stripe, and this thread's own column
+        int zc[2];
+        bool zok[2], okc[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            zc[p] = zl[p] - lo[1 - p];
+            zok[p] = zl[p] != int(FK_NONE24) && unsigned(zc[p]) < unsigned(W) && zc[p] < pitch[1 - p];
+            okc[p] = valid[p] && col < pitch[p];
+        }
         // forward flags of (plane p, absolute column x, row tt); tt == t+1 may lie in the stripe above
         auto fin_at = [&](int p, int x, int tt) -> int {
             if (tt >= Lt) return 0;
@@ -460,7 +470,10 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
                 }
                 // swap successor z = (other plane, zl, t+1)
                 const bool hasz = zl[p] != int(FK_NONE24);
-                const int zf = hasz ? fin_at(o, zl[p], t + 1) : 0;
+                // (inside a stripe the row below lies in the same staged rows at the same origin: no general lookup)
+                const bool zin = zok[p] && t + 1 < Lt;
+                const int zf = first ? (hasz ? fin_at(o, zl[p], t + 1) : 0)
+                                     : int(fin[cur][o][zin ? (t + 1 - t0) * pitch[o] + zc[p] : 0]) & (zin ? 0xff : 0);
                 const int zs = gather_s(pp, o, hasz ? zl[p] - (first ? plo[o] : lo[o]) : -1);
                 if ((uint32_t(zf) & F_SWP_KEY_MASK) == zkey[p]) {
                     const int v = zs + ((bkc[p] >> 27) & 1);
@@ -471,24 +484,25 @@ __global__ void __launch_bounds__(NW * 64) k_bwd_wide(DevBatch B, const AlnDesc 
                 if (!valid[p]) { b = S_NEG; m = 0; }
                 best[p] = b;
                 bm[p] = m;
-                f0[p] = valid[p] ? fin_at(p, x, t) : 0;                 // forward flags of (x, t)
-                const int f0r = fin_at(p, x + 1, t);                    // forward flags of (x+1, t)
+                f0[p] = okc[p] ? int(fin[cur][p][(t - t0) * pitch[p] + col]) : 0;      // forward flags of (x, t)
+                // forward flags of (x+1, t): the lane before (columns are mirrored) has just read them; the first lane of a wave
+                // reads them itself.  (Behind the plane's last column both give "no INS link": a column that does not exist has no score)
+                int f0r = wave_shr1(f0[p], 0);
+                if (lane == 0) f0r = (x + 1 <= hi[p]) ? fin_at(p, x + 1, t) : 0;
                 f0rr[p] = f0r;
                 lk[p] = (f0r & F_INS) ? tp_right[p] : -1;
                 g[p].A = b; g[p].B = lk[p];
             }
             MP hq = g[0], hr = g[1];
             wave_prefix_mp2(hq, hr);                                    // wave-local inclusive compositions
-            rowA[par][0][col] = hq.A; rowB[par][0][col] = hq.B;
-            rowA[par][1][col] = hr.A; rowB[par][1][col] = hr.B;
-            if (lane == 63) {
-                totA[par][0][wave] = hq.A; totB[par][0][wave] = hq.B;
-                totA[par][1][wave] = hr.A; totB[par][1][wave] = hr.B;
-            }
+            rowM[par][0][col] = make_int2(hq.A, hq.B);
+            rowM[par][1][col] = make_int2(hr.A, hr.B);
+            if (lane == 63) totM[par][wave] = make_int4(hq.A, hq.B, hr.A, hr.B);
             lds_barrier<NW * 64>();
             MP tq, tr;
-            tq.A = (lane < NW) ? totA[par][0][lane & 15] : S_NEG; tq.B = (lane < NW) ? totB[par][0][lane & 15] : -1;
-            tr.A = (lane < NW) ? totA[par][1][lane & 15] : S_NEG; tr.B = (lane < NW) ? totB[par][1][lane & 15] : -1;
+            const int4 tm = totM[par][lane & 15];
+            tq.A = (lane < NW) ? tm.x : S_NEG; tq.B = (lane < NW) ? tm.y : -1;
+            tr.A = (lane < NW) ? tm.z : S_NEG; tr.B = (lane < NW) ? tm.w : -1;
             row_prefix_mp2(tq, tr);
             pinA[0] = tq.A; pinA[1] = tr.A;
             int carry[2];
