@@ -404,11 +404,15 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
     // at r * 512 + lane * 8), a lane's LAST row with them (it used to be a load of its own, waited for, in up to 64 different
     // iterations of a wave): a row step no longer waits for memory.
     auto row_at = [&](int r) -> zl_u2 { return log_row(r, r >= 0 && r < nrow); };
+    // The four rows in flight live in four FIXED registers, the loop is unrolled four times and each copy of the row step names its
+    // own: as a queue (q0 = q1; q1 = q2; q2 = load) the compiler rotated the registers with moves, a move of a register whose load
+    // is in flight waits for it -- `s_waitcnt vmcnt(0)` at the head of every row: the newest request, and the path_ptr store behind
+    // it: the look-ahead bought nothing (round 6, found in the ISA).
     zl_u2 lastpre = row_at(bmax - 1);
-    zl_u2 q0 = row_at(bmax - 2), q1 = row_at(bmax - 3), q2 = row_at(bmax - 4);
-    for (int t = bmax - 1; t >= 1; t--) {
-        const bool act = t < nrow;
-        const bool first = t == nrow - 1;     // this lane's last row: the end cell has score 0 (dist.cpp:538-546)
+    zl_u2 rA = row_at(bmax - 2), rB = row_at(bmax - 3), rC = row_at(bmax - 4), rD = zl_u2{0, 0};
+    auto bwd_step = [&](int t, const zl_u2 &pre_reg, zl_u2 &next_reg) {     // pre_reg: row t - 1; next_reg: free, receives row t - 4
+        const bool act = t >= 1 && t < nrow;
+        const bool first = t == nrow - 1 && t >= 1;     // this lane's last row: the end cell has score 0 (dist.cpp:538-546)
         if (first) {
             const int ep = endq >= 0 ? 0 : 1, es = endq >= 0 ? endq : endr;
             cur = lastpre;
@@ -418,13 +422,19 @@ __global__ void __launch_bounds__(64, 6) k_zero_lane(const AlnDesc *__restrict__
                 for (int s = 0; s < 4; s++) sc[p][s] = (p == ep && s == es) ? 0 : -1;
             }
         }
-        const zl_u2 pre = q0;                 // row t - 1
-        q0 = q1; q1 = q2; q2 = row_at(t - 4);
+        next_reg = row_at(t - 4);
+        const zl_u2 pre = pre_reg;            // row t - 1
         // upper slots in use in either row (by any lane)?
         const bool upper = act && (((cur.x | cur.y | pre.x | pre.y) & 0xffff0000u) != 0u);
         if (__any(upper)) bwd_row(std::integral_constant<int, 4>{}, t, act, pre);
         else bwd_row(std::integral_constant<int, 2>{}, t, act, pre);
         lastpre = pre;
+    };
+    for (int t = bmax - 1; t >= 1; t -= 4) {      // (the copies past row 1 of the last round do nothing: act is false, their loads are out of range)
+        bwd_step(t, rA, rD);
+        bwd_step(t - 1, rB, rA);
+        bwd_step(t - 2, rC, rB);
+        bwd_step(t - 3, rD, rC);
     }
     // (QUERY, 0, 0) on a path to the end?  dist.cpp:811-814
     const int beg_plane = sc[0][0] >= 0 ? VPR_PLANE_QUERY : VPR_PLANE_REF;
