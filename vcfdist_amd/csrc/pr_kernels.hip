@@ -1173,18 +1173,47 @@ __global__ void __launch_bounds__(64) k_walk(DevBatch B, const AlnDesc *__restri
 #pragma unroll
                 for (int pl = 0; pl < 2; pl++) {
                     const int pos = (pl == hi) ? qri : other;
-                    const int c0 = max(0, min(pos - 64, (pl == 0 ? q_size : r_size) - WALK_TW));
-                    for (int r = 0; r < rows; r++) {
-                        const int org = banded ? blo[pl * t_size + ti + r] : 0;
-                        const int wdt = banded ? d.band_w : (pl == 0 ? q_size : r_size);
-                        const uint8_t *src = mat[pl] + size_t(ti + r) * d.pitch[pl];
-                        uint32_t v = 0;
+                    int c0 = max(0, min(pos - 64, (pl == 0 ? q_size : r_size) - WALK_TW));
+                    // (all rows of a dense matrix are requested before the first is used, one aligned word per lane and row: row by
+                    // row with four byte loads and a wait in front of every LDS store a tile took ~30 us -- 113 tiles of the slowest
+                    // dense walk of sv_synth were 3.4 of its 8.4 ms.  Window rows (origins per row) keep the byte loads, eight rows at a time)
+                    const int wdt = banded ? d.band_w : (pl == 0 ? q_size : r_size);
+                    if (!banded && (d.pitch[pl] & 3) == 0 && (reinterpret_cast<uintptr_t>(mat[pl]) & 3) == 0) {
+                        // (an aligned origin: up to three columns further left -- the tile still ends behind the plane's last column)
+                        c0 = max(0, min(pos - 64, (pl == 0 ? q_size : r_size) - (WALK_TW - 4))) & ~3;
+                        uint32_t v[WALK_TR];
+                        const int x = c0 + lane * 4;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int x = c0 + lane * 4 + k - org;
-                            if (x >= 0 && x < wdt) v |= uint32_t(src[x]) << (8 * k);
+                        for (int r = 0; r < WALK_TR; r++) {
+                            v[r] = 0;
+                            if (r < rows && x < d.pitch[pl]) v[r] = *reinterpret_cast<const uint32_t *>(mat[pl] + size_t(ti + r) * d.pitch[pl] + x);
                         }
-                        *reinterpret_cast<uint32_t *>(tile + (pl * WALK_TR + r) * WALK_TW + lane * 4) = v;
+                        const uint32_t keep = x + 3 < wdt ? 0xffffffffu : (x >= wdt ? 0u : (0xffffffffu >> (8 * (4 - (wdt - x)))));
+#pragma unroll
+                        for (int r = 0; r < WALK_TR; r++)
+                            if (r < rows) *reinterpret_cast<uint32_t *>(tile + (pl * WALK_TR + r) * WALK_TW + lane * 4) = v[r] & keep;
+                    } else {
+                        for (int r0 = 0; r0 < rows; r0 += 8) {
+                            int org[8];
+                            uint32_t v[8];
+#pragma unroll
+                            for (int r = 0; r < 8; r++) org[r] = (banded && r0 + r < rows) ? blo[pl * t_size + ti + r0 + r] : 0;
+#pragma unroll
+                            for (int r = 0; r < 8; r++) {
+                                v[r] = 0;
+                                if (r0 + r < rows) {
+                                    const uint8_t *src = mat[pl] + size_t(ti + r0 + r) * d.pitch[pl];
+#pragma unroll
+                                    for (int k = 0; k < 4; k++) {
+                                        const int xx = c0 + lane * 4 + k - org[r];
+                                        if (xx >= 0 && xx < wdt) v[r] |= uint32_t(src[xx]) << (8 * k);
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int r = 0; r < 8; r++)
+                                if (r0 + r < rows) *reinterpret_cast<uint32_t *>(tile + (pl * WALK_TR + r0 + r) * WALK_TW + lane * 4) = v[r];
+                        }
                     }
                     if (lane == 0) tblo[pl * WALK_TR] = c0;
                 }
