@@ -13,10 +13,13 @@
 //     whose value is given -- and everything else (diagonal move, INS chain, swap sources, the backward max-plus chain)
 //     is the single-workgroup code unchanged;
 //   * a strip publishes its boundary column in blocks of 64 rows (values staged in LDS, one coalesced store, a release
-//     of its progress counter); the consumer acquires the counter once per 64 rows.  A workgroup's strip is a ticket
-//     drawn at entry and a strip only ever waits for the ticket before its own, so the wait cannot deadlock.
+//     of its progress counter); the consumer acquires the counter once per 64 rows.  A workgroup's strip comes with a
+//     ticket drawn at entry, from a list that holds every alignment's strip j - 1 before its strip j (strip-major: the host,
+//     strip_plan in pr_api.hip), and a strip only ever waits for the strip before its own, so the wait cannot deadlock.
 // Flag matrices, results and everything downstream (walk, credit) are those of k_fwd / k_bwd (pr_kernels.hip): dist.cpp
-// :251-443 (forward), :486-823 (backward).
+// :251-443 (forward), :486-823 (backward) -- with one difference: the backward sweep rewrites the flag bytes of the cells it
+// SCORES (the cells on optimal paths) and leaves the others as the forward sweep wrote them; the walk only ever reads scored
+// cells, and the one reader of whole workspaces, an early tie replay, is kept away from strip workspaces (tie_round).
 #ifndef PR_STRIP_HIP_
 #define PR_STRIP_HIP_
 
