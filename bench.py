@@ -880,11 +880,16 @@ def main():
         # workloads of long alignments -- : the largest accumulated time.
         sweeps = {k: v for k, v in stats_acc.items() if k[0] in (1, 2) and v[0] > 0}
         bulk = {k: v for k, v in sweeps.items() if units_acc.get(k, 0) / v[0] >= 0.01 * 4 * args.n_sc}
-        # (with batches in flight a launch is stretched by whatever runs beside it, differently from run to run: among the throughput
-        # kernels the one with the longest launch ALONE -- the extra steps after the timed region -- is the dominant one)
+        # Among the throughput kernels the dominant one is the one that moves the most ALGORITHMIC BYTES per step (SURVEY 8(d)'s
+        # model: a byte per swept cell + the inputs) -- the roofline question is asked of the kernel that carries the path's
+        # traffic.  (Until the end of round 6 the longest accumulated launch time decided, then the longest launch alone: the lane
+        # kernel, 2.8 - 2.9 ms and 5.8 GB a step, and the 16-cell forward kernel, three launches of 2.9 - 3.0 ms and 0.5 GB together,
+        # are a few per cent apart, and the line's `roofline.kernel` flipped between runs of one build.  The kernel with the largest
+        # accumulated launch time is `by_time` below, whatever it sweeps.)  Ties: the longer launch alone.
         def _weight(kv):
             a_ = alone_acc.get(kv[0])
-            return (a_[1] / a_[0]) * (kv[1][0] / max(args.steps, 1)) if a_ and a_[0] > 0 else kv[1][1] / max(args.steps, 1)
+            t_ = (a_[1] / a_[0]) * (kv[1][0] / max(args.steps, 1)) if a_ and a_[0] > 0 else kv[1][1] / max(args.steps, 1)
+            return (kv[1][2] / max(args.steps, 1), t_)
         (kind, kname), (nl, ms, byt, cells, dense, _, _) = max((bulk or sweeps).items(), key=_weight)
         avg_s = ms / nl * 1e-3
         # Three byte counts for that launch: (1) what the PMC counters of the committed rocprofv3
